@@ -1,0 +1,202 @@
+/* portal_amd.h -- C ABI of libportal_amd.so, the MI355X backend for optozorax/portal scenes.
+ *
+ * Two layers, both plain C (pointers and sizes only):
+ *
+ *  1. ptl_kernel_*  -- the drop-in boundary.  Replaces exactly what the reference asks of
+ *     macroquad/miniquad for its trace shader:
+ *         load_material(ShaderSource::Glsl{..}, MaterialParams{uniforms, textures})
+ *                                                   src/gui/scene.rs:1132-1143  -> ptl_kernel_compile
+ *         material.set_uniform(name, value)         src/gui/scene.rs:587-588,624-632,641-649,
+ *                                                   src/main.rs:1269-1358      -> ptl_kernel_set_uniform
+ *         material.set_texture(name, texture)       src/main.rs:1077-1078      -> ptl_kernel_set_texture
+ *         render_target(w,h) + gl_use_material + draw_rectangle(0,0,w,h)
+ *                                                   src/main.rs:1041-1042,1424-1425 -> ptl_kernel_render
+ *         texture.get_texture_data()                src/main.rs:2939-2943      -> ptl_kernel_render_to_host
+ *     A Rust host binds these with `extern "C"` (INTEGRATION.md shows the stub).
+ *
+ *  2. ptl_scene_* / ptl_renderer_*  -- the host side above that boundary, written in C++
+ *     because no Rust toolchain exists in the build image: .ron loader, uniform/matrix
+ *     evaluator, scene -> HIP source generator, and the SceneRenderer driver
+ *     (src/main.rs:934-1064,1266-1359,1411-1428).  Python (portal_amd/__init__.py), the CLI and
+ *     the tests call this layer through ctypes.
+ *
+ * Threading: a handle is not thread-safe; different handles may be used from different threads
+ * (one per GPU).  Every function returns 0 on success unless stated otherwise.
+ */
+#ifndef PORTAL_AMD_H
+#define PORTAL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ---------------------------------------------------------------------- */
+#define PTL_OK 0
+#define PTL_UNKNOWN_UNIFORM 1 /* set_uniform: the kernel has no such uniform; ignored, like macroquad */
+#define PTL_ERR_INVALID (-1)
+#define PTL_ERR_COMPILE (-2) /* hiprtc diagnostics are in the log buffer */
+#define PTL_ERR_HIP (-3)     /* HIP runtime call failed; see ptl_last_error() */
+#define PTL_ERR_TYPE (-4)    /* set_uniform: type differs from the declared one */
+#define PTL_ERR_SCENE (-5)   /* scene file / evaluation error */
+#define PTL_ERR_NO_DEVICE (-6)
+
+/* Last error message of the calling thread ("" if none). */
+const char* ptl_last_error(void);
+
+/* Library / toolchain description: "portal_amd <ver>; hip=<path>; hiprtc=<path>". */
+const char* ptl_version(void);
+
+/* Number of HIP devices visible (0 when the HIP runtime cannot be loaded). */
+int ptl_device_count(void);
+
+/* ---- layer 1: kernel handle ---------------------------------------------------------------- */
+typedef struct ptl_kernel ptl_kernel;
+
+typedef enum { PTL_MAT4 = 0, PTL_F32 = 1, PTL_I32 = 2, PTL_VEC2 = 3, PTL_VEC3 = 4, PTL_SAMPLER = 5 } ptl_type;
+
+typedef struct {
+    const char* name;
+    ptl_type type;
+    size_t offset; /* byte offset in the kernel's `ptl_uniform_block` (see ptl_scene_uniform_layout) */
+} ptl_uniform_desc;
+
+/* Compile `hip_source` (a translation unit produced by ptl_scene_generate_source, or written
+ * by hand against the same conventions) for `device` with hiprtc and load it.
+ *   uniforms/n_uniforms : every uniform of the block incl. samplers, with offsets
+ *   defines/n_defines   : preprocessor symbols, e.g. "PTL_COUNT_SEGMENTS"
+ *   log/log_cap         : receives the hiprtc log (NUL-terminated, truncated to fit)
+ * device = -1 compiles only (no GPU needed): the handle can then only be queried with
+ * ptl_kernel_code_object. */
+int ptl_kernel_compile(int device, const char* hip_source, const ptl_uniform_desc* uniforms, int n_uniforms,
+                       size_t uniform_block_size, const char* const* defines, int n_defines, ptl_kernel** out, char* log,
+                       size_t log_cap);
+
+/* The compiled gfx950 code object (valid until ptl_kernel_destroy). */
+int ptl_kernel_code_object(ptl_kernel* k, const void** data, size_t* size);
+
+/* value points at 16 floats (column-major) / 1 float / 1 int32 / 2 floats / 3 floats. */
+int ptl_kernel_set_uniform(ptl_kernel* k, const char* name, ptl_type type, const void* value);
+
+/* RGBA8 texels, row 0 first, are copied to device memory; sampled bilinear, clamp-to-edge. */
+int ptl_kernel_set_texture(ptl_kernel* k, const char* sampler, const uint8_t* rgba8, int width, int height);
+
+/* Row-block sharding of one frame: the frame is cut into blocks of 8 pixel rows; this launch
+ * renders blocks phase, phase+stride, phase+2*stride, ...  (1 GPU: phase 0, stride 1). */
+typedef struct {
+    int width, height;       /* full frame, used for the pixel -> ray mapping */
+    int rb_phase, rb_stride; /* row-block interleave */
+} ptl_frame;
+
+/* Rows rendered by a shard (they are stored packed, in block order, in the output buffers). */
+int ptl_frame_shard_rows(const ptl_frame* f);
+
+/* Launch on `stream` (a hipStream_t, NULL = default stream).  Outputs are DEVICE pointers, either
+ * may be NULL: out_rgba8 = shard_rows*width*4 bytes, out_rgba32f = shard_rows*width*16 bytes.
+ * segments (DEVICE pointer to one uint64, may be NULL) accumulates bounce-loop trips when the
+ * kernel was compiled with PTL_COUNT_SEGMENTS.  If elapsed_ms is non-NULL the launch is bracketed
+ * by HIP events on `stream` and the call waits for completion. */
+int ptl_kernel_render(ptl_kernel* k, const ptl_frame* frame, void* out_rgba8, void* out_rgba32f, void* segments,
+                      void* stream, float* elapsed_ms);
+
+/* Convenience: render the shard and copy it to HOST buffers (either may be NULL). */
+int ptl_kernel_render_to_host(ptl_kernel* k, const ptl_frame* frame, uint8_t* host_rgba8, float* host_rgba32f,
+                              uint64_t* host_segments, float* elapsed_ms);
+
+void ptl_kernel_destroy(ptl_kernel* k);
+
+/* ---- layer 2: scene + renderer ------------------------------------------------------------- */
+typedef struct ptl_scene ptl_scene;
+typedef struct ptl_renderer ptl_renderer;
+
+/* Scene::from_serialized(ron::from_str(..)) -- src/main.rs:2882, src/gui/scene.rs:142-146 */
+int ptl_scene_load_file(const char* path, ptl_scene** out);
+int ptl_scene_load_text(const char* ron_text, ptl_scene** out);
+void ptl_scene_free(ptl_scene* s);
+
+/* Override a named uniform's stored value (what a GUI slider / stage does). 1 = no such uniform. */
+int ptl_scene_set_uniform(ptl_scene* s, const char* name, double value);
+/* Formula time inputs (FormulasCache::set_time / set_total_time). */
+int ptl_scene_set_time(ptl_scene* s, double time, double total_time);
+
+/* AnyUniform::get: kind 0 = bool, 1 = int, 2 = float.  Returns 1 if the uniform cannot be evaluated. */
+int ptl_scene_eval_uniform(ptl_scene* s, const char* name, int* kind, double* value);
+/* Matrix::get as binary64, column-major.  Returns 1 if it cannot be evaluated. */
+int ptl_scene_eval_matrix(ptl_scene* s, const char* name, double out16[16]);
+/* Scene `cam` block: look_at xyz, alpha, beta, r, offset_after_material. */
+int ptl_scene_cam(ptl_scene* s, double out7[7]);
+
+/* Scene::generate_shader_code: returns a malloc'ed NUL-terminated HIP C++ source (free with
+ * ptl_free).  flags: bit0 = bake Bool/Int uniforms as literals, bit1 = count segments. */
+int ptl_scene_generate_source(ptl_scene* s, unsigned flags, char** source);
+/* Scene::uniforms + layout: descs are owned by the scene handle and stay valid until the next
+ * call of this function or ptl_scene_free. */
+int ptl_scene_uniform_layout(ptl_scene* s, const ptl_uniform_desc** descs, int* n, size_t* block_size);
+/* Scene::set_uniforms: evaluate and upload X_mat / X_mat_inv / *_mat_teleport / user uniforms. */
+int ptl_scene_set_uniforms(ptl_scene* s, ptl_kernel* k);
+/* The same values without a kernel (tests): callback per uniform. */
+typedef void (*ptl_uniform_cb)(void* user, const char* name, ptl_type type, const void* value);
+int ptl_scene_visit_uniforms(ptl_scene* s, ptl_uniform_cb cb, void* user);
+/* Which scene element produced generated line `line` (1-based) of the last generated source:
+ * kind/name are written into caller buffers.  Returns 1 if the line is template text. */
+int ptl_scene_source_line_owner(ptl_scene* s, int line, char* kind, size_t kind_cap, char* name, size_t name_cap,
+                                int* local_line);
+void ptl_free(void* p);
+
+/* SceneRenderer::new (src/main.rs:934-1064): generate + compile + upload scene uniforms and
+ * textures (paths are resolved against `asset_root`).  device = -1: no GPU, only
+ * ptl_renderer_uniform_* queries work. */
+int ptl_renderer_create(ptl_scene* s, int device, const char* asset_root, unsigned flags, ptl_renderer** out, char* log,
+                        size_t log_cap);
+/* CLI / GUI knobs of SceneRenderer, by the reference's field names: "render_depth", "aa_count",
+ * "aa_start", "view_angle", "use_panini_projection", "panini_param", "use_360_camera",
+ * "use_180_camera", "darken_by_distance", "gray_t_start", "gray_t_size", "draw_depth_map",
+ * "depth_map_min", "depth_map_max", "angle_color_disable", "grid_disable",
+ * "black_border_disable", "offset_after_material", "draw_side_by_side". */
+int ptl_renderer_set_option(ptl_renderer* r, const char* name, double value);
+/* Camera (RotateAroundCam): look_at xyz, alpha, beta, r. */
+int ptl_renderer_set_camera(ptl_renderer* r, const double look_at[3], double alpha, double beta, double radius);
+/* The value draw_texture would upload for a builtin or scene uniform (floats; ints as 1 float). */
+int ptl_renderer_uniform_value(ptl_renderer* r, int width, int height, const char* name, float out16[16], int* n_values);
+/* SceneRenderer::draw_texture (src/main.rs:1411-1428): scene.set_uniforms + set_uniforms(w,h) +
+ * one launch.  Same output conventions as ptl_kernel_render. */
+int ptl_renderer_draw(ptl_renderer* r, const ptl_frame* frame, void* out_rgba8, void* out_rgba32f, void* segments,
+                      void* stream, float* elapsed_ms);
+int ptl_renderer_draw_to_host(ptl_renderer* r, const ptl_frame* frame, uint8_t* host_rgba8, float* host_rgba32f,
+                              uint64_t* host_segments, float* elapsed_ms);
+ptl_kernel* ptl_renderer_kernel(ptl_renderer* r);
+void ptl_renderer_destroy(ptl_renderer* r);
+
+/* Place the packed rows of shard (phase, stride) into a full-frame RGBA8 image (host memory). */
+int ptl_deinterleave_rows(const uint8_t* shard_rgba8, const ptl_frame* frame, uint8_t* full_rgba8);
+
+/* PNG I/O (RGBA8): the reference's Texture2D::from_file_with_format / Image::export_png. */
+int ptl_png_read(const char* path, uint8_t** rgba8, int* width, int* height); /* free with ptl_free */
+int ptl_png_write(const char* path, const uint8_t* rgba8, int width, int height);
+
+/* ---- template engine test hooks (src/code_generation.rs) ----------------------------------- */
+typedef struct ptl_strstore ptl_strstore;
+ptl_strstore* ptl_strstore_new(void);
+void ptl_strstore_free(ptl_strstore* s);
+void ptl_strstore_add_string(ptl_strstore* s, const char* text);
+void ptl_strstore_add_identifier_string(ptl_strstore* s, const char* kind, const char* name, const char* text);
+/* consumes (frees) the storages it is given */
+ptl_strstore* ptl_apply_template(const char* tmpl, const char* const* slot_names, ptl_strstore* const* storages, int n);
+const char* ptl_strstore_text(const ptl_strstore* s);
+int ptl_strstore_current_line(const ptl_strstore* s);
+/* range of element (kind, name): 0 found, 1 missing; [start, end) 1-based */
+int ptl_strstore_range(const ptl_strstore* s, const char* kind, const char* name, int* start, int* end);
+int ptl_strstore_get_identifier(const ptl_strstore* s, int line, char* kind, size_t kind_cap, char* name, size_t name_cap,
+                                int* local_line);
+
+/* GLSL snippet -> C++ (malloc'ed, ptl_free) and the formula evaluator, exposed for tests. */
+char* ptl_translate_glsl(const char* glsl);
+/* names/values: free variables; returns 0 and *out, 1 if the formula is invalid or unresolvable */
+int ptl_formula_eval(const char* text, const char* const* names, const double* values, int n, double time, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PORTAL_AMD_H */

@@ -1,0 +1,358 @@
+"""portal_amd -- MI355X-native offline renderer for optozorax/portal scenes.
+
+Python is only the thin host-side mirror of the reference's operator interface
+(``Scene`` / ``SceneRenderer``, reference src/gui/scene.rs and src/main.rs:732-1544) over the
+C ABI of ``libportal_amd.so`` (include/portal_amd.h).  All work -- .ron loading, uniform /
+matrix evaluation, scene -> HIP source generation, hiprtc compilation, kernel launch --
+happens in the native library; there is no Python or CPU fallback for the render path: if
+the library or a GPU is missing the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Callable, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libportal_amd.so")
+
+# default code-object cache (gfx950 binaries keyed by source hash); travels with the repo
+os.environ.setdefault("PTL_CACHE_DIR", os.path.join(_HERE, "_cache"))
+
+PTL_MAT4, PTL_F32, PTL_I32, PTL_VEC2, PTL_VEC3, PTL_SAMPLER = range(6)
+FLAG_SPECIALIZE_INTS = 1
+FLAG_COUNT_SEGMENTS = 2
+
+
+class PortalError(RuntimeError):
+    pass
+
+
+class UniformDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("type", C.c_int), ("offset", C.c_size_t)]
+
+
+class Frame(C.Structure):
+    """Row-block sharding of one frame (ptl_frame)."""
+
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("rb_phase", C.c_int), ("rb_stride", C.c_int)]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise PortalError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` or `make`")
+    lib = C.CDLL(LIB_PATH)
+    vp, cp, ci, cd, cs = C.c_void_p, C.c_char_p, C.c_int, C.c_double, C.c_size_t
+    P = C.POINTER
+    sig = {
+        "ptl_last_error": (cp, []),
+        "ptl_version": (cp, []),
+        "ptl_device_count": (ci, []),
+        "ptl_kernel_compile": (ci, [ci, cp, P(UniformDesc), ci, cs, P(cp), ci, P(vp), cp, cs]),
+        "ptl_kernel_code_object": (ci, [vp, P(vp), P(cs)]),
+        "ptl_kernel_set_uniform": (ci, [vp, cp, ci, vp]),
+        "ptl_kernel_set_texture": (ci, [vp, cp, vp, ci, ci]),
+        "ptl_frame_shard_rows": (ci, [P(Frame)]),
+        "ptl_kernel_render": (ci, [vp, P(Frame), vp, vp, vp, vp, P(C.c_float)]),
+        "ptl_kernel_render_to_host": (ci, [vp, P(Frame), vp, vp, P(C.c_uint64), P(C.c_float)]),
+        "ptl_kernel_destroy": (None, [vp]),
+        "ptl_scene_load_file": (ci, [cp, P(vp)]),
+        "ptl_scene_load_text": (ci, [cp, P(vp)]),
+        "ptl_scene_free": (None, [vp]),
+        "ptl_scene_set_uniform": (ci, [vp, cp, cd]),
+        "ptl_scene_set_time": (ci, [vp, cd, cd]),
+        "ptl_scene_eval_uniform": (ci, [vp, cp, P(ci), P(cd)]),
+        "ptl_scene_eval_matrix": (ci, [vp, cp, P(cd)]),
+        "ptl_scene_cam": (ci, [vp, P(cd)]),
+        "ptl_scene_generate_source": (ci, [vp, C.c_uint, P(vp)]),
+        "ptl_scene_uniform_layout": (ci, [vp, P(P(UniformDesc)), P(ci), P(cs)]),
+        "ptl_scene_set_uniforms": (ci, [vp, vp]),
+        "ptl_scene_visit_uniforms": (ci, [vp, vp, vp]),
+        "ptl_scene_source_line_owner": (ci, [vp, ci, cp, cs, cp, cs, P(ci)]),
+        "ptl_free": (None, [vp]),
+        "ptl_renderer_create": (ci, [vp, ci, cp, C.c_uint, P(vp), cp, cs]),
+        "ptl_renderer_set_option": (ci, [vp, cp, cd]),
+        "ptl_renderer_set_camera": (ci, [vp, P(cd), cd, cd, cd]),
+        "ptl_renderer_uniform_value": (ci, [vp, ci, ci, cp, P(C.c_float), P(ci)]),
+        "ptl_renderer_draw": (ci, [vp, P(Frame), vp, vp, vp, vp, P(C.c_float)]),
+        "ptl_renderer_draw_to_host": (ci, [vp, P(Frame), vp, vp, P(C.c_uint64), P(C.c_float)]),
+        "ptl_renderer_kernel": (vp, [vp]),
+        "ptl_renderer_destroy": (None, [vp]),
+        "ptl_deinterleave_rows": (ci, [vp, P(Frame), vp]),
+        "ptl_png_read": (ci, [cp, P(vp), P(ci), P(ci)]),
+        "ptl_png_write": (ci, [cp, vp, ci, ci]),
+        "ptl_strstore_new": (vp, []),
+        "ptl_strstore_free": (None, [vp]),
+        "ptl_strstore_add_string": (None, [vp, cp]),
+        "ptl_strstore_add_identifier_string": (None, [vp, cp, cp, cp]),
+        "ptl_apply_template": (vp, [cp, P(cp), P(vp), ci]),
+        "ptl_strstore_text": (cp, [vp]),
+        "ptl_strstore_current_line": (ci, [vp]),
+        "ptl_strstore_range": (ci, [vp, cp, cp, P(ci), P(ci)]),
+        "ptl_strstore_get_identifier": (ci, [vp, ci, cp, cs, cp, cs, P(ci)]),
+        "ptl_translate_glsl": (vp, [cp]),
+        "ptl_formula_eval": (ci, [cp, P(cp), P(cd), ci, cd, P(cd)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _err() -> str:
+    return lib().ptl_last_error().decode("utf-8", "replace")
+
+
+def _check(rc: int, what: str) -> int:
+    if rc < 0:
+        raise PortalError(f"{what} failed ({rc}): {_err()}")
+    return rc
+
+
+def version() -> str:
+    return lib().ptl_version().decode()
+
+
+def device_count() -> int:
+    return lib().ptl_device_count()
+
+
+def shard_rows(frame: Frame) -> int:
+    return lib().ptl_frame_shard_rows(C.byref(frame))
+
+
+# --------------------------------------------------------------------------------------------
+class Scene:
+    """A loaded .ron scene (reference: Scene::from_serialized, src/gui/scene.rs:142-146)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_file(cls, path: str) -> "Scene":
+        h = C.c_void_p()
+        rc = lib().ptl_scene_load_file(path.encode(), C.byref(h))
+        if rc != 0:
+            raise PortalError(f"Failed to parse scene `{path}`: {_err()}")
+        return cls(h)
+
+    @classmethod
+    def from_text(cls, text: str) -> "Scene":
+        h = C.c_void_p()
+        rc = lib().ptl_scene_load_text(text.encode("utf-8"), C.byref(h))
+        if rc != 0:
+            raise PortalError(f"Failed to parse scene: {_err()}")
+        return cls(h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ptl_scene_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_uniform(self, name: str, value: float) -> bool:
+        return lib().ptl_scene_set_uniform(self._h, name.encode(), float(value)) == 0
+
+    def set_time(self, time: float, total_time: Optional[float] = None) -> None:
+        lib().ptl_scene_set_time(self._h, float(time), float(time if total_time is None else total_time))
+
+    def eval_uniform(self, name: str):
+        """AnyUniform::get -> bool | int | float, or None if it cannot be evaluated."""
+        kind, val = C.c_int(), C.c_double()
+        rc = lib().ptl_scene_eval_uniform(self._h, name.encode(), C.byref(kind), C.byref(val))
+        _check(rc, "eval_uniform")
+        if rc != 0:
+            return None
+        return bool(val.value) if kind.value == 0 else int(val.value) if kind.value == 1 else val.value
+
+    def eval_matrix(self, name: str) -> Optional[np.ndarray]:
+        """Matrix::get as a 4x4 float64 array, m[row, col] (stored column-major in the ABI)."""
+        out = (C.c_double * 16)()
+        rc = lib().ptl_scene_eval_matrix(self._h, name.encode(), out)
+        _check(rc, "eval_matrix")
+        if rc != 0:
+            return None
+        return np.array(out, dtype=np.float64).reshape(4, 4).T.copy()
+
+    def cam(self) -> dict:
+        out = (C.c_double * 7)()
+        _check(lib().ptl_scene_cam(self._h, out), "scene_cam")
+        return {"look_at": tuple(out[0:3]), "alpha": out[3], "beta": out[4], "r": out[5], "offset_after_material": out[6]}
+
+    def generate_source(self, flags: int = 0) -> str:
+        """Scene::generate_shader_code: the complete HIP C++ translation unit."""
+        p = C.c_void_p()
+        _check(lib().ptl_scene_generate_source(self._h, flags, C.byref(p)), "generate_source")
+        try:
+            return C.string_at(p).decode("utf-8")
+        finally:
+            lib().ptl_free(p)
+
+    def uniform_layout(self):
+        """[(name, type, offset)], block_size -- Scene::uniforms plus the block layout."""
+        descs, n, size = C.POINTER(UniformDesc)(), C.c_int(), C.c_size_t()
+        _check(lib().ptl_scene_uniform_layout(self._h, C.byref(descs), C.byref(n), C.byref(size)), "uniform_layout")
+        return [(descs[i].name.decode(), descs[i].type, descs[i].offset) for i in range(n.value)], size.value
+
+    def uniform_values(self) -> dict:
+        """What Scene::set_uniforms uploads: name -> float32 array (mat4: 4x4 m[row, col]) or int."""
+        out = {}
+        CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p)
+
+        def cb(_user, name, typ, value):
+            if typ == PTL_MAT4:
+                out[name.decode()] = np.ctypeslib.as_array(C.cast(value, C.POINTER(C.c_float)), (16,)).copy().reshape(4, 4).T.copy()
+            elif typ == PTL_I32:
+                out[name.decode()] = int(C.cast(value, C.POINTER(C.c_int))[0])
+            else:
+                out[name.decode()] = np.float32(C.cast(value, C.POINTER(C.c_float))[0])
+
+        fn = CB(cb)
+        _check(lib().ptl_scene_visit_uniforms(self._h, C.cast(fn, C.c_void_p), None), "visit_uniforms")
+        return out
+
+    def source_line_owner(self, line: int):
+        kind, name, local = C.create_string_buffer(64), C.create_string_buffer(256), C.c_int()
+        rc = lib().ptl_scene_source_line_owner(self._h, line, kind, 64, name, 256, C.byref(local))
+        if rc != 0:
+            return None
+        return kind.value.decode(), name.value.decode(), local.value
+
+
+class SceneRenderer:
+    """Reference: SceneRenderer (src/main.rs:732-1544), the offline image path.
+
+    ``device=-1`` builds a GPU-less renderer (source generation, hiprtc compile, uniform
+    queries); drawing then raises.
+    """
+
+    def __init__(self, scene: Scene, device: int = 0, asset_root: Optional[str] = None, flags: int = 0):
+        self.scene = scene
+        h = C.c_void_p()
+        log = C.create_string_buffer(1 << 16)
+        root = (asset_root if asset_root is not None else REPO_ROOT).encode()
+        rc = lib().ptl_renderer_create(scene._h, device, root, flags, C.byref(h), log, len(log))
+        self.compile_log = log.value.decode("utf-8", "replace")
+        if rc != 0:
+            raise PortalError(f"SceneRenderer::new failed ({rc}): {_err()}\n{self.compile_log}")
+        self._h = h
+        self.device = device
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().ptl_renderer_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_option(self, name: str, value: float) -> None:
+        rc = lib().ptl_renderer_set_option(self._h, name.encode(), float(value))
+        if rc != 0:
+            raise PortalError(f"unknown renderer option `{name}`")
+
+    def set_camera(self, look_at, alpha: float, beta: float, r: float) -> None:
+        la = (C.c_double * 3)(*look_at)
+        _check(lib().ptl_renderer_set_camera(self._h, la, alpha, beta, r), "set_camera")
+
+    def uniform_value(self, name: str, width: int, height: int):
+        out, n = (C.c_float * 16)(), C.c_int()
+        rc = lib().ptl_renderer_uniform_value(self._h, width, height, name.encode(), out, C.byref(n))
+        _check(rc, "uniform_value")
+        if rc != 0:
+            return None
+        a = np.array(out[: n.value], dtype=np.float32)
+        return a.reshape(4, 4).T.copy() if n.value == 16 else (a[0] if n.value == 1 else a)
+
+    def code_object(self) -> bytes:
+        k = lib().ptl_renderer_kernel(self._h)
+        data, size = C.c_void_p(), C.c_size_t()
+        _check(lib().ptl_kernel_code_object(k, C.byref(data), C.byref(size)), "code_object")
+        return C.string_at(data, size.value)
+
+    # -- drawing ---------------------------------------------------------------------------
+    def draw_device(self, frame: Frame, out_rgba8: int = 0, out_rgba32f: int = 0, segments: int = 0, stream: int = 0, timed: bool = False):
+        """draw_texture into DEVICE buffers given as integer addresses (e.g. torch data_ptr()).
+        Returns the kernel time in ms when ``timed`` (waits for completion), else None."""
+        ms = C.c_float()
+        rc = lib().ptl_renderer_draw(self._h, C.byref(frame), C.c_void_p(out_rgba8 or None), C.c_void_p(out_rgba32f or None),
+                                     C.c_void_p(segments or None), C.c_void_p(stream or None), C.byref(ms) if timed else None)
+        _check(rc, "draw_texture")
+        return ms.value if timed else None
+
+    def draw(self, width: int, height: int, rgba8: bool = True, rgba32f: bool = False, segments: bool = False, rb_phase: int = 0, rb_stride: int = 1):
+        """draw_texture + read back to numpy.  Returns dict(rgba8=HxWx4 u8, rgba32f=HxWx4 f32,
+        segments=int, ms=float); H = rows of the shard."""
+        frame = Frame(width, height, rb_phase, rb_stride)
+        rows = shard_rows(frame)
+        if rows < 0:
+            raise PortalError("bad frame")
+        a8 = np.empty((rows, width, 4), np.uint8) if rgba8 else None
+        a32 = np.empty((rows, width, 4), np.float32) if rgba32f else None
+        seg, ms = C.c_uint64(0), C.c_float()
+        rc = lib().ptl_renderer_draw_to_host(self._h, C.byref(frame), a8.ctypes.data if rgba8 else None, a32.ctypes.data if rgba32f else None,
+                                             C.byref(seg) if segments else None, C.byref(ms))
+        _check(rc, "draw_texture")
+        return {"rgba8": a8, "rgba32f": a32, "segments": seg.value if segments else None, "ms": ms.value}
+
+
+def deinterleave_rows(shard: np.ndarray, frame: Frame, full: np.ndarray) -> None:
+    _check(lib().ptl_deinterleave_rows(shard.ctypes.data, C.byref(frame), full.ctypes.data), "deinterleave_rows")
+
+
+def png_write(path: str, rgba8: np.ndarray) -> None:
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    _check(lib().ptl_png_write(path.encode(), a.ctypes.data, a.shape[1], a.shape[0]), "png_write")
+
+
+def png_read(path: str) -> np.ndarray:
+    p, w, h = C.c_void_p(), C.c_int(), C.c_int()
+    _check(lib().ptl_png_read(path.encode(), C.byref(p), C.byref(w), C.byref(h)), "png_read")
+    try:
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value, 4)).copy()
+    finally:
+        lib().ptl_free(p)
+
+
+def translate_glsl(code: str) -> str:
+    p = lib().ptl_translate_glsl(code.encode("utf-8"))
+    try:
+        return C.string_at(p).decode("utf-8")
+    finally:
+        lib().ptl_free(p)
+
+
+def formula_eval(text: str, variables: Optional[dict] = None, time: float = 0.0) -> Optional[float]:
+    variables = variables or {}
+    names = (C.c_char_p * len(variables))(*[k.encode() for k in variables])
+    vals = (C.c_double * len(variables))(*[float(v) for v in variables.values()])
+    out = C.c_double()
+    rc = lib().ptl_formula_eval(text.encode(), names, vals, len(variables), time, C.byref(out))
+    return out.value if rc == 0 else None
+
+
+def scene_path(name: str) -> str:
+    """`monoportal` -> <repo>/scenes/monoportal.ron (the reference resolves names through its
+    built-in registry, src/gui/scenes.rs:589-603)."""
+    if os.path.exists(name):
+        return name
+    cand = os.path.join(REPO_ROOT, "scenes", name if name.endswith(".ron") else name + ".ron")
+    if os.path.exists(cand):
+        return cand
+    raise PortalError(f"Unknown scene `{name}`")

@@ -1,0 +1,105 @@
+// ptl_entry.h -- launchable entry points appended after the filled-in trace template.
+//
+// Takes the place of the reference's full-screen quad draw (src/main.rs:1424-1425): one
+// invocation of glsl::shade_pixel per framebuffer pixel.
+//
+// gfx950 mapping: a 256-thread workgroup renders a 32x8 pixel block as four 8x8 tiles,
+// one per 64-lane wavefront, so the lanes of a wave trace a compact bundle of rays and
+// the bounce loop's exit test is wave-uniform as soon as all 64 rays have finished
+// (the loop back-edge is a scalar branch on `exec == 0`; no explicit ballot is needed,
+// the compiler's structurizer produces exactly that).  Row blocks (8 rows) are the
+// sharding unit: a launch renders blocks phase, phase+stride, ... so N GPUs interleave.
+
+#if PTL_DEVICE_BUILD
+
+extern "C" __global__ void __launch_bounds__(256)
+ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this shard, or null
+                  float* __restrict__ out_rgba32f,        // same, 4 floats per pixel, or null
+                  int width, int height,                   // full frame size
+                  int rb_phase, int rb_stride,             // row-block interleave
+                  unsigned long long* __restrict__ segment_counter) {
+    __shared__ unsigned int tile[8][32 + 1];
+    const int t = (int)threadIdx.x;
+    const int wave = t >> 6, lane = t & 63;
+    const int lx = wave * 8 + (lane & 7);
+    const int ly = lane >> 3;
+    const int local_block = (int)blockIdx.y;
+    const int px = (int)blockIdx.x * 32 + lx;
+    const int py = (rb_phase + local_block * rb_stride) * 8 + ly;
+    const bool live = px < width && py < height;
+
+#ifdef PTL_COUNT_SEGMENTS
+    ptl_segments_lds[t] = 0u;
+#endif
+    glsl::vec4 c = glsl::vec4(0.0f);
+    if (live) c = glsl::shade_pixel(glsl::vec2((float)px + 0.5f, (float)py + 0.5f));
+
+    const long shard_row = (long)local_block * 8 + ly;
+    if (out_rgba32f != nullptr && live) {
+        float4 v = make_float4(c.x, c.y, c.z, c.w);
+        *reinterpret_cast<float4*>(out_rgba32f + 4 * (shard_row * width + px)) = v;  // 8 lanes x 16 B = one 128 B line per tile row
+    }
+    if (out_rgba8 != nullptr) {
+        tile[ly][lx] = glsl::pack_rgba8(c);
+        __syncthreads();
+        const int row = t >> 5, col = t & 31;  // each wave now owns two full 32-pixel rows = 2 x 128 B
+        const int gx = (int)blockIdx.x * 32 + col;
+        const int gy = (rb_phase + local_block * rb_stride) * 8 + row;
+        if (gx < width && gy < height) out_rgba8[((long)local_block * 8 + row) * width + gx] = tile[row][col];
+    }
+#ifdef PTL_COUNT_SEGMENTS
+    if (segment_counter != nullptr) {
+        unsigned int n = ptl_segments_lds[t];
+        for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
+        if (lane == 0) atomicAdd(segment_counter, (unsigned long long)n);
+    }
+#endif
+}
+
+// One-thread launch: the camera-teleport query of src/main.rs:1361-1409 would go here
+// ("next"); not part of the image path.
+
+#else  // host build of the same source (oracle/host_build): rows [row_begin, row_end) of the frame
+
+#include <cstdint>
+#include <cstring>
+
+extern "C" void* ptl_host_uniform_block(unsigned long* size) {
+    if (size) *size = sizeof(glsl::ptl_u);
+    return &glsl::ptl_u;
+}
+
+// Renders pixel rows [row_begin, row_end) x [0, width) into out_* (row 0 of the buffers =
+// row_begin), with `threads` OpenMP threads (static row-block schedule).  Returns the number
+// of bounce-loop trips when compiled with PTL_COUNT_SEGMENTS, else 0.
+extern "C" unsigned long long ptl_host_render(uint8_t* out_rgba8, float* out_rgba32f, int width, int height,
+                                              int row_begin, int row_end, int col_begin, int col_end, int threads) {
+    unsigned long long segments = 0;
+    (void)height;
+    (void)threads;
+    const int cols = col_end - col_begin;
+#pragma omp parallel for schedule(static, 1) num_threads(threads) reduction(+ : segments)
+    for (int py = row_begin; py < row_end; ++py) {
+#ifdef PTL_COUNT_SEGMENTS
+        ptl_segments_tls = 0;
+#endif
+        for (int px = col_begin; px < col_end; ++px) {
+            glsl::vec4 c = glsl::shade_pixel(glsl::vec2((float)px + 0.5f, (float)py + 0.5f));
+            long idx = (long)(py - row_begin) * cols + (px - col_begin);
+            if (out_rgba32f) {
+                float v[4] = {c.x, c.y, c.z, c.w};
+                std::memcpy(out_rgba32f + 4 * idx, v, sizeof v);
+            }
+            if (out_rgba8) {
+                uint32_t p = glsl::pack_rgba8(c);
+                std::memcpy(out_rgba8 + 4 * idx, &p, 4);
+            }
+        }
+#ifdef PTL_COUNT_SEGMENTS
+        segments += ptl_segments_tls;
+#endif
+    }
+    return segments;
+}
+
+#endif

@@ -1,0 +1,640 @@
+// ptl_glsl.h -- GLSL ES 3.00 value types and builtins for the generated portal-trace kernel.
+//
+// This header is compiled twice from the same text: by hiprtc for gfx950 (the product)
+// and by g++ for the host build used as CPU baseline / cross-check (oracle/host_build).
+// It therefore fixes a *numerics contract*: every builtin is spelled out in IEEE-754
+// binary32 operations (+ - * / sqrt fma, all correctly rounded) in a fixed order, so
+// that any conforming implementation - this header on either compiler, or the numpy
+// oracle in oracle/glsl_math.py - produces bit-identical results.  Compile with
+// -ffp-contract=off: fused multiply-adds appear only where this header says fma().
+//
+// Replaces: the GLSL builtins the reference gets from the GL driver's compiler
+// (src/library.glsl:1-7 `precision highp float`; GLSL ES 3.00 spec ch. 8), which the
+// reference leaves implementation-defined.  Contract choices where GLSL leaves freedom:
+//   dot / length / mat*vec / cross     : fma chains, lowest component first
+//   normalize(v), v / s                : multiply by the correctly-rounded reciprocal
+//   min(a,b)=b<a?b:a  max(a,b)=a<b?b:a : GLSL ES 3.00 8.3 (NaN handling follows from this)
+//   sin cos tan asin acos atan exp log exp2 log2 pow : polynomial kernels below
+
+#if defined(__HIPCC_RTC__) || defined(__HIP_DEVICE_COMPILE__)
+#define PTL_FN __device__ __forceinline__
+#define PTL_DEVICE_BUILD 1
+#else
+#define PTL_FN inline
+#define PTL_DEVICE_BUILD 0
+#endif
+
+namespace glsl {
+
+// ---------------------------------------------------------------------------------------
+// scalar primitives
+// ---------------------------------------------------------------------------------------
+PTL_FN float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PTL_FN float sqrt(float x) { return __builtin_sqrtf(x); }
+PTL_FN float abs(float x) { return __builtin_fabsf(x); }
+PTL_FN int abs(int x) { return x < 0 ? -x : x; }
+PTL_FN float floor(float x) { return __builtin_floorf(x); }
+PTL_FN float ceil(float x) { return __builtin_ceilf(x); }
+PTL_FN float trunc(float x) { return __builtin_truncf(x); }
+PTL_FN float roundEven(float x) { return __builtin_rintf(x); }
+PTL_FN float round(float x) { return __builtin_rintf(x); }
+PTL_FN float inversesqrt(float x) { return 1.0f / sqrt(x); }
+PTL_FN float fract(float x) { return x - floor(x); }
+PTL_FN float mod(float x, float y) { return x - y * floor(x / y); }
+PTL_FN float min(float a, float b) { return b < a ? b : a; }
+PTL_FN float max(float a, float b) { return a < b ? b : a; }
+PTL_FN int min(int a, int b) { return b < a ? b : a; }
+PTL_FN int max(int a, int b) { return a < b ? b : a; }
+PTL_FN float clamp(float x, float lo, float hi) { return min(max(x, lo), hi); }
+PTL_FN int clamp(int x, int lo, int hi) { return min(max(x, lo), hi); }
+PTL_FN float sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+PTL_FN float step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+PTL_FN float mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+PTL_FN float smoothstep(float e0, float e1, float x) {
+    float t = clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+PTL_FN float radians(float d) { return d * 0x1.1df46ap-6f; }
+PTL_FN float degrees(float r) { return r * 0x1.ca5dc2p+5f; }
+
+PTL_FN int floatBitsToInt(float x) { return __builtin_bit_cast(int, x); }
+PTL_FN float intBitsToFloat(int b) { return __builtin_bit_cast(float, b); }
+PTL_FN bool isnan(float x) { return x != x; }
+PTL_FN bool isinf(float x) { return abs(x) == __builtin_inff(); }
+
+// 2^e for e in [-126, 127]
+PTL_FN float ptl_pow2i(int e) { return intBitsToFloat((e + 127) << 23); }
+// z * 2^n for n in [-252, 254], exact except for the final (sub)normal rounding
+PTL_FN float ptl_scale2(float z, int n) {
+    int h = n >> 1;
+    return z * ptl_pow2i(h) * ptl_pow2i(n - h);
+}
+
+// ---------------------------------------------------------------------------------------
+// sin / cos / tan: k = rint(x*2/pi); 3-term Cody-Waite reduction with fma; degree-7 / 8
+// minimax kernels on [-pi/4, pi/4] (Cephes sinf/cosf coefficients).
+// ---------------------------------------------------------------------------------------
+struct ptl_SinCos { float s, c; };
+PTL_FN ptl_SinCos ptl_sincos(float x, float& quadrant) {
+    float k = __builtin_rintf(x * 0x1.45f306p-1f);
+    float r = fma(-k, 0x1.921fb6p+0f, x);
+    r = fma(-k, -0x1.777a5cp-25f, r);
+    r = fma(-k, -0x1.ee59dap-50f, r);
+    quadrant = k - 4.0f * floor(k * 0.25f);
+    float z = r * r;
+    float ps = fma(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fma(z, ps, -1.6666654611e-1f);
+    float pc = fma(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fma(z, pc, 4.166664568298827e-2f);
+    ptl_SinCos o;
+    o.s = fma(r * z, ps, r);
+    o.c = fma(z * z, pc, fma(-0.5f, z, 1.0f));
+    return o;
+}
+PTL_FN float sin(float x) {
+    float q;
+    ptl_SinCos k = ptl_sincos(x, q);
+    float v = (q == 1.0f || q == 3.0f) ? k.c : k.s;
+    return (q == 2.0f || q == 3.0f) ? -v : v;
+}
+PTL_FN float cos(float x) {
+    float q;
+    ptl_SinCos k = ptl_sincos(x, q);
+    float v = (q == 1.0f || q == 3.0f) ? k.s : k.c;
+    return (q == 1.0f || q == 2.0f) ? -v : v;
+}
+PTL_FN float tan(float x) { return sin(x) / cos(x); }
+
+// ---------------------------------------------------------------------------------------
+// atan / atan2 (Cephes atanf): reduce to [0, tan(pi/8)], degree-9 odd kernel.
+// ---------------------------------------------------------------------------------------
+PTL_FN float atan(float x0) {
+    float x = abs(x0);
+    float y = 0.0f;
+    if (x > 2.414213562373095f) {
+        y = 0x1.921fb6p+0f;
+        x = -(1.0f / x);
+    } else if (x > 0.4142135623730950f) {
+        y = 0x1.921fb6p-1f;
+        x = (x - 1.0f) / (x + 1.0f);
+    }
+    float z = x * x;
+    float p = fma(z, 8.05374449538e-2f, -1.38776856032e-1f);
+    p = fma(z, p, 1.99777106478e-1f);
+    p = fma(z, p, -3.33329491539e-1f);
+    y = y + fma(p * z, x, x);
+    return x0 < 0.0f ? -y : y;
+}
+PTL_FN float atan(float y, float x) {
+    if (x == 0.0f) {
+        return y > 0.0f ? 0x1.921fb6p+0f : (y < 0.0f ? -0x1.921fb6p+0f : 0.0f);
+    }
+    float w = 0.0f;
+    if (x < 0.0f) w = y < 0.0f ? -0x1.921fb6p+1f : 0x1.921fb6p+1f;
+    return w + atan(y / x);
+}
+
+// ---------------------------------------------------------------------------------------
+// asin / acos (Cephes asinf / acosf).  acos(-1.) == float(pi), which the reference's
+// `#define PI acos(-1.)` (src/library.glsl:15) relies on.
+// ---------------------------------------------------------------------------------------
+PTL_FN float asin(float x0) {
+    float a = abs(x0);
+    bool big = a > 0.5f;
+    float z = big ? 0.5f * (1.0f - a) : a * a;
+    float x = big ? sqrt(z) : a;
+    float p = fma(z, 4.2163199048e-2f, 2.4181311049e-2f);
+    p = fma(z, p, 4.5470025998e-2f);
+    p = fma(z, p, 7.4953002686e-2f);
+    p = fma(z, p, 1.6666752422e-1f);
+    float r = fma(p * z, x, x);
+    if (big) r = 0x1.921fb6p+0f - (r + r);
+    return x0 < 0.0f ? -r : r;
+}
+PTL_FN float acos(float x) {
+    if (x < -0.5f) return 0x1.921fb6p+1f - 2.0f * asin(sqrt(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * asin(sqrt(0.5f * (1.0f - x)));
+    return 0x1.921fb6p+0f - asin(x);
+}
+
+// ---------------------------------------------------------------------------------------
+// exp2 / log2 / exp / log / pow
+// ---------------------------------------------------------------------------------------
+PTL_FN float exp2(float x) {
+    if (x != x) return x;
+    if (x > 128.0f) return __builtin_inff();
+    if (x < -150.0f) return 0.0f;
+    float n = __builtin_rintf(x);
+    float f = x - n;
+    float p = fma(f, 1.535336188319500e-4f, 1.339887440266574e-3f);
+    p = fma(f, p, 9.618437357674640e-3f);
+    p = fma(f, p, 5.550332471162809e-2f);
+    p = fma(f, p, 2.402264791363012e-1f);
+    p = fma(f, p, 6.931472028550421e-1f);
+    return ptl_scale2(fma(f, p, 1.0f), (int)n);
+}
+// frexp-style split: x = m * 2^e with m in [sqrt(1/2), sqrt(2)); returns m - 1
+PTL_FN float ptl_log_split(float x, float& e_out) {
+    float e_adj = 0.0f;
+    if (x < 0x1p-126f) {
+        x = x * 0x1p+24f;
+        e_adj = -24.0f;
+    }
+    int b = floatBitsToInt(x);
+    int e = ((b >> 23) & 0xff) - 126;
+    float m = intBitsToFloat((b & 0x007fffff) | 0x3f000000);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = m + m;
+    }
+    e_out = (float)e + e_adj;
+    return m - 1.0f;
+}
+PTL_FN float ptl_log_poly(float m) {
+    float p = fma(m, 7.0376836292e-2f, -1.1514610310e-1f);
+    p = fma(m, p, 1.1676998740e-1f);
+    p = fma(m, p, -1.2420140846e-1f);
+    p = fma(m, p, 1.4249322787e-1f);
+    p = fma(m, p, -1.6668057665e-1f);
+    p = fma(m, p, 2.0000714765e-1f);
+    p = fma(m, p, -2.4999993993e-1f);
+    p = fma(m, p, 3.3333331174e-1f);
+    float z = m * m;
+    return fma(-0.5f, z, p * m * z);
+}
+PTL_FN float log(float x) {
+    if (x != x || x < 0.0f) return __builtin_nanf("");
+    if (x == 0.0f) return -__builtin_inff();
+    if (x == __builtin_inff()) return x;
+    float e;
+    float m = ptl_log_split(x, e);
+    float y = ptl_log_poly(m);
+    y = fma(e, -2.12194440e-4f, y);
+    return fma(e, 0.693359375f, m + y);
+}
+PTL_FN float log2(float x) {
+    if (x != x || x < 0.0f) return __builtin_nanf("");
+    if (x == 0.0f) return -__builtin_inff();
+    if (x == __builtin_inff()) return x;
+    float e;
+    float m = ptl_log_split(x, e);
+    float y = ptl_log_poly(m);
+    // log2(1+m) = (m + y) * log2(e), with log2(e) = 1 + 0.44269504088896340735992
+    float z = y * 0.44269504088896340735992f;
+    z = fma(m, 0.44269504088896340735992f, z);
+    z = z + y;
+    z = z + m;
+    return z + e;
+}
+PTL_FN float exp(float x) {
+    if (x != x) return x;
+    if (x > 88.72283905206835f) return __builtin_inff();
+    if (x < -103.972076416015625f) return 0.0f;
+    float n = floor(fma(x, 0x1.715476p+0f, 0.5f));
+    float r = fma(-n, 0.693359375f, x);
+    r = fma(-n, -2.12194440e-4f, r);
+    float p = fma(r, 1.9875691500e-4f, 1.3981999507e-3f);
+    p = fma(r, p, 8.3334519073e-3f);
+    p = fma(r, p, 4.1665795894e-2f);
+    p = fma(r, p, 1.6666665459e-1f);
+    p = fma(r, p, 5.0000001201e-1f);
+    float y = fma(p, r * r, r) + 1.0f;
+    return ptl_scale2(y, (int)n);
+}
+// GLSL: pow(x, y) undefined for x < 0 and for x == 0 && y <= 0.
+PTL_FN float pow(float x, float y) {
+    if (y == 0.0f) return 1.0f;
+    if (x == 0.0f) return y > 0.0f ? 0.0f : __builtin_inff();
+    return exp2(y * log2(x));
+}
+
+// ---------------------------------------------------------------------------------------
+// vectors
+// ---------------------------------------------------------------------------------------
+struct vec2;
+struct vec3;
+struct vec4;
+
+template <class V, int N, int A, int B, int C, int D> struct ptl_swizzle_ref;
+template <int N> struct ptl_vec_of;
+template <> struct ptl_vec_of<2> { using type = vec2; };
+template <> struct ptl_vec_of<3> { using type = vec3; };
+template <> struct ptl_vec_of<4> { using type = vec4; };
+
+struct vec2 {
+    union { float x; float r; float s; };
+    union { float y; float g; };
+    vec2() = default;
+    PTL_FN explicit vec2(float a) : x(a), y(a) {}
+    PTL_FN vec2(float a, float b) : x(a), y(b) {}
+    PTL_FN explicit vec2(const vec3& v);
+    PTL_FN explicit vec2(const vec4& v);
+    template <int I> PTL_FN float c() const { return I == 0 ? x : y; }
+    template <int I> PTL_FN float& cr() { if constexpr (I == 0) return x; else return y; }
+    PTL_FN float& operator[](int i) { return i == 0 ? x : y; }
+    PTL_FN float operator[](int i) const { return i == 0 ? x : y; }
+    template <int A, int B> PTL_FN vec2 sw() const;
+    template <int A, int B, int C> PTL_FN vec3 sw() const;
+    template <int A, int B, int C, int D> PTL_FN vec4 sw() const;
+    template <int A, int B> PTL_FN ptl_swizzle_ref<vec2, 2, A, B, 0, 0> swr();
+    template <int A, int B, int C> PTL_FN ptl_swizzle_ref<vec2, 3, A, B, C, 0> swr();
+    template <int A, int B, int C, int D> PTL_FN ptl_swizzle_ref<vec2, 4, A, B, C, D> swr();
+};
+
+struct vec3 {
+    union { float x; float r; float s; };
+    union { float y; float g; };
+    union { float z; float b; };
+    vec3() = default;
+    PTL_FN explicit vec3(float a) : x(a), y(a), z(a) {}
+    PTL_FN vec3(float a, float b_, float c_) : x(a), y(b_), z(c_) {}
+    PTL_FN vec3(const vec2& v, float c_) : x(v.x), y(v.y), z(c_) {}
+    PTL_FN vec3(float a, const vec2& v) : x(a), y(v.x), z(v.y) {}
+    PTL_FN explicit vec3(const vec4& v);
+    template <int I> PTL_FN float c() const { return I == 0 ? x : (I == 1 ? y : z); }
+    template <int I> PTL_FN float& cr() {
+        if constexpr (I == 0) return x; else if constexpr (I == 1) return y; else return z;
+    }
+    PTL_FN float& operator[](int i) { return i == 0 ? x : (i == 1 ? y : z); }
+    PTL_FN float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+    template <int A, int B> PTL_FN vec2 sw() const;
+    template <int A, int B, int C> PTL_FN vec3 sw() const;
+    template <int A, int B, int C, int D> PTL_FN vec4 sw() const;
+    template <int A, int B> PTL_FN ptl_swizzle_ref<vec3, 2, A, B, 0, 0> swr();
+    template <int A, int B, int C> PTL_FN ptl_swizzle_ref<vec3, 3, A, B, C, 0> swr();
+    template <int A, int B, int C, int D> PTL_FN ptl_swizzle_ref<vec3, 4, A, B, C, D> swr();
+};
+
+struct vec4 {
+    union { float x; float r; float s; };
+    union { float y; float g; };
+    union { float z; float b; };
+    union { float w; float a; };
+    vec4() = default;
+    PTL_FN explicit vec4(float v) : x(v), y(v), z(v), w(v) {}
+    PTL_FN vec4(float a_, float b_, float c_, float d_) : x(a_), y(b_), z(c_), w(d_) {}
+    PTL_FN vec4(const vec3& v, float d_) : x(v.x), y(v.y), z(v.z), w(d_) {}
+    PTL_FN vec4(float a_, const vec3& v) : x(a_), y(v.x), z(v.y), w(v.z) {}
+    PTL_FN vec4(const vec2& p, const vec2& q) : x(p.x), y(p.y), z(q.x), w(q.y) {}
+    PTL_FN vec4(const vec2& p, float c_, float d_) : x(p.x), y(p.y), z(c_), w(d_) {}
+    PTL_FN vec4(float a_, const vec2& p, float d_) : x(a_), y(p.x), z(p.y), w(d_) {}
+    PTL_FN vec4(float a_, float b_, const vec2& p) : x(a_), y(b_), z(p.x), w(p.y) {}
+    template <int I> PTL_FN float c() const { return I == 0 ? x : (I == 1 ? y : (I == 2 ? z : w)); }
+    template <int I> PTL_FN float& cr() {
+        if constexpr (I == 0) return x; else if constexpr (I == 1) return y;
+        else if constexpr (I == 2) return z; else return w;
+    }
+    PTL_FN float& operator[](int i) { return i == 0 ? x : (i == 1 ? y : (i == 2 ? z : w)); }
+    PTL_FN float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : (i == 2 ? z : w)); }
+    template <int A, int B> PTL_FN vec2 sw() const;
+    template <int A, int B, int C> PTL_FN vec3 sw() const;
+    template <int A, int B, int C, int D> PTL_FN vec4 sw() const;
+    template <int A, int B> PTL_FN ptl_swizzle_ref<vec4, 2, A, B, 0, 0> swr();
+    template <int A, int B, int C> PTL_FN ptl_swizzle_ref<vec4, 3, A, B, C, 0> swr();
+    template <int A, int B, int C, int D> PTL_FN ptl_swizzle_ref<vec4, 4, A, B, C, D> swr();
+};
+
+PTL_FN vec2::vec2(const vec3& v) : x(v.x), y(v.y) {}
+PTL_FN vec2::vec2(const vec4& v) : x(v.x), y(v.y) {}
+PTL_FN vec3::vec3(const vec4& v) : x(v.x), y(v.y), z(v.z) {}
+
+#define PTL_SWIZZLES(V)                                                                          \
+    template <int A, int B> PTL_FN vec2 V::sw() const { return vec2(c<A>(), c<B>()); }            \
+    template <int A, int B, int C> PTL_FN vec3 V::sw() const { return vec3(c<A>(), c<B>(), c<C>()); } \
+    template <int A, int B, int C, int D> PTL_FN vec4 V::sw() const {                            \
+        return vec4(c<A>(), c<B>(), c<C>(), c<D>());                                             \
+    }
+PTL_SWIZZLES(vec2)
+PTL_SWIZZLES(vec3)
+PTL_SWIZZLES(vec4)
+#undef PTL_SWIZZLES
+
+// writable swizzle view: `v.xy = e`, `v.zyx += e` (translator emits v.swr<..>())
+template <class V, int N, int A, int B, int C, int D> struct ptl_swizzle_ref {
+    using T = typename ptl_vec_of<N>::type;
+    V& v;
+    PTL_FN T get() const {
+        if constexpr (N == 2) return T(v.template c<A>(), v.template c<B>());
+        else if constexpr (N == 3) return T(v.template c<A>(), v.template c<B>(), v.template c<C>());
+        else return T(v.template c<A>(), v.template c<B>(), v.template c<C>(), v.template c<D>());
+    }
+    PTL_FN operator T() const { return get(); }
+    PTL_FN ptl_swizzle_ref& operator=(const T& t) {
+        v.template cr<A>() = t.x;
+        v.template cr<B>() = t.y;
+        if constexpr (N >= 3) v.template cr<C>() = t.z;
+        if constexpr (N >= 4) v.template cr<D>() = t.w;
+        return *this;
+    }
+    PTL_FN ptl_swizzle_ref& operator+=(const T& t) { return *this = get() + t; }
+    PTL_FN ptl_swizzle_ref& operator-=(const T& t) { return *this = get() - t; }
+    PTL_FN ptl_swizzle_ref& operator*=(const T& t) { return *this = get() * t; }
+    PTL_FN ptl_swizzle_ref& operator/=(const T& t) { return *this = get() / t; }
+    PTL_FN ptl_swizzle_ref& operator*=(float t) { return *this = get() * t; }
+    PTL_FN ptl_swizzle_ref& operator/=(float t) { return *this = get() / t; }
+};
+#define PTL_SWIZZLE_REFS(V)                                                                      \
+    template <int A, int B> PTL_FN ptl_swizzle_ref<V, 2, A, B, 0, 0> V::swr() { return {*this}; }  \
+    template <int A, int B, int C> PTL_FN ptl_swizzle_ref<V, 3, A, B, C, 0> V::swr() { return {*this}; } \
+    template <int A, int B, int C, int D> PTL_FN ptl_swizzle_ref<V, 4, A, B, C, D> V::swr() { return {*this}; }
+PTL_SWIZZLE_REFS(vec2)
+PTL_SWIZZLE_REFS(vec3)
+PTL_SWIZZLE_REFS(vec4)
+#undef PTL_SWIZZLE_REFS
+
+// component-wise operators --------------------------------------------------------------
+#define PTL_VEC_BINOP(OP)                                                                        \
+    PTL_FN vec2 operator OP(const vec2& a, const vec2& b) { return vec2(a.x OP b.x, a.y OP b.y); } \
+    PTL_FN vec3 operator OP(const vec3& a, const vec3& b) { return vec3(a.x OP b.x, a.y OP b.y, a.z OP b.z); } \
+    PTL_FN vec4 operator OP(const vec4& a, const vec4& b) { return vec4(a.x OP b.x, a.y OP b.y, a.z OP b.z, a.w OP b.w); } \
+    PTL_FN vec2 operator OP(const vec2& a, float b) { return vec2(a.x OP b, a.y OP b); }          \
+    PTL_FN vec3 operator OP(const vec3& a, float b) { return vec3(a.x OP b, a.y OP b, a.z OP b); } \
+    PTL_FN vec4 operator OP(const vec4& a, float b) { return vec4(a.x OP b, a.y OP b, a.z OP b, a.w OP b); } \
+    PTL_FN vec2 operator OP(float a, const vec2& b) { return vec2(a OP b.x, a OP b.y); }          \
+    PTL_FN vec3 operator OP(float a, const vec3& b) { return vec3(a OP b.x, a OP b.y, a OP b.z); } \
+    PTL_FN vec4 operator OP(float a, const vec4& b) { return vec4(a OP b.x, a OP b.y, a OP b.z, a OP b.w); }
+PTL_VEC_BINOP(+)
+PTL_VEC_BINOP(-)
+PTL_VEC_BINOP(*)
+#undef PTL_VEC_BINOP
+// division: vec/vec and float/vec are true component divisions; vec/float multiplies by
+// the correctly-rounded reciprocal (contract, see header comment).
+PTL_FN vec2 operator/(const vec2& a, const vec2& b) { return vec2(a.x / b.x, a.y / b.y); }
+PTL_FN vec3 operator/(const vec3& a, const vec3& b) { return vec3(a.x / b.x, a.y / b.y, a.z / b.z); }
+PTL_FN vec4 operator/(const vec4& a, const vec4& b) { return vec4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
+PTL_FN vec2 operator/(float a, const vec2& b) { return vec2(a / b.x, a / b.y); }
+PTL_FN vec3 operator/(float a, const vec3& b) { return vec3(a / b.x, a / b.y, a / b.z); }
+PTL_FN vec4 operator/(float a, const vec4& b) { return vec4(a / b.x, a / b.y, a / b.z, a / b.w); }
+PTL_FN vec2 operator/(const vec2& a, float b) { float i = 1.0f / b; return vec2(a.x * i, a.y * i); }
+PTL_FN vec3 operator/(const vec3& a, float b) { float i = 1.0f / b; return vec3(a.x * i, a.y * i, a.z * i); }
+PTL_FN vec4 operator/(const vec4& a, float b) { float i = 1.0f / b; return vec4(a.x * i, a.y * i, a.z * i, a.w * i); }
+
+PTL_FN vec2 operator-(const vec2& a) { return vec2(-a.x, -a.y); }
+PTL_FN vec3 operator-(const vec3& a) { return vec3(-a.x, -a.y, -a.z); }
+PTL_FN vec4 operator-(const vec4& a) { return vec4(-a.x, -a.y, -a.z, -a.w); }
+PTL_FN vec2 operator+(const vec2& a) { return a; }
+PTL_FN vec3 operator+(const vec3& a) { return a; }
+PTL_FN vec4 operator+(const vec4& a) { return a; }
+
+#define PTL_VEC_ASSIGN(V)                                                                        \
+    PTL_FN V& operator+=(V& a, const V& b) { a = a + b; return a; }                               \
+    PTL_FN V& operator-=(V& a, const V& b) { a = a - b; return a; }                               \
+    PTL_FN V& operator*=(V& a, const V& b) { a = a * b; return a; }                               \
+    PTL_FN V& operator/=(V& a, const V& b) { a = a / b; return a; }                               \
+    PTL_FN V& operator+=(V& a, float b) { a = a + b; return a; }                                  \
+    PTL_FN V& operator-=(V& a, float b) { a = a - b; return a; }                                  \
+    PTL_FN V& operator*=(V& a, float b) { a = a * b; return a; }                                  \
+    PTL_FN V& operator/=(V& a, float b) { a = a / b; return a; }
+PTL_VEC_ASSIGN(vec2)
+PTL_VEC_ASSIGN(vec3)
+PTL_VEC_ASSIGN(vec4)
+#undef PTL_VEC_ASSIGN
+
+PTL_FN bool operator==(const vec2& a, const vec2& b) { return a.x == b.x && a.y == b.y; }
+PTL_FN bool operator==(const vec3& a, const vec3& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+PTL_FN bool operator==(const vec4& a, const vec4& b) { return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w; }
+PTL_FN bool operator!=(const vec2& a, const vec2& b) { return !(a == b); }
+PTL_FN bool operator!=(const vec3& a, const vec3& b) { return !(a == b); }
+PTL_FN bool operator!=(const vec4& a, const vec4& b) { return !(a == b); }
+
+// component-wise builtins ---------------------------------------------------------------
+#define PTL_MAP1(F)                                                                              \
+    PTL_FN vec2 F(const vec2& a) { return vec2(F(a.x), F(a.y)); }                                 \
+    PTL_FN vec3 F(const vec3& a) { return vec3(F(a.x), F(a.y), F(a.z)); }                         \
+    PTL_FN vec4 F(const vec4& a) { return vec4(F(a.x), F(a.y), F(a.z), F(a.w)); }
+PTL_MAP1(sin) PTL_MAP1(cos) PTL_MAP1(tan) PTL_MAP1(asin) PTL_MAP1(acos) PTL_MAP1(atan)
+PTL_MAP1(exp) PTL_MAP1(log) PTL_MAP1(exp2) PTL_MAP1(log2) PTL_MAP1(sqrt) PTL_MAP1(inversesqrt)
+PTL_MAP1(abs) PTL_MAP1(sign) PTL_MAP1(floor) PTL_MAP1(ceil) PTL_MAP1(fract) PTL_MAP1(trunc)
+PTL_MAP1(round) PTL_MAP1(roundEven) PTL_MAP1(radians) PTL_MAP1(degrees)
+#undef PTL_MAP1
+#define PTL_MAP2(F)                                                                              \
+    PTL_FN vec2 F(const vec2& a, const vec2& b) { return vec2(F(a.x, b.x), F(a.y, b.y)); }         \
+    PTL_FN vec3 F(const vec3& a, const vec3& b) { return vec3(F(a.x, b.x), F(a.y, b.y), F(a.z, b.z)); } \
+    PTL_FN vec4 F(const vec4& a, const vec4& b) { return vec4(F(a.x, b.x), F(a.y, b.y), F(a.z, b.z), F(a.w, b.w)); }
+#define PTL_MAP2S(F) /* second operand scalar */                                                 \
+    PTL_FN vec2 F(const vec2& a, float b) { return vec2(F(a.x, b), F(a.y, b)); }                   \
+    PTL_FN vec3 F(const vec3& a, float b) { return vec3(F(a.x, b), F(a.y, b), F(a.z, b)); }        \
+    PTL_FN vec4 F(const vec4& a, float b) { return vec4(F(a.x, b), F(a.y, b), F(a.z, b), F(a.w, b)); }
+PTL_MAP2(min) PTL_MAP2(max) PTL_MAP2(mod) PTL_MAP2(pow) PTL_MAP2(atan) PTL_MAP2(step)
+PTL_MAP2S(min) PTL_MAP2S(max) PTL_MAP2S(mod)
+#undef PTL_MAP2
+#undef PTL_MAP2S
+PTL_FN vec2 step(float e, const vec2& a) { return vec2(step(e, a.x), step(e, a.y)); }
+PTL_FN vec3 step(float e, const vec3& a) { return vec3(step(e, a.x), step(e, a.y), step(e, a.z)); }
+PTL_FN vec4 step(float e, const vec4& a) { return vec4(step(e, a.x), step(e, a.y), step(e, a.z), step(e, a.w)); }
+PTL_FN vec2 clamp(const vec2& a, float lo, float hi) { return vec2(clamp(a.x, lo, hi), clamp(a.y, lo, hi)); }
+PTL_FN vec3 clamp(const vec3& a, float lo, float hi) { return vec3(clamp(a.x, lo, hi), clamp(a.y, lo, hi), clamp(a.z, lo, hi)); }
+PTL_FN vec4 clamp(const vec4& a, float lo, float hi) { return vec4(clamp(a.x, lo, hi), clamp(a.y, lo, hi), clamp(a.z, lo, hi), clamp(a.w, lo, hi)); }
+PTL_FN vec2 clamp(const vec2& a, const vec2& lo, const vec2& hi) { return min(max(a, lo), hi); }
+PTL_FN vec3 clamp(const vec3& a, const vec3& lo, const vec3& hi) { return min(max(a, lo), hi); }
+PTL_FN vec4 clamp(const vec4& a, const vec4& lo, const vec4& hi) { return min(max(a, lo), hi); }
+PTL_FN vec2 mix(const vec2& a, const vec2& b, float t) { return vec2(mix(a.x, b.x, t), mix(a.y, b.y, t)); }
+PTL_FN vec3 mix(const vec3& a, const vec3& b, float t) { return vec3(mix(a.x, b.x, t), mix(a.y, b.y, t), mix(a.z, b.z, t)); }
+PTL_FN vec4 mix(const vec4& a, const vec4& b, float t) { return vec4(mix(a.x, b.x, t), mix(a.y, b.y, t), mix(a.z, b.z, t), mix(a.w, b.w, t)); }
+PTL_FN vec2 mix(const vec2& a, const vec2& b, const vec2& t) { return vec2(mix(a.x, b.x, t.x), mix(a.y, b.y, t.y)); }
+PTL_FN vec3 mix(const vec3& a, const vec3& b, const vec3& t) { return vec3(mix(a.x, b.x, t.x), mix(a.y, b.y, t.y), mix(a.z, b.z, t.z)); }
+PTL_FN vec4 mix(const vec4& a, const vec4& b, const vec4& t) { return vec4(mix(a.x, b.x, t.x), mix(a.y, b.y, t.y), mix(a.z, b.z, t.z), mix(a.w, b.w, t.w)); }
+PTL_FN vec2 smoothstep(float e0, float e1, const vec2& a) { return vec2(smoothstep(e0, e1, a.x), smoothstep(e0, e1, a.y)); }
+PTL_FN vec3 smoothstep(float e0, float e1, const vec3& a) { return vec3(smoothstep(e0, e1, a.x), smoothstep(e0, e1, a.y), smoothstep(e0, e1, a.z)); }
+
+// geometric -----------------------------------------------------------------------------
+PTL_FN float dot(const vec2& a, const vec2& b) { return fma(a.y, b.y, a.x * b.x); }
+PTL_FN float dot(const vec3& a, const vec3& b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
+PTL_FN float dot(const vec4& a, const vec4& b) { return fma(a.w, b.w, fma(a.z, b.z, fma(a.y, b.y, a.x * b.x))); }
+PTL_FN float length(float a) { return abs(a); }
+PTL_FN float length(const vec2& a) { return sqrt(dot(a, a)); }
+PTL_FN float length(const vec3& a) { return sqrt(dot(a, a)); }
+PTL_FN float length(const vec4& a) { return sqrt(dot(a, a)); }
+PTL_FN float distance(const vec2& a, const vec2& b) { return length(a - b); }
+PTL_FN float distance(const vec3& a, const vec3& b) { return length(a - b); }
+PTL_FN float distance(const vec4& a, const vec4& b) { return length(a - b); }
+PTL_FN vec2 normalize(const vec2& a) { return a / length(a); }
+PTL_FN vec3 normalize(const vec3& a) { return a / length(a); }
+PTL_FN vec4 normalize(const vec4& a) { return a / length(a); }
+PTL_FN vec3 cross(const vec3& a, const vec3& b) {
+    return vec3(fma(a.y, b.z, -(a.z * b.y)), fma(a.z, b.x, -(a.x * b.z)), fma(a.x, b.y, -(a.y * b.x)));
+}
+PTL_FN vec2 reflect(const vec2& i, const vec2& n) { return i - n * (2.0f * dot(n, i)); }
+PTL_FN vec3 reflect(const vec3& i, const vec3& n) { return i - n * (2.0f * dot(n, i)); }
+PTL_FN vec3 refract(const vec3& i, const vec3& n, float eta) {
+    float d = dot(n, i);
+    float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k < 0.0f) return vec3(0.0f);
+    return i * eta - n * (eta * d + sqrt(k));
+}
+PTL_FN vec3 faceforward(const vec3& n, const vec3& i, const vec3& nref) { return dot(nref, i) < 0.0f ? n : -n; }
+
+// ---------------------------------------------------------------------------------------
+// matrices (column-major, m[i] is column i, as in GLSL)
+// ---------------------------------------------------------------------------------------
+struct mat4;
+struct mat2 {
+    vec2 c[2];
+    mat2() = default;
+    PTL_FN explicit mat2(float d) { c[0] = vec2(d, 0.0f); c[1] = vec2(0.0f, d); }
+    PTL_FN mat2(const vec2& a, const vec2& b) { c[0] = a; c[1] = b; }
+    PTL_FN mat2(float a, float b, float cc, float d) { c[0] = vec2(a, b); c[1] = vec2(cc, d); }
+    PTL_FN vec2& operator[](int i) { return c[i]; }
+    PTL_FN const vec2& operator[](int i) const { return c[i]; }
+};
+struct mat3 {
+    vec3 c[3];
+    mat3() = default;
+    PTL_FN explicit mat3(float d) { c[0] = vec3(d, 0.0f, 0.0f); c[1] = vec3(0.0f, d, 0.0f); c[2] = vec3(0.0f, 0.0f, d); }
+    PTL_FN mat3(const vec3& a, const vec3& b, const vec3& cc) { c[0] = a; c[1] = b; c[2] = cc; }
+    PTL_FN mat3(float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1, float c2) {
+        c[0] = vec3(a0, a1, a2); c[1] = vec3(b0, b1, b2); c[2] = vec3(c0, c1, c2);
+    }
+    PTL_FN explicit mat3(const mat4& m);
+    PTL_FN vec3& operator[](int i) { return c[i]; }
+    PTL_FN const vec3& operator[](int i) const { return c[i]; }
+};
+struct mat4 {
+    vec4 c[4];
+    mat4() = default;
+    PTL_FN explicit mat4(float d) {
+        c[0] = vec4(d, 0.0f, 0.0f, 0.0f); c[1] = vec4(0.0f, d, 0.0f, 0.0f);
+        c[2] = vec4(0.0f, 0.0f, d, 0.0f); c[3] = vec4(0.0f, 0.0f, 0.0f, d);
+    }
+    PTL_FN mat4(const vec4& a, const vec4& b, const vec4& cc, const vec4& d) { c[0] = a; c[1] = b; c[2] = cc; c[3] = d; }
+    PTL_FN mat4(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3,
+                float c0, float c1, float c2, float c3, float d0, float d1, float d2, float d3) {
+        c[0] = vec4(a0, a1, a2, a3); c[1] = vec4(b0, b1, b2, b3);
+        c[2] = vec4(c0, c1, c2, c3); c[3] = vec4(d0, d1, d2, d3);
+    }
+    PTL_FN vec4& operator[](int i) { return c[i]; }
+    PTL_FN const vec4& operator[](int i) const { return c[i]; }
+};
+PTL_FN mat3::mat3(const mat4& m) { c[0] = vec3(m.c[0]); c[1] = vec3(m.c[1]); c[2] = vec3(m.c[2]); }
+
+PTL_FN vec2 operator*(const mat2& m, const vec2& v) {
+    return vec2(fma(m.c[1].x, v.y, m.c[0].x * v.x), fma(m.c[1].y, v.y, m.c[0].y * v.x));
+}
+PTL_FN vec3 operator*(const mat3& m, const vec3& v) {
+    return vec3(fma(m.c[2].x, v.z, fma(m.c[1].x, v.y, m.c[0].x * v.x)),
+                fma(m.c[2].y, v.z, fma(m.c[1].y, v.y, m.c[0].y * v.x)),
+                fma(m.c[2].z, v.z, fma(m.c[1].z, v.y, m.c[0].z * v.x)));
+}
+PTL_FN vec4 operator*(const mat4& m, const vec4& v) {
+    return vec4(fma(m.c[3].x, v.w, fma(m.c[2].x, v.z, fma(m.c[1].x, v.y, m.c[0].x * v.x))),
+                fma(m.c[3].y, v.w, fma(m.c[2].y, v.z, fma(m.c[1].y, v.y, m.c[0].y * v.x))),
+                fma(m.c[3].z, v.w, fma(m.c[2].z, v.z, fma(m.c[1].z, v.y, m.c[0].z * v.x))),
+                fma(m.c[3].w, v.w, fma(m.c[2].w, v.z, fma(m.c[1].w, v.y, m.c[0].w * v.x))));
+}
+// row vector times matrix: component i is dot(v, column i)
+PTL_FN vec2 operator*(const vec2& v, const mat2& m) { return vec2(dot(v, m.c[0]), dot(v, m.c[1])); }
+PTL_FN vec3 operator*(const vec3& v, const mat3& m) { return vec3(dot(v, m.c[0]), dot(v, m.c[1]), dot(v, m.c[2])); }
+PTL_FN vec4 operator*(const vec4& v, const mat4& m) { return vec4(dot(v, m.c[0]), dot(v, m.c[1]), dot(v, m.c[2]), dot(v, m.c[3])); }
+PTL_FN mat2 operator*(const mat2& a, const mat2& b) { return mat2(a * b.c[0], a * b.c[1]); }
+PTL_FN mat3 operator*(const mat3& a, const mat3& b) { return mat3(a * b.c[0], a * b.c[1], a * b.c[2]); }
+PTL_FN mat4 operator*(const mat4& a, const mat4& b) { return mat4(a * b.c[0], a * b.c[1], a * b.c[2], a * b.c[3]); }
+PTL_FN mat2 operator*(const mat2& a, float s) { return mat2(a.c[0] * s, a.c[1] * s); }
+PTL_FN mat3 operator*(const mat3& a, float s) { return mat3(a.c[0] * s, a.c[1] * s, a.c[2] * s); }
+PTL_FN mat4 operator*(const mat4& a, float s) { return mat4(a.c[0] * s, a.c[1] * s, a.c[2] * s, a.c[3] * s); }
+PTL_FN mat2 operator*(float s, const mat2& a) { return a * s; }
+PTL_FN mat3 operator*(float s, const mat3& a) { return a * s; }
+PTL_FN mat4 operator*(float s, const mat4& a) { return a * s; }
+PTL_FN mat2 operator+(const mat2& a, const mat2& b) { return mat2(a.c[0] + b.c[0], a.c[1] + b.c[1]); }
+PTL_FN mat3 operator+(const mat3& a, const mat3& b) { return mat3(a.c[0] + b.c[0], a.c[1] + b.c[1], a.c[2] + b.c[2]); }
+PTL_FN mat4 operator+(const mat4& a, const mat4& b) { return mat4(a.c[0] + b.c[0], a.c[1] + b.c[1], a.c[2] + b.c[2], a.c[3] + b.c[3]); }
+PTL_FN mat2 operator-(const mat2& a, const mat2& b) { return mat2(a.c[0] - b.c[0], a.c[1] - b.c[1]); }
+PTL_FN mat3 operator-(const mat3& a, const mat3& b) { return mat3(a.c[0] - b.c[0], a.c[1] - b.c[1], a.c[2] - b.c[2]); }
+PTL_FN mat4 operator-(const mat4& a, const mat4& b) { return mat4(a.c[0] - b.c[0], a.c[1] - b.c[1], a.c[2] - b.c[2], a.c[3] - b.c[3]); }
+PTL_FN mat2& operator*=(mat2& a, const mat2& b) { a = a * b; return a; }
+PTL_FN mat3& operator*=(mat3& a, const mat3& b) { a = a * b; return a; }
+PTL_FN mat4& operator*=(mat4& a, const mat4& b) { a = a * b; return a; }
+PTL_FN vec2& operator*=(vec2& v, const mat2& m) { v = v * m; return v; }
+PTL_FN vec3& operator*=(vec3& v, const mat3& m) { v = v * m; return v; }
+PTL_FN vec4& operator*=(vec4& v, const mat4& m) { v = v * m; return v; }
+PTL_FN mat2 transpose(const mat2& m) { return mat2(m.c[0].x, m.c[1].x, m.c[0].y, m.c[1].y); }
+PTL_FN mat3 transpose(const mat3& m) {
+    return mat3(m.c[0].x, m.c[1].x, m.c[2].x, m.c[0].y, m.c[1].y, m.c[2].y, m.c[0].z, m.c[1].z, m.c[2].z);
+}
+PTL_FN mat4 transpose(const mat4& m) {
+    return mat4(m.c[0].x, m.c[1].x, m.c[2].x, m.c[3].x, m.c[0].y, m.c[1].y, m.c[2].y, m.c[3].y,
+                m.c[0].z, m.c[1].z, m.c[2].z, m.c[3].z, m.c[0].w, m.c[1].w, m.c[2].w, m.c[3].w);
+}
+PTL_FN float determinant(const mat2& m) { return m.c[0].x * m.c[1].y - m.c[1].x * m.c[0].y; }
+PTL_FN float determinant(const mat3& m) { return dot(m.c[0], cross(m.c[1], m.c[2])); }
+PTL_FN mat2 inverse(const mat2& m) {
+    float i = 1.0f / determinant(m);
+    return mat2(m.c[1].y * i, -m.c[0].y * i, -m.c[1].x * i, m.c[0].x * i);
+}
+PTL_FN mat3 inverse(const mat3& m) {
+    vec3 r0 = cross(m.c[1], m.c[2]), r1 = cross(m.c[2], m.c[0]), r2 = cross(m.c[0], m.c[1]);
+    float i = 1.0f / dot(m.c[0], r0);
+    return mat3(r0.x * i, r1.x * i, r2.x * i, r0.y * i, r1.y * i, r2.y * i, r0.z * i, r1.z * i, r2.z * i);
+}
+
+// ---------------------------------------------------------------------------------------
+// textures: RGBA8, bilinear, clamp-to-edge, texel centres at +0.5, row 0 at v = 0
+// (macroquad Texture2D::from_file_with_format defaults; reference src/main.rs:1066-1083).
+// ---------------------------------------------------------------------------------------
+struct sampler2D {
+    const unsigned char* texels;
+    int width;
+    int height;
+};
+PTL_FN vec4 ptl_texel(const sampler2D& s, int ix, int iy) {
+    ix = clamp(ix, 0, s.width - 1);
+    iy = clamp(iy, 0, s.height - 1);
+    const unsigned char* p = s.texels + 4 * ((long)iy * s.width + ix);
+    return vec4((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f);
+}
+PTL_FN vec4 texture(const sampler2D& s, const vec2& uv) {
+    if (s.texels == nullptr || s.width <= 0 || s.height <= 0) return vec4(0.0f, 0.0f, 0.0f, 1.0f);
+    float x = uv.x * (float)s.width - 0.5f;
+    float y = uv.y * (float)s.height - 0.5f;
+    if (x != x) x = 0.0f;
+    if (y != y) y = 0.0f;
+    x = clamp(x, -1.0f, (float)s.width);
+    y = clamp(y, -1.0f, (float)s.height);
+    float x0 = floor(x), y0 = floor(y);
+    float fx = x - x0, fy = y - y0;
+    int ix = (int)x0, iy = (int)y0;
+    vec4 a = mix(ptl_texel(s, ix, iy), ptl_texel(s, ix + 1, iy), fx);
+    vec4 b = mix(ptl_texel(s, ix, iy + 1), ptl_texel(s, ix + 1, iy + 1), fx);
+    return mix(a, b, fy);
+}
+
+}  // namespace glsl

@@ -1,0 +1,355 @@
+// ptl_library.h -- the fixed prelude every generated portal kernel starts with.
+//
+// HIP C++ restatement of the reference's GLSL prelude src/library.glsl (598 lines): the
+// types and helper functions that scene snippets inside the .ron files call by name, so
+// names, argument order and arithmetic order are the interface and are kept; everything
+// else (struct layout, control flow shape, value-returning style) is written for
+// hipcc/gfx950.  Each function cites the reference lines it follows.
+//
+// Expects: ptl_glsl.h included, and the uniform accessors _grid_disable,
+// _angle_color_disable, _offset_after_material, _black_border_disable defined by the
+// generated uniform block (codegen.cpp).
+
+namespace glsl {
+
+#define PI acos(-1.0f)            /* src/library.glsl:15 */
+#define PI2 (acos(-1.0f) / 2.0f)  /* src/library.glsl:16 */
+
+// src/library.glsl:19-34
+PTL_FN bool between(float a, float x, float b) { return a <= x && x <= b; }
+PTL_FN float sqr(float a) { return a * a; }
+PTL_FN vec3 sqrvec(vec3 v) { return vec3(sqr(v.x), sqr(v.y), sqr(v.z)); }
+
+// --- rays -------------------------------------------------------------- library.glsl:40-53
+struct Ray {
+    vec4 o;            // origin
+    vec4 d;            // direction
+    float tmul;        // distance multiplier accumulated through scaling portals
+    bool in_subspace;  // "plus ultra" scenes
+};
+PTL_FN Ray ptl_ray_none() { return Ray{vec4(0.0f), vec4(0.0f), 0.0f, false}; }
+#define ray_none (ptl_ray_none())
+
+PTL_FN Ray offset_ray(Ray r, float t) {
+    r.o += r.d * t;
+    return r;
+}
+
+// library.glsl:56-62 -- unit normal facing against `dir`
+PTL_FN vec3 normalize_normal(vec3 normal, vec3 dir) {
+    normal = normalize(normal);
+    if (dot(normal, dir) > 0.0f) normal *= -1.0f;
+    return normal;
+}
+
+// library.glsl:65-67
+PTL_FN bool is_collinear(vec3 a, vec3 b) {
+    return abs(dot(a, b) / (length(a) * length(b)) - 1.0f) < 0.01f;
+}
+
+// library.glsl:70-72
+PTL_FN vec3 my_reflect(vec3 dir, vec3 normal) {
+    return dir - normal * dot(dir, normal) / dot(normal, normal) * 2.0f;
+}
+
+// library.glsl:75-92
+PTL_FN vec3 my_refract(vec3 dir, vec3 normal, float refractive_index) {
+    float ri = refractive_index;
+    bool from_outside = dot(normal, dir) > 0.0f;
+    if (!from_outside) {
+        ri = 1.0f / ri;
+    } else {
+        normal = -normal;
+    }
+    dir = normalize(dir);
+    float c = -dot(normal, dir);
+    float d = 1.0f - ri * ri * (1.0f - c * c);
+    if (d > 0.0f) return dir * ri + normal * (ri * c - sqrt(d));
+    return my_reflect(dir, normal);
+}
+
+// library.glsl:95-120
+PTL_FN Ray transform(const mat4& matrix, const Ray& r) {
+    return Ray{matrix * r.o, matrix * r.d, r.tmul, r.in_subspace};
+}
+PTL_FN vec3 get_normal(const mat4& matrix) { return (matrix * vec4(0.0f, 0.0f, 1.0f, 0.0f)).sw<0, 1, 2>(); }
+PTL_FN Ray normalize_ray(Ray r) {
+    float len = length(r.d);
+    r.d /= len;
+    r.tmul /= len;
+    return r;
+}
+PTL_FN mat3 adjugate(const mat4& m) {
+    return mat3(cross(vec3(m[1]), vec3(m[2])), cross(vec3(m[2]), vec3(m[0])), cross(vec3(m[0]), vec3(m[1])));
+}
+
+// --- surface hits ---------------------------------------------------- library.glsl:127-162
+struct SurfaceIntersection {
+    bool hit;
+    float t;  // distance along the ray
+    float u;  // surface coordinates
+    float v;
+    vec3 n;   // normal at the hit point
+};
+PTL_FN SurfaceIntersection ptl_intersection_none() { return SurfaceIntersection{false, 1e10f, 0.0f, 0.0f, vec3(0.0f)}; }
+#define intersection_none (ptl_intersection_none())
+
+PTL_FN SurfaceIntersection plane_intersect_normalized(const Ray& r) {
+    float t = -r.o.z / r.d.z;
+    if (t < 0.0f) return intersection_none;
+    vec4 pos = r.o + r.d * t;
+    return SurfaceIntersection{true, t, pos.x, pos.y, vec3(0.0f, 0.0f, 1.0f)};
+}
+
+// Ray against the z = 0 plane of `plane` given `plane_inv` = inverse(plane).
+PTL_FN SurfaceIntersection plane_intersect(Ray r, const mat4& plane_inv, vec3 normal) {
+    normal = normalize_normal(normal, r.d.sw<0, 1, 2>());
+    r = transform(plane_inv, r);
+    float len = length(r.d);
+    r.d = normalize(r.d);
+    SurfaceIntersection result = plane_intersect_normalized(r);
+    if (result.hit) {
+        result.t /= len;
+        result.n = normal;
+    }
+    return result;
+}
+
+// --- colours ------------------------------------------------------- library.glsl:169-288
+PTL_FN vec3 color(float r, float g, float b) { return vec3(r * r, g * g, b * b); }
+
+PTL_FN float color_normal(vec3 normal, vec4 direction) {
+    if (_angle_color_disable == 1) return 1.0f;
+    return abs(dot(normalize(direction.sw<0, 1, 2>()), normalize(normal)));
+}
+
+PTL_FN vec3 color_grid(vec3 start, vec2 uv) {
+    if (_grid_disable == 1) return start;
+    uv = fract(uv * 0.25f);
+    return start * mix(mix(0.7f, 1.1f, step(uv.x, 0.5f)), mix(1.1f, 0.7f, step(uv.x, 0.5f)), step(uv.y, 0.5f));
+}
+
+PTL_FN float circle_sdf(vec2 position) {
+    vec2 s = vec2(2.0f, sqrt(3.0f) * 2.0f);
+    position /= s;
+    vec2 d1 = (fract(position) - 0.5f) * s;
+    vec2 d2 = (fract(position + 0.5f) - 0.5f) * s;
+    return sqrt(min(dot(d1, d1), dot(d2, d2))) - 1.0f;
+}
+PTL_FN vec3 color_grid2(vec3 start, vec2 uv) {
+    float d = circle_sdf(uv);
+    float val = 0.7f;
+    if (d < -0.2f) val = 1.1f;
+    return start * val;
+}
+
+PTL_FN vec3 color_grid3(vec3 start, vec2 uv) {
+    if (_grid_disable == 1) return start;
+    uv = fract(uv * 0.5f) - vec2(0.5f, 0.5f);
+    float dist = max(abs(uv.x), abs(uv.y)) * 2.0f;
+    if (dist > 0.985f) return start * 0.4f;
+    if (dist < 0.94f) return start;
+    if (uv.x > uv.y) return start * 0.7f;
+    return start * 1.2f;
+}
+
+PTL_FN vec3 color_add_weighted(vec3 a, vec3 b, float coef) { return a * (1.0f - coef) + b * coef; }
+
+// --- materials ------------------------------------------------------ library.glsl:297-384
+struct MaterialProcessing {
+    bool is_final;      // false: keep tracing along new_ray
+    vec3 mul_to_color;  // throughput factor (final: the surface colour)
+    Ray new_ray;
+};
+PTL_FN MaterialProcessing material_empty() { return MaterialProcessing{true, vec3(0.0f), ray_none}; }
+PTL_FN MaterialProcessing material_final(vec3 color) { return MaterialProcessing{true, color, ray_none}; }
+PTL_FN MaterialProcessing material_next(vec3 mul_color, Ray new_ray) { return MaterialProcessing{false, mul_color, new_ray}; }
+
+PTL_FN MaterialProcessing material_simple2(SurfaceIntersection hit, Ray r, vec3 color, float normal_coef, bool grid,
+                                           float grid_scale, float grid_coef, bool grid2, bool grid3) {
+    color = color_add_weighted(color, color * color_normal(hit.n, r.d), normal_coef);
+    if (grid) {
+        vec2 cell = vec2(hit.u, hit.v) * grid_scale;
+        if (grid3) {
+            color = color_add_weighted(color, color_grid3(color, cell), grid_coef);
+        } else if (grid2) {
+            color = color_add_weighted(color, color_grid2(color, cell), grid_coef);
+        } else {
+            color = color_add_weighted(color, color_grid(color, cell), grid_coef);
+        }
+    }
+    return material_final(color);
+}
+PTL_FN MaterialProcessing material_simple(SurfaceIntersection hit, Ray r, vec3 color, float normal_coef, bool grid,
+                                          float grid_scale, float grid_coef) {
+    return material_simple2(hit, r, color, normal_coef, grid, grid_scale, grid_coef, false, false);
+}
+PTL_FN MaterialProcessing material_reflect(SurfaceIntersection hit, Ray r, vec3 add_to_color) {
+    r.d = vec4(my_reflect(r.d.sw<0, 1, 2>(), hit.n), 0.0f);
+    r.o += r.d * _offset_after_material;
+    return material_next(add_to_color, r);
+}
+PTL_FN MaterialProcessing material_refract(SurfaceIntersection hit, Ray r, vec3 add_to_color, float refractive_index) {
+    r.d = vec4(my_refract(r.d.sw<0, 1, 2>(), hit.n, refractive_index), 0.0f);
+    r.o += r.d * _offset_after_material;
+    return material_next(add_to_color, r);
+}
+PTL_FN MaterialProcessing material_teleport_transformed(Ray r, vec3 n) {
+    r.o += r.d * _offset_after_material;
+    r = normalize_ray(r);
+    return material_next(vec3(1.0f), r);
+}
+PTL_FN MaterialProcessing material_teleport(SurfaceIntersection hit, Ray r, const mat4& teleport_matrix) {
+    return material_teleport_transformed(transform(teleport_matrix, r), hit.n);
+}
+PTL_FN MaterialProcessing material_change_subspace(Ray r) {
+    r.in_subspace = !r.in_subspace;
+    return material_next(vec3(1.0f), r);
+}
+
+// material ids -------------------------------------------------------- library.glsl:387-398
+#define CUSTOM_MATERIAL (-1)
+#define NOT_INSIDE 0
+#define TELEPORT 1
+#define TELEPORT_SUBSPACE 2
+#define DEBUG_RED 3
+#define DEBUG_GREEN 4
+#define DEBUG_BLUE 5
+#define USER_MATERIAL_OFFSET 10
+
+// --- scene hits ------------------------------------------------------ library.glsl:405-423
+struct SceneIntersection {
+    int material;
+    SurfaceIntersection hit;
+    bool in_subspace;
+};
+PTL_FN SceneIntersection ptl_scene_intersection_none() { return SceneIntersection{0, intersection_none, false}; }
+#define scene_intersection_none (ptl_scene_intersection_none())
+
+PTL_FN bool nearer(const SurfaceIntersection& result, const SurfaceIntersection& current) {
+    return current.hit && (current.t > 0.0f) && (!result.hit || (result.hit && current.t < result.t));
+}
+PTL_FN bool nearer(const SceneIntersection& result, const SurfaceIntersection& current) { return nearer(result.hit, current); }
+PTL_FN bool nearer(const SceneIntersection& result, const SceneIntersection& current) { return nearer(result.hit, current.hit); }
+
+// --- primitives (after iq, shadertoy Xt3SzX / 4lcSRn) --------------- library.glsl:426-525
+PTL_FN vec3 cap_normal(vec3 pos, vec3 a, vec3 b, float radius) {
+    vec3 ba = b - a;
+    vec3 pa = pos - a;
+    float h = clamp(dot(pa, ba) / dot(ba, ba), 0.0f, 1.0f);
+    return (pa - h * ba) / radius;
+}
+PTL_FN SurfaceIntersection cap(Ray r, vec3 pa, vec3 pb, float radius) {
+    vec3 ro = r.o.sw<0, 1, 2>();
+    vec3 rd = r.d.sw<0, 1, 2>();
+    vec3 ba = pb - pa;
+    vec3 oa = ro - pa;
+    float baba = dot(ba, ba);
+    float bard = dot(ba, rd);
+    float baoa = dot(ba, oa);
+    float rdoa = dot(rd, oa);
+    float oaoa = dot(oa, oa);
+    float a = baba - bard * bard;
+    float b = baba * rdoa - baoa * bard;
+    float c = baba * oaoa - baoa * baoa - radius * radius * baba;
+    float h = b * b - a * c;
+    if (h >= 0.0f) {
+        float t = (-b - sqrt(h)) / a;
+        float y = baoa + t * bard;
+        if (y > 0.0f && y < baba) {  // body
+            vec3 pos = ro + rd * t;
+            return SurfaceIntersection{true, t, 0.0f, 0.0f, cap_normal(pos, pa, pb, radius)};
+        }
+        vec3 oc = (y <= 0.0f) ? oa : ro - pb;  // caps
+        b = dot(rd, oc);
+        c = dot(oc, oc) - radius * radius;
+        h = b * b - c;
+        if (h > 0.0f) {
+            t = -b - sqrt(h);
+            vec3 pos = ro + rd * t;
+            return SurfaceIntersection{true, t, 0.0f, 0.0f, cap_normal(pos, pa, pb, radius)};
+        }
+    }
+    return intersection_none;
+}
+PTL_FN SurfaceIntersection cylinder(Ray r, vec3 pa, vec3 pb, float ra) {
+    vec3 ro = r.o.sw<0, 1, 2>();
+    vec3 rd = r.d.sw<0, 1, 2>();
+    vec3 ba = pb - pa;
+    vec3 oc = ro - pa;
+    float baba = dot(ba, ba);
+    float bard = dot(ba, rd);
+    float baoc = dot(ba, oc);
+    float k2 = baba - bard * bard;
+    float k1 = baba * dot(oc, rd) - baoc * bard;
+    float k0 = baba * dot(oc, oc) - baoc * baoc - ra * ra * baba;
+    float h = k1 * k1 - k2 * k0;
+    if (h < 0.0f) return intersection_none;
+    h = sqrt(h);
+    float t = (-k1 - h) / k2;  // near side
+    float y = baoc + t * bard;
+    if (y > 0.0f && y < baba) return SurfaceIntersection{true, t, 0.0f, 0.0f, (oc + t * rd - ba * y / baba) / ra};
+    t = (-k1 + h) / k2;  // far side
+    y = baoc + t * bard;
+    if (y > 0.0f && y < baba) return SurfaceIntersection{true, t, 0.0f, 0.0f, (oc + t * rd - ba * y / baba) / ra};
+    return intersection_none;
+}
+PTL_FN SurfaceIntersection triangle(Ray r, vec3 v0, vec3 v1, vec3 v2) {
+    vec3 ro = r.o.sw<0, 1, 2>();
+    vec3 rd = r.d.sw<0, 1, 2>();
+    vec3 v1v0 = v1 - v0;
+    vec3 v2v0 = v2 - v0;
+    vec3 rov0 = ro - v0;
+    vec3 n = cross(v1v0, v2v0);
+    vec3 q = cross(rov0, rd);
+    float d = 1.0f / dot(rd, n);
+    float u = d * dot(-q, v2v0);
+    float v = d * dot(q, v1v0);
+    float t = d * dot(-n, rov0);
+    if (u < 0.0f || v < 0.0f || (u + v) > 1.0f) return intersection_none;
+    return SurfaceIntersection{true, t, u, v, normalize_normal(cross(v1 - v0, v2 - v0), rd)};
+}
+
+// library.glsl:528-554 -- the three axis capsules drawn for Object::DebugMatrix
+PTL_FN SceneIntersection debug_intersect(Ray r) {
+    const vec3 pa = vec3(0.0f);
+    const float radius = 0.03f;
+    SceneIntersection i = SceneIntersection{0, intersection_none, false};
+    SurfaceIntersection hit = cap(r, pa, vec3(1.0f, 0.0f, 0.0f), radius);
+    if (nearer(i, hit)) { i.material = DEBUG_RED; i.hit = hit; }
+    hit = cap(r, pa, vec3(0.0f, 1.0f, 0.0f), radius);
+    if (nearer(i, hit)) { i.material = DEBUG_GREEN; i.hit = hit; }
+    hit = cap(r, pa, vec3(0.0f, 0.0f, 1.0f), radius);
+    if (nearer(i, hit)) { i.material = DEBUG_BLUE; i.hit = hit; }
+    return i;
+}
+
+// library.glsl:560-589 -- what an is_inside_N() verdict does to the running nearest hit
+PTL_FN SceneIntersection process_plane_intersection(SceneIntersection i, SurfaceIntersection hit, int inside) {
+    if (inside != NOT_INSIDE && inside != TELEPORT && inside != TELEPORT_SUBSPACE) {
+        i.hit = hit;
+        i.material = inside;
+    }
+    return i;
+}
+PTL_FN SceneIntersection process_portal_intersection(SceneIntersection i, SurfaceIntersection hit, int inside, int teleport_material) {
+    if (inside == NOT_INSIDE) return i;
+    i.hit = hit;
+    if (inside == TELEPORT) {
+        i.material = teleport_material;
+    } else if (inside == TELEPORT_SUBSPACE) {
+        i.material = teleport_material;
+        i.in_subspace = true;
+    } else {
+        i.material = inside;
+    }
+    return i;
+}
+
+// library.glsl:595-598
+struct SceneIntersectionWithMaterial {
+    SceneIntersection scene;      // scene.material == CUSTOM_MATERIAL: use `material` below
+    MaterialProcessing material;
+};
+
+}  // namespace glsl

@@ -1,0 +1,313 @@
+// ptl_trace.tpl -- per-scene kernel template, filled in by codegen.cpp (apply_template).
+//
+// Plays the role of the reference's src/frag.glsl: the slash-slash-percent markers are the slots
+// Scene::generate_shader_code fills (src/gui/scene.rs:693-1110, src/code_generation.rs:81-98).
+// The text around the slots is a from-scratch HIP C++ restatement of the per-pixel path
+// (AA loop -> primary ray -> bounce loop -> shade), laid out for gfx950: one 64-lane
+// wavefront owns an 8x8 pixel tile, four tiles form a 32x8 block, uniforms live in one
+// __constant__ block read through the scalar cache, the RGBA8 tile is transposed through
+// LDS so that every wave stores two full 128-byte rows.
+//%predefined_library//%
+
+// bounce-loop trip counter (segment Mray/s, SURVEY.md 8d); compiled in only on request
+#ifdef PTL_COUNT_SEGMENTS
+#if PTL_DEVICE_BUILD
+__shared__ unsigned int ptl_segments_lds[256];
+#define PTL_COUNT_SEGMENT() (ptl_segments_lds[threadIdx.x] += 1u)
+#else
+thread_local unsigned long long ptl_segments_tls = 0;
+#define PTL_COUNT_SEGMENT() (ptl_segments_tls += 1ull)
+#endif
+#else
+#define PTL_COUNT_SEGMENT() ((void)0)
+#endif
+
+namespace glsl {
+
+// --- scene uniforms (reference: `uniform ...;` declarations, scene.rs:661-718) -------------
+//%uniforms//%
+
+// --- material ids (scene.rs:720-845) ---------------------------------------------------------
+//%materials_defines//%
+
+// Scene snippets are plain GLSL functions without HIP attributes: let clang treat every
+// function declared in this region as __host__ __device__.
+#if PTL_DEVICE_BUILD
+#pragma clang force_cuda_host_device begin
+#endif
+
+// --- scene library snippets (scene.rs:1037-1044) ---------------------------------------------
+//%library//%
+
+// --- is_inside_N / intersect_N wrappers around scene snippets (scene.rs:847-883) ------------
+//%intersection_functions//%
+
+// --- intersect_material_N (scene.rs:1011-1024) -----------------------------------------------
+//%intersection_material_functions//%
+
+#if PTL_DEVICE_BUILD
+#pragma clang force_cuda_host_device end
+#endif
+
+// Nearest object hit along r: one generated statement group per scene object.
+// (reference shell: src/frag.glsl:19-31)
+PTL_FN SceneIntersection scene_intersect(const Ray& r) {
+    SceneIntersection i = SceneIntersection{0, intersection_none, false};
+    SceneIntersection ihit = SceneIntersection{0, intersection_none, false};
+    SurfaceIntersection hit = intersection_none;
+    vec3 normal = vec3(0.0f);
+    int inside = NOT_INSIDE;
+    float len = 1.0f;
+    Ray transformed_ray = ray_none;
+    (void)ihit; (void)hit; (void)normal; (void)inside; (void)len; (void)transformed_ray;
+
+//%intersections//%
+
+    return i;
+}
+
+// Material id -> what happens to the path. (reference shell: src/frag.glsl:33-50)
+PTL_FN MaterialProcessing material_process(Ray r, const SceneIntersection& i) {
+    SurfaceIntersection hit = i.hit;
+    if (i.in_subspace) r.in_subspace = !r.in_subspace;
+    if (i.material == 0) {
+    } else if (i.material == DEBUG_RED) {
+        return material_simple2(hit, r, color(0.9f, 0.2f, 0.2f), 0.5f, false, 1.0f, 0.0f, false, false);
+    } else if (i.material == DEBUG_GREEN) {
+        return material_simple2(hit, r, color(0.2f, 0.9f, 0.2f), 0.5f, false, 1.0f, 0.0f, false, false);
+    } else if (i.material == DEBUG_BLUE) {
+        return material_simple2(hit, r, color(0.2f, 0.2f, 0.9f), 0.5f, false, 1.0f, 0.0f, false, false);
+
+//%material_processing//%
+
+    }
+    return material_final(vec3(0.0f));  // unknown material id
+}
+
+// Scene snippets that return hit and material in one go. (src/frag.glsl:52-59)
+PTL_FN SceneIntersectionWithMaterial scene_intersect_material_process(const Ray& r) {
+    SceneIntersectionWithMaterial result = SceneIntersectionWithMaterial{scene_intersection_none, material_empty()};
+    SceneIntersectionWithMaterial hit = SceneIntersectionWithMaterial{scene_intersection_none, material_empty()};
+    (void)hit;
+
+//%intersection_material_processing//%
+
+    return result;
+}
+
+// --- the bounce loop -------------------------------------------------- src/frag.glsl:74-159
+struct RayTraceResult {
+    vec3 color;
+    float depth;
+    bool has_depth;
+};
+
+PTL_FN float normalize_depth_value(float depth) {  // frag.glsl:80-84
+    float depth_min = min(_depth_map_min, _depth_map_max);
+    float depth_max = max(_depth_map_min, _depth_map_max);
+    return clamp((depth - depth_min) / max(1e-6f, depth_max - depth_min), 0.0f, 1.0f);
+}
+
+PTL_FN vec3 depth_gradient_inferno(float t) {  // frag.glsl:86-99
+    vec3 c0 = sqrvec(vec3(0.001462f, 0.000466f, 0.013866f));
+    vec3 c1 = sqrvec(vec3(0.258234f, 0.038571f, 0.406485f));
+    vec3 c2 = sqrvec(vec3(0.578304f, 0.148039f, 0.404411f));
+    vec3 c3 = sqrvec(vec3(0.865006f, 0.316822f, 0.226055f));
+    vec3 c4 = sqrvec(vec3(0.987622f, 0.645320f, 0.039886f));
+    vec3 c5 = sqrvec(vec3(0.988362f, 0.998364f, 0.644924f));
+    if (t < 0.2f) return mix(c0, c1, t / 0.2f);
+    if (t < 0.4f) return mix(c1, c2, (t - 0.2f) / 0.2f);
+    if (t < 0.6f) return mix(c2, c3, (t - 0.4f) / 0.2f);
+    if (t < 0.8f) return mix(c3, c4, (t - 0.6f) / 0.2f);
+    return mix(c4, c5, (t - 0.8f) / 0.2f);
+}
+
+PTL_FN vec3 sample_depth_gradient(float depth) {  // frag.glsl:101-104
+    return depth_gradient_inferno(1.0f - normalize_depth_value(depth));
+}
+
+PTL_FN RayTraceResult ray_tracing(Ray r, float camera_scale) {
+    //%skybox_processing//%
+
+    vec3 current_color = vec3(1.0f);
+    float all_t = 0.0f;
+    for (int j = 0; j < _ray_tracing_depth; j++) {
+        PTL_COUNT_SEGMENT();
+        SceneIntersection i = scene_intersect(r);
+        SceneIntersectionWithMaterial i2 = scene_intersect_material_process(r);
+
+        // `m` is left unset by the reference when a snippet reports hit with t <= 0 (GLSL:
+        // undefined value); this build defines that case as the all-zero MaterialProcessing.
+        MaterialProcessing m = MaterialProcessing{false, vec3(0.0f), ray_none};
+        if (nearer(i.hit, i2.scene.hit)) {
+            r.o += r.d * i2.scene.hit.t;
+            all_t += i2.scene.hit.t * r.tmul;
+            if (i2.scene.material == CUSTOM_MATERIAL) {
+                m = i2.material;
+            } else {
+                m = material_process(r, i2.scene);
+            }
+        } else if (i.hit.hit) {
+            r.o += r.d * i.hit.t;
+            all_t += i.hit.t * r.tmul;
+            m = material_process(r, i);
+        }
+
+        if (!(i.hit.hit || i2.scene.hit.hit)) {  // escaped the scene
+            if (r.in_subspace) return RayTraceResult{color(0.0f, 0.0f, 0.0f), 0.0f, false};
+            return RayTraceResult{current_color * not_found_color, 0.0f, false};
+        }
+        current_color *= m.mul_to_color;
+        if (m.is_final) {
+            float depth = all_t / max(camera_scale, 1e-6f);
+            if (all_t > _t_start * camera_scale && _darken_by_distance == 1) {  // fade to black with distance
+                if (all_t > _t_end * camera_scale) all_t = _t_end * camera_scale;
+                float gray_t = (all_t - _t_start * camera_scale) / (_t_end - _t_start) / camera_scale;
+                return RayTraceResult{
+                    color(0.0f, 0.0f, 0.0f) * sqr(sqr(gray_t)) + current_color * sqr(sqr(1.0f - gray_t)), depth, true};
+            }
+            return RayTraceResult{current_color, depth, true};
+        }
+        r = m.new_ray;
+    }
+    return RayTraceResult{color(0.0f, 0.0f, 0.0f), 0.0f, false};  // depth exhausted
+}
+
+// --- camera ---------------------------------------------------------- src/frag.glsl:297-342
+PTL_FN float Pow2(float x) { return x * x; }
+
+// Pannini inverse mapping, tc in [-1,1]^2, fov in [0,pi), d in [0,1] (after shadertoy Wt3fzB)
+PTL_FN vec3 PaniniProjection(vec2 tc, float fov, float d) {
+    const float Pi05 = 3.14159265359f * 0.5f;
+    float d2 = d * d;
+    {
+        float fo = Pi05 - fov * 0.5f;
+        float f = cos(fo) / sin(fo);
+        float f2 = f * f;
+        float b = (sqrt(max(0.0f, Pow2(d + d2) * (f2 + f2 * f2))) - (d * f + f)) / (d2 + d2 * f2 - 1.0f);
+        tc *= b;
+    }
+    float h = tc.x;
+    float v = tc.y;
+    float h2 = h * h;
+    float k = h2 / Pow2(d + 1.0f);
+    float k2 = k * k;
+    float discr = max(0.0f, k2 * d2 - (k + 1.0f) * (k * d2 - 1.0f));
+    float cosPhi = (-k * d + sqrt(discr)) / (k + 1.0f);
+    float S = (d + 1.0f) / (d + cosPhi);
+    float tanTheta = v / S;
+    float sinPhi = sqrt(max(0.0f, 1.0f - Pow2(cosPhi)));
+    if (tc.x < 0.0f) sinPhi *= -1.0f;
+    float s = inversesqrt(1.0f + Pow2(tanTheta));
+    return vec3(sinPhi, tanTheta, cosPhi) * s;
+}
+
+// Primary ray for one image-plane position, then trace it.  (src/frag.glsl:408-464)
+PTL_FN vec3 get_color2(vec2 image_position, const mat4& camera_matrix, bool in_subspace, float camera_scale, vec2 resolution) {
+    const float Pi = 3.14159265359f;
+    const float Pi05 = Pi * 0.5f;
+    vec4 o = camera_matrix * vec4(0.0f, 0.0f, 0.0f, 1.0f);
+    vec4 d;
+    if (_use_panini_projection == 1) {
+        d = normalize(camera_matrix * vec4(PaniniProjection(vec2(image_position.x, image_position.y), _view_angle, _panini_param), 0.0f));
+    } else if (_use_360_camera == 1) {  // equirectangular, 2:1, black bars outside
+        float coef = min(resolution.x, resolution.y);
+        float ax = resolution.x / coef;
+        float ay = resolution.y / coef;
+        float rx;
+        float ry;
+        if (ax >= 2.0f * ay) {
+            ry = ay;
+            rx = 2.0f * ay;
+        } else {
+            rx = ax;
+            ry = ax / 2.0f;
+        }
+        if (abs(image_position.x) > rx || abs(image_position.y) > ry) return vec3(0.0f);
+        float yaw = (image_position.x / rx) * Pi;
+        float pitch = (image_position.y / ry) * Pi05;
+        vec3 dir_local = vec3(sin(yaw) * cos(pitch), sin(pitch), cos(yaw) * cos(pitch));
+        d = normalize(camera_matrix * vec4(dir_local, 0.0f));
+    } else if (_use_180_camera == 1) {  // VR180 front hemisphere
+        if (abs(image_position.x) > 1.0f || abs(image_position.y) > 1.0f) return vec3(0.0f);
+        float yaw = image_position.x * Pi05;
+        float pitch = image_position.y * Pi05;
+        vec3 dir_local = vec3(sin(yaw) * cos(pitch), sin(pitch), cos(yaw) * cos(pitch));
+        d = normalize(camera_matrix * vec4(dir_local, 0.0f));
+    } else {  // pinhole
+        float h = tan(_view_angle / 2.0f);
+        d = normalize(camera_matrix * vec4(image_position.x * h, image_position.y * h, 1.0f, 0.0f));
+    }
+
+    RayTraceResult trace = ray_tracing(Ray{o, d, 1.0f, in_subspace}, camera_scale);
+    if (_draw_depth_map == 1) {
+        if (trace.has_depth) return sample_depth_gradient(trace.depth);
+        return vec3(0.0f);
+    }
+    return trace.color;
+}
+
+// Mono / side-by-side selection.  (src/frag.glsl:466-503; anaglyph lines are stripped by the
+// reference's native defaults, src/main.rs:935-941, so they are not restated here.)
+PTL_FN vec3 get_color(vec2 image_position) {
+    mat4 final_matrix = _camera;
+    bool final_in_subspace = _camera_in_subspace == 1;
+    float final_scale = _camera_scale;
+    vec2 final_resolution = _resolution;
+
+    if (_draw_side_by_side == 1) {
+        float coef = min(_resolution.x, _resolution.y);
+        vec2 position = image_position / 2.0f * coef + _resolution / 2.0f;
+        vec2 resolution = vec2(_resolution.x / 2.0f, _resolution.y);
+        float coef2 = min(resolution.x, resolution.y);
+        if (position.x < resolution.x) {
+            image_position = (position - resolution / 2.0f) / coef2 * 2.0f;
+            final_matrix = _camera_left_eye;
+            final_in_subspace = _left_eye_in_subspace == 1;
+            final_scale = _left_eye_scale;
+        } else {
+            image_position = (position - vec2(resolution.x, 0.0f) - resolution / 2.0f) / coef2 * 2.0f;
+            final_matrix = _camera_right_eye;
+            final_in_subspace = _right_eye_in_subspace == 1;
+            final_scale = _right_eye_scale;
+        }
+        final_resolution = resolution;
+    }
+    return get_color2(image_position, final_matrix, final_in_subspace, final_scale, final_resolution);
+}
+
+// R2 low-discrepancy sub-pixel offsets.  (src/frag.glsl:506-513)
+PTL_FN vec2 quasi_random(int i) {
+    const float a1 = 0.7548776662466927600500267982588025643670318456949186300834636687f;
+    const float a2 = 0.5698402909980532659121818632752155853637566123932930564053138358f;
+    return vec2(mod(0.5f + a1 * float(i), 1.0f), mod(0.5f + a2 * float(i), 1.0f));
+}
+
+// One pixel: `position` is the pixel centre in pixel units, y down, (0,0) = top-left corner
+// (vertex stage src/gui/scene.rs:1674-1697 evaluated at the fragment centre; AA loop and
+// gamma-2 encode src/frag.glsl:515-527,550-551).  Returns the RGBA the reference writes to
+// FragColor, before the GL RGBA8 conversion.
+PTL_FN vec4 shade_pixel(vec2 position) {
+    float coef = min(_resolution.x, _resolution.y);
+    vec2 uv_screen = (position - _resolution / 2.0f) / coef * 2.0f;
+    vec3 result = vec3(0.0f);
+    float pixel_size = 1.0f / min(_resolution.x, _resolution.y);
+    for (int a = _aa_start; a < _aa_count + _aa_start; a++) {
+        vec2 offset = quasi_random(a);
+        result += get_color(uv_screen + offset * pixel_size * 2.0f);
+    }
+    result = sqrt(result / float(_aa_count));
+    return vec4(result, 1.0f);
+}
+
+// GL fixed-point conversion of one channel: clamp to [0,1], scale, round to nearest.
+PTL_FN unsigned int unorm8(float v) {
+    if (!(v > 0.0f)) return 0u;  // also NaN
+    if (v >= 1.0f) return 255u;
+    return (unsigned int)floor(fma(v, 255.0f, 0.5f));
+}
+PTL_FN unsigned int pack_rgba8(vec4 c) {
+    return unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (unorm8(c.w) << 24);
+}
+
+}  // namespace glsl

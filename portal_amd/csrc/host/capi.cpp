@@ -1,0 +1,521 @@
+// capi.cpp -- layer 2 of the C ABI: scene handles and the SceneRenderer driver.
+//
+// Host-side mirror of SceneRenderer (src/main.rs:732-1544) for the offline image path:
+//   SceneRenderer::new          src/main.rs:934-1064   -> ptl_renderer_create
+//   SceneRenderer::set_uniforms src/main.rs:1266-1359  -> builtin_uniforms()
+//   RotateAroundCam::get_matrix src/main.rs:278-304    -> Camera::matrix()
+//   SceneRenderer::draw_texture src/main.rs:1411-1428  -> ptl_renderer_draw
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/portal_amd.h"
+#include "codegen.h"
+#include "formula.h"
+#include "glsl_translate.h"
+#include "internal.h"
+#include "scene.h"
+
+using namespace ptl;
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846264338327950288;
+double deg2rad(double deg) { return deg / 180.0 * kPi; }  // src/gui/common.rs:23-25
+
+// RotateAroundCam (src/main.rs:35-340), the fields the offline path reads
+struct Camera {
+    DVec3 look_at;
+    double alpha = deg2rad(81.0), beta = deg2rad(64.0), r = 3.5;
+    double view_angle = deg2rad(90.0);
+    bool use_panini_projection = false;
+    double panini_param = 1.0;
+    bool use_360_camera = false, use_180_camera = false;
+    DMat4 teleport_matrix = DMat4::identity();
+    bool in_subspace = false, free_movement = false;
+
+    DVec3 pos_vec() const { return DVec3(std::sin(beta) * std::cos(alpha), std::cos(beta), std::sin(beta) * std::sin(alpha)) * r; }
+    DMat4 matrix() const {  // src/main.rs:286-304
+        DVec3 pos = pos_vec() + look_at;
+        DVec3 k = (look_at - pos).normalize();
+        DVec3 i = k.cross(DVec3(0.0, 1.0, 0.0)).normalize();
+        DVec3 j = k.cross(i).normalize();
+        DVec3 p = free_movement ? look_at : pos;
+        return teleport_matrix * DMat4::from_cols({i.x, i.y, i.z, 0.0}, {j.x, j.y, j.z, 0.0}, {k.x, k.y, k.z, 0.0}, {p.x, p.y, p.z, 1.0});
+    }
+};
+
+double calc_scale(const DMat4& m) {  // src/main.rs:1325-1333
+    return (m.c[0].length() + m.c[1].length() + m.c[2].length()) / 3.0;
+}
+
+void copy_str(char* dst, size_t cap, const std::string& s) {
+    if (!dst || !cap) return;
+    std::strncpy(dst, s.c_str(), cap - 1);
+    dst[cap - 1] = '\0';
+}
+
+ptl_type to_c_type(UniformType t) { return (ptl_type)(int)t; }
+
+}  // namespace
+
+struct ptl_scene {
+    std::shared_ptr<Scene> scene;
+    GeneratedKernel last;  // most recent generate_kernel_source() result
+    std::vector<ptl_uniform_desc> descs;
+    std::vector<std::string> desc_names;
+};
+
+struct ptl_renderer {
+    ptl_scene* owner = nullptr;
+    std::shared_ptr<Scene> scene;
+    ptl_kernel* kernel = nullptr;
+    Camera cam;
+    // SceneRenderer defaults, src/main.rs:1021-1040
+    double offset_after_material = 0.005, gray_t_start = 10.0, gray_t_size = 200.0;
+    int render_depth = 100, aa_count = 1, aa_start = 0;
+    bool draw_side_by_side = false, draw_depth_map = false, angle_color_disable = false, grid_disable = false,
+         black_border_disable = false, darken_by_distance = true;
+    double depth_map_min = 0.0, depth_map_max = 10.0, anaglyph_p = 0.29, anaglyph_q = 0.06;
+};
+
+namespace {
+
+int guarded(const std::function<int()>& fn) {
+    try {
+        return fn();
+    } catch (const ron::ParseError& e) {
+        set_last_error(e.what());
+        return PTL_ERR_SCENE;
+    } catch (const SceneError& e) {
+        set_last_error(e.what());
+        return PTL_ERR_SCENE;
+    } catch (const std::exception& e) {
+        set_last_error(std::string("internal error: ") + e.what());
+        return PTL_ERR_INVALID;
+    }
+}
+
+std::vector<UniformUpload> builtin_uniforms(const ptl_renderer& r, int width, int height) {
+    std::vector<UniformUpload> out;
+    auto f1 = [&](const char* n, double v) {
+        UniformUpload u;
+        u.name = n;
+        u.type = UniformType::Float1;
+        u.f[0] = (float)v;
+        out.push_back(u);
+    };
+    auto i1 = [&](const char* n, int v) {
+        UniformUpload u;
+        u.name = n;
+        u.type = UniformType::Int1;
+        u.i = v;
+        out.push_back(u);
+    };
+    auto m4 = [&](const char* n, const DMat4& m) {
+        UniformUpload u;
+        u.name = n;
+        u.type = UniformType::Mat4;
+        m.to_f32(u.f);
+        out.push_back(u);
+    };
+    {
+        UniformUpload u;
+        u.name = "_resolution";
+        u.type = UniformType::Float2;
+        u.f[0] = (float)width;
+        u.f[1] = (float)height;
+        out.push_back(u);
+    }
+    DMat4 cam = r.cam.matrix();
+    m4("_camera", cam);
+    m4("_camera_left_eye", DMat4::identity());
+    m4("_camera_right_eye", DMat4::identity());
+    i1("_left_eye_in_subspace", 0);
+    i1("_right_eye_in_subspace", 0);
+    m4("_camera_mul_inv", r.cam.teleport_matrix.inverse());
+    i1("_camera_in_subspace", r.cam.in_subspace ? 1 : 0);
+    f1("_view_angle", r.cam.view_angle);
+    f1("_panini_param", r.cam.panini_param);
+    i1("_use_panini_projection", r.cam.use_panini_projection ? 1 : 0);
+    i1("_use_360_camera", r.cam.use_360_camera ? 1 : 0);
+    i1("_use_180_camera", r.cam.use_180_camera ? 1 : 0);
+    i1("_ray_tracing_depth", r.render_depth);
+    i1("_aa_count", r.aa_count);
+    i1("_aa_start", r.aa_start);
+    i1("_draw_side_by_side", r.draw_side_by_side ? 1 : 0);
+    i1("_draw_anaglyph", 0);
+    f1("_anaglyph_p", r.anaglyph_p);
+    f1("_anaglyph_q", r.anaglyph_q);
+    i1("_anaglyph_mode", 0);
+    i1("_draw_depth_map", r.draw_depth_map ? 1 : 0);
+    f1("_depth_map_min", r.depth_map_min);
+    f1("_depth_map_max", r.depth_map_max);
+    f1("_offset_after_material", r.offset_after_material);
+    f1("_t_start", r.gray_t_start);
+    f1("_t_end", r.gray_t_start + r.gray_t_size);
+    f1("_camera_scale", calc_scale(cam));
+    f1("_left_eye_scale", calc_scale(DMat4::identity()));
+    f1("_right_eye_scale", calc_scale(DMat4::identity()));
+    i1("_angle_color_disable", r.angle_color_disable ? 1 : 0);
+    i1("_grid_disable", r.grid_disable ? 1 : 0);
+    i1("_black_border_disable", r.black_border_disable ? 1 : 0);
+    i1("_darken_by_distance", r.darken_by_distance ? 1 : 0);
+    i1("_teleport_external_ray", 0);
+    return out;
+}
+
+int upload(ptl_kernel* k, const std::vector<UniformUpload>& ups) {
+    for (const UniformUpload& u : ups) {
+        const void* v = u.type == UniformType::Int1 ? (const void*)&u.i : (const void*)u.f;
+        int rc = ptl_kernel_set_uniform(k, u.name.c_str(), to_c_type(u.type), v);
+        if (rc < 0) return rc;  // unknown names are tolerated (macroquad looks names up at upload time)
+    }
+    return PTL_OK;
+}
+
+}  // namespace
+
+// ---- scenes -----------------------------------------------------------------------------------
+extern "C" int ptl_scene_load_file(const char* path, ptl_scene** out) {
+    if (!path || !out) return PTL_ERR_INVALID;
+    return guarded([&] {
+        auto s = std::make_unique<ptl_scene>();
+        s->scene = Scene::from_file(path);
+        *out = s.release();
+        return PTL_OK;
+    });
+}
+extern "C" int ptl_scene_load_text(const char* text, ptl_scene** out) {
+    if (!text || !out) return PTL_ERR_INVALID;
+    return guarded([&] {
+        auto s = std::make_unique<ptl_scene>();
+        s->scene = Scene::from_ron_text(text);
+        *out = s.release();
+        return PTL_OK;
+    });
+}
+extern "C" void ptl_scene_free(ptl_scene* s) { delete s; }
+extern "C" void ptl_free(void* p) { std::free(p); }
+
+extern "C" int ptl_scene_set_uniform(ptl_scene* s, const char* name, double value) {
+    if (!s || !name) return PTL_ERR_INVALID;
+    return s->scene->set_uniform_value(name, value) ? PTL_OK : PTL_UNKNOWN_UNIFORM;
+}
+extern "C" int ptl_scene_set_time(ptl_scene* s, double time, double total_time) {
+    if (!s) return PTL_ERR_INVALID;
+    s->scene->time = time;
+    s->scene->total_time = total_time;
+    return PTL_OK;
+}
+extern "C" int ptl_scene_eval_uniform(ptl_scene* s, const char* name, int* kind, double* value) {
+    if (!s || !name) return PTL_ERR_INVALID;
+    return guarded([&] {
+        auto v = s->scene->eval_uniform(s->scene->find_uniform(name));
+        if (!v) return 1;
+        if (kind) *kind = (int)v->kind;
+        if (value) *value = v->as_f64();
+        return PTL_OK;
+    });
+}
+extern "C" int ptl_scene_eval_matrix(ptl_scene* s, const char* name, double out16[16]) {
+    if (!s || !name || !out16) return PTL_ERR_INVALID;
+    return guarded([&] {
+        auto m = s->scene->eval_matrix(s->scene->find_matrix(name));
+        if (!m) return 1;
+        for (int k = 0; k < 4; ++k) {
+            out16[4 * k + 0] = m->c[k].x;
+            out16[4 * k + 1] = m->c[k].y;
+            out16[4 * k + 2] = m->c[k].z;
+            out16[4 * k + 3] = m->c[k].w;
+        }
+        return PTL_OK;
+    });
+}
+extern "C" int ptl_scene_cam(ptl_scene* s, double out7[7]) {
+    if (!s || !out7) return PTL_ERR_INVALID;
+    const CamSettings& c = s->scene->cam;
+    double v[7] = {c.look_at.x, c.look_at.y, c.look_at.z, c.alpha, c.beta, c.r, c.offset_after_material};
+    std::memcpy(out7, v, sizeof v);
+    return PTL_OK;
+}
+
+static KernelOptions options_from_flags(unsigned flags) {
+    KernelOptions o;
+    o.specialize_ints = (flags & 1u) != 0;
+    o.count_segments = (flags & 2u) != 0;
+    return o;
+}
+
+static void refresh_generated(ptl_scene* s, unsigned flags) {
+    s->last = generate_kernel_source(*s->scene, CodegenFlags{}, options_from_flags(flags));
+    s->desc_names.clear();
+    s->descs.clear();
+    for (auto& u : s->last.uniforms) s->desc_names.push_back(u.name);
+    for (size_t k = 0; k < s->last.uniforms.size(); ++k)
+        s->descs.push_back(ptl_uniform_desc{s->desc_names[k].c_str(), to_c_type(s->last.uniforms[k].type), s->last.uniforms[k].offset});
+}
+
+extern "C" int ptl_scene_generate_source(ptl_scene* s, unsigned flags, char** source) {
+    if (!s || !source) return PTL_ERR_INVALID;
+    return guarded([&] {
+        refresh_generated(s, flags);
+        *source = (char*)std::malloc(s->last.source.size() + 1);
+        std::memcpy(*source, s->last.source.c_str(), s->last.source.size() + 1);
+        return PTL_OK;
+    });
+}
+extern "C" int ptl_scene_uniform_layout(ptl_scene* s, const ptl_uniform_desc** descs, int* n, size_t* block_size) {
+    if (!s) return PTL_ERR_INVALID;
+    return guarded([&] {
+        if (s->last.source.empty()) refresh_generated(s, 0);
+        if (descs) *descs = s->descs.data();
+        if (n) *n = (int)s->descs.size();
+        if (block_size) *block_size = s->last.uniform_block_size;
+        return PTL_OK;
+    });
+}
+extern "C" int ptl_scene_set_uniforms(ptl_scene* s, ptl_kernel* k) {
+    if (!s || !k) return PTL_ERR_INVALID;
+    return guarded([&] {
+        std::vector<std::string> errors;
+        int rc = upload(k, evaluate_scene_uniforms(*s->scene, &errors));
+        if (!errors.empty()) set_last_error(errors[0]);
+        return rc;
+    });
+}
+extern "C" int ptl_scene_visit_uniforms(ptl_scene* s, ptl_uniform_cb cb, void* user) {
+    if (!s || !cb) return PTL_ERR_INVALID;
+    return guarded([&] {
+        for (const UniformUpload& u : evaluate_scene_uniforms(*s->scene, nullptr))
+            cb(user, u.name.c_str(), to_c_type(u.type), u.type == UniformType::Int1 ? (const void*)&u.i : (const void*)u.f);
+        return PTL_OK;
+    });
+}
+extern "C" int ptl_scene_source_line_owner(ptl_scene* s, int line, char* kind, size_t kind_cap, char* name, size_t name_cap, int* local_line) {
+    if (!s) return PTL_ERR_INVALID;
+    ElementKey key;
+    int local = 0;
+    if (!s->last.line_numbers.get_identifier(line, &key, &local)) return 1;
+    copy_str(kind, kind_cap, key.kind);
+    copy_str(name, name_cap, key.name);
+    if (local_line) *local_line = local;
+    return PTL_OK;
+}
+
+// ---- renderer ---------------------------------------------------------------------------------
+extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_root, unsigned flags, ptl_renderer** out, char* log,
+                                   size_t log_cap) {
+    if (!s || !out) return PTL_ERR_INVALID;
+    if (log && log_cap) log[0] = '\0';
+    return guarded([&] {
+        auto r = std::make_unique<ptl_renderer>();
+        r->owner = s;
+        r->scene = s->scene;
+        refresh_generated(s, flags);
+        std::vector<const char*> defines;
+        for (auto& d : s->last.defines) defines.push_back(d.c_str());
+        int rc = ptl_kernel_compile(device, s->last.source.c_str(), s->descs.data(), (int)s->descs.size(), s->last.uniform_block_size, defines.data(),
+                                    (int)defines.size(), &r->kernel, log, log_cap);
+        if (rc != PTL_OK) return rc;
+        // cam.set_cam(scene.cam); offset_after_material from the scene (main.rs:1057-1059)
+        const CamSettings& c = s->scene->cam;
+        r->cam.look_at = c.look_at;
+        r->cam.alpha = c.alpha;
+        r->cam.beta = c.beta;
+        r->cam.r = c.r;
+        r->offset_after_material = c.offset_after_material;
+        // reload_textures (main.rs:1066-1083)
+        if (device >= 0) {
+            for (const Texture& t : s->scene->textures) {
+                std::string path = (asset_root && *asset_root) ? std::string(asset_root) + "/" + t.path : t.path;
+                uint8_t* px = nullptr;
+                int w = 0, h = 0;
+                int prc = ptl_png_read(path.c_str(), &px, &w, &h);
+                if (prc != PTL_OK) {
+                    ptl_kernel_destroy(r->kernel);
+                    return PTL_ERR_SCENE;
+                }
+                int trc = ptl_kernel_set_texture(r->kernel, (t.name + "_tex").c_str(), px, w, h);
+                std::free(px);
+                if (trc < 0) {
+                    ptl_kernel_destroy(r->kernel);
+                    return trc;
+                }
+            }
+        }
+        *out = r.release();
+        return PTL_OK;
+    });
+}
+
+extern "C" int ptl_renderer_set_option(ptl_renderer* r, const char* name, double v) {
+    if (!r || !name) return PTL_ERR_INVALID;
+    std::string n = name;
+    bool b = v > 0.5;
+    if (n == "render_depth") r->render_depth = (int)v;
+    else if (n == "aa_count") r->aa_count = (int)v;
+    else if (n == "aa_start") r->aa_start = (int)v;
+    else if (n == "view_angle") r->cam.view_angle = v;
+    else if (n == "use_panini_projection") r->cam.use_panini_projection = b;
+    else if (n == "panini_param") r->cam.panini_param = v;
+    else if (n == "use_360_camera") r->cam.use_360_camera = b;
+    else if (n == "use_180_camera") r->cam.use_180_camera = b;
+    else if (n == "darken_by_distance") r->darken_by_distance = b;
+    else if (n == "gray_t_start") r->gray_t_start = v;
+    else if (n == "gray_t_size") r->gray_t_size = v;
+    else if (n == "draw_depth_map") r->draw_depth_map = b;
+    else if (n == "depth_map_min") r->depth_map_min = v;
+    else if (n == "depth_map_max") r->depth_map_max = v;
+    else if (n == "angle_color_disable") r->angle_color_disable = b;
+    else if (n == "grid_disable") r->grid_disable = b;
+    else if (n == "black_border_disable") r->black_border_disable = b;
+    else if (n == "offset_after_material") r->offset_after_material = v;
+    else if (n == "draw_side_by_side") r->draw_side_by_side = b;
+    else if (n == "in_subspace") r->cam.in_subspace = b;
+    else return PTL_UNKNOWN_UNIFORM;
+    return PTL_OK;
+}
+
+extern "C" int ptl_renderer_set_camera(ptl_renderer* r, const double look_at[3], double alpha, double beta, double radius) {
+    if (!r || !look_at) return PTL_ERR_INVALID;
+    r->cam.look_at = DVec3(look_at[0], look_at[1], look_at[2]);
+    r->cam.alpha = alpha;
+    r->cam.beta = beta;
+    r->cam.r = radius;
+    return PTL_OK;
+}
+
+extern "C" int ptl_renderer_uniform_value(ptl_renderer* r, int width, int height, const char* name, float out16[16], int* n_values) {
+    if (!r || !name || !out16) return PTL_ERR_INVALID;
+    return guarded([&] {
+        auto all = builtin_uniforms(*r, width, height);
+        auto scene_vals = evaluate_scene_uniforms(*r->scene, nullptr);
+        all.insert(all.end(), scene_vals.begin(), scene_vals.end());
+        for (const UniformUpload& u : all) {
+            if (u.name != name) continue;
+            int n = u.type == UniformType::Mat4 ? 16 : u.type == UniformType::Float2 ? 2 : u.type == UniformType::Float3 ? 3 : 1;
+            if (u.type == UniformType::Int1) out16[0] = (float)u.i;
+            else std::memcpy(out16, u.f, sizeof(float) * n);
+            if (n_values) *n_values = n;
+            return PTL_OK;
+        }
+        return (int)PTL_UNKNOWN_UNIFORM;
+    });
+}
+
+static int prepare_draw(ptl_renderer* r, const ptl_frame* frame) {
+    std::vector<std::string> errors;
+    int rc = upload(r->kernel, evaluate_scene_uniforms(*r->scene, &errors));  // scene.set_uniforms
+    if (rc < 0) return rc;
+    return upload(r->kernel, builtin_uniforms(*r, frame->width, frame->height));  // self.set_uniforms(w, h)
+}
+
+extern "C" int ptl_renderer_draw(ptl_renderer* r, const ptl_frame* frame, void* out_rgba8, void* out_rgba32f, void* segments, void* stream,
+                                 float* elapsed_ms) {
+    if (!r || !frame) return PTL_ERR_INVALID;
+    return guarded([&] {
+        int rc = prepare_draw(r, frame);
+        if (rc < 0) return rc;
+        return ptl_kernel_render(r->kernel, frame, out_rgba8, out_rgba32f, segments, stream, elapsed_ms);
+    });
+}
+extern "C" int ptl_renderer_draw_to_host(ptl_renderer* r, const ptl_frame* frame, uint8_t* host_rgba8, float* host_rgba32f,
+                                         uint64_t* host_segments, float* elapsed_ms) {
+    if (!r || !frame) return PTL_ERR_INVALID;
+    return guarded([&] {
+        int rc = prepare_draw(r, frame);
+        if (rc < 0) return rc;
+        return ptl_kernel_render_to_host(r->kernel, frame, host_rgba8, host_rgba32f, host_segments, elapsed_ms);
+    });
+}
+extern "C" ptl_kernel* ptl_renderer_kernel(ptl_renderer* r) { return r ? r->kernel : nullptr; }
+extern "C" void ptl_renderer_destroy(ptl_renderer* r) {
+    if (!r) return;
+    ptl_kernel_destroy(r->kernel);
+    delete r;
+}
+
+// ---- template engine hooks ----------------------------------------------------------------------
+struct ptl_strstore {
+    StringStorage s;
+};
+extern "C" ptl_strstore* ptl_strstore_new(void) { return new ptl_strstore(); }
+extern "C" void ptl_strstore_free(ptl_strstore* s) { delete s; }
+extern "C" void ptl_strstore_add_string(ptl_strstore* s, const char* text) {
+    if (s && text) s->s.add_string(text);
+}
+extern "C" void ptl_strstore_add_identifier_string(ptl_strstore* s, const char* kind, const char* name, const char* text) {
+    if (s && kind && name && text) s->s.add_identifier_string({kind, name}, text);
+}
+extern "C" ptl_strstore* ptl_apply_template(const char* tmpl, const char* const* slot_names, ptl_strstore* const* storages, int n) {
+    std::map<std::string, StringStorage> m;
+    for (int k = 0; k < n; ++k) {
+        m[slot_names[k]] = std::move(storages[k]->s);
+        delete storages[k];
+    }
+    try {
+        auto* out = new ptl_strstore();
+        out->s = apply_template(tmpl, std::move(m));
+        return out;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return nullptr;
+    }
+}
+extern "C" const char* ptl_strstore_text(const ptl_strstore* s) { return s ? s->s.storage.c_str() : ""; }
+extern "C" int ptl_strstore_current_line(const ptl_strstore* s) { return s ? s->s.current_line_no : 0; }
+extern "C" int ptl_strstore_range(const ptl_strstore* s, const char* kind, const char* name, int* start, int* end) {
+    if (!s) return PTL_ERR_INVALID;
+    auto it = s->s.line_numbers.ranges.find(ElementKey{kind, name});
+    if (it == s->s.line_numbers.ranges.end()) return 1;
+    if (start) *start = it->second.start;
+    if (end) *end = it->second.end;
+    return PTL_OK;
+}
+extern "C" int ptl_strstore_get_identifier(const ptl_strstore* s, int line, char* kind, size_t kind_cap, char* name, size_t name_cap,
+                                           int* local_line) {
+    if (!s) return PTL_ERR_INVALID;
+    ElementKey key;
+    int local = 0;
+    if (!s->s.line_numbers.get_identifier(line, &key, &local)) return 1;
+    copy_str(kind, kind_cap, key.kind);
+    copy_str(name, name_cap, key.name);
+    if (local_line) *local_line = local;
+    return PTL_OK;
+}
+
+extern "C" char* ptl_translate_glsl(const char* glsl) {
+    if (!glsl) return nullptr;
+    std::string out = translate_glsl(glsl);
+    char* p = (char*)std::malloc(out.size() + 1);
+    std::memcpy(p, out.c_str(), out.size() + 1);
+    return p;
+}
+
+extern "C" int ptl_formula_eval(const char* text, const char* const* names, const double* values, int n, double time, double* out) {
+    if (!text || !out) return PTL_ERR_INVALID;
+    std::string err;
+    auto f = Formula::compile(text, &err);
+    if (!f) {
+        set_last_error(err);
+        return 1;
+    }
+    FormulaNamespace ns = [&](const std::string& name, const std::vector<double>& args) -> std::optional<double> {
+        bool known = false;
+        auto r = formula_custom_function(name, args, &known);
+        if (known) return r;
+        if (name == "time" || name == "total_time") return time;
+        for (int k = 0; k < n; ++k)
+            if (name == names[k]) return values[k];
+        return std::nullopt;
+    };
+    auto v = f->eval(ns);
+    if (!v) return 1;
+    *out = *v;
+    return PTL_OK;
+}

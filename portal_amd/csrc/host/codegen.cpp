@@ -1,0 +1,534 @@
+// codegen.cpp -- see codegen.h.
+#include "codegen.h"
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <set>
+#include <sstream>
+
+namespace ptl {
+
+// ------------------------------------------------------------------------------------------
+// template engine (src/code_generation.rs)
+// ------------------------------------------------------------------------------------------
+void LineNumbersByKey::offset(int lines) {
+    for (auto& kv : ranges) {
+        kv.second.start += lines;
+        kv.second.end += lines;
+    }
+}
+void LineNumbersByKey::add(const ElementKey& key, LineRange r) {
+    if (ranges.count(key)) throw std::logic_error("LineNumbersByKey: duplicate key " + key.kind + ":" + key.name);
+    ranges[key] = r;
+}
+void LineNumbersByKey::extend(const LineNumbersByKey& other) {
+    for (auto& kv : other.ranges) add(kv.first, kv.second);
+}
+bool LineNumbersByKey::get_identifier(int line_no, ElementKey* key, int* local_line) const {
+    for (auto& kv : ranges) {
+        if (line_no >= kv.second.start && line_no < kv.second.end) {
+            if (key) *key = kv.first;
+            if (local_line) *local_line = line_no - kv.second.start + 1;
+            return true;
+        }
+    }
+    return false;
+}
+
+void StringStorage::add_string(const std::string& s) {
+    current_line_no += (int)std::count(s.begin(), s.end(), '\n');
+    storage += s;
+}
+void StringStorage::add_identifier_string(const ElementKey& id, const std::string& s) {
+    int start = current_line_no;
+    add_string(s);
+    line_numbers.add(id, LineRange{start, current_line_no + 1});
+}
+void StringStorage::add_string_storage(StringStorage other) {
+    other.line_numbers.offset(current_line_no - 1);
+    add_string(other.storage);
+    line_numbers.extend(other.line_numbers);
+}
+
+StringStorage apply_template(const std::string& tmpl, std::map<std::string, StringStorage> storages) {
+    StringStorage result;
+    size_t pos = 0;
+    bool is_name = false;
+    for (;;) {
+        size_t next = tmpl.find("//%", pos);
+        std::string piece = tmpl.substr(pos, next == std::string::npos ? std::string::npos : next - pos);
+        if (is_name) {
+            auto it = storages.find(piece);
+            if (it == storages.end()) throw std::logic_error("apply_template: no storage for slot `" + piece + "`");
+            result.add_string_storage(std::move(it->second));
+            storages.erase(it);
+        } else {
+            result.add_string(piece);
+        }
+        if (next == std::string::npos) break;
+        pos = next + 3;
+        is_name = !is_name;
+    }
+    return result;
+}
+
+// ------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------
+std::string format_lower_exp(double v) {
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
+    char buf[64];
+    auto res = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::scientific);
+    std::string s(buf, res.ptr);  // d.ddde[+-]XX
+    size_t e = s.find('e');
+    std::string mant = s.substr(0, e), exp = s.substr(e + 1);
+    bool neg = !exp.empty() && exp[0] == '-';
+    if (!exp.empty() && (exp[0] == '-' || exp[0] == '+')) exp.erase(0, 1);
+    while (exp.size() > 1 && exp[0] == '0') exp.erase(0, 1);
+    return mant + "e" + (neg ? "-" : "") + exp;
+}
+
+size_t uniform_type_size(UniformType t) {
+    switch (t) {
+        case UniformType::Mat4: return 64;
+        case UniformType::Float1: return 4;
+        case UniformType::Int1: return 4;
+        case UniformType::Float2: return 8;
+        case UniformType::Float3: return 12;
+        case UniformType::Sampler: return 16;
+    }
+    return 0;
+}
+
+namespace {
+
+const char* cxx_type(UniformType t) {
+    switch (t) {
+        case UniformType::Mat4: return "mat4";
+        case UniformType::Float1: return "float";
+        case UniformType::Int1: return "int";
+        case UniformType::Float2: return "vec2";
+        case UniformType::Float3: return "vec3";
+        case UniformType::Sampler: return "sampler2D";
+    }
+    return "?";
+}
+
+const std::string& matrix_name(const Scene& s, int idx, const Object& o) {
+    if (idx < 0 || idx >= (int)s.matrices.size()) throw SceneError("object `" + o.name + "` refers to no matrix");
+    return s.matrices[idx].name;
+}
+std::string normal_name(const std::string& m) { return m + "_mat"; }
+std::string inverse_name(const std::string& m) { return m + "_mat_inv"; }
+std::string teleport_name(const std::string& from, const std::string& to) { return from + "_to_" + to + "_mat_teleport"; }
+
+std::string f32_literal(double v) { return format_lower_exp(v) + "f"; }
+const char* bool_lit(bool b) { return b ? "true" : "false"; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// uniforms (scene.rs:424-543)
+// ------------------------------------------------------------------------------------------
+std::vector<std::string> scene_texture_list(const Scene& scene) {
+    std::set<std::string> names;
+    for (auto& t : scene.textures) names.insert(t.name);
+    std::vector<std::string> out;
+    for (auto& n : names) out.push_back(n + "_tex");
+    return out;
+}
+
+std::vector<UniformDesc> scene_uniform_list(const Scene& scene) {
+    std::set<std::string> mats;  // BTreeSet: sorted, unique
+    for (const Object& o : scene.objects) {
+        if (o.kind == Object::DebugMatrix || !o.portal) {
+            const std::string& m = matrix_name(scene, o.m0, o);
+            mats.insert(normal_name(m));
+            mats.insert(inverse_name(m));
+        } else {
+            const std::string& a = matrix_name(scene, o.m0, o);
+            const std::string& b = matrix_name(scene, o.m1, o);
+            mats.insert(normal_name(a));
+            mats.insert(inverse_name(a));
+            mats.insert(normal_name(b));
+            mats.insert(inverse_name(b));
+            mats.insert(teleport_name(a, b));
+            if (a != b) mats.insert(teleport_name(b, a));
+        }
+    }
+    for (const MatrixEntry& m : scene.matrices) {
+        if (!m.named) continue;
+        mats.insert(normal_name(m.name));
+        mats.insert(inverse_name(m.name));
+    }
+    std::vector<UniformDesc> out;
+    for (auto& n : mats) out.push_back({n, UniformType::Mat4, 0});
+    for (size_t k = 0; k < scene.uniforms.size(); ++k) {
+        const UniformEntry& u = scene.uniforms[k];
+        if (u.name.empty()) continue;  // inline uniforms are not visible
+        auto v = scene.eval_uniform((int)k);
+        if (!v) continue;
+        out.push_back({u.name + "_u", v->kind == UniformValue::Float ? UniformType::Float1 : UniformType::Int1, 0});
+    }
+    static const std::pair<const char*, UniformType> builtins[] = {
+        {"_camera", UniformType::Mat4},
+        {"_camera_left_eye", UniformType::Mat4},
+        {"_camera_right_eye", UniformType::Mat4},
+        {"_camera_mul_inv", UniformType::Mat4},
+        {"_camera_in_subspace", UniformType::Int1},
+        {"_left_eye_in_subspace", UniformType::Int1},
+        {"_right_eye_in_subspace", UniformType::Int1},
+        {"_resolution", UniformType::Float2},
+        {"_ray_tracing_depth", UniformType::Int1},
+        {"_aa_count", UniformType::Int1},
+        {"_aa_start", UniformType::Int1},
+        {"_draw_side_by_side", UniformType::Int1},
+        {"_offset_after_material", UniformType::Float1},
+        {"_draw_anaglyph", UniformType::Int1},
+        {"_anaglyph_p", UniformType::Float1},
+        {"_anaglyph_q", UniformType::Float1},
+        {"_anaglyph_mode", UniformType::Int1},
+        {"_draw_depth_map", UniformType::Int1},
+        {"_depth_map_min", UniformType::Float1},
+        {"_depth_map_max", UniformType::Float1},
+        {"_camera_scale", UniformType::Float1},
+        {"_left_eye_scale", UniformType::Float1},
+        {"_right_eye_scale", UniformType::Float1},
+        {"_t_start", UniformType::Float1},
+        {"_t_end", UniformType::Float1},
+        {"_view_angle", UniformType::Float1},
+        {"_use_panini_projection", UniformType::Int1},
+        {"_use_360_camera", UniformType::Int1},
+        {"_use_180_camera", UniformType::Int1},
+        {"_angle_color_disable", UniformType::Int1},
+        {"_darken_by_distance", UniformType::Int1},
+        {"_grid_disable", UniformType::Int1},
+        {"_black_border_disable", UniformType::Int1},
+        {"_panini_param", UniformType::Float1},
+        {"_teleport_external_ray", UniformType::Int1},
+        {"_external_ray_a", UniformType::Float3},
+        {"_external_ray_b", UniformType::Float3},
+    };
+    for (auto& b : builtins) out.push_back({b.first, b.second, 0});
+    return out;
+}
+
+std::vector<UniformUpload> evaluate_scene_uniforms(const Scene& scene, std::vector<std::string>* errors) {
+    std::vector<UniformUpload> out;
+    auto put_mat = [&](const std::string& name, const DMat4& m) {
+        UniformUpload u;
+        u.name = name;
+        u.type = UniformType::Mat4;
+        m.to_f32(u.f);
+        out.push_back(u);
+    };
+    // matrices used by objects, then all named matrices (scene.rs:551-592)
+    std::vector<int> passed;
+    for (const Object& o : scene.objects) {
+        if (o.m0 >= 0) passed.push_back(o.m0);
+        if (o.kind != Object::DebugMatrix && o.portal && o.m1 >= 0) passed.push_back(o.m1);
+    }
+    for (size_t k = 0; k < scene.matrices.size(); ++k)
+        if (scene.matrices[k].named) passed.push_back((int)k);
+    for (int idx : passed) {
+        const std::string& name = scene.matrices[idx].name;
+        auto m = scene.eval_matrix(idx);
+        if (m) {
+            put_mat(normal_name(name), *m);
+            put_mat(inverse_name(name), m->inverse());
+        } else if (errors) {
+            errors->push_back("matrix `" + name + "` can't be getted");
+        }
+    }
+    // teleport matrices (scene.rs:594-635)
+    for (const Object& o : scene.objects) {
+        if (o.kind == Object::DebugMatrix || !o.portal || o.m0 < 0 || o.m1 < 0) continue;
+        auto a = scene.eval_matrix(o.m0);
+        auto b = scene.eval_matrix(o.m1);
+        if (!a || !b) continue;
+        const std::string& na = scene.matrices[o.m0].name;
+        const std::string& nb = scene.matrices[o.m1].name;
+        put_mat(teleport_name(na, nb), *b * a->inverse());
+        if (na != nb) put_mat(teleport_name(nb, na), *a * b->inverse());
+    }
+    // user uniforms (scene.rs:637-656)
+    for (size_t k = 0; k < scene.uniforms.size(); ++k) {
+        const UniformEntry& e = scene.uniforms[k];
+        if (e.name.empty()) continue;
+        auto v = scene.eval_uniform((int)k);
+        if (!v) {
+            if (errors && e.value.kind != Uniform::Trefoil) errors->push_back("Error getting `" + e.name + "` uniform");
+            continue;
+        }
+        UniformUpload u;
+        u.name = e.name + "_u";
+        if (v->kind == UniformValue::Float) {
+            u.type = UniformType::Float1;
+            u.f[0] = (float)v->f;
+        } else {
+            u.type = UniformType::Int1;
+            u.i = v->kind == UniformValue::Bool ? (v->b ? 1 : 0) : v->i;
+        }
+        out.push_back(u);
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------
+// slot generators (scene.rs:693-1063)
+// ------------------------------------------------------------------------------------------
+namespace {
+
+std::string snippet(const std::string& glsl, const CodegenFlags& flags) { return translate_glsl(filter_tagged_lines(glsl, flags)); }
+
+struct PortalMaterialNames {
+    int pos;
+    std::string a, b;
+};
+
+}  // namespace
+
+GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& flags, const KernelOptions& opts) {
+    GeneratedKernel gk;
+    std::map<std::string, StringStorage> storages;
+
+    // --- uniform block --------------------------------------------------------------------
+    {
+        std::vector<UniformDesc> list;
+        for (auto& tex : scene_texture_list(scene)) list.push_back({tex, UniformType::Sampler, 0});
+        for (auto& u : scene_uniform_list(scene)) list.push_back(u);
+        size_t off = 0;
+        for (auto& u : list) {
+            u.offset = off;
+            off += uniform_type_size(u.type);
+        }
+        gk.uniform_block_size = (off + 7) & ~(size_t)7;
+        gk.uniforms = list;
+
+        StringStorage s;
+        s.add_string("struct ptl_uniform_block {\n");
+        for (auto& u : list) s.add_string(std::string("    ") + cxx_type(u.type) + " " + u.name + ";\n");
+        s.add_string("};\n");
+        s.add_string("#if PTL_DEVICE_BUILD\n__constant__ ptl_uniform_block ptl_u;\n#else\nptl_uniform_block ptl_u;\n#endif\n");
+        for (auto& u : list)
+            s.add_string("static_assert(__builtin_offsetof(ptl_uniform_block, " + u.name + ") == " + std::to_string(u.offset) + ", \"uniform layout\");\n");
+        std::map<std::string, int> baked;
+        if (opts.specialize_ints) {
+            for (auto& up : evaluate_scene_uniforms(scene, nullptr))
+                if (up.type == UniformType::Int1) baked[up.name] = up.i;
+        }
+        for (auto& u : list) {
+            auto it = baked.find(u.name);
+            if (it != baked.end()) s.add_string("#define " + u.name + " (" + std::to_string(it->second) + ")\n");
+            else s.add_string("#define " + u.name + " (ptl_u." + u.name + ")\n");
+        }
+        storages["uniforms"] = std::move(s);
+    }
+
+    // --- materials (scene.rs:720-845) -----------------------------------------------------
+    {
+        StringStorage processing, defines;
+        int counter = 0;
+        for (const Material& m : scene.materials) {
+            std::string name_m = m.name + "_M";
+            defines.add_string("#define " + name_m + " (USER_MATERIAL_OFFSET + " + std::to_string(counter++) + ")\n");
+            processing.add_string("} else if (i.material == " + name_m + ") {\n");
+            switch (m.kind) {
+                case Material::Simple:
+                    processing.add_string("return material_simple2(hit, r, vec3(" + f32_literal(m.color[0]) + ", " + f32_literal(m.color[1]) + ", " +
+                                          f32_literal(m.color[2]) + "), " + f32_literal(m.normal_coef) + ", " + bool_lit(m.grid) + ", " +
+                                          f32_literal(m.grid_scale) + ", " + f32_literal(m.grid_coef) + ", " + bool_lit(m.grid2) + ", " + bool_lit(m.grid3) + ");\n");
+                    break;
+                case Material::Reflect:
+                    processing.add_string("return material_reflect(hit, r, vec3(" + f32_literal(m.color[0]) + ", " + f32_literal(m.color[1]) + ", " +
+                                          f32_literal(m.color[2]) + "));\n");
+                    break;
+                case Material::Refract:
+                    processing.add_string("return material_refract(hit, r, vec3(" + f32_literal(m.color[0]) + ", " + f32_literal(m.color[1]) + ", " +
+                                          f32_literal(m.color[2]) + "), " + f32_literal(m.refractive_index) + ");\n");
+                    break;
+                case Material::Complex:
+                    processing.add_identifier_string({"material", m.name}, snippet(m.code, flags));
+                    processing.add_string("\n");
+                    break;
+            }
+        }
+        for (size_t pos = 0; pos < scene.objects.size(); ++pos) {
+            const Object& o = scene.objects[pos];
+            if (o.kind == Object::DebugMatrix || !o.portal) continue;
+            if (o.m0 < 0 || o.m1 < 0) continue;
+            const std::string& a = matrix_name(scene, o.m0, o);
+            const std::string& b = matrix_name(scene, o.m1, o);
+            std::string m1 = "teleport_" + std::to_string(pos) + "_1_M", m2 = "teleport_" + std::to_string(pos) + "_2_M";
+            defines.add_string("#define " + m1 + " (USER_MATERIAL_OFFSET + " + std::to_string(counter++) + ")\n");
+            defines.add_string("#define " + m2 + " (USER_MATERIAL_OFFSET + " + std::to_string(counter++) + ")\n");
+            processing.add_string("} else if (i.material == " + m1 + ") {\n");
+            processing.add_string("return material_teleport(hit, r, " + teleport_name(a, b) + ");");
+            processing.add_string("} else if (i.material == " + m2 + ") {\n");
+            processing.add_string("return material_teleport(hit, r, " + teleport_name(b, a) + ");");
+        }
+        storages["material_processing"] = std::move(processing);
+        storages["materials_defines"] = std::move(defines);
+    }
+
+    // --- is_inside_N / intersect_N (scene.rs:847-883) --------------------------------------
+    {
+        StringStorage s;
+        for (size_t pos = 0; pos < scene.objects.size(); ++pos) {
+            const Object& o = scene.objects[pos];
+            std::string p = std::to_string(pos);
+            if (o.kind == Object::Flat) {
+                if (o.portal) s.add_string("PTL_FN int is_inside_" + p + "(vec4 pos, float x, float y, bool back, bool first) {\n");
+                else s.add_string("PTL_FN int is_inside_" + p + "(vec4 pos, float x, float y, bool back) {\n");
+                s.add_identifier_string({"object", o.name}, snippet(o.code, flags));
+                s.add_string("\n}\n");
+            } else if (o.kind == Object::Complex) {
+                if (o.portal) s.add_string("PTL_FN SceneIntersection intersect_" + p + "(Ray r, bool first) {\n");
+                else s.add_string("PTL_FN SceneIntersection intersect_" + p + "(Ray r) {\n");
+                s.add_identifier_string({"object", o.name}, snippet(o.code, flags));
+                s.add_string("\n}\n");
+            }
+        }
+        storages["intersection_functions"] = std::move(s);
+    }
+
+    // --- per-object intersection statements (scene.rs:885-1009) ----------------------------
+    {
+        StringStorage s;
+        for (size_t pos = 0; pos < scene.objects.size(); ++pos) {
+            const Object& o = scene.objects[pos];
+            std::string p = std::to_string(pos);
+            auto open_guard = [&] {
+                if (o.in_subspace == Subspace::Normal) s.add_string("if (r.in_subspace == false) {");
+                else if (o.in_subspace == Subspace::Subspace) s.add_string("if (r.in_subspace == true) {");
+            };
+            auto close_guard = [&] {
+                if (o.in_subspace != Subspace::Both) s.add_string("}");
+            };
+            auto transformed = [&](const std::string& inv) {
+                s.add_string("transformed_ray = transform(" + inv + ", r);\nlen = length(transformed_ray.d);\ntransformed_ray = normalize_ray(transformed_ray);");
+            };
+            if (o.kind == Object::DebugMatrix) {
+                const std::string& m = matrix_name(scene, o.m0, o);
+                transformed(inverse_name(m));
+                s.add_string("ihit = debug_intersect(transformed_ray);\nihit.hit.t /= len;\n");
+                // quirk kept from the reference: the normal uses adjugate of the *inverse* matrix here
+                s.add_string("if (nearer(i, ihit)) { i = ihit; i.hit.n = normalize(adjugate(" + inverse_name(m) + ") * i.hit.n); }\n\n");
+            } else if (o.kind == Object::Flat) {
+                open_guard();
+                if (!o.portal) {
+                    const std::string& m = matrix_name(scene, o.m0, o);
+                    s.add_string("normal = -get_normal(" + normal_name(m) + ");\n");
+                    s.add_string("hit = plane_intersect(r, " + inverse_name(m) + ", get_normal(" + normal_name(m) + "));\n");
+                    s.add_string("if (nearer(i, hit)) { i = process_plane_intersection(i, hit, is_inside_" + p +
+                                 "(r.o + r.d * hit.t, hit.u, hit.v, is_collinear(hit.n, normal))); }\n\n");
+                } else {
+                    auto side = [&](const std::string& m, bool first, const std::string& material) {
+                        s.add_string(std::string("normal = ") + (first ? "-" : "") + "get_normal(" + normal_name(m) + ");\n");
+                        s.add_string("hit = plane_intersect(r, " + inverse_name(m) + ", normal);\n");
+                        s.add_string("if (nearer(i, hit)) { i = process_portal_intersection(i, hit, is_inside_" + p +
+                                     "(r.o + r.d * hit.t, hit.u, hit.v, is_collinear(hit.n, normal), " + bool_lit(first) + "), " + material + "); }\n\n");
+                    };
+                    const std::string& a = matrix_name(scene, o.m0, o);
+                    const std::string& b = matrix_name(scene, o.m1, o);
+                    side(a, true, "teleport_" + p + "_1_M");
+                    side(b, false, "teleport_" + p + "_2_M");
+                }
+                close_guard();
+            } else {  // Complex
+                open_guard();
+                if (!o.portal) {
+                    const std::string& m = matrix_name(scene, o.m0, o);
+                    transformed(inverse_name(m));
+                    s.add_string("ihit = intersect_" + p + "(transformed_ray);\nihit.hit.t /= len;\n");
+                    s.add_string("if (nearer(i, ihit)) { i = ihit; i.hit.n = normalize(adjugate(" + normal_name(m) + ") * i.hit.n); }\n\n");
+                } else {
+                    auto side = [&](const std::string& m, bool first, const std::string& material) {
+                        transformed(inverse_name(m));
+                        s.add_string("ihit = intersect_" + p + "(transformed_ray, " + bool_lit(first) + ");\nihit.hit.t /= len;\n");
+                        s.add_string("if (nearer(i, ihit) && ihit.material != NOT_INSIDE) { if (ihit.material == TELEPORT) { ihit.material = " + material +
+                                     "; } if (ihit.material == TELEPORT_SUBSPACE) { ihit.material = " + material +
+                                     "; ihit.in_subspace = true; } i = ihit; i.hit.n = normalize(adjugate(" + normal_name(m) + ") * i.hit.n); }\n\n");
+                    };
+                    const std::string& a = matrix_name(scene, o.m0, o);
+                    const std::string& b = matrix_name(scene, o.m1, o);
+                    side(a, true, "teleport_" + p + "_1_M");
+                    side(b, false, "teleport_" + p + "_2_M");
+                }
+                close_guard();
+            }
+            s.add_string("\n");
+        }
+        storages["intersections"] = std::move(s);
+    }
+
+    // --- intersection materials (scene.rs:1011-1035) --------------------------------------
+    {
+        StringStorage fns, calls;
+        for (size_t pos = 0; pos < scene.intersection_materials.size(); ++pos) {
+            const NamedCode& im = scene.intersection_materials[pos];
+            fns.add_string("PTL_FN SceneIntersectionWithMaterial intersect_material_" + std::to_string(pos) + "(Ray r) {\n");
+            fns.add_identifier_string({"intersection_material", im.name}, snippet(im.code, flags));
+            fns.add_string("\n}\n");
+            calls.add_string("hit = intersect_material_" + std::to_string(pos) + "(r);\n");
+            calls.add_string("if (nearer(result.scene.hit, hit.scene.hit)) { result = hit; }\n\n");
+        }
+        storages["intersection_material_functions"] = std::move(fns);
+        storages["intersection_material_processing"] = std::move(calls);
+    }
+
+    // --- library (scene.rs:1037-1044) -----------------------------------------------------
+    {
+        StringStorage s;
+        for (const NamedCode& lib : scene.library) {
+            // scene functions are plain GLSL functions: give them the device attribute by defining
+            // them inside a PTL_FN-aware region (see ptl_scene_fn below)
+            s.add_identifier_string({"library", lib.name}, snippet(lib.code, flags));
+        }
+        storages["library"] = std::move(s);
+    }
+
+    // --- prelude + skybox -----------------------------------------------------------------
+    {
+        StringStorage s;
+        s.add_string(device_source_glsl());
+        s.add_string("\n");
+        storages["predefined_library"] = std::move(s);
+    }
+    {
+        StringStorage s;
+        if (scene.skybox) {
+            s.add_string("vec4 rd2 = _camera_mul_inv * r.d;");
+            s.add_string("float u = atan(rd2.z, rd2.x);");
+            s.add_string("float v = atan(sqrt(rd2.x * rd2.x + rd2.z * rd2.z), rd2.y);");
+            s.add_string("vec3 not_found_color = sqrvec(texture(" + *scene.skybox + "_tex, vec2((u/PI+1.0f)/2.0f, v/PI)).sw<0,1,2>());");
+        } else {
+            s.add_string("vec3 not_found_color = color(0.6f, 0.6f, 0.6f);");
+        }
+        storages["skybox_processing"] = std::move(s);
+    }
+
+    // The prelude needs the uniform accessors, so the library header goes after the uniform
+    // block: splice it at the head of the `materials_defines` slot (order in the reference:
+    // predefined library -> uniforms -> textures -> material defines -> library -> ...).
+    {
+        StringStorage s;
+        s.add_string("}  // namespace glsl\n");
+        s.add_string(device_source_library());
+        s.add_string("\nnamespace glsl {\n");
+        s.add_string_storage(std::move(storages["materials_defines"]));
+        storages["materials_defines"] = std::move(s);
+    }
+
+    StringStorage body = apply_template(device_source_trace_template(), std::move(storages));
+    body.add_string("\n");
+    body.add_string(device_source_entry());
+    gk.source = std::move(body.storage);
+    gk.line_numbers = std::move(body.line_numbers);
+    if (opts.count_segments) gk.defines.push_back("PTL_COUNT_SEGMENTS");
+    return gk;
+}
+
+}  // namespace ptl

@@ -1,0 +1,103 @@
+// codegen.h -- scene -> HIP C++ kernel source.
+//
+// Host-side mirror of the reference's L3 "scene -> kernel codegen":
+//   StringStorage / LineNumbersByKey / apply_template   src/code_generation.rs:10-98
+//   Scene::uniforms, generate_uniforms_declarations      src/gui/scene.rs:424-543, 661-691
+//   Scene::generate_shader_code (slot generators)        src/gui/scene.rs:693-1110
+// The reference emits GLSL for the GL driver; this emits one self-contained HIP C++
+// translation unit (device/ptl_glsl.h + ptl_library.h + filled ptl_trace.tpl + ptl_entry.h)
+// for hiprtc, which the host build (oracle/host_build) compiles unchanged with g++.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "glsl_translate.h"
+#include "scene.h"
+
+namespace ptl {
+
+// Which scene element a span of generated lines came from (reference: (TypeId, UniqueId)).
+struct ElementKey {
+    std::string kind;  // "object", "material", "intersection_material", "library"
+    std::string name;
+    bool operator<(const ElementKey& o) const { return kind != o.kind ? kind < o.kind : name < o.name; }
+    bool operator==(const ElementKey& o) const { return kind == o.kind && name == o.name; }
+};
+struct LineRange {
+    int start = 0, end = 0;  // [start, end), 1-based like the reference
+};
+
+class LineNumbersByKey {
+public:
+    std::map<ElementKey, LineRange> ranges;
+    void offset(int lines);
+    void add(const ElementKey& key, LineRange r);
+    void extend(const LineNumbersByKey& other);
+    // element containing `line_no` and the line number local to that element (1-based)
+    bool get_identifier(int line_no, ElementKey* key, int* local_line) const;
+};
+
+class StringStorage {
+public:
+    std::string storage;
+    LineNumbersByKey line_numbers;
+    int current_line_no = 1;
+    void add_string(const std::string& s);
+    void add_identifier_string(const ElementKey& id, const std::string& s);
+    void add_string_storage(StringStorage other);
+};
+
+// Splits `tmpl` on "//%"; odd pieces are slot names looked up in `storages`.
+StringStorage apply_template(const std::string& tmpl, std::map<std::string, StringStorage> storages);
+
+// --- uniforms ------------------------------------------------------------------------------
+enum class UniformType { Mat4 = 0, Float1 = 1, Int1 = 2, Float2 = 3, Float3 = 4, Sampler = 5 };
+struct UniformDesc {
+    std::string name;
+    UniformType type;
+    size_t offset = 0;  // byte offset inside the kernel's uniform block
+};
+size_t uniform_type_size(UniformType t);
+
+struct KernelOptions {
+    bool specialize_ints = false;  // bake current Bool/Int uniform values in as literals (recompile when they change)
+    bool count_segments = false;   // compile with PTL_COUNT_SEGMENTS
+};
+
+struct GeneratedKernel {
+    std::string source;                 // complete translation unit
+    LineNumbersByKey line_numbers;      // lines that came from scene snippets
+    std::vector<UniformDesc> uniforms;  // block layout: samplers first, then Scene::uniforms() order
+    size_t uniform_block_size = 0;
+    std::vector<std::string> defines;   // e.g. "PTL_COUNT_SEGMENTS"
+};
+
+// Scene::uniforms (scene.rs:424-543): names and types, in the reference's order.
+std::vector<UniformDesc> scene_uniform_list(const Scene& scene);
+// Sampler names "{name}_tex" for textures (scene.rs:394-412), sorted and de-duplicated.
+std::vector<std::string> scene_texture_list(const Scene& scene);
+
+GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& flags, const KernelOptions& opts);
+
+// One evaluated uniform value, as Scene::set_uniforms (scene.rs:545-657) would upload it.
+struct UniformUpload {
+    std::string name;
+    UniformType type;
+    float f[16] = {0};
+    int i = 0;
+};
+// All scene-derived uniforms: X_mat, X_mat_inv, A_to_B_mat_teleport, user uniforms.
+// `errors` receives the reference's "matrix `x` can't be getted" style messages.
+std::vector<UniformUpload> evaluate_scene_uniforms(const Scene& scene, std::vector<std::string>* errors);
+
+// Rust `{:e}` formatting of an f64 (shortest round-trip digits, exponent without padding).
+std::string format_lower_exp(double v);
+
+// The fixed device sources (embedded at build time from csrc/device/).
+const char* device_source_glsl();
+const char* device_source_library();
+const char* device_source_trace_template();
+const char* device_source_entry();
+
+}  // namespace ptl

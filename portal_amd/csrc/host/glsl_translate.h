@@ -1,0 +1,35 @@
+// glsl_translate.h -- token-level rewrite of the GLSL ES 3.00 snippets stored in scene files
+// into C++ that compiles against device/ptl_glsl.h (for hiprtc and for the host build).
+//
+// The reference hands these snippets verbatim to the GL driver's GLSL compiler
+// (src/gui/scene.rs:776,865,877,1020,1041).  A HIP kernel has no GLSL front end, so the
+// differences between the two languages are bridged here, lexically and line-preserving
+// (the output has exactly as many lines as the input, so compiler diagnostics still point
+// at the right snippet line -- the job of src/code_generation.rs's LineNumbersByKey):
+//   * floating literals get an `f` suffix (GLSL literals are binary32, C++'s are binary64)
+//   * multi-component swizzles  v.xyz -> v.sw<0,1,2>(),  v.xy = e -> v.swr<0,1>() = e
+//   * `in` / `out` / `inout` / precision qualifiers in parameter lists
+//   * identifiers that are C++ keywords are renamed
+//   * the tagged-line filter of src/gui/scene.rs:1065-1107 (!FOR_NUMBER! etc.)
+#pragma once
+#include <string>
+
+namespace ptl {
+
+// Feature switches of the reference's `Data` (src/gui/common.rs:63-86) with the native
+// (non-wasm) defaults of src/main.rs:935-941.
+struct CodegenFlags {
+    bool for_prefer_variable = true;
+    bool disable_antialiasing = false;
+    bool disable_anaglyph = true;
+    bool disable_camera_teleportation = false;
+    bool use_300_version = true;
+};
+
+// Drops (blanks) the lines whose tags are switched off; keeps the line count.
+std::string filter_tagged_lines(const std::string& text, const CodegenFlags& flags);
+
+// GLSL snippet -> C++ (line-preserving).
+std::string translate_glsl(const std::string& glsl);
+
+}  // namespace ptl

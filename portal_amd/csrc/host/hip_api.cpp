@@ -1,0 +1,121 @@
+// hip_api.cpp -- see hip_api.h.
+#include "hip_api.h"
+
+#include <dlfcn.h>
+#include <link.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace ptl::hip {
+namespace {
+
+// Path of an already-loaded shared object whose file name starts with `stem` ("" if none).
+std::string loaded_library_path(const char* stem) {
+    struct Ctx {
+        const char* stem;
+        std::string found;
+    } ctx{stem, ""};
+    dl_iterate_phdr(
+        [](struct dl_phdr_info* info, size_t, void* data) -> int {
+            auto* c = static_cast<Ctx*>(data);
+            if (!info->dlpi_name || !*info->dlpi_name) return 0;
+            const char* base = std::strrchr(info->dlpi_name, '/');
+            base = base ? base + 1 : info->dlpi_name;
+            if (std::strncmp(base, c->stem, std::strlen(c->stem)) == 0) {
+                c->found = info->dlpi_name;
+                return 1;
+            }
+            return 0;
+        },
+        &ctx);
+    return ctx.found;
+}
+
+void* open_first(const std::vector<std::string>& candidates, std::string* chosen, std::string* error) {
+    std::string errs;
+    for (const std::string& c : candidates) {
+        if (c.empty()) continue;
+        void* h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (h) {
+            *chosen = c;
+            return h;
+        }
+        errs += std::string(dlerror()) + "; ";
+    }
+    if (error) *error = errs;
+    return nullptr;
+}
+
+template <class F>
+bool bind(void* h, const char* name, F& fn, std::string* error) {
+    fn = reinterpret_cast<F>(dlsym(h, name));
+    if (!fn && error) *error = std::string("missing symbol ") + name;
+    return fn != nullptr;
+}
+
+std::string dir_of(const std::string& path) {
+    size_t p = path.rfind('/');
+    return p == std::string::npos ? "" : path.substr(0, p + 1);
+}
+
+}  // namespace
+
+const Runtime* runtime(std::string* error) {
+    static std::mutex mu;
+    static Runtime rt;
+    static bool tried = false, ok = false;
+    static std::string err;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tried) {
+        tried = true;
+        const char* env = std::getenv("PTL_HIP_LIB");
+        std::vector<std::string> candidates = {env ? env : "", loaded_library_path("libamdhip64.so"), "libamdhip64.so",
+                                               "/opt/rocm/lib/libamdhip64.so"};
+        void* h = open_first(candidates, &rt.path, &err);
+        if (h) {
+            ok = bind(h, "hipInit", rt.hipInit, &err) && bind(h, "hipGetDeviceCount", rt.hipGetDeviceCount, &err) &&
+                 bind(h, "hipSetDevice", rt.hipSetDevice, &err) && bind(h, "hipGetDevice", rt.hipGetDevice, &err) &&
+                 bind(h, "hipMalloc", rt.hipMalloc, &err) && bind(h, "hipFree", rt.hipFree, &err) &&
+                 bind(h, "hipMemcpy", rt.hipMemcpy, &err) && bind(h, "hipMemcpyAsync", rt.hipMemcpyAsync, &err) &&
+                 bind(h, "hipMemsetAsync", rt.hipMemsetAsync, &err) && bind(h, "hipStreamSynchronize", rt.hipStreamSynchronize, &err) &&
+                 bind(h, "hipDeviceSynchronize", rt.hipDeviceSynchronize, &err) && bind(h, "hipEventCreate", rt.hipEventCreate, &err) &&
+                 bind(h, "hipEventDestroy", rt.hipEventDestroy, &err) && bind(h, "hipEventRecord", rt.hipEventRecord, &err) &&
+                 bind(h, "hipEventSynchronize", rt.hipEventSynchronize, &err) &&
+                 bind(h, "hipEventElapsedTime", rt.hipEventElapsedTime, &err) && bind(h, "hipModuleLoadData", rt.hipModuleLoadData, &err) &&
+                 bind(h, "hipModuleUnload", rt.hipModuleUnload, &err) && bind(h, "hipModuleGetFunction", rt.hipModuleGetFunction, &err) &&
+                 bind(h, "hipModuleGetGlobal", rt.hipModuleGetGlobal, &err) &&
+                 bind(h, "hipModuleLaunchKernel", rt.hipModuleLaunchKernel, &err) && bind(h, "hipGetErrorString", rt.hipGetErrorString, &err);
+        }
+    }
+    if (!ok && error) *error = "HIP runtime unavailable: " + err;
+    return ok ? &rt : nullptr;
+}
+
+const Rtc* rtc(std::string* error) {
+    static std::mutex mu;
+    static Rtc r;
+    static bool tried = false, ok = false;
+    static std::string err;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tried) {
+        tried = true;
+        const char* env = std::getenv("PTL_HIPRTC_LIB");
+        std::string loaded_rt = loaded_library_path("libamdhip64.so");
+        std::vector<std::string> candidates = {env ? env : "", loaded_library_path("libhiprtc.so"), "/opt/rocm/lib/libhiprtc.so",
+                                               loaded_rt.empty() ? "" : dir_of(loaded_rt) + "libhiprtc.so", "libhiprtc.so"};
+        void* h = open_first(candidates, &r.path, &err);
+        if (h) {
+            ok = bind(h, "hiprtcCreateProgram", r.hiprtcCreateProgram, &err) && bind(h, "hiprtcCompileProgram", r.hiprtcCompileProgram, &err) &&
+                 bind(h, "hiprtcGetProgramLogSize", r.hiprtcGetProgramLogSize, &err) && bind(h, "hiprtcGetProgramLog", r.hiprtcGetProgramLog, &err) &&
+                 bind(h, "hiprtcGetCodeSize", r.hiprtcGetCodeSize, &err) && bind(h, "hiprtcGetCode", r.hiprtcGetCode, &err) &&
+                 bind(h, "hiprtcDestroyProgram", r.hiprtcDestroyProgram, &err) && bind(h, "hiprtcGetErrorString", r.hiprtcGetErrorString, &err);
+        }
+    }
+    if (!ok && error) *error = "hiprtc unavailable: " + err;
+    return ok ? &r : nullptr;
+}
+
+}  // namespace ptl::hip

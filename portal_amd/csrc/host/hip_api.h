@@ -1,0 +1,68 @@
+// hip_api.h -- the slice of the HIP runtime and hiprtc this library uses, bound at run time.
+//
+// libportal_amd.so does not link libamdhip64: inside a PyTorch process the runtime that is
+// already loaded (torch ships its own copy) must be the one whose streams and device pointers
+// we are handed, and in a stand-alone process (the CLI) /opt/rocm's is used.  Binding through
+// dlopen/dlsym keeps one library working in both, and lets `ptl_kernel_compile(device=-1)`
+// run hiprtc on a machine without any GPU (the build container).
+#pragma once
+#include <cstddef>
+#include <string>
+
+namespace ptl::hip {
+
+using hipError_t = int;
+using hipStream_t = void*;
+using hipEvent_t = void*;
+using hipModule_t = void*;
+using hipFunction_t = void*;
+using hipDeviceptr_t = void*;
+using hiprtcProgram = void*;
+using hiprtcResult = int;
+
+struct Runtime {
+    std::string path;
+    hipError_t (*hipInit)(unsigned);
+    hipError_t (*hipGetDeviceCount)(int*);
+    hipError_t (*hipSetDevice)(int);
+    hipError_t (*hipGetDevice)(int*);
+    hipError_t (*hipMalloc)(void**, size_t);
+    hipError_t (*hipFree)(void*);
+    hipError_t (*hipMemcpy)(void*, const void*, size_t, int);
+    hipError_t (*hipMemcpyAsync)(void*, const void*, size_t, int, hipStream_t);
+    hipError_t (*hipMemsetAsync)(void*, int, size_t, hipStream_t);
+    hipError_t (*hipStreamSynchronize)(hipStream_t);
+    hipError_t (*hipDeviceSynchronize)();
+    hipError_t (*hipEventCreate)(hipEvent_t*);
+    hipError_t (*hipEventDestroy)(hipEvent_t);
+    hipError_t (*hipEventRecord)(hipEvent_t, hipStream_t);
+    hipError_t (*hipEventSynchronize)(hipEvent_t);
+    hipError_t (*hipEventElapsedTime)(float*, hipEvent_t, hipEvent_t);
+    hipError_t (*hipModuleLoadData)(hipModule_t*, const void*);
+    hipError_t (*hipModuleUnload)(hipModule_t);
+    hipError_t (*hipModuleGetFunction)(hipFunction_t*, hipModule_t, const char*);
+    hipError_t (*hipModuleGetGlobal)(hipDeviceptr_t*, size_t*, hipModule_t, const char*);
+    hipError_t (*hipModuleLaunchKernel)(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned,
+                                        hipStream_t, void**, void**);
+    const char* (*hipGetErrorString)(hipError_t);
+};
+constexpr int kMemcpyHostToDevice = 1;
+constexpr int kMemcpyDeviceToHost = 2;
+
+struct Rtc {
+    std::string path;
+    hiprtcResult (*hiprtcCreateProgram)(hiprtcProgram*, const char*, const char*, int, const char**, const char**);
+    hiprtcResult (*hiprtcCompileProgram)(hiprtcProgram, int, const char**);
+    hiprtcResult (*hiprtcGetProgramLogSize)(hiprtcProgram, size_t*);
+    hiprtcResult (*hiprtcGetProgramLog)(hiprtcProgram, char*);
+    hiprtcResult (*hiprtcGetCodeSize)(hiprtcProgram, size_t*);
+    hiprtcResult (*hiprtcGetCode)(hiprtcProgram, char*);
+    hiprtcResult (*hiprtcDestroyProgram)(hiprtcProgram*);
+    const char* (*hiprtcGetErrorString)(hiprtcResult);
+};
+
+// nullptr (and *error filled) if the library cannot be found / lacks a symbol.
+const Runtime* runtime(std::string* error = nullptr);
+const Rtc* rtc(std::string* error = nullptr);
+
+}  // namespace ptl::hip

@@ -1,0 +1,374 @@
+// kernel.cpp -- layer 1 of the C ABI: compile / set_uniform / set_texture / render.
+// The MI355X replacement for the macroquad material API the reference calls at
+// src/gui/scene.rs:1132-1143 and src/main.rs:1077-1078,1269-1358,1424-1425.
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <memory>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../../include/portal_amd.h"
+#include "hip_api.h"
+#include "internal.h"
+
+namespace ptl {
+
+thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+
+namespace {
+
+bool hip_ok(const hip::Runtime* rt, int err, const char* what) {
+    if (err == 0) return true;
+    set_last_error(std::string(what) + ": " + (rt ? rt->hipGetErrorString(err) : "?") + " (" + std::to_string(err) + ")");
+    return false;
+}
+
+unsigned long long fnv1a(const std::string& s, unsigned long long h = 1469598103934665603ull) {
+    for (unsigned char c : s) {
+        h ^= c;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+std::string cache_dir() {
+    const char* env = std::getenv("PTL_CACHE_DIR");
+    if (env && !*env) return "";  // PTL_CACHE_DIR="" disables the cache
+    return env ? env : "";
+}
+
+std::vector<std::string> compile_options(const char* const* defines, int n_defines) {
+    const char* arch = std::getenv("PTL_OFFLOAD_ARCH");
+    std::vector<std::string> o = {std::string("--offload-arch=") + (arch ? arch : "gfx950"),
+                                  "-O3",
+                                  "-std=c++20",
+                                  "-ffp-contract=off",  // FMAs only where device/ptl_glsl.h spells them
+                                  "-fhip-fp32-correctly-rounded-divide-sqrt",
+                                  "-fno-gpu-approx-transcendentals" /* no-op on older clang, harmless */};
+    if (const char* extra = std::getenv("PTL_HIPRTC_FLAGS")) {
+        std::string e = extra;
+        size_t pos = 0;
+        while (pos < e.size()) {
+            size_t sp = e.find(' ', pos);
+            if (sp == std::string::npos) sp = e.size();
+            if (sp > pos) o.push_back(e.substr(pos, sp - pos));
+            pos = sp + 1;
+        }
+    }
+    for (int k = 0; k < n_defines; ++k) o.push_back(std::string("-D") + defines[k]);
+    return o;
+}
+
+}  // namespace
+}  // namespace ptl
+
+using namespace ptl;
+
+struct ptl_kernel {
+    int device = -1;
+    std::vector<char> code;
+    hip::hipModule_t module = nullptr;
+    hip::hipFunction_t fn = nullptr;
+    void* dev_block = nullptr;  // address of __constant__ ptl_u
+    size_t dev_block_size = 0;
+    std::vector<unsigned char> shadow;  // host copy of the uniform block
+    bool dirty = true;
+    struct Slot {
+        ptl_type type;
+        size_t offset;
+    };
+    std::map<std::string, Slot> slots;
+    std::map<std::string, void*> textures;  // sampler -> device texel buffer
+    hip::hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" const char* ptl_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char* ptl_version(void) {
+    static std::string v;
+    std::string e1, e2;
+    const hip::Runtime* rt = hip::runtime(&e1);
+    const hip::Rtc* rc = hip::rtc(&e2);
+    v = std::string("portal_amd 0.1; hip=") + (rt ? rt->path : "<none>") + "; hiprtc=" + (rc ? rc->path : "<none>");
+    return v.c_str();
+}
+
+extern "C" int ptl_device_count(void) {
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!rt) return 0;
+    int n = 0;
+    if (rt->hipGetDeviceCount(&n) != 0) return 0;
+    return n;
+}
+
+static size_t type_size(ptl_type t) {
+    switch (t) {
+        case PTL_MAT4: return 64;
+        case PTL_F32: case PTL_I32: return 4;
+        case PTL_VEC2: return 8;
+        case PTL_VEC3: return 12;
+        case PTL_SAMPLER: return 16;
+    }
+    return 0;
+}
+
+extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_uniform_desc* uniforms, int n_uniforms,
+                                  size_t uniform_block_size, const char* const* defines, int n_defines, ptl_kernel** out, char* log,
+                                  size_t log_cap) {
+    if (log && log_cap) log[0] = '\0';
+    if (!hip_source || !out) return PTL_ERR_INVALID;
+    *out = nullptr;
+    auto k = std::make_unique<ptl_kernel>();
+    k->device = device;
+    for (int i = 0; i < n_uniforms; ++i) {
+        k->slots[uniforms[i].name] = {uniforms[i].type, uniforms[i].offset};
+        if (uniforms[i].offset + type_size(uniforms[i].type) > uniform_block_size) {
+            set_last_error(std::string("uniform `") + uniforms[i].name + "` lies outside the block");
+            return PTL_ERR_INVALID;
+        }
+    }
+    k->shadow.assign(uniform_block_size, 0);
+
+    std::vector<std::string> opts = compile_options(defines, n_defines);
+    // ---- code-object cache: same source + options -> same gfx950 binary -----------------------
+    std::string cdir = cache_dir();
+    std::string cache_path;
+    if (!cdir.empty()) {
+        unsigned long long h = fnv1a(hip_source);
+        for (auto& o : opts) h = fnv1a(o, h);
+        char name[64];
+        std::snprintf(name, sizeof name, "/ptl_%016llx.hsaco", h);
+        cache_path = cdir + name;
+        std::ifstream f(cache_path, std::ios::binary);
+        if (f) k->code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    }
+    if (k->code.empty()) {
+        std::string err;
+        const hip::Rtc* rc = hip::rtc(&err);
+        if (!rc) {
+            set_last_error(err);
+            return PTL_ERR_COMPILE;
+        }
+        hip::hiprtcProgram prog = nullptr;
+        int r = rc->hiprtcCreateProgram(&prog, hip_source, "portal_scene.hip", 0, nullptr, nullptr);
+        if (r != 0) {
+            set_last_error(std::string("hiprtcCreateProgram: ") + rc->hiprtcGetErrorString(r));
+            return PTL_ERR_COMPILE;
+        }
+        std::vector<const char*> copts;
+        for (auto& o : opts) copts.push_back(o.c_str());
+        r = rc->hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
+        size_t log_size = 0;
+        rc->hiprtcGetProgramLogSize(prog, &log_size);
+        if (log_size > 1) {
+            std::vector<char> buf(log_size + 1, 0);
+            rc->hiprtcGetProgramLog(prog, buf.data());
+            if (log && log_cap) {
+                std::strncpy(log, buf.data(), log_cap - 1);
+                log[log_cap - 1] = '\0';
+            }
+            if (r != 0) set_last_error(std::string("hiprtc: ") + buf.data());
+        }
+        if (r != 0) {
+            if (log_size <= 1) set_last_error(std::string("hiprtcCompileProgram: ") + rc->hiprtcGetErrorString(r));
+            rc->hiprtcDestroyProgram(&prog);
+            return PTL_ERR_COMPILE;
+        }
+        size_t code_size = 0;
+        rc->hiprtcGetCodeSize(prog, &code_size);
+        k->code.resize(code_size);
+        rc->hiprtcGetCode(prog, k->code.data());
+        rc->hiprtcDestroyProgram(&prog);
+        if (!cache_path.empty()) {
+            ::mkdir(cdir.c_str(), 0755);
+            std::string tmp = cache_path + ".tmp" + std::to_string((long)getpid());
+            std::ofstream f(tmp, std::ios::binary);
+            f.write(k->code.data(), (std::streamsize)k->code.size());
+            f.close();
+            if (f) std::rename(tmp.c_str(), cache_path.c_str());
+        }
+    }
+    if (device < 0) {  // compile-only handle
+        *out = k.release();
+        return PTL_OK;
+    }
+
+    std::string err;
+    const hip::Runtime* rt = hip::runtime(&err);
+    if (!rt) {
+        set_last_error(err);
+        return PTL_ERR_NO_DEVICE;
+    }
+    if (!hip_ok(rt, rt->hipSetDevice(device), "hipSetDevice")) return PTL_ERR_HIP;
+    if (!hip_ok(rt, rt->hipModuleLoadData(&k->module, k->code.data()), "hipModuleLoadData")) return PTL_ERR_HIP;
+    if (!hip_ok(rt, rt->hipModuleGetFunction(&k->fn, k->module, "ptl_render_kernel"), "hipModuleGetFunction(ptl_render_kernel)"))
+        return PTL_ERR_HIP;
+    if (!hip_ok(rt, rt->hipModuleGetGlobal(&k->dev_block, &k->dev_block_size, k->module, "_ZN4glsl5ptl_uE"), "hipModuleGetGlobal(ptl_u)"))
+        return PTL_ERR_HIP;
+    if (k->dev_block_size < uniform_block_size) {
+        set_last_error("uniform block in the code object is smaller than the declared layout");
+        return PTL_ERR_INVALID;
+    }
+    rt->hipEventCreate(&k->ev0);
+    rt->hipEventCreate(&k->ev1);
+    *out = k.release();
+    return PTL_OK;
+}
+
+extern "C" int ptl_kernel_code_object(ptl_kernel* k, const void** data, size_t* size) {
+    if (!k) return PTL_ERR_INVALID;
+    if (data) *data = k->code.data();
+    if (size) *size = k->code.size();
+    return PTL_OK;
+}
+
+extern "C" int ptl_kernel_set_uniform(ptl_kernel* k, const char* name, ptl_type type, const void* value) {
+    if (!k || !name || !value) return PTL_ERR_INVALID;
+    auto it = k->slots.find(name);
+    if (it == k->slots.end()) return PTL_UNKNOWN_UNIFORM;
+    if (it->second.type != type || type == PTL_SAMPLER) return PTL_ERR_TYPE;
+    size_t n = type_size(type);
+    if (std::memcmp(k->shadow.data() + it->second.offset, value, n) != 0) {
+        std::memcpy(k->shadow.data() + it->second.offset, value, n);
+        k->dirty = true;
+    }
+    return PTL_OK;
+}
+
+extern "C" int ptl_kernel_set_texture(ptl_kernel* k, const char* sampler, const uint8_t* rgba8, int width, int height) {
+    if (!k || !sampler || !rgba8 || width <= 0 || height <= 0) return PTL_ERR_INVALID;
+    auto it = k->slots.find(sampler);
+    if (it == k->slots.end()) return PTL_UNKNOWN_UNIFORM;
+    if (it->second.type != PTL_SAMPLER) return PTL_ERR_TYPE;
+    if (k->device < 0) return PTL_ERR_NO_DEVICE;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;
+    void*& dev = k->textures[sampler];
+    if (dev) {
+        rt->hipFree(dev);
+        dev = nullptr;
+    }
+    size_t bytes = (size_t)width * height * 4;
+    if (!hip_ok(rt, rt->hipMalloc(&dev, bytes), "hipMalloc(texture)")) return PTL_ERR_HIP;
+    if (!hip_ok(rt, rt->hipMemcpy(dev, rgba8, bytes, hip::kMemcpyHostToDevice), "hipMemcpy(texture)")) return PTL_ERR_HIP;
+    struct {
+        void* texels;
+        int w, h;
+    } s{dev, width, height};
+    static_assert(sizeof s == 16, "sampler2D layout");
+    std::memcpy(k->shadow.data() + it->second.offset, &s, sizeof s);
+    k->dirty = true;
+    return PTL_OK;
+}
+
+extern "C" int ptl_frame_shard_rows(const ptl_frame* f) {
+    if (!f || f->width <= 0 || f->height <= 0 || f->rb_stride <= 0 || f->rb_phase < 0 || f->rb_phase >= f->rb_stride) return -1;
+    int blocks = (f->height + 7) / 8;
+    int rows = 0;
+    for (int b = f->rb_phase; b < blocks; b += f->rb_stride) rows += (b * 8 + 8 <= f->height) ? 8 : f->height - b * 8;
+    return rows;
+}
+
+static int shard_blocks(const ptl_frame* f) {
+    int blocks = (f->height + 7) / 8;
+    return blocks > f->rb_phase ? (blocks - f->rb_phase + f->rb_stride - 1) / f->rb_stride : 0;
+}
+
+extern "C" int ptl_kernel_render(ptl_kernel* k, const ptl_frame* frame, void* out_rgba8, void* out_rgba32f, void* segments,
+                                 void* stream, float* elapsed_ms) {
+    if (!k || !frame || ptl_frame_shard_rows(frame) < 0) return PTL_ERR_INVALID;
+    if (k->device < 0 || !k->fn) return PTL_ERR_NO_DEVICE;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;
+    if (k->dirty) {
+        // stream-ordered upload of the whole block: one copy, a few KB
+        if (!hip_ok(rt, rt->hipMemcpyAsync(k->dev_block, k->shadow.data(), k->shadow.size(), hip::kMemcpyHostToDevice, stream),
+                    "hipMemcpyAsync(uniform block)"))
+            return PTL_ERR_HIP;
+        // the shadow buffer is pageable host memory: the async copy has staged it before returning
+        k->dirty = false;
+    }
+    int nby = shard_blocks(frame);
+    if (nby == 0) {
+        if (elapsed_ms) *elapsed_ms = 0.0f;
+        return PTL_OK;
+    }
+    int width = frame->width, height = frame->height, phase = frame->rb_phase, stride = frame->rb_stride;
+    void* args[] = {&out_rgba8, &out_rgba32f, &width, &height, &phase, &stride, &segments};
+    unsigned gx = (unsigned)((width + 31) / 32), gy = (unsigned)nby;
+    if (elapsed_ms) rt->hipEventRecord(k->ev0, stream);
+    if (!hip_ok(rt, rt->hipModuleLaunchKernel(k->fn, gx, gy, 1, 256, 1, 1, 0, stream, args, nullptr), "hipModuleLaunchKernel")) return PTL_ERR_HIP;
+    if (elapsed_ms) {
+        rt->hipEventRecord(k->ev1, stream);
+        if (!hip_ok(rt, rt->hipEventSynchronize(k->ev1), "hipEventSynchronize")) return PTL_ERR_HIP;
+        rt->hipEventElapsedTime(elapsed_ms, k->ev0, k->ev1);
+    }
+    return PTL_OK;
+}
+
+extern "C" int ptl_kernel_render_to_host(ptl_kernel* k, const ptl_frame* frame, uint8_t* host_rgba8, float* host_rgba32f,
+                                         uint64_t* host_segments, float* elapsed_ms) {
+    if (!k || !frame) return PTL_ERR_INVALID;
+    int rows = ptl_frame_shard_rows(frame);
+    if (rows < 0) return PTL_ERR_INVALID;
+    if (k->device < 0) return PTL_ERR_NO_DEVICE;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;
+    size_t px = (size_t)rows * frame->width;
+    void *d8 = nullptr, *d32 = nullptr, *dseg = nullptr;
+    int rc = PTL_OK;
+    auto cleanup = [&] {
+        if (d8) rt->hipFree(d8);
+        if (d32) rt->hipFree(d32);
+        if (dseg) rt->hipFree(dseg);
+    };
+    if (host_rgba8 && !hip_ok(rt, rt->hipMalloc(&d8, px * 4 + 16), "hipMalloc(rgba8)")) rc = PTL_ERR_HIP;
+    if (rc == PTL_OK && host_rgba32f && !hip_ok(rt, rt->hipMalloc(&d32, px * 16 + 16), "hipMalloc(rgba32f)")) rc = PTL_ERR_HIP;
+    if (rc == PTL_OK && host_segments) {
+        if (!hip_ok(rt, rt->hipMalloc(&dseg, 8), "hipMalloc(segments)")) rc = PTL_ERR_HIP;
+        else rt->hipMemsetAsync(dseg, 0, 8, nullptr);
+    }
+    if (rc == PTL_OK) rc = ptl_kernel_render(k, frame, d8, d32, dseg, nullptr, elapsed_ms);
+    if (rc == PTL_OK && !hip_ok(rt, rt->hipStreamSynchronize(nullptr), "hipStreamSynchronize")) rc = PTL_ERR_HIP;
+    if (rc == PTL_OK && d8 && !hip_ok(rt, rt->hipMemcpy(host_rgba8, d8, px * 4, hip::kMemcpyDeviceToHost), "hipMemcpy(rgba8)")) rc = PTL_ERR_HIP;
+    if (rc == PTL_OK && d32 && !hip_ok(rt, rt->hipMemcpy(host_rgba32f, d32, px * 16, hip::kMemcpyDeviceToHost), "hipMemcpy(rgba32f)")) rc = PTL_ERR_HIP;
+    if (rc == PTL_OK && dseg && !hip_ok(rt, rt->hipMemcpy(host_segments, dseg, 8, hip::kMemcpyDeviceToHost), "hipMemcpy(segments)")) rc = PTL_ERR_HIP;
+    cleanup();
+    return rc;
+}
+
+extern "C" void ptl_kernel_destroy(ptl_kernel* k) {
+    if (!k) return;
+    const hip::Runtime* rt = k->device >= 0 ? hip::runtime(nullptr) : nullptr;
+    if (rt) {
+        rt->hipSetDevice(k->device);
+        for (auto& t : k->textures)
+            if (t.second) rt->hipFree(t.second);
+        if (k->ev0) rt->hipEventDestroy(k->ev0);
+        if (k->ev1) rt->hipEventDestroy(k->ev1);
+        if (k->module) rt->hipModuleUnload(k->module);
+    }
+    delete k;
+}
+
+extern "C" int ptl_deinterleave_rows(const uint8_t* shard, const ptl_frame* f, uint8_t* full) {
+    if (!shard || !f || !full || ptl_frame_shard_rows(f) < 0) return PTL_ERR_INVALID;
+    int blocks = (f->height + 7) / 8;
+    size_t pitch = (size_t)f->width * 4;
+    size_t src_row = 0;
+    for (int b = f->rb_phase; b < blocks; b += f->rb_stride) {
+        for (int r = 0; r < 8 && b * 8 + r < f->height; ++r) {
+            std::memcpy(full + (size_t)(b * 8 + r) * pitch, shard + src_row * pitch, pitch);
+            ++src_row;
+        }
+    }
+    return PTL_OK;
+}

@@ -1,0 +1,177 @@
+// png_io.cpp -- minimal PNG reader / writer on top of zlib (RGBA8 in memory).
+//
+// Stands in for the third-party image code behind the reference's
+// Texture2D::from_file_with_format (src/main.rs:1075) and Image::export_png
+// (src/main.rs:2939-2943).  Reads 8/16-bit grey, grey+alpha, RGB, RGBA and 1/2/4/8-bit
+// palette images, non-interlaced; writes RGBA8.
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/portal_amd.h"
+#include "internal.h"
+
+namespace {
+
+unsigned be32(const unsigned char* p) { return ((unsigned)p[0] << 24) | ((unsigned)p[1] << 16) | ((unsigned)p[2] << 8) | p[3]; }
+void put_be32(std::vector<unsigned char>& v, unsigned x) {
+    v.push_back((unsigned char)(x >> 24));
+    v.push_back((unsigned char)(x >> 16));
+    v.push_back((unsigned char)(x >> 8));
+    v.push_back((unsigned char)x);
+}
+int paeth(int a, int b, int c) {
+    int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+void write_chunk(std::vector<unsigned char>& out, const char* type, const unsigned char* data, size_t n) {
+    put_be32(out, (unsigned)n);
+    size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    if (n) out.insert(out.end(), data, data + n);
+    unsigned crc = (unsigned)crc32(0L, out.data() + start, (uInt)(n + 4));
+    put_be32(out, crc);
+}
+
+}  // namespace
+
+extern "C" int ptl_png_read(const char* path, uint8_t** rgba8, int* width, int* height) {
+    if (!path || !rgba8 || !width || !height) return PTL_ERR_INVALID;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) {
+        ptl::set_last_error(std::string("cannot open `") + path + "`");
+        return PTL_ERR_INVALID;
+    }
+    std::vector<unsigned char> file;
+    unsigned char buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + n);
+    std::fclose(f);
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (file.size() < 8 || std::memcmp(file.data(), sig, 8) != 0) {
+        ptl::set_last_error(std::string("`") + path + "` is not a PNG file");
+        return PTL_ERR_INVALID;
+    }
+    unsigned w = 0, h = 0;
+    int depth = 0, color = 0, interlace = 0;
+    std::vector<unsigned char> idat, palette, trns;
+    size_t pos = 8;
+    while (pos + 12 <= file.size()) {
+        unsigned len = be32(&file[pos]);
+        const unsigned char* type = &file[pos + 4];
+        const unsigned char* data = &file[pos + 8];
+        if (pos + 12 + len > file.size()) break;
+        if (!std::memcmp(type, "IHDR", 4)) {
+            w = be32(data);
+            h = be32(data + 4);
+            depth = data[8];
+            color = data[9];
+            interlace = data[12];
+        } else if (!std::memcmp(type, "PLTE", 4)) {
+            palette.assign(data, data + len);
+        } else if (!std::memcmp(type, "tRNS", 4)) {
+            trns.assign(data, data + len);
+        } else if (!std::memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (!std::memcmp(type, "IEND", 4)) {
+            break;
+        }
+        pos += 12 + len;
+    }
+    if (!w || !h || interlace != 0) {
+        ptl::set_last_error("unsupported PNG (interlaced or empty)");
+        return PTL_ERR_INVALID;
+    }
+    int channels = color == 0 ? 1 : color == 2 ? 3 : color == 3 ? 1 : color == 4 ? 2 : color == 6 ? 4 : 0;
+    if (!channels) return PTL_ERR_INVALID;
+    size_t bpp_bits = (size_t)channels * depth;
+    size_t stride = (w * bpp_bits + 7) / 8;
+    size_t bpp = (bpp_bits + 7) / 8;
+    std::vector<unsigned char> raw((stride + 1) * h);
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) {
+        ptl::set_last_error("PNG inflate failed");
+        return PTL_ERR_INVALID;
+    }
+    std::vector<unsigned char> prev(stride, 0), cur(stride);
+    uint8_t* out = (uint8_t*)std::malloc((size_t)w * h * 4);
+    for (unsigned y = 0; y < h; ++y) {
+        const unsigned char* line = &raw[y * (stride + 1)];
+        int ft = line[0];
+        for (size_t x = 0; x < stride; ++x) {
+            int a = x >= bpp ? cur[x - bpp] : 0, b = prev[x], c = x >= bpp ? prev[x - bpp] : 0;
+            int v = line[1 + x];
+            switch (ft) {
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) / 2; break;
+                case 4: v += paeth(a, b, c); break;
+                default: break;
+            }
+            cur[x] = (unsigned char)v;
+        }
+        for (unsigned x = 0; x < w; ++x) {
+            uint8_t* px = out + ((size_t)y * w + x) * 4;
+            auto sample = [&](int ch) -> unsigned {
+                if (depth == 8) return cur[x * channels + ch];
+                if (depth == 16) return cur[(x * channels + ch) * 2];  // high byte
+                size_t bit = (size_t)x * depth;                       // 1/2/4-bit (channels == 1)
+                unsigned v = (cur[bit / 8] >> (8 - depth - bit % 8)) & ((1u << depth) - 1);
+                return color == 3 ? v : v * 255 / ((1u << depth) - 1);
+            };
+            if (color == 3) {
+                unsigned idx = sample(0);
+                px[0] = idx * 3 + 2 < palette.size() ? palette[idx * 3] : 0;
+                px[1] = idx * 3 + 2 < palette.size() ? palette[idx * 3 + 1] : 0;
+                px[2] = idx * 3 + 2 < palette.size() ? palette[idx * 3 + 2] : 0;
+                px[3] = idx < trns.size() ? trns[idx] : 255;
+            } else if (color == 0 || color == 4) {
+                px[0] = px[1] = px[2] = (uint8_t)sample(0);
+                px[3] = color == 4 ? (uint8_t)sample(1) : 255;
+            } else {
+                px[0] = (uint8_t)sample(0);
+                px[1] = (uint8_t)sample(1);
+                px[2] = (uint8_t)sample(2);
+                px[3] = color == 6 ? (uint8_t)sample(3) : 255;
+            }
+        }
+        prev.swap(cur);
+    }
+    *rgba8 = out;
+    *width = (int)w;
+    *height = (int)h;
+    return PTL_OK;
+}
+
+extern "C" int ptl_png_write(const char* path, const uint8_t* rgba8, int width, int height) {
+    if (!path || !rgba8 || width <= 0 || height <= 0) return PTL_ERR_INVALID;
+    size_t stride = (size_t)width * 4;
+    std::vector<unsigned char> raw((stride + 1) * height);
+    for (int y = 0; y < height; ++y) {
+        raw[y * (stride + 1)] = 0;
+        std::memcpy(&raw[y * (stride + 1) + 1], rgba8 + y * stride, stride);
+    }
+    uLongf clen = compressBound((uLong)raw.size());
+    std::vector<unsigned char> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return PTL_ERR_INVALID;
+    std::vector<unsigned char> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<unsigned char> ihdr;
+    put_be32(ihdr, (unsigned)width);
+    put_be32(ihdr, (unsigned)height);
+    ihdr.insert(ihdr.end(), {8, 6, 0, 0, 0});
+    write_chunk(out, "IHDR", ihdr.data(), ihdr.size());
+    write_chunk(out, "IDAT", comp.data(), clen);
+    write_chunk(out, "IEND", nullptr, 0);
+    FILE* f = std::fopen(path, "wb");
+    if (!f) {
+        ptl::set_last_error(std::string("cannot write `") + path + "`");
+        return PTL_ERR_INVALID;
+    }
+    bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    std::fclose(f);
+    return ok ? PTL_OK : PTL_ERR_INVALID;
+}

@@ -1,0 +1,479 @@
+// scene.cpp -- RON document -> Scene, and evaluation of uniforms / matrices (see scene.h).
+#include "scene.h"
+
+#include <fstream>
+#include <sstream>
+
+namespace ptl {
+namespace {
+
+using ron::Value;
+
+const Value& storage_list(const Value& doc, const char* field, bool required) {
+    static const Value empty_list = [] {
+        Value v;
+        v.kind = Value::List;
+        return v;
+    }();
+    const Value* f = doc.find(field);
+    if (!f) {
+        if (required) throw SceneError(std::string("scene: missing field `") + field + "`");
+        return empty_list;
+    }
+    const Value& inner = f->unwrap_newtypes();  // SerStorage<T>(Vec<Named<T>>)
+    if (inner.kind != Value::List) throw SceneError(std::string("scene: field `") + field + "` is not a list");
+    return inner;
+}
+
+const std::string& as_string(const Value& v, const char* what) {
+    const Value& s = v.unwrap_newtypes();
+    if (s.kind != Value::String) throw SceneError(std::string("scene: expected string for ") + what);
+    return s.s;
+}
+double as_f64(const Value& v, const char* what) {
+    const Value& n = v.unwrap_newtypes();
+    if (!n.is_number()) throw SceneError(std::string("scene: expected number for ") + what);
+    return n.number();
+}
+bool as_bool(const Value& v, const char* what) {
+    const Value& n = v.unwrap_newtypes();
+    if (n.kind != Value::Bool) throw SceneError(std::string("scene: expected bool for ") + what);
+    return n.b;
+}
+DVec3 as_dvec3(const Value& v, const char* what) {
+    if (v.kind == Value::Tuple && v.items.size() == 3) return {as_f64(v.items[0], what), as_f64(v.items[1], what), as_f64(v.items[2], what)};
+    if (v.kind == Value::Struct) return {as_f64(v.at("x"), what), as_f64(v.at("y"), what), as_f64(v.at("z"), what)};
+    throw SceneError(std::string("scene: expected 3-vector for ") + what);
+}
+
+struct Loader {
+    Scene& scene;
+    std::map<std::string, int> matrix_by_name;
+
+    Uniform parse_uniform(const Value& v) {
+        Uniform u;
+        if (v.kind != Value::Tuple && v.kind != Value::Struct) throw SceneError("scene: bad uniform value");
+        const std::string& tag = v.s;
+        if (tag == "Bool") {
+            u.kind = Uniform::Bool;
+            u.b = as_bool(v.items.at(0), "Bool uniform");
+        } else if (tag == "Int") {
+            u.kind = Uniform::Int;
+            u.i = (int)as_f64(v.items.at(0).unwrap_newtypes().at("value"), "Int uniform");
+        } else if (tag == "Float") {
+            u.kind = Uniform::Float;
+            u.f = as_f64(v.items.at(0).unwrap_newtypes().at("value"), "Float uniform");
+        } else if (tag == "Angle") {
+            u.kind = Uniform::Angle;
+            u.f = as_f64(v.items.at(0), "Angle uniform");
+        } else if (tag == "Progress") {
+            u.kind = Uniform::Progress;
+            u.f = as_f64(v.items.at(0), "Progress uniform");
+        } else if (tag == "Formula" || tag == "FormulaInt") {
+            u.kind = tag == "Formula" ? Uniform::Formula : Uniform::FormulaInt;
+            u.formula = as_string(v.items.at(0), "Formula uniform");
+        } else if (tag == "TrefoilSpecial") {
+            u.kind = Uniform::Trefoil;
+        } else {
+            throw SceneError("scene: unknown uniform kind `" + tag + "`");
+        }
+        return u;
+    }
+    // Option<UniformRef> -> index
+    int uniform_ref(const Value& opt) {
+        const Value* r = opt.some();
+        if (!r) return -1;
+        if (r->is_named("Named")) return scene.find_uniform(as_string(r->items.at(0), "UniformRef"));
+        if (r->is_named("Inline")) {
+            scene.uniforms.push_back(UniformEntry{"", parse_uniform(r->items.at(0))});
+            return (int)scene.uniforms.size() - 1;
+        }
+        throw SceneError("scene: bad UniformRef");
+    }
+    Param parse_param(const Value& v) {
+        Param p;
+        if (v.is_named("Value")) {
+            p.value = as_f64(v.items.at(0), "ParametrizeOrNot::Value");
+        } else if (v.is_named("Uniform")) {
+            p.is_uniform = true;
+            p.uniform = uniform_ref(v.items.at(0));
+        } else {
+            throw SceneError("scene: bad ParametrizeOrNot");
+        }
+        return p;
+    }
+    void parse_tvec(const Value& v, Param* out, int n) {
+        static const char* names[4] = {"x", "y", "z", "w"};
+        for (int k = 0; k < n; ++k) out[k] = parse_param(v.at(names[k]));
+    }
+    // Option<MatrixRef> -> index; inline matrices are appended depth-first
+    int matrix_ref(const Value& opt) {
+        const Value* r = opt.some();
+        if (!r) return -1;
+        if (r->is_named("Named")) {
+            auto it = matrix_by_name.find(as_string(r->items.at(0), "MatrixRef"));
+            return it == matrix_by_name.end() ? -1 : it->second;
+        }
+        if (r->is_named("Inline")) {
+            int idx = (int)scene.matrices.size();
+            scene.matrices.push_back(MatrixEntry{"id" + std::to_string(idx), false, Matrix{}});
+            Matrix m = parse_matrix(r->items.at(0));
+            scene.matrices[idx].value = m;
+            return idx;
+        }
+        throw SceneError("scene: bad MatrixRef");
+    }
+    Matrix parse_matrix(const Value& v) {
+        Matrix m;
+        const std::string& tag = v.s;
+        if (tag == "Mul") {
+            m.kind = Matrix::Mul;
+            m.a = matrix_ref(v.at("to"));
+            m.b = matrix_ref(v.at("what"));
+        } else if (tag == "Teleport") {
+            m.kind = Matrix::Teleport;
+            m.a = matrix_ref(v.at("first_portal"));
+            m.b = matrix_ref(v.at("second_portal"));
+            m.c = matrix_ref(v.at("what"));
+        } else if (tag == "Simple") {
+            m.kind = Matrix::Simple;
+            m.offset = as_dvec3(v.at("offset"), "Simple.offset");
+            m.scale = as_f64(v.at("scale"), "Simple.scale");
+            m.rotate = as_dvec3(v.at("rotate"), "Simple.rotate");
+            const Value& mir = v.at("mirror");
+            for (int k = 0; k < 3; ++k) m.mirror[k] = as_bool(mir.items.at(k), "Simple.mirror");
+        } else if (tag == "Parametrized") {
+            m.kind = Matrix::Parametrized;
+            parse_tvec(v.at("offset"), m.p + 0, 3);
+            parse_tvec(v.at("rotate"), m.p + 3, 3);
+            parse_tvec(v.at("mirror"), m.p + 6, 3);
+            m.p[9] = parse_param(v.at("scale"));
+        } else if (tag == "Exact") {
+            m.kind = Matrix::Exact;
+            parse_tvec(v.at("i"), m.p + 0, 3);
+            parse_tvec(v.at("j"), m.p + 3, 3);
+            parse_tvec(v.at("k"), m.p + 6, 3);
+            parse_tvec(v.at("pos"), m.p + 9, 3);
+        } else if (tag == "ExactFull") {
+            m.kind = Matrix::ExactFull;
+            parse_tvec(v.at("c0"), m.p + 0, 4);
+            parse_tvec(v.at("c1"), m.p + 4, 4);
+            parse_tvec(v.at("c2"), m.p + 8, 4);
+            parse_tvec(v.at("c3"), m.p + 12, 4);
+        } else if (tag == "If") {
+            m.kind = Matrix::If;
+            m.cond = parse_param(v.at("condition"));
+            m.a = matrix_ref(v.at("then"));
+            m.b = matrix_ref(v.at("otherwise"));
+        } else if (tag == "Sqrt") {
+            m.kind = Matrix::Sqrt;
+            m.a = matrix_ref(v.items.at(0));
+        } else if (tag == "Inv") {
+            m.kind = Matrix::Inv;
+            m.a = matrix_ref(v.items.at(0));
+        } else if (tag == "Lerp") {
+            m.kind = Matrix::Lerp;
+            m.cond = parse_param(v.at("t"));
+            m.a = matrix_ref(v.at("first"));
+            m.b = matrix_ref(v.at("second"));
+        } else if (tag == "Camera") {
+            m.kind = Matrix::Camera;
+        } else {
+            throw SceneError("scene: unknown matrix kind `" + tag + "`");
+        }
+        return m;
+    }
+    Subspace parse_subspace(const Value* v) {
+        if (!v) return Subspace::Normal;
+        if (v->is_named("Subspace")) return Subspace::Subspace;
+        if (v->is_named("Both")) return Subspace::Both;
+        return Subspace::Normal;
+    }
+    void parse_kind(const Value& kind, Object& o) {
+        if (kind.is_named("Simple")) {
+            o.portal = false;
+            o.m0 = matrix_ref(kind.items.at(0));
+        } else if (kind.is_named("Portal")) {
+            o.portal = true;
+            o.m0 = matrix_ref(kind.items.at(0));
+            o.m1 = matrix_ref(kind.items.at(1));
+        } else {
+            throw SceneError("scene: bad ObjectType");
+        }
+    }
+
+    void load(const Value& doc) {
+        if (doc.kind != Value::Struct) throw SceneError("scene: top level is not a struct");
+        // cam
+        const Value& cam = doc.at("cam");
+        scene.cam.look_at = as_dvec3(cam.at("look_at"), "cam.look_at");
+        scene.cam.alpha = as_f64(cam.at("alpha"), "cam.alpha");
+        scene.cam.beta = as_f64(cam.at("beta"), "cam.beta");
+        scene.cam.r = as_f64(cam.at("r"), "cam.r");
+        scene.cam.offset_after_material = as_f64(cam.at("offset_after_material"), "cam.offset_after_material");
+        if (const Value* v = doc.find("use_time")) scene.use_time = as_bool(*v, "use_time");
+        if (const Value* v = doc.find("skybox"))
+            if (const Value* s = v->some()) scene.skybox = as_string(*s, "skybox");
+
+        // order follows deserialize_scene_new_format (scene_serialized.rs:1102-1230)
+        for (const Value& t : storage_list(doc, "textures", true).items)
+            scene.textures.push_back(Texture{as_string(t.at("name"), "texture name"), as_string(t.at("data"), "texture path")});
+        for (const Value& u : storage_list(doc, "uniforms", true).items)
+            scene.uniforms.push_back(UniformEntry{as_string(u.at("name"), "uniform name"), parse_uniform(u.at("data"))});
+
+        const Value& mats = storage_list(doc, "matrices", true);
+        for (const Value& m : mats.items) {
+            std::string name = as_string(m.at("name"), "matrix name");
+            matrix_by_name[name] = (int)scene.matrices.size();
+            scene.matrices.push_back(MatrixEntry{name, true, Matrix{}});
+        }
+        for (const Value& m : mats.items) {
+            int idx = matrix_by_name[as_string(m.at("name"), "matrix name")];
+            Matrix value = parse_matrix(m.at("data"));
+            scene.matrices[idx].value = value;
+        }
+
+        for (const Value& o : storage_list(doc, "objects", true).items) {
+            Object obj;
+            obj.name = as_string(o.at("name"), "object name");
+            const Value& d = o.at("data");
+            if (d.is_named("DebugMatrix")) {
+                obj.kind = Object::DebugMatrix;
+                obj.m0 = matrix_ref(d.items.at(0));
+            } else if (d.is_named("Flat")) {
+                obj.kind = Object::Flat;
+                parse_kind(d.at("kind"), obj);
+                obj.code = as_string(d.at("is_inside"), "is_inside code");
+                obj.in_subspace = parse_subspace(d.find("in_subspace"));
+            } else if (d.is_named("Complex")) {
+                obj.kind = Object::Complex;
+                parse_kind(d.at("kind"), obj);
+                obj.code = as_string(d.at("intersect"), "intersect code");
+                obj.in_subspace = parse_subspace(d.find("in_subspace"));
+            } else {
+                throw SceneError("scene: unknown object kind `" + d.s + "`");
+            }
+            scene.objects.push_back(std::move(obj));
+        }
+
+        for (const Value& m : storage_list(doc, "materials", true).items) {
+            Material mat;
+            mat.name = as_string(m.at("name"), "material name");
+            const Value& d = m.at("data");
+            auto rgb = [&](const Value& c) {
+                for (int k = 0; k < 3; ++k) mat.color[k] = as_f64(c.items.at(k), "material color");
+            };
+            if (d.is_named("Simple")) {
+                mat.kind = Material::Simple;
+                rgb(d.at("color"));
+                mat.normal_coef = as_f64(d.at("normal_coef"), "normal_coef");
+                mat.grid = as_bool(d.at("grid"), "grid");
+                mat.grid_scale = as_f64(d.at("grid_scale"), "grid_scale");
+                mat.grid_coef = as_f64(d.at("grid_coef"), "grid_coef");
+                mat.grid2 = d.find("grid2") ? as_bool(d.at("grid2"), "grid2") : false;
+                mat.grid3 = d.find("grid3") ? as_bool(d.at("grid3"), "grid3") : false;
+            } else if (d.is_named("Reflect")) {
+                mat.kind = Material::Reflect;
+                rgb(d.at("add_to_color"));
+            } else if (d.is_named("Refract")) {
+                mat.kind = Material::Refract;
+                rgb(d.at("add_to_color"));
+                mat.refractive_index = as_f64(d.at("refractive_index"), "refractive_index");
+            } else if (d.is_named("Complex")) {
+                mat.kind = Material::Complex;
+                mat.code = as_string(d.at("code"), "material code");
+            } else {
+                throw SceneError("scene: unknown material kind `" + d.s + "`");
+            }
+            scene.materials.push_back(std::move(mat));
+        }
+        for (const Value& m : storage_list(doc, "intersection_materials", false).items)
+            scene.intersection_materials.push_back(NamedCode{as_string(m.at("name"), "name"), as_string(m.at("data"), "intersection material code")});
+        for (const Value& m : storage_list(doc, "library", true).items)
+            scene.library.push_back(NamedCode{as_string(m.at("name"), "name"), as_string(m.at("data"), "library code")});
+    }
+};
+
+}  // namespace
+
+std::shared_ptr<Scene> Scene::from_ron_text(const std::string& text) {
+    ron::Value doc = ron::parse(text);
+    auto scene = std::make_shared<Scene>();
+    Loader loader{*scene, {}};
+    loader.load(doc);
+    return scene;
+}
+
+std::shared_ptr<Scene> Scene::from_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw SceneError("cannot open scene file `" + path + "`");
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return from_ron_text(ss.str());
+}
+
+int Scene::find_uniform(const std::string& name) const {
+    for (size_t k = 0; k < uniforms.size(); ++k)
+        if (!uniforms[k].name.empty() && uniforms[k].name == name) return (int)k;
+    return -1;
+}
+int Scene::find_matrix(const std::string& name) const {
+    for (size_t k = 0; k < matrices.size(); ++k)
+        if (matrices[k].name == name) return (int)k;
+    return -1;
+}
+
+bool Scene::set_uniform_value(const std::string& name, double v) {
+    int idx = find_uniform(name);
+    if (idx < 0) return false;
+    Uniform& u = uniforms[idx].value;
+    switch (u.kind) {
+        case Uniform::Bool: u.b = v > 0.5; break;
+        case Uniform::Int: u.i = (int)v; break;
+        case Uniform::Float: case Uniform::Angle: case Uniform::Progress: u.f = v; break;
+        default: u.kind = Uniform::Float; u.f = v; break;  // a stage replaces a formula by a value
+    }
+    return true;
+}
+
+std::optional<double> Scene::eval_formula(const std::string& text) const {
+    auto it = formula_cache_.find(text);
+    if (it == formula_cache_.end()) it = formula_cache_.emplace(text, Formula::compile(text)).first;
+    if (!it->second) return std::nullopt;
+    FormulaNamespace ns = [this](const std::string& name, const std::vector<double>& args) -> std::optional<double> {
+        bool known = false;
+        auto r = formula_custom_function(name, args, &known);
+        if (known) return r;
+        if (name == "time") return time;
+        if (name == "total_time") return total_time;
+        int idx = find_uniform(name);  // free variable = another named uniform
+        if (idx < 0) return std::nullopt;
+        auto v = eval_uniform(idx);
+        if (!v) return std::nullopt;
+        return v->as_f64();
+    };
+    return it->second->eval(ns);
+}
+
+std::optional<UniformValue> Scene::eval_uniform(int index) const {
+    if (index < 0 || index >= (int)uniforms.size()) return std::nullopt;
+    if (uniform_busy_.size() < uniforms.size()) uniform_busy_.resize(uniforms.size(), 0);
+    if (uniform_busy_[index]) return std::nullopt;  // recursion
+    const Uniform& u = uniforms[index].value;
+    UniformValue out;
+    switch (u.kind) {
+        case Uniform::Bool: out.kind = UniformValue::Bool; out.b = u.b; return out;
+        case Uniform::Int: out.kind = UniformValue::Int; out.i = u.i; return out;
+        case Uniform::Float: case Uniform::Angle: case Uniform::Progress: out.kind = UniformValue::Float; out.f = u.f; return out;
+        case Uniform::Formula: case Uniform::FormulaInt: {
+            uniform_busy_[index] = 1;
+            auto v = eval_formula(u.formula);
+            uniform_busy_[index] = 0;
+            if (!v) return std::nullopt;
+            if (u.kind == Uniform::Formula) {
+                out.kind = UniformValue::Float;
+                out.f = *v;
+            } else {
+                out.kind = UniformValue::Int;
+                double d = *v;  // Rust `as i32`: saturating, NaN -> 0
+                out.i = std::isnan(d) ? 0 : (d >= 2147483647.0 ? 2147483647 : (d <= -2147483648.0 ? (-2147483647 - 1) : (int)d));
+            }
+            return out;
+        }
+        case Uniform::Trefoil: return std::nullopt;
+    }
+    return std::nullopt;
+}
+
+std::optional<double> Scene::eval_param(const Param& p) const {
+    if (!p.is_uniform) return p.value;
+    auto v = eval_uniform(p.uniform);
+    if (!v) return std::nullopt;
+    return v->as_f64();
+}
+
+std::optional<DMat4> Scene::eval_matrix(int index) const {
+    if (index < 0 || index >= (int)matrices.size()) return std::nullopt;
+    if (matrix_busy_.size() < matrices.size()) matrix_busy_.resize(matrices.size(), 0);
+    if (matrix_busy_[index]) return std::nullopt;
+    struct Guard {
+        char& flag;
+        explicit Guard(char& f) : flag(f) { flag = 1; }
+        ~Guard() { flag = 0; }
+    } guard(matrix_busy_[index]);
+
+    const Matrix& m = matrices[index].value;
+    auto srt = [](const DVec3& scale, const DVec3& rot, const DVec3& offset) {
+        return DMat4::from_scale_rotation_translation(scale, DQuat::rotation_x(rot.x) * DQuat::rotation_y(rot.y) * DQuat::rotation_z(rot.z), offset);
+    };
+    switch (m.kind) {
+        case Matrix::Mul: {
+            auto to = eval_matrix(m.a);
+            if (!to) return std::nullopt;
+            auto what = eval_matrix(m.b);
+            if (!what) return std::nullopt;
+            return *what * *to;
+        }
+        case Matrix::Teleport: {
+            auto first = eval_matrix(m.a);
+            if (!first) return std::nullopt;
+            auto second = eval_matrix(m.b);
+            if (!second) return std::nullopt;
+            auto what = eval_matrix(m.c);
+            if (!what) return std::nullopt;
+            return *second * first->inverse() * *what;
+        }
+        case Matrix::Simple:
+            return srt(DVec3(m.scale * (m.mirror[0] ? -1.0 : 1.0), m.scale * (m.mirror[1] ? -1.0 : 1.0), m.scale * (m.mirror[2] ? -1.0 : 1.0)), m.rotate, m.offset);
+        case Matrix::Parametrized: {
+            double v[10];
+            // evaluation order of the reference: scale, mirror xyz, rotate xyz, offset xyz
+            auto s = eval_param(m.p[9]);
+            if (!s) return std::nullopt;
+            v[9] = *s;
+            for (int k : {6, 7, 8, 3, 4, 5, 0, 1, 2}) {
+                auto x = eval_param(m.p[k]);
+                if (!x) return std::nullopt;
+                v[k] = *x;
+            }
+            return srt(DVec3(v[9] * (1.0 - 2.0 * v[6]), v[9] * (1.0 - 2.0 * v[7]), v[9] * (1.0 - 2.0 * v[8])), DVec3(v[3], v[4], v[5]), DVec3(v[0], v[1], v[2]));
+        }
+        case Matrix::Exact: {
+            double v[12];
+            for (int k = 0; k < 12; ++k) {
+                auto x = eval_param(m.p[k]);
+                if (!x) return std::nullopt;
+                v[k] = *x;
+            }
+            return DMat4::from_cols({v[0], v[1], v[2], 0.0}, {v[3], v[4], v[5], 0.0}, {v[6], v[7], v[8], 0.0}, {v[9], v[10], v[11], 1.0});
+        }
+        case Matrix::ExactFull: {
+            double v[16];
+            for (int k = 0; k < 16; ++k) {
+                auto x = eval_param(m.p[k]);
+                if (!x) return std::nullopt;
+                v[k] = *x;
+            }
+            return DMat4::from_cols({v[0], v[1], v[2], v[3]}, {v[4], v[5], v[6], v[7]}, {v[8], v[9], v[10], v[11]}, {v[12], v[13], v[14], v[15]});
+        }
+        case Matrix::If: {
+            auto c = eval_param(m.cond);
+            if (!c) return std::nullopt;
+            return eval_matrix(*c > 0.5 ? m.a : m.b);
+        }
+        case Matrix::Inv: {
+            auto a = eval_matrix(m.a);
+            if (!a) return std::nullopt;
+            return a->inverse();
+        }
+        case Matrix::Camera: return camera_matrix;
+        case Matrix::Sqrt:
+        case Matrix::Lerp:
+            // src/gui/matrix.rs:593-617,909-988 (argmin BFGS matrix square root, TRS lerp): not used by
+            // any BASELINE config; reported as "can't be getted" until implemented.
+            return std::nullopt;
+    }
+    return std::nullopt;
+}
+
+}  // namespace ptl

@@ -1,0 +1,141 @@
+// scene.h -- in-memory scene model and its constant evaluator.
+//
+// Host-side mirror of the reference's L4 "scene model + evaluator" for exactly the part the
+// render path reads: src/gui/scene_serialized.rs:610-646 (on-disk schema),
+// :1102-1477 (deserialize_scene_new_format), src/gui/uniform.rs:268-278,1009-1140
+// (AnyUniform::get), src/gui/matrix.rs:16-65,510-631 (Matrix::get).  The reference keeps
+// elements in Storage2<T> graphs keyed by UniqueId (src/gui/storage2.rs); here elements are
+// plain vectors in declaration order and references are indices (-1 = None).  Inline
+// (unnamed) matrices get the generated name `id<N>`, like src/gui/object.rs:188-193.
+#pragma once
+#include <array>
+#include <map>
+#include <memory>
+#include <optional>
+#include <string>
+#include <vector>
+
+#include "dmath.h"
+#include "formula.h"
+#include "ron.h"
+
+namespace ptl {
+
+struct SceneError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// --- uniforms (src/gui/uniform.rs:268-278) ----------------------------------------------
+struct Uniform {
+    enum Kind { Bool, Int, Float, Angle, Progress, Formula, FormulaInt, Trefoil } kind = Float;
+    bool b = false;
+    int i = 0;
+    double f = 0.0;
+    std::string formula;
+};
+struct UniformValue {
+    enum Kind { Bool, Int, Float } kind = Float;
+    bool b = false;
+    int i = 0;
+    double f = 0.0;
+    double as_f64() const { return kind == Bool ? (b ? 1.0 : 0.0) : (kind == Int ? (double)i : f); }
+};
+struct UniformEntry {
+    std::string name;  // empty for inline uniforms
+    Uniform value;
+};
+
+// ParametrizeOrNot (src/gui/uniform.rs:330-334)
+struct Param {
+    bool is_uniform = false;
+    double value = 0.0;
+    int uniform = -1;
+};
+
+// --- matrices (src/gui/matrix.rs:16-65) ---------------------------------------------------
+struct Matrix {
+    enum Kind { Mul, Teleport, Simple, Parametrized, Exact, ExactFull, If, Sqrt, Lerp, Camera, Inv } kind = Simple;
+    int a = -1, b = -1, c = -1;  // Mul{to=a, what=b}; Teleport{first=a, second=b, what=c}; If{then=a, otherwise=b};
+                                 // Sqrt/Inv{a}; Lerp{first=a, second=b}
+    DVec3 offset, rotate;
+    double scale = 1.0;
+    bool mirror[3] = {false, false, false};
+    Param p[16];  // Parametrized: offset xyz [0..2], rotate xyz [3..5], mirror xyz [6..8], scale [9]
+                  // Exact: i,j,k,pos xyz [0..11]; ExactFull: c0..c3 xyzw [0..15]
+    Param cond;   // If.condition / Lerp.t
+};
+struct MatrixEntry {
+    std::string name;  // generated `id<N>` for inline matrices
+    bool named = false;
+    Matrix value;
+};
+
+// --- objects / materials (src/gui/object.rs:32-63, src/gui/material.rs:14-38) -------------
+enum class Subspace { Normal, Subspace, Both };
+struct Object {
+    enum Kind { DebugMatrix, Flat, Complex } kind = Flat;
+    bool portal = false;
+    int m0 = -1, m1 = -1;  // Simple(m0) / Portal(m0, m1) / DebugMatrix(m0)
+    std::string code;      // is_inside (Flat) or intersect (Complex) snippet
+    Subspace in_subspace = Subspace::Normal;
+    std::string name;
+};
+struct Material {
+    enum Kind { Simple, Reflect, Refract, Complex } kind = Simple;
+    double color[3] = {0.5, 0.2, 0.2};  // Simple.color / add_to_color
+    double normal_coef = 0.5, grid_scale = 4.0, grid_coef = 0.3, refractive_index = 1.0;
+    bool grid = true, grid2 = false, grid3 = false;
+    std::string code;
+    std::string name;
+};
+struct NamedCode {
+    std::string name, code;
+};
+struct Texture {
+    std::string name, path;
+};
+
+// Scene `cam` block (src/gui/scene.rs:33-52)
+struct CamSettings {
+    DVec3 look_at;
+    double alpha = 0.0, beta = 0.0, r = 3.5, offset_after_material = 0.000025;
+};
+
+class Scene {
+public:
+    static std::shared_ptr<Scene> from_ron_text(const std::string& text);
+    static std::shared_ptr<Scene> from_file(const std::string& path);
+
+    CamSettings cam;
+    std::vector<UniformEntry> uniforms;
+    std::vector<MatrixEntry> matrices;
+    std::vector<Object> objects;
+    std::vector<Material> materials;
+    std::vector<NamedCode> intersection_materials;
+    std::vector<NamedCode> library;
+    std::vector<Texture> textures;
+    std::optional<std::string> skybox;
+    bool use_time = false;
+
+    // formula time inputs (FormulasCache, src/gui/uniform.rs:625-697)
+    double time = 0.0, total_time = 0.0;
+    DMat4 camera_matrix = DMat4::identity();
+
+    int find_uniform(const std::string& name) const;
+    int find_matrix(const std::string& name) const;
+
+    // AnyUniform::get / Matrix::get; nullopt = "can't be getted" in the reference
+    std::optional<UniformValue> eval_uniform(int index) const;
+    std::optional<DMat4> eval_matrix(int index) const;
+    std::optional<double> eval_param(const Param& p) const;
+
+    // overrides (what a stage / animation / user slider does): set the stored value
+    bool set_uniform_value(const std::string& name, double v);
+
+private:
+    mutable std::map<std::string, std::shared_ptr<Formula>> formula_cache_;
+    mutable std::vector<char> uniform_busy_, matrix_busy_;  // cycle guards (Storage2::get)
+    std::optional<double> eval_formula(const std::string& text) const;
+};
+
+}  // namespace ptl
