@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- Mray/s and ms/frame of the portal trace kernel on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU.  A "step" is one full frame of the headline
+workload (BASELINE.json: scenes/portal_in_portal.ron, 3840x2160, aa 1, depth 40): every rank
+renders its interleaved row blocks (no data-path collective while tracing), then ONE gather of
+the RGBA8 shards to rank 0 over RCCL and a de-interleave copy assemble the image.  Inputs
+(scene constants, portal matrices) are resident in device constant memory before the timed
+region; the frame stays in HBM (no host copy inside the timed region).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (ptl_render_kernel):
+algorithmic bytes = the RGBA8 framebuffer this launch stores (W*H*4 / N), divided by the
+kernel's mean launch time measured with HIP events on the launch stream.  The kernel is
+FP32-VALU- and divergence-bound, so that HBM fraction is tiny by construction;
+`roofline_valu` reports the figure that actually bounds it.  `cpu_baseline` times the same
+generated source compiled for the host (oracle/host_build.py, "port") on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
+
+# counted by the numpy oracle (oracle/flops.py), executed binary32 operations per bounce-loop trip
+# (fma = 2); filled in per scene as they are measured, None = not yet counted
+FLOPS_PER_SEGMENT = {}
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--scene", default="portal_in_portal")
+    p.add_argument("--width", type=int, default=3840)
+    p.add_argument("--height", type=int, default=2160)
+    p.add_argument("--depth", type=int, default=40)
+    p.add_argument("--aa", type=int, default=1)
+    p.add_argument("--panini", type=float, default=-1.0, help="Panini d parameter (enables the projection); fov via --fov")
+    p.add_argument("--fov", type=float, default=90.0)
+    p.add_argument("--specialize", type=int, default=0, help="1: bake Bool/Int uniforms into the kernel")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    p.add_argument("--save-png", default="")
+    return p.parse_args()
+
+
+def cpu_baseline(args, pa):
+    """The host build of the same generated kernel, timed on a bounded sample of the same frame:
+    every `stride`-th 8-row block (so cheap and expensive image regions are both sampled)."""
+    from oracle import host_build as hb
+
+    scene = pa.Scene.from_file(pa.scene_path(args.scene))
+    ref = pa.SceneRenderer(scene, device=-1)
+    configure(ref, args)
+    hk = hb.host_kernel_for(ref, scene, args.width, args.height)
+    cores = os.cpu_count() or 1
+    blocks = (args.height + 7) // 8
+    # calibrate on one block from the middle, then pick the sample size
+    t0 = time.perf_counter()
+    hk.render(args.width, args.height, rows=(8 * (blocks // 2), min(args.height, 8 * (blocks // 2) + 8)), threads=cores, rgba32f=False)
+    per_block = max(time.perf_counter() - t0, 1e-4)
+    n_blocks = int(max(4, min(blocks, args.cpu_seconds / per_block)))
+    stride = max(1, blocks // n_blocks)
+    picked = list(range(0, blocks, stride))
+    rays = 0
+    t0 = time.perf_counter()
+    for b in picked:
+        r0, r1 = 8 * b, min(args.height, 8 * b + 8)
+        hk.render(args.width, args.height, rows=(r0, r1), threads=cores, rgba32f=False)
+        rays += (r1 - r0) * args.width * args.aa
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(rays / dt / 1e6, 4),
+        "unit": "Mray/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{len(picked)} of {blocks} 8-row blocks (every {stride}th) of the {args.width}x{args.height} frame, "
+                  f"{rays} primary rays in {dt:.2f} s, g++ -O2 -ffp-contract=off -mfma -fopenmp",
+    }
+
+
+def configure(renderer, args):
+    renderer.set_option("render_depth", args.depth)
+    renderer.set_option("aa_count", args.aa)
+    if args.panini >= 0.0:
+        renderer.set_option("use_panini_projection", 1)
+        renderer.set_option("panini_param", args.panini)
+    renderer.set_option("view_angle", args.fov / 180.0 * np.pi)
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import portal_amd as pa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the render path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H = args.width, args.height
+    scene = pa.Scene.from_file(pa.scene_path(args.scene))
+    renderer = pa.SceneRenderer(scene, device=local_rank, flags=pa.FLAG_SPECIALIZE_INTS if args.specialize else 0)
+    configure(renderer, args)
+    frame = pa.Frame(W, H, rank, world)
+    rows = pa.shard_rows(frame)
+    blocks = (H + 7) // 8
+    blocks_max = (blocks + world - 1) // world
+    # shard buffer padded to blocks_max so every rank contributes the same byte count to the gather
+    shard = torch.zeros((blocks_max * 8, W, 4), dtype=torch.uint8, device=dev)
+    gathered = [torch.empty_like(shard) for _ in range(world)] if (world > 1 and rank == 0) else None
+    full = torch.empty((blocks_max * world * 8, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    stream = torch.cuda.current_stream(dev)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        renderer.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream)
+        if ev is not None:
+            ev[1].record(stream)
+        if world > 1:
+            dist.gather(shard, gathered, dst=0)
+            if rank == 0:
+                # block b = k*world + g lives in gathered[g] at local block k: one strided copy
+                torch.stack(gathered, dim=1, out=full.view(blocks_max, world, 8, W, 4))
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
+    kernel_ms = float(kms.item())
+
+    # bounce-loop trips per frame (untimed, separate kernel variant with the counter compiled in)
+    segments = None
+    try:
+        counting = pa.SceneRenderer(scene, device=local_rank, flags=pa.FLAG_COUNT_SEGMENTS)
+        configure(counting, args)
+        seg = torch.zeros(1, dtype=torch.int64, device=dev)
+        counting.draw_device(frame, segments=seg.data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.all_reduce(seg)
+        segments = int(seg.item())
+        del counting
+    except Exception as e:  # the headline number does not depend on it
+        print(f"[bench] segment count unavailable: {e}", file=sys.stderr)
+
+    if rank == 0:
+        if args.save_png:
+            img = (full if world > 1 else shard)[:H].cpu().numpy()
+            pa.png_write(args.save_png, img)
+        rays = W * H * args.aa
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rays * args.steps / elapsed / 1e6
+        launch_bytes = rows * W * 4  # RGBA8 stored by this rank's launch
+        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mray/s (primary rays) + ms/frame at 3840x2160, portal_in_portal depth=40",
+            "value": round(value, 3),
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic: the reference's shipped scene file, no stage applied, camera from the scene `cam` block",
+            "config": {
+                "workload": f"scenes/{args.scene}.ron {W}x{H} aa={args.aa} depth={args.depth}"
+                            + (f" panini d={args.panini} fov={args.fov}" if args.panini >= 0 else ""),
+                "parallelism": f"row-block interleave x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
+                "specialize_ints": bool(args.specialize),
+            },
+            "kernel_ms": round(kernel_ms, 4),
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 3),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6),
+                "traffic": None,
+                "note": "algorithmic bytes = RGBA8 framebuffer store only; the kernel is FP32-VALU/divergence-bound, see roofline_valu",
+            },
+        }
+        if segments is not None:
+            out["segments_per_frame"] = segments
+            out["segment_mray_s"] = round(segments / (ms_per_step * 1e-3) / 1e6, 3)
+            fl = FLOPS_PER_SEGMENT.get(args.scene)
+            if fl:
+                tf = segments * fl / (kernel_ms * 1e-3) / 1e12 / world
+                out["roofline_valu"] = {"bound": "valu_fp32", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": round(tf / FP32_PEAK_TFLOPS, 5), "flops_per_segment": fl}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, pa)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": str(e)[:300]}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

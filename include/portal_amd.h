@@ -128,6 +128,10 @@ int ptl_scene_eval_matrix(ptl_scene* s, const char* name, double out16[16]);
 /* Scene `cam` block: look_at xyz, alpha, beta, r, offset_after_material. */
 int ptl_scene_cam(ptl_scene* s, double out7[7]);
 
+/* Texture `index` of the scene: name ("monoportal") and path ("scenes/img/monoportal.png").
+ * Returns 1 when index is past the end. */
+int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char* path, size_t path_cap);
+
 /* Scene::generate_shader_code: returns a malloc'ed NUL-terminated HIP C++ source (free with
  * ptl_free).  flags: bit0 = bake Bool/Int uniforms as literals, bit1 = count segments. */
 int ptl_scene_generate_source(ptl_scene* s, unsigned flags, char** source);

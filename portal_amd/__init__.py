@@ -67,6 +67,7 @@ def _load() -> C.CDLL:
         "ptl_scene_eval_uniform": (ci, [vp, cp, P(ci), P(cd)]),
         "ptl_scene_eval_matrix": (ci, [vp, cp, P(cd)]),
         "ptl_scene_cam": (ci, [vp, P(cd)]),
+        "ptl_scene_texture": (ci, [vp, ci, cp, cs, cp, cs]),
         "ptl_scene_generate_source": (ci, [vp, C.c_uint, P(vp)]),
         "ptl_scene_uniform_layout": (ci, [vp, P(P(UniformDesc)), P(ci), P(cs)]),
         "ptl_scene_set_uniforms": (ci, [vp, vp]),
@@ -194,6 +195,15 @@ class Scene:
         out = (C.c_double * 7)()
         _check(lib().ptl_scene_cam(self._h, out), "scene_cam")
         return {"look_at": tuple(out[0:3]), "alpha": out[3], "beta": out[4], "r": out[5], "offset_after_material": out[6]}
+
+    def textures(self) -> dict:
+        """name -> path of the scene's textures (src/gui/texture.rs)."""
+        out, i = {}, 0
+        name, path = C.create_string_buffer(256), C.create_string_buffer(1024)
+        while lib().ptl_scene_texture(self._h, i, name, 256, path, 1024) == 0:
+            out[name.value.decode()] = path.value.decode()
+            i += 1
+        return out
 
     def generate_source(self, flags: int = 0) -> str:
         """Scene::generate_shader_code: the complete HIP C++ translation unit."""

@@ -244,6 +244,14 @@ extern "C" int ptl_scene_cam(ptl_scene* s, double out7[7]) {
     return PTL_OK;
 }
 
+extern "C" int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char* path, size_t path_cap) {
+    if (!s || index < 0) return PTL_ERR_INVALID;
+    if (index >= (int)s->scene->textures.size()) return 1;
+    copy_str(name, name_cap, s->scene->textures[index].name);
+    copy_str(path, path_cap, s->scene->textures[index].path);
+    return PTL_OK;
+}
+
 static KernelOptions options_from_flags(unsigned flags) {
     KernelOptions o;
     o.specialize_ints = (flags & 1u) != 0;
