@@ -65,22 +65,25 @@ def cpu_baseline(args, pa):
     ref = pa.SceneRenderer(scene, device=-1)
     configure(ref, args)
     hk = hb.host_kernel_for(ref, scene, args.width, args.height)
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     blocks = (args.height + 7) // 8
-    # calibrate on one block from the middle, then pick the sample size
+
+    def rows_of(block_ids):
+        return np.concatenate([np.arange(8 * b, min(args.height, 8 * b + 8)) for b in block_ids]).astype(np.int32)
+
+    # calibrate on 2*cores rows spread over the frame, then size the sample for ~cpu_seconds
+    calib = rows_of(range(0, blocks, max(1, blocks // max(1, cores // 4))))
     t0 = time.perf_counter()
-    hk.render(args.width, args.height, rows=(8 * (blocks // 2), min(args.height, 8 * (blocks // 2) + 8)), threads=cores, rgba32f=False)
-    per_block = max(time.perf_counter() - t0, 1e-4)
-    n_blocks = int(max(4, min(blocks, args.cpu_seconds / per_block)))
+    hk.render(args.width, args.height, rows=calib, threads=cores, rgba32f=False)
+    per_row = max(time.perf_counter() - t0, 1e-4) / len(calib)
+    n_blocks = int(max(cores // 8 + 1, min(blocks, args.cpu_seconds / (per_row * 8))))
     stride = max(1, blocks // n_blocks)
     picked = list(range(0, blocks, stride))
-    rays = 0
+    rows = rows_of(picked)
     t0 = time.perf_counter()
-    for b in picked:
-        r0, r1 = 8 * b, min(args.height, 8 * b + 8)
-        hk.render(args.width, args.height, rows=(r0, r1), threads=cores, rgba32f=False)
-        rays += (r1 - r0) * args.width * args.aa
+    hk.render(args.width, args.height, rows=rows, threads=cores, rgba32f=False)
     dt = time.perf_counter() - t0
+    rays = len(rows) * args.width * args.aa
     return {
         "value": round(rays / dt / 1e6, 4),
         "unit": "Mray/s",

@@ -55,7 +55,7 @@ class HostKernel:
         self.lib.ptl_host_uniform_block.restype = C.c_void_p
         self.lib.ptl_host_uniform_block.argtypes = [C.POINTER(C.c_ulong)]
         self.lib.ptl_host_render.restype = C.c_ulonglong
-        self.lib.ptl_host_render.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7
+        self.lib.ptl_host_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         size = C.c_ulong()
         self.block = self.lib.ptl_host_uniform_block(C.byref(size))
         assert size.value >= block_size, (size.value, block_size)
@@ -87,13 +87,17 @@ class HostKernel:
         return True
 
     def render(self, width: int, height: int, rows=None, cols=None, threads: int = 0, rgba8: bool = True, rgba32f: bool = True):
-        """Render the window rows=[r0,r1) x cols=[c0,c1) of a width x height frame."""
-        r0, r1 = rows if rows else (0, height)
+        """Render rows x cols of a width x height frame.  `rows` is a (r0, r1) range or an
+        explicit list/array of row indices (output row i = rows[i]); `cols` a (c0, c1) range."""
+        if rows is None:
+            rows = (0, height)
+        row_idx = np.arange(rows[0], rows[1], dtype=np.int32) if isinstance(rows, tuple) else np.ascontiguousarray(rows, dtype=np.int32)
         c0, c1 = cols if cols else (0, width)
-        a8 = np.zeros((r1 - r0, c1 - c0, 4), np.uint8) if rgba8 else None
-        a32 = np.zeros((r1 - r0, c1 - c0, 4), np.float32) if rgba32f else None
+        a8 = np.zeros((len(row_idx), c1 - c0, 4), np.uint8) if rgba8 else None
+        a32 = np.zeros((len(row_idx), c1 - c0, 4), np.float32) if rgba32f else None
         threads = threads or (os.cpu_count() or 1)
-        seg = self.lib.ptl_host_render(a8.ctypes.data if rgba8 else None, a32.ctypes.data if rgba32f else None, width, height, r0, r1, c0, c1, threads)
+        seg = self.lib.ptl_host_render(a8.ctypes.data if rgba8 else None, a32.ctypes.data if rgba32f else None, width, height,
+                                       row_idx.ctypes.data, len(row_idx), c0, c1, threads)
         return {"rgba8": a8, "rgba32f": a32, "segments": int(seg)}
 
 

@@ -69,23 +69,25 @@ extern "C" void* ptl_host_uniform_block(unsigned long* size) {
     return &glsl::ptl_u;
 }
 
-// Renders pixel rows [row_begin, row_end) x [0, width) into out_* (row 0 of the buffers =
-// row_begin), with `threads` OpenMP threads (static row-block schedule).  Returns the number
-// of bounce-loop trips when compiled with PTL_COUNT_SEGMENTS, else 0.
+// Renders the listed pixel rows x columns [col_begin, col_end) of a width x height frame into
+// out_* (output row i = rows[i]) with `threads` OpenMP threads.  Returns the number of
+// bounce-loop trips when compiled with PTL_COUNT_SEGMENTS, else 0.
 extern "C" unsigned long long ptl_host_render(uint8_t* out_rgba8, float* out_rgba32f, int width, int height,
-                                              int row_begin, int row_end, int col_begin, int col_end, int threads) {
+                                              const int* rows, int n_rows, int col_begin, int col_end, int threads) {
     unsigned long long segments = 0;
+    (void)width;
     (void)height;
     (void)threads;
     const int cols = col_end - col_begin;
-#pragma omp parallel for schedule(static, 1) num_threads(threads) reduction(+ : segments)
-    for (int py = row_begin; py < row_end; ++py) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : segments)
+    for (int i = 0; i < n_rows; ++i) {
+        const int py = rows[i];
 #ifdef PTL_COUNT_SEGMENTS
         ptl_segments_tls = 0;
 #endif
         for (int px = col_begin; px < col_end; ++px) {
             glsl::vec4 c = glsl::shade_pixel(glsl::vec2((float)px + 0.5f, (float)py + 0.5f));
-            long idx = (long)(py - row_begin) * cols + (px - col_begin);
+            long idx = (long)i * cols + (px - col_begin);
             if (out_rgba32f) {
                 float v[4] = {c.x, c.y, c.z, c.w};
                 std::memcpy(out_rgba32f + 4 * idx, v, sizeof v);

@@ -304,7 +304,8 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             u.offset = off;
             off += uniform_type_size(u.type);
         }
-        gk.uniform_block_size = (off + 7) & ~(size_t)7;
+        bool has_sampler = !list.empty() && list[0].type == UniformType::Sampler;  // pointer member -> 8-byte struct alignment
+        gk.uniform_block_size = has_sampler ? ((off + 7) & ~(size_t)7) : off;
         gk.uniforms = list;
 
         StringStorage s;
