@@ -133,7 +133,8 @@ int ptl_scene_cam(ptl_scene* s, double out7[7]);
 int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char* path, size_t path_cap);
 
 /* Scene::generate_shader_code: returns a malloc'ed NUL-terminated HIP C++ source (free with
- * ptl_free).  flags: bit0 = bake Bool/Int uniforms as literals, bit1 = count segments. */
+ * ptl_free).  flags: bit0 = bake Bool/Int scene uniforms as literals, bit1 = count segments,
+ * bit2 = bake every scene uniform (ints, floats, matrices; camera and other builtins stay dynamic). */
 int ptl_scene_generate_source(ptl_scene* s, unsigned flags, char** source);
 /* Scene::uniforms + layout: descs are owned by the scene handle and stay valid until the next
  * call of this function or ptl_scene_free. */

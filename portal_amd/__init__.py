@@ -25,6 +25,7 @@ os.environ.setdefault("PTL_CACHE_DIR", os.path.join(_HERE, "_cache"))
 PTL_MAT4, PTL_F32, PTL_I32, PTL_VEC2, PTL_VEC3, PTL_SAMPLER = range(6)
 FLAG_SPECIALIZE_INTS = 1
 FLAG_COUNT_SEGMENTS = 2
+FLAG_SPECIALIZE_ALL = 4
 
 
 class PortalError(RuntimeError):

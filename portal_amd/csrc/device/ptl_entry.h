@@ -12,7 +12,13 @@
 
 #if PTL_DEVICE_BUILD
 
-extern "C" __global__ void __launch_bounds__(256)
+#ifdef PTL_WAVES_PER_EU
+#define PTL_LAUNCH_BOUNDS __launch_bounds__(256, PTL_WAVES_PER_EU)
+#else
+#define PTL_LAUNCH_BOUNDS __launch_bounds__(256)
+#endif
+
+extern "C" __global__ void PTL_LAUNCH_BOUNDS
 ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this shard, or null
                   float* __restrict__ out_rgba32f,        // same, 4 floats per pixel, or null
                   int width, int height,                   // full frame size
@@ -30,6 +36,14 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
 
 #ifdef PTL_COUNT_SEGMENTS
     ptl_segments_lds[t] = 0u;
+#endif
+#ifdef PTL_UNIFORMS_IN_LDS
+    {  // stage the scene constants (portal matrices, uniforms) in LDS once per workgroup
+        const unsigned int* src = reinterpret_cast<const unsigned int*>(&glsl::ptl_u);
+        unsigned int* dst = reinterpret_cast<unsigned int*>(&glsl::ptl_lds_u);
+        for (int i = t; i < (int)(sizeof(glsl::ptl_uniform_block) / 4); i += 256) dst[i] = src[i];
+        __syncthreads();
+    }
 #endif
     glsl::vec4 c = glsl::vec4(0.0f);
     if (live) c = glsl::shade_pixel(glsl::vec2((float)px + 0.5f, (float)py + 0.5f));

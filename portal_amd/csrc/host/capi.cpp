@@ -256,6 +256,7 @@ static KernelOptions options_from_flags(unsigned flags) {
     KernelOptions o;
     o.specialize_ints = (flags & 1u) != 0;
     o.count_segments = (flags & 2u) != 0;
+    o.specialize_all = (flags & 4u) != 0;
     return o;
 }
 

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <charconv>
 #include <cmath>
+#include <cstdio>
 #include <set>
 #include <sstream>
 
@@ -313,17 +314,38 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         for (auto& u : list) s.add_string(std::string("    ") + cxx_type(u.type) + " " + u.name + ";\n");
         s.add_string("};\n");
         s.add_string("#if PTL_DEVICE_BUILD\n__constant__ ptl_uniform_block ptl_u;\n#else\nptl_uniform_block ptl_u;\n#endif\n");
+        // where the kernel reads uniforms from: the __constant__ block through the scalar cache
+        // (default), or a per-workgroup LDS copy (-DPTL_UNIFORMS_IN_LDS, staged in ptl_entry.h)
+        s.add_string("#if PTL_DEVICE_BUILD && defined(PTL_UNIFORMS_IN_LDS)\n__shared__ ptl_uniform_block ptl_lds_u;\n#define PTL_U ptl_lds_u\n#else\n#define PTL_U ptl_u\n#endif\n");
         for (auto& u : list)
             s.add_string("static_assert(__builtin_offsetof(ptl_uniform_block, " + u.name + ") == " + std::to_string(u.offset) + ", \"uniform layout\");\n");
-        std::map<std::string, int> baked;
-        if (opts.specialize_ints) {
-            for (auto& up : evaluate_scene_uniforms(scene, nullptr))
-                if (up.type == UniformType::Int1) baked[up.name] = up.i;
+        // JIT-time specialisation: current values baked in as literals (same arithmetic, the
+        // compiler folds branches on mode switches / ray-independent subexpressions)
+        std::map<std::string, std::string> baked;
+        if (opts.specialize_ints || opts.specialize_all) {
+            auto hexf = [](float v) -> std::string {
+                if (std::isnan(v)) return "__builtin_nanf(\"\")";
+                if (std::isinf(v)) return v > 0 ? "__builtin_inff()" : "(-__builtin_inff())";
+                char buf[48];
+                std::snprintf(buf, sizeof buf, "%af", (double)v);
+                return buf;
+            };
+            for (auto& up : evaluate_scene_uniforms(scene, nullptr)) {
+                if (up.type == UniformType::Int1) {
+                    baked[up.name] = std::to_string(up.i);
+                } else if (opts.specialize_all && up.type == UniformType::Float1) {
+                    baked[up.name] = hexf(up.f[0]);
+                } else if (opts.specialize_all && up.type == UniformType::Mat4) {
+                    std::string m = "mat4(";
+                    for (int k = 0; k < 16; ++k) m += (k ? ", " : "") + hexf(up.f[k]);
+                    baked[up.name] = m + ")";
+                }
+            }
         }
         for (auto& u : list) {
             auto it = baked.find(u.name);
-            if (it != baked.end()) s.add_string("#define " + u.name + " (" + std::to_string(it->second) + ")\n");
-            else s.add_string("#define " + u.name + " (ptl_u." + u.name + ")\n");
+            if (it != baked.end()) s.add_string("#define " + u.name + " (" + it->second + ")\n");
+            else s.add_string("#define " + u.name + " (PTL_U." + u.name + ")\n");
         }
         storages["uniforms"] = std::move(s);
     }

@@ -62,6 +62,7 @@ size_t uniform_type_size(UniformType t);
 
 struct KernelOptions {
     bool specialize_ints = false;  // bake current Bool/Int uniform values in as literals (recompile when they change)
+    bool specialize_all = false;   // also bake Float / matrix scene uniforms (not the camera / builtins)
     bool count_segments = false;   // compile with PTL_COUNT_SEGMENTS
 };
 

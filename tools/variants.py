@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""tools/variants.py -- time kernel build variants on the GPU (development aid, not a test).
+
+usage: python tools/variants.py [scene:W:H:depth:aa ...]   (defaults: the BASELINE configs)
+Variants are hiprtc flag sets passed through PTL_HIPRTC_FLAGS; each is compiled (cached),
+run 6 times, and the median kernel time, register counts and an output checksum are printed
+(the checksum must not change between variants: they are all the same arithmetic).
+"""
+import hashlib, os, re, subprocess, sys, json
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+VARIANTS = {
+    "base": "",
+    "spec": "SPECIALIZE",
+    "spec_w3": "SPECIALIZE -DPTL_WAVES_PER_EU=3",
+    "spec_w4": "SPECIALIZE -DPTL_WAVES_PER_EU=4",
+    "all": "SPECIALIZE_ALL",
+    "all_w3": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=3",
+    "all_w4": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4",
+    "w4": "-DPTL_WAVES_PER_EU=4",
+}
+CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1"]
+
+
+def notes(code):
+    path = "/tmp/_variant.hsaco"
+    open(path, "wb").write(code)
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", path], capture_output=True, text=True).stdout
+    g = lambda k: (re.findall(re.escape(k) + r":\s*(\d+)", out) or ["?"])[0]
+    return f"v{g('.vgpr_count')} a{g('.agpr_count')} s{g('.sgpr_count')} ss{g('.sgpr_spill_count')} vs{g('.vgpr_spill_count')} scr{g('.private_segment_fixed_size')}"
+
+
+def run_one(case, vname, flags):
+    import portal_amd as pa
+    scene_name, w, h, d, aa = case.split(":")
+    w, h, d, aa = int(w), int(h), int(d), int(aa)
+    toks = flags.split()
+    rflags = (pa.FLAG_SPECIALIZE_INTS if "SPECIALIZE" in toks else 0) | (pa.FLAG_SPECIALIZE_ALL if "SPECIALIZE_ALL" in toks else 0)
+    os.environ["PTL_HIPRTC_FLAGS"] = " ".join(t for t in toks if t.startswith("-"))
+    scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    r = pa.SceneRenderer(scene, device=0, flags=rflags)
+    r.set_option("render_depth", d)
+    r.set_option("aa_count", aa)
+    times, digest = [], None
+    for k in range(6):
+        out = r.draw(w, h, rgba8=True)
+        times.append(out["ms"])
+        digest = hashlib.sha1(out["rgba8"].tobytes()).hexdigest()[:10]
+    return {"case": case, "variant": vname, "ms": float(np.median(times[1:])), "min_ms": float(min(times)), "regs": notes(r.code_object()), "sha": digest}
+
+
+if __name__ == "__main__":
+    cases = [a for a in sys.argv[1:] if ":" in a] or CASES
+    names = [a for a in sys.argv[1:] if ":" not in a] or list(VARIANTS)
+    for case in cases:
+        for v in names:
+            try:
+                print(json.dumps(run_one(case, v, VARIANTS[v])), flush=True)
+            except Exception as e:
+                print(json.dumps({"case": case, "variant": v, "error": str(e)[:400]}), flush=True)
