@@ -1,0 +1,694 @@
+"""oracle/portal_oracle.py -- CPU oracle for the per-pixel recursive portal ray tracer.
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may import anything under oracle/; the product (portal_amd/) never does.
+
+PARITY UNPINNED: the reference ships no CPU tracer, no golden image and no known-answer vector
+for this path, and it cannot be built or run here
+(no Rust toolchain, no GL context).  This oracle is therefore a restatement, pinned only by
+the hand-derived known-answer tests in tests/test_oracle_kat.py.
+
+What it restates, in numpy over "lanes" (one lane = one pixel sample), independently of the
+product's C++ host code, of its GLSL->C++ translator and of its device prelude:
+  src/library.glsl (all)            -> the `Natives` below (names/arguments are the interface
+                                       scene snippets call, so they are kept)
+  src/frag.glsl                     -> ray_tracing(), get_color2(), shade_pixels()
+  src/gui/scene.rs:885-1035         -> scene_intersect(), material_process(),
+                                       scene_intersect_material_process(): what the generated
+                                       code computes, interpreted directly from the scene model
+  src/gui/scene.rs:1674-1697        -> pixel centre -> uv_screen
+  scene snippets (GLSL in .ron)     -> executed by oracle/glsl_interp.py
+Arithmetic: binary32 under the numerics contract (oracle/glsl_math.py).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import glsl_math as M
+from . import glsl_values as V
+from .glsl_interp import Interp
+from .glsl_values import Mat, Sampler, Struct, Vec
+from .scene_eval import OracleScene, builtin_uniforms
+
+F32, I32 = np.float32, np.int32
+
+CUSTOM_MATERIAL, NOT_INSIDE, TELEPORT, TELEPORT_SUBSPACE = -1, 0, 1, 2
+DEBUG_RED, DEBUG_GREEN, DEBUG_BLUE, USER_MATERIAL_OFFSET = 3, 4, 5, 10
+
+STRUCTS = {  # src/library.glsl:40-46,127-133,297-301,405-409,595-598
+    "Ray": [("vec4", "o"), ("vec4", "d"), ("float", "tmul"), ("bool", "in_subspace")],
+    "SurfaceIntersection": [("bool", "hit"), ("float", "t"), ("float", "u"), ("float", "v"), ("vec3", "n")],
+    "MaterialProcessing": [("bool", "is_final"), ("vec3", "mul_to_color"), ("Ray", "new_ray")],
+    "SceneIntersection": [("int", "material"), ("SurfaceIntersection", "hit"), ("bool", "in_subspace")],
+    "SceneIntersectionWithMaterial": [("SceneIntersection", "scene"), ("MaterialProcessing", "material")],
+}
+
+
+def fl(x):
+    return F32(x)
+
+
+def vec(*c):
+    return Vec(c)
+
+
+def add(a, b):
+    return V.binop("+", a, b)
+
+
+def sub(a, b):
+    return V.binop("-", a, b)
+
+
+def mul(a, b):
+    return V.binop("*", a, b)
+
+
+def div(a, b):
+    return V.binop("/", a, b)
+
+
+def xyz(v: Vec) -> Vec:
+    return Vec(v.c[:3])
+
+
+def mk(tname, **f):
+    return Struct(tname, f)
+
+
+def Ray(o, d, tmul, in_subspace):
+    return mk("Ray", o=o, d=d, tmul=M.f32(tmul), in_subspace=np.asarray(in_subspace, bool))
+
+
+def Surf(hit, t, u, v, n):
+    return mk("SurfaceIntersection", hit=np.asarray(hit, bool), t=M.f32(t), u=M.f32(u), v=M.f32(v), n=n)
+
+
+def SceneI(material, hit, in_subspace):
+    return mk("SceneIntersection", material=np.asarray(material, I32), hit=hit, in_subspace=np.asarray(in_subspace, bool))
+
+
+def MatProc(is_final, mul_to_color, new_ray):
+    return mk("MaterialProcessing", is_final=np.asarray(is_final, bool), mul_to_color=mul_to_color, new_ray=new_ray)
+
+
+RAY_NONE = Ray(vec(0, 0, 0, 0), vec(0, 0, 0, 0), 0.0, False)               # library.glsl:53
+INTERSECTION_NONE = Surf(False, fl(1e10), 0.0, 0.0, vec(0, 0, 0))            # library.glsl:136
+SCENE_INTERSECTION_NONE = SceneI(0, INTERSECTION_NONE, False)                # library.glsl:411
+
+
+# =============================================================================================
+# src/library.glsl restated on the value model.  Each function is pure and evaluates all
+# lanes; data-dependent branches become selects.
+# =============================================================================================
+class Natives:
+    def __init__(self, uniforms):
+        self.u = uniforms  # name -> value (0-d arrays / Vec / Mat)
+
+    # -- library.glsl:19-34
+    @staticmethod
+    def between(a, x, b):
+        return M.le(a, x) & M.le(x, b)
+
+    @staticmethod
+    def sqr(a):
+        return M.mul(a, a)
+
+    def sqrvec(self, v):
+        return vec(self.sqr(v.c[0]), self.sqr(v.c[1]), self.sqr(v.c[2]))
+
+    # -- library.glsl:48-51
+    @staticmethod
+    def offset_ray(r, t):
+        return r.with_field("o", add(r.f["o"], mul(r.f["d"], t)))
+
+    # -- library.glsl:56-62
+    @staticmethod
+    def normalize_normal(normal, direction):
+        normal = V.normalize(normal)
+        flip = M.gt(V.dot(normal, direction), fl(0))
+        return V.select(flip, mul(normal, fl(-1.0)), normal)
+
+    # -- library.glsl:65-67
+    @staticmethod
+    def is_collinear(a, b):
+        q = M.div(V.dot(a, b), M.mul(V.length(a), V.length(b)))
+        return M.lt(M.absf(M.sub(q, fl(1.0))), M.lit("0.01"))
+
+    # -- library.glsl:70-72
+    @staticmethod
+    def my_reflect(direction, normal):
+        t = div(mul(normal, V.dot(direction, normal)), V.dot(normal, normal))
+        return sub(direction, mul(t, fl(2.0)))
+
+    # -- library.glsl:75-92
+    def my_refract(self, direction, normal, refractive_index):
+        ri = M.f32(refractive_index)
+        from_outside = M.gt(V.dot(normal, direction), fl(0))
+        ri = V.select(from_outside, ri, M.div(fl(1.0), ri))
+        normal = V.select(from_outside, V.neg(normal), normal)
+        direction = V.normalize(direction)
+        c = M.neg(V.dot(normal, direction))
+        d = M.sub(fl(1.0), M.mul(M.mul(ri, ri), M.sub(fl(1.0), M.mul(c, c))))
+        refr = add(mul(direction, ri), mul(normal, M.sub(M.mul(ri, c), M.sqrt(d))))
+        return V.select(M.gt(d, fl(0)), refr, self.my_reflect(direction, normal))
+
+    # -- library.glsl:95-120
+    @staticmethod
+    def transform(matrix, r):
+        return Ray(mul(matrix, r.f["o"]), mul(matrix, r.f["d"]), r.f["tmul"], r.f["in_subspace"])
+
+    @staticmethod
+    def get_normal(matrix):
+        return xyz(mul(matrix, vec(0.0, 0.0, 1.0, 0.0)))
+
+    @staticmethod
+    def normalize_ray(r):
+        ln = V.length(r.f["d"])
+        return r.with_field("d", div(r.f["d"], ln)).with_field("tmul", M.div(r.f["tmul"], ln))
+
+    @staticmethod
+    def adjugate(m):
+        c0, c1, c2 = xyz(m.cols[0]), xyz(m.cols[1]), xyz(m.cols[2])
+        return Mat([V.cross(c1, c2), V.cross(c2, c0), V.cross(c0, c1)])
+
+    # -- library.glsl:138-162
+    @staticmethod
+    def plane_intersect_normalized(r):
+        o, d = r.f["o"], r.f["d"]
+        t = M.div(M.neg(o.c[2]), d.c[2])
+        pos = add(o, mul(d, t))
+        hit = Surf(True, t, pos.c[0], pos.c[1], vec(0.0, 0.0, 1.0))
+        return V.select(M.lt(t, fl(0)), INTERSECTION_NONE, hit)
+
+    def plane_intersect(self, r, plane_inv, normal):
+        normal = self.normalize_normal(normal, xyz(r.f["d"]))
+        r = self.transform(plane_inv, r)
+        ln = V.length(r.f["d"])
+        r = r.with_field("d", V.normalize(r.f["d"]))
+        res = self.plane_intersect_normalized(r)
+        hit = res.f["hit"]
+        res = res.with_field("t", V.select(hit, M.div(res.f["t"], ln), res.f["t"]))
+        return res.with_field("n", V.select(hit, normal, res.f["n"]))
+
+    # -- library.glsl:169-288
+    @staticmethod
+    def color(r, g, b):
+        return vec(M.mul(r, r), M.mul(g, g), M.mul(b, b))
+
+    def color_normal(self, normal, direction):
+        if int(self.u["_angle_color_disable"]) == 1:
+            return fl(1.0)
+        return M.absf(V.dot(V.normalize(xyz(direction)), V.normalize(normal)))
+
+    def color_grid(self, start, uv):
+        if int(self.u["_grid_disable"]) == 1:
+            return start
+        uv = V.map1(M.fract, mul(uv, fl(0.25)))
+        sx, sy = M.step(uv.c[0], fl(0.5)), M.step(uv.c[1], fl(0.5))
+        a = M.mix(M.lit("0.7"), M.lit("1.1"), sx)
+        b = M.mix(M.lit("1.1"), M.lit("0.7"), sx)
+        return mul(start, M.mix(a, b, sy))
+
+    @staticmethod
+    def circle_sdf(position):
+        s = vec(fl(2.0), M.mul(M.sqrt(fl(3.0)), fl(2.0)))
+        position = div(position, s)
+        d1 = mul(sub(V.map1(M.fract, position), fl(0.5)), s)
+        d2 = mul(sub(V.map1(M.fract, add(position, fl(0.5))), fl(0.5)), s)
+        return M.sub(M.sqrt(M.fmin(V.dot(d1, d1), V.dot(d2, d2))), fl(1.0))
+
+    def color_grid2(self, start, uv):
+        d = self.circle_sdf(uv)
+        val = V.select(M.lt(d, M.lit("-0.2")), M.lit("1.1"), M.lit("0.7"))
+        return mul(start, val)
+
+    def color_grid3(self, start, uv):
+        if int(self.u["_grid_disable"]) == 1:
+            return start
+        uv = sub(V.map1(M.fract, mul(uv, fl(0.5))), vec(0.5, 0.5))
+        dist = M.mul(M.fmax(M.absf(uv.c[0]), M.absf(uv.c[1])), fl(2.0))
+        edge = V.select(M.gt(uv.c[0], uv.c[1]), mul(start, M.lit("0.7")), mul(start, M.lit("1.2")))
+        inner = V.select(M.lt(dist, M.lit("0.94")), start, edge)
+        return V.select(M.gt(dist, M.lit("0.985")), mul(start, M.lit("0.4")), inner)
+
+    @staticmethod
+    def color_add_weighted(a, b, coef):
+        return add(mul(a, M.sub(fl(1.0), coef)), mul(b, coef))
+
+    # -- library.glsl:303-384
+    @staticmethod
+    def material_empty():
+        return MatProc(True, vec(0, 0, 0), RAY_NONE)
+
+    @staticmethod
+    def material_final(color):
+        return MatProc(True, color, RAY_NONE)
+
+    @staticmethod
+    def material_next(mul_color, new_ray):
+        return MatProc(False, mul_color, new_ray)
+
+    def material_simple2(self, hit, r, color, normal_coef, grid, grid_scale, grid_coef, grid2, grid3):
+        color = self.color_add_weighted(color, mul(color, self.color_normal(hit.f["n"], r.f["d"])), M.f32(normal_coef))
+        grid, grid2, grid3 = (np.asarray(x, bool) for x in (grid, grid2, grid3))
+        if grid.any():
+            cell = mul(vec(hit.f["u"], hit.f["v"]), M.f32(grid_scale))
+            pattern = V.select(grid3, self.color_grid3(color, cell), V.select(grid2, self.color_grid2(color, cell), self.color_grid(color, cell)))
+            color = V.select(grid, self.color_add_weighted(color, pattern, M.f32(grid_coef)), color)
+        return self.material_final(color)
+
+    def material_simple(self, hit, r, color, normal_coef, grid, grid_scale, grid_coef):
+        return self.material_simple2(hit, r, color, normal_coef, grid, grid_scale, grid_coef, False, False)
+
+    def material_reflect(self, hit, r, add_to_color):
+        d = Vec(list(self.my_reflect(xyz(r.f["d"]), hit.f["n"]).c) + [fl(0.0)])
+        r = r.with_field("d", d)
+        r = r.with_field("o", add(r.f["o"], mul(d, self.u["_offset_after_material"])))
+        return self.material_next(add_to_color, r)
+
+    def material_refract(self, hit, r, add_to_color, refractive_index):
+        d = Vec(list(self.my_refract(xyz(r.f["d"]), hit.f["n"], refractive_index).c) + [fl(0.0)])
+        r = r.with_field("d", d)
+        r = r.with_field("o", add(r.f["o"], mul(d, self.u["_offset_after_material"])))
+        return self.material_next(add_to_color, r)
+
+    def material_teleport_transformed(self, r, n=None):
+        r = r.with_field("o", add(r.f["o"], mul(r.f["d"], self.u["_offset_after_material"])))
+        return self.material_next(vec(1.0, 1.0, 1.0), self.normalize_ray(r))
+
+    def material_teleport(self, hit, r, teleport_matrix):
+        return self.material_teleport_transformed(self.transform(teleport_matrix, r), hit.f["n"])
+
+    def material_change_subspace(self, r):
+        return self.material_next(vec(1.0, 1.0, 1.0), r.with_field("in_subspace", ~r.f["in_subspace"]))
+
+    # -- library.glsl:413-423
+    @staticmethod
+    def nearer(result, current):
+        if result.tname != "SurfaceIntersection":
+            result = result.f["hit"]
+        if current.tname != "SurfaceIntersection":
+            current = current.f["hit"]
+        return current.f["hit"] & M.gt(current.f["t"], fl(0)) & (~result.f["hit"] | (result.f["hit"] & M.lt(current.f["t"], result.f["t"])))
+
+    # -- library.glsl:560-589
+    @staticmethod
+    def process_plane_intersection(i, hit, inside):
+        inside = np.asarray(inside, I32)
+        take = (inside != NOT_INSIDE) & (inside != TELEPORT) & (inside != TELEPORT_SUBSPACE)
+        return V.select(take, i.with_field("hit", hit).with_field("material", inside), i)
+
+    @staticmethod
+    def process_portal_intersection(i, hit, inside, teleport_material):
+        inside = np.asarray(inside, I32)
+        tm = np.asarray(teleport_material, I32)
+        is_tp = (inside == TELEPORT) | (inside == TELEPORT_SUBSPACE)
+        new = i.with_field("hit", hit).with_field("material", np.where(is_tp, tm, inside).astype(I32))
+        new = new.with_field("in_subspace", np.where(inside == TELEPORT_SUBSPACE, True, i.f["in_subspace"]))
+        return V.select(inside != NOT_INSIDE, new, i)
+
+
+def _wrap(fn):
+    return lambda interp, args, mask: fn(*args)
+
+
+# =============================================================================================
+# the tracer
+# =============================================================================================
+class Oracle:
+    def __init__(self, scene_path: str, asset_root: str | None = None):
+        self.scene = OracleScene(scene_path)
+        self.asset_root = asset_root or os.path.dirname(os.path.dirname(os.path.abspath(scene_path)))
+        self.options = dict(render_depth=100, aa_count=1, aa_start=0, view_angle=None, use_panini=False, panini_param=1.0)
+        self.camera = None
+        self._program = None
+        self.stats = {}
+
+    # ---- program = uniforms + natives + snippets, parsed once ---------------------------------
+    def _uniform_values(self, width, height):
+        vals = dict(self.scene.scene_uniform_values())
+        vals.update(builtin_uniforms(self.scene, width, height, camera=self.camera, **self.options))
+        out = {}
+        for name, v in vals.items():
+            a = np.asarray(v)
+            if a.shape == (16,):
+                out[name] = Mat([Vec(a[4 * c:4 * c + 4]) for c in range(4)])
+            elif a.shape == (2,):
+                out[name] = Vec(a)
+            else:
+                out[name] = a[()]
+        return out
+
+    def build(self, width, height):
+        from PIL import Image
+
+        uniforms = self._uniform_values(width, height)
+        prog = Interp(1)
+        prog.structs.update(STRUCTS)
+        prog.globals.update(uniforms)
+        for name, path in self.scene.textures:
+            prog.globals[name + "_tex"] = Sampler(np.array(Image.open(os.path.join(self.asset_root, path)).convert("RGBA")))
+        for name, mid in self.scene.material_ids().items():
+            prog.globals[name] = I32(mid)
+        consts = dict(CUSTOM_MATERIAL=CUSTOM_MATERIAL, NOT_INSIDE=NOT_INSIDE, TELEPORT=TELEPORT, TELEPORT_SUBSPACE=TELEPORT_SUBSPACE, DEBUG_RED=DEBUG_RED,
+                      DEBUG_GREEN=DEBUG_GREEN, DEBUG_BLUE=DEBUG_BLUE, USER_MATERIAL_OFFSET=USER_MATERIAL_OFFSET)
+        for k, v in consts.items():
+            prog.globals[k] = I32(v)
+        prog.globals["PI"] = M.acos(fl(-1.0))[()]                      # library.glsl:15
+        prog.globals["PI2"] = M.div(M.acos(fl(-1.0)), fl(2.0))[()]     # library.glsl:16
+        prog.globals["ray_none"] = RAY_NONE
+        prog.globals["intersection_none"] = INTERSECTION_NONE
+        prog.globals["scene_intersection_none"] = SCENE_INTERSECTION_NONE
+        nat = Natives(uniforms)
+        self.nat = nat
+        for name in ("between", "sqr", "sqrvec", "offset_ray", "normalize_normal", "is_collinear", "my_reflect", "my_refract", "transform", "get_normal",
+                     "normalize_ray", "adjugate", "plane_intersect_normalized", "plane_intersect", "color", "color_normal", "color_grid", "circle_sdf",
+                     "color_grid2", "color_grid3", "color_add_weighted", "material_empty", "material_final", "material_next", "material_simple2",
+                     "material_simple", "material_reflect", "material_refract", "material_teleport_transformed", "material_teleport",
+                     "material_change_subspace", "nearer", "process_plane_intersection", "process_portal_intersection"):
+            prog.natives[name] = _wrap(getattr(nat, name))
+        flags = dict(FOR_NUMBER=False, FOR_VARIABLE=True, ANTIALIASING=True, ANAGLYPH=False, CAMERA_TELEPORTATION=True, GLSL100=False, GLSL300=True)
+
+        def filt(code):  # the tagged-line filter, src/gui/scene.rs:1065-1107 (native defaults main.rs:935-941)
+            out = []
+            for line in code.split("\n"):
+                drop = any(("!" + tag + "!") in line and not keep for tag, keep in flags.items())
+                out.append("" if drop else line)
+            return "\n".join(out)
+
+        for _, code in self.scene.library:
+            prog.load_unit(filt(code))
+        for pos, o in enumerate(self.scene.objects):
+            if o["kind"] == "flat":
+                params = [("vec4", "pos"), ("float", "x"), ("float", "y"), ("bool", "back")] + ([("bool", "first")] if o["portal"] else [])
+                prog.define_function("int", f"is_inside_{pos}", params, filt(o["code"]))
+            elif o["kind"] == "complex":
+                params = [("Ray", "r")] + ([("bool", "first")] if o["portal"] else [])
+                prog.define_function("SceneIntersection", f"intersect_{pos}", params, filt(o["code"]))
+        for k, m in enumerate(self.scene.materials):
+            if m["kind"] == "Complex":  # the snippet sees `hit`, `r`, `i` (scene.rs:736-778, frag.glsl:33-35)
+                prog.define_function("MaterialProcessing", f"__material_{k}", [("SurfaceIntersection", "hit"), ("Ray", "r"), ("SceneIntersection", "i")], filt(m["code"]))
+        for k, (_, code) in enumerate(self.scene.intersection_materials):
+            prog.define_function("SceneIntersectionWithMaterial", f"intersect_material_{k}", [("Ray", "r")], filt(code))
+        self._program = prog
+        self.uniforms = uniforms
+        self.material_ids = self.scene.material_ids()
+
+    # ---- generated code, interpreted (scene.rs:885-1035) --------------------------------------
+    def _mat(self, idx, suffix):
+        return self.uniforms[self.scene.matrices[idx][0] + suffix]
+
+    def scene_intersect(self, it: Interp, r, mask):
+        nat, n = self.nat, it.n
+        i = V.expand(SceneI(0, INTERSECTION_NONE, False), n)
+        for pos, o in enumerate(self.scene.objects):
+            guard = mask
+            if o["sub"] == "Normal":
+                guard = mask & ~r.f["in_subspace"]
+            elif o["sub"] == "Subspace":
+                guard = mask & r.f["in_subspace"]
+            if not guard.any():
+                continue
+            M.set_active(guard.sum())
+            sides = [(o["m0"], True, f"teleport_{pos}_1_M"), (o["m1"], False, f"teleport_{pos}_2_M")] if o["portal"] else [(o["m0"], None, None)]
+            for midx, first, tmat in sides:
+                M.set_active(guard.sum())
+                if o["kind"] == "flat":
+                    gn = nat.get_normal(self._mat(midx, "_mat"))
+                    if first is None:      # Flat/Simple, scene.rs:912-927
+                        normal = V.neg(gn)
+                        hit = nat.plane_intersect(r, self._mat(midx, "_mat_inv"), gn)
+                    else:                  # Flat/Portal, scene.rs:928-948
+                        normal = V.neg(gn) if first else gn
+                        hit = nat.plane_intersect(r, self._mat(midx, "_mat_inv"), normal)
+                    near = guard & nat.nearer(i, hit)
+                    if not near.any():
+                        continue
+                    M.set_active(near.sum())
+                    pos_w = add(r.f["o"], mul(r.f["d"], hit.f["t"]))
+                    back = nat.is_collinear(hit.f["n"], normal)
+                    args = [pos_w, hit.f["u"], hit.f["v"], back] + ([np.full(n, first)] if first is not None else [])
+                    inside = V.expand(it.run_function(f"is_inside_{pos}", args, near), n)
+                    if first is None:
+                        new_i = nat.process_plane_intersection(i, hit, inside)
+                    else:
+                        new_i = nat.process_portal_intersection(i, hit, inside, I32(self.material_ids[tmat]))
+                    i = V.select(near, V.expand(new_i, n), i)
+                else:                      # Complex / DebugMatrix, scene.rs:893-904, 962-998
+                    tr = nat.transform(self._mat(midx, "_mat_inv"), r)
+                    ln = V.length(tr.f["d"])
+                    tr = nat.normalize_ray(tr)
+                    if o["kind"] == "debug":
+                        raise NotImplementedError("DebugMatrix objects are not restated in the oracle yet")
+                    args = [V.expand(tr, n)] + ([np.full(n, first)] if first is not None else [])
+                    ihit = V.expand(it.run_function(f"intersect_{pos}", args, guard), n)
+                    M.set_active(guard.sum())
+                    ihit = ihit.with_field("hit", ihit.f["hit"].with_field("t", M.div(ihit.f["hit"].f["t"], ln)))
+                    near = guard & nat.nearer(i, ihit)
+                    if first is not None:
+                        near = near & (ihit.f["material"] != NOT_INSIDE)
+                        tm = I32(self.material_ids[tmat])
+                        mat = ihit.f["material"]
+                        sub = ihit.f["in_subspace"] | (mat == TELEPORT_SUBSPACE)
+                        mat = np.where((mat == TELEPORT) | (mat == TELEPORT_SUBSPACE), tm, mat).astype(I32)
+                        ihit = ihit.with_field("material", mat).with_field("in_subspace", sub)
+                    if not near.any():
+                        continue
+                    M.set_active(near.sum())
+                    nrm = V.normalize(mul(nat.adjugate(self._mat(midx, "_mat")), ihit.f["hit"].f["n"]))
+                    ihit = ihit.with_field("hit", ihit.f["hit"].with_field("n", nrm))
+                    i = V.select(near, ihit, i)
+        return i
+
+    def material_process(self, it: Interp, r, i, mask):
+        """frag.glsl:33-50 + the generated else-if chain (scene.rs:726-840)."""
+        nat, n = self.nat, it.n
+        hit = i.f["hit"]
+        r = r.with_field("in_subspace", np.where(i.f["in_subspace"], ~r.f["in_subspace"], r.f["in_subspace"]))
+        out = V.expand(nat.material_final(vec(0.0, 0.0, 0.0)), n)  # unknown material id
+        mat = i.f["material"]
+
+        def put(sel, value):
+            nonlocal out
+            out = V.select(sel, V.expand(value, n), out)
+
+        for dbg, col in ((DEBUG_RED, (0.9, 0.2, 0.2)), (DEBUG_GREEN, (0.2, 0.9, 0.2)), (DEBUG_BLUE, (0.2, 0.2, 0.9))):
+            sel = mask & (mat == dbg)
+            if sel.any():
+                c = nat.color(*(M.lit(str(x)) for x in col))
+                put(sel, nat.material_simple2(hit, r, c, fl(0.5), False, fl(1.0), fl(0.0), False, False))
+        for k, m in enumerate(self.scene.materials):
+            sel = mask & (mat == self.material_ids[m["name"] + "_M"])
+            if not sel.any():
+                continue
+            M.set_active(sel.sum())
+            if m["kind"] == "Simple":
+                # the generator prints `{:e}` decimals of the f64 values, the GLSL compiler rounds them to binary32
+                c = vec(*(M.lit(repr(x)) for x in m["color"]))
+                put(sel, nat.material_simple2(hit, r, c, M.lit(repr(m["normal_coef"])), m["grid"], M.lit(repr(m["grid_scale"])), M.lit(repr(m["grid_coef"])),
+                                              m["grid2"], m["grid3"]))
+            elif m["kind"] == "Reflect":
+                put(sel, nat.material_reflect(hit, r, vec(*(M.lit(repr(x)) for x in m["color"]))))
+            elif m["kind"] == "Refract":
+                put(sel, nat.material_refract(hit, r, vec(*(M.lit(repr(x)) for x in m["color"])), M.lit(repr(m["refractive_index"]))))
+            else:
+                put(sel, it.run_function(f"__material_{k}", [V.expand(hit, n), V.expand(r, n), V.expand(i, n)], sel))
+        for pos, o in enumerate(self.scene.objects):
+            if o["kind"] == "debug" or not o["portal"] or o["m0"] < 0 or o["m1"] < 0:
+                continue
+            na, nb = self.scene.matrices[o["m0"]][0], self.scene.matrices[o["m1"]][0]
+            for which, tname in ((1, f"{na}_to_{nb}_mat_teleport"), (2, f"{nb}_to_{na}_mat_teleport")):
+                sel = mask & (mat == self.material_ids[f"teleport_{pos}_{which}_M"])
+                if sel.any():
+                    M.set_active(sel.sum())
+                    put(sel, nat.material_teleport(hit, r, self.uniforms[tname]))
+        return out
+
+    def scene_intersect_material_process(self, it: Interp, r, mask):
+        """frag.glsl:52-59 + scene.rs:1026-1035."""
+        n = it.n
+        result = V.expand(mk("SceneIntersectionWithMaterial", scene=SCENE_INTERSECTION_NONE, material=Natives.material_empty()), n)
+        for k in range(len(self.scene.intersection_materials)):
+            hit = V.expand(it.run_function(f"intersect_material_{k}", [V.expand(r, n)], mask), n)
+            near = mask & Natives.nearer(result.f["scene"].f["hit"], hit.f["scene"].f["hit"])
+            result = V.select(near, hit, result)
+        return result
+
+    # ---- frag.glsl:106-159 -----------------------------------------------------------------------
+    def ray_tracing(self, r, camera_scale):
+        """r: Ray over N lanes.  Returns (rgb float32 (N,3), segments per lane)."""
+        nat, u = self.nat, self.uniforms
+        N = len(np.asarray(r.f["tmul"]))
+        depth = int(u["_ray_tracing_depth"])
+        not_found = nat.color(M.lit("0.6"), M.lit("0.6"), M.lit("0.6"))
+        result = np.zeros((N, 3), F32)  # depth exhausted -> color(0,0,0)
+        segments = np.zeros(N, np.int64)
+        idx = np.arange(N)              # lanes still tracing
+        color = V.expand(vec(1.0, 1.0, 1.0), N)
+        all_t = np.zeros(N, F32)
+        t_start, t_end = u["_t_start"], u["_t_end"]
+        for _ in range(depth):
+            n = len(idx)
+            if n == 0:
+                break
+            it = Interp(n, self._program)
+            full = np.ones(n, bool)
+            segments[idx] += 1
+            M.set_active(n)
+            i = self.scene_intersect(it, r, full)
+            i2 = self.scene_intersect_material_process(it, r, full)
+            M.set_active(n)
+            use2 = nat.nearer(i.f["hit"], i2.f["scene"].f["hit"])
+            use1 = ~use2 & i.f["hit"].f["hit"]
+            t_hit = np.where(use2, i2.f["scene"].f["hit"].f["t"], i.f["hit"].f["t"]).astype(F32)
+            moved = use1 | use2
+            r_adv = r.with_field("o", V.select(moved, add(r.f["o"], mul(r.f["d"], t_hit)), r.f["o"]))
+            all_t = np.where(moved, M.add(all_t, M.mul(t_hit, r.f["tmul"])), all_t).astype(F32)
+            # reference leaves `m` unset when a snippet reports hit with t <= 0; defined as all-zero here too
+            m = V.expand(MatProc(False, vec(0.0, 0.0, 0.0), RAY_NONE), n)
+            custom = use2 & (i2.f["scene"].f["material"] == CUSTOM_MATERIAL)
+            m = V.select(custom, i2.f["material"], m)
+            via2 = use2 & ~custom
+            if via2.any():
+                m = V.select(via2, self.material_process(it, r_adv, i2.f["scene"], via2), m)
+            if use1.any():
+                m = V.select(use1, self.material_process(it, r_adv, i, use1), m)
+            M.set_active(n)
+            any_hit = i.f["hit"].f["hit"] | i2.f["scene"].f["hit"].f["hit"]
+            # escaped the scene
+            esc = ~any_hit
+            esc_col = V.select(r_adv.f["in_subspace"], vec(0.0, 0.0, 0.0), mul(color, not_found))
+            color_next = mul(color, m.f["mul_to_color"])
+            final = any_hit & m.f["is_final"]
+            # distance darkening (frag.glsl:135-146)
+            lim_lo, lim_hi = M.mul(t_start, camera_scale), M.mul(t_end, camera_scale)
+            dark = M.gt(all_t, lim_lo) & (int(u["_darken_by_distance"]) == 1)
+            at = np.where(M.gt(all_t, lim_hi), lim_hi, all_t).astype(F32)
+            gray = M.div(M.div(M.sub(at, lim_lo), M.sub(t_end, t_start)), camera_scale)
+            g4 = nat.sqr(nat.sqr(gray))
+            k4 = nat.sqr(nat.sqr(M.sub(fl(1.0), gray)))
+            darkened = add(mul(nat.color(fl(0.0), fl(0.0), fl(0.0)), g4), mul(color_next, k4))
+            fin_col = V.select(dark, darkened, color_next)
+            done = esc | final
+            out_col = V.select(esc, esc_col, fin_col)
+            if done.any():
+                lanes = idx[done]
+                for c in range(3):
+                    result[lanes, c] = np.broadcast_to(out_col.c[c], (n,))[done]
+            keep = ~done
+            idx = idx[keep]
+            if len(idx) == 0:
+                break
+            sel = np.nonzero(keep)[0]
+            r = V.take(V.expand(m.f["new_ray"], n), sel)
+            color = V.take(V.expand(color_next, n), sel)
+            all_t = all_t[sel]
+        return result, segments
+
+    # ---- frag.glsl:305-342 -----------------------------------------------------------------------
+    def panini(self, tc, fov, d):
+        pow2 = lambda x: M.mul(x, x)
+        d2 = M.mul(d, d)
+        pi05 = M.mul(M.lit("3.14159265359"), fl(0.5))
+        fo = M.sub(pi05, M.mul(fov, fl(0.5)))
+        f = M.div(M.cos(fo), M.sin(fo))
+        f2 = M.mul(f, f)
+        b = M.div(M.sub(M.sqrt(M.fmax(fl(0.0), M.mul(pow2(M.add(d, d2)), M.add(f2, M.mul(f2, f2))))), M.add(M.mul(d, f), f)),
+                  M.sub(M.add(d2, M.mul(d2, f2)), fl(1.0)))
+        tc = mul(tc, b)
+        h, v = tc.c
+        h2 = M.mul(h, h)
+        k = M.div(h2, pow2(M.add(d, fl(1.0))))
+        k2 = M.mul(k, k)
+        discr = M.fmax(fl(0.0), M.sub(M.mul(k2, d2), M.mul(M.add(k, fl(1.0)), M.sub(M.mul(k, d2), fl(1.0)))))
+        cos_phi = M.div(M.add(M.mul(M.neg(k), d), M.sqrt(discr)), M.add(k, fl(1.0)))
+        s_big = M.div(M.add(d, fl(1.0)), M.add(d, cos_phi))
+        tan_theta = M.div(v, s_big)
+        sin_phi = M.sqrt(M.fmax(fl(0.0), M.sub(fl(1.0), pow2(cos_phi))))
+        sin_phi = np.where(M.lt(tc.c[0], fl(0.0)), M.mul(sin_phi, fl(-1.0)), sin_phi).astype(F32)
+        s = M.inversesqrt(M.add(fl(1.0), pow2(tan_theta)))
+        return mul(vec(sin_phi, tan_theta, cos_phi), s)
+
+    # ---- frag.glsl:408-464 (pinhole / Panini) ------------------------------------------------------
+    def get_color2(self, image_position, camera, in_subspace, camera_scale):
+        u = self.uniforms
+        n = len(np.asarray(image_position.c[0]))
+        o = mul(camera, vec(0.0, 0.0, 0.0, 1.0))
+        if int(u["_use_panini_projection"]) == 1:
+            p = self.panini(vec(image_position.c[0], image_position.c[1]), u["_view_angle"], u["_panini_param"])
+            d = V.normalize(mul(camera, Vec(list(p.c) + [fl(0.0)])))
+        elif int(u["_use_360_camera"]) == 1 or int(u["_use_180_camera"]) == 1:
+            raise NotImplementedError("360/180 cameras are not restated in the oracle yet")
+        else:
+            h = M.tan(M.div(u["_view_angle"], fl(2.0)))
+            d = V.normalize(mul(camera, vec(M.mul(image_position.c[0], h), M.mul(image_position.c[1], h), fl(1.0), fl(0.0))))
+        ray = V.expand(Ray(o, d, fl(1.0), np.full(n, bool(in_subspace))), n)
+        rgb, seg = self.ray_tracing(ray, camera_scale)
+        if int(u["_draw_depth_map"]) == 1:
+            raise NotImplementedError("depth map colouring is not restated in the oracle yet")
+        return rgb, seg
+
+    # ---- frag.glsl:506-527,550-551 + vertex stage scene.rs:1674-1697 ---------------------------------
+    def shade_pixels(self, width, height, px, py):
+        """px, py: integer pixel coordinates (arrays).  Returns dict(rgba32f (N,4), rgba8 (N,4), segments (N,))."""
+        self.build(width, height)
+        M.reset_stats()
+        u = self.uniforms
+        res = u["_resolution"]
+        position = vec(M.add(M.f32(px), fl(0.5)), M.add(M.f32(py), fl(0.5)))
+        coef = M.fmin(res.c[0], res.c[1])
+        uv_screen = mul(div(sub(position, div(res, fl(2.0))), coef), fl(2.0))
+        pixel_size = M.div(fl(1.0), M.fmin(res.c[0], res.c[1]))
+        n = len(np.atleast_1d(px))
+        total = np.zeros((n, 3), F32)
+        segments = np.zeros(n, np.int64)
+        aa_start, aa_count = int(u["_aa_start"]), int(u["_aa_count"])
+        a1, a2 = M.lit("0.7548776662466927600500267982588025643670318456949186300834636687"), M.lit("0.5698402909980532659121818632752155853637566123932930564053138358")
+        for a in range(aa_start, aa_start + aa_count):
+            af = F32(a)
+            offset = vec(M.mod(M.add(fl(0.5), M.mul(a1, af)), fl(1.0)), M.mod(M.add(fl(0.5), M.mul(a2, af)), fl(1.0)))  # quasi_random
+            pos = add(uv_screen, mul(mul(offset, pixel_size), fl(2.0)))
+            rgb, seg = self.get_color2(V.expand(pos, n), u["_camera"], int(u["_camera_in_subspace"]) == 1, u["_camera_scale"])
+            total = M.add(total, rgb)
+            segments += seg
+        M.set_active(n)
+        rgb = M.sqrt(np.multiply(total, M.div(fl(1.0), F32(aa_count))))  # result / float(aa_count): vec / scalar contract
+        rgba = np.concatenate([rgb, np.ones((n, 1), F32)], axis=1)
+        self.stats = dict(M.STATS, segments=int(segments.sum()))
+        return dict(rgba32f=rgba, rgba8=to_rgba8(rgba), segments=segments)
+
+    def render(self, width, height, rows=None, cols=None):
+        r0, r1 = rows if rows else (0, height)
+        c0, c1 = cols if cols else (0, width)
+        ys, xs = np.meshgrid(np.arange(r0, r1), np.arange(c0, c1), indexing="ij")
+        out = self.shade_pixels(width, height, xs.ravel(), ys.ravel())
+        shape = (r1 - r0, c1 - c0)
+        return dict(rgba32f=out["rgba32f"].reshape(*shape, 4), rgba8=out["rgba8"].reshape(*shape, 4), segments=out["segments"].reshape(shape))
+
+
+def to_rgba8(rgba32f):
+    """GL fixed-point conversion: clamp to [0,1], *255, round to nearest (NaN -> 0)."""
+    v = np.asarray(rgba32f, F32)
+    with np.errstate(invalid="ignore"):
+        q = np.floor(M.fma(v, F32(255.0), F32(0.5)))
+        q = np.where(v >= 1.0, 255.0, np.where(v > 0.0, q, 0.0))
+    return q.astype(np.uint8)
+
+
+if __name__ == "__main__":
+    import sys
+    import time
+
+    from PIL import Image
+
+    path, w, h, depth = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    o = Oracle(path)
+    o.options["render_depth"] = depth
+    t0 = time.time()
+    out = o.render(w, h)
+    print(f"{time.time()-t0:.1f}s segments={o.stats['segments']} flops/segment={o.stats['flops']/max(1,o.stats['segments']):.0f}")
+    if len(sys.argv) > 5:
+        Image.fromarray(out["rgba8"]).save(sys.argv[5])

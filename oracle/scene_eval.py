@@ -1,0 +1,432 @@
+"""oracle/scene_eval.py -- scene file -> the constants a frame needs (oracle side).
+
+TEST INFRASTRUCTURE ONLY (CPU oracle).  Nothing under portal_amd/ may import this.
+
+Independent restatement (Python, binary64) of
+  * the on-disk schema and loader   src/gui/scene_serialized.rs:610-646, 1102-1230
+  * AnyUniform::get                  src/gui/uniform.rs:268-278, 1009-1140
+  * Matrix::get                      src/gui/matrix.rs:510-631  (+ glam 0.13.1 formulas, Cargo.lock:718)
+  * Scene::set_uniforms              src/gui/scene.rs:545-657   (X_mat, X_mat_inv, A_to_B_mat_teleport)
+  * RotateAroundCam::get_matrix      src/main.rs:278-304
+  * SceneRenderer::set_uniforms      src/main.rs:1266-1359      (builtin `_...` uniforms, defaults :1021-1040)
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import formula as F
+from . import ron
+
+# ---------------------------------------------------------------------------------------------
+# binary64 4x4 matrices as lists of 4 columns of 4 floats (glam: x_axis..w_axis)
+# ---------------------------------------------------------------------------------------------
+IDENT = [[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]]
+
+
+def m_mul_vec(m, v):
+    r = [m[0][i] * v[0] for i in range(4)]
+    for k in (1, 2, 3):
+        r = [m[k][i] * v[k] + r[i] for i in range(4)]
+    return r
+
+
+def m_mul(a, b):
+    return [m_mul_vec(a, col) for col in b]
+
+
+def m_inverse(m):
+    (m00, m01, m02, m03), (m10, m11, m12, m13), (m20, m21, m22, m23), (m30, m31, m32, m33) = m
+    c00 = m22 * m33 - m32 * m23; c02 = m12 * m33 - m32 * m13; c03 = m12 * m23 - m22 * m13
+    c04 = m21 * m33 - m31 * m23; c06 = m11 * m33 - m31 * m13; c07 = m11 * m23 - m21 * m13
+    c08 = m21 * m32 - m31 * m22; c10 = m11 * m32 - m31 * m12; c11 = m11 * m22 - m21 * m12
+    c12 = m20 * m33 - m30 * m23; c14 = m10 * m33 - m30 * m13; c15 = m10 * m23 - m20 * m13
+    c16 = m20 * m32 - m30 * m22; c18 = m10 * m32 - m30 * m12; c19 = m10 * m22 - m20 * m12
+    c20 = m20 * m31 - m30 * m21; c22 = m10 * m31 - m30 * m11; c23 = m10 * m21 - m20 * m11
+    f0, f1, f2 = (c00, c00, c02, c03), (c04, c04, c06, c07), (c08, c08, c10, c11)
+    f3, f4, f5 = (c12, c12, c14, c15), (c16, c16, c18, c19), (c20, c20, c22, c23)
+    v0, v1, v2, v3 = (m10, m00, m00, m00), (m11, m01, m01, m01), (m12, m02, m02, m02), (m13, m03, m03, m03)
+    i0 = [v1[k] * f0[k] - v2[k] * f1[k] + v3[k] * f2[k] for k in range(4)]
+    i1 = [v0[k] * f0[k] - v2[k] * f3[k] + v3[k] * f4[k] for k in range(4)]
+    i2 = [v0[k] * f1[k] - v1[k] * f3[k] + v3[k] * f5[k] for k in range(4)]
+    i3 = [v0[k] * f2[k] - v1[k] * f4[k] + v2[k] * f5[k] for k in range(4)]
+    sa, sb = (1.0, -1.0, 1.0, -1.0), (-1.0, 1.0, -1.0, 1.0)
+    inv = [[i0[k] * sa[k] for k in range(4)], [i1[k] * sb[k] for k in range(4)], [i2[k] * sa[k] for k in range(4)], [i3[k] * sb[k] for k in range(4)]]
+    d = [m[0][k] * (inv[0][0], inv[1][0], inv[2][0], inv[3][0])[k] for k in range(4)]
+    det = d[0] + d[1] + d[2] + d[3]
+    with np.errstate(all="ignore"):
+        rcp = float(np.float64(1.0) / np.float64(det))
+        return [[float(np.float64(x) * np.float64(rcp)) for x in col] for col in inv]
+
+
+def q_mul(a, b):
+    x0, y0, z0, w0 = a
+    x1, y1, z1, w1 = b
+    return (w0 * x1 + x0 * w1 + y0 * z1 - z0 * y1, w0 * y1 - x0 * z1 + y0 * w1 + z0 * x1,
+            w0 * z1 + x0 * y1 - y0 * x1 + z0 * w1, w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1)
+
+
+def from_scale_rotation_translation(scale, rot_xyz, t):
+    qx = (math.sin(rot_xyz[0] * 0.5), 0.0, 0.0, math.cos(rot_xyz[0] * 0.5))
+    qy = (0.0, math.sin(rot_xyz[1] * 0.5), 0.0, math.cos(rot_xyz[1] * 0.5))
+    qz = (0.0, 0.0, math.sin(rot_xyz[2] * 0.5), math.cos(rot_xyz[2] * 0.5))
+    x, y, z, w = q_mul(q_mul(qx, qy), qz)
+    x2, y2, z2 = x + x, y + y, z + z
+    xx, xy, xz = x * x2, x * y2, x * z2
+    yy, yz, zz = y * y2, y * z2, z * z2
+    wx, wy, wz = w * x2, w * y2, w * z2
+    xa = [1.0 - (yy + zz), xy + wz, xz - wy, 0.0]
+    ya = [xy - wz, 1.0 - (xx + zz), yz + wx, 0.0]
+    za = [xz + wy, yz - wx, 1.0 - (xx + yy), 0.0]
+    return [[c * scale[0] for c in xa], [c * scale[1] for c in ya], [c * scale[2] for c in za], [t[0], t[1], t[2], 1.0]]
+
+
+def to_f32_colmajor(m) -> np.ndarray:
+    """as_f32(): 16 float32 values, column-major."""
+    with np.errstate(all="ignore"):
+        return np.array([x for col in m for x in col], dtype=np.float64).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# scene model
+# ---------------------------------------------------------------------------------------------
+def _newtype(v):
+    while isinstance(v, ron.Tuple) and v.name is None and len(v.items) == 1:
+        v = v.items[0]
+    return v
+
+
+def _code(v):
+    while isinstance(v, ron.Tuple) and len(v.items) == 1:
+        v = v.items[0]
+    assert isinstance(v, str), v
+    return v
+
+
+class OracleScene:
+    def __init__(self, path_or_text: str, is_text: bool = False):
+        doc = ron.loads(path_or_text) if is_text else ron.load(path_or_text)
+        cam = doc["cam"]
+        self.cam = dict(look_at=tuple(float(x) for x in cam["look_at"].items), alpha=float(cam["alpha"]), beta=float(cam["beta"]), r=float(cam["r"]),
+                        offset_after_material=float(cam["offset_after_material"]))
+        self.time = 0.0
+        self.total_time = 0.0
+        self.uniforms = []   # [name|None, kind, payload]
+        self.matrices = []   # [name, named, node]
+        self.textures = [(t["name"], _code(t["data"])) for t in _newtype(doc["textures"])]
+        for u in _newtype(doc["uniforms"]):
+            self.uniforms.append([u["name"], *self._uniform(u["data"])])
+        mats = _newtype(doc["matrices"])
+        self._mat_by_name = {}
+        for m in mats:
+            self._mat_by_name[m["name"]] = len(self.matrices)
+            self.matrices.append([m["name"], True, None])
+        for m in mats:
+            self.matrices[self._mat_by_name[m["name"]]][2] = self._matrix(m["data"])
+        self.objects = []
+        for o in _newtype(doc["objects"]):
+            d = o["data"]
+            if d.name == "DebugMatrix":
+                self.objects.append(dict(name=o["name"], kind="debug", portal=False, m0=self._mref(d.items[0]), m1=-1, code="", sub="Normal"))
+                continue
+            kind = d["kind"]
+            portal = kind.name == "Portal"
+            m0 = self._mref(kind.items[0])
+            m1 = self._mref(kind.items[1]) if portal else -1
+            sub = d.get("in_subspace")
+            self.objects.append(dict(name=o["name"], kind="flat" if d.name == "Flat" else "complex", portal=portal, m0=m0, m1=m1,
+                                     code=_code(d["is_inside"] if d.name == "Flat" else d["intersect"]), sub=sub.name if sub is not None else "Normal"))
+        self.materials = []
+        for m in _newtype(doc["materials"]):
+            d = m["data"]
+            entry = dict(name=m["name"], kind=d.name)
+            if d.name == "Simple":
+                entry.update(color=[float(x) for x in d["color"].items], normal_coef=float(d["normal_coef"]), grid=bool(d["grid"]), grid_scale=float(d["grid_scale"]),
+                             grid_coef=float(d["grid_coef"]), grid2=bool(d.get("grid2", False)), grid3=bool(d.get("grid3", False)))
+            elif d.name == "Reflect":
+                entry.update(color=[float(x) for x in d["add_to_color"].items])
+            elif d.name == "Refract":
+                entry.update(color=[float(x) for x in d["add_to_color"].items], refractive_index=float(d["refractive_index"]))
+            else:
+                entry.update(code=_code(d["code"]))
+            self.materials.append(entry)
+        im = doc.get("intersection_materials")
+        self.intersection_materials = [(m["name"], _code(m["data"])) for m in (_newtype(im) if im is not None else [])]
+        self.library = [(m["name"], _code(m["data"])) for m in _newtype(doc["library"])]
+        sky = doc.get("skybox")
+        self.skybox = ron.unwrap_some(sky) if sky is not None else None
+        self._busy_u, self._busy_m = set(), set()
+        self._formulas = {}
+
+    # --- parsing helpers
+    def _uniform(self, d):
+        tag = d.name
+        if tag == "Bool":
+            return "bool", bool(d.items[0])
+        if tag == "Int":
+            return "int", int(_newtype(d.items[0])["value"])
+        if tag == "Float":
+            return "float", float(_newtype(d.items[0])["value"])
+        if tag in ("Angle", "Progress"):
+            return "float", float(d.items[0])
+        if tag in ("Formula", "FormulaInt"):
+            return ("formula" if tag == "Formula" else "formula_int"), _code(d.items[0])
+        if tag == "TrefoilSpecial":
+            return "trefoil", None
+        raise ValueError(f"unknown uniform kind {tag}")
+
+    def _uref(self, opt):
+        r = ron.unwrap_some(opt)
+        if r is None:
+            return -1
+        if r.name == "Named":
+            return self.find_uniform(r.items[0])
+        self.uniforms.append([None, *self._uniform(r.items[0])])
+        return len(self.uniforms) - 1
+
+    def _param(self, v):
+        if v.name == "Value":
+            return ("value", float(v.items[0]))
+        return ("uniform", self._uref(v.items[0]))
+
+    def _tvec(self, v, names="xyz"):
+        return [self._param(v[k]) for k in names]
+
+    def _mref(self, opt):
+        r = ron.unwrap_some(opt)
+        if r is None:
+            return -1
+        if r.name == "Named":
+            return self._mat_by_name.get(r.items[0], -1)
+        idx = len(self.matrices)
+        self.matrices.append([f"oracle_inline{idx}", False, None])
+        self.matrices[idx][2] = self._matrix(r.items[0])
+        return idx
+
+    def _matrix(self, v):
+        t = v.name
+        if t == "Mul":
+            return ("Mul", self._mref(v["to"]), self._mref(v["what"]))
+        if t == "Teleport":
+            return ("Teleport", self._mref(v["first_portal"]), self._mref(v["second_portal"]), self._mref(v["what"]))
+        if t == "Simple":
+            return ("Simple", [float(x) for x in v["offset"].items], float(v["scale"]), [float(x) for x in v["rotate"].items], [bool(x) for x in v["mirror"].items])
+        if t == "Parametrized":
+            return ("Parametrized", self._tvec(v["offset"]), self._tvec(v["rotate"]), self._tvec(v["mirror"]), self._param(v["scale"]))
+        if t == "Exact":
+            return ("Exact", self._tvec(v["i"]), self._tvec(v["j"]), self._tvec(v["k"]), self._tvec(v["pos"]))
+        if t == "ExactFull":
+            return ("ExactFull", *[self._tvec(v[c], "xyzw") for c in ("c0", "c1", "c2", "c3")])
+        if t == "If":
+            return ("If", self._param(v["condition"]), self._mref(v["then"]), self._mref(v["otherwise"]))
+        if t == "Inv":
+            return ("Inv", self._mref(v.items[0]))
+        if t == "Camera":
+            return ("Camera",)
+        return ("Unsupported", t)
+
+    # --- evaluation
+    def find_uniform(self, name):
+        for k, u in enumerate(self.uniforms):
+            if u[0] == name:
+                return k
+        return -1
+
+    def eval_uniform(self, idx):
+        """-> ('bool'|'int'|'float', value) or None"""
+        if idx < 0 or idx >= len(self.uniforms) or idx in self._busy_u:
+            return None
+        _, kind, payload = self.uniforms[idx]
+        if kind in ("bool", "int", "float"):
+            return kind, payload
+        if kind == "trefoil":
+            return None
+        if payload not in self._formulas:
+            try:
+                self._formulas[payload] = F.compile_formula(payload)
+            except F.FormulaError:
+                self._formulas[payload] = None
+        node = self._formulas[payload]
+        if node is None:
+            return None
+
+        def ns(name, args):
+            known, val = F.custom_function(name, args)
+            if known:
+                return val
+            if name == "time":
+                return self.time
+            if name == "total_time":
+                return self.total_time
+            r = self.eval_uniform(self.find_uniform(name))
+            if r is None:
+                return None
+            return float(r[1])
+
+        self._busy_u.add(idx)
+        try:
+            v = F.evaluate(node, ns)
+        finally:
+            self._busy_u.discard(idx)
+        if v is None:
+            return None
+        if kind == "formula":
+            return "float", v
+        if math.isnan(v):
+            return "int", 0
+        return "int", int(max(-2147483648.0, min(2147483647.0, v)))  # Rust `as i32` saturates
+
+    def _p(self, p):
+        if p[0] == "value":
+            return p[1]
+        r = self.eval_uniform(p[1])
+        return None if r is None else float(r[1])
+
+    def eval_matrix(self, idx):
+        if idx < 0 or idx >= len(self.matrices) or idx in self._busy_m:
+            return None
+        node = self.matrices[idx][2]
+        self._busy_m.add(idx)
+        try:
+            return self._eval_node(node)
+        finally:
+            self._busy_m.discard(idx)
+
+    def _eval_node(self, node):
+        t = node[0]
+        if t == "Mul":
+            to, what = self.eval_matrix(node[1]), self.eval_matrix(node[2])
+            return None if to is None or what is None else m_mul(what, to)
+        if t == "Teleport":
+            first, second, what = self.eval_matrix(node[1]), self.eval_matrix(node[2]), self.eval_matrix(node[3])
+            if first is None or second is None or what is None:
+                return None
+            return m_mul(m_mul(second, m_inverse(first)), what)
+        if t == "Simple":
+            _, offset, scale, rot, mirror = node
+            s = [scale * (-1.0 if mirror[k] else 1.0) for k in range(3)]
+            return from_scale_rotation_translation(s, rot, offset)
+        if t == "Parametrized":
+            _, offset, rot, mirror, scale = node
+            sc = self._p(scale)
+            mir = [self._p(x) for x in mirror]
+            ro = [self._p(x) for x in rot]
+            of = [self._p(x) for x in offset]
+            if sc is None or None in mir or None in ro or None in of:
+                return None
+            return from_scale_rotation_translation([sc * (1.0 - 2.0 * m) for m in mir], ro, of)
+        if t == "Exact":
+            cols = [[self._p(x) for x in node[k]] for k in (1, 2, 3, 4)]
+            if any(None in c for c in cols):
+                return None
+            return [cols[0] + [0.0], cols[1] + [0.0], cols[2] + [0.0], cols[3] + [1.0]]
+        if t == "ExactFull":
+            cols = [[self._p(x) for x in node[k]] for k in (1, 2, 3, 4)]
+            return None if any(None in c for c in cols) else cols
+        if t == "If":
+            c = self._p(node[1])
+            return None if c is None else self.eval_matrix(node[2] if c > 0.5 else node[3])
+        if t == "Inv":
+            a = self.eval_matrix(node[1])
+            return None if a is None else m_inverse(a)
+        if t == "Camera":
+            return IDENT
+        return None
+
+    # --- what the kernel sees
+    def material_ids(self):
+        """#define NAME_M (USER_MATERIAL_OFFSET + k), then two per portal object (scene.rs:720-842)."""
+        ids, k = {}, 0
+        for m in self.materials:
+            ids[m["name"] + "_M"] = 10 + k
+            k += 1
+        for pos, o in enumerate(self.objects):
+            if o["kind"] != "debug" and o["portal"] and o["m0"] >= 0 and o["m1"] >= 0:
+                ids[f"teleport_{pos}_1_M"] = 10 + k
+                ids[f"teleport_{pos}_2_M"] = 10 + k + 1
+                k += 2
+        return ids
+
+    def scene_uniform_values(self):
+        """name -> np.float32 (16,) column-major | np.float32 | np.int32  (Scene::set_uniforms)"""
+        out = {}
+        passed = []
+        for o in self.objects:
+            if o["m0"] >= 0:
+                passed.append(o["m0"])
+            if o["kind"] != "debug" and o["portal"] and o["m1"] >= 0:
+                passed.append(o["m1"])
+        passed += [k for k, m in enumerate(self.matrices) if m[1]]
+        for idx in passed:
+            m = self.eval_matrix(idx)
+            if m is None:
+                continue
+            name = self.matrices[idx][0]
+            out[name + "_mat"] = to_f32_colmajor(m)
+            out[name + "_mat_inv"] = to_f32_colmajor(m_inverse(m))
+        for o in self.objects:
+            if o["kind"] == "debug" or not o["portal"] or o["m0"] < 0 or o["m1"] < 0:
+                continue
+            a, b = self.eval_matrix(o["m0"]), self.eval_matrix(o["m1"])
+            if a is None or b is None:
+                continue
+            na, nb = self.matrices[o["m0"]][0], self.matrices[o["m1"]][0]
+            out[f"{na}_to_{nb}_mat_teleport"] = to_f32_colmajor(m_mul(b, m_inverse(a)))
+            if na != nb:
+                out[f"{nb}_to_{na}_mat_teleport"] = to_f32_colmajor(m_mul(a, m_inverse(b)))
+        for k, u in enumerate(self.uniforms):
+            if u[0] is None:
+                continue
+            r = self.eval_uniform(k)
+            if r is None:
+                continue
+            kind, v = r
+            out[u[0] + "_u"] = np.float32(v) if kind == "float" else np.int32(1 if v is True else 0 if v is False else v)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# camera + builtin uniforms (src/main.rs)
+# ---------------------------------------------------------------------------------------------
+def _norm3(v):
+    inv = 1.0 / math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+    return [v[0] * inv, v[1] * inv, v[2] * inv]
+
+
+def _cross(a, b):
+    return [a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1]]
+
+
+def camera_matrix(look_at, alpha, beta, r):
+    """RotateAroundCam::get_matrix with teleport_matrix = I, free_movement = false."""
+    pv = [math.sin(beta) * math.cos(alpha) * r, math.cos(beta) * r, math.sin(beta) * math.sin(alpha) * r]
+    pos = [pv[k] + look_at[k] for k in range(3)]
+    k = _norm3([look_at[n] - pos[n] for n in range(3)])
+    i = _norm3(_cross(k, [0.0, 1.0, 0.0]))
+    j = _norm3(_cross(k, i))
+    return m_mul(IDENT, [i + [0.0], j + [0.0], k + [0.0], pos + [1.0]])
+
+
+def builtin_uniforms(scene: OracleScene, width, height, render_depth=100, aa_count=1, aa_start=0, view_angle=None, use_panini=False, panini_param=1.0,
+                     camera=None):
+    cam = dict(scene.cam)
+    if camera:
+        cam.update(camera)
+    m = camera_matrix(cam["look_at"], cam["alpha"], cam["beta"], cam["r"])
+    scale = sum(math.sqrt(sum(x * x for x in m[c])) for c in range(3)) / 3.0
+    f, i = np.float32, np.int32
+    ident = to_f32_colmajor(IDENT)
+    return {
+        "_resolution": np.array([width, height], np.float32),
+        "_camera": to_f32_colmajor(m), "_camera_left_eye": ident, "_camera_right_eye": ident, "_camera_mul_inv": to_f32_colmajor(m_inverse(IDENT)),
+        "_camera_in_subspace": i(0), "_left_eye_in_subspace": i(0), "_right_eye_in_subspace": i(0),
+        "_view_angle": f(90.0 / 180.0 * math.pi if view_angle is None else view_angle),
+        "_panini_param": f(panini_param), "_use_panini_projection": i(1 if use_panini else 0), "_use_360_camera": i(0), "_use_180_camera": i(0),
+        "_ray_tracing_depth": i(render_depth), "_aa_count": i(aa_count), "_aa_start": i(aa_start),
+        "_draw_side_by_side": i(0), "_draw_anaglyph": i(0), "_anaglyph_p": f(0.29), "_anaglyph_q": f(0.06), "_anaglyph_mode": i(0),
+        "_draw_depth_map": i(0), "_depth_map_min": f(0.0), "_depth_map_max": f(10.0),
+        "_offset_after_material": f(cam["offset_after_material"]),
+        "_t_start": f(10.0), "_t_end": f(10.0 + 200.0), "_camera_scale": f(scale), "_left_eye_scale": f(1.0), "_right_eye_scale": f(1.0),
+        "_angle_color_disable": i(0), "_grid_disable": i(0), "_black_border_disable": i(0), "_darken_by_distance": i(1), "_teleport_external_ray": i(0),
+    }
