@@ -32,9 +32,16 @@ sys.path.insert(0, HERE)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 
-# counted by the numpy oracle (oracle/flops.py), executed binary32 operations per bounce-loop trip
-# (fma = 2); filled in per scene as they are measured, None = not yet counted
-FLOPS_PER_SEGMENT = {}
+
+
+def flops_per_segment(scene: str):
+    """Executed binary32 operations per bounce-loop trip (fma = 2), counted by the numpy oracle
+    on the scaled-down golden frame of the scene (tests/golden/make_golden.py).  Data file only."""
+    import glob
+
+    for path in glob.glob(os.path.join(HERE, "tests", "golden", scene + "_*.npz")):
+        return float(np.load(path)["flops_per_segment"])
+    return None
 
 
 def parse_args():
@@ -49,7 +56,8 @@ def parse_args():
     p.add_argument("--aa", type=int, default=1)
     p.add_argument("--panini", type=float, default=-1.0, help="Panini d parameter (enables the projection); fov via --fov")
     p.add_argument("--fov", type=float, default=90.0)
-    p.add_argument("--specialize", type=int, default=0, help="1: bake Bool/Int uniforms into the kernel")
+    p.add_argument("--specialize", type=int, default=2, help="JIT specialisation: 0 none, 1 bake Bool/Int scene uniforms, 2 bake all scene uniforms")
+    p.add_argument("--waves", type=int, default=-1, help="occupancy hint (__launch_bounds__(256, n)); -1 = pick the fastest of {0,3,4} before timing")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     p.add_argument("--save-png", default="")
@@ -124,17 +132,36 @@ def main():
 
     W, H = args.width, args.height
     scene = pa.Scene.from_file(pa.scene_path(args.scene))
-    renderer = pa.SceneRenderer(scene, device=local_rank, flags=pa.FLAG_SPECIALIZE_INTS if args.specialize else 0)
-    configure(renderer, args)
+    from portal_amd import parallel
+
     frame = pa.Frame(W, H, rank, world)
     rows = pa.shard_rows(frame)
-    blocks = (H + 7) // 8
-    blocks_max = (blocks + world - 1) // world
-    # shard buffer padded to blocks_max so every rank contributes the same byte count to the gather
-    shard = torch.zeros((blocks_max * 8, W, 4), dtype=torch.uint8, device=dev)
-    gathered = [torch.empty_like(shard) for _ in range(world)] if (world > 1 and rank == 0) else None
-    full = torch.empty((blocks_max * world * 8, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    shard = parallel.alloc_shard(H, W, world, dev)
     stream = torch.cuda.current_stream(dev)
+    spec_flags = {0: 0, 1: pa.FLAG_SPECIALIZE_INTS, 2: pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL}[args.specialize]
+
+    def make_renderer(waves):
+        r = pa.SceneRenderer(scene, device=local_rank, flags=spec_flags | pa.flag_waves(waves))
+        configure(r, args)
+        return r
+
+    # untimed: JIT-compile the candidate builds (same arithmetic, different register budgets) and keep
+    # the fastest on this rank's shard
+    tried = {}
+    for waves in ([0, 3, 4] if args.waves < 0 else [args.waves]):
+        cand = make_renderer(waves)
+        ms = min(cand.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(3))
+        tried[waves] = (ms, cand)
+    best_waves = min(tried, key=lambda k: tried[k][0])
+    if world > 1:  # all ranks must run the same build: take rank 0's choice
+        choice = torch.tensor([best_waves], device=dev)
+        dist.broadcast(choice, 0)
+        best_waves = int(choice.item())
+    renderer = tried[best_waves][1]
+    tuning = {str(k): round(v[0], 4) for k, v in tried.items()}
+    del tried
+    gatherer = parallel.FrameGatherer(H, W, rank, world, dev)
+    last_frame = [None]
 
     def step(ev=None):
         if ev is not None:
@@ -142,11 +169,7 @@ def main():
         renderer.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream)
         if ev is not None:
             ev[1].record(stream)
-        if world > 1:
-            dist.gather(shard, gathered, dst=0)
-            if rank == 0:
-                # block b = k*world + g lives in gathered[g] at local block k: one strided copy
-                torch.stack(gathered, dim=1, out=full.view(blocks_max, world, 8, W, 4))
+        last_frame[0] = gatherer.gather(shard)  # world == 1: a view of the shard, no copy
 
     for _ in range(args.warmup):
         step()
@@ -174,7 +197,7 @@ def main():
     # bounce-loop trips per frame (untimed, separate kernel variant with the counter compiled in)
     segments = None
     try:
-        counting = pa.SceneRenderer(scene, device=local_rank, flags=pa.FLAG_COUNT_SEGMENTS)
+        counting = pa.SceneRenderer(scene, device=local_rank, flags=pa.FLAG_COUNT_SEGMENTS | spec_flags)
         configure(counting, args)
         seg = torch.zeros(1, dtype=torch.int64, device=dev)
         counting.draw_device(frame, segments=seg.data_ptr(), stream=stream.cuda_stream)
@@ -188,7 +211,7 @@ def main():
 
     if rank == 0:
         if args.save_png:
-            img = (full if world > 1 else shard)[:H].cpu().numpy()
+            img = last_frame[0].cpu().numpy()
             pa.png_write(args.save_png, img)
         rays = W * H * args.aa
         ms_per_step = elapsed / args.steps * 1e3
@@ -212,7 +235,9 @@ def main():
                 "workload": f"scenes/{args.scene}.ron {W}x{H} aa={args.aa} depth={args.depth}"
                             + (f" panini d={args.panini} fov={args.fov}" if args.panini >= 0 else ""),
                 "parallelism": f"row-block interleave x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
-                "specialize_ints": bool(args.specialize),
+                "jit_specialisation": ["none", "int/bool scene uniforms baked", "all scene uniforms baked (camera dynamic)"][args.specialize],
+                "waves_per_simd_hint": best_waves,
+                "tuning_ms": tuning,
             },
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {
@@ -228,11 +253,12 @@ def main():
         if segments is not None:
             out["segments_per_frame"] = segments
             out["segment_mray_s"] = round(segments / (ms_per_step * 1e-3) / 1e6, 3)
-            fl = FLOPS_PER_SEGMENT.get(args.scene)
+            fl = flops_per_segment(args.scene)
             if fl:
                 tf = segments * fl / (kernel_ms * 1e-3) / 1e12 / world
                 out["roofline_valu"] = {"bound": "valu_fp32", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": round(tf / FP32_PEAK_TFLOPS, 5), "flops_per_segment": fl}
+                                        "frac": round(tf / FP32_PEAK_TFLOPS, 5), "flops_per_segment": round(fl, 1),
+                                        "note": "algorithmic binary32 ops of the un-specialised arithmetic (oracle count) x segments / kernel time"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, pa)

@@ -134,7 +134,9 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
 
 /* Scene::generate_shader_code: returns a malloc'ed NUL-terminated HIP C++ source (free with
  * ptl_free).  flags: bit0 = bake Bool/Int scene uniforms as literals, bit1 = count segments,
- * bit2 = bake every scene uniform (ints, floats, matrices; camera and other builtins stay dynamic). */
+ * bit2 = bake every scene uniform (ints, floats, matrices; camera and other builtins stay dynamic).
+ * ptl_renderer_create additionally reads bits 8-11 as an occupancy hint n (0 = none):
+ * the kernel is built with __launch_bounds__(256, n), i.e. at least n waves per SIMD. */
 int ptl_scene_generate_source(ptl_scene* s, unsigned flags, char** source);
 /* Scene::uniforms + layout: descs are owned by the scene handle and stay valid until the next
  * call of this function or ptl_scene_free. */
@@ -195,6 +197,12 @@ int ptl_strstore_current_line(const ptl_strstore* s);
 int ptl_strstore_range(const ptl_strstore* s, const char* kind, const char* name, int* start, int* end);
 int ptl_strstore_get_identifier(const ptl_strstore* s, int line, char* kind, size_t kind_cap, char* name, size_t name_cap,
                                 int* local_line);
+
+/* The fixed device sources embedded in the library: "glsl" (types + numerics contract),
+ * "library" (prelude), "trace" (kernel template), "entry" (launchable entry points).
+ * Returns NULL for an unknown name.  Lets a caller write its own kernel against the same
+ * conventions and hand it to ptl_kernel_compile. */
+const char* ptl_device_source(const char* which);
 
 /* GLSL snippet -> C++ (malloc'ed, ptl_free) and the formula evaluator, exposed for tests. */
 char* ptl_translate_glsl(const char* glsl);

@@ -44,8 +44,7 @@ def _tokens(text):
             pos = end
             continue
         if m.lastgroup == "id":
-            name = m.group("id")
-            out.append(("op", "||") if name == "or" else ("op", "&&") if name == "and" else ("id", name))
+            out.append(("id", m.group("id")))
         else:
             out.append(("op", m.group("op")))
         pos = m.end()
@@ -64,8 +63,12 @@ class _Parser:
     def expr(self):
         first = self.value()
         pairs = []
-        while self.peek()[0] == "op" and self.peek()[1] in PREC:
-            op = self.peek()[1]
+        while True:
+            kind, op = self.peek()
+            if kind == "id" and op in ("and", "or"):  # keyword spellings, only in operator position
+                op = "&&" if op == "and" else "||"
+            elif not (kind == "op" and op in PREC):
+                break
             self.i += 1
             pairs.append((op, self.value()))
         return ("expr", first, pairs)

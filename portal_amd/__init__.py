@@ -28,6 +28,11 @@ FLAG_COUNT_SEGMENTS = 2
 FLAG_SPECIALIZE_ALL = 4
 
 
+def flag_waves(n: int) -> int:
+    """Occupancy hint for SceneRenderer flags: build with __launch_bounds__(256, n)."""
+    return (int(n) & 0xF) << 8
+
+
 class PortalError(RuntimeError):
     pass
 
@@ -95,6 +100,7 @@ def _load() -> C.CDLL:
         "ptl_strstore_current_line": (ci, [vp]),
         "ptl_strstore_range": (ci, [vp, cp, cp, P(ci), P(ci)]),
         "ptl_strstore_get_identifier": (ci, [vp, ci, cp, cs, cp, cs, P(ci)]),
+        "ptl_device_source": (cp, [cp]),
         "ptl_translate_glsl": (vp, [cp]),
         "ptl_formula_eval": (ci, [cp, P(cp), P(cd), ci, cd, P(cd)]),
     }
@@ -321,6 +327,61 @@ class SceneRenderer:
                                              C.byref(seg) if segments else None, C.byref(ms))
         _check(rc, "draw_texture")
         return {"rgba8": a8, "rgba32f": a32, "segments": seg.value if segments else None, "ms": ms.value}
+
+
+class Kernel:
+    """Layer 1 of the C ABI (ptl_kernel_*): a hand-written or generated HIP source compiled with
+    hiprtc -- the drop-in replacement for macroquad's load_material / set_uniform / set_texture /
+    draw (reference src/gui/scene.rs:1132-1143, src/main.rs:1077-1078,1269-1358,1424-1425)."""
+
+    def __init__(self, source: str, uniforms, block_size: int, device: int = 0, defines=()):
+        self._keep = [n.encode() for n, _, _ in uniforms]
+        descs = (UniformDesc * len(uniforms))(*[UniformDesc(self._keep[i], t, o) for i, (_, t, o) in enumerate(uniforms)])
+        defs = (C.c_char_p * len(defines))(*[d.encode() for d in defines])
+        h, log = C.c_void_p(), C.create_string_buffer(1 << 16)
+        rc = lib().ptl_kernel_compile(device, source.encode("utf-8"), descs, len(uniforms), block_size, defs, len(defines), C.byref(h), log, len(log))
+        self.compile_log = log.value.decode("utf-8", "replace")
+        if rc != 0:
+            raise PortalError(f"ptl_kernel_compile failed ({rc}): {_err()}\n{self.compile_log}")
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().ptl_kernel_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_uniform(self, name: str, typ: int, value) -> int:
+        if typ == PTL_I32:
+            buf = np.array([value], np.int32)
+        elif typ == PTL_MAT4:
+            buf = np.ascontiguousarray(np.asarray(value, np.float32).T).reshape(16)  # m[row, col] -> column-major
+        else:
+            buf = np.atleast_1d(np.asarray(value, np.float32))
+        return _check(lib().ptl_kernel_set_uniform(self._h, name.encode(), typ, buf.ctypes.data), "set_uniform")
+
+    def set_texture(self, sampler: str, rgba8: np.ndarray) -> int:
+        a = np.ascontiguousarray(rgba8, np.uint8)
+        return _check(lib().ptl_kernel_set_texture(self._h, sampler.encode(), a.ctypes.data, a.shape[1], a.shape[0]), "set_texture")
+
+    def render(self, width: int, height: int, rgba8: bool = True, rgba32f: bool = False, rb_phase: int = 0, rb_stride: int = 1):
+        frame = Frame(width, height, rb_phase, rb_stride)
+        rows = shard_rows(frame)
+        a8 = np.empty((rows, width, 4), np.uint8) if rgba8 else None
+        a32 = np.empty((rows, width, 4), np.float32) if rgba32f else None
+        ms = C.c_float()
+        rc = lib().ptl_kernel_render_to_host(self._h, C.byref(frame), a8.ctypes.data if rgba8 else None, a32.ctypes.data if rgba32f else None, None, C.byref(ms))
+        _check(rc, "ptl_kernel_render_to_host")
+        return {"rgba8": a8, "rgba32f": a32, "ms": ms.value}
+
+
+def device_source(which: str) -> str:
+    p = lib().ptl_device_source(which.encode())
+    if p is None:
+        raise PortalError(f"no device source `{which}`")
+    return p.decode("utf-8")
 
 
 def deinterleave_rows(shard: np.ndarray, frame: Frame, full: np.ndarray) -> None:

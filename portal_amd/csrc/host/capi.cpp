@@ -326,6 +326,8 @@ extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_r
         r->owner = s;
         r->scene = s->scene;
         refresh_generated(s, flags);
+        unsigned waves = (flags >> 8) & 0xFu;  // occupancy hint: __launch_bounds__(256, waves)
+        if (waves) s->last.defines.push_back("PTL_WAVES_PER_EU=" + std::to_string(waves));
         std::vector<const char*> defines;
         for (auto& d : s->last.defines) defines.push_back(d.c_str());
         int rc = ptl_kernel_compile(device, s->last.source.c_str(), s->descs.data(), (int)s->descs.size(), s->last.uniform_block_size, defines.data(),
@@ -496,6 +498,16 @@ extern "C" int ptl_strstore_get_identifier(const ptl_strstore* s, int line, char
     copy_str(name, name_cap, key.name);
     if (local_line) *local_line = local;
     return PTL_OK;
+}
+
+extern "C" const char* ptl_device_source(const char* which) {
+    if (!which) return nullptr;
+    std::string w = which;
+    if (w == "glsl") return device_source_glsl();
+    if (w == "library") return device_source_library();
+    if (w == "trace") return device_source_trace_template();
+    if (w == "entry") return device_source_entry();
+    return nullptr;
 }
 
 extern "C" char* ptl_translate_glsl(const char* glsl) {

@@ -1,0 +1,74 @@
+"""The N > 1 path on CPU: two `gloo` ranks each render their interleaved row blocks (with the
+host build standing in for the GPU launch), ONE gather assembles the frame on rank 0, and the
+result equals the single-process frame byte for byte.  Exercises portal_amd/parallel.py, the
+code bench.py runs over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, DEPTH = 70, 52, 20  # ragged on purpose: 7 row blocks (last one 4 rows), 70 px wide
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_path):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import portal_amd as pa
+        from oracle import host_build as hb
+        from portal_amd import parallel
+
+        scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+        r = pa.SceneRenderer(scene, device=-1)
+        r.set_option("render_depth", DEPTH)
+        hk = hb.host_kernel_for(r, scene, W, H)
+        frame = pa.Frame(W, H, rank, world)
+        blocks = range(rank, parallel.blocks_of(H), world)
+        rows = np.concatenate([np.arange(8 * b, min(H, 8 * b + 8)) for b in blocks])
+        assert pa.shard_rows(frame) == len(rows)
+        shard = parallel.alloc_shard(H, W, world, "cpu")
+        shard[: len(rows)] = torch.from_numpy(hk.render(W, H, rows=rows, threads=1, rgba32f=False)["rgba8"])
+        g = parallel.FrameGatherer(H, W, rank, world, "cpu")
+        full = g.gather(shard)
+        if rank == 0:
+            np.save(out_path, full.numpy())
+        else:
+            assert full is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_render_and_gather_equals_single_process(pa, tmp_path, world):
+    from oracle import host_build as hb
+
+    out_path = str(tmp_path / "full.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+    r = pa.SceneRenderer(scene, device=-1)
+    r.set_option("render_depth", DEPTH)
+    want = hb.host_kernel_for(r, scene, W, H).render(W, H, rgba32f=False)["rgba8"]
+    assert np.array_equal(np.load(out_path), want)
+
+
+def test_gatherer_single_rank_is_identity():
+    from portal_amd import parallel
+
+    shard = parallel.alloc_shard(20, 5, 1, "cpu")
+    shard[:] = torch.arange(shard.numel(), dtype=torch.int64).reshape(shard.shape).to(torch.uint8)
+    g = parallel.FrameGatherer(20, 5, 0, 1, "cpu")
+    assert torch.equal(g.gather(shard), shard[:20])

@@ -71,3 +71,126 @@ def test_segment_counter_matches_host(gpu):
     hk = host_build.host_kernel_for(r, scene, 128, 72, flags=pa.FLAG_COUNT_SEGMENTS, count_segments=True)
     ref = hk.render(128, 72)
     assert out["segments"] == ref["segments"] > 128 * 72
+
+
+# ---- against the committed golden frames and the independent numpy oracle ---------------------
+import glob
+import os
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+
+
+def _case(path):
+    base = os.path.basename(path)[: -len(".npz")]
+    scene, dims, depth, aa = base.rsplit("_", 3)
+    w, h = dims.split("x")
+    return scene, int(w), int(h), int(depth[1:]), int(aa[2:])
+
+
+def _bits_equal(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+@pytest.mark.parametrize("flags_name", ["none", "FLAG_SPECIALIZE_INTS", "FLAG_SPECIALIZE_ALL"])
+def test_gpu_matches_golden_frames(gpu, path, flags_name):
+    """Golden frames = numpy-oracle output (tests/golden/make_golden.py).  Every build variant
+    (dynamic uniforms, JIT-specialised) must reproduce them bit for bit, incl. the trip counter."""
+    pa = gpu
+    scene_name, w, h, depth, aa = _case(path)
+    g = np.load(path)
+    flags = 0 if flags_name == "none" else getattr(pa, flags_name)
+    r = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path(scene_name)), device=0, flags=flags | pa.FLAG_COUNT_SEGMENTS)
+    r.set_option("render_depth", depth)
+    r.set_option("aa_count", aa)
+    out = r.draw(w, h, rgba8=True, rgba32f=True, segments=True)
+    ok = _bits_equal(out["rgba32f"], g["rgba32f_bits"].view(np.float32))
+    assert ok.all(), f"{int((~ok).any(axis=2).sum())} of {w*h} pixels differ from the golden frame"
+    assert np.array_equal(out["rgba8"], g["rgba8"])
+    assert out["segments"] == int(g["segments"].sum())
+
+
+def test_gpu_matches_numpy_oracle_on_a_fresh_view(gpu):
+    """Not a stored vector: a camera position no fixture has seen, oracle computed on the spot."""
+    from oracle.portal_oracle import Oracle
+
+    pa = gpu
+    w, h = 80, 45
+    cam = dict(look_at=(0.3, -0.1, 0.2), alpha=0.7, beta=1.1, r=2.6)
+    scene = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    scene.set_uniform("progress", 0.35)  # moves portal b0 (formula-driven matrix)
+    r = pa.SceneRenderer(scene, device=0)
+    r.set_option("render_depth", 40)
+    r.set_camera(cam["look_at"], cam["alpha"], cam["beta"], cam["r"])
+    out = r.draw(w, h, rgba32f=True)
+    o = Oracle(pa.scene_path("portal_in_portal"))
+    idx = o.scene.find_uniform("progress")
+    o.scene.uniforms[idx][2] = 0.35
+    o.options["render_depth"] = 40
+    o.camera = cam
+    want = o.render(w, h)
+    assert _bits_equal(out["rgba32f"], want["rgba32f"]).all()
+    assert np.array_equal(out["rgba8"], want["rgba8"])
+
+
+def test_numerics_contract_on_gfx950(gpu):
+    """Every contract builtin, 4096 samples incl. specials and raw bit patterns: the hiprtc build on
+    the GPU == the numpy restatement, bit for bit (layer 1 of the C ABI with a hand-written kernel)."""
+    from tests import probe
+
+    pa = gpu
+    samples = probe.inputs()
+    k = pa.Kernel(probe.source(pa), probe.LAYOUT, probe.BLOCK_SIZE, device=0)
+    assert k.set_texture("in_tex", probe.as_texture(samples)) == 0
+    assert k.set_uniform("n_u", pa.PTL_I32, len(samples)) == 0
+    assert k.set_uniform("does_not_exist", pa.PTL_F32, 1.0) == 1          # unknown names are tolerated (macroquad semantics)
+    with pytest.raises(pa.PortalError):
+        k.set_uniform("n_u", pa.PTL_F32, 1.0)                             # declared int
+    got = k.render(len(samples), len(probe.functions()), rgba8=False, rgba32f=True)["rgba32f"]
+    assert np.array_equal(got[0, :, 1].view(np.uint32), samples[:, 0].view(np.uint32))
+    want = probe.numpy_results(samples)
+    for i, (name, _, _) in enumerate(probe.functions()):
+        ok = probe.same_bits(got[i, :, 0], want[i])
+        bad = np.nonzero(~ok)[0]
+        assert ok.all(), f"{name}: {len(bad)} differ, e.g. {samples[bad[0]]} -> gpu {got[i, bad[0], 0]!r} numpy {want[i][bad[0]]!r}"
+
+
+def test_compile_error_is_reported_with_scene_element(gpu):
+    """A broken snippet: hiprtc's diagnostic line maps back to the scene element that produced it
+    (reference: shader error -> LineNumbersByKey::get_identifier, src/gui/scene.rs:1157-1171)."""
+    import re
+
+    pa = gpu
+    text = open(pa.scene_path("basics")).read().replace("int is_inside_square(", "int is_inside_square(undeclared_type zz, ", 1)
+    scene = pa.Scene.from_text(text)
+    with pytest.raises(pa.PortalError) as e:
+        pa.SceneRenderer(scene, device=0)
+    m = re.search(r"portal_scene\.hip:(\d+):\d+: error", str(e.value))
+    assert m, str(e.value)[:500]
+    scene.generate_source()
+    owner = scene.source_line_owner(int(m.group(1)))
+    assert owner is not None and owner[0] == "library" and owner[1] == "room"
+
+
+def test_full_size_properties_triple_portal_4k(gpu):
+    """BASELINE config C3 at full size (3840x2160, depth 40): no oracle run is affordable, so check
+    size-independent properties: 8 interleaved shards == whole frame, alpha == 255 everywhere,
+    trip count within [pixels, pixels * depth], and a 3-row window bit-equal to the host build."""
+    from oracle import host_build
+
+    pa = gpu
+    w, h, depth = 3840, 2160, 40
+    scene = pa.Scene.from_file(pa.scene_path("triple_portal"))
+    r = pa.SceneRenderer(scene, device=0, flags=pa.FLAG_COUNT_SEGMENTS | pa.FLAG_SPECIALIZE_ALL)
+    r.set_option("render_depth", depth)
+    whole = r.draw(w, h, rgba8=True, rgba32f=True, segments=True)
+    assert (whole["rgba8"][:, :, 3] == 255).all()
+    assert w * h <= whole["segments"] <= w * h * depth
+    full = np.zeros_like(whole["rgba8"])
+    for phase in range(8):
+        pa.deinterleave_rows(r.draw(w, h, rb_phase=phase, rb_stride=8)["rgba8"], pa.Frame(w, h, phase, 8), full)
+    assert np.array_equal(full, whole["rgba8"])
+    rows = [0, 1079, 2159]
+    ref = host_build.host_kernel_for(r, scene, w, h).render(w, h, rows=rows)
+    assert _bits_equal(whole["rgba32f"][rows], ref["rgba32f"]).all()

@@ -1,0 +1,341 @@
+"""CPU tests of the host side (no GPU): C ABI surface, RON reader, formula evaluator, matrix
+graph, template engine, GLSL->C++ translator, generator bookkeeping.
+
+Where the reference has a unit test for the component, it is restated here with the same
+inputs and expected values (src/code_generation.rs:100-184).  Everything else is pinned by
+hand-derived values and by agreement with the independent oracle implementation.
+"""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENES = ["basics", "monoportal", "triple_portal", "portal_in_portal", "mobius_monoportal"]
+
+
+# ---------------------------------------------------------------------------------------------
+# C ABI
+# ---------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol(pa):
+    header = open(os.path.join(ROOT, "include", "portal_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    names = set(re.findall(r"\b(ptl_[a-z0-9_]+)\s*\(", header))
+    assert len(names) > 40
+    lib = C.CDLL(pa.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, f"declared in include/portal_amd.h but not exported: {missing}"
+
+
+def test_version_and_no_gpu_paths_fail_loudly(pa):
+    assert "portal_amd" in pa.version()
+    scene = pa.Scene.from_file(pa.scene_path("basics"))
+    r = pa.SceneRenderer(scene, device=-1)  # compile-only
+    assert len(r.code_object()) > 1000 and r.code_object()[:4] == b"\x7fELF"
+    with pytest.raises(pa.PortalError):  # no CPU fallback for rendering
+        r.draw(16, 16)
+
+
+def test_unknown_scene_and_bad_ron(pa):
+    with pytest.raises(pa.PortalError):
+        pa.Scene.from_file("/nonexistent/scene.ron")
+    with pytest.raises(pa.PortalError, match="line 3"):
+        pa.Scene.from_text("(\n cam: (look_at: (0,0,0),\n alpha: @")
+
+
+# ---------------------------------------------------------------------------------------------
+# template engine: the reference's own unit test, src/code_generation.rs:100-184
+# ---------------------------------------------------------------------------------------------
+def test_string_storage_and_apply_template_reference_vectors(pa):
+    L = pa.lib()
+    s1 = L.ptl_strstore_new()
+    L.ptl_strstore_add_string(s1, b"1\n2\n3\n")
+    L.ptl_strstore_add_identifier_string(s1, b"CustomId1", b"0", b"\n4\n5\n")
+    assert L.ptl_strstore_text(s1) == b"1\n2\n3\n\n4\n5\n"
+    assert L.ptl_strstore_current_line(s1) == 7
+    a, b = C.c_int(), C.c_int()
+    assert L.ptl_strstore_range(s1, b"CustomId1", b"0", C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == (4, 8)
+
+    s2 = L.ptl_strstore_new()
+    L.ptl_strstore_add_string(s2, b"a\nb")
+    L.ptl_strstore_add_identifier_string(s2, b"CustomId2", b"1", b"c\nd")
+    assert L.ptl_strstore_text(s2) == b"a\nbc\nd"
+    assert L.ptl_strstore_current_line(s2) == 3
+    assert L.ptl_strstore_range(s2, b"CustomId2", b"1", C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == (2, 4)
+
+    names = (C.c_char_p * 2)(b"s1", b"s2")
+    stores = (C.c_void_p * 2)(s1, s2)
+    s = L.ptl_apply_template(b"abc\n//%s2//%\n\ne\nf\n//%s1//%\n9", names, stores, 2)
+    assert L.ptl_strstore_text(s) == b"abc\na\nbc\nd\n\ne\nf\n1\n2\n3\n\n4\n5\n\n9"
+    assert L.ptl_strstore_current_line(s) == 15
+    assert L.ptl_strstore_range(s, b"CustomId1", b"0", C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == (11, 15)
+    assert L.ptl_strstore_range(s, b"CustomId2", b"1", C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == (3, 5)
+    # LineNumbersByKey::get_identifier: line 12 is local line 2 of CustomId1; line 1 belongs to nobody
+    kind, name, local = C.create_string_buffer(32), C.create_string_buffer(32), C.c_int()
+    assert L.ptl_strstore_get_identifier(s, 12, kind, 32, name, 32, C.byref(local)) == 0
+    assert (kind.value, name.value, local.value) == (b"CustomId1", b"0", 2)
+    assert L.ptl_strstore_get_identifier(s, 1, kind, 32, name, 32, C.byref(local)) == 1
+    L.ptl_strstore_free(s)
+
+
+# ---------------------------------------------------------------------------------------------
+# formulas: hand values + agreement with the oracle's independent evaluator
+# ---------------------------------------------------------------------------------------------
+FORMULA_KAT = [  # (text from the config scenes, variables, expected by hand)
+    ("0.035", {}, 0.035),
+    ("1 - progress * 1.73", {"progress": 0.25}, 1 + (-(0.25 * 1.73))),
+    ("deg2rad(-90) * min(progress, 0.5) / 0.5", {"progress": 0.3}, (-90 / 180.0 * math.pi) * 0.3 * (1 / 0.5)),
+    ("-room_size_x", {"room_size_x": 4.0}, -4.0),
+    ("(2^0.5)/2", {}, math.pow(2, 0.5) * (1 / 2.0)),
+    ("((2^0.5)/2+border_size+black_border_size)*sin(pass_angle)*pass_scale * (1-2*pass_progress)",
+     {"border_size": 0.035, "black_border_size": 0.01, "pass_angle": math.pi / 4, "pass_scale": 1.0, "pass_progress": 0.0},
+     (math.pow(2, 0.5) * 0.5 + 0.035 + 0.01) * math.sin(math.pi / 4) * 1.0 * (1 + (-(0.0 * 2)))),
+    ("if(progress == 0, 0.001, 0)+on(progress, 0., 0.8)", {"progress": 0.4}, 0.0 + 0.5),
+    ("t1%180", {"t1": 200.0}, 20.0),
+    ("2^3^2", {}, 512.0),
+    ("3-2-1", {}, 0.0),
+    ("10/2/5", {}, 10 * 0.5 * 0.2),
+    ("1+2*3", {}, 7.0),
+    ("lerp(1.5, 5, easing_in_out(time*2))", {}, (1 - 0.5) * 1.5 + 0.5 * 5),  # time = 0.25 -> easing_in_out(0.5) = 0.5
+    ("pi()/2 - e()^0", {}, math.pi * 0.5 + (-1.0)),
+    ("switch(2, 10, 20, 30)", {}, 20.0),
+    ("sqrt(r1^2-o2^2)", {"r1": 5.0, "o2": 3.0}, 4.0),
+    ("and(1, not(0)) + or(0, 0)", {}, 1.0),
+]
+
+
+@pytest.mark.parametrize("text,variables,expected", FORMULA_KAT)
+def test_formula_known_answers(pa, text, variables, expected):
+    from oracle import formula as OF
+
+    got = pa.formula_eval(text, variables, time=0.25)
+    assert got is not None and got == pytest.approx(expected, rel=1e-15, abs=1e-15)
+    node = OF.compile_formula(text)
+
+    def ns(name, args):
+        known, v = OF.custom_function(name, args)
+        if known:
+            return v
+        return 0.25 if name in ("time", "total_time") else variables.get(name)
+
+    assert OF.evaluate(node, ns) == got  # two independent implementations, bit-equal binary64
+
+
+def test_formula_errors(pa):
+    assert pa.formula_eval("1 +") is None
+    assert pa.formula_eval("unknown_name * 2") is None
+    assert pa.formula_eval("(1 + 2") is None
+
+
+def test_every_formula_of_the_config_scenes_agrees_with_the_oracle(pa):
+    from oracle.scene_eval import OracleScene
+
+    n = 0
+    for name in SCENES:
+        ps = pa.Scene.from_file(pa.scene_path(name))
+        osc = OracleScene(pa.scene_path(name))
+        for k, (uname, kind, payload) in enumerate(osc.uniforms):
+            if uname is None:
+                continue
+            want = osc.eval_uniform(k)
+            got = ps.eval_uniform(uname)
+            if want is None:
+                assert got is None
+                continue
+            assert got == want[1], (name, uname, payload)
+            n += 1
+    assert n > 80
+
+
+# ---------------------------------------------------------------------------------------------
+# matrix graph + uniform upload values
+# ---------------------------------------------------------------------------------------------
+def test_matrix_simple_is_translate_rotate_scale(pa):
+    text = open(pa.scene_path("portal_in_portal")).read()
+    s = pa.Scene.from_text(text)
+    tr = s.eval_matrix("tr")  # Simple(offset (0.27,0.39,-1.01), scale 0.1, rotate (pi/2,0,0))
+    assert tr[:3, 3] == pytest.approx([0.27, 0.39, -1.01])
+    c, sn = math.cos(math.pi / 2), math.sin(math.pi / 2)
+    want = 0.1 * np.array([[1, 0, 0], [0, c, -sn], [0, sn, c]])
+    assert tr[:3, :3] == pytest.approx(want, abs=1e-15)
+    # Teleport: b1 = b0 * a^-1 * b0   (matrix.rs:520-529)
+    a, b0, b1 = s.eval_matrix("a"), s.eval_matrix("b0"), s.eval_matrix("b1")
+    assert b1 == pytest.approx(b0 @ np.linalg.inv(a) @ b0, abs=1e-12)
+    # Mul{to, what} = what * to   (matrix.rs:514-518)
+    cube2, cube = s.eval_matrix("cube2"), s.eval_matrix("cube")
+    assert cube2 == pytest.approx(cube @ np.diag([0.07, 0.07, 0.07, 1.0]), abs=1e-15)
+    # a zero-scale matrix evaluates (its inverse is non-finite, like the reference's glam inverse)
+    c0 = s.eval_matrix("c0")
+    assert np.all(c0[:3, :3] == 0)
+    assert not np.isfinite(s.uniform_values()["c0_mat_inv"]).all()
+
+
+def test_uniform_overrides_and_time(pa):
+    s = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    z0 = s.eval_matrix("b0")[2, 3]
+    assert z0 == 1.0  # "1 - progress * 1.73" at progress 0
+    assert s.set_uniform("progress", 0.5)
+    assert s.eval_matrix("b0")[2, 3] == pytest.approx(1 - 0.5 * 1.73)
+    assert not s.set_uniform("no_such_uniform", 1.0)
+    assert s.eval_uniform("show_teleported") == 10 and s.eval_uniform("teleport_light") is True
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_scene_uniform_uploads_match_oracle_bit_for_bit(pa, name):
+    """X_mat / X_mat_inv / A_to_B_mat_teleport / user uniforms as binary32: product == oracle."""
+    from oracle.scene_eval import OracleScene
+
+    got = pa.Scene.from_file(pa.scene_path(name)).uniform_values()
+    want = OracleScene(pa.scene_path(name)).scene_uniform_values()
+    # inline matrices have implementation-chosen names on both sides: compare them as multisets
+    def split(d):
+        named = {k: v for k, v in d.items() if not re.match(r"^(id\d+|oracle_inline\d+)_", k)}
+        inline = sorted(np.asarray(v, np.float32).T.reshape(-1).view(np.uint32).tolist() if np.asarray(v).shape == (4, 4)
+                        else np.asarray(v, np.float32).reshape(-1).view(np.uint32).tolist() for k, v in d.items() if k not in named)
+        return named, inline
+
+    gn, gi = split(got)
+    wn, wi = split(want)
+    assert set(gn) == set(wn)
+    for k in gn:
+        g, w = gn[k], wn[k]
+        if np.asarray(g).shape == (4, 4):
+            g = np.asarray(g, np.float32).T.reshape(16)  # m[row, col] -> column-major
+        gb, wb = np.asarray(g).reshape(-1), np.asarray(w).reshape(-1)
+        assert gb.dtype.kind == wb.dtype.kind, k
+        same = (gb.view(np.uint32) == wb.view(np.uint32)) if gb.dtype.kind == "f" else (gb == wb)
+        nan_ok = np.isnan(gb) & np.isnan(wb) if gb.dtype.kind == "f" else False
+        assert np.all(same | nan_ok), k
+    assert gi == wi
+
+
+def test_builtin_uniforms_match_oracle(pa):
+    from oracle.scene_eval import OracleScene, builtin_uniforms
+
+    for name in SCENES:
+        s = pa.Scene.from_file(pa.scene_path(name))
+        r = pa.SceneRenderer(s, device=-1)
+        r.set_option("render_depth", 40)
+        want = builtin_uniforms(OracleScene(pa.scene_path(name)), 3840, 2160, render_depth=40)
+        for k, w in want.items():
+            g = r.uniform_value(k, 3840, 2160)
+            assert g is not None, k
+            if np.asarray(g).shape == (4, 4):
+                g = np.asarray(g).T.reshape(16)
+            assert np.array_equal(np.asarray(g, np.float32).reshape(-1), np.asarray(w, np.float32).reshape(-1)), (name, k)
+
+
+def test_camera_matrix_known_answer(pa):
+    """RotateAroundCam::get_matrix (src/main.rs:286-304): k looks from pos to look_at, i = k x up, j = k x i."""
+    s = pa.Scene.from_file(pa.scene_path("basics"))
+    r = pa.SceneRenderer(s, device=-1)
+    r.set_camera((1.0, 2.0, 3.0), alpha=math.pi / 2, beta=math.pi / 2, r=5.0)
+    m = r.uniform_value("_camera", 100, 100)
+    assert m[:3, 3] == pytest.approx([1.0, 2.0, 8.0], abs=1e-6)       # pos = look_at + 5 * (0, 0, 1)
+    assert m[:3, 2] == pytest.approx([0.0, 0.0, -1.0], abs=1e-6)      # forward
+    assert m[:3, 0] == pytest.approx([1.0, 0.0, 0.0], abs=1e-6)       # k x (0,1,0)
+    assert m[:3, 1] == pytest.approx([0.0, -1.0, 0.0], abs=1e-6)      # k x i: image y points world-down
+    assert r.uniform_value("_camera_scale", 100, 100) == pytest.approx(1.0, abs=1e-7)
+    assert r.uniform_value("_view_angle", 100, 100) == np.float32(math.pi / 2)
+    assert r.uniform_value("_t_end", 100, 100) == np.float32(210.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# GLSL -> C++ translator
+# ---------------------------------------------------------------------------------------------
+def test_translate_glsl_rewrites(pa):
+    t = pa.translate_glsl
+    assert t("float x = 1.;") == "float x = 1.f;"
+    assert t("x = 2.5e-3 + 1e5 + 3 + 0x10;") == "x = 2.5e-3f + 1e5f + 3 + 0x10;"
+    assert t("vec3 m = 1.0/r.d.xyz;") == "vec3 m = 1.0f/r.d.sw<0,1,2>();"
+    assert t("step(t1.yzx,t1.xyz)") == "step(t1.sw<1,2,0>(),t1.sw<0,1,2>())"
+    assert t("c.rgb *= 2.0;") == "c.swr<0,1,2>() *= 2.0f;"
+    assert t("p.xy = q.yx;") == "p.swr<0,1>() = q.sw<1,0>();"
+    assert t("hit.t /= len; best.u == r.x") == "hit.t /= len; best.u == r.x"   # single components / struct fields untouched
+    assert t("void f(in vec3 a, out float b, inout vec2 c)") == "void f( vec3 a,  float& b,  vec2& c)"
+    assert t("float new = delete;") == "float new_ = delete_;"
+    assert t("a // 1.0 .xyz\nb") == "a // 1.0 .xyz\nb"                        # comments are not rewritten
+    src = "line1\n  x = 1.0; // !FOR_NUMBER!\nline3"
+    assert t(src).count("\n") == src.count("\n")
+
+
+def test_generated_source_line_bookkeeping(pa):
+    """Every snippet line of the generated kernel maps back to its scene element (the job of
+    LineNumbersByKey, src/code_generation.rs:10-41), and tagged lines are filtered in place."""
+    s = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    src = s.generate_source().split("\n")
+    owners = {}
+    for ln in range(1, len(src) + 1):
+        o = s.source_line_owner(ln)
+        if o:
+            owners.setdefault((o[0], o[1]), []).append((ln, o[2]))
+    assert ("intersection_material", "portal_in_portal") in owners and ("library", "portal_advanced") in owners
+    lines = owners[("library", "portal_advanced")]
+    # consecutive snippets share a line when the earlier one has no trailing newline (same in the
+    # reference, whose ranges are start..end+1): the shared line is reported for the first owner
+    locs = [loc for _, loc in lines]
+    assert locs == list(range(locs[0], locs[0] + len(lines))) and locs[0] in (1, 2)
+    first = lines[0][0] - (locs[0] - 1)
+    assert "is_inside_portal_advanced" in src[first - 1]
+    text = "\n".join(src[ln - 1] for ln, _ in lines)
+    assert "!FOR_NUMBER!" not in text and "!FOR_VARIABLE!" in text
+    ron_code = re.search(r'name: "portal_advanced",\s*data: \(\("(.*?)"\)\)', open(pa.scene_path("portal_in_portal")).read(), re.S).group(1)
+    assert locs[-1] in (ron_code.count("\n"), ron_code.count("\n") + 1)  # line-preserving (last line may be shared too)
+
+
+def test_material_ids_and_defines(pa):
+    """#define NAME_M (USER_MATERIAL_OFFSET + k) in declaration order, then two per portal object."""
+    s = pa.Scene.from_file(pa.scene_path("triple_portal"))
+    src = s.generate_source()
+    defs = re.findall(r"#define (\w+_M) \(USER_MATERIAL_OFFSET \+ (\d+)\)", src)
+    assert [int(k) for _, k in defs] == list(range(len(defs)))
+    from oracle.scene_eval import OracleScene
+
+    want = OracleScene(pa.scene_path("triple_portal")).material_ids()
+    assert {n: 10 + int(k) for n, k in defs} == want
+
+
+def test_uniform_layout_is_packed_and_static_asserted(pa):
+    s = pa.Scene.from_file(pa.scene_path("monoportal"))
+    layout, size = s.uniform_layout()
+    sizes = {pa.PTL_MAT4: 64, pa.PTL_F32: 4, pa.PTL_I32: 4, pa.PTL_VEC2: 8, pa.PTL_VEC3: 12, pa.PTL_SAMPLER: 16}
+    off = 0
+    for name, typ, o in layout:
+        assert o == off, name
+        off += sizes[typ]
+    assert layout[0] == ("monoportal_tex", pa.PTL_SAMPLER, 0) and size == (off + 7) // 8 * 8
+    names = [n for n, _, _ in layout]
+    assert "_camera" in names and "portal_rotate_angle_u" in names and "_external_ray_b" == names[-1]
+    assert s.generate_source().count("static_assert(__builtin_offsetof(ptl_uniform_block") == len(layout)
+
+
+def test_png_roundtrip_and_against_pil(pa, tmp_path):
+    from PIL import Image
+
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    path = str(tmp_path / "a.png")
+    pa.png_write(path, img)
+    assert np.array_equal(pa.png_read(path), img)
+    assert np.array_equal(np.array(Image.open(path).convert("RGBA")), img)
+    tex = os.path.join(ROOT, "scenes", "img", "monoportal.png")
+    assert np.array_equal(pa.png_read(tex), np.array(Image.open(tex).convert("RGBA")))
+
+
+def test_shard_rows_and_deinterleave(pa):
+    w, h = 40, 100  # 13 row blocks, the last one has 4 rows
+    full = np.arange(h * w * 4, dtype=np.uint32).astype(np.uint8).reshape(h, w, 4)
+    out = np.zeros_like(full)
+    total = 0
+    for phase in range(4):
+        f = pa.Frame(w, h, phase, 4)
+        blocks = list(range(phase, 13, 4))
+        rows = np.concatenate([np.arange(8 * b, min(h, 8 * b + 8)) for b in blocks])
+        assert pa.shard_rows(f) == len(rows)
+        total += len(rows)
+        pa.deinterleave_rows(np.ascontiguousarray(full[rows]), f, out)
+    assert total == h and np.array_equal(out, full)
+    assert pa.shard_rows(pa.Frame(w, h, 4, 4)) == -1  # phase must be < stride

@@ -1,0 +1,121 @@
+"""CPU parity: the product's generated kernel (compiled for the host, oracle/host_build) against
+the independent numpy oracle and the committed golden frames -- bit-exact.
+
+This checks everything of the product except the gfx950 compiler + hardware leg (that leg is
+tests/test_gpu_parity.py): .ron loading, uniform/matrix evaluation, scene -> source generation,
+the GLSL -> C++ translation of scene snippets, the device prelude and the trace template.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+
+
+def parse_case(path):
+    base = os.path.basename(path)[: -len(".npz")]
+    scene, dims, depth, aa = base.rsplit("_", 3)
+    w, h = dims.split("x")
+    return scene, int(w), int(h), int(depth[1:]), int(aa[2:])
+
+
+def bits_equal(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+
+
+def host_render(pa, scene_name, w, h, depth, aa, flags=0, options=()):
+    from oracle import host_build as hb
+
+    scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    r = pa.SceneRenderer(scene, device=-1, flags=flags)
+    r.set_option("render_depth", depth)
+    r.set_option("aa_count", aa)
+    for k, v in options:
+        r.set_option(k, v)
+    hk = hb.host_kernel_for(r, scene, w, h, flags=flags | pa.FLAG_COUNT_SEGMENTS, count_segments=True)
+    return hk.render(w, h)
+
+
+def test_golden_files_present():
+    assert len(GOLDEN) == 5
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_product_host_build_matches_golden(pa, path):
+    scene, w, h, depth, aa = parse_case(path)
+    g = np.load(path)
+    out = host_render(pa, scene, w, h, depth, aa)
+    want = g["rgba32f_bits"].view(np.float32)
+    ok = bits_equal(out["rgba32f"], want)
+    assert ok.all(), f"{int((~ok).any(axis=2).sum())} of {w*h} pixels differ from the golden frame"
+    assert np.array_equal(out["rgba8"], g["rgba8"])
+    assert out["segments"] == int(g["segments"].sum())
+
+
+@pytest.mark.parametrize("path", GOLDEN[:4], ids=[os.path.basename(p) for p in GOLDEN[:4]])
+def test_oracle_reproduces_golden(path):
+    """The golden frames are this oracle's own output (make_golden.py): guards against drift."""
+    from oracle.portal_oracle import Oracle
+
+    scene, w, h, depth, aa = parse_case(path)
+    g = np.load(path)
+    o = Oracle(os.path.join(ROOT, "scenes", scene + ".ron"))
+    o.options.update(render_depth=depth, aa_count=aa)
+    rows = (h // 2 - 6, h // 2 + 6)  # a 12-row band keeps the CPU suite short; the full frame is checked via the product above
+    out = o.render(w, h, rows=rows)
+    assert bits_equal(out["rgba32f"], g["rgba32f_bits"].view(np.float32)[rows[0]:rows[1]]).all()
+    assert np.array_equal(out["segments"], g["segments"][rows[0]:rows[1]])
+
+
+@pytest.mark.parametrize("flags_name", ["FLAG_SPECIALIZE_INTS", "FLAG_SPECIALIZE_ALL"])
+@pytest.mark.parametrize("scene", ["portal_in_portal", "triple_portal"])
+def test_jit_specialisation_does_not_change_a_single_bit(pa, scene, flags_name):
+    base = host_render(pa, scene, 64, 36, 40, 1)
+    spec = host_render(pa, scene, 64, 36, 40, 1, flags=getattr(pa, flags_name))
+    assert bits_equal(base["rgba32f"], spec["rgba32f"]).all() and base["segments"] == spec["segments"]
+
+
+def test_panini_projection_matches_oracle(pa):
+    """north_star names the Panini projection (src/frag.glsl:305-342): product == oracle, bit-exact."""
+    from oracle.portal_oracle import Oracle
+
+    w, h = 64, 36
+    opts = [("use_panini_projection", 1), ("panini_param", 1.0), ("view_angle", np.radians(140.0))]
+    got = host_render(pa, "portal_in_portal", w, h, 40, 1, options=opts)
+    o = Oracle(os.path.join(ROOT, "scenes", "portal_in_portal.ron"))
+    o.options.update(render_depth=40, use_panini=True, panini_param=1.0, view_angle=np.radians(140.0))
+    want = o.render(w, h)
+    assert bits_equal(got["rgba32f"], want["rgba32f"]).all()
+    plain = host_render(pa, "portal_in_portal", w, h, 40, 1)
+    assert not np.array_equal(plain["rgba8"], got["rgba8"])  # the projection really is in effect
+
+
+def test_antialiasing_is_the_mean_of_r2_offset_samples(pa):
+    """frag.glsl:515-526: result = sqrt(mean over a of get_color(uv + R2(a) * pixel * 2))."""
+    one = host_render(pa, "monoportal", 48, 27, 20, 1)
+    four = host_render(pa, "monoportal", 48, 27, 20, 4)
+    assert four["segments"] > 3 * one["segments"]
+    from oracle.portal_oracle import Oracle
+
+    o = Oracle(os.path.join(ROOT, "scenes", "monoportal.ron"))
+    o.options.update(render_depth=20, aa_count=4)
+    want = o.render(48, 27, rows=(10, 16))
+    assert bits_equal(four["rgba32f"][10:16], want["rgba32f"]).all()
+
+
+def test_window_rendering_equals_full_frame(pa):
+    from oracle import host_build as hb
+
+    scene = pa.Scene.from_file(pa.scene_path("basics"))
+    r = pa.SceneRenderer(scene, device=-1)
+    r.set_option("render_depth", 4)
+    hk = hb.host_kernel_for(r, scene, 80, 60)
+    full = hk.render(80, 60)["rgba32f"]
+    win = hk.render(80, 60, rows=(13, 29), cols=(7, 61))["rgba32f"]
+    assert np.array_equal(full[13:29, 7:61].view(np.uint32), win.view(np.uint32))
+    picked = hk.render(80, 60, rows=[59, 0, 17])["rgba32f"]
+    assert np.array_equal(picked.view(np.uint32), full[[59, 0, 17]].view(np.uint32))
