@@ -162,19 +162,41 @@ def main():
     renderer = tried[best_waves][1]
     tuning = {str(k): round(v[0], 4) for k, v in tried.items()}
     del tried
-    gatherer = parallel.FrameGatherer(H, W, rank, world, dev)
+    # N > 1: two shard buffers; the gather of frame n (RCCL, on the process group's stream) overlaps the
+    # tracing of frame n+1; a buffer is reused only after its gather has been waited for
+    depth = 2 if world > 1 else 1
+    shards = [shard] + [parallel.alloc_shard(H, W, world, dev) for _ in range(depth - 1)]
+    gatherer = parallel.FrameGatherer(H, W, rank, world, dev, depth=depth)
+    pending = [None] * depth
     last_frame = [None]
+    counter = [0]
+
+    def drain(slot):
+        if pending[slot] is not None:
+            last_frame[0] = gatherer.finish(pending[slot], shards[slot], slot)
+            pending[slot] = None
 
     def step(ev=None):
+        slot = counter[0] % depth
+        counter[0] += 1
+        drain(slot)
         if ev is not None:
             ev[0].record(stream)
-        renderer.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream)
+        renderer.draw_device(frame, out_rgba8=shards[slot].data_ptr(), stream=stream.cuda_stream)
         if ev is not None:
             ev[1].record(stream)
-        last_frame[0] = gatherer.gather(shard)  # world == 1: a view of the shard, no copy
+        if world > 1:
+            pending[slot] = gatherer.gather_async(shards[slot], slot)
+        else:
+            last_frame[0] = shards[slot][:H]  # a view: no copy, the frame stays in HBM
+
+    def drain_all():
+        for k in range(depth):
+            drain((counter[0] + k) % depth)
 
     for _ in range(args.warmup):
         step()
+    drain_all()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -182,6 +204,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
+    drain_all()  # every frame of the timed region is fully assembled on rank 0
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -202,7 +225,7 @@ def main():
         counting = pa.SceneRenderer(scene, device=local_rank, flags=pa.FLAG_COUNT_SEGMENTS | spec_flags)
         configure(counting, args)
         seg = torch.zeros(1, dtype=torch.int64, device=dev)
-        counting.draw_device(frame, segments=seg.data_ptr(), stream=stream.cuda_stream)
+        counting.draw_device(frame, out_rgba8=shards[0].data_ptr(), segments=seg.data_ptr(), stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.all_reduce(seg)
@@ -236,7 +259,7 @@ def main():
             "config": {
                 "workload": f"scenes/{args.scene}.ron {W}x{H} aa={args.aa} depth={args.depth}"
                             + (f" panini d={args.panini} fov={args.fov}" if args.panini >= 0 else ""),
-                "parallelism": f"row-block interleave x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
+                "parallelism": f"row-block interleave x{world}" + (" + RCCL gather to rank 0, double-buffered (gather n overlaps trace n+1)" if world > 1 else ""),
                 "jit_specialisation": ["none", "int/bool scene uniforms baked", "all scene uniforms baked (camera dynamic)"][args.specialize],
                 "waves_per_simd_hint": best_waves,
                 "tuning_ms": tuning,

@@ -81,6 +81,17 @@ struct ptl_renderer {
     bool draw_side_by_side = false, draw_depth_map = false, angle_color_disable = false, grid_disable = false,
          black_border_disable = false, darken_by_distance = true;
     double depth_map_min = 0.0, depth_map_max = 10.0, anaglyph_p = 0.29, anaglyph_q = 0.06;
+    // draw-to-draw caching of the uploads: the reference re-evaluates and re-uploads every uniform on
+    // every draw (src/main.rs:1413-1414); the values only change when the scene, an option, the camera
+    // or the frame size does, so a draw of an unchanged state is just the kernel launch
+    unsigned long long options_version = 1, uploaded_scene = 0, uploaded_options = 0;
+    int uploaded_w = -1, uploaded_h = -1;
+    // how the kernel was built (needed to re-JIT a specialised kernel when the scene changes)
+    int device = -1;
+    unsigned flags = 0;
+    std::string asset_root;
+    unsigned long long kernel_scene_version = 0;
+    std::string kernel_source;
 };
 
 namespace {
@@ -208,6 +219,7 @@ extern "C" int ptl_scene_set_uniform(ptl_scene* s, const char* name, double valu
 }
 extern "C" int ptl_scene_set_time(ptl_scene* s, double time, double total_time) {
     if (!s) return PTL_ERR_INVALID;
+    if (s->scene->time != time || s->scene->total_time != total_time) ++s->scene->version;
     s->scene->time = time;
     s->scene->total_time = total_time;
     return PTL_OK;
@@ -317,6 +329,48 @@ extern "C" int ptl_scene_source_line_owner(ptl_scene* s, int line, char* kind, s
 }
 
 // ---- renderer ---------------------------------------------------------------------------------
+// generate + compile + load textures: the JIT step of SceneRenderer::new (main.rs:946-1010,1066-1083)
+static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
+    ptl_scene* s = r->owner;
+    refresh_generated(s, r->flags);
+    if (r->kernel && s->last.source == r->kernel_source) {  // nothing baked in changed
+        r->kernel_scene_version = r->scene->version;
+        return PTL_OK;
+    }
+    unsigned waves = (r->flags >> 8) & 0xFu;  // occupancy hint: __launch_bounds__(256, waves)
+    if (waves) s->last.defines.push_back("PTL_WAVES_PER_EU=" + std::to_string(waves));
+    std::vector<const char*> defines;
+    for (auto& d : s->last.defines) defines.push_back(d.c_str());
+    ptl_kernel* k = nullptr;
+    int rc = ptl_kernel_compile(r->device, s->last.source.c_str(), s->descs.data(), (int)s->descs.size(), s->last.uniform_block_size, defines.data(),
+                                (int)defines.size(), &k, log, log_cap);
+    if (rc != PTL_OK) return rc;
+    if (r->device >= 0) {  // reload_textures (main.rs:1066-1083)
+        for (const Texture& t : r->scene->textures) {
+            std::string path = r->asset_root.empty() ? t.path : r->asset_root + "/" + t.path;
+            uint8_t* px = nullptr;
+            int w = 0, h = 0;
+            if (ptl_png_read(path.c_str(), &px, &w, &h) != PTL_OK) {
+                ptl_kernel_destroy(k);
+                return PTL_ERR_SCENE;
+            }
+            int trc = ptl_kernel_set_texture(k, (t.name + "_tex").c_str(), px, w, h);
+            std::free(px);
+            if (trc < 0) {
+                ptl_kernel_destroy(k);
+                return trc;
+            }
+        }
+    }
+    ptl_kernel_destroy(r->kernel);
+    r->kernel = k;
+    r->kernel_source = s->last.source;
+    r->kernel_scene_version = r->scene->version;
+    r->uploaded_scene = 0;  // a fresh uniform block: upload everything again
+    r->uploaded_options = 0;
+    return PTL_OK;
+}
+
 extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_root, unsigned flags, ptl_renderer** out, char* log,
                                    size_t log_cap) {
     if (!s || !out) return PTL_ERR_INVALID;
@@ -325,13 +379,10 @@ extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_r
         auto r = std::make_unique<ptl_renderer>();
         r->owner = s;
         r->scene = s->scene;
-        refresh_generated(s, flags);
-        unsigned waves = (flags >> 8) & 0xFu;  // occupancy hint: __launch_bounds__(256, waves)
-        if (waves) s->last.defines.push_back("PTL_WAVES_PER_EU=" + std::to_string(waves));
-        std::vector<const char*> defines;
-        for (auto& d : s->last.defines) defines.push_back(d.c_str());
-        int rc = ptl_kernel_compile(device, s->last.source.c_str(), s->descs.data(), (int)s->descs.size(), s->last.uniform_block_size, defines.data(),
-                                    (int)defines.size(), &r->kernel, log, log_cap);
+        r->device = device;
+        r->flags = flags;
+        r->asset_root = asset_root ? asset_root : "";
+        int rc = build_kernel(r.get(), log, log_cap);
         if (rc != PTL_OK) return rc;
         // cam.set_cam(scene.cam); offset_after_material from the scene (main.rs:1057-1059)
         const CamSettings& c = s->scene->cam;
@@ -340,25 +391,6 @@ extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_r
         r->cam.beta = c.beta;
         r->cam.r = c.r;
         r->offset_after_material = c.offset_after_material;
-        // reload_textures (main.rs:1066-1083)
-        if (device >= 0) {
-            for (const Texture& t : s->scene->textures) {
-                std::string path = (asset_root && *asset_root) ? std::string(asset_root) + "/" + t.path : t.path;
-                uint8_t* px = nullptr;
-                int w = 0, h = 0;
-                int prc = ptl_png_read(path.c_str(), &px, &w, &h);
-                if (prc != PTL_OK) {
-                    ptl_kernel_destroy(r->kernel);
-                    return PTL_ERR_SCENE;
-                }
-                int trc = ptl_kernel_set_texture(r->kernel, (t.name + "_tex").c_str(), px, w, h);
-                std::free(px);
-                if (trc < 0) {
-                    ptl_kernel_destroy(r->kernel);
-                    return trc;
-                }
-            }
-        }
         *out = r.release();
         return PTL_OK;
     });
@@ -389,6 +421,7 @@ extern "C" int ptl_renderer_set_option(ptl_renderer* r, const char* name, double
     else if (n == "draw_side_by_side") r->draw_side_by_side = b;
     else if (n == "in_subspace") r->cam.in_subspace = b;
     else return PTL_UNKNOWN_UNIFORM;
+    ++r->options_version;
     return PTL_OK;
 }
 
@@ -398,6 +431,7 @@ extern "C" int ptl_renderer_set_camera(ptl_renderer* r, const double look_at[3],
     r->cam.alpha = alpha;
     r->cam.beta = beta;
     r->cam.r = radius;
+    ++r->options_version;
     return PTL_OK;
 }
 
@@ -420,10 +454,25 @@ extern "C" int ptl_renderer_uniform_value(ptl_renderer* r, int width, int height
 }
 
 static int prepare_draw(ptl_renderer* r, const ptl_frame* frame) {
-    std::vector<std::string> errors;
-    int rc = upload(r->kernel, evaluate_scene_uniforms(*r->scene, &errors));  // scene.set_uniforms
-    if (rc < 0) return rc;
-    return upload(r->kernel, builtin_uniforms(*r, frame->width, frame->height));  // self.set_uniforms(w, h)
+    if ((r->flags & 5u) != 0 && r->kernel_scene_version != r->scene->version) {
+        // values are baked into a specialised kernel: the scene changed, so JIT again (cached by source hash)
+        int rc = build_kernel(r, nullptr, 0);
+        if (rc != PTL_OK) return rc;
+    }
+    if (r->uploaded_scene != r->scene->version) {
+        std::vector<std::string> errors;
+        int rc = upload(r->kernel, evaluate_scene_uniforms(*r->scene, &errors));  // scene.set_uniforms
+        if (rc < 0) return rc;
+        r->uploaded_scene = r->scene->version;
+    }
+    if (r->uploaded_options != r->options_version || r->uploaded_w != frame->width || r->uploaded_h != frame->height) {
+        int rc = upload(r->kernel, builtin_uniforms(*r, frame->width, frame->height));  // self.set_uniforms(w, h)
+        if (rc < 0) return rc;
+        r->uploaded_options = r->options_version;
+        r->uploaded_w = frame->width;
+        r->uploaded_h = frame->height;
+    }
+    return PTL_OK;
 }
 
 extern "C" int ptl_renderer_draw(ptl_renderer* r, const ptl_frame* frame, void* out_rgba8, void* out_rgba32f, void* segments, void* stream,

@@ -327,6 +327,7 @@ bool Scene::set_uniform_value(const std::string& name, double v) {
     int idx = find_uniform(name);
     if (idx < 0) return false;
     Uniform& u = uniforms[idx].value;
+    ++version;
     switch (u.kind) {
         case Uniform::Bool: u.b = v > 0.5; break;
         case Uniform::Int: u.i = (int)v; break;

@@ -117,6 +117,8 @@ public:
     std::optional<std::string> skybox;
     bool use_time = false;
 
+    // bumped by every mutation that can change an evaluated value (renderers cache on it)
+    unsigned long long version = 1;
     // formula time inputs (FormulasCache, src/gui/uniform.rs:625-697)
     double time = 0.0, total_time = 0.0;
     DMat4 camera_matrix = DMat4::identity();

@@ -31,32 +31,46 @@ def alloc_shard(height: int, width: int, world: int, device) -> torch.Tensor:
 
 
 class FrameGatherer:
-    """Pre-allocated buffers for gathering one frame per step on `dst`."""
+    """Pre-allocated buffers for gathering one frame per step on `dst`.
 
-    def __init__(self, height: int, width: int, rank: int, world: int, device, dst: int = 0):
+    `depth` > 1 double-buffers the gather target so that `gather_async` of frame n can overlap the
+    tracing of frame n+1 (the collective runs on the process group's own stream)."""
+
+    def __init__(self, height: int, width: int, rank: int, world: int, device, dst: int = 0, depth: int = 1):
         self.h, self.w, self.rank, self.world, self.dst = height, width, rank, world, dst
         self.kmax = shard_blocks_max(height, world)
-        self.parts = None
-        self.full = None
-        if rank == dst:
-            self.full = torch.empty((self.kmax * world * 8, width, 4), dtype=torch.uint8, device=device)
-            if world > 1:
-                self.parts = [torch.empty((self.kmax * 8, width, 4), dtype=torch.uint8, device=device) for _ in range(world)]
+        self.slots = []
+        for _ in range(depth):
+            full = gathered = None
+            if rank == dst:
+                full = torch.empty((self.kmax * world * 8, width, 4), dtype=torch.uint8, device=device)
+                if world > 1:
+                    gathered = torch.empty((world, self.kmax * 8, width, 4), dtype=torch.uint8, device=device)
+            self.slots.append((full, gathered))
 
-    def gather(self, shard: torch.Tensor) -> Optional[torch.Tensor]:
+    def _assemble(self, slot: int) -> torch.Tensor:
+        full, gathered = self.slots[slot]
+        # gathered[g, k*8:(k+1)*8] is frame block k*world + g: one strided copy puts every block in place
+        full.view(self.kmax, self.world, 8, self.w, 4).copy_(gathered.view(self.world, self.kmax, 8, self.w, 4).transpose(0, 1))
+        return full[: self.h]
+
+    def gather(self, shard: torch.Tensor, slot: int = 0) -> Optional[torch.Tensor]:
         """shard: this rank's packed rows, shape (kmax*8, W, 4).  Returns the (H, W, 4) frame on dst."""
         if self.world == 1:
             return shard[: self.h]
-        dist.gather(shard, self.parts, dst=self.dst)
-        if self.rank != self.dst:
+        gathered = self.slots[slot][1]
+        dist.gather(shard, list(gathered.unbind(0)) if self.rank == self.dst else None, dst=self.dst)
+        return self._assemble(slot) if self.rank == self.dst else None
+
+    def gather_async(self, shard: torch.Tensor, slot: int = 0):
+        """Start the gather; returns a handle for `finish`."""
+        if self.world == 1:
             return None
-        # gathered[g][k*8:(k+1)*8] is frame block k*world + g: stack along a new axis 1 and flatten
-        _interleave(self.parts, self.full, self.kmax, self.world, self.w)
-        return self.full[: self.h]
+        gathered = self.slots[slot][1]
+        return dist.gather(shard, list(gathered.unbind(0)) if self.rank == self.dst else None, dst=self.dst, async_op=True)
 
-
-def _interleave(parts, full, kmax, world, width):
-    view = full.view(kmax, world, 8, width, 4)
-    for g, p in enumerate(parts):
-        view[:, g].copy_(p.view(kmax, 8, width, 4))
-    return full
+    def finish(self, work, shard: torch.Tensor, slot: int = 0) -> Optional[torch.Tensor]:
+        if self.world == 1:
+            return shard[: self.h]
+        work.wait()
+        return self._assemble(slot) if self.rank == self.dst else None

@@ -194,3 +194,25 @@ def test_full_size_properties_triple_portal_4k(gpu):
     rows = [0, 1079, 2159]
     ref = host_build.host_kernel_for(r, scene, w, h).render(w, h, rows=rows)
     assert _bits_equal(whole["rgba32f"][rows], ref["rgba32f"]).all()
+
+
+def test_specialised_kernel_follows_scene_changes(gpu):
+    """JIT specialisation bakes scene uniforms into the kernel: changing one afterwards must
+    re-JIT (transparently) and give exactly the frame of the dynamic-uniform kernel."""
+    pa = gpu
+    frames = {}
+    for name, flags in (("dynamic", 0), ("baked", pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)):
+        scene = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+        r = pa.SceneRenderer(scene, device=0, flags=flags)
+        r.set_option("render_depth", 40)
+        a = r.draw(128, 72)["rgba8"]
+        scene.set_uniform("progress", 0.4)         # formula-driven portal matrix
+        scene.set_uniform("teleport_light", 0)     # mode switch (Bool)
+        b = r.draw(128, 72)["rgba8"]
+        r.set_camera((0.0, 0.0, 0.0), 0.5, 1.2, 3.0)  # builtins stay dynamic: no re-JIT needed
+        c = r.draw(128, 72)["rgba8"]
+        frames[name] = (a, b, c)
+    for x, y in zip(frames["dynamic"], frames["baked"]):
+        assert np.array_equal(x, y)
+    a, b, c = frames["dynamic"]
+    assert not np.array_equal(a, b) and not np.array_equal(b, c)
