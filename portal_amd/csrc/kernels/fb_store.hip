@@ -1,38 +1,54 @@
 // fb_store.hip -- the framebuffer store pattern of ptl_render_kernel in isolation.
 //
 // BASELINE.json asks for ">= 60 % of the HBM roofline on the framebuffer write".  Inside the
-// trace kernel the store is ~0.1 % of the time (the kernel is FP32-VALU-bound),
-// so this micro-benchmark measures what the store *instruction pattern* sustains when nothing
-// else runs: the same 32x8 block / 8x8-tile-per-wave mapping, RGBA8 through the LDS transpose
-// (two 128-byte rows per wave) and RGBA32F as one float4 per lane (128 bytes per tile row).
+// trace kernel the store is well under 1 % of the time (the kernel is FP32-VALU-bound, DESIGN.md
+// section 2.1), so this micro-benchmark measures what the store *instruction pattern* sustains when
+// nothing else runs.  Same launch geometry and entry signature as the trace kernel (it is loaded
+// through the same C ABI, ptl_kernel_compile), selected with -DPTL_FB_VARIANT=
+//   0  RGBA8 through the 32x8 LDS transpose: two 128-byte rows per wave       (what the renderer does)
+//   1  RGBA32F, one float4 per lane: 128 bytes per 8x8-tile row                (the parity buffer)
+//   2  RGBA8 straight from the 8x8 tile: 32-byte row segments                  (no transpose, for contrast)
+//   3  linear streaming store, 16 B per lane, grid-stride                      (upper reference)
+// Built ahead of time by `make kernels` (hipcc --genco, gfx950) as a compile check and at run time
+// by tools/fb_store_bench.py through hiprtc.
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
+
+#ifndef PTL_FB_VARIANT
+#define PTL_FB_VARIANT 0
+#endif
+
+namespace glsl {
+struct ptl_uniform_block { int seed_u; int pad_u; };
+__constant__ ptl_uniform_block ptl_u;
+}  // namespace glsl
 
 extern "C" __global__ void __launch_bounds__(256)
-ptl_fb_store_rgba8(unsigned int* __restrict__ out, int width, int height, unsigned int seed) {
-    __shared__ unsigned int tile[8][32 + 1];
+ptl_render_kernel(unsigned int* __restrict__ out_rgba8, float* __restrict__ out_rgba32f, int width, int height,
+                  int rb_phase, int rb_stride, unsigned long long* __restrict__ segments) {
     const int t = (int)threadIdx.x;
     const int wave = t >> 6, lane = t & 63;
     const int lx = wave * 8 + (lane & 7), ly = lane >> 3;
-    tile[ly][lx] = seed ^ (unsigned)((blockIdx.y * 8 + ly) * width + blockIdx.x * 32 + lx);
+    const int px = (int)blockIdx.x * 32 + lx;
+    const int py = (int)blockIdx.y * 8 + ly;
+    const unsigned int v = (unsigned)glsl::ptl_u.seed_u ^ (unsigned)(py * width + px);
+#if PTL_FB_VARIANT == 0
+    __shared__ unsigned int tile[8][32 + 1];
+    tile[ly][lx] = v;
     __syncthreads();
     const int row = t >> 5, col = t & 31;
     const int gx = (int)blockIdx.x * 32 + col, gy = (int)blockIdx.y * 8 + row;
-    if (gx < width && gy < height) out[(long)gy * width + gx] = tile[row][col];
-}
-
-extern "C" __global__ void __launch_bounds__(256)
-ptl_fb_store_rgba32f(float4* __restrict__ out, int width, int height, float seed) {
-    const int t = (int)threadIdx.x;
-    const int wave = t >> 6, lane = t & 63;
-    const int px = (int)blockIdx.x * 32 + wave * 8 + (lane & 7);
-    const int py = (int)blockIdx.y * 8 + (lane >> 3);
-    if (px < width && py < height) out[(long)py * width + px] = make_float4(seed, (float)px, (float)py, 1.0f);
-}
-
-// Same bytes with the textbook streaming pattern (grid-stride, 16 B per lane, fully linear),
-// as the upper reference for the two kernels above.
-extern "C" __global__ void __launch_bounds__(256)
-ptl_fb_store_linear(float4* __restrict__ out, long n_vec, float seed) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long)gridDim.x * blockDim.x)
-        out[i] = make_float4(seed, (float)i, 0.0f, 1.0f);
+    if (gx < width && gy < height) out_rgba8[(long)gy * width + gx] = tile[row][col];
+#elif PTL_FB_VARIANT == 1
+    if (px < width && py < height)
+        reinterpret_cast<float4*>(out_rgba32f)[(long)py * width + px] = make_float4((float)v, (float)px, (float)py, 1.0f);
+#elif PTL_FB_VARIANT == 2
+    if (px < width && py < height) out_rgba8[(long)py * width + px] = v;
+#else
+    const long n_vec = (long)width * height / 4;  // RGBA8 frame as uint4
+    const long stride = (long)gridDim.x * gridDim.y * 256;
+    for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + t; i < n_vec; i += stride)
+        reinterpret_cast<uint4*>(out_rgba8)[i] = make_uint4(v, v + 1, v + 2, v + 3);
+#endif
 }
