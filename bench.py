@@ -34,6 +34,19 @@ FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 
 
 
+def profiled_traffic(args, waves):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_*.json: FETCH_SIZE and
+    WRITE_SIZE are collected in separate passes, KB units, FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md) -- only when that profile is of exactly this workload and build, else None."""
+    if (args.scene, args.width, args.height, args.depth, args.aa, args.specialize) != ("portal_in_portal", 3840, 2160, 40, 1, 2) or waves != 4:
+        return None
+    try:
+        c = json.load(open(os.path.join(HERE, "profiles", "r01", "pmc_pip4k_spec_w4.json")))["counters"]
+        return int((2 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+    except Exception:
+        return None
+
+
 def flops_per_segment(scene: str):
     """Executed binary32 operations per bounce-loop trip (fma = 2), counted by the numpy oracle
     on the scaled-down golden frame of the scene (tests/golden/make_golden.py).  Data file only."""
@@ -265,25 +278,29 @@ def main():
                 "tuning_ms": tuning,
             },
             "kernel_ms": round(kernel_ms, 4),
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 3),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": None,
-                "note": "algorithmic bytes = RGBA8 framebuffer store only; the kernel is FP32-VALU/divergence-bound, see roofline_valu",
-            },
+        }
+        hbm = {
+            "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+            "traffic": profiled_traffic(args, best_waves),
+            "note": "algorithmic bytes = the RGBA8 framebuffer store (4 B/pixel); constants and textures are cache-resident",
         }
         if segments is not None:
             out["segments_per_frame"] = segments
             out["segment_mray_s"] = round(segments / (ms_per_step * 1e-3) / 1e6, 3)
-            fl = flops_per_segment(args.scene)
-            if fl:
-                tf = segments * fl / (kernel_ms * 1e-3) / 1e12 / world
-                out["roofline_valu"] = {"bound": "valu_fp32", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": round(tf / FP32_PEAK_TFLOPS, 5), "flops_per_segment": round(fl, 1),
-                                        "note": "algorithmic binary32 ops of the un-specialised arithmetic (oracle count) x segments / kernel time"}
+        fl = flops_per_segment(args.scene)
+        if segments is not None and fl:
+            # the binding roofline: binary32 arithmetic.  MI355X's f32 MFMA peak equals its f32 vector peak
+            # (157.3 TFLOP/s); this path has no contraction for the matrix cores, it runs on the VALU.
+            tf = segments / world * fl / (kernel_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5),
+                "traffic": hbm["traffic"],
+                "note": "compute-bound (FP32 VALU; f32 vector peak == f32 MFMA peak, no MFMA used). achieved = algorithmic binary32 ops per "
+                        f"bounce-loop trip ({fl:.0f}, fma=2, counted by the numpy oracle on the un-specialised arithmetic) x trips per launch / kernel time",
+            }
+            out["roofline_hbm"] = hbm
+        else:
+            out["roofline"] = hbm
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, pa)

@@ -105,6 +105,13 @@ int ptl_kernel_render(ptl_kernel* k, const ptl_frame* frame, void* out_rgba8, vo
 int ptl_kernel_render_to_host(ptl_kernel* k, const ptl_frame* frame, uint8_t* host_rgba8, float* host_rgba32f,
                               uint64_t* host_segments, float* elapsed_ms);
 
+/* SceneRenderer::teleport_external_ray (src/main.rs:1361-1409): where does point b end up when the
+ * segment a -> b is carried through the scene's portals (at most 10)?  One-thread launch of the
+ * kernel's second entry point; synchronous.  teleported = 0 means "no portal crossed" (the
+ * reference's `None`), out_pos is then (0,0,0).  Uses whatever uniforms are currently set. */
+int ptl_kernel_teleport_ray(ptl_kernel* k, const float a[3], const float b[3], float out_pos[3], int* hit_object,
+                            int* changed_subspace, int* teleported);
+
 void ptl_kernel_destroy(ptl_kernel* k);
 
 /* ---- layer 2: scene + renderer ------------------------------------------------------------- */
@@ -173,6 +180,10 @@ int ptl_renderer_draw(ptl_renderer* r, const ptl_frame* frame, void* out_rgba8, 
                       void* stream, float* elapsed_ms);
 int ptl_renderer_draw_to_host(ptl_renderer* r, const ptl_frame* frame, uint8_t* host_rgba8, float* host_rgba32f,
                               uint64_t* host_segments, float* elapsed_ms);
+/* The same through the renderer: uploads scene + builtin uniforms as teleport_external_ray does
+ * (set_uniforms(0,0), teleport_light_u = 1), then ptl_kernel_teleport_ray. */
+int ptl_renderer_teleport_ray(ptl_renderer* r, const double a[3], const double b[3], double out_pos[3], int* hit_object,
+                              int* changed_subspace, int* teleported);
 ptl_kernel* ptl_renderer_kernel(ptl_renderer* r);
 void ptl_renderer_destroy(ptl_renderer* r);
 

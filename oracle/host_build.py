@@ -56,6 +56,8 @@ class HostKernel:
         self.lib.ptl_host_uniform_block.argtypes = [C.POINTER(C.c_ulong)]
         self.lib.ptl_host_render.restype = C.c_ulonglong
         self.lib.ptl_host_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        self.lib.ptl_host_teleport.restype = None
+        self.lib.ptl_host_teleport.argtypes = [C.c_void_p]
         size = C.c_ulong()
         self.block = self.lib.ptl_host_uniform_block(C.byref(size))
         assert size.value >= block_size, (size.value, block_size)
@@ -85,6 +87,14 @@ class HostKernel:
         rec["p"], rec["w"], rec["h"] = tex.ctypes.data, tex.shape[1], tex.shape[0]
         C.memmove(self.block + off, rec.ctypes.data, 16)
         return True
+
+    def teleport_external_ray(self, a, b):
+        """-> (pos float32[3] | None, encounter_object, change_subspace); needs _external_ray_a/_b in the layout."""
+        self.set_uniform("_external_ray_a", np.asarray(a, np.float32))
+        self.set_uniform("_external_ray_b", np.asarray(b, np.float32))
+        out = np.zeros(6, np.float32)
+        self.lib.ptl_host_teleport(out.ctypes.data)
+        return (out[:3].copy() if out[3] else None), bool(out[4]), bool(out[5])
 
     def render(self, width: int, height: int, rows=None, cols=None, threads: int = 0, rgba8: bool = True, rgba32f: bool = True):
         """Render rows x cols of a width x height frame.  `rows` is a (r0, r1) range or an

@@ -588,6 +588,55 @@ class Oracle:
             all_t = all_t[sel]
         return result, segments
 
+    # ---- frag.glsl:209-257 + host side src/main.rs:1361-1409 ----------------------------------------
+    def teleport_external_ray(self, a, b):
+        """Segment a -> b through at most ten portals.  Returns (pos float32[3] | None, encounter_object,
+        change_subspace) like SceneRenderer::teleport_external_ray."""
+        self.build(0, 0)
+        u, nat = self.uniforms, self.nat
+        # src/main.rs:1367: teleport_light_u is forced to 1 for this query
+        if "teleport_light_u" in self._program.globals:
+            self._program.globals["teleport_light_u"] = I32(1)
+        a32, b32 = np.asarray(a, np.float64).astype(F32), np.asarray(b, np.float64).astype(F32)
+        in_sub = int(u["_camera_in_subspace"]) == 1
+        r = Ray(vec(a32[0], a32[1], a32[2], 1.0), Vec(list(sub(vec(*b32), vec(*a32)).c) + [fl(0.0)]), fl(1.0), np.array([in_sub]))
+        r = V.expand(nat.normalize_ray(r), 1)
+        have_result, stop_at_object = False, False
+        all_t = np.zeros(1, F32)
+        one = np.ones(1, bool)
+        for _ in range(10):
+            it = Interp(1, self._program)
+            M.set_active(1)
+            i = self.scene_intersect(it, r, one)
+            i2 = self.scene_intersect_material_process(it, r, one)
+            cont = False
+            use2 = bool(nat.nearer(i.f["hit"], i2.f["scene"].f["hit"])[0])
+            src = i2.f["scene"] if use2 else (i if bool(np.asarray(i.f["hit"].f["hit"]).reshape(-1)[0]) else None)
+            if src is not None:
+                t = src.f["hit"].f["t"]
+                if bool((M.add(M.mul(t, r.f["tmul"]), all_t) < fl(1.0))[0]):
+                    r = r.with_field("o", add(r.f["o"], mul(r.f["d"], t)))
+                    all_t = M.add(all_t, M.mul(t, r.f["tmul"]))
+                    if use2 and int(np.asarray(i2.f["scene"].f["material"]).reshape(-1)[0]) == CUSTOM_MATERIAL:
+                        m = i2.f["material"]
+                    else:
+                        m = self.material_process(it, r, src, one)
+                    final = bool(np.asarray(m.f["is_final"]).reshape(-1)[0])
+                    cont = not final
+                    stop_at_object = stop_at_object or final
+            if not cont:
+                break
+            r = V.expand(m.f["new_ray"], 1)
+            have_result = True
+        change_subspace = int(bool(np.asarray(r.f["in_subspace"]).reshape(-1)[0])) != int(u["_camera_in_subspace"])
+        if not have_result:
+            return None, stop_at_object, change_subspace
+        o = add(r.f["o"], div(mul(r.f["d"], M.sub(fl(1.0), all_t)), r.f["tmul"]))
+        pos = np.array([np.asarray(c).reshape(-1)[0] for c in o.c[:3]], F32)
+        if pos[0] == 0 and pos[1] == 0 and pos[2] == 0:
+            return None, stop_at_object, change_subspace
+        return pos, stop_at_object, change_subspace
+
     # ---- frag.glsl:305-342 -----------------------------------------------------------------------
     def panini(self, tc, fov, d):
         pow2 = lambda x: M.mul(x, x)

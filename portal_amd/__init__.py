@@ -64,6 +64,7 @@ def _load() -> C.CDLL:
         "ptl_frame_shard_rows": (ci, [P(Frame)]),
         "ptl_kernel_render": (ci, [vp, P(Frame), vp, vp, vp, vp, P(C.c_float)]),
         "ptl_kernel_render_to_host": (ci, [vp, P(Frame), vp, vp, P(C.c_uint64), P(C.c_float)]),
+        "ptl_kernel_teleport_ray": (ci, [vp, P(C.c_float), P(C.c_float), P(C.c_float), P(ci), P(ci), P(ci)]),
         "ptl_kernel_destroy": (None, [vp]),
         "ptl_scene_load_file": (ci, [cp, P(vp)]),
         "ptl_scene_load_text": (ci, [cp, P(vp)]),
@@ -86,6 +87,7 @@ def _load() -> C.CDLL:
         "ptl_renderer_uniform_value": (ci, [vp, ci, ci, cp, P(C.c_float), P(ci)]),
         "ptl_renderer_draw": (ci, [vp, P(Frame), vp, vp, vp, vp, P(C.c_float)]),
         "ptl_renderer_draw_to_host": (ci, [vp, P(Frame), vp, vp, P(C.c_uint64), P(C.c_float)]),
+        "ptl_renderer_teleport_ray": (ci, [vp, P(cd), P(cd), P(cd), P(ci), P(ci), P(ci)]),
         "ptl_renderer_kernel": (vp, [vp]),
         "ptl_renderer_destroy": (None, [vp]),
         "ptl_deinterleave_rows": (ci, [vp, P(Frame), vp]),
@@ -296,6 +298,13 @@ class SceneRenderer:
             return None
         a = np.array(out[: n.value], dtype=np.float32)
         return a.reshape(4, 4).T.copy() if n.value == 16 else (a[0] if n.value == 1 else a)
+
+    def teleport_external_ray(self, a, b):
+        """SceneRenderer::teleport_external_ray (src/main.rs:1361-1409) -> (pos | None, encounter_object, change_subspace)."""
+        pa_, pb_, out = (C.c_double * 3)(*a), (C.c_double * 3)(*b), (C.c_double * 3)()
+        hit, sub, tel = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().ptl_renderer_teleport_ray(self._h, pa_, pb_, out, C.byref(hit), C.byref(sub), C.byref(tel)), "teleport_external_ray")
+        return (tuple(out) if tel.value else None), bool(hit.value), bool(sub.value)
 
     def code_object(self) -> bytes:
         k = lib().ptl_renderer_kernel(self._h)

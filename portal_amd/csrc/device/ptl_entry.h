@@ -24,7 +24,9 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
                   int width, int height,                   // full frame size
                   int rb_phase, int rb_stride,             // row-block interleave
                   unsigned long long* __restrict__ segment_counter) {
+#ifndef PTL_DIRECT_STORE
     __shared__ unsigned int tile[8][32 + 1];
+#endif
     const int t = (int)threadIdx.x;
     const int wave = t >> 6, lane = t & 63;
     const int lx = wave * 8 + (lane & 7);
@@ -53,6 +55,9 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
         float4 v = make_float4(c.x, c.y, c.z, c.w);
         *reinterpret_cast<float4*>(out_rgba32f + 4 * (shard_row * width + px)) = v;  // 8 lanes x 16 B = one 128 B line per tile row
     }
+#ifdef PTL_DIRECT_STORE
+    if (out_rgba8 != nullptr && live) out_rgba8[shard_row * width + px] = glsl::pack_rgba8(c);  // 8 lanes x 4 B = 32 B per tile row
+#else
     if (out_rgba8 != nullptr) {
         tile[ly][lx] = glsl::pack_rgba8(c);
         __syncthreads();
@@ -61,6 +66,7 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
         const int gy = (rb_phase + local_block * rb_stride) * 8 + row;
         if (gx < width && gy < height) out_rgba8[((long)local_block * 8 + row) * width + gx] = tile[row][col];
     }
+#endif
 #ifdef PTL_COUNT_SEGMENTS
     if (segment_counter != nullptr) {
         unsigned int n = ptl_segments_lds[t];
@@ -70,8 +76,22 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
 #endif
 }
 
-// One-thread launch: the camera-teleport query of src/main.rs:1361-1409 would go here
-// ("next"); not part of the image path.
+// The camera-teleport query of src/main.rs:1361-1409: one thread instead of the reference's 2x3-pixel
+// draw with float-in-RGBA8 packing.
+extern "C" __global__ void __launch_bounds__(64) ptl_teleport_kernel(float* __restrict__ out6) {
+#ifdef PTL_UNIFORMS_IN_LDS
+    {
+        const unsigned int* src = reinterpret_cast<const unsigned int*>(&glsl::ptl_u);
+        unsigned int* dst = reinterpret_cast<unsigned int*>(&glsl::ptl_lds_u);
+        for (int i = (int)threadIdx.x; i < (int)(sizeof(glsl::ptl_uniform_block) / 4); i += 64) dst[i] = src[i];
+        __syncthreads();
+    }
+#endif
+#ifdef PTL_COUNT_SEGMENTS
+    ptl_segments_lds[threadIdx.x] = 0u;
+#endif
+    if (threadIdx.x == 0 && blockIdx.x == 0) glsl::teleport_external_ray_entry(out6);
+}
 
 #else  // host build of the same source (oracle/host_build): rows [row_begin, row_end) of the frame
 
@@ -82,6 +102,8 @@ extern "C" void* ptl_host_uniform_block(unsigned long* size) {
     if (size) *size = sizeof(glsl::ptl_u);
     return &glsl::ptl_u;
 }
+
+extern "C" void ptl_host_teleport(float* out6) { glsl::teleport_external_ray_entry(out6); }
 
 // Renders the listed pixel rows x columns [col_begin, col_end) of a width x height frame into
 // out_* (output row i = rows[i]) with `threads` OpenMP threads.  Returns the number of

@@ -173,6 +173,77 @@ PTL_FN RayTraceResult ray_tracing(Ray r, float camera_scale) {
     return RayTraceResult{color(0.0f, 0.0f, 0.0f), 0.0f, false};  // depth exhausted
 }
 
+// --- camera teleportation -------------------------------------------- src/frag.glsl:199-257
+// Follows the segment a -> b (r.o = a, r.d = b - a, so the segment is t*tmul in [0, 1]) through up to
+// ten portals and returns where b ends up.  The reference packs the three floats into RGBA8 pixels
+// (encode_float, frag.glsl:166-197,527-548) because GL can only return colours; here the kernel
+// returns the struct itself, `teleported` standing for the reference's "(x, y, z) != 0" test
+// (src/main.rs:1400-1408).
+struct ExternalRayTeleportation {
+    vec3 pos;
+    bool encounter_object;
+    bool change_subspace;
+    bool teleported;
+};
+
+PTL_FN ExternalRayTeleportation teleport_external_ray(Ray r) {
+    r = normalize_ray(r);
+    bool have_result = false;
+    bool stop_at_object = false;
+    float all_t = 0.0f;
+    const int max_camera_teleports = 10;
+    for (int j = 0; j < max_camera_teleports; j++) {
+        SceneIntersection i = scene_intersect(r);
+        SceneIntersectionWithMaterial i2 = scene_intersect_material_process(r);
+        bool continue_intersect = false;
+        MaterialProcessing m = MaterialProcessing{false, vec3(0.0f), ray_none};
+        if (nearer(i.hit, i2.scene.hit)) {
+            if (i2.scene.hit.t * r.tmul + all_t < 1.0f) {
+                r.o += r.d * i2.scene.hit.t;
+                all_t += i2.scene.hit.t * r.tmul;
+                if (i2.scene.material == CUSTOM_MATERIAL) {
+                    m = i2.material;
+                } else {
+                    m = material_process(r, i2.scene);
+                }
+                continue_intersect = !m.is_final;
+                stop_at_object = stop_at_object || m.is_final;
+            }
+        } else if (i.hit.hit) {
+            if (i.hit.t * r.tmul + all_t < 1.0f) {
+                r.o += r.d * i.hit.t;
+                all_t += i.hit.t * r.tmul;
+                m = material_process(r, i);
+                continue_intersect = !m.is_final;
+                stop_at_object = stop_at_object || m.is_final;
+            }
+        }
+        if (!continue_intersect) break;
+        r = m.new_ray;
+        have_result = true;
+    }
+    bool change_subspace = int(r.in_subspace) != _camera_in_subspace;
+    if (have_result) {
+        r.o += r.d * (1.0f - all_t) / r.tmul;
+        vec3 p = r.o.sw<0, 1, 2>();
+        return ExternalRayTeleportation{p, stop_at_object, change_subspace, !(p.x == 0.0f && p.y == 0.0f && p.z == 0.0f)};
+    }
+    return ExternalRayTeleportation{vec3(0.0f), stop_at_object, change_subspace, false};
+}
+
+// The launchable form: reads the segment from the _external_ray_a/_b uniforms (frag.glsl:529) and
+// writes {x, y, z, teleported, encounter_object, change_subspace}.
+PTL_FN void teleport_external_ray_entry(float* out6) {
+    ExternalRayTeleportation t = teleport_external_ray(
+        Ray{vec4(_external_ray_a, 1.0f), vec4(_external_ray_b - _external_ray_a, 0.0f), 1.0f, _camera_in_subspace == 1});
+    out6[0] = t.pos.x;
+    out6[1] = t.pos.y;
+    out6[2] = t.pos.z;
+    out6[3] = t.teleported ? 1.0f : 0.0f;
+    out6[4] = t.encounter_object ? 1.0f : 0.0f;
+    out6[5] = t.change_subspace ? 1.0f : 0.0f;
+}
+
 // --- camera ---------------------------------------------------------- src/frag.glsl:297-342
 PTL_FN float Pow2(float x) { return x * x; }
 

@@ -493,6 +493,25 @@ extern "C" int ptl_renderer_draw_to_host(ptl_renderer* r, const ptl_frame* frame
         return ptl_kernel_render_to_host(r->kernel, frame, host_rgba8, host_rgba32f, host_segments, elapsed_ms);
     });
 }
+extern "C" int ptl_renderer_teleport_ray(ptl_renderer* r, const double a[3], const double b[3], double out_pos[3], int* hit_object,
+                                         int* changed_subspace, int* teleported) {
+    if (!r || !a || !b) return PTL_ERR_INVALID;
+    return guarded([&] {
+        ptl_frame zero{0, 0, 0, 1};  // the reference calls self.set_uniforms(0., 0.) here
+        int rc = prepare_draw(r, &zero);
+        if (rc < 0) return rc;
+        int one = 1;
+        ptl_kernel_set_uniform(r->kernel, "teleport_light_u", PTL_I32, &one);  // src/main.rs:1367 (a scene without it: no-op)
+        float fa[3] = {(float)a[0], (float)a[1], (float)a[2]}, fb[3] = {(float)b[0], (float)b[1], (float)b[2]}, pos[3] = {0, 0, 0};
+        rc = ptl_kernel_teleport_ray(r->kernel, fa, fb, pos, hit_object, changed_subspace, teleported);
+        r->uploaded_scene = 0;  // teleport_light_u was overridden: the next draw re-uploads the scene values
+        r->uploaded_w = -1;
+        if (rc == PTL_OK && out_pos)
+            for (int k = 0; k < 3; ++k) out_pos[k] = (double)pos[k];
+        return rc;
+    });
+}
+
 extern "C" ptl_kernel* ptl_renderer_kernel(ptl_renderer* r) { return r ? r->kernel : nullptr; }
 extern "C" void ptl_renderer_destroy(ptl_renderer* r) {
     if (!r) return;

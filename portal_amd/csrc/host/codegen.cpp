@@ -331,6 +331,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 return buf;
             };
             for (auto& up : evaluate_scene_uniforms(scene, nullptr)) {
+                if (up.name == "teleport_light_u") continue;  // forced to 1 by the camera-teleport query (src/main.rs:1367)
                 if (up.type == UniformType::Int1) {
                     baked[up.name] = std::to_string(up.i);
                 } else if (opts.specialize_all && up.type == UniformType::Float1) {

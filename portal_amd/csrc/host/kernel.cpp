@@ -77,6 +77,7 @@ struct ptl_kernel {
     std::vector<char> code;
     hip::hipModule_t module = nullptr;
     hip::hipFunction_t fn = nullptr;
+    hip::hipFunction_t teleport_fn = nullptr;  // optional: ptl_teleport_kernel
     void* dev_block = nullptr;  // address of __constant__ ptl_u
     size_t dev_block_size = 0;
     std::vector<unsigned char> shadow;  // host copy of the uniform block
@@ -211,6 +212,7 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
     if (!hip_ok(rt, rt->hipModuleLoadData(&k->module, k->code.data()), "hipModuleLoadData")) return PTL_ERR_HIP;
     if (!hip_ok(rt, rt->hipModuleGetFunction(&k->fn, k->module, "ptl_render_kernel"), "hipModuleGetFunction(ptl_render_kernel)"))
         return PTL_ERR_HIP;
+    if (rt->hipModuleGetFunction(&k->teleport_fn, k->module, "ptl_teleport_kernel") != 0) k->teleport_fn = nullptr;
     if (!hip_ok(rt, rt->hipModuleGetGlobal(&k->dev_block, &k->dev_block_size, k->module, "_ZN4glsl5ptl_uE"), "hipModuleGetGlobal(ptl_u)"))
         return PTL_ERR_HIP;
     if (k->dev_block_size < uniform_block_size) {
@@ -343,6 +345,40 @@ extern "C" int ptl_kernel_render_to_host(ptl_kernel* k, const ptl_frame* frame, 
     if (rc == PTL_OK && dseg && !hip_ok(rt, rt->hipMemcpy(host_segments, dseg, 8, hip::kMemcpyDeviceToHost), "hipMemcpy(segments)")) rc = PTL_ERR_HIP;
     cleanup();
     return rc;
+}
+
+extern "C" int ptl_kernel_teleport_ray(ptl_kernel* k, const float a[3], const float b[3], float out_pos[3], int* hit_object,
+                                       int* changed_subspace, int* teleported) {
+    if (!k || !a || !b) return PTL_ERR_INVALID;
+    if (k->device < 0 || !k->fn) return PTL_ERR_NO_DEVICE;
+    if (!k->teleport_fn) {
+        set_last_error("the loaded code object has no ptl_teleport_kernel entry");
+        return PTL_ERR_INVALID;
+    }
+    int rc = ptl_kernel_set_uniform(k, "_external_ray_a", PTL_VEC3, a);
+    if (rc < 0) return rc;
+    rc = ptl_kernel_set_uniform(k, "_external_ray_b", PTL_VEC3, b);
+    if (rc < 0) return rc;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;
+    if (k->dirty) {
+        if (!hip_ok(rt, rt->hipMemcpyAsync(k->dev_block, k->shadow.data(), k->shadow.size(), hip::kMemcpyHostToDevice, nullptr), "hipMemcpyAsync(uniform block)"))
+            return PTL_ERR_HIP;
+        k->dirty = false;
+    }
+    void* dev_out = nullptr;
+    if (!hip_ok(rt, rt->hipMalloc(&dev_out, 8 * sizeof(float)), "hipMalloc(teleport result)")) return PTL_ERR_HIP;
+    void* args[] = {&dev_out};
+    float out[6] = {0};
+    bool ok = hip_ok(rt, rt->hipModuleLaunchKernel(k->teleport_fn, 1, 1, 1, 64, 1, 1, 0, nullptr, args, nullptr), "hipModuleLaunchKernel(teleport)") &&
+              hip_ok(rt, rt->hipMemcpy(out, dev_out, sizeof out, hip::kMemcpyDeviceToHost), "hipMemcpy(teleport result)");
+    rt->hipFree(dev_out);
+    if (!ok) return PTL_ERR_HIP;
+    if (out_pos) std::memcpy(out_pos, out, 3 * sizeof(float));
+    if (teleported) *teleported = out[3] != 0.0f;
+    if (hit_object) *hit_object = out[4] != 0.0f;
+    if (changed_subspace) *changed_subspace = out[5] != 0.0f;
+    return PTL_OK;
 }
 
 extern "C" void ptl_kernel_destroy(ptl_kernel* k) {

@@ -216,3 +216,33 @@ def test_specialised_kernel_follows_scene_changes(gpu):
         assert np.array_equal(x, y)
     a, b, c = frames["dynamic"]
     assert not np.array_equal(a, b) and not np.array_equal(b, c)
+
+
+@pytest.mark.parametrize("scene_name", ["basics", "triple_portal"])
+def test_teleport_external_ray_on_gpu(gpu, scene_name):
+    """Row a11: the one-thread camera-teleport kernel == the numpy oracle, bit for bit."""
+    from oracle.portal_oracle import Oracle
+
+    pa = gpu
+    scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    r = pa.SceneRenderer(scene, device=0)
+    o = Oracle(pa.scene_path(scene_name))
+    vals = scene.uniform_values()
+    rng = np.random.default_rng(9)
+    teleported = 0
+    for tname in sorted(k for k in vals if k.endswith("_mat_teleport")):
+        A = np.asarray(vals[tname[: -len("_mat_teleport")].split("_to_")[0] + "_mat"], np.float64)
+        for _ in range(4):
+            uv = rng.uniform(-0.7, 0.7, 2)
+            a = (A @ np.array([uv[0], uv[1], 0.4, 1.0]))[:3]
+            b = (A @ np.array([uv[0] + 0.1, uv[1], -0.4, 1.0]))[:3]
+            got, want = r.teleport_external_ray(a, b), o.teleport_external_ray(a, b)
+            assert got[1:] == want[1:] and (got[0] is None) == (want[0] is None)
+            if got[0] is not None:
+                assert np.array_equal(np.asarray(got[0], np.float32).view(np.uint32), want[0].view(np.uint32))
+                teleported += 1
+    assert teleported >= 2
+    # the image path still works after the query (teleport_light_u override is undone)
+    a = r.draw(64, 36)["rgba8"]
+    b = pa.SceneRenderer(scene, device=0).draw(64, 36)["rgba8"]
+    assert np.array_equal(a, b)

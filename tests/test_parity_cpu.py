@@ -119,3 +119,45 @@ def test_window_rendering_equals_full_frame(pa):
     assert np.array_equal(full[13:29, 7:61].view(np.uint32), win.view(np.uint32))
     picked = hk.render(80, 60, rows=[59, 0, 17])["rgba32f"]
     assert np.array_equal(picked.view(np.uint32), full[[59, 0, 17]].view(np.uint32))
+
+
+# ---- camera teleportation ---------------------------------------------------
+def _portal_segments(pa, scene_name, n_per_portal=5, seed=3):
+    """Segments that cross (or just miss) each portal of the scene: from local z=+0.4 to z=-0.4."""
+    vals = pa.Scene.from_file(pa.scene_path(scene_name)).uniform_values()
+    rng = np.random.default_rng(seed)
+    out = []
+    for tname in sorted(k for k in vals if k.endswith("_mat_teleport")):
+        a_name = tname[: -len("_mat_teleport")].split("_to_")[0]
+        A = np.asarray(vals[a_name + "_mat"], np.float64)
+        T = np.asarray(vals[tname], np.float64)
+        for _ in range(n_per_portal):
+            uv = rng.uniform(-0.7, 0.7, 2)
+            a = (A @ np.array([uv[0], uv[1], 0.4, 1.0]))[:3]
+            b = (A @ np.array([uv[0] + 0.1, uv[1] - 0.05, -0.4, 1.0]))[:3]
+            out.append((a, b, T))
+    return out
+
+
+@pytest.mark.parametrize("scene_name", ["basics", "monoportal", "triple_portal"])
+def test_teleport_external_ray_matches_oracle_and_the_portal_matrix(pa, scene_name):
+    """teleport_external_ray (src/frag.glsl:209-257, src/main.rs:1361-1409): product == oracle bit for
+    bit; and when a segment does cross a portal its end point b lands at T*b, T = B*A^-1 (known answer)."""
+    from oracle import host_build as hb
+    from oracle.portal_oracle import Oracle
+
+    scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    r = pa.SceneRenderer(scene, device=-1)
+    hk = hb.host_kernel_for(r, scene, 0, 0)
+    hk.set_uniform("teleport_light_u", 1)  # src/main.rs:1367
+    o = Oracle(pa.scene_path(scene_name))
+    crossed = 0
+    for a, b, T in _portal_segments(pa, scene_name):
+        got, want = hk.teleport_external_ray(a, b), o.teleport_external_ray(a, b)
+        assert got[1:] == want[1:] and (got[0] is None) == (want[0] is None)
+        if got[0] is not None:
+            assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+            expect = (T @ np.array([*b, 1.0]))[:3]
+            if np.allclose(got[0], expect, atol=2e-4):
+                crossed += 1
+    assert crossed >= 3

@@ -12,16 +12,15 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 VARIANTS = {
-    "base": "",
-    "spec": "SPECIALIZE",
-    "spec_w3": "SPECIALIZE -DPTL_WAVES_PER_EU=3",
-    "spec_w4": "SPECIALIZE -DPTL_WAVES_PER_EU=4",
     "all": "SPECIALIZE_ALL",
-    "all_w3": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=3",
     "all_w4": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4",
-    "w4": "-DPTL_WAVES_PER_EU=4",
+    "all_direct": "SPECIALIZE_ALL -DPTL_DIRECT_STORE",
+    "all_w3_direct": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=3 -DPTL_DIRECT_STORE",
+    "all_w4_direct": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -DPTL_DIRECT_STORE",
+    "base": "",
+    "base_direct": "-DPTL_DIRECT_STORE",
 }
-CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1"]
+CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
 
 
 def notes(code):
