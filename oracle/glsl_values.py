@@ -364,6 +364,9 @@ def map3(fn, a, b, c):
 def texture(s: Sampler, uv: Vec) -> Vec:
     """Contract: x = u*W - 0.5 (NaN -> 0), clamped to [-1, W]; floor/fract; 4 clamped fetches;
     channel = byte / 255; mix(mix(c00, c10, fx), mix(c01, c11, fx), fy)."""
+    if s is None:  # unbound sampler (contract: texels == nullptr)
+        n = np.broadcast(np.asarray(uv.c[0]), np.asarray(uv.c[1])).shape
+        return Vec([np.zeros(n, F32), np.zeros(n, F32), np.zeros(n, F32), np.ones(n, F32)])
     w, h = F32(s.w), F32(s.h)
     x = M.sub(M.mul(uv.c[0], w), F32(0.5))
     y = M.sub(M.mul(uv.c[1], h), F32(0.5))

@@ -132,6 +132,7 @@ def host_kernel_for(renderer, scene, width: int, height: int, flags: int = 0, co
     paths = scene.textures()
     for name, typ, _ in layout:
         if typ == pa.PTL_SAMPLER:
-            img = np.array(Image.open(os.path.join(root, paths[name[: -len("_tex")]])).convert("RGBA"))
-            hk.set_texture(name, img)
+            rel = paths.get(name[: -len("_tex")])  # videos and unreadable files stay unbound
+            if rel is not None and os.path.exists(os.path.join(root, rel)):
+                hk.set_texture(name, np.array(Image.open(os.path.join(root, rel)).convert("RGBA")))
     return hk

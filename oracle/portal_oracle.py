@@ -294,6 +294,80 @@ class Natives:
             current = current.f["hit"]
         return current.f["hit"] & M.gt(current.f["t"], fl(0)) & (~result.f["hit"] | (result.f["hit"] & M.lt(current.f["t"], result.f["t"])))
 
+    # -- library.glsl:426-470 (capsule, after iq)
+    @staticmethod
+    def cap_normal(pos, a, b, radius):
+        ba, pa_ = sub(b, a), sub(pos, a)
+        h = M.clamp(M.div(V.dot(pa_, ba), V.dot(ba, ba)), fl(0.0), fl(1.0))
+        return div(sub(pa_, mul(h, ba)), M.f32(radius))
+
+    def cap(self, r, pa_, pb, radius):
+        radius = M.f32(radius)
+        ro, rd = xyz(r.f["o"]), xyz(r.f["d"])
+        ba, oa = sub(pb, pa_), sub(ro, pa_)
+        baba, bard, baoa, rdoa, oaoa = V.dot(ba, ba), V.dot(ba, rd), V.dot(ba, oa), V.dot(rd, oa), V.dot(oa, oa)
+        a = M.sub(baba, M.mul(bard, bard))
+        b = M.sub(M.mul(baba, rdoa), M.mul(baoa, bard))
+        c = M.sub(M.sub(M.mul(baba, oaoa), M.mul(baoa, baoa)), M.mul(M.mul(radius, radius), baba))
+        h = M.sub(M.mul(b, b), M.mul(a, c))
+        t = M.div(M.sub(M.neg(b), M.sqrt(h)), a)
+        y = M.add(baoa, M.mul(t, bard))
+        body = M.ge(h, fl(0.0)) & M.gt(y, fl(0.0)) & M.lt(y, baba)
+        body_hit = Surf(True, t, 0.0, 0.0, self.cap_normal(add(ro, mul(rd, t)), pa_, pb, radius))
+        oc = V.select(M.le(y, fl(0.0)), oa, sub(ro, pb))
+        b2 = V.dot(rd, oc)
+        c2 = M.sub(V.dot(oc, oc), M.mul(radius, radius))
+        h2 = M.sub(M.mul(b2, b2), c2)
+        t2 = M.sub(M.neg(b2), M.sqrt(h2))
+        caps = M.ge(h, fl(0.0)) & ~body & M.gt(h2, fl(0.0))
+        caps_hit = Surf(True, t2, 0.0, 0.0, self.cap_normal(add(ro, mul(rd, t2)), pa_, pb, radius))
+        return V.select(body, body_hit, V.select(caps, caps_hit, INTERSECTION_NONE))
+
+    # -- library.glsl:473-504 (cylinder, after iq)
+    def cylinder(self, r, pa_, pb, ra):
+        ra = M.f32(ra)
+        ro, rd = xyz(r.f["o"]), xyz(r.f["d"])
+        ba, oc = sub(pb, pa_), sub(ro, pa_)
+        baba, bard, baoc = V.dot(ba, ba), V.dot(ba, rd), V.dot(ba, oc)
+        k2 = M.sub(baba, M.mul(bard, bard))
+        k1 = M.sub(M.mul(baba, V.dot(oc, rd)), M.mul(baoc, bard))
+        k0 = M.sub(M.sub(M.mul(baba, V.dot(oc, oc)), M.mul(baoc, baoc)), M.mul(M.mul(ra, ra), baba))
+        h = M.sub(M.mul(k1, k1), M.mul(k2, k0))
+        miss = M.lt(h, fl(0.0))
+        hs = M.sqrt(h)
+
+        def side(t):
+            y = M.add(baoc, M.mul(t, bard))
+            n = div(sub(add(oc, mul(t, rd)), div(mul(ba, y), baba)), ra)
+            return M.gt(y, fl(0.0)) & M.lt(y, baba), Surf(True, t, 0.0, 0.0, n)
+
+        ok_n, hit_n = side(M.div(M.sub(M.neg(k1), hs), k2))
+        ok_f, hit_f = side(M.div(M.add(M.neg(k1), hs), k2))
+        return V.select(miss, INTERSECTION_NONE, V.select(ok_n, hit_n, V.select(ok_f, hit_f, INTERSECTION_NONE)))
+
+    # -- library.glsl:507-525
+    def triangle(self, r, v0, v1, v2):
+        ro, rd = xyz(r.f["o"]), xyz(r.f["d"])
+        v1v0, v2v0, rov0 = sub(v1, v0), sub(v2, v0), sub(ro, v0)
+        n = V.cross(v1v0, v2v0)
+        q = V.cross(rov0, rd)
+        d = M.div(fl(1.0), V.dot(rd, n))
+        u = M.mul(d, V.dot(V.neg(q), v2v0))
+        v = M.mul(d, V.dot(q, v1v0))
+        t = M.mul(d, V.dot(V.neg(n), rov0))
+        miss = M.lt(u, fl(0.0)) | M.lt(v, fl(0.0)) | M.gt(M.add(u, v), fl(1.0))
+        hit = Surf(True, t, u, v, self.normalize_normal(V.cross(sub(v1, v0), sub(v2, v0)), rd))
+        return V.select(miss, INTERSECTION_NONE, hit)
+
+    # -- library.glsl:528-554
+    def debug_intersect(self, r):
+        i = SceneI(0, INTERSECTION_NONE, False)
+        for axis, mat in ((vec(1.0, 0.0, 0.0), DEBUG_RED), (vec(0.0, 1.0, 0.0), DEBUG_GREEN), (vec(0.0, 0.0, 1.0), DEBUG_BLUE)):
+            hit = self.cap(r, vec(0.0, 0.0, 0.0), axis, M.lit("0.03"))
+            near = self.nearer(i, hit)
+            i = V.select(near, i.with_field("material", I32(mat)).with_field("hit", hit), i)
+        return i
+
     # -- library.glsl:560-589
     @staticmethod
     def process_plane_intersection(i, hit, inside):
@@ -350,7 +424,11 @@ class Oracle:
         prog.structs.update(STRUCTS)
         prog.globals.update(uniforms)
         for name, path in self.scene.textures:
-            prog.globals[name + "_tex"] = Sampler(np.array(Image.open(os.path.join(self.asset_root, path)).convert("RGBA")))
+            full = os.path.join(self.asset_root, path)
+            # a texture file that cannot be read leaves the sampler unbound (reference: texture_errors, src/main.rs:1082-1084)
+            prog.globals[name + "_tex"] = Sampler(np.array(Image.open(full).convert("RGBA"))) if os.path.exists(full) else None
+        for name in self.scene.videos:
+            prog.globals.setdefault(name + "_tex", None)  # unbound sampler: texture() returns (0, 0, 0, 1)
         for name, mid in self.scene.material_ids().items():
             prog.globals[name] = I32(mid)
         consts = dict(CUSTOM_MATERIAL=CUSTOM_MATERIAL, NOT_INSIDE=NOT_INSIDE, TELEPORT=TELEPORT, TELEPORT_SUBSPACE=TELEPORT_SUBSPACE, DEBUG_RED=DEBUG_RED,
@@ -368,7 +446,8 @@ class Oracle:
                      "normalize_ray", "adjugate", "plane_intersect_normalized", "plane_intersect", "color", "color_normal", "color_grid", "circle_sdf",
                      "color_grid2", "color_grid3", "color_add_weighted", "material_empty", "material_final", "material_next", "material_simple2",
                      "material_simple", "material_reflect", "material_refract", "material_teleport_transformed", "material_teleport",
-                     "material_change_subspace", "nearer", "process_plane_intersection", "process_portal_intersection"):
+                     "material_change_subspace", "nearer", "process_plane_intersection", "process_portal_intersection", "cap_normal", "cap", "cylinder",
+                     "triangle", "debug_intersect"):
             prog.natives[name] = _wrap(getattr(nat, name))
         flags = dict(FOR_NUMBER=False, FOR_VARIABLE=True, ANTIALIASING=True, ANAGLYPH=False, CAMERA_TELEPORTATION=True, GLSL100=False, GLSL300=True)
 
@@ -406,7 +485,9 @@ class Oracle:
         i = V.expand(SceneI(0, INTERSECTION_NONE, False), n)
         for pos, o in enumerate(self.scene.objects):
             guard = mask
-            if o["sub"] == "Normal":
+            if o["kind"] == "debug":
+                pass
+            elif o["sub"] == "Normal":
                 guard = mask & ~r.f["in_subspace"]
             elif o["sub"] == "Subspace":
                 guard = mask & r.f["in_subspace"]
@@ -441,8 +522,14 @@ class Oracle:
                     tr = nat.transform(self._mat(midx, "_mat_inv"), r)
                     ln = V.length(tr.f["d"])
                     tr = nat.normalize_ray(tr)
-                    if o["kind"] == "debug":
-                        raise NotImplementedError("DebugMatrix objects are not restated in the oracle yet")
+                    if o["kind"] == "debug":   # scene.rs:893-904; NOTE the normal uses adjugate of the *inverse* (reference quirk)
+                        ihit = V.expand(nat.debug_intersect(tr), n)
+                        ihit = ihit.with_field("hit", ihit.f["hit"].with_field("t", M.div(ihit.f["hit"].f["t"], ln)))
+                        near = guard & nat.nearer(i, ihit)
+                        if near.any():
+                            nrm = V.normalize(mul(nat.adjugate(self._mat(midx, "_mat_inv")), ihit.f["hit"].f["n"]))
+                            i = V.select(near, ihit.with_field("hit", ihit.f["hit"].with_field("n", nrm)), i)
+                        continue
                     args = [V.expand(tr, n)] + ([np.full(n, first)] if first is not None else [])
                     ihit = V.expand(it.run_function(f"intersect_{pos}", args, guard), n)
                     M.set_active(guard.sum())
@@ -523,6 +610,16 @@ class Oracle:
         nat, u = self.nat, self.uniforms
         N = len(np.asarray(r.f["tmul"]))
         depth = int(u["_ray_tracing_depth"])
+        if self.scene.skybox is not None:   # scene.rs:1052-1059, evaluated once per ray_tracing call on the primary direction
+            rd2 = mul(u["_camera_mul_inv"], r.f["d"])
+            su = M.atan2(rd2.c[2], rd2.c[0])
+            sv = M.atan2(M.sqrt(M.add(M.mul(rd2.c[0], rd2.c[0]), M.mul(rd2.c[2], rd2.c[2]))), rd2.c[1])
+            pi = self._program.globals["PI"]
+            tex = V.texture(self._program.globals[self.scene.skybox + "_tex"], vec(M.div(M.add(M.div(su, pi), fl(1.0)), fl(2.0)), M.div(sv, pi))) \
+                if self._program.globals.get(self.scene.skybox + "_tex") is not None else vec(0.0, 0.0, 0.0, 1.0)
+            not_found_all = nat.sqrvec(xyz(tex))
+        else:
+            not_found_all = None
         not_found = nat.color(M.lit("0.6"), M.lit("0.6"), M.lit("0.6"))
         result = np.zeros((N, 3), F32)  # depth exhausted -> color(0,0,0)
         segments = np.zeros(N, np.int64)
@@ -560,7 +657,8 @@ class Oracle:
             any_hit = i.f["hit"].f["hit"] | i2.f["scene"].f["hit"].f["hit"]
             # escaped the scene
             esc = ~any_hit
-            esc_col = V.select(r_adv.f["in_subspace"], vec(0.0, 0.0, 0.0), mul(color, not_found))
+            nf = not_found if not_found_all is None else V.take(V.expand(not_found_all, N), idx)
+            esc_col = V.select(r_adv.f["in_subspace"], vec(0.0, 0.0, 0.0), mul(color, nf))
             color_next = mul(color, m.f["mul_to_color"])
             final = any_hit & m.f["is_final"]
             # distance darkening (frag.glsl:135-146)

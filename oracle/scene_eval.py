@@ -115,6 +115,8 @@ class OracleScene:
         self.uniforms = []   # [name|None, kind, payload]
         self.matrices = []   # [name, named, node]
         self.textures = [(t["name"], _code(t["data"])) for t in _newtype(doc["textures"])]
+        vids = doc.get("videos")
+        self.videos = [v["name"] for v in (_newtype(vids) if vids is not None else [])]
         for u in _newtype(doc["uniforms"]):
             self.uniforms.append([u["name"], *self._uniform(u["data"])])
         mats = _newtype(doc["matrices"])

@@ -77,7 +77,8 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
 }
 
 // The camera-teleport query of src/main.rs:1361-1409: one thread instead of the reference's 2x3-pixel
-// draw with float-in-RGBA8 packing.
+// draw with float-in-RGBA8 packing.  (A hand-written kernel without a scene can opt out.)
+#ifndef PTL_NO_TELEPORT_ENTRY
 extern "C" __global__ void __launch_bounds__(64) ptl_teleport_kernel(float* __restrict__ out6) {
 #ifdef PTL_UNIFORMS_IN_LDS
     {
@@ -92,6 +93,7 @@ extern "C" __global__ void __launch_bounds__(64) ptl_teleport_kernel(float* __re
 #endif
     if (threadIdx.x == 0 && blockIdx.x == 0) glsl::teleport_external_ray_entry(out6);
 }
+#endif
 
 #else  // host build of the same source (oracle/host_build): rows [row_begin, row_end) of the frame
 
@@ -103,7 +105,11 @@ extern "C" void* ptl_host_uniform_block(unsigned long* size) {
     return &glsl::ptl_u;
 }
 
+#ifndef PTL_NO_TELEPORT_ENTRY
 extern "C" void ptl_host_teleport(float* out6) { glsl::teleport_external_ray_entry(out6); }
+#else
+extern "C" void ptl_host_teleport(float*) {}
+#endif
 
 // Renders the listed pixel rows x columns [col_begin, col_end) of a width x height frame into
 // out_* (output row i = rows[i]) with `threads` OpenMP threads.  Returns the number of

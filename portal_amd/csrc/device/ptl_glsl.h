@@ -586,21 +586,24 @@ PTL_FN mat4& operator*=(mat4& a, const mat4& b) { a = a * b; return a; }
 PTL_FN vec2& operator*=(vec2& v, const mat2& m) { v = v * m; return v; }
 PTL_FN vec3& operator*=(vec3& v, const mat3& m) { v = v * m; return v; }
 PTL_FN vec4& operator*=(vec4& v, const mat4& m) { v = v * m; return v; }
-PTL_FN mat2 transpose(const mat2& m) { return mat2(m.c[0].x, m.c[1].x, m.c[0].y, m.c[1].y); }
-PTL_FN mat3 transpose(const mat3& m) {
+// transpose / determinant / inverse are templates with a dummy parameter: some scenes ship their own
+// `mat3 inverse(mat3)` (GLSL lets user code shadow these), and a non-template function wins overload
+// resolution against a template, so the scene's definition is the one that gets called.
+template <class PtlBuiltin = void> PTL_FN mat2 transpose(const mat2& m) { return mat2(m.c[0].x, m.c[1].x, m.c[0].y, m.c[1].y); }
+template <class PtlBuiltin = void> PTL_FN mat3 transpose(const mat3& m) {
     return mat3(m.c[0].x, m.c[1].x, m.c[2].x, m.c[0].y, m.c[1].y, m.c[2].y, m.c[0].z, m.c[1].z, m.c[2].z);
 }
-PTL_FN mat4 transpose(const mat4& m) {
+template <class PtlBuiltin = void> PTL_FN mat4 transpose(const mat4& m) {
     return mat4(m.c[0].x, m.c[1].x, m.c[2].x, m.c[3].x, m.c[0].y, m.c[1].y, m.c[2].y, m.c[3].y,
                 m.c[0].z, m.c[1].z, m.c[2].z, m.c[3].z, m.c[0].w, m.c[1].w, m.c[2].w, m.c[3].w);
 }
-PTL_FN float determinant(const mat2& m) { return m.c[0].x * m.c[1].y - m.c[1].x * m.c[0].y; }
-PTL_FN float determinant(const mat3& m) { return dot(m.c[0], cross(m.c[1], m.c[2])); }
-PTL_FN mat2 inverse(const mat2& m) {
+template <class PtlBuiltin = void> PTL_FN float determinant(const mat2& m) { return m.c[0].x * m.c[1].y - m.c[1].x * m.c[0].y; }
+template <class PtlBuiltin = void> PTL_FN float determinant(const mat3& m) { return dot(m.c[0], cross(m.c[1], m.c[2])); }
+template <class PtlBuiltin = void> PTL_FN mat2 inverse(const mat2& m) {
     float i = 1.0f / determinant(m);
     return mat2(m.c[1].y * i, -m.c[0].y * i, -m.c[1].x * i, m.c[0].x * i);
 }
-PTL_FN mat3 inverse(const mat3& m) {
+template <class PtlBuiltin = void> PTL_FN mat3 inverse(const mat3& m) {
     vec3 r0 = cross(m.c[1], m.c[2]), r1 = cross(m.c[2], m.c[0]), r2 = cross(m.c[0], m.c[1]);
     float i = 1.0f / dot(m.c[0], r0);
     return mat3(r0.x * i, r1.x * i, r2.x * i, r0.y * i, r1.y * i, r2.y * i, r0.z * i, r1.z * i, r2.z * i);

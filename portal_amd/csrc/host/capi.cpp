@@ -351,8 +351,9 @@ static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
             uint8_t* px = nullptr;
             int w = 0, h = 0;
             if (ptl_png_read(path.c_str(), &px, &w, &h) != PTL_OK) {
-                ptl_kernel_destroy(k);
-                return PTL_ERR_SCENE;
+                // like the reference (data.texture_errors, src/main.rs:1082-1084): keep going, the sampler stays
+                // unbound and reads as (0, 0, 0, 1); the message remains available through ptl_last_error()
+                continue;
             }
             int trc = ptl_kernel_set_texture(k, (t.name + "_tex").c_str(), px, w, h);
             std::free(px);

@@ -136,6 +136,7 @@ const char* bool_lit(bool b) { return b ? "true" : "false"; }
 std::vector<std::string> scene_texture_list(const Scene& scene) {
     std::set<std::string> names;
     for (auto& t : scene.textures) names.insert(t.name);
+    for (auto& v : scene.videos) names.insert(v);
     std::vector<std::string> out;
     for (auto& n : names) out.push_back(n + "_tex");
     return out;

@@ -229,7 +229,8 @@ std::string translate_glsl(const std::string& glsl) {
                     break;
                 }
                 // parameter qualifiers: only meaningful right after `(` or `,` inside parentheses
-                bool param_pos = paren_depth > 0 && p && p->kind == Token::Punct && (p->text == "(" || p->text == ",");
+                bool param_pos = paren_depth > 0 && p && ((p->kind == Token::Punct && (p->text == "(" || p->text == ",")) ||
+                                                          (p->kind == Token::Ident && p->text == "const"));  // `const in vec3 v`
                 bool next_is_type = nx && nx->kind == Token::Ident;
                 if (param_pos && next_is_type && (t.text == "in" || t.text == "out" || t.text == "inout")) {
                     if (t.text != "in") pending_ref = true;

@@ -218,6 +218,7 @@ struct Loader {
         // order follows deserialize_scene_new_format (scene_serialized.rs:1102-1230)
         for (const Value& t : storage_list(doc, "textures", true).items)
             scene.textures.push_back(Texture{as_string(t.at("name"), "texture name"), as_string(t.at("data"), "texture path")});
+        for (const Value& v : storage_list(doc, "videos", false).items) scene.videos.push_back(as_string(v.at("name"), "video name"));
         for (const Value& u : storage_list(doc, "uniforms", true).items)
             scene.uniforms.push_back(UniformEntry{as_string(u.at("name"), "uniform name"), parse_uniform(u.at("data"))});
 

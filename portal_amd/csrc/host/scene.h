@@ -114,6 +114,7 @@ public:
     std::vector<NamedCode> intersection_materials;
     std::vector<NamedCode> library;
     std::vector<Texture> textures;
+    std::vector<std::string> videos;  // names only: a video is one more sampler (src/gui/scene.rs:405-409); frames are out of scope
     std::optional<std::string> skybox;
     bool use_time = false;
 

@@ -56,6 +56,7 @@ def source(pa):
         pa.device_source("glsl")
         + """
 #define PTL_COUNT_SEGMENT() ((void)0)
+#define PTL_NO_TELEPORT_ENTRY 1
 namespace glsl {
 struct ptl_uniform_block { sampler2D in_tex; int n_u; int pad_u; };
 #if PTL_DEVICE_BUILD
