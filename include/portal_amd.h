@@ -77,6 +77,11 @@ int ptl_kernel_compile(int device, const char* hip_source, const ptl_uniform_des
 /* The compiled gfx950 code object (valid until ptl_kernel_destroy). */
 int ptl_kernel_code_object(ptl_kernel* k, const void** data, size_t* size);
 
+/* Per-lane resources of the loaded render kernel (hipFuncGetAttribute): vector registers, scratch
+ * (private segment) bytes -- non-zero means register spills that travel through the memory hierarchy --
+ * and static LDS bytes per workgroup.  -1 where the runtime cannot tell. */
+int ptl_kernel_resources(ptl_kernel* k, int* registers, int* scratch_bytes, int* lds_bytes);
+
 /* value points at 16 floats (column-major) / 1 float / 1 int32 / 2 floats / 3 floats. */
 int ptl_kernel_set_uniform(ptl_kernel* k, const char* name, ptl_type type, const void* value);
 

@@ -59,6 +59,7 @@ def _load() -> C.CDLL:
         "ptl_device_count": (ci, []),
         "ptl_kernel_compile": (ci, [ci, cp, P(UniformDesc), ci, cs, P(cp), ci, P(vp), cp, cs]),
         "ptl_kernel_code_object": (ci, [vp, P(vp), P(cs)]),
+        "ptl_kernel_resources": (ci, [vp, P(ci), P(ci), P(ci)]),
         "ptl_kernel_set_uniform": (ci, [vp, cp, ci, vp]),
         "ptl_kernel_set_texture": (ci, [vp, cp, vp, ci, ci]),
         "ptl_frame_shard_rows": (ci, [P(Frame)]),
@@ -305,6 +306,12 @@ class SceneRenderer:
         hit, sub, tel = C.c_int(), C.c_int(), C.c_int()
         _check(lib().ptl_renderer_teleport_ray(self._h, pa_, pb_, out, C.byref(hit), C.byref(sub), C.byref(tel)), "teleport_external_ray")
         return (tuple(out) if tel.value else None), bool(hit.value), bool(sub.value)
+
+    def resources(self) -> dict:
+        """Per-lane registers / scratch bytes / LDS bytes of the loaded kernel."""
+        regs, scratch, lds = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().ptl_kernel_resources(lib().ptl_renderer_kernel(self._h), C.byref(regs), C.byref(scratch), C.byref(lds)), "kernel_resources")
+        return {"registers": regs.value, "scratch_bytes": scratch.value, "lds_bytes": lds.value}
 
     def code_object(self) -> bytes:
         k = lib().ptl_renderer_kernel(self._h)

@@ -42,10 +42,12 @@ struct Runtime {
     hipError_t (*hipModuleUnload)(hipModule_t);
     hipError_t (*hipModuleGetFunction)(hipFunction_t*, hipModule_t, const char*);
     hipError_t (*hipModuleGetGlobal)(hipDeviceptr_t*, size_t*, hipModule_t, const char*);
+    hipError_t (*hipFuncGetAttribute)(int*, int, hipFunction_t);
     hipError_t (*hipModuleLaunchKernel)(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned,
                                         hipStream_t, void**, void**);
     const char* (*hipGetErrorString)(hipError_t);
 };
+constexpr int kFuncAttrSharedSizeBytes = 1, kFuncAttrLocalSizeBytes = 3, kFuncAttrNumRegs = 4;  // hipFunction_attribute
 constexpr int kMemcpyHostToDevice = 1;
 constexpr int kMemcpyDeviceToHost = 2;
 

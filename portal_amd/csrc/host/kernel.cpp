@@ -232,6 +232,17 @@ extern "C" int ptl_kernel_code_object(ptl_kernel* k, const void** data, size_t* 
     return PTL_OK;
 }
 
+extern "C" int ptl_kernel_resources(ptl_kernel* k, int* registers, int* scratch_bytes, int* lds_bytes) {
+    if (!k) return PTL_ERR_INVALID;
+    if (k->device < 0 || !k->fn) return PTL_ERR_NO_DEVICE;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    int v = 0;
+    if (registers) *registers = rt->hipFuncGetAttribute(&v, hip::kFuncAttrNumRegs, k->fn) == 0 ? v : -1;
+    if (scratch_bytes) *scratch_bytes = rt->hipFuncGetAttribute(&v, hip::kFuncAttrLocalSizeBytes, k->fn) == 0 ? v : -1;
+    if (lds_bytes) *lds_bytes = rt->hipFuncGetAttribute(&v, hip::kFuncAttrSharedSizeBytes, k->fn) == 0 ? v : -1;
+    return PTL_OK;
+}
+
 extern "C" int ptl_kernel_set_uniform(ptl_kernel* k, const char* name, ptl_type type, const void* value) {
     if (!k || !name || !value) return PTL_ERR_INVALID;
     auto it = k->slots.find(name);
