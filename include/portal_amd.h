@@ -133,6 +133,15 @@ int ptl_scene_set_uniform(ptl_scene* s, const char* name, double value);
 /* Formula time inputs (FormulasCache::set_time / set_total_time). */
 int ptl_scene_set_time(ptl_scene* s, double time, double total_time);
 
+/* Scene::init_stage_by_name (src/gui/scene.rs:1237-1250, `render-frame --stage`): apply the named
+ * animation stage's uniform / matrix overrides.  camera receives the name of the camera the stage
+ * selects ("" = the scene's original camera; an inline stage camera is reported as "#<index>").
+ * Returns 1 if the scene has no such stage. */
+int ptl_scene_init_stage(ptl_scene* s, const char* stage, char* camera, size_t camera_cap);
+/* Number of stages / cameras and their names (index past the end: returns 1). */
+int ptl_scene_stage_name(ptl_scene* s, int index, char* name, size_t cap);
+int ptl_scene_camera_name(ptl_scene* s, int index, char* name, size_t cap);
+
 /* AnyUniform::get: kind 0 = bool, 1 = int, 2 = float.  Returns 1 if the uniform cannot be evaluated. */
 int ptl_scene_eval_uniform(ptl_scene* s, const char* name, int* kind, double* value);
 /* Matrix::get as binary64, column-major.  Returns 1 if it cannot be evaluated. */
@@ -177,6 +186,10 @@ int ptl_renderer_create(ptl_scene* s, int device, const char* asset_root, unsign
 int ptl_renderer_set_option(ptl_renderer* r, const char* name, double value);
 /* Camera (RotateAroundCam): look_at xyz, alpha, beta, r. */
 int ptl_renderer_set_camera(ptl_renderer* r, const double look_at[3], double alpha, double beta, double radius);
+/* `render-frame --camera NAME` (src/main.rs:2918-2926, 1442-1478): take look_at / alpha / beta / r /
+ * in_subspace / free_movement / teleport matrix from a named scene camera ("#<index>" for an inline stage
+ * camera); "" restores the scene's `cam` block.  Returns 1 if there is no such camera. */
+int ptl_renderer_use_camera(ptl_renderer* r, const char* camera);
 /* The value draw_texture would upload for a builtin or scene uniform (floats; ints as 1 float). */
 int ptl_renderer_uniform_value(ptl_renderer* r, int width, int height, const char* name, float out16[16], int* n_values);
 /* SceneRenderer::draw_texture (src/main.rs:1411-1428): scene.set_uniforms + set_uniforms(w,h) +

@@ -156,6 +156,41 @@ class OracleScene:
         im = doc.get("intersection_materials")
         self.intersection_materials = [(m["name"], _code(m["data"])) for m in (_newtype(im) if im is not None else [])]
         self.library = [(m["name"], _code(m["data"])) for m in _newtype(doc["library"])]
+        self.cameras = []   # dict(name, look_at=('matrix', idx)|('coord', xyz), alpha, beta, r, in_subspace, free_movement, matrix)
+        cams = doc.get("cameras")
+        for c in (_newtype(cams) if cams is not None else []):
+            self.cameras.append(dict(self._camera(c["data"]), name=c["name"]))
+        self.dev_uniforms, self.dev_matrices, self.stages = {}, {}, []
+        dev = doc.get("dev_stage")
+        if dev is not None:
+            for k, v in (dev.get("uniforms") or {}).items():
+                self.dev_uniforms[k] = self._uniform(v)
+            for k, v in (dev.get("matrices") or {}).items():
+                self.dev_matrices[k] = self._matrix(v)
+        st = doc.get("animation_stages")
+        for item in (_newtype(st) if st is not None else []):
+            d = item["data"]
+
+            def change(v, is_matrix):
+                if v.name in ("Changed", "ChangedAndToUser"):
+                    return ("changed", self._mref(v.items[0]) if is_matrix else self._uref(v.items[0]))
+                return ("dev", -1)
+
+            stage = dict(name=item["name"], uniforms=[(k, change(v, False)) for k, v in (d.get("uniforms") or {}).items()],
+                         matrices=[(k, change(v, True)) for k, v in (d.get("matrices") or {}).items()], set_cam=None)
+            sc = d.get("set_cam")
+            outer = ron.unwrap_some(sc) if sc is not None else None
+            if outer is not None:
+                inner = ron.unwrap_some(outer)
+                if inner is None:
+                    stage["set_cam"] = -1
+                elif inner.name == "Named":
+                    stage["set_cam"] = next((k for k, c in enumerate(self.cameras) if c["name"] == inner.items[0]), -1)
+                else:
+                    self.cameras.append(dict(self._camera(inner.items[0]), name=None))
+                    stage["set_cam"] = len(self.cameras) - 1
+            self.stages.append(stage)
+        self.uniform_alias, self.matrix_alias = {}, {}
         sky = doc.get("skybox")
         self.skybox = ron.unwrap_some(sky) if sky is not None else None
         self._busy_u, self._busy_m = set(), set()
@@ -177,6 +212,53 @@ class OracleScene:
         if tag == "TrefoilSpecial":
             return "trefoil", None
         raise ValueError(f"unknown uniform kind {tag}")
+
+    def _camera(self, d):
+        la = d["look_at"]
+        look = ("matrix", self._mref(la.items[0])) if la.name == "MatrixCenter" else ("coord", [float(x) for x in la.items[0].items])
+        m = d.get("matrix")
+        mat = [[float(x) for x in m.items[4 * c:4 * c + 4]] for c in range(4)] if m is not None else IDENT
+        return dict(look_at=look, alpha=float(d["alpha"]), beta=float(d["beta"]), r=float(d["r"]), in_subspace=bool(d.get("in_subspace", False)),
+                    free_movement=bool(d.get("free_movement", False)), matrix=mat)
+
+    def init_stage(self, name):
+        """Scene::init_stage_by_name (scene.rs:1237-1250, animation.rs:171-183).  Returns the camera index the stage selects, or -1."""
+        stage = next(s for s in self.stages if s["name"] == name)
+        self.uniform_alias, self.matrix_alias = {}, {}
+        for key, (kind, ref) in stage["uniforms"]:
+            idx = self.find_uniform(key)
+            if idx < 0:
+                continue
+            if kind == "changed" and ref >= 0:
+                if ref != idx:
+                    self.uniform_alias[idx] = ref
+            elif kind == "dev" and key in self.dev_uniforms:
+                self.uniforms[idx][1:] = list(self.dev_uniforms[key])
+        for key, (kind, ref) in stage["matrices"]:
+            idx = self._mat_by_name.get(key, -1)
+            if idx < 0:
+                continue
+            if kind == "changed" and ref >= 0:
+                if ref != idx:
+                    self.matrix_alias[idx] = ref
+            elif kind == "dev" and key in self.dev_matrices:
+                self.matrices[idx][2] = self.dev_matrices[key]
+        return -1 if stage["set_cam"] is None else stage["set_cam"]
+
+    def camera_settings(self, idx):
+        """SceneRenderer::update's camera switch (src/main.rs:1442-1478) for scene camera `idx`."""
+        c = self.cameras[idx]
+        if c["look_at"][0] == "matrix":
+            m = self.eval_matrix(c["look_at"][1])
+            inv_w = 1.0 / m[3][3]
+            look = [m[3][k] * inv_w + 0.001 for k in range(3)]
+        else:
+            look = list(c["look_at"][1])
+        out = dict(look_at=look, alpha=c["alpha"], beta=c["beta"], r=c["r"], teleport_matrix=c["matrix"], in_subspace=c["in_subspace"], free_movement=c["free_movement"])
+        if c["free_movement"]:
+            pv = _pos_vec(c["alpha"], c["beta"], c["r"])
+            out["look_at"] = [pv[k] + look[k] for k in range(3)]
+        return out
 
     def _uref(self, opt):
         r = ron.unwrap_some(opt)
@@ -237,6 +319,9 @@ class OracleScene:
 
     def eval_uniform(self, idx):
         """-> ('bool'|'int'|'float', value) or None"""
+        hops = 0
+        while idx in self.uniform_alias and hops < 64:
+            idx, hops = self.uniform_alias[idx], hops + 1
         if idx < 0 or idx >= len(self.uniforms) or idx in self._busy_u:
             return None
         _, kind, payload = self.uniforms[idx]
@@ -286,6 +371,9 @@ class OracleScene:
         return None if r is None else float(r[1])
 
     def eval_matrix(self, idx):
+        hops = 0
+        while idx in self.matrix_alias and hops < 64:
+            idx, hops = self.matrix_alias[idx], hops + 1
         if idx < 0 or idx >= len(self.matrices) or idx in self._busy_m:
             return None
         node = self.matrices[idx][2]
@@ -400,14 +488,19 @@ def _cross(a, b):
     return [a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1]]
 
 
-def camera_matrix(look_at, alpha, beta, r):
-    """RotateAroundCam::get_matrix with teleport_matrix = I, free_movement = false."""
-    pv = [math.sin(beta) * math.cos(alpha) * r, math.cos(beta) * r, math.sin(beta) * math.sin(alpha) * r]
+def _pos_vec(alpha, beta, r):
+    return [math.sin(beta) * math.cos(alpha) * r, math.cos(beta) * r, math.sin(beta) * math.sin(alpha) * r]
+
+
+def camera_matrix(look_at, alpha, beta, r, teleport_matrix=None, free_movement=False):
+    """RotateAroundCam::get_matrix (src/main.rs:286-304)."""
+    pv = _pos_vec(alpha, beta, r)
     pos = [pv[k] + look_at[k] for k in range(3)]
     k = _norm3([look_at[n] - pos[n] for n in range(3)])
     i = _norm3(_cross(k, [0.0, 1.0, 0.0]))
     j = _norm3(_cross(k, i))
-    return m_mul(IDENT, [i + [0.0], j + [0.0], k + [0.0], pos + [1.0]])
+    p = list(look_at) if free_movement else pos
+    return m_mul(teleport_matrix if teleport_matrix is not None else IDENT, [i + [0.0], j + [0.0], k + [0.0], p + [1.0]])
 
 
 def builtin_uniforms(scene: OracleScene, width, height, render_depth=100, aa_count=1, aa_start=0, view_angle=None, use_panini=False, panini_param=1.0,
@@ -415,14 +508,15 @@ def builtin_uniforms(scene: OracleScene, width, height, render_depth=100, aa_cou
     cam = dict(scene.cam)
     if camera:
         cam.update(camera)
-    m = camera_matrix(cam["look_at"], cam["alpha"], cam["beta"], cam["r"])
+    tele = cam.get("teleport_matrix") or IDENT
+    m = camera_matrix(cam["look_at"], cam["alpha"], cam["beta"], cam["r"], tele, cam.get("free_movement", False))
     scale = sum(math.sqrt(sum(x * x for x in m[c])) for c in range(3)) / 3.0
     f, i = np.float32, np.int32
     ident = to_f32_colmajor(IDENT)
     return {
         "_resolution": np.array([width, height], np.float32),
-        "_camera": to_f32_colmajor(m), "_camera_left_eye": ident, "_camera_right_eye": ident, "_camera_mul_inv": to_f32_colmajor(m_inverse(IDENT)),
-        "_camera_in_subspace": i(0), "_left_eye_in_subspace": i(0), "_right_eye_in_subspace": i(0),
+        "_camera": to_f32_colmajor(m), "_camera_left_eye": ident, "_camera_right_eye": ident, "_camera_mul_inv": to_f32_colmajor(m_inverse(tele)),
+        "_camera_in_subspace": i(1 if cam.get("in_subspace") else 0), "_left_eye_in_subspace": i(0), "_right_eye_in_subspace": i(0),
         "_view_angle": f(90.0 / 180.0 * math.pi if view_angle is None else view_angle),
         "_panini_param": f(panini_param), "_use_panini_projection": i(1 if use_panini else 0), "_use_360_camera": i(0), "_use_180_camera": i(0),
         "_ray_tracing_depth": i(render_depth), "_aa_count": i(aa_count), "_aa_start": i(aa_start),

@@ -72,6 +72,9 @@ def _load() -> C.CDLL:
         "ptl_scene_free": (None, [vp]),
         "ptl_scene_set_uniform": (ci, [vp, cp, cd]),
         "ptl_scene_set_time": (ci, [vp, cd, cd]),
+        "ptl_scene_init_stage": (ci, [vp, cp, cp, cs]),
+        "ptl_scene_stage_name": (ci, [vp, ci, cp, cs]),
+        "ptl_scene_camera_name": (ci, [vp, ci, cp, cs]),
         "ptl_scene_eval_uniform": (ci, [vp, cp, P(ci), P(cd)]),
         "ptl_scene_eval_matrix": (ci, [vp, cp, P(cd)]),
         "ptl_scene_cam": (ci, [vp, P(cd)]),
@@ -85,6 +88,7 @@ def _load() -> C.CDLL:
         "ptl_renderer_create": (ci, [vp, ci, cp, C.c_uint, P(vp), cp, cs]),
         "ptl_renderer_set_option": (ci, [vp, cp, cd]),
         "ptl_renderer_set_camera": (ci, [vp, P(cd), cd, cd, cd]),
+        "ptl_renderer_use_camera": (ci, [vp, cp]),
         "ptl_renderer_uniform_value": (ci, [vp, ci, ci, cp, P(C.c_float), P(ci)]),
         "ptl_renderer_draw": (ci, [vp, P(Frame), vp, vp, vp, vp, P(C.c_float)]),
         "ptl_renderer_draw_to_host": (ci, [vp, P(Frame), vp, vp, P(C.c_uint64), P(C.c_float)]),
@@ -182,6 +186,27 @@ class Scene:
 
     def set_time(self, time: float, total_time: Optional[float] = None) -> None:
         lib().ptl_scene_set_time(self._h, float(time), float(time if total_time is None else total_time))
+
+    def init_stage(self, name: str) -> str:
+        """Scene::init_stage_by_name (`render-frame --stage`).  Returns the camera the stage selects ("" = original)."""
+        cam = C.create_string_buffer(256)
+        rc = _check(lib().ptl_scene_init_stage(self._h, name.encode("utf-8"), cam, 256), "init_stage")
+        if rc != 0:
+            raise PortalError(f"Scene has no stage named `{name}`")
+        return cam.value.decode("utf-8")
+
+    def _names(self, fn):
+        out, i, buf = [], 0, C.create_string_buffer(256)
+        while fn(self._h, i, buf, 256) == 0:
+            out.append(buf.value.decode("utf-8"))
+            i += 1
+        return out
+
+    def stages(self):
+        return self._names(lib().ptl_scene_stage_name)
+
+    def cameras(self):
+        return self._names(lib().ptl_scene_camera_name)
 
     def eval_uniform(self, name: str):
         """AnyUniform::get -> bool | int | float, or None if it cannot be evaluated."""
@@ -290,6 +315,11 @@ class SceneRenderer:
     def set_camera(self, look_at, alpha: float, beta: float, r: float) -> None:
         la = (C.c_double * 3)(*look_at)
         _check(lib().ptl_renderer_set_camera(self._h, la, alpha, beta, r), "set_camera")
+
+    def use_camera(self, name: str) -> None:
+        """`render-frame --camera NAME`; "" restores the scene's own `cam` block."""
+        if _check(lib().ptl_renderer_use_camera(self._h, name.encode("utf-8")), "use_camera") != 0:
+            raise PortalError(f"Scene has no camera named `{name}`")
 
     def uniform_value(self, name: str, width: int, height: int):
         out, n = (C.c_float * 16)(), C.c_int()

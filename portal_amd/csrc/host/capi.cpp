@@ -224,6 +224,30 @@ extern "C" int ptl_scene_set_time(ptl_scene* s, double time, double total_time) 
     s->scene->total_time = total_time;
     return PTL_OK;
 }
+extern "C" int ptl_scene_init_stage(ptl_scene* s, const char* stage, char* camera, size_t camera_cap) {
+    if (!s || !stage) return PTL_ERR_INVALID;
+    return guarded([&] {
+        int cam = -1;
+        if (!s->scene->init_stage_by_name(stage, &cam)) return 1;
+        std::string name;
+        if (cam >= 0) name = s->scene->cameras[cam].name.empty() ? "#" + std::to_string(cam) : s->scene->cameras[cam].name;
+        copy_str(camera, camera_cap, name);
+        return PTL_OK;
+    });
+}
+extern "C" int ptl_scene_stage_name(ptl_scene* s, int index, char* name, size_t cap) {
+    if (!s || index < 0) return PTL_ERR_INVALID;
+    if (index >= (int)s->scene->stages.size()) return 1;
+    copy_str(name, cap, s->scene->stages[index].name);
+    return PTL_OK;
+}
+extern "C" int ptl_scene_camera_name(ptl_scene* s, int index, char* name, size_t cap) {
+    if (!s || index < 0) return PTL_ERR_INVALID;
+    if (index >= (int)s->scene->cameras.size()) return 1;
+    copy_str(name, cap, s->scene->cameras[index].name.empty() ? "#" + std::to_string(index) : s->scene->cameras[index].name);
+    return PTL_OK;
+}
+
 extern "C" int ptl_scene_eval_uniform(ptl_scene* s, const char* name, int* kind, double* value) {
     if (!s || !name) return PTL_ERR_INVALID;
     return guarded([&] {
@@ -434,6 +458,40 @@ extern "C" int ptl_renderer_set_camera(ptl_renderer* r, const double look_at[3],
     r->cam.r = radius;
     ++r->options_version;
     return PTL_OK;
+}
+
+extern "C" int ptl_renderer_use_camera(ptl_renderer* r, const char* camera) {
+    if (!r || !camera) return PTL_ERR_INVALID;
+    return guarded([&] {
+        std::string name = camera;
+        ++r->options_version;
+        if (name.empty()) {  // original camera: scene.cam, teleport matrix = I (RotateAroundCam::set_cam)
+            const CamSettings& c = r->scene->cam;
+            r->cam.look_at = c.look_at;
+            r->cam.alpha = c.alpha;
+            r->cam.beta = c.beta;
+            r->cam.r = c.r;
+            r->cam.teleport_matrix = DMat4::identity();
+            r->cam.in_subspace = false;
+            r->cam.free_movement = false;
+            return PTL_OK;
+        }
+        int idx = name[0] == '#' ? std::atoi(name.c_str() + 1) : r->scene->find_camera(name);
+        if (idx < 0 || idx >= (int)r->scene->cameras.size()) return 1;
+        const SceneCamera& c = r->scene->cameras[idx];
+        auto look = r->scene->camera_look_at(c);
+        if (!look) return 1;
+        // SceneRenderer::update (src/main.rs:1465-1477)
+        r->cam.alpha = c.alpha;
+        r->cam.beta = c.beta;
+        r->cam.r = c.r;
+        r->cam.look_at = *look;
+        r->cam.teleport_matrix = c.teleport;
+        r->cam.in_subspace = c.in_subspace;
+        r->cam.free_movement = c.free_movement;
+        if (r->cam.free_movement) r->cam.look_at = r->cam.pos_vec() + r->cam.look_at;
+        return PTL_OK;
+    });
 }
 
 extern "C" int ptl_renderer_uniform_value(ptl_renderer* r, int width, int height, const char* name, float out16[16], int* n_values) {

@@ -13,7 +13,7 @@
 static void usage() {
     std::fprintf(stderr,
                  "usage: portal-amd render-frame <scene.ron> [--width W] [--height H] [--aa-count N] [--render-depth D]\n"
-                 "                  [--time T] [--output out.png] [--device I] [--asset-root DIR] [--panini D --fov DEG]\n"
+                 "                  [--stage NAME] [--camera NAME] [--time T] [--output out.png] [--device I] [--asset-root DIR] [--panini D --fov DEG]\n"
                  "       portal-amd emit-source <scene.ron>       print the generated HIP kernel source\n"
                  "       portal-amd version\n");
 }
@@ -35,7 +35,8 @@ int main(int argc, char** argv) {
     std::string scene_path = argv[2];
     int width = 1920, height = 1080, aa = 1, depth = 100, device = 0;  // CLI defaults: src/main.rs:2744-2754
     double time = 0.0, panini = -1.0, fov = 90.0;
-    std::string output = "frame.png", asset_root = ".";
+    std::string output = "frame.png", asset_root = ".", stage, camera;
+    bool have_camera = false;
     for (int i = 3; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char* {
@@ -53,6 +54,8 @@ int main(int argc, char** argv) {
         else if (a == "--output") output = next();
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--asset-root") asset_root = next();
+        else if (a == "--stage") stage = next();
+        else if (a == "--camera") { camera = next(); have_camera = true; }
         else if (a == "--panini") panini = std::atof(next());
         else if (a == "--fov") fov = std::atof(next());
         else {
@@ -66,6 +69,11 @@ int main(int argc, char** argv) {
         return 1;
     }
     ptl_scene_set_time(scene, time, time);
+    char stage_cam[256] = "";
+    if (!stage.empty() && ptl_scene_init_stage(scene, stage.c_str(), stage_cam, sizeof stage_cam) != PTL_OK) {  // src/main.rs:2900-2904
+        std::fprintf(stderr, "Scene `%s` has no stage named `%s`\n", scene_path.c_str(), stage.c_str());
+        return 1;
+    }
     if (cmd == "emit-source") {
         char* src = nullptr;
         if (ptl_scene_generate_source(scene, 0, &src) != PTL_OK) {
@@ -87,6 +95,13 @@ int main(int argc, char** argv) {
     if (rc != PTL_OK) {
         std::fprintf(stderr, "renderer: %s\n%s\n", ptl_last_error(), log.data());
         return 1;
+    }
+    if (have_camera || stage_cam[0]) {  // --camera wins over the stage's camera (src/main.rs:2918-2926)
+        const char* which = have_camera ? camera.c_str() : stage_cam;
+        if (ptl_renderer_use_camera(r, which) != PTL_OK) {
+            std::fprintf(stderr, "Scene `%s` has no camera named `%s`\n", scene_path.c_str(), which);
+            return 1;
+        }
     }
     ptl_renderer_set_option(r, "aa_count", aa);
     ptl_renderer_set_option(r, "render_depth", depth);

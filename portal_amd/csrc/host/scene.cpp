@@ -288,10 +288,80 @@ struct Loader {
             }
             scene.materials.push_back(std::move(mat));
         }
+        for (const Value& c : storage_list(doc, "cameras", false).items) {
+            SceneCamera cam = parse_camera(c.at("data"));
+            cam.name = as_string(c.at("name"), "camera name");
+            scene.cameras.push_back(cam);
+        }
         for (const Value& m : storage_list(doc, "intersection_materials", false).items)
             scene.intersection_materials.push_back(NamedCode{as_string(m.at("name"), "name"), as_string(m.at("data"), "intersection material code")});
         for (const Value& m : storage_list(doc, "library", true).items)
             scene.library.push_back(NamedCode{as_string(m.at("name"), "name"), as_string(m.at("data"), "library code")});
+
+        // dev_stage + animation stages (scene_serialized.rs:1232-1330)
+        if (const Value* dev = doc.find("dev_stage")) {
+            if (const Value* u = dev->find("uniforms"))
+                for (auto& kv : u->entries) scene.dev_uniforms.emplace_back(as_string(kv.first, "dev_stage key"), parse_uniform(kv.second));
+            if (const Value* mm = dev->find("matrices"))
+                for (auto& kv : mm->entries) scene.dev_matrices.emplace_back(as_string(kv.first, "dev_stage key"), parse_matrix(kv.second));
+        }
+        for (const Value& st : storage_list(doc, "animation_stages", false).items) {
+            AnimationStage stage;
+            stage.name = as_string(st.at("name"), "stage name");
+            const Value& d = st.at("data");
+            auto change = [&](const Value& v, bool is_matrix) {
+                StageChange c;
+                if (v.is_named("ProvidedToUser")) c.kind = StageChange::ProvidedToUser;
+                else if (v.is_named("FromDev")) c.kind = StageChange::FromDev;
+                else if (v.is_named("Changed") || v.is_named("ChangedAndToUser")) {
+                    c.kind = v.is_named("Changed") ? StageChange::Changed : StageChange::ChangedAndToUser;
+                    c.ref = is_matrix ? matrix_ref(v.items.at(0)) : uniform_ref(v.items.at(0));
+                } else throw SceneError("scene: bad stage entry `" + v.s + "`");
+                return c;
+            };
+            if (const Value* u = d.find("uniforms"))
+                for (auto& kv : u->entries) stage.uniforms.emplace_back(as_string(kv.first, "stage key"), change(kv.second, false));
+            if (const Value* mm = d.find("matrices"))
+                for (auto& kv : mm->entries) stage.matrices.emplace_back(as_string(kv.first, "stage key"), change(kv.second, true));
+            if (const Value* sc = d.find("set_cam")) {
+                if (const Value* outer = sc->some()) {  // Some(..)
+                    stage.has_set_cam = true;
+                    if (const Value* inner = outer->some()) {  // Some(Some(CamRef))
+                        if (inner->is_named("Named")) {
+                            stage.set_cam = scene.find_camera(as_string(inner->items.at(0), "CamRef"));
+                        } else if (inner->is_named("Inline")) {
+                            scene.cameras.push_back(parse_camera(inner->items.at(0)));
+                            stage.set_cam = (int)scene.cameras.size() - 1;
+                        }
+                    }
+                }
+            }
+            scene.stages.push_back(std::move(stage));
+        }
+    }
+
+    SceneCamera parse_camera(const Value& d) {
+        SceneCamera cam;
+        const Value& la = d.at("look_at");
+        if (la.is_named("MatrixCenter")) {
+            cam.look_at_matrix = true;
+            cam.matrix = matrix_ref(la.items.at(0));
+        } else {
+            cam.coordinate = as_dvec3(la.items.at(0), "camera look_at");
+        }
+        cam.alpha = as_f64(d.at("alpha"), "camera alpha");
+        cam.beta = as_f64(d.at("beta"), "camera beta");
+        cam.r = as_f64(d.at("r"), "camera r");
+        if (const Value* v = d.find("in_subspace")) cam.in_subspace = as_bool(*v, "camera in_subspace");
+        if (const Value* v = d.find("free_movement")) cam.free_movement = as_bool(*v, "camera free_movement");
+        if (const Value* v = d.find("matrix")) {
+            if (v->kind == Value::Tuple && v->items.size() == 16) {
+                double e[16];
+                for (int k = 0; k < 16; ++k) e[k] = as_f64(v->items[k], "camera matrix");
+                cam.teleport = DMat4::from_cols({e[0], e[1], e[2], e[3]}, {e[4], e[5], e[6], e[7]}, {e[8], e[9], e[10], e[11]}, {e[12], e[13], e[14], e[15]});
+            }
+        }
+        return cam;
     }
 };
 
@@ -338,6 +408,55 @@ bool Scene::set_uniform_value(const std::string& name, double v) {
     return true;
 }
 
+int Scene::find_camera(const std::string& name) const {
+    for (size_t k = 0; k < cameras.size(); ++k)
+        if (!cameras[k].name.empty() && cameras[k].name == name) return (int)k;
+    return -1;
+}
+
+std::optional<DVec3> Scene::camera_look_at(const SceneCamera& c) const {
+    if (!c.look_at_matrix) return c.coordinate;
+    auto m = eval_matrix(c.matrix);
+    if (!m) return std::nullopt;
+    double inv_w = 1.0 / m->c[3].w;  // project_point3(ZERO): w_axis.xyz / w_axis.w
+    return DVec3(m->c[3].x * inv_w, m->c[3].y * inv_w, m->c[3].z * inv_w) + DVec3(0.001, 0.001, 0.001);
+}
+
+bool Scene::init_stage_by_name(const std::string& name, int* camera) {
+    const AnimationStage* stage = nullptr;
+    for (auto& st : stages)
+        if (st.name == name) stage = &st;
+    if (!stage) return false;
+    ++version;
+    uniform_alias.assign(uniforms.size(), -1);
+    matrix_alias.assign(matrices.size(), -1);
+    // StageChanging::init_stage (animation.rs:171-183): Changed* -> set_id, FromDev / ProvidedToUser -> dev value
+    for (auto& kv : stage->uniforms) {
+        int idx = find_uniform(kv.first);
+        if (idx < 0) continue;
+        const StageChange& c = kv.second;
+        if ((c.kind == StageChange::Changed || c.kind == StageChange::ChangedAndToUser) && c.ref >= 0) {
+            if (c.ref != idx) uniform_alias[idx] = c.ref;
+        } else if (c.kind == StageChange::FromDev || c.kind == StageChange::ProvidedToUser) {
+            for (auto& dv : dev_uniforms)
+                if (dv.first == kv.first) uniforms[idx].value = dv.second;
+        }
+    }
+    for (auto& kv : stage->matrices) {
+        int idx = find_matrix(kv.first);
+        if (idx < 0 || !matrices[idx].named) continue;
+        const StageChange& c = kv.second;
+        if ((c.kind == StageChange::Changed || c.kind == StageChange::ChangedAndToUser) && c.ref >= 0) {
+            if (c.ref != idx) matrix_alias[idx] = c.ref;
+        } else if (c.kind == StageChange::FromDev || c.kind == StageChange::ProvidedToUser) {
+            for (auto& dv : dev_matrices)
+                if (dv.first == kv.first) matrices[idx].value = dv.second;
+        }
+    }
+    if (camera) *camera = stage->has_set_cam ? stage->set_cam : -1;
+    return true;
+}
+
 std::optional<double> Scene::eval_formula(const std::string& text) const {
     auto it = formula_cache_.find(text);
     if (it == formula_cache_.end()) it = formula_cache_.emplace(text, Formula::compile(text)).first;
@@ -358,6 +477,7 @@ std::optional<double> Scene::eval_formula(const std::string& text) const {
 }
 
 std::optional<UniformValue> Scene::eval_uniform(int index) const {
+    for (int hops = 0; index >= 0 && index < (int)uniform_alias.size() && uniform_alias[index] >= 0 && hops < 64; ++hops) index = uniform_alias[index];
     if (index < 0 || index >= (int)uniforms.size()) return std::nullopt;
     if (uniform_busy_.size() < uniforms.size()) uniform_busy_.resize(uniforms.size(), 0);
     if (uniform_busy_[index]) return std::nullopt;  // recursion
@@ -395,6 +515,7 @@ std::optional<double> Scene::eval_param(const Param& p) const {
 }
 
 std::optional<DMat4> Scene::eval_matrix(int index) const {
+    for (int hops = 0; index >= 0 && index < (int)matrix_alias.size() && matrix_alias[index] >= 0 && hops < 64; ++hops) index = matrix_alias[index];
     if (index < 0 || index >= (int)matrices.size()) return std::nullopt;
     if (matrix_busy_.size() < matrices.size()) matrix_busy_.resize(matrices.size(), 0);
     if (matrix_busy_[index]) return std::nullopt;

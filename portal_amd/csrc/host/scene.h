@@ -95,6 +95,27 @@ struct Texture {
     std::string name, path;
 };
 
+// Named cameras (src/gui/camera.rs:46-66) and stages (src/gui/animation.rs:29-60,171-183,217-237)
+struct SceneCamera {
+    std::string name;  // empty for a camera defined inline in a stage
+    bool look_at_matrix = false;  // CamLookAt::MatrixCenter(id) vs Coordinate(pos)
+    int matrix = -1;
+    DVec3 coordinate;
+    double alpha = 0.0, beta = 0.0, r = 3.5;
+    bool in_subspace = false, free_movement = false;
+    DMat4 teleport = DMat4::identity();  // Cam::matrix
+};
+struct StageChange {
+    enum Kind { ProvidedToUser, FromDev, Changed, ChangedAndToUser } kind = FromDev;
+    int ref = -1;  // Changed*/: index of the replacing uniform / matrix (-1 = Changed(None))
+};
+struct AnimationStage {
+    std::string name;
+    std::vector<std::pair<std::string, StageChange>> uniforms, matrices;  // by element name
+    bool has_set_cam = false;  // set_cam: Some(..)
+    int set_cam = -1;          // camera index, -1 = original camera
+};
+
 // Scene `cam` block (src/gui/scene.rs:33-52)
 struct CamSettings {
     DVec3 look_at;
@@ -117,6 +138,12 @@ public:
     std::vector<std::string> videos;  // names only: a video is one more sampler (src/gui/scene.rs:405-409); frames are out of scope
     std::optional<std::string> skybox;
     bool use_time = false;
+    std::vector<SceneCamera> cameras;
+    std::vector<AnimationStage> stages;
+    std::vector<std::pair<std::string, Uniform>> dev_uniforms;  // dev_stage: the values FromDev restores
+    std::vector<std::pair<std::string, Matrix>> dev_matrices;
+    // set_id aliases installed by a stage: element i evaluates as element alias[i] (-1: itself)
+    std::vector<int> uniform_alias, matrix_alias;
 
     // bumped by every mutation that can change an evaluated value (renderers cache on it)
     unsigned long long version = 1;
@@ -134,6 +161,13 @@ public:
 
     // overrides (what a stage / animation / user slider does): set the stored value
     bool set_uniform_value(const std::string& name, double v);
+
+    // Scene::init_stage_by_name (src/gui/scene.rs:1237-1250): apply an animation stage's overrides.
+    // Returns false if there is no such stage; *camera = index into `cameras` the stage selects, or -1.
+    bool init_stage_by_name(const std::string& name, int* camera);
+    int find_camera(const std::string& name) const;
+    // Cam::get_pos (src/gui/camera.rs:96-108)
+    std::optional<DVec3> camera_look_at(const SceneCamera& c) const;
 
 private:
     mutable std::map<std::string, std::shared_ptr<Formula>> formula_cache_;

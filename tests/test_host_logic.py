@@ -339,3 +339,66 @@ def test_shard_rows_and_deinterleave(pa):
         pa.deinterleave_rows(np.ascontiguousarray(full[rows]), f, out)
     assert total == h and np.array_equal(out, full)
     assert pa.shard_rows(pa.Frame(w, h, 4, 4)) == -1  # phase must be < stride
+
+
+# ---------------------------------------------------------------------------------------------
+# stages and named cameras (`render-frame --stage / --camera`)
+# ---------------------------------------------------------------------------------------------
+def test_stage_overrides_known_answers(pa):
+    """monoportal, stage "doorway to portal" (scenes/monoportal.ron:811-855): `portal_offset` becomes the
+    formula progress * const_max_offset + 0.01, `portal_rotate_angle` becomes Progress(0), progress 0."""
+    s = pa.Scene.from_file(pa.scene_path("monoportal"))
+    assert s.eval_uniform("portal_rotate_angle") == pytest.approx(math.pi)
+    assert s.init_stage("doorway to portal") == ""
+    assert s.eval_uniform("portal_rotate_angle") == 0.0
+    assert s.eval_uniform("portal_offset") == pytest.approx(0.0 * 1.12 + 0.01)
+    assert s.eval_uniform("portal_black_color_progress") == 1.0
+    with pytest.raises(pa.PortalError):
+        s.init_stage("no such stage")
+
+
+@pytest.mark.parametrize("name", ["monoportal", "portal_in_portal", "triple_portal", "basics", "mobius_monoportal"])
+def test_every_stage_and_camera_agrees_with_the_oracle(pa, name):
+    from oracle.scene_eval import OracleScene, builtin_uniforms
+
+    path = pa.scene_path(name)
+    stages = pa.Scene.from_file(path).stages()
+    assert stages
+    for stage in stages:
+        ps, osc = pa.Scene.from_file(path), OracleScene(path)
+        cam_name = ps.init_stage(stage)
+        cam_idx = osc.init_stage(stage)
+        got, want = ps.uniform_values(), osc.scene_uniform_values()
+        for k, w in want.items():
+            if k.startswith("oracle_inline"):
+                continue
+            g = got[k]
+            g = np.asarray(g, np.float32).T.reshape(16) if np.asarray(g).shape == (4, 4) else np.asarray(g).reshape(-1)
+            wb = np.asarray(w).reshape(-1)
+            same = (g.view(np.uint32) == wb.view(np.uint32)) if wb.dtype.kind == "f" else (g == wb)
+            assert np.all(same | (np.isnan(g.astype(np.float64)) & np.isnan(wb.astype(np.float64)))), (stage, k)
+        assert (cam_name == "") == (cam_idx < 0)
+        if cam_idx >= 0:
+            r = pa.SceneRenderer(ps, device=-1)
+            r.use_camera(cam_name)
+            b = builtin_uniforms(osc, 640, 360, camera=osc.camera_settings(cam_idx))
+            for k in ("_camera", "_camera_mul_inv", "_camera_scale", "_camera_in_subspace"):
+                g = r.uniform_value(k, 640, 360)
+                g = np.asarray(g).T.reshape(16) if np.asarray(g).shape == (4, 4) else np.asarray(g).reshape(-1)
+                assert np.array_equal(g.astype(np.float32), np.asarray(b[k], np.float32).reshape(-1)), (stage, k)
+
+
+def test_named_camera_known_answer(pa):
+    """portal_in_portal camera "a": look_at = centre of matrix `a` (0,0,-1) + 0.001 (src/gui/camera.rs:96-108)."""
+    s = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    assert s.cameras()[:2] == ["a", "b"]
+    r = pa.SceneRenderer(s, device=-1)
+    r.use_camera("a")
+    m = r.uniform_value("_camera", 100, 100)
+    alpha, beta, rad = -5.794107164726811, 0.8981089851558188, 3.50000000000001
+    pos = np.array([math.sin(beta) * math.cos(alpha), math.cos(beta), math.sin(beta) * math.sin(alpha)]) * rad + np.array([0.001, 0.001, -0.999])
+    assert m[:3, 3] == pytest.approx(pos, abs=1e-6)
+    with pytest.raises(pa.PortalError):
+        r.use_camera("nope")
+    r.use_camera("")  # back to the scene's own cam block
+    assert np.array_equal(r.uniform_value("_camera", 100, 100), pa.SceneRenderer(s, device=-1).uniform_value("_camera", 100, 100))

@@ -161,3 +161,29 @@ def test_teleport_external_ray_matches_oracle_and_the_portal_matrix(pa, scene_na
             if np.allclose(got[0], expect, atol=2e-4):
                 crossed += 1
     assert crossed >= 3
+
+
+@pytest.mark.parametrize("scene_name,stage", [("monoportal", "rotate portal"), ("portal_in_portal", "picture 2"), ("triple_portal", None)])
+def test_staged_scene_with_stage_camera_matches_oracle(pa, scene_name, stage):
+    """`render-frame --stage NAME`: overrides + the camera the stage selects."""
+    from oracle import host_build as hb
+    from oracle.portal_oracle import Oracle
+
+    path = pa.scene_path(scene_name)
+    scene = pa.Scene.from_file(path)
+    stage = stage or scene.stages()[-1]
+    cam_name = scene.init_stage(stage)
+    r = pa.SceneRenderer(scene, device=-1)
+    r.set_option("render_depth", 30)
+    if cam_name:
+        r.use_camera(cam_name)
+    got = hb.host_kernel_for(r, scene, 56, 32).render(56, 32)
+    o = Oracle(path)
+    cam_idx = o.scene.init_stage(stage)
+    if cam_idx >= 0:
+        o.camera = o.scene.camera_settings(cam_idx)
+    o.options["render_depth"] = 30
+    want = o.render(56, 32)
+    assert bits_equal(got["rgba32f"], want["rgba32f"]).all()
+    plain = host_render(pa, scene_name, 56, 32, 30, 1)
+    assert not np.array_equal(plain["rgba8"], got["rgba8"])  # the stage really changed the picture
