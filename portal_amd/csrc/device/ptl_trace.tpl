@@ -30,6 +30,29 @@ namespace glsl {
 // --- material ids (scene.rs:720-845) ---------------------------------------------------------
 //%materials_defines//%
 
+// Everything that reads scene uniforms lives in one struct whose only state is a pointer to the
+// uniform block; the uniform accessors (`a_mat`, `progress_u`, `_camera` ...) expand to loads through
+// that pointer.  The bounce loop re-launders the pointer once per trip (PTL_RELAUNDER), so the
+// scalar loads of the portal matrices can be shared inside a trip but cannot be hoisted above the loop,
+// where hipcc would otherwise keep hundreds of SGPRs live and spill them to VGPR lanes
+// (measured: triple_portal 4K 3.36 ms -> 1.2 ms, profiles/r01/variants5_uniform_reload.jsonl).
+struct ptl_tracer {
+    const ptl_uniform_block* ptl_ubp;
+#if !(PTL_DEVICE_BUILD && (defined(PTL_UNIFORMS_IN_LDS) || defined(PTL_UNIFORM_RELOAD) || defined(PTL_UNIFORM_HOIST)))
+#undef PTL_U
+#define PTL_U (*ptl_ubp)
+#endif
+#if PTL_DEVICE_BUILD && !defined(PTL_UNIFORMS_IN_LDS) && !defined(PTL_UNIFORM_RELOAD) && !defined(PTL_UNIFORM_HOIST)
+#define PTL_RELAUNDER()                                   \
+    do {                                                  \
+        const ptl_uniform_block* ptl_fresh = &ptl_u;      \
+        asm volatile("" : "+s"(ptl_fresh)); /* opaque, uniform (SGPR) */ \
+        ptl_ubp = ptl_fresh;                              \
+    } while (0)
+#else
+#define PTL_RELAUNDER() ((void)0)
+#endif
+
 // Scene snippets are plain GLSL functions without HIP attributes: let clang treat every
 // function declared in this region as __host__ __device__.
 #if PTL_DEVICE_BUILD
@@ -132,6 +155,7 @@ PTL_FN RayTraceResult ray_tracing(Ray r, float camera_scale) {
     vec3 current_color = vec3(1.0f);
     float all_t = 0.0f;
     for (int j = 0; j < _ray_tracing_depth; j++) {
+        PTL_RELAUNDER();
         PTL_COUNT_SEGMENT();
         SceneIntersection i = scene_intersect(r);
         SceneIntersectionWithMaterial i2 = scene_intersect_material_process(r);
@@ -193,6 +217,7 @@ PTL_FN ExternalRayTeleportation teleport_external_ray(Ray r) {
     float all_t = 0.0f;
     const int max_camera_teleports = 10;
     for (int j = 0; j < max_camera_teleports; j++) {
+        PTL_RELAUNDER();
         SceneIntersection i = scene_intersect(r);
         SceneIntersectionWithMaterial i2 = scene_intersect_material_process(r);
         bool continue_intersect = false;
@@ -369,6 +394,19 @@ PTL_FN vec4 shade_pixel(vec2 position) {
     }
     result = sqrt(result / float(_aa_count));
     return vec4(result, 1.0f);
+}
+
+};  // struct ptl_tracer
+#undef PTL_U
+#define PTL_U ptl_u
+
+PTL_FN vec4 shade_pixel(vec2 position) {
+    ptl_tracer t{&ptl_u};
+    return t.shade_pixel(position);
+}
+PTL_FN void teleport_external_ray_entry(float* out6) {
+    ptl_tracer t{&ptl_u};
+    t.teleport_external_ray_entry(out6);
 }
 
 // GL fixed-point conversion of one channel: clamp to [0,1], scale, round to nearest.

@@ -317,7 +317,13 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         s.add_string("#if PTL_DEVICE_BUILD\n__constant__ ptl_uniform_block ptl_u;\n#else\nptl_uniform_block ptl_u;\n#endif\n");
         // where the kernel reads uniforms from: the __constant__ block through the scalar cache
         // (default), or a per-workgroup LDS copy (-DPTL_UNIFORMS_IN_LDS, staged in ptl_entry.h)
-        s.add_string("#if PTL_DEVICE_BUILD && defined(PTL_UNIFORMS_IN_LDS)\n__shared__ ptl_uniform_block ptl_lds_u;\n#define PTL_U ptl_lds_u\n#else\n#define PTL_U ptl_u\n#endif\n");
+        s.add_string("#if PTL_DEVICE_BUILD && defined(PTL_UNIFORMS_IN_LDS)\n__shared__ ptl_uniform_block ptl_lds_u;\n#define PTL_U ptl_lds_u\n"
+                     "#elif PTL_DEVICE_BUILD && defined(PTL_UNIFORM_RELOAD)\n"
+                     "// every access goes through a pointer the optimiser cannot see through: scalar loads stay where they are\n"
+                     "// used instead of being hoisted out of the bounce loop and spilled (SGPR -> VGPR lanes)\n"
+                     "PTL_FN const ptl_uniform_block& ptl_ublock() { const ptl_uniform_block* p = &ptl_u; asm volatile(\"\" : \"+s\"(p)); return *p; }\n"
+                     "#define PTL_U (ptl_ublock())\n"
+                     "#else\n#define PTL_U ptl_u\n#endif\n");
         for (auto& u : list)
             s.add_string("static_assert(__builtin_offsetof(ptl_uniform_block, " + u.name + ") == " + std::to_string(u.offset) + ", \"uniform layout\");\n");
         // JIT-time specialisation: current values baked in as literals (same arithmetic, the

@@ -12,12 +12,14 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 VARIANTS = {
+    "base": "",
+    "base_w3": "-DPTL_WAVES_PER_EU=3",
+    "base_w4": "-DPTL_WAVES_PER_EU=4",
+    "hoist": "-DPTL_UNIFORM_HOIST",
+    "reload": "-DPTL_UNIFORM_RELOAD",
+    "spec": "SPECIALIZE",
     "all": "SPECIALIZE_ALL",
     "all_w4": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4",
-    "all_nounroll": "SPECIALIZE_ALL -fno-unroll-loops",
-    "all_nounroll_w4": "SPECIALIZE_ALL -fno-unroll-loops -DPTL_WAVES_PER_EU=4",
-    "all_O2": "SPECIALIZE_ALL -O2",
-    "all_sched": "SPECIALIZE_ALL -mllvm -amdgpu-schedule-metric-bias=100",
 }
 CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
 
