@@ -19,6 +19,14 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(CORPUS), reason="reference sce
 OUT_OF_SCOPE = {"trefoil"}
 
 
+@pytest.fixture(autouse=True)
+def _scratch_build_dir(tmp_path_factory, monkeypatch):
+    """82 one-off host builds: keep them out of oracle/_build (which travels to the GPU box)."""
+    from oracle import host_build as hb
+
+    monkeypatch.setattr(hb, "BUILD_DIR", str(tmp_path_factory.getbasetemp() / "corpus_build"))
+
+
 def scene_files():
     return [f for f in sorted(glob.glob(os.path.join(CORPUS, "*.ron"))) if os.path.getsize(f) > 0 and os.path.basename(f)[:-4] not in OUT_OF_SCOPE]
 
