@@ -30,10 +30,11 @@ BUILD_DIR = os.path.join(_HERE, "_build")
 CXXFLAGS = ["-std=c++20", "-O2", "-ffp-contract=off", "-mfma", "-fopenmp", "-fPIC", "-shared", "-x", "c++", "-w"]
 
 
-def compile_host(source: str, count_segments: bool = False) -> str:
-    """g++-compile `source` into a shared object (cached by content hash); returns its path."""
+def compile_host(source: str, count_segments: bool = False, opt: str = "-O2") -> str:
+    """g++-compile `source` into a shared object (cached by content hash); returns its path.
+    The optimisation level cannot change results (IEEE arithmetic, -ffp-contract=off, no fast-math)."""
     os.makedirs(BUILD_DIR, exist_ok=True)
-    flags = list(CXXFLAGS) + (["-DPTL_COUNT_SEGMENTS"] if count_segments else [])
+    flags = [opt if f == "-O2" else f for f in CXXFLAGS] + (["-DPTL_COUNT_SEGMENTS"] if count_segments else [])
     key = hashlib.sha256((source + "\0" + " ".join(flags)).encode()).hexdigest()[:20]
     so = os.path.join(BUILD_DIR, f"host_{key}.so")
     if not os.path.exists(so):
@@ -49,8 +50,8 @@ def compile_host(source: str, count_segments: bool = False) -> str:
 class HostKernel:
     """The host-compiled kernel of one scene: set uniforms by name, render pixel windows."""
 
-    def __init__(self, source: str, layout, block_size: int, count_segments: bool = False):
-        self.so_path = compile_host(source, count_segments)
+    def __init__(self, source: str, layout, block_size: int, count_segments: bool = False, opt: str = "-O2"):
+        self.so_path = compile_host(source, count_segments, opt)
         self.lib = C.CDLL(self.so_path)
         self.lib.ptl_host_uniform_block.restype = C.c_void_p
         self.lib.ptl_host_uniform_block.argtypes = [C.POINTER(C.c_ulong)]

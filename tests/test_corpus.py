@@ -40,7 +40,7 @@ def test_corpus_scene_product_equals_oracle(pa, path):
     scene = pa.Scene.from_file(path)
     source = scene.generate_source(0)
     layout, size = scene.uniform_layout()
-    hk = hb.HostKernel(source, layout, size)
+    hk = hb.HostKernel(source, layout, size, opt="-O0")  # tiny frames: compile time dominates
     o = Oracle(path, asset_root="/root/reference")
     o.options["render_depth"] = depth
     # uniform values: the product's (scene + builtins) go into the host kernel; the oracle computes its own
