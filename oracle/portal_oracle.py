@@ -397,6 +397,7 @@ class Oracle:
         self.scene = OracleScene(scene_path)
         self.asset_root = asset_root or os.path.dirname(os.path.dirname(os.path.abspath(scene_path)))
         self.options = dict(render_depth=100, aa_count=1, aa_start=0, view_angle=None, use_panini=False, panini_param=1.0)
+        self.overrides = {}  # builtin uniform name -> value (e.g. _use_360_camera, _draw_depth_map, _draw_side_by_side, _camera_left_eye)
         self.camera = None
         self._program = None
         self.stats = {}
@@ -405,6 +406,7 @@ class Oracle:
     def _uniform_values(self, width, height):
         vals = dict(self.scene.scene_uniform_values())
         vals.update(builtin_uniforms(self.scene, width, height, camera=self.camera, **self.options))
+        vals.update(self.overrides)
         out = {}
         for name, v in vals.items():
             a = np.asarray(v)
@@ -606,7 +608,7 @@ class Oracle:
 
     # ---- frag.glsl:106-159 -----------------------------------------------------------------------
     def ray_tracing(self, r, camera_scale):
-        """r: Ray over N lanes.  Returns (rgb float32 (N,3), segments per lane)."""
+        """r: Ray over N lanes.  Returns (rgb float32 (N,3), segments per lane, depth (N,), has_depth (N,))."""
         nat, u = self.nat, self.uniforms
         N = len(np.asarray(r.f["tmul"]))
         depth = int(u["_ray_tracing_depth"])
@@ -622,6 +624,8 @@ class Oracle:
             not_found_all = None
         not_found = nat.color(M.lit("0.6"), M.lit("0.6"), M.lit("0.6"))
         result = np.zeros((N, 3), F32)  # depth exhausted -> color(0,0,0)
+        depth_out = np.zeros(N, F32)
+        has_depth = np.zeros(N, bool)
         segments = np.zeros(N, np.int64)
         idx = np.arange(N)              # lanes still tracing
         color = V.expand(vec(1.0, 1.0, 1.0), N)
@@ -672,6 +676,10 @@ class Oracle:
             fin_col = V.select(dark, darkened, color_next)
             done = esc | final
             out_col = V.select(esc, esc_col, fin_col)
+            if final.any():  # depth = all_t / max(camera_scale, 1e-6), taken before the darkening clamp (frag.glsl:135)
+                dval = M.div(all_t, M.fmax(camera_scale, M.lit("1e-6")))
+                depth_out[idx[final]] = np.broadcast_to(dval, (n,))[final]
+                has_depth[idx[final]] = True
             if done.any():
                 lanes = idx[done]
                 for c in range(3):
@@ -684,7 +692,7 @@ class Oracle:
             r = V.take(V.expand(m.f["new_ray"], n), sel)
             color = V.take(V.expand(color_next, n), sel)
             all_t = all_t[sel]
-        return result, segments
+        return result, segments, depth_out, has_depth
 
     # ---- frag.glsl:209-257 + host side src/main.rs:1361-1409 ----------------------------------------
     def teleport_external_ray(self, a, b):
@@ -759,23 +767,89 @@ class Oracle:
         s = M.inversesqrt(M.add(fl(1.0), pow2(tan_theta)))
         return mul(vec(sin_phi, tan_theta, cos_phi), s)
 
-    # ---- frag.glsl:408-464 (pinhole / Panini) ------------------------------------------------------
-    def get_color2(self, image_position, camera, in_subspace, camera_scale):
+    # ---- frag.glsl:80-104 ----------------------------------------------------------------------------
+    def sample_depth_gradient(self, depth):
+        u, nat = self.uniforms, self.nat
+        dmin, dmax = M.fmin(u["_depth_map_min"], u["_depth_map_max"]), M.fmax(u["_depth_map_min"], u["_depth_map_max"])
+        norm = M.clamp(M.div(M.sub(depth, dmin), M.fmax(M.lit("1e-6"), M.sub(dmax, dmin))), fl(0.0), fl(1.0))
+        t = M.sub(fl(1.0), norm)
+        stops = [nat.sqrvec(vec(*(M.lit(x) for x in c))) for c in (("0.001462", "0.000466", "0.013866"), ("0.258234", "0.038571", "0.406485"),
+                 ("0.578304", "0.148039", "0.404411"), ("0.865006", "0.316822", "0.226055"), ("0.987622", "0.645320", "0.039886"),
+                 ("0.988362", "0.998364", "0.644924"))]
+        p2 = M.lit("0.2")
+        seg = [V.map3(M.mix, stops[k], stops[k + 1], M.div(M.sub(t, M.lit(lo)), p2) if lo != "0" else M.div(t, p2))
+               for k, lo in enumerate(("0", "0.2", "0.4", "0.6", "0.8"))]
+        out = seg[4]
+        for k, hi in ((3, "0.8"), (2, "0.6"), (1, "0.4"), (0, "0.2")):
+            out = V.select(M.lt(t, M.lit(hi)), seg[k], out)
+        return out
+
+    # ---- frag.glsl:408-464 ------------------------------------------------------------------------------
+    def get_color2(self, image_position, camera, in_subspace, camera_scale, resolution=None):
         u = self.uniforms
         n = len(np.asarray(image_position.c[0]))
+        resolution = resolution if resolution is not None else u["_resolution"]
         o = mul(camera, vec(0.0, 0.0, 0.0, 1.0))
+        ix, iy = image_position.c
+        black = np.zeros(n, bool)  # pixels outside the projection's valid area return vec3(0) without tracing
+        pi = M.lit("3.14159265359")
+        pi05 = M.mul(pi, fl(0.5))
         if int(u["_use_panini_projection"]) == 1:
-            p = self.panini(vec(image_position.c[0], image_position.c[1]), u["_view_angle"], u["_panini_param"])
+            p = self.panini(vec(ix, iy), u["_view_angle"], u["_panini_param"])
             d = V.normalize(mul(camera, Vec(list(p.c) + [fl(0.0)])))
         elif int(u["_use_360_camera"]) == 1 or int(u["_use_180_camera"]) == 1:
-            raise NotImplementedError("360/180 cameras are not restated in the oracle yet")
+            if int(u["_use_360_camera"]) == 1:   # frag.glsl:413-437
+                coef = M.fmin(resolution.c[0], resolution.c[1])
+                ax, ay = M.div(resolution.c[0], coef), M.div(resolution.c[1], coef)
+                wide = M.ge(ax, M.mul(fl(2.0), ay))
+                rx = np.where(wide, M.mul(fl(2.0), ay), ax).astype(F32)
+                ry = np.where(wide, ay, M.div(ax, fl(2.0))).astype(F32)
+                black = M.gt(M.absf(ix), rx) | M.gt(M.absf(iy), ry)
+                yaw, pitch = M.mul(M.div(ix, rx), pi), M.mul(M.div(iy, ry), pi05)
+            else:                                # frag.glsl:438-448
+                black = M.gt(M.absf(ix), fl(1.0)) | M.gt(M.absf(iy), fl(1.0))
+                yaw, pitch = M.mul(ix, pi05), M.mul(iy, pi05)
+            black = np.broadcast_to(black, (n,))
+            local = vec(M.mul(M.sin(yaw), M.cos(pitch)), M.sin(pitch), M.mul(M.cos(yaw), M.cos(pitch)))
+            d = V.normalize(mul(camera, Vec(list(local.c) + [fl(0.0)])))
         else:
             h = M.tan(M.div(u["_view_angle"], fl(2.0)))
-            d = V.normalize(mul(camera, vec(M.mul(image_position.c[0], h), M.mul(image_position.c[1], h), fl(1.0), fl(0.0))))
-        ray = V.expand(Ray(o, d, fl(1.0), np.full(n, bool(in_subspace))), n)
-        rgb, seg = self.ray_tracing(ray, camera_scale)
-        if int(u["_draw_depth_map"]) == 1:
-            raise NotImplementedError("depth map colouring is not restated in the oracle yet")
+            d = V.normalize(mul(camera, vec(M.mul(ix, h), M.mul(iy, h), fl(1.0), fl(0.0))))
+        rgb = np.zeros((n, 3), F32)
+        seg = np.zeros(n, np.int64)
+        live = np.nonzero(~black)[0]
+        if len(live):
+            ray = V.take(V.expand(Ray(o, d, fl(1.0), np.full(n, bool(in_subspace))), n), live)
+            col, sg, depth, has_depth = self.ray_tracing(ray, camera_scale)
+            if int(u["_draw_depth_map"]) == 1:   # frag.glsl:456-462
+                grad = self.sample_depth_gradient(depth)
+                col = np.where(has_depth[:, None], np.stack([np.broadcast_to(c, depth.shape) for c in grad.c], axis=1), F32(0)).astype(F32)
+            rgb[live] = col
+            seg[live] = sg
+        return rgb, seg
+
+    # ---- frag.glsl:466-503 (mono / side-by-side; anaglyph lines are stripped at native defaults) ----------
+    def get_color(self, image_position):
+        u = self.uniforms
+        n = len(np.asarray(image_position.c[0]))
+        if int(u["_draw_side_by_side"]) != 1:
+            return self.get_color2(image_position, u["_camera"], int(u["_camera_in_subspace"]) == 1, u["_camera_scale"], u["_resolution"])
+        res = u["_resolution"]
+        coef = M.fmin(res.c[0], res.c[1])
+        position = add(mul(div(image_position, fl(2.0)), coef), div(res, fl(2.0)))
+        half = vec(M.div(res.c[0], fl(2.0)), res.c[1])
+        coef2 = M.fmin(half.c[0], half.c[1])
+        left = np.broadcast_to(M.lt(position.c[0], half.c[0]), (n,))
+        pos_l = mul(div(sub(position, div(half, fl(2.0))), coef2), fl(2.0))
+        pos_r = mul(div(sub(sub(position, vec(half.c[0], fl(0.0))), div(half, fl(2.0))), coef2), fl(2.0))
+        rgb = np.zeros((n, 3), F32)
+        seg = np.zeros(n, np.int64)
+        for sel, pos, cam, sub_, scale in ((left, pos_l, "_camera_left_eye", "_left_eye_in_subspace", "_left_eye_scale"),
+                                           (~left, pos_r, "_camera_right_eye", "_right_eye_in_subspace", "_right_eye_scale")):
+            lanes = np.nonzero(sel)[0]
+            if len(lanes):
+                c, s = self.get_color2(V.take(V.expand(pos, n), lanes), u[cam], int(u[sub_]) == 1, u[scale], half)
+                rgb[lanes], seg[lanes] = c, s
         return rgb, seg
 
     # ---- frag.glsl:506-527,550-551 + vertex stage scene.rs:1674-1697 ---------------------------------
@@ -798,7 +872,7 @@ class Oracle:
             af = F32(a)
             offset = vec(M.mod(M.add(fl(0.5), M.mul(a1, af)), fl(1.0)), M.mod(M.add(fl(0.5), M.mul(a2, af)), fl(1.0)))  # quasi_random
             pos = add(uv_screen, mul(mul(offset, pixel_size), fl(2.0)))
-            rgb, seg = self.get_color2(V.expand(pos, n), u["_camera"], int(u["_camera_in_subspace"]) == 1, u["_camera_scale"])
+            rgb, seg = self.get_color(V.expand(pos, n))
             total = M.add(total, rgb)
             segments += seg
         M.set_active(n)

@@ -187,3 +187,26 @@ def test_staged_scene_with_stage_camera_matches_oracle(pa, scene_name, stage):
     assert bits_equal(got["rgba32f"], want["rgba32f"]).all()
     plain = host_render(pa, scene_name, 56, 32, 30, 1)
     assert not np.array_equal(plain["rgba8"], got["rgba8"])  # the stage really changed the picture
+
+
+@pytest.mark.parametrize("mode,options,overrides", [
+    ("360", [("use_360_camera", 1)], {"_use_360_camera": np.int32(1)}),
+    ("180", [("use_180_camera", 1)], {"_use_180_camera": np.int32(1)}),
+    ("depth", [("draw_depth_map", 1), ("depth_map_min", 1.0), ("depth_map_max", 7.5)],
+     {"_draw_depth_map": np.int32(1), "_depth_map_min": np.float32(1.0), "_depth_map_max": np.float32(7.5)}),
+    ("side_by_side", [("draw_side_by_side", 1)], {"_draw_side_by_side": np.int32(1)}),
+])
+def test_other_kernel_modes_match_oracle(pa, mode, options, overrides):
+    """360 / 180 equirect cameras (frag.glsl:413-448), depth-map colouring (:80-104,456-462), side-by-side
+    (:479-499; both eyes are the identity matrix offline, like the reference before teleport_eye_matrices)."""
+    from oracle.portal_oracle import Oracle
+
+    w, h = 64, 36
+    got = host_render(pa, "monoportal", w, h, 20, 1, options=options)
+    o = Oracle(os.path.join(ROOT, "scenes", "monoportal.ron"))
+    o.options["render_depth"] = 20
+    o.overrides = overrides
+    want = o.render(w, h)
+    assert bits_equal(got["rgba32f"], want["rgba32f"]).all()
+    assert got["segments"] == int(want["segments"].sum())
+    assert not np.array_equal(got["rgba8"], host_render(pa, "monoportal", w, h, 20, 1)["rgba8"])
