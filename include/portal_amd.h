@@ -202,6 +202,17 @@ int ptl_renderer_draw_to_host(ptl_renderer* r, const ptl_frame* frame, uint8_t* 
  * (set_uniforms(0,0), teleport_light_u = 1), then ptl_kernel_teleport_ray. */
 int ptl_renderer_teleport_ray(ptl_renderer* r, const double a[3], const double b[3], double out_pos[3], int* hit_object,
                               int* changed_subspace, int* teleported);
+/* Move the camera the way the interactive reference does every frame: set the new orbit parameters, then
+ * SceneRenderer::teleport_camera (src/main.rs:1217-1264): if the straight segment from the previous camera
+ * position to the new one crosses a portal, the camera's teleport matrix becomes the portal map's
+ * finite-difference Jacobian (teleport_matrix, src/main.rs:1174-1215; four ray queries) so that the view
+ * continues seamlessly on the other side.  *teleported = 1 if that happened, *blocked = 1 if the move was
+ * undone (stop_at_objects, or no Jacobian could be formed).  ptl_renderer_set_camera, by contrast, *places*
+ * the camera without looking for a crossing. */
+int ptl_renderer_move_camera(ptl_renderer* r, const double look_at[3], double alpha, double beta, double radius, int* teleported,
+                             int* blocked);
+/* Current teleport matrix (binary64, column-major), subspace flag and world position of the camera. */
+int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16], int* in_subspace, double position[3]);
 ptl_kernel* ptl_renderer_kernel(ptl_renderer* r);
 void ptl_renderer_destroy(ptl_renderer* r);
 

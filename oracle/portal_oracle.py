@@ -890,6 +890,68 @@ class Oracle:
         return dict(rgba32f=out["rgba32f"].reshape(*shape, 4), rgba8=out["rgba8"].reshape(*shape, 4), segments=out["segments"].reshape(shape))
 
 
+class CameraRig:
+    """RotateAroundCam + SceneRenderer::teleport_camera / teleport_matrix (src/main.rs:278-304, 1174-1264),
+    restated in Python floats (binary64) on top of Oracle.teleport_external_ray."""
+
+    def __init__(self, oracle: Oracle):
+        from .scene_eval import IDENT, camera_matrix, m_inverse, m_mul, m_mul_vec
+
+        self.o = oracle
+        self._cm, self._inv, self._mul, self._mv = camera_matrix, m_inverse, m_mul, m_mul_vec
+        c = oracle.scene.cam
+        self.look_at, self.alpha, self.beta, self.r = list(c["look_at"]), c["alpha"], c["beta"], c["r"]
+        self.teleport_matrix, self.in_subspace = IDENT, False
+        self.prev_cam_pos = self.cam_pos()
+
+    def matrix(self):
+        return self._cm(self.look_at, self.alpha, self.beta, self.r, self.teleport_matrix, False)
+
+    def cam_pos(self):
+        return self._mv(self.matrix(), [0.0, 0.0, 0.0, 1.0])[:3]
+
+    def settings(self):
+        return dict(look_at=self.look_at, alpha=self.alpha, beta=self.beta, r=self.r, teleport_matrix=self.teleport_matrix, in_subspace=self.in_subspace)
+
+    def _query(self, a, b):
+        self.o.camera = self.settings()
+        pos, hit, sub_ = self.o.teleport_external_ray(a, b)
+        return (None if pos is None else [float(x) for x in pos]), hit, sub_
+
+    def _teleport_matrix(self, matrix, start, direction, actual, dx):
+        cols = []
+        for axis in ([1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0]):
+            v = [x * dx for x in self._mv(matrix, axis)][:3]
+            pos, _, _ = self._query([start[k] + v[k] for k in range(3)], [direction[k] + v[k] for k in range(3)])
+            if pos is None:
+                return None
+            cols.append([(pos[k] - actual[k]) / dx for k in range(3)] + [0.0])
+        new_mat = cols + [[0.0, 0.0, 0.0, 1.0]]
+        moved = self._mv(self._mul(new_mat, self._inv(matrix)), [direction[0], direction[1], direction[2], 1.0])
+        return cols + [[actual[k] - moved[k] for k in range(3)] + [1.0]]
+
+    def move(self, look_at, alpha, beta, r):
+        """-> (teleported, blocked)"""
+        prev = (self.look_at, self.alpha, self.beta, self.r, self.teleport_matrix, self.in_subspace, self.prev_cam_pos)
+        self.look_at, self.alpha, self.beta, self.r = list(look_at), alpha, beta, r
+        pos = self.cam_pos()
+        new_pos, _hit, change_sub = self._query(self.prev_cam_pos, pos)
+        if new_pos is None:
+            self.prev_cam_pos = pos
+            return False, False
+        for dx in (0.001, 0.0001, 0.00001, 0.000001):
+            m = self._teleport_matrix(self.teleport_matrix, self.prev_cam_pos, pos, new_pos, dx)
+            if m is None:
+                continue
+            self.teleport_matrix = m
+            if change_sub:
+                self.in_subspace = not self.in_subspace
+            self.prev_cam_pos = self.cam_pos()
+            return True, False
+        self.look_at, self.alpha, self.beta, self.r, self.teleport_matrix, self.in_subspace, self.prev_cam_pos = prev
+        return False, True
+
+
 def to_rgba8(rgba32f):
     """GL fixed-point conversion: clamp to [0,1], *255, round to nearest (NaN -> 0)."""
     v = np.asarray(rgba32f, F32)

@@ -93,6 +93,8 @@ def _load() -> C.CDLL:
         "ptl_renderer_draw": (ci, [vp, P(Frame), vp, vp, vp, vp, P(C.c_float)]),
         "ptl_renderer_draw_to_host": (ci, [vp, P(Frame), vp, vp, P(C.c_uint64), P(C.c_float)]),
         "ptl_renderer_teleport_ray": (ci, [vp, P(cd), P(cd), P(cd), P(ci), P(ci), P(ci)]),
+        "ptl_renderer_move_camera": (ci, [vp, P(cd), cd, cd, cd, P(ci), P(ci)]),
+        "ptl_renderer_camera_state": (ci, [vp, P(cd), P(ci), P(cd)]),
         "ptl_renderer_kernel": (vp, [vp]),
         "ptl_renderer_destroy": (None, [vp]),
         "ptl_deinterleave_rows": (ci, [vp, P(Frame), vp]),
@@ -342,6 +344,17 @@ class SceneRenderer:
         regs, scratch, lds = C.c_int(), C.c_int(), C.c_int()
         _check(lib().ptl_kernel_resources(lib().ptl_renderer_kernel(self._h), C.byref(regs), C.byref(scratch), C.byref(lds)), "kernel_resources")
         return {"registers": regs.value, "scratch_bytes": scratch.value, "lds_bytes": lds.value}
+
+    def move_camera(self, look_at, alpha: float, beta: float, r: float):
+        """One interactive camera step incl. SceneRenderer::teleport_camera.  -> (teleported, blocked)"""
+        la, tel, blk = (C.c_double * 3)(*look_at), C.c_int(), C.c_int()
+        _check(lib().ptl_renderer_move_camera(self._h, la, alpha, beta, r, C.byref(tel), C.byref(blk)), "move_camera")
+        return bool(tel.value), bool(blk.value)
+
+    def camera_state(self) -> dict:
+        m, sub, pos = (C.c_double * 16)(), C.c_int(), (C.c_double * 3)()
+        _check(lib().ptl_renderer_camera_state(self._h, m, C.byref(sub), pos), "camera_state")
+        return {"teleport_matrix": np.array(m, np.float64).reshape(4, 4).T.copy(), "in_subspace": bool(sub.value), "position": np.array(pos)}
 
     def code_object(self) -> bytes:
         k = lib().ptl_renderer_kernel(self._h)

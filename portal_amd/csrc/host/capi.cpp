@@ -37,6 +37,8 @@ struct Camera {
     bool use_360_camera = false, use_180_camera = false;
     DMat4 teleport_matrix = DMat4::identity();
     bool in_subspace = false, free_movement = false;
+    bool allow_teleport = true, stop_at_objects = false;  // src/main.rs:136-137
+    DVec3 prev_cam_pos;
 
     DVec3 pos_vec() const { return DVec3(std::sin(beta) * std::cos(alpha), std::cos(beta), std::sin(beta) * std::sin(alpha)) * r; }
     DMat4 matrix() const {  // src/main.rs:286-304
@@ -48,6 +50,11 @@ struct Camera {
         return teleport_matrix * DMat4::from_cols({i.x, i.y, i.z, 0.0}, {j.x, j.y, j.z, 0.0}, {k.x, k.y, k.z, 0.0}, {p.x, p.y, p.z, 1.0});
     }
 };
+
+DVec3 cam_pos(const Camera& c) {  // RotateAroundCam::get_cam_pos (src/main.rs:316-318)
+    DVec4 p = c.matrix().mul_vec4(DVec4(0.0, 0.0, 0.0, 1.0));
+    return DVec3(p.x, p.y, p.z);
+}
 
 double calc_scale(const DMat4& m) {  // src/main.rs:1325-1333
     return (m.c[0].length() + m.c[1].length() + m.c[2].length()) / 3.0;
@@ -416,6 +423,7 @@ extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_r
         r->cam.beta = c.beta;
         r->cam.r = c.r;
         r->offset_after_material = c.offset_after_material;
+        r->cam.prev_cam_pos = cam_pos(r->cam);  // main.rs:1058
         *out = r.release();
         return PTL_OK;
     });
@@ -456,6 +464,7 @@ extern "C" int ptl_renderer_set_camera(ptl_renderer* r, const double look_at[3],
     r->cam.alpha = alpha;
     r->cam.beta = beta;
     r->cam.r = radius;
+    r->cam.prev_cam_pos = cam_pos(r->cam);  // placing the camera is not a move: no portal crossing is looked for
     ++r->options_version;
     return PTL_OK;
 }
@@ -569,6 +578,124 @@ extern "C" int ptl_renderer_teleport_ray(ptl_renderer* r, const double a[3], con
             for (int k = 0; k < 3; ++k) out_pos[k] = (double)pos[k];
         return rc;
     });
+}
+
+namespace {
+
+// SceneRenderer::teleport_external_ray as Option<DVec3> + flags
+struct RayQuery {
+    bool teleported = false, hit_object = false, changed_subspace = false;
+    DVec3 pos;
+};
+int query_ray(ptl_renderer* r, const DVec3& a, const DVec3& b, RayQuery* q) {
+    double pa[3] = {a.x, a.y, a.z}, pb[3] = {b.x, b.y, b.z}, out[3] = {0, 0, 0};
+    int hit = 0, sub = 0, tel = 0;
+    int rc = ptl_renderer_teleport_ray(r, pa, pb, out, &hit, &sub, &tel);
+    if (rc != PTL_OK) return rc;
+    q->teleported = tel != 0;
+    q->hit_object = hit != 0;
+    q->changed_subspace = sub != 0;
+    q->pos = DVec3(out[0], out[1], out[2]);
+    return PTL_OK;
+}
+
+// SceneRenderer::teleport_matrix (src/main.rs:1174-1215): finite-difference Jacobian of the portal map
+// around the camera, three more ray queries with +-dx offsets along the camera's axes.
+int teleport_matrix(ptl_renderer* r, const DMat4& matrix, const DVec3& start_pos, const DVec3& direction_pos, const DVec3& actual, double dx,
+                    bool* ok, DMat4* out) {
+    *ok = false;
+    DVec4 cols[3];
+    const DVec4 axes[3] = {DVec4(1, 0, 0, 0), DVec4(0, 1, 0, 0), DVec4(0, 0, 1, 0)};
+    for (int k = 0; k < 3; ++k) {
+        DVec4 v4 = matrix.mul_vec4(axes[k]) * dx;
+        DVec3 v(v4.x, v4.y, v4.z);
+        RayQuery q;
+        int rc = query_ray(r, start_pos + v, direction_pos + v, &q);
+        if (rc != PTL_OK) return rc;
+        if (!q.teleported) return PTL_OK;  // `?` on None
+        DVec3 d = q.pos - actual;
+        cols[k] = DVec4(d.x / dx, d.y / dx, d.z / dx, 0.0);  // DVec4::from((i, 0.)) / dx
+    }
+    DMat4 new_mat = DMat4::from_cols(cols[0], cols[1], cols[2], DVec4(0, 0, 0, 1));
+    DVec4 moved = (new_mat * matrix.inverse()).mul_vec4(DVec4(direction_pos.x, direction_pos.y, direction_pos.z, 1.0));
+    DVec3 pos = actual - DVec3(moved.x, moved.y, moved.z);
+    *out = DMat4::from_cols(cols[0], cols[1], cols[2], DVec4(pos.x, pos.y, pos.z, 1.0));
+    *ok = true;
+    return PTL_OK;
+}
+
+// SceneRenderer::teleport_camera (src/main.rs:1217-1264)
+int teleport_camera(ptl_renderer* r, const Camera& prev_cam, int* teleported, int* blocked) {
+    Camera& cam = r->cam;
+    if (!(cam.allow_teleport || cam.stop_at_objects)) return PTL_OK;
+    DVec3 pos = cam_pos(cam);
+    RayQuery q;
+    int rc = query_ray(r, cam.prev_cam_pos, pos, &q);
+    if (rc != PTL_OK) return rc;
+    if (cam.stop_at_objects && q.hit_object) {
+        cam = prev_cam;
+        if (blocked) *blocked = 1;
+        return PTL_OK;
+    }
+    if (!q.teleported) {
+        cam.prev_cam_pos = pos;
+        return PTL_OK;
+    }
+    if (!cam.allow_teleport) return PTL_OK;
+    for (double dx : {0.001, 0.0001, 0.00001, 0.000001}) {
+        bool ok = false;
+        DMat4 m;
+        rc = teleport_matrix(r, cam.teleport_matrix, cam.prev_cam_pos, pos, q.pos, dx, &ok, &m);
+        if (rc != PTL_OK) return rc;
+        if (!ok) continue;
+        cam.teleport_matrix = m;
+        if (q.changed_subspace) cam.in_subspace = !cam.in_subspace;
+        cam.prev_cam_pos = cam_pos(cam);
+        if (teleported) *teleported = 1;
+        return PTL_OK;
+    }
+    cam = prev_cam;  // no step size produced a Jacobian: stay where we were
+    if (blocked) *blocked = 1;
+    return PTL_OK;
+}
+
+}  // namespace
+
+extern "C" int ptl_renderer_move_camera(ptl_renderer* r, const double look_at[3], double alpha, double beta, double radius, int* teleported,
+                                        int* blocked) {
+    if (!r || !look_at) return PTL_ERR_INVALID;
+    if (teleported) *teleported = 0;
+    if (blocked) *blocked = 0;
+    return guarded([&] {
+        Camera prev = r->cam;
+        r->cam.look_at = DVec3(look_at[0], look_at[1], look_at[2]);
+        r->cam.alpha = alpha;
+        r->cam.beta = beta;
+        r->cam.r = radius;
+        ++r->options_version;
+        int rc = teleport_camera(r, prev, teleported, blocked);
+        ++r->options_version;
+        return rc;
+    });
+}
+
+extern "C" int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16], int* in_subspace, double position[3]) {
+    if (!r) return PTL_ERR_INVALID;
+    if (teleport16)
+        for (int k = 0; k < 4; ++k) {
+            teleport16[4 * k + 0] = r->cam.teleport_matrix.c[k].x;
+            teleport16[4 * k + 1] = r->cam.teleport_matrix.c[k].y;
+            teleport16[4 * k + 2] = r->cam.teleport_matrix.c[k].z;
+            teleport16[4 * k + 3] = r->cam.teleport_matrix.c[k].w;
+        }
+    if (in_subspace) *in_subspace = r->cam.in_subspace ? 1 : 0;
+    if (position) {
+        DVec3 p = cam_pos(r->cam);
+        position[0] = p.x;
+        position[1] = p.y;
+        position[2] = p.z;
+    }
+    return PTL_OK;
 }
 
 extern "C" ptl_kernel* ptl_renderer_kernel(ptl_renderer* r) { return r ? r->kernel : nullptr; }

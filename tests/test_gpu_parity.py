@@ -246,3 +246,51 @@ def test_teleport_external_ray_on_gpu(gpu, scene_name):
     a = r.draw(64, 36)["rgba8"]
     b = pa.SceneRenderer(scene, device=0).draw(64, 36)["rgba8"]
     assert np.array_equal(a, b)
+
+
+def test_camera_walks_through_a_portal(gpu):
+    """SceneRenderer::teleport_camera + teleport_matrix (src/main.rs:1174-1264) on basics.ron: orbit the
+    camera so that it crosses portal A.  Known answer: afterwards the teleport matrix is the portal map
+    B*A^-1 (to finite-difference accuracy); product state == oracle restatement bit for bit; and the frame
+    rendered from the teleported camera == the oracle's frame."""
+    from oracle.portal_oracle import CameraRig, Oracle
+
+    pa = gpu
+    scene = pa.Scene.from_file(pa.scene_path("basics"))
+    vals = scene.uniform_values()
+    A = np.asarray(vals["portal_a_mat"], np.float64)
+    T = np.asarray(vals["portal_a_to_portal_b_mat_teleport"], np.float64)
+    r = pa.SceneRenderer(scene, device=0)
+    r.set_option("render_depth", 8)
+    o = Oracle(pa.scene_path("basics"))
+    o.options["render_depth"] = 8
+    rig = CameraRig(o)
+    # aim at the portal centre and walk the orbit radius through zero so the eye passes through the portal plane
+    centre = (A @ np.array([0.1, 0.1, 0.0, 1.0]))[:3]
+    normal = A[:3, 2] / np.linalg.norm(A[:3, 2])
+    # camera position = look_at + r * (sin b cos a, cos b, sin b sin a); choose look_at so that the eye sits on the normal
+    alpha, beta = 0.3, 1.2
+    orbit = np.array([np.sin(beta) * np.cos(alpha), np.cos(beta), np.sin(beta) * np.sin(alpha)])
+    steps = []
+    for side in (0.6, 0.3, 0.05, -0.2, -0.5):   # signed distance of the eye from the portal plane
+        eye = centre + normal * side
+        steps.append((tuple(eye - orbit * 1.0), alpha, beta, 1.0))
+    r.set_camera(*steps[0])
+    rig.look_at, rig.alpha, rig.beta, rig.r = list(steps[0][0]), alpha, beta, 1.0
+    rig.prev_cam_pos = rig.cam_pos()
+    crossed = 0
+    for st in steps[1:]:
+        got = r.move_camera(*st)
+        want = rig.move(*st)
+        assert got == want
+        crossed += got[0]
+        state = r.camera_state()
+        want_m = np.array(rig.teleport_matrix, np.float64).T  # columns -> m[row, col]
+        assert np.array_equal(state["teleport_matrix"], want_m)
+        assert state["in_subspace"] == rig.in_subspace
+    assert crossed == 1
+    assert state["teleport_matrix"] == pytest.approx(T, abs=5e-3)     # the Jacobian of the portal map is the portal matrix
+    out = r.draw(64, 36, rgba32f=True)
+    o.camera = rig.settings()
+    want = o.render(64, 36)
+    assert _bits_equal(out["rgba32f"], want["rgba32f"]).all()
