@@ -7,11 +7,11 @@ CXXFLAGS ?= -O2 -g -std=c++20 -fPIC -Wall -Wextra -Wno-unused-parameter
 HOST     := portal_amd/csrc/host
 DEVICE   := portal_amd/csrc/device
 OBJDIR   := build/obj
-SRCS     := ron.cpp formula.cpp scene.cpp glsl_translate.cpp codegen.cpp embedded.cpp hip_api.cpp kernel.cpp png_io.cpp capi.cpp
+SRCS     := ron.cpp formula.cpp scene.cpp glsl_translate.cpp codegen.cpp embedded.cpp hip_api.cpp kernel.cpp postprocess.cpp png_io.cpp capi.cpp
 OBJS     := $(SRCS:%.cpp=$(OBJDIR)/%.o)
 LIB      := portal_amd/libportal_amd.so
 CLI      := portal_amd/portal-amd
-KERNELS  := portal_amd/kernels/fb_store.hsaco
+KERNELS  := portal_amd/kernels/fb_store.hsaco portal_amd/kernels/average_images.hsaco
 
 all: $(LIB) $(CLI)
 
@@ -33,7 +33,7 @@ $(CLI): $(HOST)/cli.cpp $(LIB) include/portal_amd.h
 kernels: $(KERNELS)
 portal_amd/kernels/%.hsaco: portal_amd/csrc/kernels/%.hip
 	@mkdir -p portal_amd/kernels
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 --genco $< -o $@
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 --genco --no-gpu-bundle-output $< -o $@
 
 clean:
 	rm -rf build $(LIB) $(CLI) portal_amd/kernels $(HOST)/embedded_device_sources.inc

@@ -142,6 +142,26 @@ int ptl_scene_init_stage(ptl_scene* s, const char* stage, char* camera, size_t c
 int ptl_scene_stage_name(ptl_scene* s, int index, char* name, size_t cap);
 int ptl_scene_camera_name(ptl_scene* s, int index, char* name, size_t cap);
 
+/* FormulasCache::set_camera_matrix (src/gui/uniform.rs:625-697): what Matrix::Camera evaluates to (column-major
+ * binary64).  A renderer sets it to its camera's matrix before every draw (send_camera_object_matrix). */
+int ptl_scene_set_camera_matrix(ptl_scene* s, const double m16[16]);
+/* Real animations = the clips of the video pipeline (RealAnimation, src/gui/animation.rs:1014-1043).
+ * ptl_scene_animation: name and duration (seconds) of clip `index`, 1 past the end.
+ * ptl_scene_init_animation: Scene::init_animation_by_name (src/gui/scene.rs:1254-1267): the clip's base stage,
+ * then its own replacements, then its start camera becomes the scene's current camera.  1 = no such clip. */
+int ptl_scene_animation(ptl_scene* s, int index, char* name, size_t cap, double* duration);
+int ptl_scene_init_animation(ptl_scene* s, const char* animation);
+/* CalculatedCam (src/gui/camera.rs:22-32); matrix is column-major binary64 */
+typedef struct ptl_calculated_cam {
+    double look_at[3], alpha, beta, r;
+    int free_movement, in_subspace, override_matrix;
+    double matrix[16];
+} ptl_calculated_cam;
+/* Scene::update (src/gui/scene.rs:1353-1493): map wall-clock `seconds` to the formulas' `time` (fraction of the
+ * current clip) and `total_time`, and compute the clip's interpolated camera ("OverrideCam") when it has a start
+ * and an end camera (*has_cam = 1). */
+int ptl_scene_update(ptl_scene* s, double seconds, double* time, double* total_time, int* has_cam, ptl_calculated_cam* cam);
+
 /* AnyUniform::get: kind 0 = bool, 1 = int, 2 = float.  Returns 1 if the uniform cannot be evaluated. */
 int ptl_scene_eval_uniform(ptl_scene* s, const char* name, int* kind, double* value);
 /* Matrix::get as binary64, column-major.  Returns 1 if it cannot be evaluated. */
@@ -211,6 +231,11 @@ int ptl_renderer_teleport_ray(ptl_renderer* r, const double a[3], const double b
  * the camera without looking for a crossing. */
 int ptl_renderer_move_camera(ptl_renderer* r, const double look_at[3], double alpha, double beta, double radius, int* teleported,
                              int* blocked);
+/* SceneRenderer::update (src/main.rs:1430-1538), the per-frame step of `render` and `render-frame`:
+ * ptl_scene_update(seconds); Matrix::Camera := the camera's matrix; switch to / follow the scene's current
+ * camera; apply the clip's interpolated camera; if the camera matrix moved, teleport_camera (portal crossing). */
+int ptl_renderer_update(ptl_renderer* r, double seconds, int* teleported, int* blocked);
+
 /* Current teleport matrix (binary64, column-major), subspace flag and world position of the camera. */
 int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16], int* in_subspace, double position[3]);
 ptl_kernel* ptl_renderer_kernel(ptl_renderer* r);
@@ -218,6 +243,14 @@ void ptl_renderer_destroy(ptl_renderer* r);
 
 /* Place the packed rows of shard (phase, stride) into a full-frame RGBA8 image (host memory). */
 int ptl_deinterleave_rows(const uint8_t* shard_rgba8, const ptl_frame* frame, uint8_t* full_rgba8);
+
+/* average_images (src/main.rs:645-722), the motion-blur step of the video pipeline, on the GPU: N RGBA8
+ * sub-frames (DEVICE pointers, 16-byte aligned, width*height a multiple of 4) -> one RGBA8 frame:
+ * per channel mean of c*c over the sub-frames (integer division), then (u8)(sqrt(mean) + 0.5); alpha = 255.
+ * HBM-bound: reads 4*N bytes and writes 4 bytes per pixel.  1 <= n_frames <= 64.  Launched on `stream`;
+ * with elapsed_ms != NULL it is bracketed by HIP events and the call waits. */
+int ptl_average_images(int device, const void* const* frames_rgba8, int n_frames, void* out_rgba8, int width, int height, void* stream,
+                       float* elapsed_ms);
 
 /* PNG I/O (RGBA8): the reference's Texture2D::from_file_with_format / Image::export_png. */
 int ptl_png_read(const char* path, uint8_t** rgba8, int* width, int* height); /* free with ptl_free */

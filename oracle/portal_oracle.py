@@ -30,7 +30,7 @@ from . import glsl_math as M
 from . import glsl_values as V
 from .glsl_interp import Interp
 from .glsl_values import Mat, Sampler, Struct, Vec
-from .scene_eval import OracleScene, builtin_uniforms
+from .scene_eval import OracleScene, builtin_uniforms, camera_matrix
 
 F32, I32 = np.float32, np.int32
 
@@ -404,6 +404,10 @@ class Oracle:
 
     # ---- program = uniforms + natives + snippets, parsed once ---------------------------------
     def _uniform_values(self, width, height):
+        # send_camera_object_matrix (src/main.rs:147,1530-1534): Matrix::Camera evaluates to the camera that draws
+        cam = dict(self.scene.cam)
+        cam.update(self.camera or {})
+        self.scene.camera_object_matrix = camera_matrix(cam["look_at"], cam["alpha"], cam["beta"], cam["r"], cam.get("teleport_matrix"), cam.get("free_movement", False))
         vals = dict(self.scene.scene_uniform_values())
         vals.update(builtin_uniforms(self.scene, width, height, camera=self.camera, **self.options))
         vals.update(self.overrides)
@@ -891,27 +895,45 @@ class Oracle:
 
 
 class CameraRig:
-    """RotateAroundCam + SceneRenderer::teleport_camera / teleport_matrix (src/main.rs:278-304, 1174-1264),
-    restated in Python floats (binary64) on top of Oracle.teleport_external_ray."""
+    """RotateAroundCam + SceneRenderer::update / teleport_camera / teleport_matrix (src/main.rs:278-304, 1174-1264,
+    1430-1538), restated in Python floats (binary64) on top of Oracle.teleport_external_ray."""
+
+    FIELDS = ("look_at", "alpha", "beta", "r", "teleport_matrix", "in_subspace", "free_movement", "prev_cam_pos", "from_cam", "do_not_teleport")
 
     def __init__(self, oracle: Oracle):
-        from .scene_eval import IDENT, camera_matrix, m_inverse, m_mul, m_mul_vec
+        from .scene_eval import IDENT, camera_matrix, m_inverse, m_mul, m_mul_vec, _pos_vec
 
         self.o = oracle
-        self._cm, self._inv, self._mul, self._mv = camera_matrix, m_inverse, m_mul, m_mul_vec
+        self._cm, self._inv, self._mul, self._mv, self._pv = camera_matrix, m_inverse, m_mul, m_mul_vec, _pos_vec
         c = oracle.scene.cam
         self.look_at, self.alpha, self.beta, self.r = list(c["look_at"]), c["alpha"], c["beta"], c["r"]
-        self.teleport_matrix, self.in_subspace = IDENT, False
+        self.teleport_matrix, self.in_subspace, self.free_movement = IDENT, False, False
+        self.from_cam, self.do_not_teleport, self.allow_teleport = -1, False, True
         self.prev_cam_pos = self.cam_pos()
+        self.original = self._calculated()
+        self.prev = self._snapshot()
 
-    def matrix(self):
-        return self._cm(self.look_at, self.alpha, self.beta, self.r, self.teleport_matrix, False)
+    def _snapshot(self):
+        return {k: (list(getattr(self, k)) if k in ("look_at", "prev_cam_pos") else getattr(self, k)) for k in self.FIELDS}
+
+    def _restore(self, snap):
+        for k, v in snap.items():
+            setattr(self, k, list(v) if k in ("look_at", "prev_cam_pos") else v)
+
+    def _calculated(self):
+        return dict(look_at=list(self.look_at), alpha=self.alpha, beta=self.beta, r=self.r, teleport_matrix=self.teleport_matrix,
+                    in_subspace=self.in_subspace, free_movement=self.free_movement)
+
+    def matrix(self, snap=None):
+        c = snap or self.__dict__
+        return self._cm(c["look_at"], c["alpha"], c["beta"], c["r"], c["teleport_matrix"], c["free_movement"])
 
     def cam_pos(self):
         return self._mv(self.matrix(), [0.0, 0.0, 0.0, 1.0])[:3]
 
     def settings(self):
-        return dict(look_at=self.look_at, alpha=self.alpha, beta=self.beta, r=self.r, teleport_matrix=self.teleport_matrix, in_subspace=self.in_subspace)
+        return dict(look_at=self.look_at, alpha=self.alpha, beta=self.beta, r=self.r, teleport_matrix=self.teleport_matrix, in_subspace=self.in_subspace,
+                    free_movement=self.free_movement)
 
     def _query(self, a, b):
         self.o.camera = self.settings()
@@ -930,10 +952,14 @@ class CameraRig:
         moved = self._mv(self._mul(new_mat, self._inv(matrix)), [direction[0], direction[1], direction[2], 1.0])
         return cols + [[actual[k] - moved[k] for k in range(3)] + [1.0]]
 
-    def move(self, look_at, alpha, beta, r):
-        """-> (teleported, blocked)"""
-        prev = (self.look_at, self.alpha, self.beta, self.r, self.teleport_matrix, self.in_subspace, self.prev_cam_pos)
-        self.look_at, self.alpha, self.beta, self.r = list(look_at), alpha, beta, r
+    def _teleport_camera(self, prev):
+        """SceneRenderer::teleport_camera (allow_teleport on, stop_at_objects off).  -> (teleported, blocked)"""
+        if self.do_not_teleport:
+            self.do_not_teleport = False
+            self.prev_cam_pos = self.cam_pos()
+            return False, False
+        if not self.allow_teleport:
+            return False, False
         pos = self.cam_pos()
         new_pos, _hit, change_sub = self._query(self.prev_cam_pos, pos)
         if new_pos is None:
@@ -948,8 +974,50 @@ class CameraRig:
                 self.in_subspace = not self.in_subspace
             self.prev_cam_pos = self.cam_pos()
             return True, False
-        self.look_at, self.alpha, self.beta, self.r, self.teleport_matrix, self.in_subspace, self.prev_cam_pos = prev
+        self._restore(prev)
         return False, True
+
+    def move(self, look_at, alpha, beta, r):
+        """One interactive step: place the orbit, then teleport_camera against the previous state.  -> (teleported, blocked)"""
+        prev = self._snapshot()
+        self.look_at, self.alpha, self.beta, self.r = list(look_at), alpha, beta, r
+        return self._teleport_camera(prev)
+
+    def update(self, seconds):
+        """SceneRenderer::update (src/main.rs:1430-1538).  Leaves oracle.camera = the camera to draw with.  -> (teleported, blocked)"""
+        sc = self.o.scene
+        override = sc.update(seconds)
+        sc.camera_object_matrix = self.matrix()
+        cur = sc.current_cam
+        if self.from_cam != cur:
+            if cur >= 0:
+                if self.from_cam < 0:
+                    self.original = self._calculated()
+                c = sc.calculated_cam(cur)
+            else:
+                c = self.original
+            self.from_cam = cur
+            self.look_at, self.alpha, self.beta, self.r = list(c["look_at"]), c["alpha"], c["beta"], c["r"]
+            self.teleport_matrix, self.in_subspace, self.free_movement = c["teleport_matrix"], c["in_subspace"], c["free_movement"]
+            if self.free_movement:
+                pv = self._pv(self.alpha, self.beta, self.r)
+                self.look_at = [pv[k] + self.look_at[k] for k in range(3)]
+            self.do_not_teleport = True
+        elif self.from_cam >= 0 and not self.free_movement:
+            self.look_at = list(sc.calculated_cam(self.from_cam)["look_at"])
+        if override is not None:
+            self.look_at, self.alpha, self.beta, self.r = list(override["look_at"]), override["alpha"], override["beta"], override["r"]
+            self.free_movement = override["free_movement"]
+            if override["override_matrix"]:
+                self.teleport_matrix, self.in_subspace = override["teleport_matrix"], override["in_subspace"]
+                self.do_not_teleport = True
+        result = (False, False)
+        if self.matrix() != self.matrix(self.prev):
+            result = self._teleport_camera(dict(self.prev))
+        self.prev = self._snapshot()
+        sc.camera_object_matrix = self.matrix()
+        self.o.camera = self.settings()
+        return result
 
 
 def to_rgba8(rgba32f):

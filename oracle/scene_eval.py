@@ -190,6 +190,58 @@ class OracleScene:
                     self.cameras.append(dict(self._camera(inner.items[0]), name=None))
                     stage["set_cam"] = len(self.cameras) - 1
             self.stages.append(stage)
+        # real animations (RealAnimationSer, scene_serialized.rs:556-583; loaded at :1370-1473)
+        self.animations = []
+        an = doc.get("animations")
+        items = list(_newtype(an)) if an is not None else []
+        anim_index = {a["name"]: k for k, a in enumerate(items)}
+
+        def stage_ref(v):
+            if v.name == "Animation":
+                return ("stage", next((k for k, s_ in enumerate(self.stages) if s_["name"] == v.items[0]), None))
+            if v.name == "RealAnimation":
+                return ("anim", anim_index.get(v.items[0]))
+            return ("dev", None)
+
+        def cam_ref(v):
+            inner = ron.unwrap_some(v) if v is not None else None
+            if inner is None:
+                return -1
+            if inner.name == "Named":
+                return next((k for k, c in enumerate(self.cameras) if c["name"] == inner.items[0]), -1)
+            self.cameras.append(dict(self._camera(inner.items[0]), name=None))
+            return len(self.cameras) - 1
+
+        def opt(v):
+            return None if v is None else ron.unwrap_some(v)
+
+        for a in items:
+            d = a["data"]
+            entry = dict(name=a["name"], duration=float(d.get("duration", 0.0)), uniforms=[], matrices=[])
+            kind, idx = stage_ref(d["animation_stage"])
+            entry["base"] = ("dev", None) if idx is None else (kind, idx)
+            for key, is_matrix in (("uniforms", False), ("matrices", True)):
+                for name, v in (_newtype(d[key]) or {}).items():
+                    if isinstance(v, ron.Tuple) and v.name == "Changed":
+                        ref = self._mref(v.items[0]) if is_matrix else self._uref(v.items[0])
+                        if ref >= 0:
+                            entry[key].append((name, ref))
+            entry["use_prev_cam"] = bool(d.get("use_prev_cam", False))
+            entry["use_start_cam_as_end"] = bool(d.get("use_start_cam_as_end", False))
+            entry["cam_start"], entry["cam_end"] = cam_ref(d.get("cam_start")), cam_ref(d.get("cam_end"))
+            entry["any_start"], entry["any_end"] = opt(d.get("use_any_cam_as_start")), opt(d.get("use_any_cam_as_end"))
+            entry["cam_any_start"] = anim_index.get(opt(d.get("cam_any_start")), -1)
+            entry["cam_any_end"] = anim_index.get(opt(d.get("cam_any_end")), -1)
+            e = d.get("cam_easing")
+            entry["easing"] = e.name if e is not None else "Linear"
+            eu = d.get("cam_easing_uniform")
+            entry["easing_uniform"] = self._uref(eu) if eu is not None else -1
+            self.animations.append(entry)
+        self.current_stage, self.current_cam, self.prev_t_raw, self.camera_object_matrix = ("dev", None), -1, 0.0, IDENT
+        cs = doc.get("current_stage")
+        if cs is not None:
+            kind, idx = stage_ref(cs)
+            self.current_stage = ("dev", None) if idx is None else (kind, idx)
         self.uniform_alias, self.matrix_alias = {}, {}
         sky = doc.get("skybox")
         self.skybox = ron.unwrap_some(sky) if sky is not None else None
@@ -223,26 +275,147 @@ class OracleScene:
 
     def init_stage(self, name):
         """Scene::init_stage_by_name (scene.rs:1237-1250, animation.rs:171-183).  Returns the camera index the stage selects, or -1."""
-        stage = next(s for s in self.stages if s["name"] == name)
-        self.uniform_alias, self.matrix_alias = {}, {}
+        k = next(k for k, s in enumerate(self.stages) if s["name"] == name)
+        return self._init(("stage", k))
+
+    def init_animation(self, name):
+        """Scene::init_animation_by_name (scene.rs:1254-1267): base stage, then the clip's Changed(Some(..)) entries, then its start camera."""
+        k = next(k for k, a in enumerate(self.animations) if a["name"] == name)
+        self._init(("anim", k))
+
+    def _init(self, stage, depth=0):
+        kind, idx = stage
+        if kind == "stage":
+            self.current_cam = self._init_plain_stage(self.stages[idx])
+        elif kind == "dev":  # DevStageChanging::init_stage: every stored dev value comes back
+            for key, val in self.dev_uniforms.items():
+                i = self.find_uniform(key)
+                if i >= 0:
+                    self.uniforms[i][1:] = list(val)
+                    self.uniform_alias.pop(i, None)
+            for key, val in self.dev_matrices.items():
+                i = self._mat_by_name.get(key, -1)
+                if i >= 0:
+                    self.matrices[i][2] = val
+                    self.matrix_alias.pop(i, None)
+            self.current_cam = -1
+        else:
+            a = self.animations[idx]
+            if a["base"] != stage and depth < 64:
+                self._init(a["base"], depth + 1)
+            for key, ref in a["uniforms"]:
+                i = self.find_uniform(key)
+                if i >= 0:
+                    self.uniform_alias.pop(i, None)
+                    if i != ref:
+                        self.uniform_alias[i] = ref
+            for key, ref in a["matrices"]:
+                i = self._mat_by_name.get(key, -1)
+                if i >= 0:
+                    self.matrix_alias.pop(i, None)
+                    if i != ref:
+                        self.matrix_alias[i] = ref
+            cam = self.start_cam(idx)
+            if cam >= 0:
+                self.current_cam = cam
+        self.current_stage = stage
+        return self.current_cam
+
+    def start_cam(self, k, depth=0):
+        """Scene::get_start_cam (scene.rs:1303-1328)."""
+        if k is None or k < 0 or depth > 200:
+            return -1
+        a = self.animations[k]
+        if a["use_prev_cam"]:
+            return self.end_cam(k - 1, depth + 1) if k > 0 else -1
+        if a["any_start"] is not None:
+            j = a["cam_any_start"]
+            return -1 if j < 0 else (self.end_cam(j, depth + 1) if a["any_start"] else self.start_cam(j, depth + 1))
+        return a["cam_start"]
+
+    def end_cam(self, k, depth=0):
+        """Scene::get_end_cam (scene.rs:1330-1344)."""
+        if k is None or k < 0 or depth > 200:
+            return -1
+        a = self.animations[k]
+        if a["use_start_cam_as_end"]:
+            return self.start_cam(k, depth + 1)
+        if a["any_end"] is not None:
+            j = a["cam_any_end"]
+            return -1 if j < 0 else (self.end_cam(j, depth + 1) if a["any_end"] else self.start_cam(j, depth + 1))
+        return a["cam_end"]
+
+    def calculated_cam(self, idx):
+        """Cam::get (camera.rs:96-140): look_at from a coordinate or a matrix centre (+0.001)."""
+        c = self.cameras[idx]
+        if c["look_at"][0] == "matrix":
+            m = self.eval_matrix(c["look_at"][1])
+            inv_w = 1.0 / m[3][3]
+            look = [m[3][k] * inv_w + 0.001 for k in range(3)]
+        else:
+            look = list(c["look_at"][1])
+        return dict(look_at=look, alpha=c["alpha"], beta=c["beta"], r=c["r"], teleport_matrix=c["matrix"], in_subspace=c["in_subspace"], free_movement=c["free_movement"])
+
+    def update(self, seconds):
+        """Scene::update (scene.rs:1353-1493) with run_animations off and no manual-time slider: sets time / total_time,
+        returns the clip's interpolated camera (dict, incl. override_matrix) or None."""
+        t, total = float(seconds), float(seconds)
+        if self.current_stage[0] == "anim":
+            k = self.current_stage[1]
+            duration = self.animations[k]["duration"]
+            if duration > 0.0:
+                local = math.fmod(t, duration)
+                t = local / duration
+                total = sum(a["duration"] for a in self.animations[:k]) + local
+            else:
+                t, total = 0.0, 0.0
+        self.time, self.total_time = t, total
+        if self.current_stage[0] != "anim":
+            return None
+        a = self.animations[k]
+        c1, c2 = self.start_cam(k), self.end_cam(k)
+        if c1 < 0 or c2 < 0:
+            return None
+        cam1, cam2 = self.calculated_cam(c1), self.calculated_cam(c2)
+        t_raw = math.fmod(self.time, 1.0)
+        te = ease(a["easing"], t_raw)
+        if a["easing_uniform"] >= 0:
+            v = self.eval_uniform(a["easing_uniform"])
+            if v is not None:
+                v = float(v[1])  # `value.into()`: bool -> 0/1, int -> f64
+                te = min(1.0, max(0.0, v if math.isfinite(v) else 0.0))
+        out = dict(look_at=[cam1["look_at"][n] + (cam2["look_at"][n] - cam1["look_at"][n]) * te for n in range(3)],
+                   alpha=(1.0 - te) * cam1["alpha"] + te * cam2["alpha"], beta=(1.0 - te) * cam1["beta"] + te * cam2["beta"],
+                   r=(1.0 - te) * cam1["r"] + te * cam2["r"], in_subspace=cam1["in_subspace"], free_movement=cam1["free_movement"],
+                   teleport_matrix=cam1["teleport_matrix"], override_matrix=(t_raw < self.prev_t_raw or t_raw == 0.0))
+        self.prev_t_raw = t_raw
+        return out
+
+    def _init_plain_stage(self, stage):
+        """StageChanging::init_stage (animation.rs:171-183).  set_id copies the replacement's value into the element;
+        an alias is the same thing as long as replacements are immutable, which inline stage elements are."""
         for key, (kind, ref) in stage["uniforms"]:
             idx = self.find_uniform(key)
             if idx < 0:
                 continue
             if kind == "changed" and ref >= 0:
+                self.uniform_alias.pop(idx, None)
                 if ref != idx:
                     self.uniform_alias[idx] = ref
             elif kind == "dev" and key in self.dev_uniforms:
                 self.uniforms[idx][1:] = list(self.dev_uniforms[key])
+                self.uniform_alias.pop(idx, None)
         for key, (kind, ref) in stage["matrices"]:
             idx = self._mat_by_name.get(key, -1)
             if idx < 0:
                 continue
             if kind == "changed" and ref >= 0:
+                self.matrix_alias.pop(idx, None)
                 if ref != idx:
                     self.matrix_alias[idx] = ref
             elif kind == "dev" and key in self.dev_matrices:
                 self.matrices[idx][2] = self.dev_matrices[key]
+                self.matrix_alias.pop(idx, None)
         return -1 if stage["set_cam"] is None else stage["set_cam"]
 
     def camera_settings(self, idx):
@@ -421,7 +594,7 @@ class OracleScene:
             a = self.eval_matrix(node[1])
             return None if a is None else m_inverse(a)
         if t == "Camera":
-            return IDENT
+            return self.camera_object_matrix  # formulas_cache.get_camera_matrix(): what SceneRenderer::update last sent
         return None
 
     # --- what the kernel sees
@@ -479,6 +652,27 @@ class OracleScene:
 # ---------------------------------------------------------------------------------------------
 # camera + builtin uniforms (src/main.rs)
 # ---------------------------------------------------------------------------------------------
+def ease(kind, t):
+    """Easing::ease (src/gui/easing.rs:6-101)."""
+    e_in = lambda x: 1.0 - math.cos(x * math.pi * 0.5)
+    e_io = lambda x: (1.0 - math.cos(x * math.pi)) * 0.5
+    if kind == "Linear":
+        return t
+    if kind == "In":
+        return e_in(t)
+    if kind == "Out":
+        return 1.0 - e_in(1.0 - t)
+    if kind == "InOut":
+        return e_io(t)
+    if kind == "InOutFast":
+        return e_io(e_io(t))
+    if kind == "ElasticOut":
+        if t == 0.0 or t == 1.0:
+            return t
+        return 2.0 ** (-10.0 * t) * math.sin((t * 10.0 - 0.75) * (2.0 * math.pi) / 3.0) + 1.0
+    raise ValueError(kind)
+
+
 def _norm3(v):
     inv = 1.0 / math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
     return [v[0] * inv, v[1] * inv, v[2] * inv]

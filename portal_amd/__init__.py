@@ -41,6 +41,13 @@ class UniformDesc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("type", C.c_int), ("offset", C.c_size_t)]
 
 
+class CalculatedCam(C.Structure):
+    """ptl_calculated_cam (CalculatedCam, src/gui/camera.rs:22-32)."""
+
+    _fields_ = [("look_at", C.c_double * 3), ("alpha", C.c_double), ("beta", C.c_double), ("r", C.c_double), ("free_movement", C.c_int),
+                ("in_subspace", C.c_int), ("override_matrix", C.c_int), ("matrix", C.c_double * 16)]
+
+
 class Frame(C.Structure):
     """Row-block sharding of one frame (ptl_frame)."""
 
@@ -75,6 +82,11 @@ def _load() -> C.CDLL:
         "ptl_scene_init_stage": (ci, [vp, cp, cp, cs]),
         "ptl_scene_stage_name": (ci, [vp, ci, cp, cs]),
         "ptl_scene_camera_name": (ci, [vp, ci, cp, cs]),
+        "ptl_scene_set_camera_matrix": (ci, [vp, P(cd)]),
+        "ptl_scene_animation": (ci, [vp, ci, cp, cs, P(cd)]),
+        "ptl_scene_init_animation": (ci, [vp, cp]),
+        "ptl_scene_update": (ci, [vp, cd, P(cd), P(cd), P(ci), P(CalculatedCam)]),
+        "ptl_renderer_update": (ci, [vp, cd, P(ci), P(ci)]),
         "ptl_scene_eval_uniform": (ci, [vp, cp, P(ci), P(cd)]),
         "ptl_scene_eval_matrix": (ci, [vp, cp, P(cd)]),
         "ptl_scene_cam": (ci, [vp, P(cd)]),
@@ -98,6 +110,7 @@ def _load() -> C.CDLL:
         "ptl_renderer_kernel": (vp, [vp]),
         "ptl_renderer_destroy": (None, [vp]),
         "ptl_deinterleave_rows": (ci, [vp, P(Frame), vp]),
+        "ptl_average_images": (ci, [ci, P(vp), ci, vp, ci, ci, vp, P(C.c_float)]),
         "ptl_png_read": (ci, [cp, P(vp), P(ci), P(ci)]),
         "ptl_png_write": (ci, [cp, vp, ci, ci]),
         "ptl_strstore_new": (vp, []),
@@ -196,6 +209,35 @@ class Scene:
         if rc != 0:
             raise PortalError(f"Scene has no stage named `{name}`")
         return cam.value.decode("utf-8")
+
+    def set_camera_matrix(self, m) -> None:
+        """What Matrix::Camera evaluates to: 4x4, m[row][col] (a renderer sends its camera's matrix itself)."""
+        a = (C.c_double * 16)(*np.asarray(m, np.float64).reshape(4, 4).T.reshape(-1))
+        _check(lib().ptl_scene_set_camera_matrix(self._h, a), "set_camera_matrix")
+
+    def animations(self):
+        """[(name, duration seconds)] of the scene's real animations (the clips `render` turns into videos)."""
+        out, i, buf, dur = [], 0, C.create_string_buffer(256), C.c_double()
+        while lib().ptl_scene_animation(self._h, i, buf, 256, C.byref(dur)) == 0:
+            out.append((buf.value.decode("utf-8"), dur.value))
+            i += 1
+        return out
+
+    def init_animation(self, name: str) -> None:
+        """Scene::init_animation_by_name (`render-frame --animation`, `render`)."""
+        if _check(lib().ptl_scene_init_animation(self._h, name.encode("utf-8")), "init_animation") != 0:
+            raise PortalError(f"Scene has no animation named `{name}`")
+
+    def update(self, seconds: float) -> dict:
+        """Scene::update -> {"time", "total_time", "camera": None | dict(look_at, alpha, beta, r, ...)}."""
+        t, tt, has, cam = C.c_double(), C.c_double(), C.c_int(), CalculatedCam()
+        _check(lib().ptl_scene_update(self._h, float(seconds), C.byref(t), C.byref(tt), C.byref(has), C.byref(cam)), "update")
+        camera = None
+        if has.value:
+            camera = dict(look_at=list(cam.look_at), alpha=cam.alpha, beta=cam.beta, r=cam.r, free_movement=bool(cam.free_movement),
+                          in_subspace=bool(cam.in_subspace), override_matrix=bool(cam.override_matrix),
+                          matrix=np.array(cam.matrix, np.float64).reshape(4, 4).T.copy())
+        return {"time": t.value, "total_time": tt.value, "camera": camera}
 
     def _names(self, fn):
         out, i, buf = [], 0, C.create_string_buffer(256)
@@ -351,6 +393,12 @@ class SceneRenderer:
         _check(lib().ptl_renderer_move_camera(self._h, la, alpha, beta, r, C.byref(tel), C.byref(blk)), "move_camera")
         return bool(tel.value), bool(blk.value)
 
+    def update(self, seconds: float):
+        """SceneRenderer::update: the per-frame step of the video pipeline.  -> (teleported, blocked)"""
+        tel, blk = C.c_int(), C.c_int()
+        _check(lib().ptl_renderer_update(self._h, float(seconds), C.byref(tel), C.byref(blk)), "update")
+        return bool(tel.value), bool(blk.value)
+
     def camera_state(self) -> dict:
         m, sub, pos = (C.c_double * 16)(), C.c_int(), (C.c_double * 3)()
         _check(lib().ptl_renderer_camera_state(self._h, m, C.byref(sub), pos), "camera_state")
@@ -445,6 +493,15 @@ def device_source(which: str) -> str:
 
 def deinterleave_rows(shard: np.ndarray, frame: Frame, full: np.ndarray) -> None:
     _check(lib().ptl_deinterleave_rows(shard.ctypes.data, C.byref(frame), full.ctypes.data), "deinterleave_rows")
+
+
+def average_images_device(frame_ptrs, out_ptr: int, width: int, height: int, device: int = 0, stream: int = 0, timed: bool = False):
+    """average_images (src/main.rs:645-722) on DEVICE buffers given as integer addresses."""
+    arr = (C.c_void_p * len(frame_ptrs))(*frame_ptrs)
+    ms = C.c_float()
+    _check(lib().ptl_average_images(device, arr, len(frame_ptrs), C.c_void_p(out_ptr), width, height, C.c_void_p(stream or None), C.byref(ms) if timed else None),
+           "average_images")
+    return ms.value if timed else None
 
 
 def png_write(path: str, rgba8: np.ndarray) -> None:

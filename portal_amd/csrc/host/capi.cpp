@@ -39,6 +39,8 @@ struct Camera {
     bool in_subspace = false, free_movement = false;
     bool allow_teleport = true, stop_at_objects = false;  // src/main.rs:136-137
     DVec3 prev_cam_pos;
+    bool do_not_teleport_one_frame = false;  // src/main.rs:86,1218-1222
+    int from = -1;                           // RotateAroundCam::from: scene camera in use, -1 = original
 
     DVec3 pos_vec() const { return DVec3(std::sin(beta) * std::cos(alpha), std::cos(beta), std::sin(beta) * std::sin(alpha)) * r; }
     DMat4 matrix() const {  // src/main.rs:286-304
@@ -99,6 +101,10 @@ struct ptl_renderer {
     std::string asset_root;
     unsigned long long kernel_scene_version = 0;
     std::string kernel_source;
+    // SceneRenderer::update state (src/main.rs:1430-1538)
+    Camera prev_cam;
+    bool has_prev_cam = false;
+    CalculatedCam original_cam;  // egui memory "OriginalCam"
 };
 
 namespace {
@@ -231,6 +237,14 @@ extern "C" int ptl_scene_set_time(ptl_scene* s, double time, double total_time) 
     s->scene->total_time = total_time;
     return PTL_OK;
 }
+extern "C" int ptl_scene_set_camera_matrix(ptl_scene* s, const double m16[16]) {
+    if (!s || !m16) return PTL_ERR_INVALID;
+    DMat4 m = DMat4::from_cols({m16[0], m16[1], m16[2], m16[3]}, {m16[4], m16[5], m16[6], m16[7]}, {m16[8], m16[9], m16[10], m16[11]},
+                               {m16[12], m16[13], m16[14], m16[15]});
+    s->scene->camera_matrix = m;
+    ++s->scene->version;
+    return PTL_OK;
+}
 extern "C" int ptl_scene_init_stage(ptl_scene* s, const char* stage, char* camera, size_t camera_cap) {
     if (!s || !stage) return PTL_ERR_INVALID;
     return guarded([&] {
@@ -253,6 +267,46 @@ extern "C" int ptl_scene_camera_name(ptl_scene* s, int index, char* name, size_t
     if (index >= (int)s->scene->cameras.size()) return 1;
     copy_str(name, cap, s->scene->cameras[index].name.empty() ? "#" + std::to_string(index) : s->scene->cameras[index].name);
     return PTL_OK;
+}
+
+extern "C" int ptl_scene_animation(ptl_scene* s, int index, char* name, size_t cap, double* duration) {
+    if (!s || index < 0) return PTL_ERR_INVALID;
+    if (index >= (int)s->scene->animations.size()) return 1;
+    copy_str(name, cap, s->scene->animations[index].name);
+    if (duration) *duration = s->scene->animations[index].duration;
+    return PTL_OK;
+}
+extern "C" int ptl_scene_init_animation(ptl_scene* s, const char* animation) {
+    if (!s || !animation) return PTL_ERR_INVALID;
+    return guarded([&] { return s->scene->init_animation_by_name(animation) ? PTL_OK : 1; });
+}
+static void fill_cam(const CalculatedCam& c, ptl_calculated_cam* out) {
+    out->look_at[0] = c.look_at.x;
+    out->look_at[1] = c.look_at.y;
+    out->look_at[2] = c.look_at.z;
+    out->alpha = c.alpha;
+    out->beta = c.beta;
+    out->r = c.r;
+    out->in_subspace = c.in_subspace;
+    out->free_movement = c.free_movement;
+    out->override_matrix = c.override_matrix;
+    for (int k = 0; k < 4; ++k) {
+        out->matrix[4 * k + 0] = c.matrix.c[k].x;
+        out->matrix[4 * k + 1] = c.matrix.c[k].y;
+        out->matrix[4 * k + 2] = c.matrix.c[k].z;
+        out->matrix[4 * k + 3] = c.matrix.c[k].w;
+    }
+}
+extern "C" int ptl_scene_update(ptl_scene* s, double seconds, double* time, double* total_time, int* has_cam, ptl_calculated_cam* cam) {
+    if (!s) return PTL_ERR_INVALID;
+    return guarded([&] {
+        auto c = s->scene->update(seconds);
+        if (time) *time = s->scene->time;
+        if (total_time) *total_time = s->scene->total_time;
+        if (has_cam) *has_cam = c ? 1 : 0;
+        if (c && cam) fill_cam(*c, cam);
+        return PTL_OK;
+    });
 }
 
 extern "C" int ptl_scene_eval_uniform(ptl_scene* s, const char* name, int* kind, double* value) {
@@ -361,6 +415,37 @@ extern "C" int ptl_scene_source_line_owner(ptl_scene* s, int line, char* kind, s
 
 // ---- renderer ---------------------------------------------------------------------------------
 // generate + compile + load textures: the JIT step of SceneRenderer::new (main.rs:946-1010,1066-1083)
+namespace {
+
+CalculatedCam calculated_of(const Camera& c) {  // RotateAroundCam::get_calculated_cam (src/main.rs:156-167)
+    CalculatedCam out;
+    out.look_at = c.look_at;
+    out.alpha = c.alpha;
+    out.beta = c.beta;
+    out.r = c.r;
+    out.in_subspace = c.in_subspace;
+    out.free_movement = c.free_movement;
+    out.matrix = c.teleport_matrix;
+    return out;
+}
+
+bool same_matrix(const DMat4& a, const DMat4& b) {
+    for (int k = 0; k < 4; ++k)
+        if (a.c[k].x != b.c[k].x || a.c[k].y != b.c[k].y || a.c[k].z != b.c[k].z || a.c[k].w != b.c[k].w) return false;
+    return true;
+}
+
+// `send_camera_object_matrix` (src/main.rs:147,1432-1436,1530-1534): Matrix::Camera evaluates to the camera's matrix
+void send_camera_matrix(ptl_renderer* r) {
+    DMat4 m = r->cam.matrix();
+    if (!same_matrix(m, r->scene->camera_matrix)) {
+        r->scene->camera_matrix = m;
+        ++r->scene->version;
+    }
+}
+
+}  // namespace
+
 static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     ptl_scene* s = r->owner;
     refresh_generated(s, r->flags);
@@ -424,6 +509,7 @@ extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_r
         r->cam.r = c.r;
         r->offset_after_material = c.offset_after_material;
         r->cam.prev_cam_pos = cam_pos(r->cam);  // main.rs:1058
+        r->original_cam = calculated_of(r->cam);  // render_frame inserts "OriginalCam" up front (main.rs:2893-2896)
         *out = r.release();
         return PTL_OK;
     });
@@ -453,6 +539,8 @@ extern "C" int ptl_renderer_set_option(ptl_renderer* r, const char* name, double
     else if (n == "offset_after_material") r->offset_after_material = v;
     else if (n == "draw_side_by_side") r->draw_side_by_side = b;
     else if (n == "in_subspace") r->cam.in_subspace = b;
+    else if (n == "allow_teleport") r->cam.allow_teleport = b;    // RotateAroundCam toggles, src/main.rs:136-137
+    else if (n == "stop_at_objects") r->cam.stop_at_objects = b;
     else return PTL_UNKNOWN_UNIFORM;
     ++r->options_version;
     return PTL_OK;
@@ -483,6 +571,7 @@ extern "C" int ptl_renderer_use_camera(ptl_renderer* r, const char* camera) {
             r->cam.teleport_matrix = DMat4::identity();
             r->cam.in_subspace = false;
             r->cam.free_movement = false;
+            r->cam.from = r->scene->current_cam = -1;
             return PTL_OK;
         }
         int idx = name[0] == '#' ? std::atoi(name.c_str() + 1) : r->scene->find_camera(name);
@@ -490,6 +579,7 @@ extern "C" int ptl_renderer_use_camera(ptl_renderer* r, const char* camera) {
         const SceneCamera& c = r->scene->cameras[idx];
         auto look = r->scene->camera_look_at(c);
         if (!look) return 1;
+        if (r->cam.from < 0) r->original_cam = calculated_of(r->cam);
         // SceneRenderer::update (src/main.rs:1465-1477)
         r->cam.alpha = c.alpha;
         r->cam.beta = c.beta;
@@ -499,6 +589,8 @@ extern "C" int ptl_renderer_use_camera(ptl_renderer* r, const char* camera) {
         r->cam.in_subspace = c.in_subspace;
         r->cam.free_movement = c.free_movement;
         if (r->cam.free_movement) r->cam.look_at = r->cam.pos_vec() + r->cam.look_at;
+        r->cam.from = r->scene->current_cam = idx;
+        r->cam.do_not_teleport_one_frame = true;
         return PTL_OK;
     });
 }
@@ -522,6 +614,7 @@ extern "C" int ptl_renderer_uniform_value(ptl_renderer* r, int width, int height
 }
 
 static int prepare_draw(ptl_renderer* r, const ptl_frame* frame) {
+    send_camera_matrix(r);
     if ((r->flags & 5u) != 0 && r->kernel_scene_version != r->scene->version) {
         // values are baked into a specialised kernel: the scene changed, so JIT again (cached by source hash)
         int rc = build_kernel(r, nullptr, 0);
@@ -627,6 +720,11 @@ int teleport_matrix(ptl_renderer* r, const DMat4& matrix, const DVec3& start_pos
 // SceneRenderer::teleport_camera (src/main.rs:1217-1264)
 int teleport_camera(ptl_renderer* r, const Camera& prev_cam, int* teleported, int* blocked) {
     Camera& cam = r->cam;
+    if (cam.do_not_teleport_one_frame) {
+        cam.do_not_teleport_one_frame = false;
+        cam.prev_cam_pos = cam_pos(cam);
+        return PTL_OK;
+    }
     if (!(cam.allow_teleport || cam.stop_at_objects)) return PTL_OK;
     DVec3 pos = cam_pos(cam);
     RayQuery q;
@@ -674,6 +772,74 @@ extern "C" int ptl_renderer_move_camera(ptl_renderer* r, const double look_at[3]
         r->cam.r = radius;
         ++r->options_version;
         int rc = teleport_camera(r, prev, teleported, blocked);
+        ++r->options_version;
+        return rc;
+    });
+}
+
+// SceneRenderer::update (src/main.rs:1430-1538): the per-frame step of the video pipeline and of render-frame
+extern "C" int ptl_renderer_update(ptl_renderer* r, double seconds, int* teleported, int* blocked) {
+    if (!r) return PTL_ERR_INVALID;
+    if (teleported) *teleported = 0;
+    if (blocked) *blocked = 0;
+    return guarded([&] {
+        Scene& scene = *r->scene;
+        Camera& cam = r->cam;
+        if (!r->has_prev_cam) {  // SceneRenderer::new: prev_cam = cam.clone()
+            r->prev_cam = cam;
+            r->has_prev_cam = true;
+        }
+        ++r->options_version;
+        std::optional<CalculatedCam> override_cam = scene.update(seconds);
+        send_camera_matrix(r);
+
+        int current_cam = scene.current_cam;
+        if (cam.from != current_cam) {
+            CalculatedCam c;
+            if (current_cam >= 0) {
+                if (cam.from < 0) r->original_cam = calculated_of(cam);
+                auto got = scene.calculated_cam(scene.cameras.at(current_cam));
+                if (!got) throw SceneError("camera can't be evaluated");
+                c = *got;
+            } else {
+                c = r->original_cam;
+            }
+            cam.from = current_cam;
+            cam.alpha = c.alpha;
+            cam.beta = c.beta;
+            cam.r = c.r;
+            cam.look_at = c.look_at;
+            cam.teleport_matrix = c.matrix;
+            cam.in_subspace = c.in_subspace;
+            cam.free_movement = c.free_movement;
+            if (cam.free_movement) cam.look_at = cam.pos_vec() + cam.look_at;
+            cam.do_not_teleport_one_frame = true;
+        } else if (cam.from >= 0) {
+            auto got = scene.calculated_cam(scene.cameras.at(cam.from));
+            if (!got) throw SceneError("camera can't be evaluated");
+            if (!cam.free_movement) cam.look_at = got->look_at;
+        }
+
+        if (override_cam) {
+            cam.alpha = override_cam->alpha;
+            cam.beta = override_cam->beta;
+            cam.r = override_cam->r;
+            cam.look_at = override_cam->look_at;
+            cam.free_movement = override_cam->free_movement;
+            if (override_cam->override_matrix) {
+                cam.teleport_matrix = override_cam->matrix;
+                cam.in_subspace = override_cam->in_subspace;
+                cam.do_not_teleport_one_frame = true;
+            }
+        }
+
+        int rc = PTL_OK;
+        if (!same_matrix(cam.matrix(), r->prev_cam.matrix())) {
+            Camera prev = r->prev_cam;
+            rc = teleport_camera(r, prev, teleported, blocked);
+        }
+        r->prev_cam = cam;
+        send_camera_matrix(r);
         ++r->options_version;
         return rc;
     });

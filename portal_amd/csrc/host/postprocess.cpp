@@ -1,0 +1,116 @@
+// postprocess.cpp -- C ABI for the fixed (ahead-of-time compiled) gfx950 helper kernels.
+//
+// ptl_average_images: the GPU form of the reference's average_images (src/main.rs:645-722), the
+// motion-blur step of the video pipeline (src/main.rs:1787-1817).  The kernel is built by
+// `make kernels` (hipcc --genco --offload-arch=gfx950, portal_amd/csrc/kernels/average_images.hip)
+// into portal_amd/kernels/average_images.hsaco next to this library and loaded with hipModuleLoadData.
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../../include/portal_amd.h"
+#include "hip_api.h"
+#include "internal.h"
+
+using namespace ptl;
+
+namespace {
+
+constexpr int kMaxSubframes = 64;  // PTL_MAX_SUBFRAMES in average_images.hip
+
+struct LoadedKernel {
+    hip::hipModule_t module = nullptr;
+    hip::hipFunction_t fn = nullptr;
+    hip::hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+std::string library_dir() {
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&library_dir), &info) == 0 || !info.dli_fname) return ".";
+    std::string path = info.dli_fname;
+    size_t p = path.rfind('/');
+    return p == std::string::npos ? "." : path.substr(0, p);
+}
+
+// one module per (device, kernel file)
+int load_kernel(int device, const char* file, const char* entry, LoadedKernel** out) {
+    static std::mutex mu;
+    static std::map<std::string, LoadedKernel> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    std::string key = std::to_string(device) + ":" + file;
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+        *out = &it->second;
+        return PTL_OK;
+    }
+    std::string err;
+    const hip::Runtime* rt = hip::runtime(&err);
+    if (!rt) {
+        set_last_error(err);
+        return PTL_ERR_NO_DEVICE;
+    }
+    std::string path = library_dir() + "/kernels/" + file;
+    std::ifstream f(path, std::ios::binary);
+    if (!f) {
+        set_last_error("missing gfx950 code object `" + path + "`: run `make kernels` (no CPU fallback)");
+        return PTL_ERR_INVALID;
+    }
+    std::vector<char> code((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    LoadedKernel k;
+    if (rt->hipSetDevice(device) != 0 || rt->hipModuleLoadData(&k.module, code.data()) != 0 ||
+        rt->hipModuleGetFunction(&k.fn, k.module, entry) != 0) {
+        set_last_error("cannot load `" + path + "` on device " + std::to_string(device));
+        return PTL_ERR_HIP;
+    }
+    rt->hipEventCreate(&k.ev0);
+    rt->hipEventCreate(&k.ev1);
+    *out = &cache.emplace(key, k).first->second;
+    return PTL_OK;
+}
+
+}  // namespace
+
+extern "C" int ptl_average_images(int device, const void* const* frames_rgba8, int n_frames, void* out_rgba8, int width, int height,
+                                  void* stream, float* elapsed_ms) {
+    if (!frames_rgba8 || !out_rgba8 || n_frames < 1 || n_frames > kMaxSubframes || width <= 0 || height <= 0) return PTL_ERR_INVALID;
+    if (((long)width * height) % 4 != 0) {
+        set_last_error("ptl_average_images: width*height must be a multiple of 4 pixels (16-byte vectors)");
+        return PTL_ERR_INVALID;
+    }
+    for (int k = 0; k < n_frames; ++k)
+        if (!frames_rgba8[k] || (reinterpret_cast<uintptr_t>(frames_rgba8[k]) & 15u)) return PTL_ERR_INVALID;
+    if (reinterpret_cast<uintptr_t>(out_rgba8) & 15u) return PTL_ERR_INVALID;
+    LoadedKernel* k = nullptr;
+    int rc = load_kernel(device, "average_images.hsaco", "ptl_average_images_kernel", &k);
+    if (rc != PTL_OK) return rc;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    rt->hipSetDevice(device);
+    struct {
+        const void* frame[kMaxSubframes];
+    } list{};
+    for (int i = 0; i < n_frames; ++i) list.frame[i] = frames_rgba8[i];
+    long n_vec = (long)width * height / 4;
+    int n = n_frames;
+    void* args[] = {&list, &n, &out_rgba8, &n_vec};
+    long blocks = (n_vec + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
+    if (elapsed_ms) rt->hipEventRecord(k->ev0, stream);
+    int err = rt->hipModuleLaunchKernel(k->fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+    if (err != 0) {
+        set_last_error(std::string("hipModuleLaunchKernel(average_images): ") + rt->hipGetErrorString(err));
+        return PTL_ERR_HIP;
+    }
+    if (elapsed_ms) {
+        rt->hipEventRecord(k->ev1, stream);
+        rt->hipEventSynchronize(k->ev1);
+        rt->hipEventElapsedTime(elapsed_ms, k->ev0, k->ev1);
+    }
+    return PTL_OK;
+}

@@ -326,18 +326,98 @@ struct Loader {
             if (const Value* sc = d.find("set_cam")) {
                 if (const Value* outer = sc->some()) {  // Some(..)
                     stage.has_set_cam = true;
-                    if (const Value* inner = outer->some()) {  // Some(Some(CamRef))
-                        if (inner->is_named("Named")) {
-                            stage.set_cam = scene.find_camera(as_string(inner->items.at(0), "CamRef"));
-                        } else if (inner->is_named("Inline")) {
-                            scene.cameras.push_back(parse_camera(inner->items.at(0)));
-                            stage.set_cam = (int)scene.cameras.size() - 1;
-                        }
-                    }
+                    stage.set_cam = cam_ref(*outer);  // Some(Some(CamRef))
                 }
             }
             scene.stages.push_back(std::move(stage));
         }
+
+        // real animations (scene_serialized.rs:1370-1473): names first, they may refer to each other
+        const auto& anims = storage_list(doc, "animations", false).items;
+        for (const Value& a : anims) {
+            RealAnimation ra;
+            ra.name = as_string(a.at("name"), "animation name");
+            scene.animations.push_back(std::move(ra));
+        }
+        for (size_t k = 0; k < anims.size(); ++k) {
+            const Value& d = anims[k].at("data");
+            RealAnimation& ra = scene.animations[k];
+            if (const Value* v = d.find("duration")) ra.duration = as_f64(*v, "animation duration");
+            ra.base = stage_ref(d.at("animation_stage"));
+            auto changes = [&](const Value* map, bool is_matrix, std::vector<std::pair<std::string, int>>& out) {
+                if (!map) return;
+                for (auto& kv : map->unwrap_newtypes().entries) {  // RealStageChangingSer is a newtype: ({..})
+                    const Value& v = kv.second;
+                    if (v.is_named("CopyPrev")) continue;
+                    if (!v.is_named("Changed")) throw SceneError("scene: bad real-animation entry `" + v.s + "`");
+                    int ref = is_matrix ? matrix_ref(v.items.at(0)) : uniform_ref(v.items.at(0));
+                    if (ref >= 0) out.emplace_back(as_string(kv.first, "animation key"), ref);
+                }
+            };
+            changes(d.find("uniforms"), false, ra.uniforms);
+            changes(d.find("matrices"), true, ra.matrices);
+            if (const Value* v = d.find("use_prev_cam")) ra.use_prev_cam = as_bool(*v, "use_prev_cam");
+            if (const Value* v = d.find("use_start_cam_as_end")) ra.use_start_cam_as_end = as_bool(*v, "use_start_cam_as_end");
+            if (const Value* v = d.find("cam_start")) ra.cam_start = cam_ref(*v);
+            if (const Value* v = d.find("cam_end")) ra.cam_end = cam_ref(*v);
+            auto opt_bool = [&](const char* key) -> std::optional<bool> {
+                const Value* v = d.find(key);
+                const Value* inner = v ? v->some() : nullptr;
+                if (!inner) return std::nullopt;
+                return as_bool(*inner, key);
+            };
+            ra.use_any_cam_as_start = opt_bool("use_any_cam_as_start");
+            ra.use_any_cam_as_end = opt_bool("use_any_cam_as_end");
+            auto anim_ref = [&](const char* key) {
+                const Value* v = d.find(key);
+                const Value* inner = v ? v->some() : nullptr;
+                return inner ? scene.find_animation(as_string(*inner, key)) : -1;
+            };
+            ra.cam_any_start = anim_ref("cam_any_start");
+            ra.cam_any_end = anim_ref("cam_any_end");
+            if (const Value* v = d.find("cam_easing")) {
+                static const char* names[6] = {"Linear", "In", "Out", "InOut", "InOutFast", "ElasticOut"};
+                bool ok = false;
+                for (int e = 0; e < 6; ++e)
+                    if (v->is_named(names[e])) {
+                        ra.cam_easing = (Easing)e;
+                        ok = true;
+                    }
+                if (!ok) throw SceneError("scene: unknown easing `" + v->s + "`");
+            }
+            if (const Value* v = d.find("cam_easing_uniform")) {
+                int ref = uniform_ref(*v);
+                ra.has_easing_uniform = ref >= 0;
+                ra.easing_uniform = ref;
+            }
+        }
+        if (const Value* cs = doc.find("current_stage")) scene.current_stage = stage_ref(*cs);
+    }
+
+    // CurrentStageSer (scene_serialized.rs:210-229): unknown names fall back to Dev
+    StageRef stage_ref(const Value& v) {
+        StageRef r;
+        if (v.is_named("Animation")) {
+            std::string name = as_string(v.items.at(0), "stage name");
+            for (size_t k = 0; k < scene.stages.size(); ++k)
+                if (scene.stages[k].name == name && r.index < 0) r = StageRef{StageRef::Animation, (int)k};
+        } else if (v.is_named("RealAnimation")) {
+            int idx = scene.find_animation(as_string(v.items.at(0), "animation name"));
+            if (idx >= 0) r = StageRef{StageRef::RealAnimation, idx};
+        }
+        return r;
+    }
+
+    // Option<CamRef> -> camera index (inline cameras are appended)
+    int cam_ref(const Value& opt) {
+        const Value* inner = opt.some();
+        if (!inner) return -1;
+        if (inner->is_named("Named")) return scene.find_camera(as_string(inner->items.at(0), "CamRef"));
+        if (inner->is_named("Inline")) {
+            scene.cameras.push_back(parse_camera(inner->items.at(0)));
+            return (int)scene.cameras.size() - 1;
+        }
+        throw SceneError("scene: bad CamRef");
     }
 
     SceneCamera parse_camera(const Value& d) {
@@ -397,6 +477,10 @@ int Scene::find_matrix(const std::string& name) const {
 bool Scene::set_uniform_value(const std::string& name, double v) {
     int idx = find_uniform(name);
     if (idx < 0) return false;
+    if (idx < (int)uniform_alias.size() && uniform_alias[idx] >= 0) {  // Storage2::set_id copied the value: edits apply to the copy
+        uniforms[idx].value = uniforms[uniform_alias[idx]].value;
+        uniform_alias[idx] = -1;
+    }
     Uniform& u = uniforms[idx].value;
     ++version;
     switch (u.kind) {
@@ -423,38 +507,235 @@ std::optional<DVec3> Scene::camera_look_at(const SceneCamera& c) const {
 }
 
 bool Scene::init_stage_by_name(const std::string& name, int* camera) {
-    const AnimationStage* stage = nullptr;
-    for (auto& st : stages)
-        if (st.name == name) stage = &st;
-    if (!stage) return false;
-    ++version;
-    uniform_alias.assign(uniforms.size(), -1);
-    matrix_alias.assign(matrices.size(), -1);
-    // StageChanging::init_stage (animation.rs:171-183): Changed* -> set_id, FromDev / ProvidedToUser -> dev value
-    for (auto& kv : stage->uniforms) {
-        int idx = find_uniform(kv.first);
-        if (idx < 0) continue;
-        const StageChange& c = kv.second;
-        if ((c.kind == StageChange::Changed || c.kind == StageChange::ChangedAndToUser) && c.ref >= 0) {
-            if (c.ref != idx) uniform_alias[idx] = c.ref;
-        } else if (c.kind == StageChange::FromDev || c.kind == StageChange::ProvidedToUser) {
-            for (auto& dv : dev_uniforms)
-                if (dv.first == kv.first) uniforms[idx].value = dv.second;
-        }
-    }
-    for (auto& kv : stage->matrices) {
-        int idx = find_matrix(kv.first);
-        if (idx < 0 || !matrices[idx].named) continue;
-        const StageChange& c = kv.second;
-        if ((c.kind == StageChange::Changed || c.kind == StageChange::ChangedAndToUser) && c.ref >= 0) {
-            if (c.ref != idx) matrix_alias[idx] = c.ref;
-        } else if (c.kind == StageChange::FromDev || c.kind == StageChange::ProvidedToUser) {
-            for (auto& dv : dev_matrices)
-                if (dv.first == kv.first) matrices[idx].value = dv.second;
-        }
-    }
-    if (camera) *camera = stage->has_set_cam ? stage->set_cam : -1;
+    int found = -1;
+    for (size_t k = 0; k < stages.size(); ++k)
+        if (stages[k].name == name) found = (int)k;
+    if (found < 0) return false;
+    init_stage(StageRef{StageRef::Animation, found});
+    if (camera) *camera = current_cam;
     return true;
+}
+
+int Scene::find_animation(const std::string& name) const {
+    for (size_t k = 0; k < animations.size(); ++k)
+        if (animations[k].name == name) return (int)k;
+    return -1;
+}
+
+bool Scene::init_animation_by_name(const std::string& name) {
+    int idx = find_animation(name);
+    if (idx < 0) return false;
+    init_stage(StageRef{StageRef::RealAnimation, idx});
+    return true;
+}
+
+void Scene::init_stage(StageRef stage, int depth) {
+    ++version;
+    if (uniform_alias.size() != uniforms.size()) uniform_alias.assign(uniforms.size(), -1);
+    if (matrix_alias.size() != matrices.size()) matrix_alias.assign(matrices.size(), -1);
+    auto restore_dev_uniform = [&](const std::string& name, int idx) {
+        for (auto& dv : dev_uniforms)
+            if (dv.first == name) {
+                uniforms[idx].value = dv.second;
+                uniform_alias[idx] = -1;
+            }
+    };
+    auto restore_dev_matrix = [&](const std::string& name, int idx) {
+        for (auto& dv : dev_matrices)
+            if (dv.first == name) {
+                matrices[idx].value = dv.second;
+                matrix_alias[idx] = -1;
+            }
+    };
+    switch (stage.kind) {
+        case StageRef::Animation: {
+            const AnimationStage& st = stages.at(stage.index);
+            // StageChanging::init_stage (animation.rs:171-183): Changed* -> set_id, FromDev / ProvidedToUser -> dev value
+            for (auto& kv : st.uniforms) {
+                int idx = find_uniform(kv.first);
+                if (idx < 0) continue;
+                const StageChange& c = kv.second;
+                if ((c.kind == StageChange::Changed || c.kind == StageChange::ChangedAndToUser) && c.ref >= 0) {
+                    uniform_alias[idx] = c.ref != idx ? c.ref : -1;
+                } else if (c.kind == StageChange::FromDev || c.kind == StageChange::ProvidedToUser) {
+                    restore_dev_uniform(kv.first, idx);
+                }
+            }
+            for (auto& kv : st.matrices) {
+                int idx = find_matrix(kv.first);
+                if (idx < 0 || !matrices[idx].named) continue;
+                const StageChange& c = kv.second;
+                if ((c.kind == StageChange::Changed || c.kind == StageChange::ChangedAndToUser) && c.ref >= 0) {
+                    matrix_alias[idx] = c.ref != idx ? c.ref : -1;
+                } else if (c.kind == StageChange::FromDev || c.kind == StageChange::ProvidedToUser) {
+                    restore_dev_matrix(kv.first, idx);
+                }
+            }
+            current_cam = st.has_set_cam ? st.set_cam : -1;
+            break;
+        }
+        case StageRef::Dev: {  // DevStageChanging::init_stage (animation.rs:222-228)
+            for (auto& dv : dev_uniforms) {
+                int idx = find_uniform(dv.first);
+                if (idx >= 0) restore_dev_uniform(dv.first, idx);
+            }
+            for (auto& dv : dev_matrices) {
+                int idx = find_matrix(dv.first);
+                if (idx >= 0 && matrices[idx].named) restore_dev_matrix(dv.first, idx);
+            }
+            current_cam = -1;
+            break;
+        }
+        case StageRef::RealAnimation: {  // scene.rs:1208-1231
+            const RealAnimation& a = animations.at(stage.index);
+            if (!(a.base == stage) && depth < 64) init_stage(a.base, depth + 1);  // else: "Initialization recursion!"
+            // RealAnimationStageChanging::init_stage (animation.rs:985-991): only Changed(Some(..)) entries act
+            for (auto& kv : a.uniforms) {
+                int idx = find_uniform(kv.first);
+                if (idx >= 0) uniform_alias[idx] = kv.second != idx ? kv.second : -1;
+            }
+            for (auto& kv : a.matrices) {
+                int idx = find_matrix(kv.first);
+                if (idx >= 0 && matrices[idx].named) matrix_alias[idx] = kv.second != idx ? kv.second : -1;
+            }
+            int cam = animation_start_cam(stage.index);
+            if (cam >= 0) current_cam = cam;
+            break;
+        }
+    }
+    current_stage = stage;
+}
+
+int Scene::animation_start_cam(int id, int depth) const {
+    if (id < 0 || id >= (int)animations.size() || depth > 256) return -1;
+    const RealAnimation& a = animations[id];
+    if (a.use_prev_cam) return id > 0 ? animation_end_cam(id - 1, depth + 1) : -1;
+    if (a.use_any_cam_as_start) {
+        if (a.cam_any_start < 0) return -1;
+        return *a.use_any_cam_as_start ? animation_end_cam(a.cam_any_start, depth + 1) : animation_start_cam(a.cam_any_start, depth + 1);
+    }
+    return a.cam_start;
+}
+
+int Scene::animation_end_cam(int id, int depth) const {
+    if (id < 0 || id >= (int)animations.size() || depth > 256) return -1;
+    const RealAnimation& a = animations[id];
+    if (a.use_start_cam_as_end) return animation_start_cam(id, depth + 1);
+    if (a.use_any_cam_as_end) {
+        if (a.cam_any_end < 0) return -1;
+        return *a.use_any_cam_as_end ? animation_end_cam(a.cam_any_end, depth + 1) : animation_start_cam(a.cam_any_end, depth + 1);
+    }
+    return a.cam_end;
+}
+
+double Scene::total_animation_duration() const {
+    double total = 0.0;
+    for (auto& a : animations) total += a.duration;
+    return total;
+}
+
+std::optional<CalculatedCam> Scene::calculated_cam(const SceneCamera& c) const {
+    auto look = camera_look_at(c);
+    if (!look) return std::nullopt;
+    CalculatedCam out;
+    out.look_at = *look;
+    out.alpha = c.alpha;
+    out.beta = c.beta;
+    out.r = c.r;
+    out.in_subspace = c.in_subspace;
+    out.free_movement = c.free_movement;
+    out.matrix = c.teleport;
+    out.override_matrix = true;
+    return out;
+}
+
+double ease(Easing e, double t) {
+    constexpr double kPi = 3.14159265358979323846264338327950288;
+    auto in = [&](double x) { return 1.0 - std::cos(x * kPi * 0.5); };
+    auto in_out = [&](double x) { return (1.0 - std::cos(x * kPi)) * 0.5; };
+    switch (e) {
+        case Easing::Linear: return t;
+        case Easing::In: return in(t);
+        case Easing::Out: return 1.0 - in(1.0 - t);
+        case Easing::InOut: return in_out(t);
+        case Easing::InOutFast: return in_out(in_out(t));
+        case Easing::ElasticOut: {
+            double c4 = (2.0 * kPi) / 3.0;
+            if (t == 0.0) return 0.0;
+            if (t == 1.0) return 1.0;
+            return std::pow(2.0, -10.0 * t) * std::sin((t * 10.0 - 0.75) * c4) + 1.0;
+        }
+    }
+    return t;
+}
+
+std::optional<CalculatedCam> Scene::update(double seconds) {
+    double t = seconds, total = 0.0;
+    if (run_animations) {  // scene.rs:1359-1386
+        double total_duration = total_animation_duration();
+        if (total_duration > 0.0) {
+            t = std::fmod(t, total_duration);
+            total = t;
+        } else {
+            t = 0.0;
+        }
+        for (size_t id = 0; id < animations.size(); ++id) {
+            double duration = animations[id].duration;
+            if (t < duration) {
+                StageRef want{StageRef::RealAnimation, (int)id};
+                if (!(current_stage == want)) init_stage(want);
+                t /= duration;
+                break;
+            }
+            t -= duration;
+        }
+    } else if (current_stage.kind == StageRef::RealAnimation) {  // scene.rs:1387-1426 (no manual-time slider offline)
+        double duration = animations[current_stage.index].duration;
+        if (duration > 0.0) {
+            double local_seconds = std::fmod(t, duration);
+            t = local_seconds / duration;
+            double prefix = 0.0;
+            for (int k = 0; k < current_stage.index; ++k) prefix += animations[k].duration;
+            total = prefix + local_seconds;
+        } else {
+            t = 0.0;
+        }
+    } else {
+        total = t;
+    }
+    if (t != time || total != total_time) ++version;
+    time = t;
+    total_time = total;
+
+    if (current_stage.kind != StageRef::RealAnimation) return std::nullopt;
+    int id = current_stage.index;
+    const RealAnimation& a = animations[id];
+    int c1 = animation_start_cam(id), c2 = animation_end_cam(id);
+    if (c1 < 0 || c2 < 0) return std::nullopt;
+    auto cam1 = calculated_cam(cameras.at(c1));
+    auto cam2 = calculated_cam(cameras.at(c2));
+    if (!cam1 || !cam2) throw SceneError("scene: animation camera can't be evaluated");  // .unwrap() in the reference
+    double t_raw = std::fmod(time, 1.0);
+    double te = ease(a.cam_easing, t_raw);
+    if (a.has_easing_uniform) {  // scene.rs:1453-1469
+        if (auto v = eval_uniform(a.easing_uniform)) {
+            double x = v->as_f64();
+            if (!std::isfinite(x)) x = 0.0;
+            te = x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x);
+        }
+    }
+    CalculatedCam cam;
+    cam.look_at = cam1->look_at + (cam2->look_at - cam1->look_at) * te;  // glam 0.13 DVec3::lerp
+    auto lerp = [&](double lo, double hi) { return (1.0 - te) * lo + te * hi; };  // emath 0.31 lerp
+    cam.alpha = lerp(cam1->alpha, cam2->alpha);
+    cam.beta = lerp(cam1->beta, cam2->beta);
+    cam.r = lerp(cam1->r, cam2->r);
+    cam.in_subspace = cam1->in_subspace;
+    cam.free_movement = cam1->free_movement;
+    cam.matrix = cam1->matrix;
+    cam.override_matrix = t_raw < prev_t_raw || t_raw == 0.0;
+    prev_t_raw = t_raw;
+    return cam;
 }
 
 std::optional<double> Scene::eval_formula(const std::string& text) const {

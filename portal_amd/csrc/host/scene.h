@@ -116,6 +116,41 @@ struct AnimationStage {
     int set_cam = -1;          // camera index, -1 = original camera
 };
 
+// Easing (src/gui/easing.rs:6-101)
+enum class Easing { Linear, In, Out, InOut, InOutFast, ElasticOut };
+double ease(Easing e, double t);
+
+// CurrentStage (src/gui/scene.rs:60-66); `index` into stages / animations
+struct StageRef {
+    enum Kind { Dev, Animation, RealAnimation } kind = Dev;
+    int index = -1;
+    bool operator==(const StageRef& o) const { return kind == o.kind && (kind == Dev || index == o.index); }
+};
+
+// RealAnimation (src/gui/animation.rs:1014-1043): one clip of the video pipeline
+struct RealAnimation {
+    std::string name;
+    double duration = 0.0;
+    StageRef base;                                                 // animation_stage
+    std::vector<std::pair<std::string, int>> uniforms, matrices;  // the Changed(Some(ref)) entries; CopyPrev / Changed(None) leave the base stage's value
+    bool use_prev_cam = false, use_start_cam_as_end = false;
+    int cam_start = -1, cam_end = -1;  // camera indices
+    std::optional<bool> use_any_cam_as_start, use_any_cam_as_end;
+    int cam_any_start = -1, cam_any_end = -1;  // animation indices
+    Easing cam_easing = Easing::Linear;
+    bool has_easing_uniform = false;  // cam_easing_uniform: Some(Some(id))
+    int easing_uniform = -1;
+};
+
+// CalculatedCam (src/gui/camera.rs:22-32)
+struct CalculatedCam {
+    DVec3 look_at;
+    double alpha = 0.0, beta = 0.0, r = 3.5;
+    bool free_movement = false, in_subspace = false;
+    DMat4 matrix = DMat4::identity();
+    bool override_matrix = true;
+};
+
 // Scene `cam` block (src/gui/scene.rs:33-52)
 struct CamSettings {
     DVec3 look_at;
@@ -140,6 +175,11 @@ public:
     bool use_time = false;
     std::vector<SceneCamera> cameras;
     std::vector<AnimationStage> stages;
+    std::vector<RealAnimation> animations;
+    StageRef current_stage;
+    int current_cam = -1;        // egui memory "CurrentCam": camera the current stage selects, -1 = original camera
+    bool run_animations = false; // src/gui/scene.rs:115
+    double prev_t_raw = 0.0;
     std::vector<std::pair<std::string, Uniform>> dev_uniforms;  // dev_stage: the values FromDev restores
     std::vector<std::pair<std::string, Matrix>> dev_matrices;
     // set_id aliases installed by a stage: element i evaluates as element alias[i] (-1: itself)
@@ -166,6 +206,20 @@ public:
     // Returns false if there is no such stage; *camera = index into `cameras` the stage selects, or -1.
     bool init_stage_by_name(const std::string& name, int* camera);
     int find_camera(const std::string& name) const;
+    // Scene::init_stage (src/gui/scene.rs:1180-1236), all three kinds; sets current_stage and current_cam
+    void init_stage(StageRef stage, int depth = 0);
+    // Scene::init_animation_by_name / _by_position (src/gui/scene.rs:1254-1277)
+    bool init_animation_by_name(const std::string& name);
+    int find_animation(const std::string& name) const;
+    // Scene::get_start_cam / get_end_cam (src/gui/scene.rs:1303-1344): camera index or -1
+    int animation_start_cam(int animation, int depth = 0) const;
+    int animation_end_cam(int animation, int depth = 0) const;
+    double total_animation_duration() const;
+    // Scene::update (src/gui/scene.rs:1353-1493): maps wall-clock seconds to the formulas' `time` /
+    // `total_time`, and returns the interpolated "OverrideCam" of a real animation (if it has both cameras)
+    std::optional<CalculatedCam> update(double seconds);
+    // Cam::get (src/gui/camera.rs:125-140)
+    std::optional<CalculatedCam> calculated_cam(const SceneCamera& c) const;
     // Cam::get_pos (src/gui/camera.rs:96-108)
     std::optional<DVec3> camera_look_at(const SceneCamera& c) const;
 

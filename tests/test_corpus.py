@@ -46,6 +46,10 @@ def test_corpus_scene_product_equals_oracle(pa, path):
     # uniform values: the product's (scene + builtins) go into the host kernel; the oracle computes its own
     from oracle.scene_eval import builtin_uniforms
 
+    from oracle.scene_eval import camera_matrix
+
+    c = o.scene.cam  # Matrix::Camera evaluates to the drawing camera's matrix (the renderer sends it; here the test does)
+    scene.set_camera_matrix(np.array(camera_matrix(c["look_at"], c["alpha"], c["beta"], c["r"])).T)
     vals = scene.uniform_values()
     for name, typ, _ in layout:
         if name in vals:
@@ -88,3 +92,39 @@ def test_corpus_sample_compiles_for_gfx950(pa, name):
     scene = pa.Scene.from_file(os.path.join(CORPUS, name + ".ron"))
     r = pa.SceneRenderer(scene, device=-1, asset_root="/root/reference")
     assert r.code_object()[:4] == b"\x7fELF"
+
+
+def animated_scene_files():
+    out = []
+    for f in scene_files():
+        with open(f, encoding="utf-8") as fh:
+            if "animation_stage:" in fh.read():
+                out.append(f)
+    return out
+
+
+@pytest.mark.parametrize("path", animated_scene_files(), ids=[os.path.basename(f)[:-4] for f in animated_scene_files()])
+def test_corpus_real_animations_product_equals_oracle(pa, path):
+    """Every clip of every scene that has real animations (28 scenes, ~480 clips): the per-frame host step of the video
+    pipeline gives the oracle's formula time, uniform values and camera at two times per clip.  Host logic only (no kernel
+    build: a renderer is not needed to evaluate a scene), camera compared through Scene::update's interpolated camera."""
+    from oracle.scene_eval import OracleScene
+
+    ps, osc = pa.Scene.from_file(path), OracleScene(path)
+    clips = ps.animations()
+    assert [c[0] for c in clips] == [a["name"] for a in osc.animations]
+    import tests.test_host_logic as hl
+
+    for clip, duration in clips:
+        ps.init_animation(clip)
+        osc.init_animation(clip)
+        for frac in (0.0, 0.625):
+            t = frac * duration
+            got, want = ps.update(t), osc.update(t)
+            assert (got["time"], got["total_time"]) == (osc.time, osc.total_time), (clip, t)
+            assert (got["camera"] is None) == (want is None), (clip, t)
+            if want is not None:
+                for k in ("look_at", "alpha", "beta", "r", "free_movement", "in_subspace", "override_matrix"):
+                    assert got["camera"][k] == want[k], (clip, t, k)
+                assert np.array_equal(got["camera"]["matrix"], np.array(want["teleport_matrix"]).T), (clip, t)
+            hl._same_uniforms(ps.uniform_values(), osc.scene_uniform_values(), (clip, t))

@@ -294,3 +294,40 @@ def test_camera_walks_through_a_portal(gpu):
     o.camera = rig.settings()
     want = o.render(64, 36)
     assert _bits_equal(out["rgba32f"], want["rgba32f"]).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 7, 16])
+def test_average_images_kernel_matches_oracle(gpu, n):
+    """Motion-blur averaging (src/main.rs:645-722): byte-exact against the CPU restatement, ragged N."""
+    import torch
+    from oracle import postprocess as pp
+
+    pa = gpu
+    h, w = 135, 244  # h*w divisible by 4, rows not a multiple of the vector width
+    rng = np.random.default_rng(n)
+    frames = [rng.integers(0, 256, (h, w, 4), dtype=np.uint8) for _ in range(n)]
+    frames[0][:4] = 255
+    frames[-1][-4:] = 0
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    pa.average_images_device([d.data_ptr() for d in dev], out.data_ptr(), w, h, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = pp.average_images(frames) if n > 1 else np.concatenate([frames[0][..., :3], np.full((h, w, 1), 255, np.uint8)], axis=2)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_average_images_full_size_properties(gpu):
+    """4K, 4 sub-frames: averaging identical frames is the identity on RGB; permuting the inputs changes nothing."""
+    import torch
+
+    pa = gpu
+    w, h = 3840, 2160
+    g = torch.Generator(device="cuda").manual_seed(5)
+    frames = [torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device="cuda", generator=g) for _ in range(4)]
+    out1, out2 = torch.empty_like(frames[0]), torch.empty_like(frames[0])
+    st = torch.cuda.current_stream().cuda_stream
+    pa.average_images_device([f.data_ptr() for f in frames], out1.data_ptr(), w, h, stream=st)
+    pa.average_images_device([f.data_ptr() for f in reversed(frames)], out2.data_ptr(), w, h, stream=st)
+    assert torch.equal(out1, out2) and bool((out1[..., 3] == 255).all())
+    pa.average_images_device([frames[0].data_ptr()] * 4, out1.data_ptr(), w, h, stream=st)
+    assert torch.equal(out1[..., :3], frames[0][..., :3])

@@ -402,3 +402,85 @@ def test_named_camera_known_answer(pa):
         r.use_camera("nope")
     r.use_camera("")  # back to the scene's own cam block
     assert np.array_equal(r.uniform_value("_camera", 100, 100), pa.SceneRenderer(s, device=-1).uniform_value("_camera", 100, 100))
+
+
+def test_average_images_oracle_known_answers():
+    """(9) src/main.rs:645-662: L_TO_S[S_TO_L[c]] == c for every byte; mean in linear light, not in bytes."""
+    from oracle import postprocess as pp
+
+    assert np.array_equal(pp.L_TO_S[pp.S_TO_L.astype(np.int64)], np.arange(256, dtype=np.uint8))
+    a = np.zeros((2, 2, 4), np.uint8)
+    b = np.full((2, 2, 4), 255, np.uint8)
+    out = pp.average_images([a, b])
+    assert out[0, 0].tolist() == [180, 180, 180, 255]          # sqrt(65025 // 2) = 180.3 -> 180 (a byte mean would give 127)
+    assert np.array_equal(pp.average_images([b]), b)
+    c = np.array([[[10, 20, 30, 7]]], np.uint8)
+    assert pp.average_images([c, c, c])[0, 0].tolist() == [10, 20, 30, 255]
+
+
+def _same_uniforms(got, want, where):
+    for k, w in want.items():
+        if "oracle_inline" in k:  # unnamed matrices: the two sides number them differently
+            continue
+        g = got[k]
+        g = np.asarray(g, np.float32).T.reshape(16) if np.asarray(g).shape == (4, 4) else np.asarray(g).reshape(-1)
+        wb = np.asarray(w).reshape(-1)
+        same = (g.view(np.uint32) == wb.view(np.uint32)) if wb.dtype.kind == "f" else (g == wb)
+        assert np.all(same | (np.isnan(g.astype(np.float64)) & np.isnan(wb.astype(np.float64)))), (where, k)
+
+
+@pytest.mark.parametrize("name", ["portal_in_portal", "triple_portal", "basics"])
+def test_every_real_animation_frame_state_agrees_with_the_oracle(pa, name):
+    """The video pipeline's per-frame step (Scene::init_animation_by_name + SceneRenderer::update, src/gui/scene.rs:1208-1231,
+    1353-1493, src/main.rs:1430-1538): for every clip of the scene, at the motion-blur sub-frame times render_animation uses
+    (src/main.rs:1787-1800), the product and the oracle agree on time / total_time, on every scene uniform and on the camera."""
+    from oracle.portal_oracle import CameraRig, Oracle
+    from oracle.scene_eval import builtin_uniforms
+
+    path = pa.scene_path(name)
+    ps, o = pa.Scene.from_file(path), Oracle(path)
+    clips = ps.animations()
+    assert clips and [c[0] for c in clips] == [a["name"] for a in o.scene.animations]
+    r = pa.SceneRenderer(ps, device=-1)
+    r.set_option("allow_teleport", 0)  # crossing a portal needs the GPU ray query: covered by the -m gpu test
+    rig = CameraRig(o)
+    rig.allow_teleport = False
+    for clip, duration in clips:
+        ps.init_animation(clip)
+        o.scene.init_animation(clip)
+        count, blur, exposure = 3, 2, 0.5
+        for i in range(count):
+            for j in range(blur):
+                t = (i / count + j / blur / count * exposure) * duration
+                r.update(t)
+                rig.update(t)
+                assert (ps.eval_uniform("no such uniform") is None)
+                assert r.camera_state()["in_subspace"] == rig.in_subspace
+                _same_uniforms(ps.uniform_values(), o.scene.scene_uniform_values(), (clip, t))
+                b = builtin_uniforms(o.scene, 320, 180, camera=rig.settings())
+                for k in ("_camera", "_camera_mul_inv", "_camera_scale", "_camera_in_subspace"):
+                    g = r.uniform_value(k, 320, 180)
+                    g = np.asarray(g).T.reshape(16) if np.asarray(g).shape == (4, 4) else np.asarray(g).reshape(-1)
+                    assert np.array_equal(g.astype(np.float32), np.asarray(b[k], np.float32).reshape(-1)), (clip, t, k)
+    with pytest.raises(pa.PortalError):
+        ps.init_animation("no such clip")
+
+
+def test_real_animation_known_answers(pa):
+    """portal_in_portal `intro.2`: 1 s, base stage "How 2", progress := easing_in_out(time), camera = end camera of intro.1
+    (use_prev_cam + use_start_cam_as_end); `total_time` continues after intro.1's 3 s (src/gui/scene.rs:1412-1420)."""
+    s = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    assert s.animations()[:2] == [("intro.1", 3.0), ("intro.2", 1.0)]
+    s.init_animation("intro.2")
+    u = s.update(0.25)
+    assert (u["time"], u["total_time"]) == (0.25, 3.25)
+    assert s.eval_uniform("progress") == pytest.approx((1 - math.cos(0.25 * math.pi)) / 2, abs=1e-15)
+    assert u["camera"]["alpha"] == 0.4130013084411631 and u["camera"]["beta"] == 1.1425471496582034 and not u["camera"]["override_matrix"]
+    assert s.update(1.0)["camera"]["override_matrix"]      # wrapped around: t_raw < prev_t_raw
+    s.init_animation("intro.1")
+    u = s.update(1.5)                                         # half way, InOut easing = 0.5
+    assert u["time"] == 0.5 and u["camera"]["alpha"] == pytest.approx((-0.8084996795654297 + 0.4130013084411631) / 2, abs=1e-12)
+    for kind, t, want in (("Linear", 0.3, 0.3), ("In", 1.0, 1.0), ("Out", 0.0, 0.0), ("InOut", 0.5, 0.5), ("InOutFast", 0.5, 0.5), ("ElasticOut", 1.0, 1.0)):
+        from oracle.scene_eval import ease
+
+        assert ease(kind, t) == pytest.approx(want, abs=1e-15)
