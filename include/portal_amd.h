@@ -247,10 +247,18 @@ int ptl_deinterleave_rows(const uint8_t* shard_rgba8, const ptl_frame* frame, ui
 /* average_images (src/main.rs:645-722), the motion-blur step of the video pipeline, on the GPU: N RGBA8
  * sub-frames (DEVICE pointers, 16-byte aligned, width*height a multiple of 4) -> one RGBA8 frame:
  * per channel mean of c*c over the sub-frames (integer division), then (u8)(sqrt(mean) + 0.5); alpha = 255.
- * HBM-bound: reads 4*N bytes and writes 4 bytes per pixel.  1 <= n_frames <= 64.  Launched on `stream`;
+ * HBM-bound: reads 4*N bytes and writes 4 bytes per pixel.  1 <= n_frames <= 64.  (For one image the reference
+ * hands it back untouched; callers skip the call then -- the kernel would still force alpha to 255.)  Launched on `stream`;
  * with elapsed_ms != NULL it is bracketed by HIP events and the call waits. */
 int ptl_average_images(int device, const void* const* frames_rgba8, int n_frames, void* out_rgba8, int width, int height, void* stream,
                        float* elapsed_ms);
+
+/* Device frame buffers for callers that keep frames on the GPU between kernels (sub-frames -> ptl_average_images ->
+ * one download); the reference's counterpart is the macroquad render target + Texture2D::get_texture_data()
+ * (src/main.rs:1041-1042,1803-1816).  ptl_device_download waits for `stream` first (it is a stream-ordered copy). */
+int ptl_device_alloc(int device, size_t bytes, void** out);
+int ptl_device_free(void* p);
+int ptl_device_download(void* host_dst, const void* device_src, size_t bytes, void* stream);
 
 /* PNG I/O (RGBA8): the reference's Texture2D::from_file_with_format / Image::export_png. */
 int ptl_png_read(const char* path, uint8_t** rgba8, int* width, int* height); /* free with ptl_free */

@@ -22,6 +22,30 @@ LIB_PATH = os.path.join(_HERE, "libportal_amd.so")
 # default code-object cache (gfx950 binaries keyed by source hash); travels with the repo
 os.environ.setdefault("PTL_CACHE_DIR", os.path.join(_HERE, "_cache"))
 
+
+
+def _share_torch_hip_runtime() -> None:
+    """One HIP runtime per process: PyTorch ships its own libamdhip64 and loads it on `import torch`.  If this library
+    bound /opt/rocm's copy first and torch came later, the process would hold two runtimes whose streams and device
+    pointers do not mix.  So when torch is installed but not imported yet, point the C side at torch's copy by path
+    (importing torch itself would cost seconds for callers that never need it)."""
+    if "PTL_HIP_LIB" in os.environ:
+        return
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for root in (spec.submodule_search_locations if spec and spec.submodule_search_locations else []):
+        cand = os.path.join(root, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            os.environ["PTL_HIP_LIB"] = cand  # hiprtc stays /opt/rocm's: a compiler, not shared state
+            return
+
+
+_share_torch_hip_runtime()
+
 PTL_MAT4, PTL_F32, PTL_I32, PTL_VEC2, PTL_VEC3, PTL_SAMPLER = range(6)
 FLAG_SPECIALIZE_INTS = 1
 FLAG_COUNT_SEGMENTS = 2
@@ -111,6 +135,9 @@ def _load() -> C.CDLL:
         "ptl_renderer_destroy": (None, [vp]),
         "ptl_deinterleave_rows": (ci, [vp, P(Frame), vp]),
         "ptl_average_images": (ci, [ci, P(vp), ci, vp, ci, ci, vp, P(C.c_float)]),
+        "ptl_device_alloc": (ci, [ci, cs, P(vp)]),
+        "ptl_device_free": (ci, [vp]),
+        "ptl_device_download": (ci, [vp, vp, cs, vp]),
         "ptl_png_read": (ci, [cp, P(vp), P(ci), P(ci)]),
         "ptl_png_write": (ci, [cp, vp, ci, ci]),
         "ptl_strstore_new": (vp, []),

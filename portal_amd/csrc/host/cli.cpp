@@ -1,22 +1,373 @@
-// cli.cpp -- `portal-amd render-frame`, the offline counterpart of the reference CLI
-// (`portal render-frame <scene> --width --height --aa-count --render-depth --output`,
-// src/main.rs:2726-2755,2876-2946), writing a PNG instead of drawing to a window.
+// cli.cpp -- `portal-amd render-frame` and `portal-amd render`, the offline counterparts of the reference CLI
+// (`portal render-frame <scene> ...` src/main.rs:2726-2755,2876-2946 and `portal render <scenes> [animations] ...`
+// src/main.rs:2757-2874 + render_animation src/main.rs:1758-1873), writing PNG files instead of drawing to a
+// window.  Everything goes through the C ABI (include/portal_amd.h); this file holds no rendering logic.
+//
+// Video pipeline (render): for every frame i of a clip, `motion_blur_frames` sub-frames are traced straight into
+// device buffers (aa_start = j, time = i/count + j/blur/count*exposure), averaged on the GPU (ptl_average_images),
+// downloaded once, and PNG-encoded on a pool of host threads while the GPU already traces the next frame.
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/portal_amd.h"
 
-static void usage() {
+namespace {
+
+void usage() {
     std::fprintf(stderr,
-                 "usage: portal-amd render-frame <scene.ron> [--width W] [--height H] [--aa-count N] [--render-depth D]\n"
-                 "                  [--stage NAME] [--camera NAME] [--time T] [--output out.png] [--device I] [--asset-root DIR] [--panini D --fov DEG]\n"
-                 "       portal-amd emit-source <scene.ron>       print the generated HIP kernel source\n"
+                 "usage: portal-amd render-frame <scene.ron> [--stage NAME | --animation NAME] [--camera NAME] [--time T] [--output out.png]\n"
+                 "                  [--width W] [--height H] [--aa-count N] [--render-depth D] [--device I] [--asset-root DIR] [--panini D --fov DEG]\n"
+                 "       portal-amd render <scene[,scene..]> [clip[,clip..]] [--width 3840] [--height 2160] [--fps 60] [--motion-blur-frames 1]\n"
+                 "                  [--stereoimage] [--no-skip-existing] [--filter-starts-with P] [--aa-count 4] [--render-depth 150]\n"
+                 "                  [--scenes-dir DIR] [--out-dir DIR] [--device I] [--shard K/N] [--max-frames N] [--asset-root DIR]\n"
+                 "       portal-amd emit-source <scene.ron> [--stage NAME]     print the generated HIP kernel source\n"
                  "       portal-amd version\n");
 }
+
+std::vector<std::string> split_list(const std::string& s) {  // "a, b,,c" -> {a, b, c}
+    std::vector<std::string> out;
+    size_t pos = 0;
+    while (pos <= s.size()) {
+        size_t comma = s.find(',', pos);
+        if (comma == std::string::npos) comma = s.size();
+        std::string item = s.substr(pos, comma - pos);
+        size_t b = item.find_first_not_of(" \t"), e = item.find_last_not_of(" \t");
+        if (b != std::string::npos) out.push_back(item.substr(b, e - b + 1));
+        pos = comma + 1;
+    }
+    return out;
+}
+
+bool exists(const std::string& path) {
+    struct stat st;
+    return ::stat(path.c_str(), &st) == 0;
+}
+
+void make_dirs(const std::string& path) {  // mkdir -p
+    for (size_t p = 1; p <= path.size(); ++p)
+        if (p == path.size() || path[p] == '/') ::mkdir(path.substr(0, p).c_str(), 0777);
+}
+
+std::string dir_of(const std::string& path) {
+    size_t p = path.rfind('/');
+    return p == std::string::npos ? "" : path.substr(0, p);
+}
+
+// The reference compiles its scene list in (src/gui/scenes.rs); here a scene is a path, or a bare name under --scenes-dir.
+std::string scene_file(const std::string& arg, const std::string& scenes_dir) {
+    if (exists(arg)) return arg;
+    return scenes_dir + "/" + arg + ".ron";
+}
+
+std::string scene_link(const std::string& path) {  // "dir/name.ron" -> "name"
+    size_t slash = path.rfind('/');
+    std::string base = slash == std::string::npos ? path : path.substr(slash + 1);
+    return base.size() > 4 && base.substr(base.size() - 4) == ".ron" ? base.substr(0, base.size() - 4) : base;
+}
+
+// Host threads that PNG-encode finished frames while the GPU traces the next ones.
+class EncoderPool {
+public:
+    explicit EncoderPool(int threads, size_t max_pending) : max_pending_(max_pending) {
+        for (int k = 0; k < threads; ++k) workers_.emplace_back([this] { run(); });
+    }
+    ~EncoderPool() { finish(); }
+    void submit(std::function<void()> job) {
+        std::unique_lock<std::mutex> lock(mu_);
+        space_.wait(lock, [&] { return jobs_.size() < max_pending_; });
+        jobs_.push_back(std::move(job));
+        work_.notify_one();
+    }
+    void finish() {
+        {
+            std::unique_lock<std::mutex> lock(mu_);
+            done_ = true;
+        }
+        work_.notify_all();
+        for (auto& t : workers_)
+            if (t.joinable()) t.join();
+    }
+
+private:
+    void run() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                work_.wait(lock, [&] { return done_ || !jobs_.empty(); });
+                if (jobs_.empty()) return;
+                job = std::move(jobs_.front());
+                jobs_.pop_front();
+                space_.notify_one();
+            }
+            job();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable work_, space_;
+    std::deque<std::function<void()>> jobs_;
+    std::vector<std::thread> workers_;
+    size_t max_pending_;
+    bool done_ = false;
+};
+
+struct Options {
+    std::string scene, clips, output = "frame.png", asset_root = ".", stage, animation, camera, scenes_dir = "scenes", out_dir = ".", starts_with;
+    bool have_camera = false, stereo = false, skip_existing = true, aa_given = false, depth_given = false, size_given = false;
+    int width = 1920, height = 1080, aa = 1, depth = 100, device = 0, fps = 60, blur = 1, shard = 0, shards = 1, max_frames = -1;
+    double time = 0.0, panini = -1.0, fov = 90.0;
+};
+
+// SceneRenderer::update_inner_variables (src/main.rs:1688-1756): per-clip settings the reference hard-codes for its
+// published videos.  Data, not logic: clip name -> what changes.
+struct ClipOverride {
+    const char* clip;
+    int subspace_degree;  // 0 = leave
+    int render_depth;     // 0 = leave
+    int fps;              // 0 = leave
+};
+const ClipOverride kClipOverrides[] = {
+    {"v2.face.2", 500, 0, 0},     {"v2.face.3", 500, 0, 0},     {"v2.face.4", 500, 0, 0},      {"v2.face.5", 500, 0, 0},
+    {"v2.inside.1", 500, 0, 0},   {"v2.inside.3", 500, 0, 0},   {"v2.intro.1", 500, 0, 0},     {"v2.normal.2", 500, 0, 0},
+    {"v2.normal.3", 500, 0, 0},   {"v2.rod.2", 500, 0, 0},      {"v2.rod.3", 500, 0, 0},       {"v2.spiral.3", 500, 0, 0},
+    {"v2.spiral.4", 1000, 0, 0},  {"v2.spiral.5", 1000, 0, 0},  {"v2.spiral.6", 1000, 0, 0},   {"v2.spiral.7", 500, 0, 0},
+    {"v2.spiral.9", 500, 0, 0},   {"v2.spaaaace.0", 500, 0, 0}, {"v4.golden.0", 500, 0, 0},    {"v4.golden.1", 500, 0, 0},
+    {"v4.golden.2", 500, 0, 0},   {"v4.thumbnail.2", 500, 0, 0}, {"v2.rotated.0", 0, 100, 0},  {"v2.spiral.0", 0, 100, 0},
+    {"v2.screenshot.5", 0, 100, 0}, {"v2.screenshot.6", 0, 100, 0}, {"v2.screenshot.3", 0, 0, 600},
+};
+
+void apply_clip_overrides(ptl_scene* scene, ptl_renderer* r, const std::string& clip, int* fps) {
+    for (const ClipOverride& o : kClipOverrides) {
+        if (clip != o.clip) continue;
+        if (o.subspace_degree) ptl_scene_set_uniform(scene, "subspace_degree", o.subspace_degree);  // no such uniform: nothing happens
+        if (o.render_depth) ptl_renderer_set_option(r, "render_depth", o.render_depth);
+        if (o.fps && fps) *fps = o.fps;
+    }
+}
+
+int fail(const char* what) {
+    std::fprintf(stderr, "%s: %s\n", what, ptl_last_error());
+    return 1;
+}
+
+int render_frame(const Options& o) {
+    ptl_scene* scene = nullptr;
+    if (ptl_scene_load_file(o.scene.c_str(), &scene) != PTL_OK) {
+        std::fprintf(stderr, "Failed to parse scene `%s`: %s\n", o.scene.c_str(), ptl_last_error());
+        return 1;
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<char> log(1 << 16);
+    ptl_renderer* r = nullptr;
+    if (ptl_renderer_create(scene, o.device, o.asset_root.c_str(), 0, &r, log.data(), log.size()) != PTL_OK) {
+        std::fprintf(stderr, "renderer: %s\n%s\n", ptl_last_error(), log.data());
+        return 1;
+    }
+    ptl_renderer_set_option(r, "aa_count", o.aa);
+    ptl_renderer_set_option(r, "render_depth", o.depth);
+    char stage_cam[256] = "";
+    if (!o.stage.empty() && ptl_scene_init_stage(scene, o.stage.c_str(), stage_cam, sizeof stage_cam) != PTL_OK) {  // src/main.rs:2900-2904
+        std::fprintf(stderr, "Scene `%s` has no stage named `%s`\n", o.scene.c_str(), o.stage.c_str());
+        return 1;
+    }
+    if (!o.animation.empty()) {  // src/main.rs:2905-2917
+        if (ptl_scene_init_animation(scene, o.animation.c_str()) != PTL_OK) {
+            std::fprintf(stderr, "Scene `%s` has no animation named `%s`\n", o.scene.c_str(), o.animation.c_str());
+            return 1;
+        }
+        apply_clip_overrides(scene, r, o.animation, nullptr);
+    }
+    if (o.have_camera && ptl_renderer_use_camera(r, o.camera.c_str()) != PTL_OK) {  // --camera wins (src/main.rs:2918-2926)
+        std::fprintf(stderr, "Scene `%s` has no camera named `%s`\n", o.scene.c_str(), o.camera.c_str());
+        return 1;
+    }
+    if (o.panini >= 0.0) {
+        ptl_renderer_set_option(r, "use_panini_projection", 1);
+        ptl_renderer_set_option(r, "panini_param", o.panini);
+    }
+    ptl_renderer_set_option(r, "view_angle", o.fov / 180.0 * 3.14159265358979323846);
+    if (ptl_renderer_update(r, o.time, nullptr, nullptr) != PTL_OK) return fail("update");  // src/main.rs:2928
+    ptl_frame frame{o.width, o.height, 0, 1};
+    std::vector<uint8_t> img((size_t)o.width * o.height * 4);
+    float ms = 0.0f;
+    if (ptl_renderer_draw_to_host(r, &frame, img.data(), nullptr, nullptr, &ms) != PTL_OK) return fail("render");
+    if (!dir_of(o.output).empty()) make_dirs(dir_of(o.output));
+    if (ptl_png_write(o.output.c_str(), img.data(), o.width, o.height) != PTL_OK) return fail("png");
+    double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("Rendered `%s` to `%s` (%dx%d, aa %d, depth %d): kernel %.3f ms, %.1f Mray/s; total %.2f s\n", o.scene.c_str(), o.output.c_str(),
+                o.width, o.height, o.aa, o.depth, ms, (double)o.width * o.height * o.aa / (ms * 1e3), total);
+    ptl_renderer_destroy(r);
+    ptl_scene_free(scene);
+    return 0;
+}
+
+// render_animation (src/main.rs:1758-1873)
+int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::string& scene_name, const std::string& clip, double duration, int fps,
+                int width, int height, std::vector<void*>& subframes, void* averaged, EncoderPool& pool) {
+    auto started = std::chrono::steady_clock::now();
+    std::string video_base = o.out_dir + "/video/" + scene_name + "/" + clip;
+    if (o.skip_existing && exists(video_base + ".mov")) {
+        std::printf("Skip `%s/%s`, because it's already exists\n", scene_name.c_str(), clip.c_str());
+        return 0;
+    }
+    make_dirs(dir_of(video_base));
+    std::string anim_dir = o.out_dir + "/anim";
+    make_dirs(anim_dir);
+    int count = std::max(1, (int)((float)duration * (float)fps));  // ((duration_seconds * fps as f32) as usize).max(1)
+    const double exposure = 0.5;
+    size_t frame_bytes = (size_t)width * height * 4;
+    double gpu_ms = 0.0;
+    long traced = 0;
+    ptl_frame frame{width, height, 0, 1};
+    int last = o.max_frames >= 0 ? std::min(count, o.max_frames) : count;
+    for (int i = 0; i < last; ++i) {
+        if (i % o.shards != o.shard) continue;  // frames are independent: shard K of N takes every N-th
+        std::string name = anim_dir + "/frame_" + std::to_string(i) + ".png";
+        if (exists(name)) continue;
+        for (int j = 0; j < o.blur; ++j) {
+            double t = ((double)i / count) + (double)j / o.blur / count * exposure;
+            ptl_renderer_set_option(r, "aa_start", j);
+            if (ptl_renderer_update(r, t * (double)(float)duration, nullptr, nullptr) != PTL_OK) return fail("update");
+            float ms = 0.0f;
+            if (ptl_renderer_draw(r, &frame, subframes[j], nullptr, nullptr, nullptr, &ms) != PTL_OK) return fail("render");
+            gpu_ms += ms;
+            ++traced;
+            bool first = i == 0 && j == 0, final_one = i == count - 1 && j == o.blur - 1;
+            if (first || final_one) {
+                std::vector<uint8_t> still(frame_bytes);
+                if (ptl_device_download(still.data(), subframes[j], frame_bytes, nullptr) != PTL_OK) return fail("download");
+                if (first && ptl_png_write((video_base + ".start.png").c_str(), still.data(), width, height) != PTL_OK) return fail("png");
+                if (final_one && ptl_png_write((video_base + ".end.png").c_str(), still.data(), width, height) != PTL_OK) return fail("png");
+            }
+        }
+        const void* result = subframes[0];  // one image: average_images hands it back untouched
+        if (o.blur > 1) {
+            float ms = 0.0f;
+            if (ptl_average_images(o.device, subframes.data(), o.blur, averaged, width, height, nullptr, &ms) != PTL_OK) return fail("average_images");
+            gpu_ms += ms;
+            result = averaged;
+        }
+        auto pixels = std::make_shared<std::vector<uint8_t>>(frame_bytes);
+        if (ptl_device_download(pixels->data(), result, frame_bytes, nullptr) != PTL_OK) return fail("download");
+        pool.submit([pixels, name, width, height] {
+            if (ptl_png_write(name.c_str(), pixels->data(), width, height) != PTL_OK) std::fprintf(stderr, "\n%s\n", ptl_last_error());
+        });
+        std::printf("\r%d/%d done      ", i, count);
+        std::fflush(stdout);
+    }
+    std::printf("\n");
+    double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
+    std::printf("Traced `%s/%s`: %ld sub-frames %dx%d, GPU %.1f ms (%.3f ms each), wall %.2f s\n", scene_name.c_str(), clip.c_str(), traced, width, height,
+                gpu_ms, traced ? gpu_ms / traced : 0.0, wall);
+    (void)scene;
+    return 0;
+}
+
+// the reference's ffmpeg hand-off (src/main.rs:1829-1869), same arguments; frames are kept when there is no ffmpeg
+int encode_video(const Options& o, const std::string& scene_name, const std::string& clip, int fps) {
+    if (std::system("command -v ffmpeg >/dev/null 2>&1") != 0) {
+        std::printf("ffmpeg not found: frames stay in `%s/anim` (ffmpeg -framerate %d -i anim/frame_%%d.png ... video/%s/%s.mov)\n", o.out_dir.c_str(), fps,
+                    scene_name.c_str(), clip.c_str());
+        return 0;
+    }
+    std::printf("Start ffmpeg to render video\n");
+    std::string cmd = "cd '" + o.out_dir + "' && ffmpeg -framerate " + std::to_string(fps) +
+                      " -i anim/frame_%d.png -vf zscale=primariesin=bt709:transferin=iec61966-2-1:matrixin=bt709:rangein=full:primaries=bt709:"
+                      "transfer=iec61966-2-1:matrix=bt709:range=full,format=yuv420p10le -c:v libx265 -pix_fmt yuv420p10le -crf 15 -preset slow "
+                      "-x265-params colorprim=bt709:transfer=iec61966-2-1:colormatrix=bt709:range=full -colorspace bt709 -color_primaries bt709 "
+                      "-color_trc iec61966-2-1 -color_range pc -movflags +write_colr+faststart -tag:v hvc1 -y 'video/" +
+                      scene_name + "/" + clip + ".mov' >/dev/null 2>&1";
+    int status = std::system(cmd.c_str());
+    std::printf("ffmpeg status: %d\n", status);
+    if (status == 0 && std::system(("rm -rf '" + o.out_dir + "/anim'").c_str()) != 0) std::fprintf(stderr, "could not remove anim/\n");
+    return 0;
+}
+
+int render(const Options& o) {
+    int width = o.stereo ? o.width * 2 : o.width;  // src/main.rs:2822-2829
+    auto total_start = std::chrono::steady_clock::now();
+    for (const std::string& scene_arg : split_list(o.scene)) {
+        std::string path = scene_file(scene_arg, o.scenes_dir), scene_name = scene_link(path);
+        std::printf("Rendering scene %s\n", scene_name.c_str());
+        ptl_scene* scene = nullptr;
+        if (ptl_scene_load_file(path.c_str(), &scene) != PTL_OK) {
+            std::fprintf(stderr, "Failed to parse scene `%s`: %s\n", scene_name.c_str(), ptl_last_error());
+            return 1;
+        }
+        std::vector<char> log(1 << 16);
+        ptl_renderer* r = nullptr;
+        if (ptl_renderer_create(scene, o.device, o.asset_root.c_str(), 0, &r, log.data(), log.size()) != PTL_OK) {
+            std::fprintf(stderr, "renderer: %s\n%s\n", ptl_last_error(), log.data());
+            return 1;
+        }
+        ptl_renderer_set_option(r, "aa_count", o.aa);
+        ptl_renderer_set_option(r, "render_depth", o.depth);
+        ptl_renderer_set_option(r, "draw_side_by_side", o.stereo ? 1 : 0);
+        std::vector<void*> subframes(std::max(1, o.blur), nullptr);
+        void* averaged = nullptr;
+        size_t bytes = (size_t)width * o.height * 4;
+        for (void*& p : subframes)
+            if (ptl_device_alloc(o.device, bytes, &p) != PTL_OK) return fail("alloc");
+        if (ptl_device_alloc(o.device, bytes, &averaged) != PTL_OK) return fail("alloc");
+
+        // which clips: the named ones (render_named_animations) or all, optionally filtered (render_all_animations)
+        std::vector<std::pair<std::string, double>> clips;
+        char name[256];
+        double duration = 0.0;
+        for (int k = 0; ptl_scene_animation(scene, k, name, sizeof name, &duration) == PTL_OK; ++k) clips.emplace_back(name, duration);
+        std::vector<std::pair<std::string, double>> todo;
+        if (!o.clips.empty()) {
+            for (const std::string& want : split_list(o.clips)) {
+                auto it = std::find_if(clips.begin(), clips.end(), [&](auto& c) { return c.first == want; });
+                if (it == clips.end()) {
+                    std::fprintf(stderr, "Scene `%s` has no animation named `%s`\n", scene_name.c_str(), want.c_str());
+                    return 1;
+                }
+                todo.push_back(*it);
+            }
+        } else {
+            for (auto& c : clips)
+                if (o.starts_with.empty() || c.first.compare(0, o.starts_with.size(), o.starts_with) == 0) todo.push_back(c);
+        }
+        int threads = (int)std::min(32u, std::max(2u, std::thread::hardware_concurrency() / 2));
+        for (size_t k = 0; k < todo.size(); ++k) {
+            const std::string& clip = todo[k].first;
+            if (ptl_scene_init_animation(scene, clip.c_str()) != PTL_OK) return fail("init_animation");
+            if (ptl_renderer_update(r, 0.0, nullptr, nullptr) != PTL_OK) return fail("update");
+            int fps = o.fps;
+            ptl_renderer_set_option(r, "render_depth", o.depth);
+            apply_clip_overrides(scene, r, clip, &fps);
+            std::printf("Rendering animation %s, %zu/%zu\n", clip.c_str(), k + 1, todo.size());
+            {
+                EncoderPool pool(threads, (size_t)threads * 2);
+                int rc = render_clip(o, scene, r, scene_name, clip, todo[k].second, fps, width, o.height, subframes, averaged, pool);
+                if (rc != 0) return rc;
+            }  // joins the encoders: every frame file is on disk
+            if (o.shards == 1 && o.max_frames < 0) encode_video(o, scene_name, clip, fps);
+        }
+        for (void* p : subframes) ptl_device_free(p);
+        ptl_device_free(averaged);
+        ptl_renderer_destroy(r);
+        ptl_scene_free(scene);
+    }
+    std::printf("Total render time: %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - total_start).count());
+    return 0;
+}
+
+}  // namespace
 
 int main(int argc, char** argv) {
     if (argc < 2) {
@@ -28,17 +379,21 @@ int main(int argc, char** argv) {
         std::printf("%s\ndevices: %d\n", ptl_version(), ptl_device_count());
         return 0;
     }
-    if (argc < 3) {
+    if (argc < 3 || (cmd != "render-frame" && cmd != "render" && cmd != "emit-source")) {
         usage();
         return 2;
     }
-    std::string scene_path = argv[2];
-    int width = 1920, height = 1080, aa = 1, depth = 100, device = 0;  // CLI defaults: src/main.rs:2744-2754
-    double time = 0.0, panini = -1.0, fov = 90.0;
-    std::string output = "frame.png", asset_root = ".", stage, camera;
-    bool have_camera = false;
+    Options o;
+    o.scene = argv[2];
+    if (cmd == "render") {  // CLI defaults of RenderCliOptions (src/main.rs:2757-2805)
+        o.width = 3840;
+        o.height = 2160;
+        o.aa = 4;
+        o.depth = 150;
+    }
     for (int i = 3; i < argc; ++i) {
         std::string a = argv[i];
+        std::replace(a.begin(), a.end(), '_', '-');  // the reference accepts --aa_count etc. as aliases
         auto next = [&]() -> const char* {
             if (i + 1 >= argc) {
                 usage();
@@ -46,86 +401,63 @@ int main(int argc, char** argv) {
             }
             return argv[++i];
         };
-        if (a == "--width") width = std::atoi(next());
-        else if (a == "--height") height = std::atoi(next());
-        else if (a == "--aa-count") aa = std::atoi(next());
-        else if (a == "--render-depth") depth = std::atoi(next());
-        else if (a == "--time") time = std::atof(next());
-        else if (a == "--output") output = next();
-        else if (a == "--device") device = std::atoi(next());
-        else if (a == "--asset-root") asset_root = next();
-        else if (a == "--stage") stage = next();
-        else if (a == "--camera") { camera = next(); have_camera = true; }
-        else if (a == "--panini") panini = std::atof(next());
-        else if (a == "--fov") fov = std::atof(next());
+        if (a == "--width") o.width = std::atoi(next());
+        else if (a == "--height") o.height = std::atoi(next());
+        else if (a == "--aa-count") o.aa = std::atoi(next());
+        else if (a == "--render-depth") o.depth = std::atoi(next());
+        else if (a == "--time") o.time = std::atof(next());
+        else if (a == "--output") o.output = next();
+        else if (a == "--device") o.device = std::atoi(next());
+        else if (a == "--asset-root") o.asset_root = next();
+        else if (a == "--stage") o.stage = next();
+        else if (a == "--animation") o.animation = next();
+        else if (a == "--camera") { o.camera = next(); o.have_camera = true; }
+        else if (a == "--panini") o.panini = std::atof(next());
+        else if (a == "--fov") o.fov = std::atof(next());
+        else if (a == "--fps") o.fps = std::atoi(next());
+        else if (a == "--motion-blur-frames") o.blur = std::atoi(next());
+        else if (a == "--stereoimage" || a == "--stereo-image") o.stereo = true;
+        else if (a == "--no-skip-existing") o.skip_existing = false;
+        else if (a == "--filter-starts-with" || a == "--starts-with") o.starts_with = next();
+        else if (a == "--scenes-dir") o.scenes_dir = next();
+        else if (a == "--out-dir") o.out_dir = next();
+        else if (a == "--max-frames") o.max_frames = std::atoi(next());
+        else if (a == "--shard") {
+            if (std::sscanf(next(), "%d/%d", &o.shard, &o.shards) != 2 || o.shards < 1 || o.shard < 0 || o.shard >= o.shards) {
+                std::fprintf(stderr, "--shard K/N with 0 <= K < N\n");
+                return 2;
+            }
+        } else if (cmd == "render" && a.rfind("--", 0) != 0 && o.clips.empty()) o.clips = argv[i];
         else {
-            std::fprintf(stderr, "unknown option %s\n", a.c_str());
+            std::fprintf(stderr, "unknown option %s\n", argv[i]);
             return 2;
         }
     }
-    ptl_scene* scene = nullptr;
-    if (ptl_scene_load_file(scene_path.c_str(), &scene) != PTL_OK) {
-        std::fprintf(stderr, "Failed to parse scene `%s`: %s\n", scene_path.c_str(), ptl_last_error());
-        return 1;
-    }
-    ptl_scene_set_time(scene, time, time);
-    char stage_cam[256] = "";
-    if (!stage.empty() && ptl_scene_init_stage(scene, stage.c_str(), stage_cam, sizeof stage_cam) != PTL_OK) {  // src/main.rs:2900-2904
-        std::fprintf(stderr, "Scene `%s` has no stage named `%s`\n", scene_path.c_str(), stage.c_str());
-        return 1;
-    }
-    if (cmd == "emit-source") {
-        char* src = nullptr;
-        if (ptl_scene_generate_source(scene, 0, &src) != PTL_OK) {
-            std::fprintf(stderr, "%s\n", ptl_last_error());
-            return 1;
-        }
-        std::fputs(src, stdout);
-        ptl_free(src);
-        return 0;
-    }
-    if (cmd != "render-frame") {
-        usage();
+    if (!o.stage.empty() && !o.animation.empty()) {
+        std::fprintf(stderr, "--stage and --animation exclude each other\n");
         return 2;
     }
-    auto t0 = std::chrono::steady_clock::now();
-    std::vector<char> log(1 << 16);
-    ptl_renderer* r = nullptr;
-    int rc = ptl_renderer_create(scene, device, asset_root.c_str(), 0, &r, log.data(), log.size());
-    if (rc != PTL_OK) {
-        std::fprintf(stderr, "renderer: %s\n%s\n", ptl_last_error(), log.data());
+    if (o.blur < 1 || o.blur > 64) {
+        std::fprintf(stderr, "--motion-blur-frames must be 1..64\n");
+        return 2;
+    }
+    if (cmd == "render") return render(o);
+    if (cmd == "render-frame") return render_frame(o);
+    // emit-source
+    ptl_scene* scene = nullptr;
+    if (ptl_scene_load_file(o.scene.c_str(), &scene) != PTL_OK) {
+        std::fprintf(stderr, "Failed to parse scene `%s`: %s\n", o.scene.c_str(), ptl_last_error());
         return 1;
     }
-    if (have_camera || stage_cam[0]) {  // --camera wins over the stage's camera (src/main.rs:2918-2926)
-        const char* which = have_camera ? camera.c_str() : stage_cam;
-        if (ptl_renderer_use_camera(r, which) != PTL_OK) {
-            std::fprintf(stderr, "Scene `%s` has no camera named `%s`\n", scene_path.c_str(), which);
-            return 1;
-        }
-    }
-    ptl_renderer_set_option(r, "aa_count", aa);
-    ptl_renderer_set_option(r, "render_depth", depth);
-    if (panini >= 0.0) {
-        ptl_renderer_set_option(r, "use_panini_projection", 1);
-        ptl_renderer_set_option(r, "panini_param", panini);
-    }
-    ptl_renderer_set_option(r, "view_angle", fov / 180.0 * 3.14159265358979323846);
-    ptl_frame frame{width, height, 0, 1};
-    std::vector<uint8_t> img((size_t)width * height * 4);
-    float ms = 0.0f;
-    rc = ptl_renderer_draw_to_host(r, &frame, img.data(), nullptr, nullptr, &ms);
-    if (rc != PTL_OK) {
-        std::fprintf(stderr, "render: %s\n", ptl_last_error());
+    char stage_cam[256] = "";
+    if (!o.stage.empty() && ptl_scene_init_stage(scene, o.stage.c_str(), stage_cam, sizeof stage_cam) != PTL_OK) {
+        std::fprintf(stderr, "Scene `%s` has no stage named `%s`\n", o.scene.c_str(), o.stage.c_str());
         return 1;
     }
-    if (ptl_png_write(output.c_str(), img.data(), width, height) != PTL_OK) {
-        std::fprintf(stderr, "%s\n", ptl_last_error());
-        return 1;
-    }
-    double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::printf("Rendered `%s` to `%s` (%dx%d, aa %d, depth %d): kernel %.3f ms, %.1f Mray/s; total %.2f s\n", scene_path.c_str(),
-                output.c_str(), width, height, aa, depth, ms, (double)width * height * aa / (ms * 1e3), total);
-    ptl_renderer_destroy(r);
+    char* src = nullptr;
+    if (ptl_scene_generate_source(scene, 0, &src) != PTL_OK) return fail("generate");
+    std::fputs(src, stdout);
+    ptl_free(src);
     ptl_scene_free(scene);
     return 0;
 }

@@ -46,6 +46,7 @@ struct Runtime {
     hipError_t (*hipModuleLaunchKernel)(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned,
                                         hipStream_t, void**, void**);
     const char* (*hipGetErrorString)(hipError_t);
+    hipError_t (*hipGetLastError)();  // also CLEARS the thread's sticky error: call after a failure that was expected
 };
 constexpr int kFuncAttrSharedSizeBytes = 1, kFuncAttrLocalSizeBytes = 3, kFuncAttrNumRegs = 4;  // hipFunction_attribute
 constexpr int kMemcpyHostToDevice = 1;

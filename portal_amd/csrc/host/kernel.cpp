@@ -28,6 +28,7 @@ namespace {
 bool hip_ok(const hip::Runtime* rt, int err, const char* what) {
     if (err == 0) return true;
     set_last_error(std::string(what) + ": " + (rt ? rt->hipGetErrorString(err) : "?") + " (" + std::to_string(err) + ")");
+    if (rt) rt->hipGetLastError();  // reported through our own status code: do not leave it sticky in the shared runtime
     return false;
 }
 
@@ -212,7 +213,11 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
     if (!hip_ok(rt, rt->hipModuleLoadData(&k->module, k->code.data()), "hipModuleLoadData")) return PTL_ERR_HIP;
     if (!hip_ok(rt, rt->hipModuleGetFunction(&k->fn, k->module, "ptl_render_kernel"), "hipModuleGetFunction(ptl_render_kernel)"))
         return PTL_ERR_HIP;
-    if (rt->hipModuleGetFunction(&k->teleport_fn, k->module, "ptl_teleport_kernel") != 0) k->teleport_fn = nullptr;
+    if (rt->hipModuleGetFunction(&k->teleport_fn, k->module, "ptl_teleport_kernel") != 0) {
+        k->teleport_fn = nullptr;   // hand-written layer-1 kernels need not have the second entry point
+        rt->hipGetLastError();      // ... and the expected hipErrorNotFound must not stay behind as the thread's sticky
+                                    // error: the next HIP user in the process (PyTorch) would report it as its own
+    }
     if (!hip_ok(rt, rt->hipModuleGetGlobal(&k->dev_block, &k->dev_block_size, k->module, "_ZN4glsl5ptl_uE"), "hipModuleGetGlobal(ptl_u)"))
         return PTL_ERR_HIP;
     if (k->dev_block_size < uniform_block_size) {

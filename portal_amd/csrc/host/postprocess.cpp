@@ -114,3 +114,42 @@ extern "C" int ptl_average_images(int device, const void* const* frames_rgba8, i
     }
     return PTL_OK;
 }
+
+// Device frame buffers for callers that keep frames on the GPU between kernels (the video pipeline: sub-frames ->
+// ptl_average_images -> one download).  The reference's counterpart is the macroquad render target and
+// Texture2D::get_texture_data() (src/main.rs:1041-1042,1803-1816).
+extern "C" int ptl_device_alloc(int device, size_t bytes, void** out) {
+    if (!out || bytes == 0) return PTL_ERR_INVALID;
+    std::string err;
+    const hip::Runtime* rt = hip::runtime(&err);
+    if (!rt) {
+        set_last_error(err);
+        return PTL_ERR_NO_DEVICE;
+    }
+    int e = rt->hipSetDevice(device);
+    if (e == 0) e = rt->hipMalloc(out, bytes);
+    if (e != 0) {
+        set_last_error(std::string("hipMalloc: ") + rt->hipGetErrorString(e));
+        return PTL_ERR_HIP;
+    }
+    return PTL_OK;
+}
+
+extern "C" int ptl_device_free(void* p) {
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!rt) return PTL_ERR_NO_DEVICE;
+    return rt->hipFree(p) == 0 ? PTL_OK : PTL_ERR_HIP;
+}
+
+extern "C" int ptl_device_download(void* host_dst, const void* device_src, size_t bytes, void* stream) {
+    if (!host_dst || !device_src) return PTL_ERR_INVALID;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!rt) return PTL_ERR_NO_DEVICE;
+    int e = rt->hipMemcpyAsync(host_dst, device_src, bytes, hip::kMemcpyDeviceToHost, stream);
+    if (e == 0) e = rt->hipStreamSynchronize(stream);
+    if (e != 0) {
+        set_last_error(std::string("hipMemcpy(D2H): ") + rt->hipGetErrorString(e));
+        return PTL_ERR_HIP;
+    }
+    return PTL_OK;
+}

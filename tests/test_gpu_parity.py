@@ -331,3 +331,74 @@ def test_average_images_full_size_properties(gpu):
     assert torch.equal(out1, out2) and bool((out1[..., 3] == 255).all())
     pa.average_images_device([frames[0].data_ptr()] * 4, out1.data_ptr(), w, h, stream=st)
     assert torch.equal(out1[..., :3], frames[0][..., :3])
+
+
+def test_video_pipeline_frames_match_the_oracle(gpu):
+    """render_animation's per-frame step on the GPU (src/main.rs:1787-1817): two clips of portal_in_portal, motion-blur
+    sub-frame times and aa_start = j, camera teleportation enabled (its ray queries run the kernel's second entry).
+    Camera state and every frame == the oracle's restatement of SceneRenderer::update + its own tracer, bit for bit."""
+    from oracle.portal_oracle import CameraRig, Oracle
+
+    pa = gpu
+    path = pa.scene_path("portal_in_portal")
+    scene = pa.Scene.from_file(path)
+    r = pa.SceneRenderer(scene, device=0)
+    o = Oracle(path)
+    rig = CameraRig(o)
+    w, h, depth, count, blur, exposure = 48, 27, 10, 3, 2, 0.5
+    r.set_option("render_depth", depth)
+    o.options["render_depth"] = depth
+    clips = dict(scene.animations())
+    for clip in ("intro.1", "intro.2"):
+        scene.init_animation(clip)
+        o.scene.init_animation(clip)
+        for i in range(count):
+            for j in range(blur):
+                t = (i / count + j / blur / count * exposure) * clips[clip]
+                r.set_option("aa_start", j)
+                o.options["aa_start"] = j
+                assert r.update(t) == rig.update(t)
+                state = r.camera_state()
+                assert np.array_equal(state["teleport_matrix"], np.array(rig.teleport_matrix, np.float64).T)
+                assert state["in_subspace"] == rig.in_subspace
+                if (i, j) in ((0, 0), (count - 1, blur - 1)):
+                    got = r.draw(w, h, rgba32f=True)["rgba32f"]
+                    want = o.render(w, h)["rgba32f"]
+                    assert _bits_equal(got, want).all(), (clip, i, j)
+
+
+def test_render_cli_writes_the_frames_the_library_draws(gpu, tmp_path):
+    """`portal-amd render` end to end (src/main.rs:1758-1817,2807-2874): frame files, .start/.end stills, motion blur =
+    GPU sub-frames -> ptl_average_images; every PNG decodes to what the Python side computes with the same C ABI calls
+    plus the CPU restatement of average_images."""
+    import subprocess
+
+    from oracle import postprocess as pp
+
+    pa = gpu
+    exe = os.path.join(os.path.dirname(pa.__file__), "portal-amd")
+    w, h, fps, blur = 64, 36, 2, 3
+    clip, duration = pa.Scene.from_file(pa.scene_path("basics")).animations()[0]
+    out = subprocess.run([exe, "render", pa.scene_path("basics"), clip, "--width", str(w), "--height", str(h), "--fps", str(fps), "--motion-blur-frames",
+                          str(blur), "--aa-count", "2", "--render-depth", "12", "--out-dir", str(tmp_path), "--asset-root", os.path.dirname(os.path.dirname(pa.scene_path("basics")))],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr + out.stdout
+    count = max(1, int(np.float32(duration) * np.float32(fps)))
+    scene = pa.Scene.from_file(pa.scene_path("basics"))
+    r = pa.SceneRenderer(scene, device=0)
+    r.set_option("aa_count", 2)
+    r.set_option("render_depth", 12)
+    scene.init_animation(clip)
+    r.update(0.0)
+    for i in range(count):
+        subs = []
+        for j in range(blur):
+            r.set_option("aa_start", j)
+            r.update((i / count + j / blur / count * 0.5) * float(np.float32(duration)))
+            subs.append(r.draw(w, h)["rgba8"])
+        want = pp.average_images(subs)
+        got = pa.png_read(str(tmp_path / "anim" / f"frame_{i}.png"))
+        assert np.array_equal(got, want), i
+        if i == 0:
+            assert np.array_equal(pa.png_read(str(tmp_path / "video" / "basics" / f"{clip}.start.png")), subs[0])
+    assert np.array_equal(pa.png_read(str(tmp_path / "video" / "basics" / f"{clip}.end.png")), subs[-1])
