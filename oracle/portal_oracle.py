@@ -909,6 +909,8 @@ class CameraRig:
         self.look_at, self.alpha, self.beta, self.r = list(c["look_at"]), c["alpha"], c["beta"], c["r"]
         self.teleport_matrix, self.in_subspace, self.free_movement = IDENT, False, False
         self.from_cam, self.do_not_teleport, self.allow_teleport = -1, False, True
+        self.left_eye_matrix, self.right_eye_matrix, self.left_eye_in_subspace, self.right_eye_in_subspace = IDENT, IDENT, False, False
+        self.stereo, self.eye_distance, self.swap_eyes = False, 0.07, False  # draw_side_by_side, src/main.rs:1028-1029
         self.prev_cam_pos = self.cam_pos()
         self.original = self._calculated()
         self.prev = self._snapshot()
@@ -933,7 +935,35 @@ class CameraRig:
 
     def settings(self):
         return dict(look_at=self.look_at, alpha=self.alpha, beta=self.beta, r=self.r, teleport_matrix=self.teleport_matrix, in_subspace=self.in_subspace,
-                    free_movement=self.free_movement)
+                    free_movement=self.free_movement, left_eye_matrix=self.left_eye_matrix, right_eye_matrix=self.right_eye_matrix,
+                    left_eye_in_subspace=self.left_eye_in_subspace, right_eye_in_subspace=self.right_eye_in_subspace)
+
+    def teleport_eye_matrices(self):
+        """SceneRenderer::teleport_eye_matrices (src/main.rs:1121-1172)."""
+        if not (self.stereo and self.allow_teleport):
+            return
+        dist = -self.eye_distance if self.swap_eyes else self.eye_distance
+
+        def one_eye(x):
+            start = self.cam_pos()
+            m = self.matrix()
+            direction = self._mv(m, [x, 0.0, 0.0, 1.0])[:3]
+            shift = [direction[k] - start[k] for k in range(3)]
+            result = self._mul([[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], shift + [1.0]], m)
+            sub_ = self.in_subspace
+            new_pos, _hit, change_sub = self._query(start, direction)
+            if new_pos is not None:
+                for dx in (0.001, 0.0001, 0.00001, 0.000001):
+                    tm = self._teleport_matrix(result, start, direction, new_pos, dx)
+                    if tm is not None:
+                        result = tm
+                        if change_sub:
+                            sub_ = not self.in_subspace
+                        break
+            return result, sub_
+
+        self.left_eye_matrix, self.left_eye_in_subspace = one_eye(-dist)
+        self.right_eye_matrix, self.right_eye_in_subspace = one_eye(dist)
 
     def _query(self, a, b):
         self.o.camera = self.settings()
@@ -981,7 +1011,9 @@ class CameraRig:
         """One interactive step: place the orbit, then teleport_camera against the previous state.  -> (teleported, blocked)"""
         prev = self._snapshot()
         self.look_at, self.alpha, self.beta, self.r = list(look_at), alpha, beta, r
-        return self._teleport_camera(prev)
+        out = self._teleport_camera(prev)
+        self.teleport_eye_matrices()
+        return out
 
     def update(self, seconds):
         """SceneRenderer::update (src/main.rs:1430-1538).  Leaves oracle.camera = the camera to draw with.  -> (teleported, blocked)"""
@@ -1014,6 +1046,7 @@ class CameraRig:
         result = (False, False)
         if self.matrix() != self.matrix(self.prev):
             result = self._teleport_camera(dict(self.prev))
+        self.teleport_eye_matrices()
         self.prev = self._snapshot()
         sc.camera_object_matrix = self.matrix()
         self.o.camera = self.settings()

@@ -82,6 +82,51 @@ def from_scale_rotation_translation(scale, rot_xyz, t):
     return [[c * scale[0] for c in xa], [c * scale[1] for c in ya], [c * scale[2] for c in za], [t[0], t[1], t[2], 1.0]]
 
 
+def to_scale_rotation_translation(m):
+    """glam 0.13 Mat4::to_scale_rotation_translation on columns m[c][r] -> (scale xyz, quaternion xyzw, translation xyz)."""
+    (m00, m01, m02, m03), (m10, m11, m12, m13), (m20, m21, m22, m23), (m30, m31, m32, m33) = m
+    a2323, a1323, a1223 = m22 * m33 - m23 * m32, m21 * m33 - m23 * m31, m21 * m32 - m22 * m31
+    a0323, a0223, a0123 = m20 * m33 - m23 * m30, m20 * m32 - m22 * m30, m20 * m31 - m21 * m30
+    det = (m00 * (m11 * a2323 - m12 * a1323 + m13 * a1223) - m01 * (m10 * a2323 - m12 * a0323 + m13 * a0223)
+           + m02 * (m10 * a1323 - m11 * a0323 + m13 * a0123) - m03 * (m10 * a1223 - m11 * a0223 + m12 * a0123))
+    length = lambda c: math.sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3])
+    scale = [length(m[0]) * math.copysign(1.0, det), length(m[1]), length(m[2])]
+    ax = [[m[c][r] * (1.0 / scale[c]) for r in range(3)] for c in range(3)]
+    (x0, x1, x2), (y0, y1, y2), (z0, z1, z2) = ax
+    if z2 <= 0.0:      # Mike Day's branches, as in glam's from_rotation_axes
+        dif10, omm22 = y1 - x0, 1.0 - z2
+        if dif10 <= 0.0:
+            f = omm22 - dif10
+            i = 0.5 / math.sqrt(f)
+            q = [f * i, (x1 + y0) * i, (x2 + z0) * i, (y2 - z1) * i]
+        else:
+            f = omm22 + dif10
+            i = 0.5 / math.sqrt(f)
+            q = [(x1 + y0) * i, f * i, (y2 + z1) * i, (z0 - x2) * i]
+    else:
+        sum10, opm22 = y1 + x0, 1.0 + z2
+        if sum10 <= 0.0:
+            f = opm22 - sum10
+            i = 0.5 / math.sqrt(f)
+            q = [(x2 + z0) * i, (y2 + z1) * i, f * i, (x1 - y0) * i]
+        else:
+            f = opm22 + sum10
+            i = 0.5 / math.sqrt(f)
+            q = [(y2 - z1) * i, (z0 - x2) * i, (x1 - y0) * i, f * i]
+    return scale, q, [m30, m31, m32]
+
+
+def compose_trs(scale, q, t):
+    """glam 0.13 Mat4::from_scale_rotation_translation with a quaternion xyzw."""
+    x, y, z, w = q
+    x2, y2, z2 = x + x, y + y, z + z
+    xx, xy, xz, yy, yz, zz, wx, wy, wz = x * x2, x * y2, x * z2, y * y2, y * z2, z * z2, w * x2, w * y2, w * z2
+    cx = [1.0 - (yy + zz), xy + wz, xz - wy, 0.0]
+    cy = [xy - wz, 1.0 - (xx + zz), yz + wx, 0.0]
+    cz = [xz + wy, yz - wx, 1.0 - (xx + yy), 0.0]
+    return [[c * scale[0] for c in cx], [c * scale[1] for c in cy], [c * scale[2] for c in cz], [t[0], t[1], t[2], 1.0]]
+
+
 def to_f32_colmajor(m) -> np.ndarray:
     """as_f32(): 16 float32 values, column-major."""
     with np.errstate(all="ignore"):
@@ -481,6 +526,10 @@ class OracleScene:
             return ("Inv", self._mref(v.items[0]))
         if t == "Camera":
             return ("Camera",)
+        if t == "Lerp":
+            return ("Lerp", self._param(v["t"]), self._mref(v["first"]), self._mref(v["second"]))
+        if t == "Sqrt":  # BFGS matrix square root: not a defined function, stays "can't be getted" (but its operand is still an element)
+            return ("Unsupported", t, self._mref(v.items[0]))
         return ("Unsupported", t)
 
     # --- evaluation
@@ -593,6 +642,18 @@ class OracleScene:
         if t == "Inv":
             a = self.eval_matrix(node[1])
             return None if a is None else m_inverse(a)
+        if t == "Lerp":  # src/gui/matrix.rs:614-627 on glam 0.13's to_scale_rotation_translation / Quat::lerp / Vec3::lerp
+            tt = self._p(node[1])
+            a = None if tt is None else self.eval_matrix(node[2])
+            b = None if a is None else self.eval_matrix(node[3])
+            if b is None:
+                return None
+            (fs, fr, ft), (ss, sr, st) = to_scale_rotation_translation(a), to_scale_rotation_translation(b)
+            mix3 = lambda p, q: [p[k] + (q[k] - p[k]) * tt for k in range(3)]
+            bias = 1.0 if sum(fr[k] * sr[k] for k in range(4)) >= 0.0 else -1.0
+            q = [fr[k] + (sr[k] * bias - fr[k]) * tt for k in range(4)]
+            inv = 1.0 / math.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+            return compose_trs(mix3(fs, ss), [c * inv for c in q], mix3(ft, st))
         if t == "Camera":
             return self.camera_object_matrix  # formulas_cache.get_camera_matrix(): what SceneRenderer::update last sent
         return None
@@ -704,19 +765,22 @@ def builtin_uniforms(scene: OracleScene, width, height, render_depth=100, aa_cou
         cam.update(camera)
     tele = cam.get("teleport_matrix") or IDENT
     m = camera_matrix(cam["look_at"], cam["alpha"], cam["beta"], cam["r"], tele, cam.get("free_movement", False))
-    scale = sum(math.sqrt(sum(x * x for x in m[c])) for c in range(3)) / 3.0
+    calc_scale = lambda mm: sum(math.sqrt(sum(x * x for x in mm[c])) for c in range(3)) / 3.0  # src/main.rs:1325-1333
+    scale = calc_scale(m)
     f, i = np.float32, np.int32
-    ident = to_f32_colmajor(IDENT)
+    left, right = cam.get("left_eye_matrix") or IDENT, cam.get("right_eye_matrix") or IDENT
     return {
         "_resolution": np.array([width, height], np.float32),
-        "_camera": to_f32_colmajor(m), "_camera_left_eye": ident, "_camera_right_eye": ident, "_camera_mul_inv": to_f32_colmajor(m_inverse(tele)),
-        "_camera_in_subspace": i(1 if cam.get("in_subspace") else 0), "_left_eye_in_subspace": i(0), "_right_eye_in_subspace": i(0),
+        "_camera": to_f32_colmajor(m), "_camera_left_eye": to_f32_colmajor(left), "_camera_right_eye": to_f32_colmajor(right),
+        "_camera_mul_inv": to_f32_colmajor(m_inverse(tele)),
+        "_camera_in_subspace": i(1 if cam.get("in_subspace") else 0), "_left_eye_in_subspace": i(1 if cam.get("left_eye_in_subspace") else 0),
+        "_right_eye_in_subspace": i(1 if cam.get("right_eye_in_subspace") else 0),
         "_view_angle": f(90.0 / 180.0 * math.pi if view_angle is None else view_angle),
         "_panini_param": f(panini_param), "_use_panini_projection": i(1 if use_panini else 0), "_use_360_camera": i(0), "_use_180_camera": i(0),
         "_ray_tracing_depth": i(render_depth), "_aa_count": i(aa_count), "_aa_start": i(aa_start),
         "_draw_side_by_side": i(0), "_draw_anaglyph": i(0), "_anaglyph_p": f(0.29), "_anaglyph_q": f(0.06), "_anaglyph_mode": i(0),
         "_draw_depth_map": i(0), "_depth_map_min": f(0.0), "_depth_map_max": f(10.0),
         "_offset_after_material": f(cam["offset_after_material"]),
-        "_t_start": f(10.0), "_t_end": f(10.0 + 200.0), "_camera_scale": f(scale), "_left_eye_scale": f(1.0), "_right_eye_scale": f(1.0),
+        "_t_start": f(10.0), "_t_end": f(10.0 + 200.0), "_camera_scale": f(scale), "_left_eye_scale": f(calc_scale(left)), "_right_eye_scale": f(calc_scale(right)),
         "_angle_color_disable": i(0), "_grid_disable": i(0), "_black_border_disable": i(0), "_darken_by_distance": i(1), "_teleport_external_ray": i(0),
     }

@@ -41,6 +41,8 @@ struct Camera {
     DVec3 prev_cam_pos;
     bool do_not_teleport_one_frame = false;  // src/main.rs:86,1218-1222
     int from = -1;                           // RotateAroundCam::from: scene camera in use, -1 = original
+    DMat4 left_eye_matrix = DMat4::identity(), right_eye_matrix = DMat4::identity();  // src/main.rs:87-90,149-152
+    bool left_eye_in_subspace = false, right_eye_in_subspace = false;
 
     DVec3 pos_vec() const { return DVec3(std::sin(beta) * std::cos(alpha), std::cos(beta), std::sin(beta) * std::sin(alpha)) * r; }
     DMat4 matrix() const {  // src/main.rs:286-304
@@ -90,6 +92,8 @@ struct ptl_renderer {
     bool draw_side_by_side = false, draw_depth_map = false, angle_color_disable = false, grid_disable = false,
          black_border_disable = false, darken_by_distance = true;
     double depth_map_min = 0.0, depth_map_max = 10.0, anaglyph_p = 0.29, anaglyph_q = 0.06;
+    double eye_distance = 0.07;  // src/main.rs:1028-1029
+    bool swap_eyes = false;
     // draw-to-draw caching of the uploads: the reference re-evaluates and re-uploads every uniform on
     // every draw (src/main.rs:1413-1414); the values only change when the scene, an option, the camera
     // or the frame size does, so a draw of an unchanged state is just the kernel launch
@@ -157,10 +161,10 @@ std::vector<UniformUpload> builtin_uniforms(const ptl_renderer& r, int width, in
     }
     DMat4 cam = r.cam.matrix();
     m4("_camera", cam);
-    m4("_camera_left_eye", DMat4::identity());
-    m4("_camera_right_eye", DMat4::identity());
-    i1("_left_eye_in_subspace", 0);
-    i1("_right_eye_in_subspace", 0);
+    m4("_camera_left_eye", r.cam.left_eye_matrix);
+    m4("_camera_right_eye", r.cam.right_eye_matrix);
+    i1("_left_eye_in_subspace", r.cam.left_eye_in_subspace ? 1 : 0);
+    i1("_right_eye_in_subspace", r.cam.right_eye_in_subspace ? 1 : 0);
     m4("_camera_mul_inv", r.cam.teleport_matrix.inverse());
     i1("_camera_in_subspace", r.cam.in_subspace ? 1 : 0);
     f1("_view_angle", r.cam.view_angle);
@@ -183,8 +187,8 @@ std::vector<UniformUpload> builtin_uniforms(const ptl_renderer& r, int width, in
     f1("_t_start", r.gray_t_start);
     f1("_t_end", r.gray_t_start + r.gray_t_size);
     f1("_camera_scale", calc_scale(cam));
-    f1("_left_eye_scale", calc_scale(DMat4::identity()));
-    f1("_right_eye_scale", calc_scale(DMat4::identity()));
+    f1("_left_eye_scale", calc_scale(r.cam.left_eye_matrix));
+    f1("_right_eye_scale", calc_scale(r.cam.right_eye_matrix));
     i1("_angle_color_disable", r.angle_color_disable ? 1 : 0);
     i1("_grid_disable", r.grid_disable ? 1 : 0);
     i1("_black_border_disable", r.black_border_disable ? 1 : 0);
@@ -539,6 +543,8 @@ extern "C" int ptl_renderer_set_option(ptl_renderer* r, const char* name, double
     else if (n == "offset_after_material") r->offset_after_material = v;
     else if (n == "draw_side_by_side") r->draw_side_by_side = b;
     else if (n == "in_subspace") r->cam.in_subspace = b;
+    else if (n == "eye_distance") r->eye_distance = v;
+    else if (n == "swap_eyes") r->swap_eyes = b;
     else if (n == "allow_teleport") r->cam.allow_teleport = b;    // RotateAroundCam toggles, src/main.rs:136-137
     else if (n == "stop_at_objects") r->cam.stop_at_objects = b;
     else return PTL_UNKNOWN_UNIFORM;
@@ -757,6 +763,42 @@ int teleport_camera(ptl_renderer* r, const Camera& prev_cam, int* teleported, in
     return PTL_OK;
 }
 
+// SceneRenderer::teleport_eye_matrices (src/main.rs:1121-1172): each eye sits eye_distance to the side of the camera; if
+// the segment camera -> eye crosses a portal, the eye gets its own teleported matrix (and subspace flag).
+int teleport_eye_matrices(ptl_renderer* r) {
+    Camera& cam = r->cam;
+    if (!(r->draw_side_by_side && cam.allow_teleport)) return PTL_OK;  // draw_anaglyph: stripped from the kernel (disable_anaglyph)
+    double eye_distance = r->swap_eyes ? -r->eye_distance : r->eye_distance;
+    auto one_eye = [&](double x, DMat4* out_m, bool* out_sub) -> int {
+        DVec3 start_pos = cam_pos(cam);
+        DMat4 m = cam.matrix();
+        DVec4 d4 = m.mul_vec4(DVec4(x, 0.0, 0.0, 1.0));
+        DVec3 direction_pos(d4.x, d4.y, d4.z);
+        DVec3 shift = direction_pos - start_pos;
+        DMat4 translation = DMat4::from_cols({1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {shift.x, shift.y, shift.z, 1});
+        *out_m = translation * m;
+        *out_sub = cam.in_subspace;
+        RayQuery q;
+        int rc = query_ray(r, start_pos, direction_pos, &q);
+        if (rc != PTL_OK) return rc;
+        if (!q.teleported) return PTL_OK;
+        for (double dx : {0.001, 0.0001, 0.00001, 0.000001}) {
+            bool ok = false;
+            DMat4 tm;
+            rc = teleport_matrix(r, *out_m, start_pos, direction_pos, q.pos, dx, &ok, &tm);
+            if (rc != PTL_OK) return rc;
+            if (!ok) continue;
+            *out_m = tm;
+            if (q.changed_subspace) *out_sub = !cam.in_subspace;
+            break;
+        }
+        return PTL_OK;
+    };
+    int rc = one_eye(-eye_distance, &cam.left_eye_matrix, &cam.left_eye_in_subspace);
+    if (rc == PTL_OK) rc = one_eye(eye_distance, &cam.right_eye_matrix, &cam.right_eye_in_subspace);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" int ptl_renderer_move_camera(ptl_renderer* r, const double look_at[3], double alpha, double beta, double radius, int* teleported,
@@ -772,6 +814,7 @@ extern "C" int ptl_renderer_move_camera(ptl_renderer* r, const double look_at[3]
         r->cam.r = radius;
         ++r->options_version;
         int rc = teleport_camera(r, prev, teleported, blocked);
+        if (rc == PTL_OK) rc = teleport_eye_matrices(r);
         ++r->options_version;
         return rc;
     });
@@ -838,6 +881,7 @@ extern "C" int ptl_renderer_update(ptl_renderer* r, double seconds, int* telepor
             Camera prev = r->prev_cam;
             rc = teleport_camera(r, prev, teleported, blocked);
         }
+        if (rc == PTL_OK) rc = teleport_eye_matrices(r);
         r->prev_cam = cam;
         send_camera_matrix(r);
         ++r->options_version;

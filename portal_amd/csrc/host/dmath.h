@@ -42,6 +42,34 @@ struct DQuat {
     static DQuat rotation_x(double a) { return {std::sin(a * 0.5), 0, 0, std::cos(a * 0.5)}; }
     static DQuat rotation_y(double a) { return {0, std::sin(a * 0.5), 0, std::cos(a * 0.5)}; }
     static DQuat rotation_z(double a) { return {0, 0, std::sin(a * 0.5), std::cos(a * 0.5)}; }
+    // glam 0.13 Quaternion::from_rotation_axes (Mike Day, "Converting a Rotation Matrix to a Quaternion")
+    static DQuat from_rotation_axes(const DVec3& xa, const DVec3& ya, const DVec3& za) {
+        double m00 = xa.x, m01 = xa.y, m02 = xa.z, m10 = ya.x, m11 = ya.y, m12 = ya.z, m20 = za.x, m21 = za.y, m22 = za.z;
+        if (m22 <= 0.0) {
+            double dif10 = m11 - m00, omm22 = 1.0 - m22;
+            if (dif10 <= 0.0) {
+                double four_xsq = omm22 - dif10, inv4x = 0.5 / std::sqrt(four_xsq);
+                return {four_xsq * inv4x, (m01 + m10) * inv4x, (m02 + m20) * inv4x, (m12 - m21) * inv4x};
+            }
+            double four_ysq = omm22 + dif10, inv4y = 0.5 / std::sqrt(four_ysq);
+            return {(m01 + m10) * inv4y, four_ysq * inv4y, (m12 + m21) * inv4y, (m20 - m02) * inv4y};
+        }
+        double sum10 = m11 + m00, opm22 = 1.0 + m22;
+        if (sum10 <= 0.0) {
+            double four_zsq = opm22 - sum10, inv4z = 0.5 / std::sqrt(four_zsq);
+            return {(m02 + m20) * inv4z, (m12 + m21) * inv4z, four_zsq * inv4z, (m01 - m10) * inv4z};
+        }
+        double four_wsq = opm22 + sum10, inv4w = 0.5 / std::sqrt(four_wsq);
+        return {(m12 - m21) * inv4w, (m20 - m02) * inv4w, (m01 - m10) * inv4w, four_wsq * inv4w};
+    }
+    double dot(const DQuat& o) const { return x * o.x + y * o.y + z * o.z + w * o.w; }
+    // glam 0.13 Quaternion::lerp: shortest-arc linear blend, then normalize (x * (1 / length))
+    DQuat lerp(const DQuat& end, double s) const {
+        double bias = dot(end) >= 0.0 ? 1.0 : -1.0;
+        DQuat q{x + (end.x * bias - x) * s, y + (end.y * bias - y) * s, z + (end.z * bias - z) * s, w + (end.w * bias - w) * s};
+        double inv = 1.0 / std::sqrt(q.dot(q));
+        return {q.x * inv, q.y * inv, q.z * inv, q.w * inv};
+    }
     DQuat operator*(const DQuat& o) const {
         return {w * o.x + x * o.w + y * o.z - z * o.y, w * o.y - x * o.z + y * o.w + z * o.x,
                 w * o.z + x * o.y - y * o.x + z * o.w, w * o.w - x * o.x - y * o.y - z * o.z};
@@ -73,6 +101,25 @@ struct DMat4 {
         DVec4 ya(xy - wz, 1.0 - (xx + zz), yz + wx, 0.0);
         DVec4 za(xz + wy, yz - wx, 1.0 - (xx + yy), 0.0);
         return from_cols(xa * s.x, ya * s.y, za * s.z, DVec4(t.x, t.y, t.z, 1.0));
+    }
+    double determinant() const {  // glam 0.13 Matrix4x4::determinant
+        double m00 = c[0].x, m01 = c[0].y, m02 = c[0].z, m03 = c[0].w, m10 = c[1].x, m11 = c[1].y, m12 = c[1].z, m13 = c[1].w;
+        double m20 = c[2].x, m21 = c[2].y, m22 = c[2].z, m23 = c[2].w, m30 = c[3].x, m31 = c[3].y, m32 = c[3].z, m33 = c[3].w;
+        double a2323 = m22 * m33 - m23 * m32, a1323 = m21 * m33 - m23 * m31, a1223 = m21 * m32 - m22 * m31;
+        double a0323 = m20 * m33 - m23 * m30, a0223 = m20 * m32 - m22 * m30, a0123 = m20 * m31 - m21 * m30;
+        return m00 * (m11 * a2323 - m12 * a1323 + m13 * a1223) - m01 * (m10 * a2323 - m12 * a0323 + m13 * a0223) +
+               m02 * (m10 * a1323 - m11 * a0323 + m13 * a0123) - m03 * (m10 * a1223 - m11 * a0223 + m12 * a0123);
+    }
+    // glam 0.13 Mat4::to_scale_rotation_translation: scale = axis lengths (x negated for a mirrored basis), rotation from
+    // the axes divided by the scale, translation = w axis
+    void to_scale_rotation_translation(DVec3* scale, DQuat* rotation, DVec3* translation) const {
+        double det = determinant();
+        double sign = std::isnan(det) ? det : (std::signbit(det) ? -1.0 : 1.0);  // f64::signum
+        *scale = DVec3(c[0].length() * sign, c[1].length(), c[2].length());
+        double ix = 1.0 / scale->x, iy = 1.0 / scale->y, iz = 1.0 / scale->z;
+        *rotation = DQuat::from_rotation_axes(DVec3(c[0].x * ix, c[0].y * ix, c[0].z * ix), DVec3(c[1].x * iy, c[1].y * iy, c[1].z * iy),
+                                              DVec3(c[2].x * iz, c[2].y * iz, c[2].z * iz));
+        *translation = DVec3(c[3].x, c[3].y, c[3].z);
     }
     DVec4 mul_vec4(const DVec4& v) const {
         DVec4 r = c[0] * v.x;

@@ -871,10 +871,23 @@ std::optional<DMat4> Scene::eval_matrix(int index) const {
             return a->inverse();
         }
         case Matrix::Camera: return camera_matrix;
+        case Matrix::Lerp: {  // src/gui/matrix.rs:614-627: decompose both into TRS, blend each part, recompose
+            auto t = eval_param(m.cond);
+            if (!t) return std::nullopt;
+            auto first = eval_matrix(m.a);
+            if (!first) return std::nullopt;
+            auto second = eval_matrix(m.b);
+            if (!second) return std::nullopt;
+            DVec3 fs, ft, ss, st;
+            DQuat fr, sr;
+            first->to_scale_rotation_translation(&fs, &fr, &ft);
+            second->to_scale_rotation_translation(&ss, &sr, &st);
+            return DMat4::from_scale_rotation_translation(fs.lerp(ss, *t), fr.lerp(sr, *t), ft.lerp(st, *t));
+        }
         case Matrix::Sqrt:
-        case Matrix::Lerp:
-            // src/gui/matrix.rs:593-617,909-988 (argmin BFGS matrix square root, TRS lerp): not used by
-            // any BASELINE config; reported as "can't be getted" until implemented.
+            // src/gui/matrix.rs:606-612,909-988: the square root comes out of a BFGS minimiser (argmin + finite differences),
+            // i.e. its digits are an artefact of that solver's iteration, not a defined function: out of scope, reported as
+            // "can't be getted" (one use in the corpus, portal_in_portal_plus_ultra).
             return std::nullopt;
     }
     return std::nullopt;

@@ -402,3 +402,42 @@ def test_render_cli_writes_the_frames_the_library_draws(gpu, tmp_path):
         if i == 0:
             assert np.array_equal(pa.png_read(str(tmp_path / "video" / "basics" / f"{clip}.start.png")), subs[0])
     assert np.array_equal(pa.png_read(str(tmp_path / "video" / "basics" / f"{clip}.end.png")), subs[-1])
+
+
+def test_stereo_eye_matrices_and_side_by_side_frame(gpu):
+    """`render --stereoimage` (src/main.rs:1121-1172,2822-2841): the two eye cameras sit eye_distance either side of the
+    camera; with the camera 3 cm in front of basics' portal A and its x axis along the portal normal, one eye is behind the
+    portal plane and gets a teleported matrix.  Eye uniforms == the oracle's restatement, side-by-side frame == oracle."""
+    from oracle.portal_oracle import CameraRig, Oracle
+    from oracle.scene_eval import builtin_uniforms
+
+    pa = gpu
+    scene = pa.Scene.from_file(pa.scene_path("basics"))
+    r = pa.SceneRenderer(scene, device=0)
+    r.set_option("render_depth", 8)
+    r.set_option("draw_side_by_side", 1)
+    o = Oracle(pa.scene_path("basics"))
+    o.options["render_depth"] = 8
+    o.overrides["_draw_side_by_side"] = np.int32(1)
+    rig = CameraRig(o)
+    rig.stereo = True
+    alpha, beta, rad = 3.0, 1.45, 1.0
+    orbit = np.array([np.sin(beta) * np.cos(alpha), np.cos(beta), np.sin(beta) * np.sin(alpha)])
+    w, h = 96, 27
+    crossed = []
+    for eye_z in (-2.0, -2.97):          # far from the portal plane z = -3, then 3 cm in front of it
+        eye = np.array([0.1, 0.1, eye_z])
+        st = (tuple(eye - orbit * rad), alpha, beta, rad)
+        assert r.move_camera(*st) == rig.move(*st)
+        want = builtin_uniforms(o.scene, w, h, camera=rig.settings())
+        for k in ("_camera", "_camera_left_eye", "_camera_right_eye", "_left_eye_in_subspace", "_right_eye_in_subspace", "_left_eye_scale", "_right_eye_scale"):
+            g = r.uniform_value(k, w, h)
+            g = np.asarray(g).T.reshape(16) if np.asarray(g).shape == (4, 4) else np.asarray(g).reshape(-1)
+            assert np.array_equal(g.astype(np.float32), np.asarray(want[k], np.float32).reshape(-1)), (eye_z, k)
+        cam, left, right = (np.asarray(r.uniform_value(k, w, h), np.float64) for k in ("_camera", "_camera_left_eye", "_camera_right_eye"))
+        # an eye that crossed nothing is the camera translated by 7 cm: same rotation block
+        crossed.append([not np.allclose(e[:3, :3], cam[:3, :3], atol=1e-6) or abs(np.linalg.norm(e[:3, 3] - cam[:3, 3]) - 0.07) > 1e-3 for e in (left, right)])
+    assert crossed[0] == [False, False] and sum(crossed[1]) == 1
+    out = r.draw(w, h, rgba32f=True)
+    o.camera = rig.settings()
+    assert _bits_equal(out["rgba32f"], o.render(w, h)["rgba32f"]).all()

@@ -484,3 +484,34 @@ def test_real_animation_known_answers(pa):
         from oracle.scene_eval import ease
 
         assert ease(kind, t) == pytest.approx(want, abs=1e-15)
+
+
+def test_matrix_lerp_known_answers(pa):
+    """Matrix::Lerp (src/gui/matrix.rs:614-627): TRS decomposition, per-part blend (quaternion shortest arc, normalised),
+    recomposition.  Half way between the identity and (rotate 90 degrees about z, move 2 along x, scale 3) is
+    (rotate 45 degrees, move 1, scale 2); the ends reproduce the operands; product == oracle bit for bit; Matrix::Camera
+    follows ptl_scene_set_camera_matrix."""
+    from oracle.scene_eval import OracleScene
+    from tests import synthetic
+
+    extra = '''
+        (name: "far", data: Simple(offset: (2.0, 0.0, 0.0), scale: 3.0, rotate: (0.0, 0.0, 1.5707963267948966), mirror: (false, false, false))),
+        (name: "mid", data: Lerp(t: Value(0.5), first: Some(Named("wall")), second: Some(Named("far")))),
+        (name: "t0", data: Lerp(t: Value(0.0), first: Some(Named("wall")), second: Some(Named("far")))),
+        (name: "t1", data: Lerp(t: Uniform(Some(Named("one"))), first: Some(Named("wall")), second: Some(Named("far")))),
+        (name: "cam_follow", data: Mul(to: Some(Inline(Camera)), what: Some(Named("far")))),
+    '''
+    text = synthetic.wall_scene(extra_matrices=extra).replace('uniforms: ([', 'uniforms: ([ (name: "one", data: Float((min: None, max: None, value: 1.0))),')
+    s, o = pa.Scene.from_text(text), OracleScene(text, is_text=True)
+    mid = s.eval_matrix("mid")
+    c = math.sqrt(0.5)
+    want = np.array([[2 * c, -2 * c, 0, 1], [2 * c, 2 * c, 0, 0], [0, 0, 2, 0], [0, 0, 0, 1]])
+    assert mid == pytest.approx(want, abs=1e-15)
+    assert s.eval_matrix("t0") == pytest.approx(s.eval_matrix("wall"), abs=1e-15)
+    assert s.eval_matrix("t1") == pytest.approx(s.eval_matrix("far"), abs=1e-15)
+    shift = np.eye(4)
+    shift[:3, 3] = (0.5, -1.0, 4.0)
+    s.set_camera_matrix(shift)
+    o.camera_object_matrix = [list(col) for col in shift.T]
+    assert s.eval_matrix("cam_follow") == pytest.approx(s.eval_matrix("far") @ shift, abs=1e-15)   # Mul = what * to (matrix.rs:517-520)
+    _same_uniforms(s.uniform_values(), o.scene_uniform_values(), "lerp")
