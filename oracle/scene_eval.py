@@ -306,8 +306,8 @@ class OracleScene:
             return "float", float(d.items[0])
         if tag in ("Formula", "FormulaInt"):
             return ("formula" if tag == "Formula" else "formula_int"), _code(d.items[0])
-        if tag == "TrefoilSpecial":
-            return "trefoil", None
+        if tag == "TrefoilSpecial":  # 18 x (enabled, value, color), src/gui/uniform.rs:19-20
+            return "trefoil", [(bool(e.items[0]), int(e.items[1]), int(e.items[2])) for e in _newtype(d.items[0]).items]
         raise ValueError(f"unknown uniform kind {tag}")
 
     def _camera(self, d):
@@ -701,6 +701,13 @@ class OracleScene:
                 out[f"{nb}_to_{na}_mat_teleport"] = to_f32_colmajor(m_mul(a, m_inverse(b)))
         for k, u in enumerate(self.uniforms):
             if u[0] is None:
+                continue
+            j, hops = k, 0
+            while j in self.uniform_alias and hops < 64:
+                j, hops = self.uniform_alias[j], hops + 1
+            if self.uniforms[j][1] == "trefoil":  # packed as value + enabled*10000 + color*1000 (scene.rs:644-650)
+                for i, (enabled, value, color) in enumerate(self.uniforms[j][2]):
+                    out[f"ts_{i}_{u[0]}_u"] = np.int32(value + (10000 if enabled else 0) + color * 1000)
                 continue
             r = self.eval_uniform(k)
             if r is None:

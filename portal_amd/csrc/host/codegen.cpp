@@ -170,6 +170,11 @@ std::vector<UniformDesc> scene_uniform_list(const Scene& scene) {
     for (size_t k = 0; k < scene.uniforms.size(); ++k) {
         const UniformEntry& u = scene.uniforms[k];
         if (u.name.empty()) continue;  // inline uniforms are not visible
+        const Uniform* now = scene.resolved_uniform((int)k);
+        if (now && now->kind == Uniform::Trefoil) {  // 18 packed ints `ts_<i>_<name>_u` (scene.rs:488-492)
+            for (int i = 0; i < 18; ++i) out.push_back({"ts_" + std::to_string(i) + "_" + u.name + "_u", UniformType::Int1, 0});
+            continue;
+        }
         auto v = scene.eval_uniform((int)k);
         if (!v) continue;
         out.push_back({u.name + "_u", v->kind == UniformValue::Float ? UniformType::Float1 : UniformType::Int1, 0});
@@ -259,9 +264,20 @@ std::vector<UniformUpload> evaluate_scene_uniforms(const Scene& scene, std::vect
     for (size_t k = 0; k < scene.uniforms.size(); ++k) {
         const UniformEntry& e = scene.uniforms[k];
         if (e.name.empty()) continue;
+        const Uniform* now = scene.resolved_uniform((int)k);
+        if (now && now->kind == Uniform::Trefoil) {  // value + enabled * 10000 + color * 1000 (scene.rs:644-650)
+            for (int i = 0; i < 18; ++i) {
+                UniformUpload u;
+                u.name = "ts_" + std::to_string(i) + "_" + e.name + "_u";
+                u.type = UniformType::Int1;
+                u.i = now->trefoil[i][1] + now->trefoil[i][0] * 10000 + now->trefoil[i][2] * 1000;
+                out.push_back(u);
+            }
+            continue;
+        }
         auto v = scene.eval_uniform((int)k);
         if (!v) {
-            if (errors && e.value.kind != Uniform::Trefoil) errors->push_back("Error getting `" + e.name + "` uniform");
+            if (errors) errors->push_back("Error getting `" + e.name + "` uniform");
             continue;
         }
         UniformUpload u;

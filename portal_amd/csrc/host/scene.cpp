@@ -74,6 +74,15 @@ struct Loader {
             u.formula = as_string(v.items.at(0), "Formula uniform");
         } else if (tag == "TrefoilSpecial") {
             u.kind = Uniform::Trefoil;
+            const Value& arr = v.items.at(0).unwrap_newtypes();  // TrefoilSpecial(( ((b, v, c), ... x18) ))
+            if (arr.kind != Value::Tuple || arr.items.size() != 18) throw SceneError("scene: TrefoilSpecial needs 18 entries");
+            for (int k = 0; k < 18; ++k) {
+                const Value& e = arr.items[k];
+                if (e.items.size() != 3) throw SceneError("scene: bad TrefoilSpecial entry");
+                u.trefoil[k][0] = as_bool(e.items[0], "trefoil enabled") ? 1 : 0;
+                u.trefoil[k][1] = (int)as_f64(e.items[1], "trefoil value");
+                u.trefoil[k][2] = (int)as_f64(e.items[2], "trefoil color");
+            }
         } else {
             throw SceneError("scene: unknown uniform kind `" + tag + "`");
         }
@@ -736,6 +745,12 @@ std::optional<CalculatedCam> Scene::update(double seconds) {
     cam.override_matrix = t_raw < prev_t_raw || t_raw == 0.0;
     prev_t_raw = t_raw;
     return cam;
+}
+
+const Uniform* Scene::resolved_uniform(int index) const {
+    for (int hops = 0; index >= 0 && index < (int)uniform_alias.size() && uniform_alias[index] >= 0 && hops < 64; ++hops) index = uniform_alias[index];
+    if (index < 0 || index >= (int)uniforms.size()) return nullptr;
+    return &uniforms[index].value;
 }
 
 std::optional<double> Scene::eval_formula(const std::string& text) const {

@@ -32,6 +32,7 @@ struct Uniform {
     int i = 0;
     double f = 0.0;
     std::string formula;
+    int trefoil[18][3] = {};  // TrefoilSpecial: (enabled, value, color) x 18 (src/gui/uniform.rs:19-20)
 };
 struct UniformValue {
     enum Kind { Bool, Int, Float } kind = Float;
@@ -198,6 +199,8 @@ public:
     std::optional<UniformValue> eval_uniform(int index) const;
     std::optional<DMat4> eval_matrix(int index) const;
     std::optional<double> eval_param(const Param& p) const;
+    // the element a uniform currently evaluates as (stage / clip replacements followed); nullptr if out of range
+    const Uniform* resolved_uniform(int index) const;
 
     // overrides (what a stage / animation / user slider does): set the stored value
     bool set_uniform_value(const std::string& name, double v);
