@@ -259,6 +259,9 @@ int ptl_average_images(int device, const void* const* frames_rgba8, int n_frames
 int ptl_device_alloc(int device, size_t bytes, void** out);
 int ptl_device_free(void* p);
 int ptl_device_download(void* host_dst, const void* device_src, size_t bytes, void* stream);
+/* Page-locked host memory for those downloads (PCIe-rate copies; pageable memory works too, several times slower). */
+int ptl_host_alloc(size_t bytes, void** out);
+int ptl_host_free(void* p);
 
 /* PNG I/O (RGBA8): the reference's Texture2D::from_file_with_format / Image::export_png. */
 int ptl_png_read(const char* path, uint8_t** rgba8, int* width, int* height); /* free with ptl_free */

@@ -138,6 +138,8 @@ def _load() -> C.CDLL:
         "ptl_device_alloc": (ci, [ci, cs, P(vp)]),
         "ptl_device_free": (ci, [vp]),
         "ptl_device_download": (ci, [vp, vp, cs, vp]),
+        "ptl_host_alloc": (ci, [cs, P(vp)]),
+        "ptl_host_free": (ci, [vp]),
         "ptl_png_read": (ci, [cp, P(vp), P(ci), P(ci)]),
         "ptl_png_write": (ci, [cp, vp, ci, ci]),
         "ptl_strstore_new": (vp, []),

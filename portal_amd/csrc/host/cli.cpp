@@ -124,6 +124,41 @@ private:
     bool done_ = false;
 };
 
+// Page-locked frame buffers recycled between the download and the encoder threads.
+class PinnedFrames {
+public:
+    PinnedFrames(size_t bytes, int count) : bytes_(bytes) {
+        for (int k = 0; k < count; ++k) {
+            void* p = nullptr;
+            if (ptl_host_alloc(bytes, &p) != PTL_OK) break;
+            all_.push_back(p);
+            free_.push_back(p);
+        }
+    }
+    ~PinnedFrames() {
+        for (void* p : all_) ptl_host_free(p);
+    }
+    bool ok() const { return !all_.empty(); }
+    uint8_t* take() {
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_.wait(lock, [&] { return !free_.empty(); });
+        void* p = free_.back();
+        free_.pop_back();
+        return static_cast<uint8_t*>(p);
+    }
+    void give(uint8_t* p) {
+        std::unique_lock<std::mutex> lock(mu_);
+        free_.push_back(p);
+        cv_.notify_one();
+    }
+
+private:
+    size_t bytes_;
+    std::vector<void*> all_, free_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+};
+
 struct Options {
     std::string scene, clips, output = "frame.png", asset_root = ".", stage, animation, camera, scenes_dir = "scenes", out_dir = ".", starts_with;
     bool have_camera = false, stereo = false, skip_existing = true, aa_given = false, depth_given = false, size_given = false;
@@ -216,7 +251,7 @@ int render_frame(const Options& o) {
 
 // render_animation (src/main.rs:1758-1873)
 int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::string& scene_name, const std::string& clip, double duration, int fps,
-                int width, int height, std::vector<void*>& subframes, void* averaged, EncoderPool& pool) {
+                int width, int height, std::vector<void*>& subframes, void* averaged, EncoderPool& pool, PinnedFrames& pinned) {
     auto started = std::chrono::steady_clock::now();
     std::string video_base = o.out_dir + "/video/" + scene_name + "/" + clip;
     if (o.skip_existing && exists(video_base + ".mov")) {
@@ -260,10 +295,11 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
             gpu_ms += ms;
             result = averaged;
         }
-        auto pixels = std::make_shared<std::vector<uint8_t>>(frame_bytes);
-        if (ptl_device_download(pixels->data(), result, frame_bytes, nullptr) != PTL_OK) return fail("download");
-        pool.submit([pixels, name, width, height] {
-            if (ptl_png_write(name.c_str(), pixels->data(), width, height) != PTL_OK) std::fprintf(stderr, "\n%s\n", ptl_last_error());
+        uint8_t* pixels = pinned.take();  // blocks while every buffer is still being encoded
+        if (ptl_device_download(pixels, result, frame_bytes, nullptr) != PTL_OK) return fail("download");
+        pool.submit([pixels, name, width, height, &pinned] {
+            if (ptl_png_write(name.c_str(), pixels, width, height) != PTL_OK) std::fprintf(stderr, "\n%s\n", ptl_last_error());
+            pinned.give(pixels);
         });
         std::printf("\r%d/%d done      ", i, count);
         std::fflush(stdout);
@@ -352,10 +388,13 @@ int render(const Options& o) {
             apply_clip_overrides(scene, r, clip, &fps);
             std::printf("Rendering animation %s, %zu/%zu\n", clip.c_str(), k + 1, todo.size());
             {
+                PinnedFrames pinned(bytes, threads + 2);
+                if (!pinned.ok()) return fail("pinned host memory");
                 EncoderPool pool(threads, (size_t)threads * 2);
-                int rc = render_clip(o, scene, r, scene_name, clip, todo[k].second, fps, width, o.height, subframes, averaged, pool);
+                int rc = render_clip(o, scene, r, scene_name, clip, todo[k].second, fps, width, o.height, subframes, averaged, pool, pinned);
+                pool.finish();  // joins the encoders: every frame file is on disk (and every pinned buffer is back)
                 if (rc != 0) return rc;
-            }  // joins the encoders: every frame file is on disk
+            }
             if (o.shards == 1 && o.max_frames < 0) encode_video(o, scene_name, clip, fps);
         }
         for (void* p : subframes) ptl_device_free(p);

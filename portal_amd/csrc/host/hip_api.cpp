@@ -79,6 +79,7 @@ const Runtime* runtime(std::string* error) {
             ok = bind(h, "hipInit", rt.hipInit, &err) && bind(h, "hipGetDeviceCount", rt.hipGetDeviceCount, &err) &&
                  bind(h, "hipSetDevice", rt.hipSetDevice, &err) && bind(h, "hipGetDevice", rt.hipGetDevice, &err) &&
                  bind(h, "hipMalloc", rt.hipMalloc, &err) && bind(h, "hipFree", rt.hipFree, &err) &&
+                 bind(h, "hipHostMalloc", rt.hipHostMalloc, &err) && bind(h, "hipHostFree", rt.hipHostFree, &err) &&
                  bind(h, "hipMemcpy", rt.hipMemcpy, &err) && bind(h, "hipMemcpyAsync", rt.hipMemcpyAsync, &err) &&
                  bind(h, "hipMemsetAsync", rt.hipMemsetAsync, &err) && bind(h, "hipStreamSynchronize", rt.hipStreamSynchronize, &err) &&
                  bind(h, "hipDeviceSynchronize", rt.hipDeviceSynchronize, &err) && bind(h, "hipEventCreate", rt.hipEventCreate, &err) &&

