@@ -175,7 +175,8 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
 
 /* Scene::generate_shader_code: returns a malloc'ed NUL-terminated HIP C++ source (free with
  * ptl_free).  flags: bit0 = bake Bool/Int scene uniforms as literals, bit1 = count segments,
- * bit2 = bake every scene uniform (ints, floats, matrices; camera and other builtins stay dynamic).
+ * bit2 = bake every scene uniform (ints, floats, matrices; camera and other builtins stay dynamic),
+ * bit4 = compile the anaglyph stereo mode in (the reference's `disable_anaglyph = false`, src/main.rs:939).
  * ptl_renderer_create additionally reads bits 8-11 as an occupancy hint n (0 = none):
  * the kernel is built with __launch_bounds__(256, n), i.e. at least n waves per SIMD. */
 int ptl_scene_generate_source(ptl_scene* s, unsigned flags, char** source);

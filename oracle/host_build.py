@@ -30,11 +30,11 @@ BUILD_DIR = os.path.join(_HERE, "_build")
 CXXFLAGS = ["-std=c++20", "-O2", "-ffp-contract=off", "-mfma", "-fopenmp", "-fPIC", "-shared", "-x", "c++", "-w"]
 
 
-def compile_host(source: str, count_segments: bool = False, opt: str = "-O2") -> str:
+def compile_host(source: str, count_segments: bool = False, opt: str = "-O2", defines=()) -> str:
     """g++-compile `source` into a shared object (cached by content hash); returns its path.
     The optimisation level cannot change results (IEEE arithmetic, -ffp-contract=off, no fast-math)."""
     os.makedirs(BUILD_DIR, exist_ok=True)
-    flags = [opt if f == "-O2" else f for f in CXXFLAGS] + (["-DPTL_COUNT_SEGMENTS"] if count_segments else [])
+    flags = [opt if f == "-O2" else f for f in CXXFLAGS] + (["-DPTL_COUNT_SEGMENTS"] if count_segments else []) + [f"-D{d}" for d in defines]
     key = hashlib.sha256((source + "\0" + " ".join(flags)).encode()).hexdigest()[:20]
     so = os.path.join(BUILD_DIR, f"host_{key}.so")
     if not os.path.exists(so):
@@ -50,8 +50,8 @@ def compile_host(source: str, count_segments: bool = False, opt: str = "-O2") ->
 class HostKernel:
     """The host-compiled kernel of one scene: set uniforms by name, render pixel windows."""
 
-    def __init__(self, source: str, layout, block_size: int, count_segments: bool = False, opt: str = "-O2"):
-        self.so_path = compile_host(source, count_segments, opt)
+    def __init__(self, source: str, layout, block_size: int, count_segments: bool = False, opt: str = "-O2", defines=()):
+        self.so_path = compile_host(source, count_segments, opt, defines)
         self.lib = C.CDLL(self.so_path)
         self.lib.ptl_host_uniform_block.restype = C.c_void_p
         self.lib.ptl_host_uniform_block.argtypes = [C.POINTER(C.c_ulong)]
@@ -119,7 +119,7 @@ def host_kernel_for(renderer, scene, width: int, height: int, flags: int = 0, co
 
     source = scene.generate_source(flags)
     layout, size = scene.uniform_layout()
-    hk = HostKernel(source, layout, size, count_segments)
+    hk = HostKernel(source, layout, size, count_segments, defines=("PTL_ANAGLYPH",) if flags & 16 else ())
     for name, typ, _ in layout:
         if typ == pa.PTL_SAMPLER:
             continue

@@ -399,6 +399,7 @@ class Oracle:
         self.options = dict(render_depth=100, aa_count=1, aa_start=0, view_angle=None, use_panini=False, panini_param=1.0)
         self.overrides = {}  # builtin uniform name -> value (e.g. _use_360_camera, _draw_depth_map, _draw_side_by_side, _camera_left_eye)
         self.camera = None
+        self.anaglyph_compiled_in = False  # the reference's `disable_anaglyph` (default true: the mode does not exist in the shader)
         self._program = None
         self.stats = {}
 
@@ -832,10 +833,35 @@ class Oracle:
             seg[live] = sg
         return rgb, seg
 
-    # ---- frag.glsl:466-503 (mono / side-by-side; anaglyph lines are stripped at native defaults) ----------
+    # ---- frag.glsl:343-406: red/cyan anaglyph of the two eye images (linear light) with ghosting compensation ----
+    def anaglyph_combine(self, left, right, mode):
+        u = self.uniforms
+        clamp01 = lambda v: Vec([M.clamp(c, fl(0.0), fl(1.0)) for c in v.c])
+        lv = clamp01(Vec([left[:, k] for k in range(3)]))
+        rv = clamp01(Vec([right[:, k] for k in range(3)]))
+        luma = vec(M.lit("0.299"), M.lit("0.587"), M.lit("0.114"))
+        p, q = u["_anaglyph_p"], u["_anaglyph_q"]
+        l, r = V.dot(lv, luma), V.dot(rv, luma)
+        denom = M.fmax(M.lit("1e-6"), M.sub(fl(1.0), M.mul(p, q)))
+        r_out = M.div(M.sub(l, M.mul(p, r)), denom)
+        c_out = M.div(M.sub(r, M.mul(q, l)), denom)
+        if mode == 0:
+            out = clamp01(Vec([r_out, c_out, c_out]))
+        else:
+            sum_gb = M.add(rv.c[1], rv.c[2])
+            with np.errstate(all="ignore"):
+                k = np.where(sum_gb > M.lit("1e-6"), M.div(M.mul(fl(2.0), c_out), sum_gb), F32(0.0)).astype(F32)
+            out = clamp01(Vec([r_out, M.mul(rv.c[1], k), M.mul(rv.c[2], k)]))
+        return np.stack([np.broadcast_to(np.asarray(c, F32), (left.shape[0],)) for c in out.c], axis=1).astype(F32)
+
+    # ---- frag.glsl:466-503 (mono / side-by-side / anaglyph) ----------------------------------------------
     def get_color(self, image_position):
         u = self.uniforms
         n = len(np.asarray(image_position.c[0]))
+        if int(u["_draw_anaglyph"]) == 1 and self.anaglyph_compiled_in:
+            cl, sl = self.get_color2(image_position, u["_camera_left_eye"], int(u["_left_eye_in_subspace"]) == 1, u["_left_eye_scale"], u["_resolution"])
+            cr, sr = self.get_color2(image_position, u["_camera_right_eye"], int(u["_right_eye_in_subspace"]) == 1, u["_right_eye_scale"], u["_resolution"])
+            return self.anaglyph_combine(cl, cr, int(u["_anaglyph_mode"])), sl + sr
         if int(u["_draw_side_by_side"]) != 1:
             return self.get_color2(image_position, u["_camera"], int(u["_camera_in_subspace"]) == 1, u["_camera_scale"], u["_resolution"])
         res = u["_resolution"]

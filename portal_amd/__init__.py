@@ -50,6 +50,7 @@ PTL_MAT4, PTL_F32, PTL_I32, PTL_VEC2, PTL_VEC3, PTL_SAMPLER = range(6)
 FLAG_SPECIALIZE_INTS = 1
 FLAG_COUNT_SEGMENTS = 2
 FLAG_SPECIALIZE_ALL = 4
+FLAG_ANAGLYPH = 16  # compile the anaglyph stereo mode in (the reference's `disable_anaglyph = false`)
 
 
 def flag_waves(n: int) -> int:

@@ -343,9 +343,37 @@ PTL_FN vec3 get_color2(vec2 image_position, const mat4& camera_matrix, bool in_s
     return trace.color;
 }
 
-// Mono / side-by-side selection.  (src/frag.glsl:466-503; anaglyph lines are stripped by the
-// reference's native defaults, src/main.rs:935-941, so they are not restated here.)
+#ifdef PTL_ANAGLYPH
+// Red/cyan anaglyph of the two eye images with ghosting compensation.  (src/frag.glsl:343-406; the reference strips these
+// lines unless `disable_anaglyph` is switched off, src/main.rs:939 -- here they are compiled in by FLAG_ANAGLYPH.)
+// mode 0: both eyes as luminance; mode 1: right eye keeps its green/blue hue.
+PTL_FN vec3 anaglyphCombineLinear(vec3 leftLin, vec3 rightLin, int mode) {
+    leftLin = clamp(leftLin, 0.0f, 1.0f);
+    rightLin = clamp(rightLin, 0.0f, 1.0f);
+    const vec3 LUMA = vec3(0.299f, 0.587f, 0.114f);
+    float P = _anaglyph_p;
+    float Q = _anaglyph_q;
+    float l = dot(leftLin, LUMA);
+    float r = dot(rightLin, LUMA);
+    float denom = max(1e-6f, 1.0f - P * Q);
+    float Rout = (l - P * r) / denom;
+    float Cout = (r - Q * l) / denom;
+    if (mode == 0) return clamp(vec3(Rout, Cout, Cout), 0.0f, 1.0f);
+    float sumGB = rightLin.g + rightLin.b;
+    float k = (sumGB > 1e-6f) ? (2.0f * Cout / sumGB) : 0.0f;
+    return clamp(vec3(Rout, rightLin.g * k, rightLin.b * k), 0.0f, 1.0f);
+}
+#endif
+
+// Mono / side-by-side / anaglyph selection.  (src/frag.glsl:466-503)
 PTL_FN vec3 get_color(vec2 image_position) {
+#ifdef PTL_ANAGLYPH
+    if (_draw_anaglyph == 1) {
+        return anaglyphCombineLinear(get_color2(image_position, _camera_left_eye, _left_eye_in_subspace == 1, _left_eye_scale, _resolution),
+                                     get_color2(image_position, _camera_right_eye, _right_eye_in_subspace == 1, _right_eye_scale, _resolution),
+                                     _anaglyph_mode);
+    }
+#endif
     mat4 final_matrix = _camera;
     bool final_in_subspace = _camera_in_subspace == 1;
     float final_scale = _camera_scale;

@@ -92,6 +92,7 @@ struct ptl_renderer {
     bool draw_side_by_side = false, draw_depth_map = false, angle_color_disable = false, grid_disable = false,
          black_border_disable = false, darken_by_distance = true;
     double depth_map_min = 0.0, depth_map_max = 10.0, anaglyph_p = 0.29, anaglyph_q = 0.06;
+    bool draw_anaglyph = false, anaglyph_mode = false;  // anaglyph_mode = "colorful" (src/main.rs:1551-1556)
     double eye_distance = 0.07;  // src/main.rs:1028-1029
     bool swap_eyes = false;
     // draw-to-draw caching of the uploads: the reference re-evaluates and re-uploads every uniform on
@@ -176,10 +177,10 @@ std::vector<UniformUpload> builtin_uniforms(const ptl_renderer& r, int width, in
     i1("_aa_count", r.aa_count);
     i1("_aa_start", r.aa_start);
     i1("_draw_side_by_side", r.draw_side_by_side ? 1 : 0);
-    i1("_draw_anaglyph", 0);
+    i1("_draw_anaglyph", r.draw_anaglyph ? 1 : 0);
     f1("_anaglyph_p", r.anaglyph_p);
     f1("_anaglyph_q", r.anaglyph_q);
-    i1("_anaglyph_mode", 0);
+    i1("_anaglyph_mode", r.anaglyph_mode ? 1 : 0);
     i1("_draw_depth_map", r.draw_depth_map ? 1 : 0);
     f1("_depth_map_min", r.depth_map_min);
     f1("_depth_map_max", r.depth_map_max);
@@ -358,6 +359,7 @@ static KernelOptions options_from_flags(unsigned flags) {
     o.specialize_ints = (flags & 1u) != 0;
     o.count_segments = (flags & 2u) != 0;
     o.specialize_all = (flags & 4u) != 0;
+    o.anaglyph = (flags & 16u) != 0;
     return o;
 }
 
@@ -543,6 +545,10 @@ extern "C" int ptl_renderer_set_option(ptl_renderer* r, const char* name, double
     else if (n == "offset_after_material") r->offset_after_material = v;
     else if (n == "draw_side_by_side") r->draw_side_by_side = b;
     else if (n == "in_subspace") r->cam.in_subspace = b;
+    else if (n == "draw_anaglyph") r->draw_anaglyph = b;
+    else if (n == "anaglyph_mode") r->anaglyph_mode = b;
+    else if (n == "anaglyph_p") r->anaglyph_p = v;
+    else if (n == "anaglyph_q") r->anaglyph_q = v;
     else if (n == "eye_distance") r->eye_distance = v;
     else if (n == "swap_eyes") r->swap_eyes = b;
     else if (n == "allow_teleport") r->cam.allow_teleport = b;    // RotateAroundCam toggles, src/main.rs:136-137
@@ -767,7 +773,7 @@ int teleport_camera(ptl_renderer* r, const Camera& prev_cam, int* teleported, in
 // the segment camera -> eye crosses a portal, the eye gets its own teleported matrix (and subspace flag).
 int teleport_eye_matrices(ptl_renderer* r) {
     Camera& cam = r->cam;
-    if (!(r->draw_side_by_side && cam.allow_teleport)) return PTL_OK;  // draw_anaglyph: stripped from the kernel (disable_anaglyph)
+    if (!((r->draw_anaglyph || r->draw_side_by_side) && cam.allow_teleport)) return PTL_OK;
     double eye_distance = r->swap_eyes ? -r->eye_distance : r->eye_distance;
     auto one_eye = [&](double x, DMat4* out_m, bool* out_sub) -> int {
         DVec3 start_pos = cam_pos(cam);

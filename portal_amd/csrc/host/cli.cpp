@@ -281,11 +281,17 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
             gpu_ms += ms;
             ++traced;
             bool first = i == 0 && j == 0, final_one = i == count - 1 && j == o.blur - 1;
-            if (first || final_one) {
-                std::vector<uint8_t> still(frame_bytes);
-                if (ptl_device_download(still.data(), subframes[j], frame_bytes, nullptr) != PTL_OK) return fail("download");
-                if (first && ptl_png_write((video_base + ".start.png").c_str(), still.data(), width, height) != PTL_OK) return fail("png");
-                if (final_one && ptl_png_write((video_base + ".end.png").c_str(), still.data(), width, height) != PTL_OK) return fail("png");
+            if (first || final_one) {  // the clip's .start.png / .end.png stills: same pool, same pinned buffers
+                for (int which = 0; which < 2; ++which) {
+                    if (!(which == 0 ? first : final_one)) continue;
+                    uint8_t* still = pinned.take();
+                    if (ptl_device_download(still, subframes[j], frame_bytes, nullptr) != PTL_OK) return fail("download");
+                    std::string still_name = video_base + (which == 0 ? ".start.png" : ".end.png");
+                    pool.submit([still, still_name, width, height, &pinned] {
+                        if (ptl_png_write(still_name.c_str(), still, width, height) != PTL_OK) std::fprintf(stderr, "\n%s\n", ptl_last_error());
+                        pinned.give(still);
+                    });
+                }
             }
         }
         const void* result = subframes[0];  // one image: average_images hands it back untouched
@@ -306,8 +312,8 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
     }
     std::printf("\n");
     double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
-    std::printf("Traced `%s/%s`: %ld sub-frames %dx%d, GPU %.1f ms (%.3f ms each), wall %.2f s\n", scene_name.c_str(), clip.c_str(), traced, width, height,
-                gpu_ms, traced ? gpu_ms / traced : 0.0, wall);
+    std::printf("Traced `%s/%s`: %ld sub-frames %dx%d, GPU %.1f ms (%.3f ms each), submitted after %.2f s\n", scene_name.c_str(), clip.c_str(), traced, width,
+                height, gpu_ms, traced ? gpu_ms / traced : 0.0, wall);
     (void)scene;
     return 0;
 }
@@ -388,12 +394,14 @@ int render(const Options& o) {
             apply_clip_overrides(scene, r, clip, &fps);
             std::printf("Rendering animation %s, %zu/%zu\n", clip.c_str(), k + 1, todo.size());
             {
+                auto clip_start = std::chrono::steady_clock::now();
                 PinnedFrames pinned(bytes, threads + 2);
                 if (!pinned.ok()) return fail("pinned host memory");
                 EncoderPool pool(threads, (size_t)threads * 2);
                 int rc = render_clip(o, scene, r, scene_name, clip, todo[k].second, fps, width, o.height, subframes, averaged, pool, pinned);
                 pool.finish();  // joins the encoders: every frame file is on disk (and every pinned buffer is back)
                 if (rc != 0) return rc;
+                std::printf("Clip `%s` on disk after %.2f s\n", clip.c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - clip_start).count());
             }
             if (o.shards == 1 && o.max_frames < 0) encode_video(o, scene_name, clip, fps);
         }

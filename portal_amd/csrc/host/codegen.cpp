@@ -575,6 +575,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     gk.source = std::move(body.storage);
     gk.line_numbers = std::move(body.line_numbers);
     if (opts.count_segments) gk.defines.push_back("PTL_COUNT_SEGMENTS");
+    if (opts.anaglyph) gk.defines.push_back("PTL_ANAGLYPH");
     return gk;
 }
 

@@ -64,6 +64,7 @@ struct KernelOptions {
     bool specialize_ints = false;  // bake current Bool/Int uniform values in as literals (recompile when they change)
     bool specialize_all = false;   // also bake Float / matrix scene uniforms (not the camera / builtins)
     bool count_segments = false;   // compile with PTL_COUNT_SEGMENTS
+    bool anaglyph = false;         // compile the !ANAGLYPH! code in (the reference's `disable_anaglyph = false`)
 };
 
 struct GeneratedKernel {

@@ -441,3 +441,15 @@ def test_stereo_eye_matrices_and_side_by_side_frame(gpu):
     out = r.draw(w, h, rgba32f=True)
     o.camera = rig.settings()
     assert _bits_equal(out["rgba32f"], o.render(w, h)["rgba32f"]).all()
+    # the same two eyes as a red/cyan anaglyph (frag.glsl:343-406), compiled in with FLAG_ANAGLYPH
+    ra = pa.SceneRenderer(scene, device=0, flags=pa.FLAG_ANAGLYPH)
+    ra.set_option("render_depth", 8)
+    ra.set_option("draw_anaglyph", 1)
+    ra.set_option("anaglyph_mode", 1)
+    ra.move_camera(*st)  # same position: a move of zero length still refreshes the eye matrices
+    for k in ("_camera_left_eye", "_camera_right_eye"):
+        assert np.array_equal(ra.uniform_value(k, w, h), r.uniform_value(k, w, h))
+    o.anaglyph_compiled_in = True
+    o.overrides = {"_draw_anaglyph": np.int32(1), "_anaglyph_mode": np.int32(1)}
+    got = ra.draw(48, 27, rgba32f=True)["rgba32f"]
+    assert _bits_equal(got, o.render(48, 27)["rgba32f"]).all()

@@ -210,3 +210,27 @@ def test_other_kernel_modes_match_oracle(pa, mode, options, overrides):
     assert bits_equal(got["rgba32f"], want["rgba32f"]).all()
     assert got["segments"] == int(want["segments"].sum())
     assert not np.array_equal(got["rgba8"], host_render(pa, "monoportal", w, h, 20, 1)["rgba8"])
+
+
+@pytest.mark.parametrize("colorful", [0, 1])
+def test_anaglyph_mode_matches_oracle(pa, colorful):
+    """Anaglyph stereo (frag.glsl:343-406,467-473), compiled in with FLAG_ANAGLYPH (the reference's `disable_anaglyph = false`):
+    two traces per sample, combined in linear light with ghosting compensation; mode 1 keeps the right eye's hue.  Offline
+    both eye matrices are the identity (no GPU ray query on this box; the -m gpu stereo test uses teleported eyes).  Without
+    the flag the uniform exists but the mode does not: the frame is the plain one (scene.rs:1072-1080)."""
+    from oracle.portal_oracle import Oracle
+
+    w, h = 48, 27
+    options = [("draw_anaglyph", 1), ("anaglyph_mode", colorful), ("anaglyph_p", 0.31), ("anaglyph_q", 0.05)]
+    got = host_render(pa, "monoportal", w, h, 12, 1, flags=pa.FLAG_ANAGLYPH, options=options)
+    o = Oracle(os.path.join(ROOT, "scenes", "monoportal.ron"))
+    o.options["render_depth"] = 12
+    o.anaglyph_compiled_in = True
+    o.overrides = {"_draw_anaglyph": np.int32(1), "_anaglyph_mode": np.int32(colorful), "_anaglyph_p": np.float32(0.31), "_anaglyph_q": np.float32(0.05)}
+    want = o.render(w, h)
+    assert bits_equal(got["rgba32f"], want["rgba32f"]).all()
+    assert got["segments"] == int(want["segments"].sum())
+    px = got["rgba32f"][h // 2, w // 2]
+    assert (px[1] == px[2]) == (colorful == 0)                   # grayscale mode: G == B == the cyan channel
+    stripped = host_render(pa, "monoportal", w, h, 12, 1, options=options)
+    assert np.array_equal(stripped["rgba8"], host_render(pa, "monoportal", w, h, 12, 1)["rgba8"])
