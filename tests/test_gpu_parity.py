@@ -446,7 +446,8 @@ def test_stereo_eye_matrices_and_side_by_side_frame(gpu):
     ra.set_option("render_depth", 8)
     ra.set_option("draw_anaglyph", 1)
     ra.set_option("anaglyph_mode", 1)
-    ra.move_camera(*st)  # same position: a move of zero length still refreshes the eye matrices
+    for eye_z in (-2.0, -2.97):  # the same walk
+        ra.move_camera(tuple(np.array([0.1, 0.1, eye_z]) - orbit * rad), alpha, beta, rad)
     for k in ("_camera_left_eye", "_camera_right_eye"):
         assert np.array_equal(ra.uniform_value(k, w, h), r.uniform_value(k, w, h))
     o.anaglyph_compiled_in = True
