@@ -34,6 +34,7 @@ void usage() {
                  "                  [--stereoimage] [--no-skip-existing] [--filter-starts-with P] [--aa-count 4] [--render-depth 150]\n"
                  "                  [--scenes-dir DIR] [--out-dir DIR] [--device I] [--shard K/N] [--max-frames N] [--asset-root DIR]\n"
                  "       portal-amd emit-source <scene.ron> [--stage NAME]     print the generated HIP kernel source\n"
+                 "       portal-amd check <scene.ron> [--stage NAME]           compile for gfx950 (no GPU needed); errors by scene element\n"
                  "       portal-amd version\n");
 }
 
@@ -414,6 +415,63 @@ int render(const Options& o) {
     return 0;
 }
 
+// `check`: what the reference GUI shows when a scene does not compile (shader_error_parser + LineNumbersByKey,
+// src/gui/scene.rs:1144-1171): every compiler diagnostic is attributed to the scene element whose snippet produced the
+// line, with the line number inside that snippet.  Needs no GPU: hiprtc compiles for gfx950 anywhere.
+int check(const Options& o) {
+    ptl_scene* scene = nullptr;
+    if (ptl_scene_load_file(o.scene.c_str(), &scene) != PTL_OK) {
+        std::printf("%s: cannot load: %s\n", o.scene.c_str(), ptl_last_error());
+        return 1;
+    }
+    char stage_cam[256] = "";
+    if (!o.stage.empty() && ptl_scene_init_stage(scene, o.stage.c_str(), stage_cam, sizeof stage_cam) != PTL_OK) {
+        std::printf("Scene `%s` has no stage named `%s`\n", o.scene.c_str(), o.stage.c_str());
+        return 1;
+    }
+    std::vector<char> log(1 << 18);
+    ptl_renderer* r = nullptr;
+    int rc = ptl_renderer_create(scene, -1, o.asset_root.c_str(), 0, &r, log.data(), log.size());
+    if (rc == PTL_OK) {
+        const ptl_uniform_desc* descs = nullptr;
+        int n = 0;
+        size_t block = 0;
+        ptl_scene_uniform_layout(scene, &descs, &n, &block);
+        std::printf("%s: ok (%d uniforms, %zu-byte block)\n", o.scene.c_str(), n, block);
+        ptl_renderer_destroy(r);
+        ptl_scene_free(scene);
+        return 0;
+    }
+    std::string why = ptl_last_error();
+    std::printf("%s: does not compile (%s)\n", o.scene.c_str(), why.substr(0, why.find(':')).c_str());
+    int errors = 0;
+    std::string text = log.data();
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t eol = text.find('\n', pos);
+        if (eol == std::string::npos) eol = text.size();
+        std::string line = text.substr(pos, eol - pos);
+        pos = eol + 1;
+        int src_line = 0, col = 0;
+        size_t tag = line.find("portal_scene.hip:");
+        if (tag == std::string::npos || std::sscanf(line.c_str() + tag, "portal_scene.hip:%d:%d:", &src_line, &col) != 2) continue;
+        size_t msg = line.find(": ", tag + 17);
+        std::string message = msg == std::string::npos ? line : line.substr(msg + 2);
+        bool is_error = message.rfind("error", 0) == 0 || message.rfind("fatal error", 0) == 0;
+        if (!is_error && message.rfind("warning", 0) != 0) continue;  // notes follow their error
+        char kind[64] = "", name[256] = "";
+        int local = 0;
+        if (ptl_scene_source_line_owner(scene, src_line, kind, sizeof kind, name, sizeof name, &local) == PTL_OK)
+            std::printf("  %s `%s`, line %d: %s\n", kind, name, local, message.c_str());
+        else
+            std::printf("  generated code, line %d: %s\n", src_line, message.c_str());
+        errors += is_error;
+    }
+    if (errors == 0) std::printf("%s\n", log.data());
+    ptl_scene_free(scene);
+    return 1;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -426,7 +484,7 @@ int main(int argc, char** argv) {
         std::printf("%s\ndevices: %d\n", ptl_version(), ptl_device_count());
         return 0;
     }
-    if (argc < 3 || (cmd != "render-frame" && cmd != "render" && cmd != "emit-source")) {
+    if (argc < 3 || (cmd != "render-frame" && cmd != "render" && cmd != "emit-source" && cmd != "check")) {
         usage();
         return 2;
     }
@@ -490,6 +548,7 @@ int main(int argc, char** argv) {
     }
     if (cmd == "render") return render(o);
     if (cmd == "render-frame") return render_frame(o);
+    if (cmd == "check") return check(o);
     // emit-source
     ptl_scene* scene = nullptr;
     if (ptl_scene_load_file(o.scene.c_str(), &scene) != PTL_OK) {

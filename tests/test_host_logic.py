@@ -515,3 +515,18 @@ def test_matrix_lerp_known_answers(pa):
     o.camera_object_matrix = [list(col) for col in shift.T]
     assert s.eval_matrix("cam_follow") == pytest.approx(s.eval_matrix("far") @ shift, abs=1e-15)   # Mul = what * to (matrix.rs:517-520)
     _same_uniforms(s.uniform_values(), o.scene_uniform_values(), "lerp")
+
+
+def test_check_command_attributes_compile_errors_to_scene_elements(pa, tmp_path):
+    """`portal-amd check` (SURVEY 8f-4; reference: shader_error_parser + LineNumbersByKey::get_identifier, src/gui/scene.rs:1144-1171):
+    hiprtc compiles for gfx950 without a GPU; a diagnostic inside a scene snippet is reported as element + local line."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(pa.__file__), "portal-amd")
+    ok = subprocess.run([exe, "check", pa.scene_path("basics")], capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0 and "ok (" in ok.stdout
+    broken = tmp_path / "broken.ron"
+    broken.write_text(open(pa.scene_path("basics")).read().replace("int is_inside_square(", "int is_inside_square(undeclared_type zz, ", 1))
+    bad = subprocess.run([exe, "check", str(broken)], capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 1
+    assert "library `room`, line 1: error: unknown type name 'undeclared_type'" in bad.stdout
