@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -88,7 +89,8 @@ extern "C" int ptl_average_images(int device, const void* const* frames_rgba8, i
         if (!frames_rgba8[k] || (reinterpret_cast<uintptr_t>(frames_rgba8[k]) & 15u)) return PTL_ERR_INVALID;
     if (reinterpret_cast<uintptr_t>(out_rgba8) & 15u) return PTL_ERR_INVALID;
     LoadedKernel* k = nullptr;
-    int rc = load_kernel(device, "average_images.hsaco", "ptl_average_images_kernel", &k);
+    const char* variant = std::getenv("PTL_AVERAGE_IMAGES_HSACO");  // tuning only: another build of the same kernel (tools/average_variants.py)
+    int rc = load_kernel(device, variant && *variant ? variant : "average_images.hsaco", "ptl_average_images_kernel", &k);
     if (rc != PTL_OK) return rc;
     const hip::Runtime* rt = hip::runtime(nullptr);
     rt->hipSetDevice(device);
@@ -100,7 +102,9 @@ extern "C" int ptl_average_images(int device, const void* const* frames_rgba8, i
     int n = n_frames;
     void* args[] = {&list, &n, &out_rgba8, &n_vec};
     long blocks = (n_vec + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
+    long cap = 256 * 16;  // grid-stride beyond 16 workgroups per CU
+    if (const char* c = std::getenv("PTL_AVERAGE_IMAGES_GRID_CAP")) cap = std::atol(c) > 0 ? std::atol(c) : cap;
+    if (blocks > cap) blocks = cap;
     if (elapsed_ms) rt->hipEventRecord(k->ev0, stream);
     int err = rt->hipModuleLaunchKernel(k->fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
     if (err != 0) {

@@ -8,10 +8,9 @@
 // gfx950 mapping: one lane handles 4 consecutive pixels = one 16-byte load per sub-frame
 // (64 lanes x 16 B = 1 KiB per wave-instruction, fully coalesced), accumulates 12 u32 sums in
 // registers, and issues one 16-byte store.  The sub-frame loop is unrolled x4 so at least four
-// independent 16-byte loads per lane are in flight; streaming (non-temporal) loads keep the frames
-// from displacing anything useful in L2.  No LDS, no atomics.  The LUTs are arithmetic here:
-// c*c is exact in u32, and sqrt of an integer <= 65025 in binary32 + 0.5 truncated is what the
-// reference's table holds (sqrtf is correctly rounded: -fhip-fp32-correctly-rounded-divide-sqrt).
+// independent 16-byte loads per lane are in flight.  No LDS, no atomics.  The LUTs are arithmetic here:
+// c*c is exact in u32, the integer mean is a multiply-high by a per-launch constant, and sqrt + 0.5 truncated equals
+// the reference's table entry for every l <= 65025 (see ptl_l_to_s).
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #endif
@@ -35,36 +34,75 @@ __device__ __forceinline__ void ptl_accumulate(unsigned int (&sum)[12], ptl_u32x
     }
 }
 
+// L_TO_S[l] = ((l as f32).sqrt() + 0.5) as u8 for l <= 65025.  The hardware v_sqrt_f32 (1 ulp) is enough: the value only
+// changes where sqrt(l) + 0.5 crosses an integer, i.e. near l = k*k + k + 1/4, and the nearest integers l = k*k + k and
+// k*k + k + 1 keep sqrt(l) at least 1/(8k+4) >= 4.9e-4 away from k + 0.5 -- against an ulp of 3e-5 at 256.  (Checked for
+// every l in tests/test_gpu_parity.py::test_average_images_every_linear_value.)
 __device__ __forceinline__ unsigned int ptl_l_to_s(unsigned int linear) {
-    return (unsigned int)(__builtin_sqrtf((float)linear) + 0.5f);  // truncation, like `as u8` on a value <= 255.5
+    return (unsigned int)(__builtin_amdgcn_sqrtf((float)linear) + 0.5f);  // truncation, like `as u8` on a value <= 255.5
+}
+
+// sum / n for sum <= 65025 * 64 < 2^22 and 2 <= n <= 64 as one multiply-high: with m = floor(2^32 / n) + 1,
+// m*n - 2^32 = e in (0, n], and floor(sum * m / 2^32) == floor(sum / n) whenever sum * e < 2^32 (here < 2^28).
+// A runtime `/` would be ~30 VALU instructions, twelve times per lane -- more than the whole rest of the kernel.
+__device__ __forceinline__ unsigned int ptl_div_n(unsigned int sum, unsigned int magic) {
+    return magic ? __umulhi(sum, magic) : sum;  // magic == 0 encodes n == 1
+}
+
+// Tuning knobs (tools/average_variants.py builds the alternatives; the defaults are what ships):
+#ifndef PTL_AVG_UNROLL
+#define PTL_AVG_UNROLL 4  // independent 16-byte loads in flight per lane and sub-frame group
+#endif
+#ifndef PTL_AVG_NT
+#define PTL_AVG_NT 0      // 1: non-temporal (streaming) loads and store.  Measured slower (5.3 vs 6.1 TB/s at 4K, N = 4): the
+                          // sub-frames were written by the tracer a moment ago and part of them is still in the 256 MB MALL
+#endif
+#ifndef PTL_AVG_VPT
+#define PTL_AVG_VPT 1     // 16-byte vectors per lane per grid-stride step
+#endif
+
+__device__ __forceinline__ ptl_u32x4 ptl_stream_load(const ptl_u32x4* p) {
+#if PTL_AVG_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
+__device__ __forceinline__ void ptl_average_one(const ptl_frame_list& frames, int n, unsigned int magic, ptl_u32x4* __restrict__ out, long i) {
+    unsigned int sum[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    int f = 0;
+    for (; f + PTL_AVG_UNROLL <= n; f += PTL_AVG_UNROLL) {
+        ptl_u32x4 v[PTL_AVG_UNROLL];
+#pragma unroll
+        for (int k = 0; k < PTL_AVG_UNROLL; ++k) v[k] = ptl_stream_load(frames.frame[f + k] + i);
+#pragma unroll
+        for (int k = 0; k < PTL_AVG_UNROLL; ++k) ptl_accumulate(sum, v[k]);
+    }
+    for (; f < n; ++f) ptl_accumulate(sum, ptl_stream_load(frames.frame[f] + i));
+    unsigned int px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned int r = ptl_l_to_s(ptl_div_n(sum[3 * k + 0], magic));
+        const unsigned int g = ptl_l_to_s(ptl_div_n(sum[3 * k + 1], magic));
+        const unsigned int b = ptl_l_to_s(ptl_div_n(sum[3 * k + 2], magic));
+        px[k] = r | (g << 8) | (b << 16) | 0xff000000u;
+    }
+    const ptl_u32x4 packed = {px[0], px[1], px[2], px[3]};
+#if PTL_AVG_NT
+    __builtin_nontemporal_store(packed, out + i);
+#else
+    out[i] = packed;
+#endif
 }
 
 extern "C" __global__ void __launch_bounds__(256)
 ptl_average_images_kernel(ptl_frame_list frames, int n, ptl_u32x4* __restrict__ out, long n_vec) {
     const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += stride) {
-        unsigned int sum[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-        int f = 0;
-        for (; f + 4 <= n; f += 4) {  // four independent 16-byte loads in flight per lane
-            const ptl_u32x4 a = __builtin_nontemporal_load(frames.frame[f + 0] + i);
-            const ptl_u32x4 b = __builtin_nontemporal_load(frames.frame[f + 1] + i);
-            const ptl_u32x4 c = __builtin_nontemporal_load(frames.frame[f + 2] + i);
-            const ptl_u32x4 d = __builtin_nontemporal_load(frames.frame[f + 3] + i);
-            ptl_accumulate(sum, a);
-            ptl_accumulate(sum, b);
-            ptl_accumulate(sum, c);
-            ptl_accumulate(sum, d);
-        }
-        for (; f < n; ++f) ptl_accumulate(sum, __builtin_nontemporal_load(frames.frame[f] + i));
-        unsigned int px[4];
+    const unsigned int magic = n > 1 ? 0xffffffffu / (unsigned)n + 1u : 0u;  // wave-uniform: one division on the scalar side of things
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += stride * PTL_AVG_VPT) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned int r = ptl_l_to_s(sum[3 * k + 0] / (unsigned)n);
-            const unsigned int g = ptl_l_to_s(sum[3 * k + 1] / (unsigned)n);
-            const unsigned int b = ptl_l_to_s(sum[3 * k + 2] / (unsigned)n);
-            px[k] = r | (g << 8) | (b << 16) | 0xff000000u;
-        }
-        const ptl_u32x4 packed = {px[0], px[1], px[2], px[3]};
-        __builtin_nontemporal_store(packed, out + i);
+        for (int v = 0; v < PTL_AVG_VPT; ++v)
+            if (i + v * stride < n_vec) ptl_average_one(frames, n, magic, out, i + v * stride);
     }
 }

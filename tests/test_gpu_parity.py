@@ -454,3 +454,58 @@ def test_stereo_eye_matrices_and_side_by_side_frame(gpu):
     o.overrides = {"_draw_anaglyph": np.int32(1), "_anaglyph_mode": np.int32(1)}
     got = ra.draw(48, 27, rgba32f=True)["rgba32f"]
     assert _bits_equal(got, o.render(48, 27)["rgba32f"]).all()
+
+
+def _four_frames_reaching_every_linear_value():
+    """For every l in 0..65025 that four sub-frames can produce at all, channel values (a, b, c, d) with
+    (a*a + b*b + c*c + d*d) // 4 == l (sums of three squares fill every window of four consecutive integers)."""
+    sq = np.arange(256, dtype=np.int64) ** 2
+    two = sq[:, None] + sq[None, :]
+    rep = np.full(3 * 65025 + 4, -1, np.int64)          # s -> packed (b, c, d) with b*b + c*c + d*d == s
+    for b in range(256):
+        rep[(two + sq[b]).reshape(-1)] = (b << 16) | np.arange(65536)
+    l = np.arange(65026, dtype=np.int64)
+    wit = np.full((65026, 4), -1, np.int64)
+    for a in range(255, -1, -1):
+        for off in range(4):
+            s = 4 * l - a * a + off
+            ok = (wit[:, 0] < 0) & (s >= 0) & (s < len(rep))
+            r = np.where(ok, rep[np.clip(s, 0, len(rep) - 1)], -1)
+            hit = ok & (r >= 0)
+            wit[hit] = np.stack([np.full(int(hit.sum()), a), r[hit] >> 16, (r[hit] >> 8) & 255, r[hit] & 255], axis=1)
+    found = wit[:, 0] >= 0
+    assert np.array_equal((wit[found] ** 2).sum(1) // 4, l[found])
+    return wit[found].astype(np.uint8), l[found]
+
+
+def test_average_images_every_linear_value(gpu):
+    """Every entry of the reference's L_TO_S table that four sub-frames can reach (62 175 of 65 026; the rest needs channel
+    sums no four bytes have), each hit exactly, in all three channels; plus all 256 x 256 byte pairs for n = 2 and a
+    5-frame mix.  Byte-exact against the two-LUT formulation (the kernel uses the hardware sqrt and a multiply-high)."""
+    import torch
+    from oracle import postprocess as pp
+
+    pa = gpu
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(frames):
+        h, w = frames[0].shape[:2]
+        dev = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in frames]
+        out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        pa.average_images_device([d.data_ptr() for d in dev], out.data_ptr(), w, h, stream=st)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    wit, reached = _four_frames_reaching_every_linear_value()
+    assert len(reached) > 62000 and reached[0] == 0 and reached[-1] == 65025
+    pad = (-len(wit)) % 256
+    wit = np.concatenate([wit, np.zeros((pad, 4), np.uint8)])
+    frames = [np.repeat(wit[:, k].reshape(-1, 256, 1), 4, axis=2) for k in range(4)]
+    got = run(frames)
+    assert np.array_equal(got, pp.average_images(frames))
+    assert np.array_equal(got.reshape(-1, 4)[: len(reached), 0], pp.L_TO_S[reached])
+    a = np.broadcast_to(np.arange(256, dtype=np.uint8)[None, :, None], (256, 256, 4)).copy()
+    b = np.broadcast_to(np.arange(256, dtype=np.uint8)[:, None, None], (256, 256, 4)).copy()
+    c = (255 - a).astype(np.uint8)
+    for frames in ([a, b], [a, a, b, c, c]):
+        assert np.array_equal(run(frames), pp.average_images(frames))
