@@ -176,6 +176,9 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
 /* Scene::generate_shader_code: returns a malloc'ed NUL-terminated HIP C++ source (free with
  * ptl_free).  flags: bit0 = bake Bool/Int scene uniforms as literals, bit1 = count segments,
  * bit2 = bake every scene uniform (ints, floats, matrices; camera and other builtins stay dynamic),
+ * bit3 = clip-constant specialisation: bake every scene uniform whose evaluation reads no per-frame input (time,
+ * total_time, the camera matrix) -- what stays fixed while a clip plays; a renderer checks the compiled-in values before
+ * every draw and rebuilds (demoting what moved) if one no longer holds, so results never depend on the guess,
  * bit4 = compile the anaglyph stereo mode in (the reference's `disable_anaglyph = false`, src/main.rs:939).
  * ptl_renderer_create additionally reads bits 8-11 as an occupancy hint n (0 = none):
  * the kernel is built with __launch_bounds__(256, n), i.e. at least n waves per SIMD. */
@@ -240,6 +243,8 @@ int ptl_renderer_update(ptl_renderer* r, double seconds, int* teleported, int* b
 /* Current teleport matrix (binary64, column-major), subspace flag and world position of the camera. */
 int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16], int* in_subspace, double position[3]);
 ptl_kernel* ptl_renderer_kernel(ptl_renderer* r);
+/* how many times a draw had to rebuild the clip-specialised kernel (flags bit3) since the renderer was created */
+int ptl_renderer_rejit_count(ptl_renderer* r);
 void ptl_renderer_destroy(ptl_renderer* r);
 
 /* Place the packed rows of shard (phase, stride) into a full-frame RGBA8 image (host memory). */

@@ -50,6 +50,7 @@ PTL_MAT4, PTL_F32, PTL_I32, PTL_VEC2, PTL_VEC3, PTL_SAMPLER = range(6)
 FLAG_SPECIALIZE_INTS = 1
 FLAG_COUNT_SEGMENTS = 2
 FLAG_SPECIALIZE_ALL = 4
+FLAG_SPECIALIZE_STATIC = 8  # bake what stays constant while a clip plays (checked before every draw, rebuilt if it moved)
 FLAG_ANAGLYPH = 16  # compile the anaglyph stereo mode in (the reference's `disable_anaglyph = false`)
 
 
@@ -112,6 +113,7 @@ def _load() -> C.CDLL:
         "ptl_scene_init_animation": (ci, [vp, cp]),
         "ptl_scene_update": (ci, [vp, cd, P(cd), P(cd), P(ci), P(CalculatedCam)]),
         "ptl_renderer_update": (ci, [vp, cd, P(ci), P(ci)]),
+        "ptl_renderer_rejit_count": (ci, [vp]),
         "ptl_scene_eval_uniform": (ci, [vp, cp, P(ci), P(cd)]),
         "ptl_scene_eval_matrix": (ci, [vp, cp, P(cd)]),
         "ptl_scene_cam": (ci, [vp, P(cd)]),
@@ -428,6 +430,9 @@ class SceneRenderer:
         tel, blk = C.c_int(), C.c_int()
         _check(lib().ptl_renderer_update(self._h, float(seconds), C.byref(tel), C.byref(blk)), "update")
         return bool(tel.value), bool(blk.value)
+
+    def rejit_count(self) -> int:
+        return lib().ptl_renderer_rejit_count(self._h)
 
     def camera_state(self) -> dict:
         m, sub, pos = (C.c_double * 16)(), C.c_int(), (C.c_double * 3)()

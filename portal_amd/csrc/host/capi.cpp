@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -110,6 +111,11 @@ struct ptl_renderer {
     Camera prev_cam;
     bool has_prev_cam = false;
     CalculatedCam original_cam;  // egui memory "OriginalCam"
+    // FLAG_SPECIALIZE_STATIC: what the current kernel has compiled in, for which stage, and what had to be demoted
+    std::vector<UniformUpload> baked;
+    std::set<std::string> keep_dynamic;
+    StageRef kernel_stage;
+    int rejit_count = 0;
 };
 
 namespace {
@@ -360,11 +366,14 @@ static KernelOptions options_from_flags(unsigned flags) {
     o.count_segments = (flags & 2u) != 0;
     o.specialize_all = (flags & 4u) != 0;
     o.anaglyph = (flags & 16u) != 0;
+    o.specialize_static = (flags & 8u) != 0;
     return o;
 }
 
-static void refresh_generated(ptl_scene* s, unsigned flags) {
-    s->last = generate_kernel_source(*s->scene, CodegenFlags{}, options_from_flags(flags));
+static void refresh_generated(ptl_scene* s, unsigned flags, const std::set<std::string>* keep_dynamic = nullptr) {
+    KernelOptions opts = options_from_flags(flags);
+    if (keep_dynamic) opts.keep_dynamic = *keep_dynamic;
+    s->last = generate_kernel_source(*s->scene, CodegenFlags{}, opts);
     s->desc_names.clear();
     s->descs.clear();
     for (auto& u : s->last.uniforms) s->desc_names.push_back(u.name);
@@ -454,7 +463,10 @@ void send_camera_matrix(ptl_renderer* r) {
 
 static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     ptl_scene* s = r->owner;
-    refresh_generated(s, r->flags);
+    if (!(r->kernel_stage == r->scene->current_stage)) r->keep_dynamic.clear();  // another stage / clip: judge afresh what is constant
+    refresh_generated(s, r->flags, &r->keep_dynamic);
+    r->baked = s->last.baked;
+    r->kernel_stage = r->scene->current_stage;
     if (r->kernel && s->last.source == r->kernel_source) {  // nothing baked in changed
         r->kernel_scene_version = r->scene->version;
         return PTL_OK;
@@ -545,7 +557,15 @@ extern "C" int ptl_renderer_set_option(ptl_renderer* r, const char* name, double
     else if (n == "offset_after_material") r->offset_after_material = v;
     else if (n == "draw_side_by_side") r->draw_side_by_side = b;
     else if (n == "in_subspace") r->cam.in_subspace = b;
-    else if (n == "draw_anaglyph") r->draw_anaglyph = b;
+    else if (n == "specialize_static") {  // switch clip-constant specialisation (flags bit3) on or off for what follows
+        unsigned want = b ? (r->flags | 8u) : (r->flags & ~8u);
+        if (want != r->flags) {
+            r->flags = want;
+            r->keep_dynamic.clear();
+            int rc = build_kernel(r, nullptr, 0);
+            if (rc != PTL_OK) return rc;
+        }
+    } else if (n == "draw_anaglyph") r->draw_anaglyph = b;
     else if (n == "anaglyph_mode") r->anaglyph_mode = b;
     else if (n == "anaglyph_p") r->anaglyph_p = v;
     else if (n == "anaglyph_q") r->anaglyph_q = v;
@@ -634,7 +654,30 @@ static int prepare_draw(ptl_renderer* r, const ptl_frame* frame) {
     }
     if (r->uploaded_scene != r->scene->version) {
         std::vector<std::string> errors;
-        int rc = upload(r->kernel, evaluate_scene_uniforms(*r->scene, &errors));  // scene.set_uniforms
+        std::vector<UniformUpload> values = evaluate_scene_uniforms(*r->scene, &errors);  // scene.set_uniforms
+        if ((r->flags & 8u) != 0 && (r->flags & 5u) == 0) {
+            // clip-constant specialisation: the kernel stays valid as long as every compiled-in value still holds; a value
+            // that moved after all is demoted to a run-time uniform and the kernel is built again (cached by source hash)
+            bool stale = !(r->kernel_stage == r->scene->current_stage);
+            size_t at = 0;
+            for (const UniformUpload& b : r->baked) {
+                while (at < values.size() && values[at].name != b.name) ++at;  // same order as at generation time
+                if (at == values.size()) {
+                    stale = true;
+                    break;
+                }
+                if (!values[at].same_value(b)) {
+                    r->keep_dynamic.insert(b.name);
+                    stale = true;
+                }
+            }
+            if (stale) {
+                int rc = build_kernel(r, nullptr, 0);
+                if (rc != PTL_OK) return rc;
+                ++r->rejit_count;
+            }
+        }
+        int rc = upload(r->kernel, values);
         if (rc < 0) return rc;
         r->uploaded_scene = r->scene->version;
     }
@@ -915,6 +958,7 @@ extern "C" int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16],
 }
 
 extern "C" ptl_kernel* ptl_renderer_kernel(ptl_renderer* r) { return r ? r->kernel : nullptr; }
+extern "C" int ptl_renderer_rejit_count(ptl_renderer* r) { return r ? r->rejit_count : -1; }
 extern "C" void ptl_renderer_destroy(ptl_renderer* r) {
     if (!r) return;
     ptl_kernel_destroy(r->kernel);

@@ -33,6 +33,7 @@ void usage() {
                  "       portal-amd render <scene[,scene..]> [clip[,clip..]] [--width 3840] [--height 2160] [--fps 60] [--motion-blur-frames 1]\n"
                  "                  [--stereoimage] [--no-skip-existing] [--filter-starts-with P] [--aa-count 4] [--render-depth 150]\n"
                  "                  [--scenes-dir DIR] [--out-dir DIR] [--device I] [--shard K/N] [--max-frames N] [--asset-root DIR]\n"
+                 "                  [--specialize 0|1]   bake what is constant within a clip into the kernel (default: when it pays)\n"
                  "       portal-amd emit-source <scene.ron> [--stage NAME]     print the generated HIP kernel source\n"
                  "       portal-amd check <scene.ron> [--stage NAME]           compile for gfx950 (no GPU needed); errors by scene element\n"
                  "       portal-amd version\n");
@@ -162,7 +163,8 @@ private:
 
 struct Options {
     std::string scene, clips, output = "frame.png", asset_root = ".", stage, animation, camera, scenes_dir = "scenes", out_dir = ".", starts_with;
-    bool have_camera = false, stereo = false, skip_existing = true, aa_given = false, depth_given = false, size_given = false;
+    bool have_camera = false, stereo = false, skip_existing = true;
+    int specialize = -1;  // -1 auto: clip-constant specialisation when the clip has enough sub-frames to repay the extra JIT
     int width = 1920, height = 1080, aa = 1, depth = 100, device = 0, fps = 60, blur = 1, shard = 0, shards = 1, max_frames = -1;
     double time = 0.0, panini = -1.0, fov = 90.0;
 };
@@ -254,6 +256,7 @@ int render_frame(const Options& o) {
 int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::string& scene_name, const std::string& clip, double duration, int fps,
                 int width, int height, std::vector<void*>& subframes, void* averaged, EncoderPool& pool, PinnedFrames& pinned) {
     auto started = std::chrono::steady_clock::now();
+    int rejits_before = ptl_renderer_rejit_count(r);
     std::string video_base = o.out_dir + "/video/" + scene_name + "/" + clip;
     if (o.skip_existing && exists(video_base + ".mov")) {
         std::printf("Skip `%s/%s`, because it's already exists\n", scene_name.c_str(), clip.c_str());
@@ -313,8 +316,8 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
     }
     std::printf("\n");
     double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
-    std::printf("Traced `%s/%s`: %ld sub-frames %dx%d, GPU %.1f ms (%.3f ms each), submitted after %.2f s\n", scene_name.c_str(), clip.c_str(), traced, width,
-                height, gpu_ms, traced ? gpu_ms / traced : 0.0, wall);
+    std::printf("Traced `%s/%s`: %ld sub-frames %dx%d, GPU %.1f ms (%.3f ms each), submitted after %.2f s, kernel rebuilt %d times\n", scene_name.c_str(),
+                clip.c_str(), traced, width, height, gpu_ms, traced ? gpu_ms / traced : 0.0, wall, ptl_renderer_rejit_count(r) - rejits_before);
     (void)scene;
     return 0;
 }
@@ -322,8 +325,12 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
 // the reference's ffmpeg hand-off (src/main.rs:1829-1869), same arguments; frames are kept when there is no ffmpeg
 int encode_video(const Options& o, const std::string& scene_name, const std::string& clip, int fps) {
     if (std::system("command -v ffmpeg >/dev/null 2>&1") != 0) {
-        std::printf("ffmpeg not found: frames stay in `%s/anim` (ffmpeg -framerate %d -i anim/frame_%%d.png ... video/%s/%s.mov)\n", o.out_dir.c_str(), fps,
-                    scene_name.c_str(), clip.c_str());
+        // no encoder on this machine: park the clip's frames next to where the video would be, so the next clip starts
+        // from an empty anim/ (the reference removes anim/ after ffmpeg; frame_%d.png of another clip would be "existing")
+        std::string frames = o.out_dir + "/video/" + scene_name + "/" + clip + ".frames";
+        std::string cmd = "rm -rf '" + frames + "' && mv '" + o.out_dir + "/anim' '" + frames + "'";
+        if (std::system(cmd.c_str()) != 0) std::fprintf(stderr, "could not move anim/ to %s\n", frames.c_str());
+        std::printf("ffmpeg not found: frames kept in `%s` (ffmpeg -framerate %d -i frame_%%d.png ... ../%s.mov)\n", frames.c_str(), fps, clip.c_str());
         return 0;
     }
     std::printf("Start ffmpeg to render video\n");
@@ -393,6 +400,12 @@ int render(const Options& o) {
             int fps = o.fps;
             ptl_renderer_set_option(r, "render_depth", o.depth);
             apply_clip_overrides(scene, r, clip, &fps);
+            {  // clip-constant specialisation repays its extra JIT (~2 s) only on a clip with enough work
+                int count = std::max(1, (int)((float)todo[k].second * (float)fps));
+                double samples = (double)width * o.height * o.aa * count * o.blur;
+                bool on = o.specialize >= 0 ? o.specialize != 0 : samples >= 1e10;
+                if (ptl_renderer_set_option(r, "specialize_static", on ? 1 : 0) != PTL_OK) return fail("specialize");
+            }
             std::printf("Rendering animation %s, %zu/%zu\n", clip.c_str(), k + 1, todo.size());
             {
                 auto clip_start = std::chrono::steady_clock::now();
@@ -527,6 +540,7 @@ int main(int argc, char** argv) {
         else if (a == "--scenes-dir") o.scenes_dir = next();
         else if (a == "--out-dir") o.out_dir = next();
         else if (a == "--max-frames") o.max_frames = std::atoi(next());
+        else if (a == "--specialize") o.specialize = std::atoi(next());
         else if (a == "--shard") {
             if (std::sscanf(next(), "%d/%d", &o.shard, &o.shards) != 2 || o.shards < 1 || o.shard < 0 || o.shard >= o.shards) {
                 std::fprintf(stderr, "--shard K/N with 0 <= K < N\n");

@@ -1,6 +1,8 @@
 // codegen.cpp -- see codegen.h.
 #include "codegen.h"
 
+#include <cstring>
+
 #include <algorithm>
 #include <charconv>
 #include <cmath>
@@ -222,8 +224,15 @@ std::vector<UniformDesc> scene_uniform_list(const Scene& scene) {
     return out;
 }
 
+bool UniformUpload::same_value(const UniformUpload& o) const {
+    if (type != o.type) return false;
+    if (type == UniformType::Int1) return i == o.i;
+    return std::memcmp(f, o.f, uniform_type_size(type)) == 0;  // bit patterns: NaN == NaN, -0 != +0
+}
+
 std::vector<UniformUpload> evaluate_scene_uniforms(const Scene& scene, std::vector<std::string>* errors) {
     std::vector<UniformUpload> out;
+    std::map<int, bool> matrix_animated;
     auto put_mat = [&](const std::string& name, const DMat4& m) {
         UniformUpload u;
         u.name = name;
@@ -241,10 +250,15 @@ std::vector<UniformUpload> evaluate_scene_uniforms(const Scene& scene, std::vect
         if (scene.matrices[k].named) passed.push_back((int)k);
     for (int idx : passed) {
         const std::string& name = scene.matrices[idx].name;
+        scene.take_frame_input_mark();
         auto m = scene.eval_matrix(idx);
+        bool animated = scene.take_frame_input_mark();
+        matrix_animated[idx] = animated;
         if (m) {
             put_mat(normal_name(name), *m);
+            out.back().animated = animated;
             put_mat(inverse_name(name), m->inverse());
+            out.back().animated = animated;
         } else if (errors) {
             errors->push_back("matrix `" + name + "` can't be getted");
         }
@@ -257,8 +271,13 @@ std::vector<UniformUpload> evaluate_scene_uniforms(const Scene& scene, std::vect
         if (!a || !b) continue;
         const std::string& na = scene.matrices[o.m0].name;
         const std::string& nb = scene.matrices[o.m1].name;
+        bool animated = matrix_animated[o.m0] || matrix_animated[o.m1];
         put_mat(teleport_name(na, nb), *b * a->inverse());
-        if (na != nb) put_mat(teleport_name(nb, na), *a * b->inverse());
+        out.back().animated = animated;
+        if (na != nb) {
+            put_mat(teleport_name(nb, na), *a * b->inverse());
+            out.back().animated = animated;
+        }
     }
     // user uniforms (scene.rs:637-656)
     for (size_t k = 0; k < scene.uniforms.size(); ++k) {
@@ -275,12 +294,15 @@ std::vector<UniformUpload> evaluate_scene_uniforms(const Scene& scene, std::vect
             }
             continue;
         }
+        scene.take_frame_input_mark();
         auto v = scene.eval_uniform((int)k);
+        bool animated = scene.take_frame_input_mark();
         if (!v) {
             if (errors) errors->push_back("Error getting `" + e.name + "` uniform");
             continue;
         }
         UniformUpload u;
+        u.animated = animated;
         u.name = e.name + "_u";
         if (v->kind == UniformValue::Float) {
             u.type = UniformType::Float1;
@@ -345,7 +367,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         // JIT-time specialisation: current values baked in as literals (same arithmetic, the
         // compiler folds branches on mode switches / ray-independent subexpressions)
         std::map<std::string, std::string> baked;
-        if (opts.specialize_ints || opts.specialize_all) {
+        if (opts.specialize_ints || opts.specialize_all || opts.specialize_static) {
             auto hexf = [](float v) -> std::string {
                 if (std::isnan(v)) return "__builtin_nanf(\"\")";
                 if (std::isinf(v)) return v > 0 ? "__builtin_inff()" : "(-__builtin_inff())";
@@ -355,15 +377,21 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             };
             for (auto& up : evaluate_scene_uniforms(scene, nullptr)) {
                 if (up.name == "teleport_light_u") continue;  // forced to 1 by the camera-teleport query (src/main.rs:1367)
+                if (opts.keep_dynamic.count(up.name)) continue;
+                if (opts.specialize_static && up.animated) continue;  // changes every frame: stays a run-time uniform
+                bool all = opts.specialize_all || opts.specialize_static;
                 if (up.type == UniformType::Int1) {
                     baked[up.name] = std::to_string(up.i);
-                } else if (opts.specialize_all && up.type == UniformType::Float1) {
+                } else if (all && up.type == UniformType::Float1) {
                     baked[up.name] = hexf(up.f[0]);
-                } else if (opts.specialize_all && up.type == UniformType::Mat4) {
+                } else if (all && up.type == UniformType::Mat4) {
                     std::string m = "mat4(";
                     for (int k = 0; k < 16; ++k) m += (k ? ", " : "") + hexf(up.f[k]);
                     baked[up.name] = m + ")";
+                } else {
+                    continue;
                 }
+                gk.baked.push_back(up);
             }
         }
         for (auto& u : list) {

@@ -9,6 +9,7 @@
 // for hiprtc, which the host build (oracle/host_build) compiles unchanged with g++.
 #pragma once
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -60,11 +61,23 @@ struct UniformDesc {
 };
 size_t uniform_type_size(UniformType t);
 
+// One evaluated uniform value, as Scene::set_uniforms (scene.rs:545-657) would upload it.
+struct UniformUpload {
+    std::string name;
+    UniformType type;
+    float f[16] = {0};
+    int i = 0;
+    bool animated = false;  // its evaluation read time / total_time / the camera matrix: changes from frame to frame
+    bool same_value(const UniformUpload& o) const;
+};
+
 struct KernelOptions {
     bool specialize_ints = false;  // bake current Bool/Int uniform values in as literals (recompile when they change)
     bool specialize_all = false;   // also bake Float / matrix scene uniforms (not the camera / builtins)
     bool count_segments = false;   // compile with PTL_COUNT_SEGMENTS
     bool anaglyph = false;         // compile the !ANAGLYPH! code in (the reference's `disable_anaglyph = false`)
+    bool specialize_static = false;  // bake every scene uniform whose evaluation does not read a per-frame input ...
+    std::set<std::string> keep_dynamic;  // ... except these (values that changed after all: demoted by the renderer)
 };
 
 struct GeneratedKernel {
@@ -73,6 +86,7 @@ struct GeneratedKernel {
     std::vector<UniformDesc> uniforms;  // block layout: samplers first, then Scene::uniforms() order
     size_t uniform_block_size = 0;
     std::vector<std::string> defines;   // e.g. "PTL_COUNT_SEGMENTS"
+    std::vector<UniformUpload> baked;   // the values compiled in as literals (specialised builds)
 };
 
 // Scene::uniforms (scene.rs:424-543): names and types, in the reference's order.
@@ -82,13 +96,6 @@ std::vector<std::string> scene_texture_list(const Scene& scene);
 
 GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& flags, const KernelOptions& opts);
 
-// One evaluated uniform value, as Scene::set_uniforms (scene.rs:545-657) would upload it.
-struct UniformUpload {
-    std::string name;
-    UniformType type;
-    float f[16] = {0};
-    int i = 0;
-};
 // All scene-derived uniforms: X_mat, X_mat_inv, A_to_B_mat_teleport, user uniforms.
 // `errors` receives the reference's "matrix `x` can't be getted" style messages.
 std::vector<UniformUpload> evaluate_scene_uniforms(const Scene& scene, std::vector<std::string>* errors);

@@ -761,8 +761,14 @@ std::optional<double> Scene::eval_formula(const std::string& text) const {
         bool known = false;
         auto r = formula_custom_function(name, args, &known);
         if (known) return r;
-        if (name == "time") return time;
-        if (name == "total_time") return total_time;
+        if (name == "time") {
+            frame_input_read_ = true;
+            return time;
+        }
+        if (name == "total_time") {
+            frame_input_read_ = true;
+            return total_time;
+        }
         int idx = find_uniform(name);  // free variable = another named uniform
         if (idx < 0) return std::nullopt;
         auto v = eval_uniform(idx);
@@ -885,7 +891,7 @@ std::optional<DMat4> Scene::eval_matrix(int index) const {
             if (!a) return std::nullopt;
             return a->inverse();
         }
-        case Matrix::Camera: return camera_matrix;
+        case Matrix::Camera: frame_input_read_ = true; return camera_matrix;
         case Matrix::Lerp: {  // src/gui/matrix.rs:614-627: decompose both into TRS, blend each part, recompose
             auto t = eval_param(m.cond);
             if (!t) return std::nullopt;

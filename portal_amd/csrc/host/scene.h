@@ -199,6 +199,13 @@ public:
     std::optional<UniformValue> eval_uniform(int index) const;
     std::optional<DMat4> eval_matrix(int index) const;
     std::optional<double> eval_param(const Param& p) const;
+    // Did any evaluation since the last call read a per-frame input (`time`, `total_time`, Matrix::Camera)?  Clears the mark.
+    // (How the kernel specialiser tells clip-constant values from animated ones.)
+    bool take_frame_input_mark() const {
+        bool t = frame_input_read_;
+        frame_input_read_ = false;
+        return t;
+    }
     // the element a uniform currently evaluates as (stage / clip replacements followed); nullptr if out of range
     const Uniform* resolved_uniform(int index) const;
 
@@ -229,6 +236,7 @@ public:
 private:
     mutable std::map<std::string, std::shared_ptr<Formula>> formula_cache_;
     mutable std::vector<char> uniform_busy_, matrix_busy_;  // cycle guards (Storage2::get)
+    mutable bool frame_input_read_ = false;
     std::optional<double> eval_formula(const std::string& text) const;
 };
 

@@ -397,7 +397,8 @@ def test_render_cli_writes_the_frames_the_library_draws(gpu, tmp_path):
             r.update((i / count + j / blur / count * 0.5) * float(np.float32(duration)))
             subs.append(r.draw(w, h)["rgba8"])
         want = pp.average_images(subs)
-        got = pa.png_read(str(tmp_path / "anim" / f"frame_{i}.png"))
+        frames_dir = tmp_path / "anim" if (tmp_path / "anim").exists() else tmp_path / "video" / "basics" / f"{clip}.frames"  # parked when there is no ffmpeg
+        got = pa.png_read(str(frames_dir / f"frame_{i}.png"))
         assert np.array_equal(got, want), i
         if i == 0:
             assert np.array_equal(pa.png_read(str(tmp_path / "video" / "basics" / f"{clip}.start.png")), subs[0])
@@ -509,3 +510,37 @@ def test_average_images_every_linear_value(gpu):
     c = (255 - a).astype(np.uint8)
     for frames in ([a, b], [a, a, b, c, c]):
         assert np.array_equal(run(frames), pp.average_images(frames))
+
+
+def test_clip_constant_specialisation_never_changes_a_frame(gpu):
+    """FLAG_SPECIALIZE_STATIC through two clips: every frame == the un-specialised kernel's, bit for bit; the kernel is rebuilt
+    when the clip changes (other constants), not from frame to frame; a uniform the guess got wrong (set by hand between
+    draws) is demoted instead of going stale."""
+    pa = gpu
+    path = pa.scene_path("portal_in_portal")
+    sa, sb = pa.Scene.from_file(path), pa.Scene.from_file(path)
+    ra, rb = pa.SceneRenderer(sa, device=0), pa.SceneRenderer(sb, device=0, flags=pa.FLAG_SPECIALIZE_STATIC)
+    for r in (ra, rb):
+        r.set_option("render_depth", 12)
+    clips = dict(sa.animations())
+    w, h = 96, 54
+    rebuilds = []
+    for clip in ("intro.2", "intro.4"):
+        sa.init_animation(clip)
+        sb.init_animation(clip)
+        before = rb.rejit_count()
+        for i in range(4):
+            t = i / 4 * clips[clip]
+            ra.update(t)
+            rb.update(t)
+            a = ra.draw(w, h, rgba32f=True)["rgba32f"]
+            b = rb.draw(w, h, rgba32f=True)["rgba32f"]
+            assert _bits_equal(a, b).all(), (clip, i)
+        rebuilds.append(rb.rejit_count() - before)
+    assert rebuilds[0] <= 1 and rebuilds[1] == 1                     # once per clip at most
+    before = rb.rejit_count()
+    for s_ in (sa, sb):
+        s_.set_uniform("portal_scale", 0.8)                          # a constant of the clip, changed behind the specialiser's back
+    a = ra.draw(w, h, rgba32f=True)["rgba32f"]
+    b = rb.draw(w, h, rgba32f=True)["rgba32f"]
+    assert _bits_equal(a, b).all() and rb.rejit_count() == before + 1

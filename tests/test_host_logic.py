@@ -542,3 +542,25 @@ def test_average_images_multiply_high_is_the_integer_division():
         assert np.array_equal((x * magic) >> np.uint64(32), x // np.uint64(n)), n
     s = np.sqrt(np.arange(65026, dtype=np.float64))
     assert np.abs((s + 0.5) - np.rint(s + 0.5)).min() > 4.8e-4
+
+
+def test_clip_constant_specialisation_bakes_only_what_the_clip_keeps_fixed(pa):
+    """FLAG_SPECIALIZE_STATIC: portal_in_portal clip `intro.4` pins progress = 1 (a constant: baked) and animates
+    progress_2 = easing_in_out(1 - time) (reads `time`: stays a run-time uniform, and so does every matrix built from it);
+    builtins (camera ...) and teleport_light_u are never baked."""
+    import re
+
+    s = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    s.init_animation("intro.4")
+    s.update(0.3)
+    src = s.generate_source(pa.FLAG_SPECIALIZE_STATIC)
+    define = lambda name: re.search(r"#define %s \((.*)\)\n" % re.escape(name), src).group(1)
+    assert define("progress_u") == "0x1p+0f"
+    assert define("progress_2_u") == "PTL_U.progress_2_u"
+    assert define("a_mat").startswith("mat4(") and define("b0_mat") == "PTL_U.b0_mat" and define("b0_mat_inv") == "PTL_U.b0_mat_inv"
+    assert define("_camera") == "PTL_U._camera" and define("teleport_light_u") == "PTL_U.teleport_light_u"
+    plain = s.generate_source(0)
+    assert "#define progress_u (PTL_U.progress_u)" in plain
+    # a still (no clip, nothing reads time): everything is constant, same text as FLAG_SPECIALIZE_ALL
+    still = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    assert still.generate_source(pa.FLAG_SPECIALIZE_STATIC) == still.generate_source(pa.FLAG_SPECIALIZE_ALL)
