@@ -528,8 +528,8 @@ class OracleScene:
             return ("Camera",)
         if t == "Lerp":
             return ("Lerp", self._param(v["t"]), self._mref(v["first"]), self._mref(v["second"]))
-        if t == "Sqrt":  # BFGS matrix square root: not a defined function, stays "can't be getted" (but its operand is still an element)
-            return ("Unsupported", t, self._mref(v.items[0]))
+        if t == "Sqrt":
+            return ("Sqrt", self._mref(v.items[0]))
         return ("Unsupported", t)
 
     # --- evaluation
@@ -642,6 +642,21 @@ class OracleScene:
         if t == "Inv":
             a = self.eval_matrix(node[1])
             return None if a is None else m_inverse(a)
+        if t == "Sqrt":  # src/gui/matrix.rs:606-612: M with M*M = A.  The reference takes what a BFGS minimiser reaches (residual < 1e-4);
+            a = self.eval_matrix(node[1])  # this is the exact principal root (Denman-Beavers), the point that minimisation heads for
+            if a is None:
+                return None
+            y, z = a, IDENT
+            half = lambda p, q: [[(p[c][r] + q[c][r]) * 0.5 for r in range(4)] for c in range(4)]
+            for _ in range(64):
+                yn, zn = half(y, m_inverse(z)), half(z, m_inverse(y))
+                done = yn == y
+                y, z = yn, zn
+                if done:
+                    break
+            sq = m_mul(y, y)
+            err = sum((sq[c][r] - a[c][r]) ** 2 for c in range(4) for r in range(4))
+            return y if err < 1e-9 else None
         if t == "Lerp":  # src/gui/matrix.rs:614-627 on glam 0.13's to_scale_rotation_translation / Quat::lerp / Vec3::lerp
             tt = self._p(node[1])
             a = None if tt is None else self.eval_matrix(node[2])

@@ -156,6 +156,32 @@ struct DMat4 {
         double dot1 = dot0.x + dot0.y + dot0.z + dot0.w;
         return inv * (1.0 / dot1);
     }
+    DMat4 operator+(const DMat4& o) const { return from_cols(c[0] + o.c[0], c[1] + o.c[1], c[2] + o.c[2], c[3] + o.c[3]); }
+    bool same_bits(const DMat4& o) const {
+        for (int k = 0; k < 4; ++k)
+            if (c[k].x != o.c[k].x || c[k].y != o.c[k].y || c[k].z != o.c[k].z || c[k].w != o.c[k].w) return false;
+        return true;
+    }
+    // Principal square root by the Denman-Beavers iteration Y <- (Y + Z^-1)/2, Z <- (Z + Y^-1)/2 from (A, I): Y -> A^(1/2).
+    // Stops when Y repeats bit for bit (quadratic convergence: ~8 rounds) or after 64 rounds; *ok = Y*Y reproduces A to 1e-9.
+    DMat4 sqrt_principal(bool* ok) const {
+        DMat4 y = *this, z = identity();
+        for (int round = 0; round < 64; ++round) {
+            DMat4 yn = (y + z.inverse()) * 0.5, zn = (z + y.inverse()) * 0.5;
+            bool done = yn.same_bits(y);
+            y = yn;
+            z = zn;
+            if (done) break;
+        }
+        DMat4 sq = y * y;
+        double err = 0.0;
+        for (int k = 0; k < 4; ++k) {
+            DVec4 d = sq.c[k] - c[k];
+            err += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+        }
+        *ok = err < 1e-9;  // also false for NaN (a matrix without a real square root diverges)
+        return y;
+    }
     // as_f32(): one round-to-nearest per element, column-major
     void to_f32(float out[16]) const {
         for (int k = 0; k < 4; ++k) {

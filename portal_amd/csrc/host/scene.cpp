@@ -905,11 +905,17 @@ std::optional<DMat4> Scene::eval_matrix(int index) const {
             second->to_scale_rotation_translation(&ss, &sr, &st);
             return DMat4::from_scale_rotation_translation(fs.lerp(ss, *t), fr.lerp(sr, *t), ft.lerp(st, *t));
         }
-        case Matrix::Sqrt:
-            // src/gui/matrix.rs:606-612,909-988: the square root comes out of a BFGS minimiser (argmin + finite differences),
-            // i.e. its digits are an artefact of that solver's iteration, not a defined function: out of scope, reported as
-            // "can't be getted" (one use in the corpus, portal_in_portal_plus_ultra).
-            return std::nullopt;
+        case Matrix::Sqrt: {
+            // src/gui/matrix.rs:606-612,909-988 gets M with M*M ~ A from a BFGS minimiser (argmin, <= 60 iterations, accepted when
+            // the squared residual is < 1e-4), i.e. a loose approximation whose digits belong to that solver.  Here: the exact
+            // principal square root (Denman-Beavers), which is what that minimisation converges towards from its start M = A.
+            auto a = eval_matrix(m.a);
+            if (!a) return std::nullopt;
+            bool ok = false;
+            DMat4 root = a->sqrt_principal(&ok);
+            if (!ok) return std::nullopt;  // "Can't calculate sqrt!"
+            return root;
+        }
     }
     return std::nullopt;
 }

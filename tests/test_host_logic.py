@@ -564,3 +564,28 @@ def test_clip_constant_specialisation_bakes_only_what_the_clip_keeps_fixed(pa):
     # a still (no clip, nothing reads time): everything is constant, same text as FLAG_SPECIALIZE_ALL
     still = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
     assert still.generate_source(pa.FLAG_SPECIALIZE_STATIC) == still.generate_source(pa.FLAG_SPECIALIZE_ALL)
+
+
+def test_matrix_sqrt_known_answers(pa):
+    """Matrix::Sqrt (src/gui/matrix.rs:606-612): M * M == A.  Half of (rotate 90 degrees about z, scale 4, move (3, 0, 0)) is
+    (rotate 45 degrees, scale 2, and the translation t with (I + M) t = (3, 0, 0)); product == oracle bit for bit; a
+    reflection has no real square root -> "can't be getted"."""
+    from oracle.scene_eval import OracleScene
+    from tests import synthetic
+
+    extra = '''
+        (name: "far", data: Simple(offset: (3.0, 0.0, 0.0), scale: 4.0, rotate: (0.0, 0.0, 1.5707963267948966), mirror: (false, false, false))),
+        (name: "half", data: Sqrt(Some(Named("far")))),
+        (name: "flip", data: Simple(offset: (0.0, 0.0, 0.0), scale: 1.0, rotate: (0.0, 0.0, 0.0), mirror: (true, false, false))),
+        (name: "no_root", data: Sqrt(Some(Named("flip")))),
+    '''
+    text = synthetic.wall_scene(extra_matrices=extra)
+    s, o = pa.Scene.from_text(text), OracleScene(text, is_text=True)
+    far, half = s.eval_matrix("far"), s.eval_matrix("half")
+    assert half @ half == pytest.approx(far, abs=1e-12)
+    c = 2 * math.sqrt(0.5)
+    assert half[:3, :3] == pytest.approx(np.array([[c, -c, 0], [c, c, 0], [0, 0, 2]]), abs=1e-12)
+    assert s.eval_matrix("no_root") is None
+    got, want = s.uniform_values(), o.scene_uniform_values()
+    assert "no_root_mat" not in got and "no_root_mat" not in want
+    _same_uniforms(got, want, "sqrt")
