@@ -10,6 +10,9 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <dirent.h>
+
+#include <algorithm>
 #include <set>
 #include <string>
 #include <vector>
@@ -116,6 +119,13 @@ struct ptl_renderer {
     std::set<std::string> keep_dynamic;
     StageRef kernel_stage;
     int rejit_count = 0;
+    // VideoRuntime (src/main.rs:771-925): per video, the sorted frame files and the frame currently bound
+    struct VideoState {
+        bool scanned = false;
+        std::vector<std::string> frames;
+        long bound = -1;
+    };
+    std::vector<VideoState> videos;
 };
 
 namespace {
@@ -461,6 +471,54 @@ void send_camera_matrix(ptl_renderer* r) {
 
 }  // namespace
 
+namespace {
+
+// VideoRuntime::update (src/main.rs:849-924): frame index = round((count - 1) * clamp(uniform, 0, 1)); a changed index loads
+// that PNG and binds it to the video's sampler.  IO errors are ignored like there (the sampler keeps its previous frame).
+int update_videos(ptl_renderer* r) {
+    const Scene& scene = *r->scene;
+    if (scene.video_sources.empty() || r->device < 0) return PTL_OK;
+    r->videos.resize(scene.video_sources.size());
+    for (size_t k = 0; k < scene.video_sources.size(); ++k) {
+        const Scene::Video& v = scene.video_sources[k];
+        ptl_renderer::VideoState& st = r->videos[k];
+        if (v.path.empty() || v.uniform < 0) continue;
+        if (!st.scanned) {  // video_collect_frame_files: video_png/<file stem>/*.png, sorted
+            st.scanned = true;
+            std::string base = v.path.substr(v.path.rfind('/') == std::string::npos ? 0 : v.path.rfind('/') + 1);
+            std::string stem = base.substr(0, base.rfind('.') == std::string::npos ? base.size() : base.rfind('.'));
+            std::string dir = (r->asset_root.empty() ? std::string() : r->asset_root + "/") + "video_png/" + stem;
+            if (DIR* d = opendir(dir.c_str())) {
+                while (dirent* e = readdir(d)) {
+                    std::string name = e->d_name;
+                    if (name.size() > 4 && name.compare(name.size() - 4, 4, ".png") == 0) st.frames.push_back(dir + "/" + name);
+                }
+                closedir(d);
+            }
+            std::sort(st.frames.begin(), st.frames.end());
+        }
+        if (st.frames.empty()) continue;
+        auto value = scene.eval_uniform(v.uniform);
+        if (!value) continue;
+        double x = value->as_f64();
+        x = x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x);  // f64::clamp; NaN stays NaN and ends up as index 0 below
+        double last = (double)(st.frames.size() - 1);
+        double target = std::round(last * x);
+        long index = std::isnan(target) ? 0 : (long)(target < 0.0 ? 0.0 : (target > last ? last : target));
+        if (index == st.bound) continue;
+        uint8_t* px = nullptr;
+        int w = 0, h = 0;
+        if (ptl_png_read(st.frames[index].c_str(), &px, &w, &h) != PTL_OK) continue;
+        int rc = ptl_kernel_set_texture(r->kernel, (v.name + "_tex").c_str(), px, w, h);
+        std::free(px);
+        if (rc < 0) return rc;
+        st.bound = index;
+    }
+    return PTL_OK;
+}
+
+}  // namespace
+
 static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     ptl_scene* s = r->owner;
     if (!(r->kernel_stage == r->scene->current_stage)) r->keep_dynamic.clear();  // another stage / clip: judge afresh what is constant
@@ -503,7 +561,8 @@ static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     r->kernel_scene_version = r->scene->version;
     r->uploaded_scene = 0;  // a fresh uniform block: upload everything again
     r->uploaded_options = 0;
-    return PTL_OK;
+    for (auto& v : r->videos) v.bound = -1;  // ... and fresh samplers: bind the current video frames again
+    return update_videos(r);
 }
 
 extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_root, unsigned flags, ptl_renderer** out, char* log,
@@ -934,6 +993,7 @@ extern "C" int ptl_renderer_update(ptl_renderer* r, double seconds, int* telepor
         r->prev_cam = cam;
         send_camera_matrix(r);
         ++r->options_version;
+        if (rc == PTL_OK) rc = update_videos(r);
         return rc;
     });
 }

@@ -230,6 +230,14 @@ struct Loader {
         for (const Value& v : storage_list(doc, "videos", false).items) scene.videos.push_back(as_string(v.at("name"), "video name"));
         for (const Value& u : storage_list(doc, "uniforms", true).items)
             scene.uniforms.push_back(UniformEntry{as_string(u.at("name"), "uniform name"), parse_uniform(u.at("data"))});
+        for (const Value& v : storage_list(doc, "videos", false).items) {  // second pass: the frame-position uniform can be named now
+            Scene::Video video;
+            video.name = as_string(v.at("name"), "video name");
+            const Value& d = v.at("data");
+            if (const Value* path = d.find("path")) video.path = as_string(*path, "video path");
+            if (const Value* u = d.find("uniform")) video.uniform = uniform_ref(*u);
+            scene.video_sources.push_back(std::move(video));
+        }
 
         const Value& mats = storage_list(doc, "matrices", true);
         for (const Value& m : mats.items) {

@@ -171,7 +171,14 @@ public:
     std::vector<NamedCode> intersection_materials;
     std::vector<NamedCode> library;
     std::vector<Texture> textures;
-    std::vector<std::string> videos;  // names only: a video is one more sampler (src/gui/scene.rs:405-409); frames are out of scope
+    std::vector<std::string> videos;  // names: a video is one more sampler (src/gui/scene.rs:405-409)
+    // Video (src/gui/video.rs, VideoSer scene_serialized.rs:51-55): frames are the PNG files of video_png/<stem of path>/, the one
+    // shown is picked by a uniform in [0, 1] (VideoRuntime, src/main.rs:771-925)
+    struct Video {
+        std::string name, path;
+        int uniform = -1;
+    };
+    std::vector<Video> video_sources;
     std::optional<std::string> skybox;
     bool use_time = false;
     std::vector<SceneCamera> cameras;

@@ -544,3 +544,35 @@ def test_clip_constant_specialisation_never_changes_a_frame(gpu):
     a = ra.draw(w, h, rgba32f=True)["rgba32f"]
     b = rb.draw(w, h, rgba32f=True)["rgba32f"]
     assert _bits_equal(a, b).all() and rb.rejit_count() == before + 1
+
+
+def test_video_texture_follows_its_uniform(gpu, tmp_path):
+    """Video textures (VideoRuntime, src/main.rs:771-925): the sampler of a `videos` entry shows frame
+    round((count - 1) * clamp(uniform, 0, 1)) of video_png/<stem>/*.png (sorted).  Three one-colour frames, uniform = time:
+    the wall takes the colour of the frame the formula picks, also after the kernel has been rebuilt in between."""
+    from tests import synthetic
+
+    pa = gpu
+    colours = [(255, 0, 0), (0, 255, 0), (0, 0, 255)]
+    frames_dir = tmp_path / "video_png" / "clip"
+    frames_dir.mkdir(parents=True)
+    for k, c in enumerate(colours):
+        img = np.zeros((4, 4, 4), np.uint8)
+        img[..., :3] = c
+        img[..., 3] = 255
+        pa.png_write(str(frames_dir / f"frame_{k:03d}.png"), img)
+    mat = '(name: "screen", data: Complex(code: (("MaterialProcessing result = material_simple(hit, r, vec3(1.0, 1.0, 1.0), 0.0, false, 1.0, 0.0);\\nresult.mul_to_color *= texture(vid_tex, vec2(0.5, 0.5)).rgb;\\nreturn result;")))),'
+    text = synthetic.wall_scene(extra_materials=mat).replace("return wall_M; }", "return screen_M; }")
+    text = text.replace('uniforms: ([', 'uniforms: ([ (name: "pos", data: Formula(("time"))),')
+    text = text.replace("    textures: ([]),", '    textures: ([]),\n    videos: ([ (name: "vid", data: (path: "somewhere/clip.mov", uniform: Some(Named("pos")))) ]),')
+    scene = pa.Scene.from_text(text)
+    r = pa.SceneRenderer(scene, device=0, asset_root=str(tmp_path), flags=pa.FLAG_SPECIALIZE_STATIC)
+    seen = []
+    for t in (0.0, 0.2, 0.3, 0.74, 0.76, 1.0, 7.5):
+        r.update(t)
+        px = r.draw(16, 16)["rgba8"][8, 8]
+        seen.append(tuple(int(x) for x in px[:3]))
+    assert seen == [colours[k] for k in (0, 0, 1, 1, 2, 2, 2)]
+    scene.set_uniform("size", 500.0)      # a baked constant moves: kernel rebuilt, the current frame must be bound again
+    r.update(0.5)
+    assert tuple(int(x) for x in r.draw(16, 16)["rgba8"][8, 8][:3]) == colours[1] and r.rejit_count() >= 1
