@@ -273,9 +273,18 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
     ptl_frame frame{width, height, 0, 1};
     int last = o.max_frames >= 0 ? std::min(count, o.max_frames) : count;
     for (int i = 0; i < last; ++i) {
-        if (i % o.shards != o.shard) continue;  // frames are independent: shard K of N takes every N-th
         std::string name = anim_dir + "/frame_" + std::to_string(i) + ".png";
-        if (exists(name)) continue;
+        if (i % o.shards != o.shard || exists(name)) {
+            // Not ours (shard K of N takes every N-th frame) or already on disk.  The camera is stateful -- where it is relative
+            // to the portals depends on the path it took (teleport_camera) -- so the host step still runs for every sub-frame:
+            // a shard, or a resumed run, then sees exactly the cameras of an uninterrupted run.  (The reference skips the
+            // update as well, src/main.rs:1789-1792, and so renders a resumed clip from a different camera history.)
+            for (int j = 0; j < o.blur; ++j) {
+                double t = ((double)i / count) + (double)j / o.blur / count * exposure;
+                if (ptl_renderer_update(r, t * (double)(float)duration, nullptr, nullptr) != PTL_OK) return fail("update");
+            }
+            continue;
+        }
         for (int j = 0; j < o.blur; ++j) {
             double t = ((double)i / count) + (double)j / o.blur / count * exposure;
             ptl_renderer_set_option(r, "aa_start", j);
