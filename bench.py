@@ -38,7 +38,7 @@ def profiled_traffic(args, waves):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_*.json: FETCH_SIZE and
     WRITE_SIZE are collected in separate passes, KB units, FETCH_SIZE doubled per the gfx950 note in
     MI355X_MICROARCH.md) -- only when that profile is of exactly this workload and build, else None."""
-    if (args.scene, args.width, args.height, args.depth, args.aa, args.specialize) != ("portal_in_portal", 3840, 2160, 40, 1, 2) or waves not in (0, 4):
+    if (args.scene, args.width, args.height, args.depth, args.aa, args.specialize) != ("portal_in_portal", 3840, 2160, 40, 1, 2) or waves not in (0, 3, 4):
         return None
     try:
         c = json.load(open(os.path.join(HERE, "profiles", "r01", f"pmc_pip4k_spec_w{waves}.json")))["counters"]
