@@ -6,7 +6,10 @@
 // Video pipeline (render): for every frame i of a clip, `motion_blur_frames` sub-frames are traced straight into
 // device buffers (aa_start = j, time = i/count + j/blur/count*exposure), averaged on the GPU (ptl_average_images),
 // downloaded once, and PNG-encoded on a pool of host threads while the GPU already traces the next frame.
+#include <dirent.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -331,27 +334,64 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
     return 0;
 }
 
+// Run a program without a shell (arguments are passed as they are: no quoting rules to get wrong).  -1 = could not start.
+int run_program(const std::vector<std::string>& argv, bool quiet) {
+    pid_t pid = fork();
+    if (pid < 0) return -1;
+    if (pid == 0) {
+        if (quiet) {
+            int null_fd = open("/dev/null", O_WRONLY);
+            if (null_fd >= 0) {
+                dup2(null_fd, 1);
+                dup2(null_fd, 2);
+            }
+        }
+        std::vector<char*> args;
+        for (const std::string& a : argv) args.push_back(const_cast<char*>(a.c_str()));
+        args.push_back(nullptr);
+        execvp(args[0], args.data());
+        _exit(127);
+    }
+    int status = 0;
+    if (waitpid(pid, &status, 0) < 0) return -1;
+    return WIFEXITED(status) ? WEXITSTATUS(status) : -1;
+}
+
+void remove_tree(const std::string& path) {  // rm -rf of a directory we created ourselves (frames only, one level)
+    if (DIR* d = opendir(path.c_str())) {
+        while (dirent* e = readdir(d)) {
+            std::string name = e->d_name;
+            if (name != "." && name != "..") ::unlink((path + "/" + name).c_str());
+        }
+        closedir(d);
+    }
+    ::rmdir(path.c_str());
+}
+
 // the reference's ffmpeg hand-off (src/main.rs:1829-1869), same arguments; frames are kept when there is no ffmpeg
 int encode_video(const Options& o, const std::string& scene_name, const std::string& clip, int fps) {
-    if (std::system("command -v ffmpeg >/dev/null 2>&1") != 0) {
+    std::string anim = o.out_dir + "/anim", video = o.out_dir + "/video/" + scene_name + "/" + clip + ".mov";
+    if (run_program({"ffmpeg", "-version"}, true) != 0) {
         // no encoder on this machine: park the clip's frames next to where the video would be, so the next clip starts
         // from an empty anim/ (the reference removes anim/ after ffmpeg; frame_%d.png of another clip would be "existing")
         std::string frames = o.out_dir + "/video/" + scene_name + "/" + clip + ".frames";
-        std::string cmd = "rm -rf '" + frames + "' && mv '" + o.out_dir + "/anim' '" + frames + "'";
-        if (std::system(cmd.c_str()) != 0) std::fprintf(stderr, "could not move anim/ to %s\n", frames.c_str());
+        remove_tree(frames);
+        if (::rename(anim.c_str(), frames.c_str()) != 0) std::fprintf(stderr, "could not move anim/ to %s\n", frames.c_str());
         std::printf("ffmpeg not found: frames kept in `%s` (ffmpeg -framerate %d -i frame_%%d.png ... ../%s.mov)\n", frames.c_str(), fps, clip.c_str());
         return 0;
     }
     std::printf("Start ffmpeg to render video\n");
-    std::string cmd = "cd '" + o.out_dir + "' && ffmpeg -framerate " + std::to_string(fps) +
-                      " -i anim/frame_%d.png -vf zscale=primariesin=bt709:transferin=iec61966-2-1:matrixin=bt709:rangein=full:primaries=bt709:"
-                      "transfer=iec61966-2-1:matrix=bt709:range=full,format=yuv420p10le -c:v libx265 -pix_fmt yuv420p10le -crf 15 -preset slow "
-                      "-x265-params colorprim=bt709:transfer=iec61966-2-1:colormatrix=bt709:range=full -colorspace bt709 -color_primaries bt709 "
-                      "-color_trc iec61966-2-1 -color_range pc -movflags +write_colr+faststart -tag:v hvc1 -y 'video/" +
-                      scene_name + "/" + clip + ".mov' >/dev/null 2>&1";
-    int status = std::system(cmd.c_str());
-    std::printf("ffmpeg status: %d\n", status);
-    if (status == 0 && std::system(("rm -rf '" + o.out_dir + "/anim'").c_str()) != 0) std::fprintf(stderr, "could not remove anim/\n");
+    auto started = std::chrono::steady_clock::now();
+    int status = run_program(
+        {"ffmpeg", "-framerate", std::to_string(fps), "-i", anim + "/frame_%d.png", "-vf",
+         "zscale=primariesin=bt709:transferin=iec61966-2-1:matrixin=bt709:rangein=full:primaries=bt709:transfer=iec61966-2-1:matrix=bt709:range=full,"
+         "format=yuv420p10le",
+         "-c:v", "libx265", "-pix_fmt", "yuv420p10le", "-crf", "15", "-preset", "slow", "-x265-params",
+         "colorprim=bt709:transfer=iec61966-2-1:colormatrix=bt709:range=full", "-colorspace", "bt709", "-color_primaries", "bt709", "-color_trc",
+         "iec61966-2-1", "-color_range", "pc", "-movflags", "+write_colr+faststart", "-tag:v", "hvc1", "-y", video},
+        true);
+    std::printf("ffmpeg status: %d\nffmpeg time: %.2f s\n", status, std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count());
+    remove_tree(anim);  // like the reference, whatever ffmpeg said (src/main.rs:1860)
     return 0;
 }
 
