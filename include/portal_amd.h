@@ -269,6 +269,14 @@ int ptl_device_download(void* host_dst, const void* device_src, size_t bytes, vo
 int ptl_host_alloc(size_t bytes, void** out);
 int ptl_host_free(void* p);
 
+/* The scene writer (serialize_scene_new_format + ron::ser::to_string_pretty, src/gui/scene_serialized.rs:22-24,654-1100):
+ * the scene as a .ron document in the reference's own layout, malloc'ed (ptl_free).  The document the scene was loaded from is
+ * kept whole and edited in step with the model (uniform values set through ptl_scene_set_uniform, the current stage, the cam
+ * block), so an unmodified scene comes back byte for byte -- checked on every scene file of the reference.
+ * ptl_ron_format: parse any RON text and write it back in that layout (NULL + ptl_last_error() on a syntax error). */
+int ptl_scene_to_ron(ptl_scene* s, char** text);
+char* ptl_ron_format(const char* text);
+
 /* PNG I/O (RGBA8): the reference's Texture2D::from_file_with_format / Image::export_png. */
 int ptl_png_read(const char* path, uint8_t** rgba8, int* width, int* height); /* free with ptl_free */
 int ptl_png_write(const char* path, const uint8_t* rgba8, int width, int height);

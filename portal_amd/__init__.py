@@ -143,6 +143,8 @@ def _load() -> C.CDLL:
         "ptl_device_download": (ci, [vp, vp, cs, vp]),
         "ptl_host_alloc": (ci, [cs, P(vp)]),
         "ptl_host_free": (ci, [vp]),
+        "ptl_ron_format": (vp, [cp]),
+        "ptl_scene_to_ron": (ci, [vp, P(vp)]),
         "ptl_png_read": (ci, [cp, P(vp), P(ci), P(ci)]),
         "ptl_png_write": (ci, [cp, vp, ci, ci]),
         "ptl_strstore_new": (vp, []),
@@ -246,6 +248,15 @@ class Scene:
         """What Matrix::Camera evaluates to: 4x4, m[row][col] (a renderer sends its camera's matrix itself)."""
         a = (C.c_double * 16)(*np.asarray(m, np.float64).reshape(4, 4).T.reshape(-1))
         _check(lib().ptl_scene_set_camera_matrix(self._h, a), "set_camera_matrix")
+
+    def to_ron(self) -> str:
+        """The scene as a .ron document in the reference's layout (its writer: serialize_scene_new_format + pretty RON)."""
+        p = C.c_void_p()
+        _check(lib().ptl_scene_to_ron(self._h, C.byref(p)), "to_ron")
+        try:
+            return C.string_at(p).decode("utf-8")
+        finally:
+            lib().ptl_free(p)
 
     def animations(self):
         """[(name, duration seconds)] of the scene's real animations (the clips `render` turns into videos)."""
@@ -549,6 +560,17 @@ def png_read(path: str) -> np.ndarray:
     _check(lib().ptl_png_read(path.encode(), C.byref(p), C.byref(w), C.byref(h)), "png_read")
     try:
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value, 4)).copy()
+    finally:
+        lib().ptl_free(p)
+
+
+def ron_format(text: str) -> str:
+    """Parse RON and write it back in the layout of the reference's scene files (ron 0.10 pretty printer)."""
+    p = lib().ptl_ron_format(text.encode("utf-8"))
+    if not p:
+        raise PortalError(_err())
+    try:
+        return C.string_at(p).decode("utf-8")
     finally:
         lib().ptl_free(p)
 

@@ -1092,6 +1092,25 @@ extern "C" char* ptl_translate_glsl(const char* glsl) {
     return p;
 }
 
+extern "C" int ptl_scene_to_ron(ptl_scene* s, char** text) {
+    if (!s || !text) return PTL_ERR_INVALID;
+    return guarded([&] {
+        *text = strdup(s->scene->to_ron().c_str());
+        return PTL_OK;
+    });
+}
+
+extern "C" char* ptl_ron_format(const char* text) {
+    if (!text) return nullptr;
+    try {
+        std::string out = ron::to_string(ron::parse(text));
+        return strdup(out.c_str());
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return nullptr;
+    }
+}
+
 extern "C" int ptl_formula_eval(const char* text, const char* const* names, const double* values, int n, double time, double* out) {
     if (!text || !out) return PTL_ERR_INVALID;
     std::string err;

@@ -39,6 +39,7 @@ void usage() {
                  "                  [--specialize 0|1]   bake what is constant within a clip into the kernel (default: when it pays)\n"
                  "       portal-amd emit-source <scene.ron> [--stage NAME]     print the generated HIP kernel source\n"
                  "       portal-amd check <scene.ron> [--stage NAME]           compile for gfx950 (no GPU needed); errors by scene element\n"
+                 "       portal-amd write <scene.ron> [--stage NAME] [--set UNIFORM=VALUE ...] --output out.ron     the reference's RON writer\n"
                  "       portal-amd version\n");
 }
 
@@ -167,6 +168,7 @@ private:
 struct Options {
     std::string scene, clips, output = "frame.png", asset_root = ".", stage, animation, camera, scenes_dir = "scenes", out_dir = ".", starts_with;
     bool have_camera = false, stereo = false, skip_existing = true;
+    std::vector<std::pair<std::string, double>> sets;  // --set name=value
     int specialize = -1;  // -1 auto: clip-constant specialisation when the clip has enough sub-frames to repay the extra JIT
     int width = 1920, height = 1080, aa = 1, depth = 100, device = 0, fps = 60, blur = 1, shard = 0, shards = 1, max_frames = -1;
     double time = 0.0, panini = -1.0, fov = 90.0;
@@ -534,6 +536,38 @@ int check(const Options& o) {
     return 1;
 }
 
+// `write`: load, apply --stage / --set, write the scene back in the reference's own .ron layout (an untouched scene comes
+// back byte for byte; serialize_scene_new_format + ron pretty printer, src/gui/scene_serialized.rs:22-24,654-1100).
+int write_scene(const Options& o) {
+    ptl_scene* scene = nullptr;
+    if (ptl_scene_load_file(o.scene.c_str(), &scene) != PTL_OK) {
+        std::fprintf(stderr, "Failed to parse scene `%s`: %s\n", o.scene.c_str(), ptl_last_error());
+        return 1;
+    }
+    char stage_cam[256] = "";
+    if (!o.stage.empty() && ptl_scene_init_stage(scene, o.stage.c_str(), stage_cam, sizeof stage_cam) != PTL_OK) {
+        std::fprintf(stderr, "Scene `%s` has no stage named `%s`\n", o.scene.c_str(), o.stage.c_str());
+        return 1;
+    }
+    for (auto& kv : o.sets)
+        if (ptl_scene_set_uniform(scene, kv.first.c_str(), kv.second) != PTL_OK) {
+            std::fprintf(stderr, "Scene `%s` has no uniform named `%s`\n", o.scene.c_str(), kv.first.c_str());
+            return 1;
+        }
+    char* text = nullptr;
+    if (ptl_scene_to_ron(scene, &text) != PTL_OK) return fail("write");
+    std::FILE* f = o.output == "frame.png" ? stdout : std::fopen(o.output.c_str(), "wb");
+    if (!f) {
+        std::fprintf(stderr, "cannot open `%s`\n", o.output.c_str());
+        return 1;
+    }
+    std::fwrite(text, 1, std::strlen(text), f);
+    if (f != stdout) std::fclose(f);
+    ptl_free(text);
+    ptl_scene_free(scene);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -546,7 +580,7 @@ int main(int argc, char** argv) {
         std::printf("%s\ndevices: %d\n", ptl_version(), ptl_device_count());
         return 0;
     }
-    if (argc < 3 || (cmd != "render-frame" && cmd != "render" && cmd != "emit-source" && cmd != "check")) {
+    if (argc < 3 || (cmd != "render-frame" && cmd != "render" && cmd != "emit-source" && cmd != "check" && cmd != "write")) {
         usage();
         return 2;
     }
@@ -590,6 +624,15 @@ int main(int argc, char** argv) {
         else if (a == "--out-dir") o.out_dir = next();
         else if (a == "--max-frames") o.max_frames = std::atoi(next());
         else if (a == "--specialize") o.specialize = std::atoi(next());
+        else if (a == "--set") {
+            std::string kv = next();
+            size_t eq = kv.find('=');
+            if (eq == std::string::npos) {
+                std::fprintf(stderr, "--set name=value\n");
+                return 2;
+            }
+            o.sets.emplace_back(kv.substr(0, eq), std::atof(kv.c_str() + eq + 1));
+        }
         else if (a == "--shard") {
             if (std::sscanf(next(), "%d/%d", &o.shard, &o.shards) != 2 || o.shards < 1 || o.shard < 0 || o.shard >= o.shards) {
                 std::fprintf(stderr, "--shard K/N with 0 <= K < N\n");
@@ -612,6 +655,7 @@ int main(int argc, char** argv) {
     if (cmd == "render") return render(o);
     if (cmd == "render-frame") return render_frame(o);
     if (cmd == "check") return check(o);
+    if (cmd == "write") return write_scene(o);
     // emit-source
     ptl_scene* scene = nullptr;
     if (ptl_scene_load_file(o.scene.c_str(), &scene) != PTL_OK) {

@@ -1,7 +1,9 @@
 // ron.cpp -- recursive-descent RON reader (see ron.h).
 #include "ron.h"
 
+#include <algorithm>
 #include <cctype>
+#include <charconv>
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
@@ -262,6 +264,144 @@ struct Parser {
 };
 
 }  // namespace
+
+namespace {
+
+void write_float(std::string& out, double f) {
+    if (std::isnan(f)) {
+        out += "NaN";
+        return;
+    }
+    if (std::isinf(f)) {
+        out += f > 0 ? "inf" : "-inf";
+        return;
+    }
+    char buf[400];
+    auto r = std::to_chars(buf, buf + sizeof buf, f, std::chars_format::fixed);  // shortest digits that read back as f, no exponent
+    std::string t(buf, r.ptr);
+    size_t dot = t.find('.');
+    if (dot == std::string::npos) {
+        t += ".0";
+    } else {
+        // Rust's float printing (what ron uses) resolves an exact tie between two equally short candidates upwards in
+        // magnitude, std::to_chars to the even digit: 0.99658966064453125 is "...313" there, "...312" here.  Detect the tie
+        // on the exact expansion (every binary64 has a finite one) and bump the last digit.
+        size_t decimals = t.size() - dot - 1;
+        char exact[1200];
+        auto e = std::to_chars(exact, exact + sizeof exact, f, std::chars_format::fixed, 1100);
+        std::string full(exact, e.ptr);
+        size_t fdot = full.find('.');
+        std::string rest = full.substr(fdot + 1 + decimals);
+        bool tie = !rest.empty() && rest[0] == '5' && rest.find_first_not_of('0', 1) == std::string::npos;
+        std::string truncated = full.substr(0, fdot + 1 + decimals);
+        if (tie && truncated == t) {  // to_chars rounded down (to even): take the upper neighbour
+            size_t k = t.size();
+            while (k > 0) {
+                --k;
+                if (t[k] == '.' || t[k] == '-') continue;
+                if (t[k] == '9') {
+                    t[k] = '0';
+                } else {
+                    ++t[k];
+                    break;
+                }
+            }
+        }
+    }
+    out += t;
+}
+
+void write_string(std::string& out, const std::string& s) {
+    if (s.find('"') == std::string::npos && s.find('\\') == std::string::npos) {
+        out += '"';
+        out += s;
+        out += '"';
+        return;
+    }
+    // raw string: one more hash than the longest run of hashes anywhere in the text (ron counts runs, not just those after a quote)
+    size_t need = 1, run = 0;
+    for (char c : s) {
+        run = c == '#' ? run + 1 : 0;
+        need = std::max(need, run + 1);
+    }
+    out += 'r';
+    out.append(need, '#');
+    out += '"';
+    out += s;
+    out += '"';
+    out.append(need, '#');
+}
+
+void write_value(std::string& out, const Value& v, int level) {
+    auto indent = [&](int l) { out.append((size_t)l * 4, ' '); };
+    switch (v.kind) {
+        case Value::Int: out += std::to_string(v.i); break;
+        case Value::Float: write_float(out, v.f); break;
+        case Value::Bool: out += v.b ? "true" : "false"; break;
+        case Value::String: write_string(out, v.s); break;
+        case Value::Unit: out += v.s; break;
+        case Value::Tuple:
+            out += v.s;
+            out += '(';
+            for (size_t k = 0; k < v.items.size(); ++k) {
+                if (k) out += ", ";
+                write_value(out, v.items[k], level);
+            }
+            out += ')';
+            break;
+        case Value::Struct:
+            out += v.s;
+            out += "(\n";
+            for (auto& kv : v.fields) {
+                indent(level + 1);
+                out += kv.first;
+                out += ": ";
+                write_value(out, kv.second, level + 1);
+                out += ",\n";
+            }
+            indent(level);
+            out += ')';
+            break;
+        case Value::List:
+            if (v.items.empty()) {
+                out += "[]";
+                break;
+            }
+            out += "[\n";
+            for (auto& item : v.items) {
+                indent(level + 1);
+                write_value(out, item, level + 1);
+                out += ",\n";
+            }
+            indent(level);
+            out += ']';
+            break;
+        case Value::Map:
+            if (v.entries.empty()) {
+                out += "{}";
+                break;
+            }
+            out += "{\n";
+            for (auto& kv : v.entries) {
+                indent(level + 1);
+                write_value(out, kv.first, level + 1);
+                out += ": ";
+                write_value(out, kv.second, level + 1);
+                out += ",\n";
+            }
+            indent(level);
+            out += '}';
+            break;
+    }
+}
+
+}  // namespace
+
+std::string to_string(const Value& v) {
+    std::string out;
+    write_value(out, v, 0);
+    return out;
+}
 
 Value parse(const std::string& text) {
     Parser p(text);

@@ -68,4 +68,10 @@ struct ParseError : std::runtime_error {
 
 Value parse(const std::string& text);
 
+// The writer: the layout the reference's scene files have (ron 0.10 `PrettyConfig::default().escape_strings(false)`,
+// src/gui/scene_serialized.rs:22-24,654-666): structs, lists and maps one member per line with a trailing comma and four
+// spaces per level, tuples and newtypes inline, floats in positional shortest round-trip form with at least one decimal,
+// strings verbatim (raw `r#".."#` with as many hashes as needed when they contain a quote or a backslash).
+std::string to_string(const Value& v);
+
 }  // namespace ptl::ron

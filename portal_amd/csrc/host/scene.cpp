@@ -469,6 +469,7 @@ std::shared_ptr<Scene> Scene::from_ron_text(const std::string& text) {
     auto scene = std::make_shared<Scene>();
     Loader loader{*scene, {}};
     loader.load(doc);
+    scene->doc = std::move(doc);
     return scene;
 }
 
@@ -491,6 +492,125 @@ int Scene::find_matrix(const std::string& name) const {
     return -1;
 }
 
+namespace {
+
+ron::Value ron_float(double f) {
+    ron::Value v;
+    v.kind = ron::Value::Float;
+    v.f = f;
+    return v;
+}
+ron::Value ron_unit(const char* name) {
+    ron::Value v;
+    v.kind = ron::Value::Unit;
+    v.s = name;
+    return v;
+}
+ron::Value ron_newtype(const char* name, ron::Value inner) {
+    ron::Value v;
+    v.kind = ron::Value::Tuple;
+    v.s = name;
+    v.items.push_back(std::move(inner));
+    return v;
+}
+
+// the `data:` of uniform `name` in the document follows the model (AnyUniform, scene_serialized.rs:36-49)
+void write_uniform_to_doc(ron::Value& doc, const std::string& name, const Uniform& u) {
+    for (auto& field : doc.fields) {
+        if (field.first != "uniforms") continue;
+        ron::Value* list = &field.second;
+        while (list->kind == ron::Value::Tuple && list->items.size() == 1) list = &list->items[0];
+        for (ron::Value& item : list->items) {
+            const ron::Value* n = item.find("name");
+            if (!n || n->s != name) continue;
+            for (auto& f : item.fields) {
+                if (f.first != "data") continue;
+                ron::Value& data = f.second;
+                auto clamped = [&](const char* tag, bool is_int) {  // Float((min: .., max: .., value: x)): keep the limits
+                    if (data.is_named(tag) && data.items.size() == 1) {
+                        ron::Value* inner = &data.items[0];
+                        while (inner->kind == ron::Value::Tuple && inner->items.size() == 1) inner = &inner->items[0];
+                        for (auto& g : inner->fields)
+                            if (g.first == "value") {
+                                if (is_int) {
+                                    g.second.kind = ron::Value::Int;
+                                    g.second.i = u.i;
+                                } else {
+                                    g.second = ron_float(u.f);
+                                }
+                                return;
+                            }
+                    }
+                    ron::Value st;
+                    st.kind = ron::Value::Struct;
+                    st.fields.emplace_back("min", ron_unit("None"));
+                    st.fields.emplace_back("max", ron_unit("None"));
+                    ron::Value val = ron_float(u.f);
+                    if (is_int) {
+                        val.kind = ron::Value::Int;
+                        val.i = u.i;
+                    }
+                    st.fields.emplace_back("value", val);
+                    data = ron_newtype(tag, ron_newtype("", std::move(st)));
+                };
+                switch (u.kind) {
+                    case Uniform::Bool: {
+                        ron::Value b;
+                        b.kind = ron::Value::Bool;
+                        b.b = u.b;
+                        data = ron_newtype("Bool", b);
+                        break;
+                    }
+                    case Uniform::Int: clamped("Int", true); break;
+                    case Uniform::Float: clamped("Float", false); break;
+                    case Uniform::Angle: data = ron_newtype("Angle", ron_float(u.f)); break;
+                    case Uniform::Progress: data = ron_newtype("Progress", ron_float(u.f)); break;
+                    default: break;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+std::string Scene::to_ron() const {
+    ron::Value out = doc;
+    // current_stage (CurrentStageSer, scene_serialized.rs:585-590)
+    ron::Value stage = ron_unit("Dev");
+    auto named = [](const char* tag, const std::string& name) {
+        ron::Value s;
+        s.kind = ron::Value::String;
+        s.s = name;
+        return ron_newtype(tag, s);
+    };
+    if (current_stage.kind == StageRef::Animation && current_stage.index >= 0) stage = named("Animation", stages[current_stage.index].name);
+    if (current_stage.kind == StageRef::RealAnimation && current_stage.index >= 0) stage = named("RealAnimation", animations[current_stage.index].name);
+    bool had = false;
+    for (auto& f : out.fields)
+        if (f.first == "current_stage") {
+            f.second = stage;
+            had = true;
+        }
+    if (!had && current_stage.kind != StageRef::Dev) out.fields.emplace_back("current_stage", stage);
+    // cam block (CamSettings): the camera a renderer last handed back, see Scene::cam
+    for (auto& f : out.fields) {
+        if (f.first != "cam") continue;
+        for (auto& g : f.second.fields) {
+            if (g.first == "alpha") g.second = ron_float(cam.alpha);
+            else if (g.first == "beta") g.second = ron_float(cam.beta);
+            else if (g.first == "r") g.second = ron_float(cam.r);
+            else if (g.first == "offset_after_material") g.second = ron_float(cam.offset_after_material);
+            else if (g.first == "look_at" && g.second.kind == ron::Value::Tuple && g.second.items.size() == 3) {
+                g.second.items[0] = ron_float(cam.look_at.x);
+                g.second.items[1] = ron_float(cam.look_at.y);
+                g.second.items[2] = ron_float(cam.look_at.z);
+            }
+        }
+    }
+    return ron::to_string(out);
+}
+
 bool Scene::set_uniform_value(const std::string& name, double v) {
     int idx = find_uniform(name);
     if (idx < 0) return false;
@@ -506,6 +626,7 @@ bool Scene::set_uniform_value(const std::string& name, double v) {
         case Uniform::Float: case Uniform::Angle: case Uniform::Progress: u.f = v; break;
         default: u.kind = Uniform::Float; u.f = v; break;  // a stage replaces a formula by a value
     }
+    write_uniform_to_doc(doc, name, u);
     return true;
 }
 

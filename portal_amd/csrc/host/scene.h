@@ -202,6 +202,12 @@ public:
     int find_uniform(const std::string& name) const;
     int find_matrix(const std::string& name) const;
 
+    // The document the scene was read from, kept whole (descriptions, GUI-only blocks, everything this model does not
+    // interpret) and edited in step with the model, so that to_ron() writes a file the reference loads back unchanged:
+    // serialize_scene_new_format + ron::ser::to_string_pretty (src/gui/scene_serialized.rs:22-24,654-1100).
+    ron::Value doc;
+    std::string to_ron() const;
+
     // AnyUniform::get / Matrix::get; nullopt = "can't be getted" in the reference
     std::optional<UniformValue> eval_uniform(int index) const;
     std::optional<DMat4> eval_matrix(int index) const;

@@ -127,3 +127,11 @@ def test_corpus_real_animations_product_equals_oracle(pa, path):
                     assert got["camera"][k] == want[k], (clip, t, k)
                 assert np.array_equal(got["camera"]["matrix"], np.array(want["teleport_matrix"]).T), (clip, t)
             hl._same_uniforms(ps.uniform_values(), osc.scene_uniform_values(), (clip, t))
+
+
+@pytest.mark.parametrize("path", scene_files(), ids=[os.path.basename(f)[:-4] for f in scene_files()])
+def test_corpus_scene_writer_reproduces_the_file(pa, path):
+    """All 82 scene files were written by the reference's RON writer: parse -> write must give each back byte for byte."""
+    text = open(path, encoding="utf-8").read()
+    assert pa.ron_format(text) == text
+    assert pa.Scene.from_file(path).to_ron() == text
