@@ -49,7 +49,11 @@ std::string cache_dir() {
 std::vector<std::string> compile_options(const char* const* defines, int n_defines) {
     const char* arch = std::getenv("PTL_OFFLOAD_ARCH");
     std::vector<std::string> o = {std::string("--offload-arch=") + (arch ? arch : "gfx950"),
-                                  "-O3",
+                                  // -O1, measured (profiles/r01/variants7_O1.jsonl, variants8_O1.jsonl): against -O3 the baked kernels
+                                  // are 10-16 % FASTER (portal_in_portal 4K 0.86 -> 0.72 ms, 136 -> 110 VGPRs, SGPR spills 20 -> 0),
+                                  // the dynamic ones 3-10 % faster except one (+3 %), and the JIT takes 1.8 s instead of 3.3 s.  -O2/-O3
+                                  // hoist and unroll the straight-line per-object code into long live ranges; results are identical.
+                                  "-O1",
                                   "-std=c++20",
                                   "-ffp-contract=off",  // FMAs only where device/ptl_glsl.h spells them
                                   "-fhip-fp32-correctly-rounded-divide-sqrt",

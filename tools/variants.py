@@ -20,6 +20,19 @@ VARIANTS = {
     "spec": "SPECIALIZE",
     "all": "SPECIALIZE_ALL",
     "all_w4": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4",
+    "base_O1": "-O1",
+    "all_O1": "SPECIALIZE_ALL -O1",
+    "all_O1_w4": "SPECIALIZE_ALL -O1 -DPTL_WAVES_PER_EU=4",
+    "all_O1_w5": "SPECIALIZE_ALL -O1 -DPTL_WAVES_PER_EU=5",
+    "all_O1_w6": "SPECIALIZE_ALL -O1 -DPTL_WAVES_PER_EU=6",
+    "all_O1_slp": "SPECIALIZE_ALL -O1 -fslp-vectorize",
+    "all_O2_novec": "SPECIALIZE_ALL -O2 -fno-slp-vectorize -fno-vectorize -fno-unroll-loops",
+    "all_O1_nosched": "SPECIALIZE_ALL -O1 -mllvm -amdgpu-disable-unclustered-high-rp-reschedule",
+    "base_O1_w4": "-O1 -DPTL_WAVES_PER_EU=4",
+    "all_Os": "SPECIALIZE_ALL -Os",
+    "all_Oz": "SPECIALIZE_ALL -Oz",
+    "base_Os": "-Os",
+    "base_O1_w3": "-O1 -DPTL_WAVES_PER_EU=3",
 }
 CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
 
