@@ -29,6 +29,13 @@ VARIANTS = {
     "all_O2_novec": "SPECIALIZE_ALL -O2 -fno-slp-vectorize -fno-vectorize -fno-unroll-loops",
     "all_O1_nosched": "SPECIALIZE_ALL -O1 -mllvm -amdgpu-disable-unclustered-high-rp-reschedule",
     "base_O1_w4": "-O1 -DPTL_WAVES_PER_EU=4",
+    "all_ilp": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=max-ilp",
+    "all_memclause": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=max-memory-clause",
+    "all_iter_minreg": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg",
+    "all_iter_ilp": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-ilp",
+    "all_w5": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=5",
+    "all_nomisched": "SPECIALIZE_ALL -mllvm -enable-misched=false",
+    "all_O0ish": "SPECIALIZE_ALL -O1 -mllvm -disable-licm-promotion -mllvm -enable-gvn-hoist=false",
     "all_Os": "SPECIALIZE_ALL -Os",
     "all_Oz": "SPECIALIZE_ALL -Oz",
     "base_Os": "-Os",
