@@ -173,27 +173,37 @@ def test_compile_error_is_reported_with_scene_element(gpu):
     assert owner is not None and owner[0] == "library" and owner[1] == "room"
 
 
-def test_full_size_properties_triple_portal_4k(gpu):
-    """BASELINE config C3 at full size (3840x2160, depth 40): no oracle run is affordable, so check
-    size-independent properties: 8 interleaved shards == whole frame, alpha == 255 everywhere,
-    trip count within [pixels, pixels * depth], and a 3-row window bit-equal to the host build."""
+@pytest.mark.parametrize("scene_name,w,h,depth,aa", [
+    ("monoportal", 1920, 1080, 20, 1),          # BASELINE config C2
+    ("triple_portal", 3840, 2160, 40, 1),       # C3
+    ("portal_in_portal", 3840, 2160, 40, 1),    # C4, the headline
+    ("mobius_monoportal", 7680, 4320, 64, 4),   # C5, the divergent-ray stress
+])
+def test_full_size_properties(gpu, scene_name, w, h, depth, aa):
+    """The BASELINE configs at full size: no oracle run is affordable there, so check size-independent properties:
+    8 interleaved shards == whole frame, alpha == 255 everywhere, trip count within [samples, samples * depth], three
+    rows (top, middle, bottom) bit-equal to the host build, and the clip-constant / fully baked kernel == the dynamic one."""
     from oracle import host_build
 
     pa = gpu
-    w, h, depth = 3840, 2160, 40
-    scene = pa.Scene.from_file(pa.scene_path("triple_portal"))
+    scene = pa.Scene.from_file(pa.scene_path(scene_name))
     r = pa.SceneRenderer(scene, device=0, flags=pa.FLAG_COUNT_SEGMENTS | pa.FLAG_SPECIALIZE_ALL)
     r.set_option("render_depth", depth)
+    r.set_option("aa_count", aa)
     whole = r.draw(w, h, rgba8=True, rgba32f=True, segments=True)
     assert (whole["rgba8"][:, :, 3] == 255).all()
-    assert w * h <= whole["segments"] <= w * h * depth
+    assert w * h * aa <= whole["segments"] <= w * h * aa * depth
     full = np.zeros_like(whole["rgba8"])
     for phase in range(8):
         pa.deinterleave_rows(r.draw(w, h, rb_phase=phase, rb_stride=8)["rgba8"], pa.Frame(w, h, phase, 8), full)
     assert np.array_equal(full, whole["rgba8"])
-    rows = [0, 1079, 2159]
+    rows = [0, h // 2 - 1, h - 1]
     ref = host_build.host_kernel_for(r, scene, w, h).render(w, h, rows=rows)
     assert _bits_equal(whole["rgba32f"][rows], ref["rgba32f"]).all()
+    plain = pa.SceneRenderer(scene, device=0)
+    plain.set_option("render_depth", depth)
+    plain.set_option("aa_count", aa)
+    assert np.array_equal(plain.draw(w, h)["rgba8"], whole["rgba8"])
 
 
 def test_specialised_kernel_follows_scene_changes(gpu):
