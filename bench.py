@@ -212,6 +212,13 @@ def main():
         for k in range(depth):
             drain((counter[0] + k) % depth)
 
+    # untimed: keep the GPU busy for ~0.25 s so that the W warm-up steps and the timed region run at settled clocks
+    # (a 20-step timed region is ~15 ms of work; without this it rides the power-management ramp)
+    spin_until = time.perf_counter() + 0.25
+    while time.perf_counter() < spin_until:
+        for _ in range(16):
+            renderer.draw_device(frame, out_rgba8=shards[0].data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     drain_all()
