@@ -265,6 +265,18 @@ int ptl_average_images(int device, const void* const* frames_rgba8, int n_frames
 int ptl_device_alloc(int device, size_t bytes, void** out);
 int ptl_device_free(void* p);
 int ptl_device_download(void* host_dst, const void* device_src, size_t bytes, void* stream);
+/* Streams and events, 1:1 over HIP, for callers that overlap the download of frame i (on its own non-blocking stream, into
+ * page-locked memory) with the tracing of frame i+1: record an event behind the producer, make the copy stream wait for it,
+ * ptl_device_download_async, record a second event behind the copy and ptl_event_synchronize on it where the pixels are
+ * consumed.  (`portal-amd render` does exactly this.) */
+int ptl_stream_create(int device, void** stream);
+int ptl_stream_destroy(void* stream);
+int ptl_event_create(int device, void** event);
+int ptl_event_destroy(void* event);
+int ptl_event_record(void* event, void* stream);
+int ptl_event_synchronize(void* event);
+int ptl_stream_wait_event(void* stream, void* event);
+int ptl_device_download_async(void* host_dst, const void* device_src, size_t bytes, void* stream);
 /* Page-locked host memory for those downloads (PCIe-rate copies; pageable memory works too, several times slower). */
 int ptl_host_alloc(size_t bytes, void** out);
 int ptl_host_free(void* p);
@@ -279,7 +291,9 @@ char* ptl_ron_format(const char* text);
 
 /* PNG I/O (RGBA8): the reference's Texture2D::from_file_with_format / Image::export_png. */
 int ptl_png_read(const char* path, uint8_t** rgba8, int* width, int* height); /* free with ptl_free */
-int ptl_png_write(const char* path, const uint8_t* rgba8, int width, int height);
+int ptl_png_write(const char* path, const uint8_t* rgba8, int width, int height); /* deflate level 6 */
+/* the same with an explicit deflate level 0..9 (frame sequences that an encoder consumes and deletes: level 3 is 2.3x faster) */
+int ptl_png_write_level(const char* path, const uint8_t* rgba8, int width, int height, int level);
 
 /* ---- template engine test hooks (src/code_generation.rs) ----------------------------------- */
 typedef struct ptl_strstore ptl_strstore;

@@ -37,6 +37,7 @@ void usage() {
                  "                  [--stereoimage] [--no-skip-existing] [--filter-starts-with P] [--aa-count 4] [--render-depth 150]\n"
                  "                  [--scenes-dir DIR] [--out-dir DIR] [--device I] [--shard K/N] [--max-frames N] [--asset-root DIR]\n"
                  "                  [--specialize 0|1]   bake what is constant within a clip into the kernel (default: when it pays)\n"
+                 "                  [--timing]           wait for every kernel and report GPU time (no host/GPU overlap)\n"
                  "       portal-amd emit-source <scene.ron> [--stage NAME]     print the generated HIP kernel source\n"
                  "       portal-amd check <scene.ron> [--stage NAME]           compile for gfx950 (no GPU needed); errors by scene element\n"
                  "       portal-amd write <scene.ron> [--stage NAME] [--set UNIFORM=VALUE ...] --output out.ron     the reference's RON writer\n"
@@ -168,11 +169,14 @@ private:
 // __launch_bounds__(256, 4): never slower than no hint on the BASELINE scenes, 18 % faster on the un-specialised
 // portal_in_portal kernel (profiles/r01/variants8_O1.jsonl, variants9_O1.jsonl)
 constexpr unsigned kRenderFlags = 4u << 8;
+// frames of a clip are intermediates (ffmpeg reads them, then anim/ is removed): fast deflate, 2.3x the encode rate of level 6
+constexpr int kFrameDeflateLevel = 3;
 
 struct Options {
     std::string scene, clips, output = "frame.png", asset_root = ".", stage, animation, camera, scenes_dir = "scenes", out_dir = ".", starts_with;
     bool have_camera = false, stereo = false, skip_existing = true;
     std::vector<std::pair<std::string, double>> sets;  // --set name=value
+    bool timing = false;  // --timing: wait for every kernel and report GPU milliseconds (serialises host and GPU)
     int specialize = -1;  // -1 auto: clip-constant specialisation when the clip has enough sub-frames to repay the extra JIT
     int width = 1920, height = 1080, aa = 1, depth = 100, device = 0, fps = 60, blur = 1, shard = 0, shards = 1, max_frames = -1;
     double time = 0.0, panini = -1.0, fov = 90.0;
@@ -261,9 +265,37 @@ int render_frame(const Options& o) {
     return 0;
 }
 
+// What the clip loop keeps in flight: the download of frame i runs on its own stream into page-locked memory while frame i+1
+// is being traced; `kRing` result buffers so a frame is not overwritten before its copy has left.
+struct FramePipeline {
+    static constexpr int kRing = 3;
+    int device = 0;
+    void* copy_stream = nullptr;
+    void* results[kRing] = {nullptr, nullptr, nullptr};   // device RGBA8 frames ready for download
+    void* copied[kRing] = {nullptr, nullptr, nullptr};    // event: the copy out of results[k] has finished
+    bool copy_pending[kRing] = {false, false, false};
+    void* produced = nullptr;                             // event: results[k] is complete on the tracing stream
+
+    bool create(int dev, size_t bytes) {
+        device = dev;
+        if (ptl_stream_create(dev, &copy_stream) != PTL_OK || ptl_event_create(dev, &produced) != PTL_OK) return false;
+        for (int k = 0; k < kRing; ++k)
+            if (ptl_device_alloc(dev, bytes, &results[k]) != PTL_OK || ptl_event_create(dev, &copied[k]) != PTL_OK) return false;
+        return true;
+    }
+    ~FramePipeline() {
+        if (copy_stream) ptl_stream_destroy(copy_stream);
+        if (produced) ptl_event_destroy(produced);
+        for (int k = 0; k < kRing; ++k) {
+            if (copied[k]) ptl_event_destroy(copied[k]);
+            if (results[k]) ptl_device_free(results[k]);
+        }
+    }
+};
+
 // render_animation (src/main.rs:1758-1873)
 int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::string& scene_name, const std::string& clip, double duration, int fps,
-                int width, int height, std::vector<void*>& subframes, void* averaged, EncoderPool& pool, PinnedFrames& pinned) {
+                int width, int height, std::vector<void*>& subframes, FramePipeline& pipe, EncoderPool& pool, PinnedFrames& pinned) {
     auto started = std::chrono::steady_clock::now();
     int rejits_before = ptl_renderer_rejit_count(r);
     std::string video_base = o.out_dir + "/video/" + scene_name + "/" + clip;
@@ -278,7 +310,7 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
     const double exposure = 0.5;
     size_t frame_bytes = (size_t)width * height * 4;
     double gpu_ms = 0.0;
-    long traced = 0;
+    long traced = 0, drawn_frames = 0;
     ptl_frame frame{width, height, 0, 1};
     int last = o.max_frames >= 0 ? std::min(count, o.max_frames) : count;
     for (int i = 0; i < last; ++i) {
@@ -294,12 +326,16 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
             }
             continue;
         }
+        int slot = (int)(drawn_frames++ % FramePipeline::kRing);
+        if (pipe.copy_pending[slot] && ptl_stream_wait_event(nullptr, pipe.copied[slot]) != PTL_OK) return fail("wait");  // GPU-side: slot is free
         for (int j = 0; j < o.blur; ++j) {
             double t = ((double)i / count) + (double)j / o.blur / count * exposure;
             ptl_renderer_set_option(r, "aa_start", j);
             if (ptl_renderer_update(r, t * (double)(float)duration, nullptr, nullptr) != PTL_OK) return fail("update");
+            void* target = o.blur > 1 ? subframes[j] : pipe.results[slot];  // one image: average_images hands it back untouched
             float ms = 0.0f;
-            if (ptl_renderer_draw(r, &frame, subframes[j], nullptr, nullptr, nullptr, &ms) != PTL_OK) return fail("render");
+            // without --timing the launch is not waited for: the host evaluates the next sub-frame's uniforms while this one traces
+            if (ptl_renderer_draw(r, &frame, target, nullptr, nullptr, nullptr, o.timing ? &ms : nullptr) != PTL_OK) return fail("render");
             gpu_ms += ms;
             ++traced;
             bool first = i == 0 && j == 0, final_one = i == count - 1 && j == o.blur - 1;
@@ -307,7 +343,7 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
                 for (int which = 0; which < 2; ++which) {
                     if (!(which == 0 ? first : final_one)) continue;
                     uint8_t* still = pinned.take();
-                    if (ptl_device_download(still, subframes[j], frame_bytes, nullptr) != PTL_OK) return fail("download");
+                    if (ptl_device_download(still, target, frame_bytes, nullptr) != PTL_OK) return fail("download");
                     std::string still_name = video_base + (which == 0 ? ".start.png" : ".end.png");
                     pool.submit([still, still_name, width, height, &pinned] {
                         if (ptl_png_write(still_name.c_str(), still, width, height) != PTL_OK) std::fprintf(stderr, "\n%s\n", ptl_last_error());
@@ -316,17 +352,25 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
                 }
             }
         }
-        const void* result = subframes[0];  // one image: average_images hands it back untouched
         if (o.blur > 1) {
             float ms = 0.0f;
-            if (ptl_average_images(o.device, subframes.data(), o.blur, averaged, width, height, nullptr, &ms) != PTL_OK) return fail("average_images");
+            if (ptl_average_images(o.device, subframes.data(), o.blur, pipe.results[slot], width, height, nullptr, o.timing ? &ms : nullptr) != PTL_OK)
+                return fail("average_images");
             gpu_ms += ms;
-            result = averaged;
         }
+        // hand the finished frame to the copy stream and go on tracing; the encoder job waits for its own event
         uint8_t* pixels = pinned.take();  // blocks while every buffer is still being encoded
-        if (ptl_device_download(pixels, result, frame_bytes, nullptr) != PTL_OK) return fail("download");
-        pool.submit([pixels, name, width, height, &pinned] {
-            if (ptl_png_write(name.c_str(), pixels, width, height) != PTL_OK) std::fprintf(stderr, "\n%s\n", ptl_last_error());
+        void* arrived = nullptr;
+        if (ptl_event_record(pipe.produced, nullptr) != PTL_OK || ptl_stream_wait_event(pipe.copy_stream, pipe.produced) != PTL_OK ||
+            ptl_device_download_async(pixels, pipe.results[slot], frame_bytes, pipe.copy_stream) != PTL_OK ||
+            ptl_event_record(pipe.copied[slot], pipe.copy_stream) != PTL_OK || ptl_event_create(pipe.device, &arrived) != PTL_OK ||
+            ptl_event_record(arrived, pipe.copy_stream) != PTL_OK)
+            return fail("download");
+        pipe.copy_pending[slot] = true;
+        pool.submit([pixels, name, width, height, arrived, &pinned] {
+            if (ptl_event_synchronize(arrived) != PTL_OK || ptl_png_write_level(name.c_str(), pixels, width, height, kFrameDeflateLevel) != PTL_OK)
+                std::fprintf(stderr, "\n%s\n", ptl_last_error());
+            ptl_event_destroy(arrived);
             pinned.give(pixels);
         });
         std::printf("\r%d/%d done      ", i, count);
@@ -334,8 +378,12 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
     }
     std::printf("\n");
     double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
-    std::printf("Traced `%s/%s`: %ld sub-frames %dx%d, GPU %.1f ms (%.3f ms each), submitted after %.2f s, kernel rebuilt %d times\n", scene_name.c_str(),
-                clip.c_str(), traced, width, height, gpu_ms, traced ? gpu_ms / traced : 0.0, wall, ptl_renderer_rejit_count(r) - rejits_before);
+    if (o.timing)
+        std::printf("Traced `%s/%s`: %ld sub-frames %dx%d, GPU %.1f ms (%.3f ms each), submitted after %.2f s, kernel rebuilt %d times\n", scene_name.c_str(),
+                    clip.c_str(), traced, width, height, gpu_ms, traced ? gpu_ms / traced : 0.0, wall, ptl_renderer_rejit_count(r) - rejits_before);
+    else
+        std::printf("Traced `%s/%s`: %ld sub-frames %dx%d submitted after %.2f s, kernel rebuilt %d times\n", scene_name.c_str(), clip.c_str(), traced, width,
+                    height, wall, ptl_renderer_rejit_count(r) - rejits_before);
     (void)scene;
     return 0;
 }
@@ -422,11 +470,11 @@ int render(const Options& o) {
         ptl_renderer_set_option(r, "render_depth", o.depth);
         ptl_renderer_set_option(r, "draw_side_by_side", o.stereo ? 1 : 0);
         std::vector<void*> subframes(std::max(1, o.blur), nullptr);
-        void* averaged = nullptr;
         size_t bytes = (size_t)width * o.height * 4;
         for (void*& p : subframes)
             if (ptl_device_alloc(o.device, bytes, &p) != PTL_OK) return fail("alloc");
-        if (ptl_device_alloc(o.device, bytes, &averaged) != PTL_OK) return fail("alloc");
+        FramePipeline pipe;
+        if (!pipe.create(o.device, bytes)) return fail("pipeline");
 
         // which clips: the named ones (render_named_animations) or all, optionally filtered (render_all_animations)
         std::vector<std::pair<std::string, double>> clips;
@@ -447,7 +495,7 @@ int render(const Options& o) {
             for (auto& c : clips)
                 if (o.starts_with.empty() || c.first.compare(0, o.starts_with.size(), o.starts_with) == 0) todo.push_back(c);
         }
-        int threads = (int)std::min(32u, std::max(2u, std::thread::hardware_concurrency() / 2));
+        int threads = (int)std::min(64u, std::max(2u, std::thread::hardware_concurrency() * 3 / 4));
         for (size_t k = 0; k < todo.size(); ++k) {
             const std::string& clip = todo[k].first;
             if (ptl_scene_init_animation(scene, clip.c_str()) != PTL_OK) return fail("init_animation");
@@ -467,7 +515,7 @@ int render(const Options& o) {
                 PinnedFrames pinned(bytes, threads + 2);
                 if (!pinned.ok()) return fail("pinned host memory");
                 EncoderPool pool(threads, (size_t)threads * 2);
-                int rc = render_clip(o, scene, r, scene_name, clip, todo[k].second, fps, width, o.height, subframes, averaged, pool, pinned);
+                int rc = render_clip(o, scene, r, scene_name, clip, todo[k].second, fps, width, o.height, subframes, pipe, pool, pinned);
                 pool.finish();  // joins the encoders: every frame file is on disk (and every pinned buffer is back)
                 if (rc != 0) return rc;
                 std::printf("Clip `%s` on disk after %.2f s\n", clip.c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - clip_start).count());
@@ -475,7 +523,6 @@ int render(const Options& o) {
             if (o.shards == 1 && o.max_frames < 0) encode_video(o, scene_name, clip, fps);
         }
         for (void* p : subframes) ptl_device_free(p);
-        ptl_device_free(averaged);
         ptl_renderer_destroy(r);
         ptl_scene_free(scene);
     }
@@ -628,6 +675,7 @@ int main(int argc, char** argv) {
         else if (a == "--out-dir") o.out_dir = next();
         else if (a == "--max-frames") o.max_frames = std::atoi(next());
         else if (a == "--specialize") o.specialize = std::atoi(next());
+        else if (a == "--timing") o.timing = true;
         else if (a == "--set") {
             std::string kv = next();
             size_t eq = kv.find('=');

@@ -82,7 +82,9 @@ const Runtime* runtime(std::string* error) {
                  bind(h, "hipHostMalloc", rt.hipHostMalloc, &err) && bind(h, "hipHostFree", rt.hipHostFree, &err) &&
                  bind(h, "hipMemcpy", rt.hipMemcpy, &err) && bind(h, "hipMemcpyAsync", rt.hipMemcpyAsync, &err) &&
                  bind(h, "hipMemsetAsync", rt.hipMemsetAsync, &err) && bind(h, "hipStreamSynchronize", rt.hipStreamSynchronize, &err) &&
-                 bind(h, "hipDeviceSynchronize", rt.hipDeviceSynchronize, &err) && bind(h, "hipEventCreate", rt.hipEventCreate, &err) &&
+                 bind(h, "hipDeviceSynchronize", rt.hipDeviceSynchronize, &err) &&
+                 bind(h, "hipStreamCreateWithFlags", rt.hipStreamCreateWithFlags, &err) && bind(h, "hipStreamDestroy", rt.hipStreamDestroy, &err) &&
+                 bind(h, "hipStreamWaitEvent", rt.hipStreamWaitEvent, &err) && bind(h, "hipEventCreateWithFlags", rt.hipEventCreateWithFlags, &err) && bind(h, "hipEventCreate", rt.hipEventCreate, &err) &&
                  bind(h, "hipEventDestroy", rt.hipEventDestroy, &err) && bind(h, "hipEventRecord", rt.hipEventRecord, &err) &&
                  bind(h, "hipEventSynchronize", rt.hipEventSynchronize, &err) &&
                  bind(h, "hipEventElapsedTime", rt.hipEventElapsedTime, &err) && bind(h, "hipModuleLoadData", rt.hipModuleLoadData, &err) &&

@@ -34,6 +34,10 @@ struct Runtime {
     hipError_t (*hipMemcpyAsync)(void*, const void*, size_t, int, hipStream_t);
     hipError_t (*hipMemsetAsync)(void*, int, size_t, hipStream_t);
     hipError_t (*hipStreamSynchronize)(hipStream_t);
+    hipError_t (*hipStreamCreateWithFlags)(hipStream_t*, unsigned);
+    hipError_t (*hipStreamDestroy)(hipStream_t);
+    hipError_t (*hipStreamWaitEvent)(hipStream_t, hipEvent_t, unsigned);
+    hipError_t (*hipEventCreateWithFlags)(hipEvent_t*, unsigned);
     hipError_t (*hipDeviceSynchronize)();
     hipError_t (*hipEventCreate)(hipEvent_t*);
     hipError_t (*hipEventDestroy)(hipEvent_t);
@@ -51,6 +55,7 @@ struct Runtime {
     hipError_t (*hipGetLastError)();  // also CLEARS the thread's sticky error: call after a failure that was expected
 };
 constexpr int kFuncAttrSharedSizeBytes = 1, kFuncAttrLocalSizeBytes = 3, kFuncAttrNumRegs = 4;  // hipFunction_attribute
+constexpr unsigned kStreamNonBlocking = 1, kEventDisableTiming = 2;
 constexpr int kMemcpyHostToDevice = 1;
 constexpr int kMemcpyDeviceToHost = 2;
 

@@ -147,18 +147,29 @@ extern "C" int ptl_png_read(const char* path, uint8_t** rgba8, int* width, int* 
     return PTL_OK;
 }
 
-extern "C" int ptl_png_write(const char* path, const uint8_t* rgba8, int width, int height) {
-    if (!path || !rgba8 || width <= 0 || height <= 0) return PTL_ERR_INVALID;
+extern "C" int ptl_png_write_level(const char* path, const uint8_t* rgba8, int width, int height, int level) {
+    if (!path || !rgba8 || width <= 0 || height <= 0 || level < 0 || level > 9) return PTL_ERR_INVALID;
     size_t stride = (size_t)width * 4;
-    std::vector<unsigned char> raw((stride + 1) * height);
-    for (int y = 0; y < height; ++y) {
-        raw[y * (stride + 1)] = 0;
-        std::memcpy(&raw[y * (stride + 1) + 1], rgba8 + y * stride, stride);
+    // per-thread scratch kept between calls: an encoder thread writes hundreds of equally sized frames, and two fresh 33 MB
+    // allocations per frame are mostly page faults
+    static thread_local std::vector<unsigned char> raw, comp;
+    raw.resize((stride + 1) * height);
+    // filter type 2 ("Up": each byte minus the one above it) on every row but the first: one vectorisable pass, and on rendered
+    // frames it makes deflate both faster and tighter than unfiltered rows (4K portal_in_portal: 0.44 vs 0.45 MB at level 6,
+    // 0.67 vs 0.86 MB at level 3)
+    raw[0] = 0;
+    std::memcpy(&raw[1], rgba8, stride);
+    for (int y = 1; y < height; ++y) {
+        unsigned char* dst = &raw[y * (stride + 1)];
+        const uint8_t *cur = rgba8 + y * stride, *up = cur - stride;
+        dst[0] = 2;
+        for (size_t x = 0; x < stride; ++x) dst[1 + x] = (unsigned char)(cur[x] - up[x]);
     }
     uLongf clen = compressBound((uLong)raw.size());
-    std::vector<unsigned char> comp(clen);
-    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return PTL_ERR_INVALID;
+    if (comp.size() < clen) comp.resize(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), level) != Z_OK) return PTL_ERR_INVALID;
     std::vector<unsigned char> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    out.reserve(clen + 64);
     std::vector<unsigned char> ihdr;
     put_be32(ihdr, (unsigned)width);
     put_be32(ihdr, (unsigned)height);
@@ -175,3 +186,5 @@ extern "C" int ptl_png_write(const char* path, const uint8_t* rgba8, int width, 
     std::fclose(f);
     return ok ? PTL_OK : PTL_ERR_INVALID;
 }
+
+extern "C" int ptl_png_write(const char* path, const uint8_t* rgba8, int width, int height) { return ptl_png_write_level(path, rgba8, width, height, 6); }

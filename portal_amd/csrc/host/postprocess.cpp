@@ -181,3 +181,62 @@ extern "C" int ptl_host_free(void* p) {
     if (!rt) return PTL_ERR_NO_DEVICE;
     return rt->hipHostFree(p) == 0 ? PTL_OK : PTL_ERR_HIP;
 }
+
+// Streams and events for callers that overlap downloads with tracing (the video pipeline: the copy of frame i runs on its
+// own stream while frame i+1 is traced).  Thin, 1:1 over HIP; a stream is created non-blocking (no implicit ordering
+// against the default stream), an event without timing.
+namespace {
+int hip_status(const hip::Runtime* rt, int e, const char* what) {
+    if (e == 0) return PTL_OK;
+    set_last_error(std::string(what) + ": " + rt->hipGetErrorString(e));
+    rt->hipGetLastError();
+    return PTL_ERR_HIP;
+}
+}  // namespace
+
+extern "C" int ptl_stream_create(int device, void** stream) {
+    if (!stream) return PTL_ERR_INVALID;
+    std::string err;
+    const hip::Runtime* rt = hip::runtime(&err);
+    if (!rt) {
+        set_last_error(err);
+        return PTL_ERR_NO_DEVICE;
+    }
+    int e = rt->hipSetDevice(device);
+    if (e == 0) e = rt->hipStreamCreateWithFlags(stream, hip::kStreamNonBlocking);
+    return hip_status(rt, e, "hipStreamCreate");
+}
+extern "C" int ptl_stream_destroy(void* stream) {
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    return rt ? hip_status(rt, rt->hipStreamDestroy(stream), "hipStreamDestroy") : PTL_ERR_NO_DEVICE;
+}
+extern "C" int ptl_event_create(int device, void** event) {
+    if (!event) return PTL_ERR_INVALID;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!rt) return PTL_ERR_NO_DEVICE;
+    int e = rt->hipSetDevice(device);
+    if (e == 0) e = rt->hipEventCreateWithFlags(event, hip::kEventDisableTiming);
+    return hip_status(rt, e, "hipEventCreate");
+}
+extern "C" int ptl_event_destroy(void* event) {
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    return rt ? hip_status(rt, rt->hipEventDestroy(event), "hipEventDestroy") : PTL_ERR_NO_DEVICE;
+}
+extern "C" int ptl_event_record(void* event, void* stream) {
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    return rt ? hip_status(rt, rt->hipEventRecord(event, stream), "hipEventRecord") : PTL_ERR_NO_DEVICE;
+}
+extern "C" int ptl_event_synchronize(void* event) {
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    return rt ? hip_status(rt, rt->hipEventSynchronize(event), "hipEventSynchronize") : PTL_ERR_NO_DEVICE;
+}
+extern "C" int ptl_stream_wait_event(void* stream, void* event) {
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    return rt ? hip_status(rt, rt->hipStreamWaitEvent(stream, event, 0), "hipStreamWaitEvent") : PTL_ERR_NO_DEVICE;
+}
+extern "C" int ptl_device_download_async(void* host_dst, const void* device_src, size_t bytes, void* stream) {
+    if (!host_dst || !device_src) return PTL_ERR_INVALID;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!rt) return PTL_ERR_NO_DEVICE;
+    return hip_status(rt, rt->hipMemcpyAsync(host_dst, device_src, bytes, hip::kMemcpyDeviceToHost, stream), "hipMemcpyAsync(D2H)");
+}
