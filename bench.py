@@ -269,7 +269,7 @@ def main():
         launch_bytes = rows * W * 4  # RGBA8 stored by this rank's launch
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": "Mray/s (primary rays) + ms/frame at 3840x2160, portal_in_portal depth=40",
+            "metric": f"Mray/s (primary rays) + ms/frame at {W}x{H}, {args.scene} depth={args.depth}" + (f" aa={args.aa}" if args.aa != 1 else ""),
             "value": round(value, 3),
             "unit": "Mray/s",
             "n_gpus": world,
