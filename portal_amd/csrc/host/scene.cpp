@@ -572,7 +572,105 @@ void write_uniform_to_doc(ron::Value& doc, const std::string& name, const Unifor
     }
 }
 
+ron::Value* doc_field(ron::Value& doc, const char* name) {
+    for (auto& f : doc.fields)
+        if (f.first == name) return &f.second;
+    return nullptr;
+}
+ron::Value* unwrap(ron::Value* v) {
+    while (v && v->kind == ron::Value::Tuple && v->s.empty() && v->items.size() == 1) v = &v->items[0];
+    return v;
+}
+// `data:` of the element called `name` in the storage list `list_name` ("uniforms" / "matrices")
+ron::Value* element_data(ron::Value& doc, const char* list_name, const std::string& name) {
+    ron::Value* list = unwrap(doc_field(doc, list_name));
+    if (!list) return nullptr;
+    for (ron::Value& item : list->items) {
+        const ron::Value* n = item.find("name");
+        if (!n || n->s != name) continue;
+        for (auto& f : item.fields)
+            if (f.first == "data") return &f.second;
+    }
+    return nullptr;
+}
+// Storage2::set_id / set on the document: what a stage entry puts into the element it names.
+//   Changed(Some(Inline(X))) / ChangedAndToUser(..) -> X;  ..(Some(Named(n))) -> a copy of n's data;  FromDev / ProvidedToUser -> dev value
+void apply_entries_to_doc(ron::Value& doc, const ron::Value* entries, const char* list_name, const ron::Value* dev_entries) {
+    if (!entries) return;
+    const ron::Value* map = entries;
+    while (map->kind == ron::Value::Tuple && map->s.empty() && map->items.size() == 1) map = &map->items[0];
+    for (auto& kv : map->entries) {
+        const std::string& name = kv.first.s;
+        const ron::Value& how = kv.second;
+        ron::Value replacement;
+        bool have = false;
+        if ((how.is_named("Changed") || how.is_named("ChangedAndToUser")) && how.items.size() == 1) {
+            const ron::Value* ref = how.items[0].some();
+            if (ref && ref->is_named("Inline") && ref->items.size() == 1) {
+                replacement = ref->items[0];
+                have = true;
+            } else if (ref && ref->is_named("Named") && ref->items.size() == 1) {
+                if (const ron::Value* src = element_data(doc, list_name, ref->items[0].s)) {
+                    replacement = *src;
+                    have = true;
+                }
+            }
+        } else if ((how.is_named("FromDev") || how.is_named("ProvidedToUser")) && dev_entries) {
+            const ron::Value* dev = dev_entries;
+            while (dev->kind == ron::Value::Tuple && dev->s.empty() && dev->items.size() == 1) dev = &dev->items[0];
+            for (auto& d : dev->entries)
+                if (d.first.s == name) {
+                    replacement = d.second;
+                    have = true;
+                }
+        }
+        if (!have) continue;
+        if (ron::Value* data = element_data(doc, list_name, name)) *data = std::move(replacement);
+    }
+}
+// the `data:` block of the stage / clip called `name` in the storage list `list_name`
+const ron::Value* storage_item_data(const ron::Value& doc, const char* list_name, const std::string& name) {
+    const ron::Value* list = doc.find(list_name);
+    while (list && list->kind == ron::Value::Tuple && list->s.empty() && list->items.size() == 1) list = &list->items[0];
+    if (!list) return nullptr;
+    for (const ron::Value& item : list->items) {
+        const ron::Value* n = item.find("name");
+        if (n && n->s == name) return item.find("data");
+    }
+    return nullptr;
+}
+
 }  // namespace
+
+// The document side of Scene::init_stage: the reference's set_id / set copy values INTO the stored elements, so a scene saved
+// after a stage was applied holds the stage's values.  Same here, on the RON tree (subtrees are copied as they are).
+void Scene::apply_stage_to_doc(StageRef stage) {
+    const ron::Value* dev = doc.find("dev_stage");
+    const ron::Value* dev_u = dev ? dev->find("uniforms") : nullptr;
+    const ron::Value* dev_m = dev ? dev->find("matrices") : nullptr;
+    if (stage.kind == StageRef::Dev) {
+        auto restore = [&](const ron::Value* entries, const char* list_name) {
+            if (!entries) return;
+            const ron::Value* map = entries;
+            while (map->kind == ron::Value::Tuple && map->s.empty() && map->items.size() == 1) map = &map->items[0];
+            for (auto& d : map->entries)
+                if (ron::Value* data = element_data(doc, list_name, d.first.s)) *data = d.second;
+        };
+        ron::Value du = dev_u ? *dev_u : ron::Value{}, dm = dev_m ? *dev_m : ron::Value{};  // copies: `doc` is edited below
+        restore(dev_u ? &du : nullptr, "uniforms");
+        restore(dev_m ? &dm : nullptr, "matrices");
+        return;
+    }
+    const char* list_name = stage.kind == StageRef::Animation ? "animation_stages" : "animations";
+    const std::string& name = stage.kind == StageRef::Animation ? stages.at(stage.index).name : animations.at(stage.index).name;
+    const ron::Value* data = storage_item_data(doc, list_name, name);
+    if (!data) return;
+    ron::Value entries_u = data->find("uniforms") ? *data->find("uniforms") : ron::Value{};
+    ron::Value entries_m = data->find("matrices") ? *data->find("matrices") : ron::Value{};
+    ron::Value du = dev_u ? *dev_u : ron::Value{}, dm = dev_m ? *dev_m : ron::Value{};
+    apply_entries_to_doc(doc, &entries_u, "uniforms", dev_u ? &du : nullptr);
+    apply_entries_to_doc(doc, &entries_m, "matrices", dev_m ? &dm : nullptr);
+}
 
 std::string Scene::to_ron() const {
     ron::Value out = doc;
@@ -741,6 +839,7 @@ void Scene::init_stage(StageRef stage, int depth) {
             break;
         }
     }
+    apply_stage_to_doc(stage);  // (a clip's base stage has been applied by the recursive call above)
     current_stage = stage;
 }
 

@@ -207,6 +207,7 @@ public:
     // serialize_scene_new_format + ron::ser::to_string_pretty (src/gui/scene_serialized.rs:22-24,654-1100).
     ron::Value doc;
     std::string to_ron() const;
+    void apply_stage_to_doc(StageRef stage);
 
     // AnyUniform::get / Matrix::get; nullopt = "can't be getted" in the reference
     std::optional<UniformValue> eval_uniform(int index) const;
