@@ -11,6 +11,7 @@ python $R/bench.py > $O/bench_pip4k_1gpu.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o b -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 cp /tmp/prof_bench/*kernel_stats.csv $O/kernel_stats_pip4k_bench.csv
 ( python $R/bench.py --scene monoportal --width 1920 --height 1080 --depth 20 --no-cpu-baseline
+  python $R/bench.py --panini 1.0 --fov 140 --no-cpu-baseline
   python $R/bench.py --scene triple_portal --width 3840 --height 2160 --depth 40 --no-cpu-baseline
   python $R/bench.py --scene mobius_monoportal --width 7680 --height 4320 --depth 64 --aa 4 --steps 5 --warmup 1 --no-cpu-baseline ) > $O/bench_other_configs_1gpu.jsonl 2> /dev/null
 python $R/tools/average_bench.py > $O/average_images.jsonl 2> /dev/null
