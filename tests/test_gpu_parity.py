@@ -586,3 +586,28 @@ def test_video_texture_follows_its_uniform(gpu, tmp_path):
     scene.set_uniform("size", 500.0)      # a baked constant moves: kernel rebuilt, the current frame must be bound again
     r.update(0.5)
     assert tuple(int(x) for x in r.draw(16, 16)["rgba8"][8, 8][:3]) == colours[1] and r.rejit_count() >= 1
+
+
+@pytest.mark.parametrize("in_subspace", [0, 1])
+def test_kitchen_sink_scene_on_gpu(gpu, tmp_path, in_subspace):
+    """The synthetic feature mix (GLSL Complex object, Refract / Reflect, DebugMatrix, subspace object, skybox texture,
+    formula-driven matrix): gfx950 == host build == numpy oracle, bit for bit."""
+    from oracle import host_build as hb
+    from oracle.portal_oracle import Oracle
+    from tests import synthetic
+
+    pa = gpu
+    synthetic.write_sky_texture(pa, str(tmp_path))
+    path = tmp_path / "sink.ron"
+    path.write_text(synthetic.kitchen_sink_scene())
+    w, h = 64, 36
+    scene = pa.Scene.from_file(str(path))
+    r = pa.SceneRenderer(scene, device=0, asset_root=str(tmp_path))
+    r.set_option("render_depth", 12)
+    r.set_option("in_subspace", in_subspace)
+    got = r.draw(w, h, rgba32f=True)["rgba32f"]
+    host = hb.host_kernel_for(r, scene, w, h, asset_root=str(tmp_path)).render(w, h)["rgba32f"]
+    o = Oracle(str(path), asset_root=str(tmp_path))
+    o.options["render_depth"] = 12
+    o.camera = {"in_subspace": bool(in_subspace)}
+    assert _bits_equal(got, host).all() and _bits_equal(got, o.render(w, h)["rgba32f"]).all()

@@ -234,3 +234,30 @@ def test_anaglyph_mode_matches_oracle(pa, colorful):
     assert (px[1] == px[2]) == (colorful == 0)                   # grayscale mode: G == B == the cyan channel
     stripped = host_render(pa, "monoportal", w, h, 12, 1, options=options)
     assert np.array_equal(stripped["rgba8"], host_render(pa, "monoportal", w, h, 12, 1)["rgba8"])
+
+
+@pytest.mark.parametrize("in_subspace", [0, 1])
+def test_kitchen_sink_scene_matches_oracle(pa, tmp_path, in_subspace):
+    """A synthetic scene with what the five BASELINE scenes lack together (tests/synthetic.py::kitchen_sink_scene): GLSL Complex
+    object, Refract + Reflect materials, DebugMatrix gizmo, a subspace-only object, a skybox texture, a formula-driven matrix.
+    Product (host build of the generated source) == oracle, bit for bit, from the normal space and from inside the subspace."""
+    from oracle import host_build as hb
+    from oracle.portal_oracle import Oracle
+    from tests import synthetic
+
+    synthetic.write_sky_texture(pa, str(tmp_path))
+    text = synthetic.kitchen_sink_scene()
+    path = tmp_path / "sink.ron"
+    path.write_text(text)
+    w, h = 64, 36
+    scene = pa.Scene.from_file(str(path))
+    r = pa.SceneRenderer(scene, device=-1, asset_root=str(tmp_path))
+    r.set_option("render_depth", 12)
+    r.set_option("in_subspace", in_subspace)
+    got = hb.host_kernel_for(r, scene, w, h, asset_root=str(tmp_path)).render(w, h)
+    o = Oracle(str(path), asset_root=str(tmp_path))
+    o.options["render_depth"] = 12
+    o.camera = {"in_subspace": bool(in_subspace)}
+    want = o.render(w, h)
+    assert bits_equal(got["rgba32f"], want["rgba32f"]).all()
+    assert len(np.unique(got["rgba8"].reshape(-1, 4), axis=0)) > 50       # a real picture, not a flat fill
