@@ -640,3 +640,25 @@ def test_random_cameras_bit_exact_vs_host_build(gpu, scene_name, depth):
                 if typ != pa.PTL_SAMPLER and name.startswith("_"):
                     hk.set_uniform(name, r.uniform_value(name, w, h))
         assert _bits_equal(got, hk.render(w, h)["rgba32f"]).all(), k
+
+
+@pytest.mark.parametrize("w,h,depth,aa,stride", [(1, 1, 5, 1, 1), (33, 9, 5, 3, 1), (1001, 77, 12, 1, 3), (64, 40, 0, 1, 1), (48, 27, 300, 16, 2)])
+def test_ragged_sizes_and_extreme_options(gpu, w, h, depth, aa, stride):
+    """Edges the reference's GL path handles implicitly: frames that are not a multiple of the 32 x 8 workgroup (down to one pixel),
+    shards whose last row block is partial, depth 0 (every path is "depth exhausted": black), 16 AA samples with depth 300."""
+    from oracle import host_build
+
+    pa = gpu
+    scene = pa.Scene.from_file(pa.scene_path("triple_portal"))
+    r = pa.SceneRenderer(scene, device=0)
+    r.set_option("render_depth", depth)
+    r.set_option("aa_count", aa)
+    whole = r.draw(w, h, rgba32f=True)
+    ref = host_build.host_kernel_for(r, scene, w, h).render(w, h)
+    assert _bits_equal(whole["rgba32f"], ref["rgba32f"]).all() and np.array_equal(whole["rgba8"], ref["rgba8"])
+    if depth == 0:
+        assert (whole["rgba8"][..., :3] == 0).all()
+    full = np.zeros_like(whole["rgba8"])
+    for phase in range(stride):
+        pa.deinterleave_rows(r.draw(w, h, rb_phase=phase, rb_stride=stride)["rgba8"], pa.Frame(w, h, phase, stride), full)
+    assert np.array_equal(full, whole["rgba8"])
