@@ -251,7 +251,7 @@ void ptl_renderer_destroy(ptl_renderer* r);
 int ptl_deinterleave_rows(const uint8_t* shard_rgba8, const ptl_frame* frame, uint8_t* full_rgba8);
 
 /* average_images (src/main.rs:645-722), the motion-blur step of the video pipeline, on the GPU: N RGBA8
- * sub-frames (DEVICE pointers, 16-byte aligned, width*height a multiple of 4) -> one RGBA8 frame:
+ * sub-frames (DEVICE pointers, 16-byte aligned, any width x height) -> one RGBA8 frame:
  * per channel mean of c*c over the sub-frames (integer division), then (u8)(sqrt(mean) + 0.5); alpha = 255.
  * HBM-bound: reads 4*N bytes and writes 4 bytes per pixel.  1 <= n_frames <= 64.  (For one image the reference
  * hands it back untouched; callers skip the call then -- the kernel would still force alpha to 255.)  Launched on `stream`;

@@ -6,6 +6,7 @@
 // into portal_amd/kernels/average_images.hsaco next to this library and loaded with hipModuleLoadData.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -81,10 +82,6 @@ int load_kernel(int device, const char* file, const char* entry, LoadedKernel** 
 extern "C" int ptl_average_images(int device, const void* const* frames_rgba8, int n_frames, void* out_rgba8, int width, int height,
                                   void* stream, float* elapsed_ms) {
     if (!frames_rgba8 || !out_rgba8 || n_frames < 1 || n_frames > kMaxSubframes || width <= 0 || height <= 0) return PTL_ERR_INVALID;
-    if (((long)width * height) % 4 != 0) {
-        set_last_error("ptl_average_images: width*height must be a multiple of 4 pixels (16-byte vectors)");
-        return PTL_ERR_INVALID;
-    }
     for (int k = 0; k < n_frames; ++k)
         if (!frames_rgba8[k] || (reinterpret_cast<uintptr_t>(frames_rgba8[k]) & 15u)) return PTL_ERR_INVALID;
     if (reinterpret_cast<uintptr_t>(out_rgba8) & 15u) return PTL_ERR_INVALID;
@@ -98,10 +95,10 @@ extern "C" int ptl_average_images(int device, const void* const* frames_rgba8, i
         const void* frame[kMaxSubframes];
     } list{};
     for (int i = 0; i < n_frames; ++i) list.frame[i] = frames_rgba8[i];
-    long n_vec = (long)width * height / 4;
+    long n_px = (long)width * height, n_vec = n_px / 4;
     int n = n_frames;
-    void* args[] = {&list, &n, &out_rgba8, &n_vec};
-    long blocks = (n_vec + 255) / 256;
+    void* args[] = {&list, &n, &out_rgba8, &n_px};
+    long blocks = std::max(1L, (n_vec + 255) / 256);
     long cap = 256 * 16;  // grid-stride beyond 16 workgroups per CU
     if (const char* c = std::getenv("PTL_AVERAGE_IMAGES_GRID_CAP")) cap = std::atol(c) > 0 ? std::atol(c) : cap;
     if (blocks > cap) blocks = cap;

@@ -96,13 +96,28 @@ __device__ __forceinline__ void ptl_average_one(const ptl_frame_list& frames, in
 #endif
 }
 
+// One pixel with 4-byte accesses: the up-to-three pixels behind the last whole 16-byte vector of a frame.
+__device__ __forceinline__ void ptl_average_tail_pixel(const ptl_frame_list& frames, int n, unsigned int magic, unsigned int* __restrict__ out, long px) {
+    unsigned int r = 0u, g = 0u, b = 0u;
+    for (int f = 0; f < n; ++f) {
+        const unsigned int w = reinterpret_cast<const unsigned int*>(frames.frame[f])[px];
+        const unsigned int cr = w & 0xffu, cg = (w >> 8) & 0xffu, cb = (w >> 16) & 0xffu;
+        r += cr * cr;
+        g += cg * cg;
+        b += cb * cb;
+    }
+    out[px] = ptl_l_to_s(ptl_div_n(r, magic)) | (ptl_l_to_s(ptl_div_n(g, magic)) << 8) | (ptl_l_to_s(ptl_div_n(b, magic)) << 16) | 0xff000000u;
+}
+
 extern "C" __global__ void __launch_bounds__(256)
-ptl_average_images_kernel(ptl_frame_list frames, int n, ptl_u32x4* __restrict__ out, long n_vec) {
+ptl_average_images_kernel(ptl_frame_list frames, int n, ptl_u32x4* __restrict__ out, long n_px) {
     const long stride = (long)gridDim.x * 256;
+    const long n_vec = n_px >> 2;  // whole 4-pixel vectors
     const unsigned int magic = n > 1 ? 0xffffffffu / (unsigned)n + 1u : 0u;  // wave-uniform: one division on the scalar side of things
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += stride * PTL_AVG_VPT) {
 #pragma unroll
         for (int v = 0; v < PTL_AVG_VPT; ++v)
             if (i + v * stride < n_vec) ptl_average_one(frames, n, magic, out, i + v * stride);
     }
+    if (blockIdx.x == 0 && threadIdx.x < (n_px & 3)) ptl_average_tail_pixel(frames, n, magic, reinterpret_cast<unsigned int*>(out), n_vec * 4 + threadIdx.x);
 }

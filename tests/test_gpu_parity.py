@@ -306,6 +306,25 @@ def test_camera_walks_through_a_portal(gpu):
     assert _bits_equal(out["rgba32f"], want["rgba32f"]).all()
 
 
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 1), (5, 7), (13, 11), (1023, 3)])
+def test_average_images_any_frame_size(gpu, w, h):
+    """Frames whose pixel count is not a multiple of four (the kernel's 16-byte vectors): the one to three pixels behind the last
+    whole vector take the scalar path; byte-exact like the rest, nothing written past the end."""
+    import torch
+    from oracle import postprocess as pp
+
+    pa = gpu
+    rng = np.random.default_rng(w * 100 + h)
+    frames = [rng.integers(0, 256, (h, w, 4), dtype=np.uint8) for _ in range(3)]
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    guard = torch.full((h * w * 4 + 64,), 77, dtype=torch.uint8, device="cuda")
+    out = guard[: h * w * 4].view(h, w, 4)
+    pa.average_images_device([d.data_ptr() for d in dev], out.data_ptr(), w, h, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), pp.average_images(frames))
+    assert bool((guard[h * w * 4:] == 77).all())
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 7, 16])
 def test_average_images_kernel_matches_oracle(gpu, n):
     """Motion-blur averaging (src/main.rs:645-722): byte-exact against the CPU restatement, ragged N."""
