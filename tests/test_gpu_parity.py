@@ -681,3 +681,23 @@ def test_ragged_sizes_and_extreme_options(gpu, w, h, depth, aa, stride):
     for phase in range(stride):
         pa.deinterleave_rows(r.draw(w, h, rb_phase=phase, rb_stride=stride)["rgba8"], pa.Frame(w, h, phase, stride), full)
     assert np.array_equal(full, whole["rgba8"])
+
+
+def test_render_cli_sharded_equals_unsharded(gpu, tmp_path):
+    """`--shard K/N` (one process per GPU, every N-th frame, no collective): two shards plus the closing pass leave exactly the
+    PNG files of one uninterrupted run -- including the camera history (skipped frames still run the host step)."""
+    import subprocess
+
+    pa = gpu
+    exe = os.path.join(os.path.dirname(pa.__file__), "portal-amd")
+    base = [exe, "render", pa.scene_path("portal_in_portal"), "intro.5", "--width", "320", "--height", "180", "--fps", "8", "--motion-blur-frames", "2",
+            "--aa-count", "2", "--render-depth", "20"]
+    runs = [(tmp_path / "whole", []), (tmp_path / "parts", ["--shard", "1/2"]), (tmp_path / "parts", ["--shard", "0/2"]), (tmp_path / "parts", [])]
+    for out_dir, extra in runs:
+        done = subprocess.run(base + ["--out-dir", str(out_dir)] + extra, capture_output=True, text=True, timeout=600)
+        assert done.returncode == 0, done.stderr + done.stdout
+    frames = lambda d: d / "video" / "portal_in_portal" / "intro.5.frames"
+    names = sorted(os.listdir(frames(tmp_path / "whole")))
+    assert names and names == sorted(os.listdir(frames(tmp_path / "parts")))
+    for n in names:
+        assert (frames(tmp_path / "whole") / n).read_bytes() == (frames(tmp_path / "parts") / n).read_bytes(), n
