@@ -34,14 +34,14 @@ FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 
 
 
-def profiled_traffic(args, waves):
+def profiled_traffic(args, build):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_*.json: FETCH_SIZE and
     WRITE_SIZE are collected in separate passes, KB units, FETCH_SIZE doubled per the gfx950 note in
     MI355X_MICROARCH.md) -- only when that profile is of exactly this workload and build, else None."""
-    if (args.scene, args.width, args.height, args.depth, args.aa, args.specialize) != ("portal_in_portal", 3840, 2160, 40, 1, 2) or waves not in (0, 3, 4):
+    if (args.scene, args.width, args.height, args.depth, args.aa, args.specialize) != ("portal_in_portal", 3840, 2160, 40, 1, 2):
         return None
     try:
-        c = json.load(open(os.path.join(HERE, "profiles", "r01", f"pmc_pip4k_spec_w{waves}.json")))["counters"]
+        c = json.load(open(os.path.join(HERE, "profiles", "r01", f"pmc_pip4k_spec_{build}.json")))["counters"]
         return int((2 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024)
     except Exception:
         return None
@@ -70,7 +70,8 @@ def parse_args():
     p.add_argument("--panini", type=float, default=-1.0, help="Panini d parameter (enables the projection); fov via --fov")
     p.add_argument("--fov", type=float, default=90.0)
     p.add_argument("--specialize", type=int, default=2, help="JIT specialisation: 0 none, 1 bake Bool/Int scene uniforms, 2 bake all scene uniforms")
-    p.add_argument("--waves", type=int, default=-1, help="occupancy hint (__launch_bounds__(256, n)); -1 = pick the fastest of {0,3,4} before timing")
+    p.add_argument("--waves", type=int, default=-1, help="occupancy hint (__launch_bounds__(256, n)); -1 = pick the fastest candidate build before timing")
+    p.add_argument("--build", default="", help="pin one candidate build by name (w0, w3, w4, minreg) instead of picking the fastest")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     p.add_argument("--save-png", default="")
@@ -155,30 +156,48 @@ def main():
     stream = torch.cuda.current_stream(dev)
     spec_flags = {0: 0, 1: pa.FLAG_SPECIALIZE_INTS, 2: pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL}[args.specialize]
 
-    def make_renderer(waves):
-        r = pa.SceneRenderer(scene, device=local_rank, flags=spec_flags | pa.flag_waves(waves))
+    def make_renderer(waves, extra_flags=""):
+        # PTL_HIPRTC_FLAGS is read when the kernel is compiled (and is part of the code-object cache key)
+        saved = os.environ.get("PTL_HIPRTC_FLAGS")
+        os.environ["PTL_HIPRTC_FLAGS"] = ((saved + " ") if saved else "") + extra_flags
+        try:
+            r = pa.SceneRenderer(scene, device=local_rank, flags=spec_flags | pa.flag_waves(waves))
+        finally:
+            if saved is None:
+                os.environ.pop("PTL_HIPRTC_FLAGS", None)
+            else:
+                os.environ["PTL_HIPRTC_FLAGS"] = saved
         configure(r, args)
         return r
 
-    # untimed: JIT-compile the candidate builds (same arithmetic, different register budgets) and keep
-    # the fastest on this rank's shard
+    # untimed: JIT-compile the candidate builds (same arithmetic: different register budgets / instruction schedulers) and keep
+    # the fastest on this rank's shard.  16 launches each after a short spin-up, so that differences of a few percent are real.
+    candidates = {"w0": (0, ""), "w3": (3, ""), "w4": (4, ""), "minreg": (0, "-mllvm -amdgpu-sched-strategy=iterative-minreg")}
+    if args.build:
+        candidates = {args.build: candidates[args.build]}
+    elif args.waves >= 0:
+        candidates = {f"w{args.waves}": (args.waves, "")}
     tried = {}
-    for waves in ([0, 3, 4] if args.waves < 0 else [args.waves]):
-        cand = make_renderer(waves)
-        ms = min(cand.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(3))
-        tried[waves] = (ms, cand, cand.resources())
+    for name, (waves, extra) in candidates.items():
+        cand = make_renderer(waves, extra)
+        for _ in range(8):
+            cand.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream)
+        ms = float(np.median([cand.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(16)]))
+        tried[name] = (ms, cand, cand.resources(), waves)
     fastest = min(v[0] for v in tried.values())
     # a build that spills to scratch moves an order of magnitude more bytes than the framebuffer for a few
     # percent of time: take it only if it wins by more than 6 %, otherwise the fastest spill-free build
     clean = {k: v for k, v in tried.items() if v[2]["scratch_bytes"] == 0 and v[0] <= fastest * 1.06}
     pool = clean if clean else tried
-    best_waves = min(pool, key=lambda k: pool[k][0])
+    best = min(pool, key=lambda k: pool[k][0])
     if world > 1:  # all ranks must run the same build: take rank 0's choice
-        choice = torch.tensor([best_waves], device=dev)
+        names = list(candidates)
+        choice = torch.tensor([names.index(best)], device=dev)
         dist.broadcast(choice, 0)
-        best_waves = int(choice.item())
-    renderer = tried[best_waves][1]
-    tuning = {str(k): {"ms": round(v[0], 4), **v[2]} for k, v in tried.items()}
+        best = names[int(choice.item())]
+    renderer = tried[best][1]
+    best_waves = tried[best][3]
+    tuning = {k: {"ms": round(v[0], 4), **v[2]} for k, v in tried.items()}
     del tried
     # N > 1: two shard buffers; the gather of frame n (RCCL, on the process group's stream) overlaps the
     # tracing of frame n+1; a buffer is reused only after its gather has been waited for
@@ -286,14 +305,14 @@ def main():
                             + (f" panini d={args.panini} fov={args.fov}" if args.panini >= 0 else ""),
                 "parallelism": f"row-block interleave x{world}" + (" + RCCL gather to rank 0, double-buffered (gather n overlaps trace n+1)" if world > 1 else ""),
                 "jit_specialisation": ["none", "int/bool scene uniforms baked", "all scene uniforms baked (camera dynamic)"][args.specialize],
-                "waves_per_simd_hint": best_waves,
+                "build": best, "waves_per_simd_hint": best_waves,
                 "tuning_ms": tuning,
             },
             "kernel_ms": round(kernel_ms, 4),
         }
         hbm = {
             "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-            "traffic": profiled_traffic(args, best_waves),
+            "traffic": profiled_traffic(args, best),
             "note": "algorithmic bytes = the RGBA8 framebuffer store (4 B/pixel); constants and textures are cache-resident",
         }
         if segments is not None:
