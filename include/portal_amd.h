@@ -130,6 +130,11 @@ void ptl_scene_free(ptl_scene* s);
 
 /* Override a named uniform's stored value (what a GUI slider / stage does). 1 = no such uniform. */
 int ptl_scene_set_uniform(ptl_scene* s, const char* name, double value);
+/* Trefoil uniforms in the reference's text form (TrefoilSpecial::decode / encode, src/gui/uniform.rs:23-98; its unit test:
+ * "1a 2a G,1b 3b B,2a 1a S" round-trips): part 1a teleports to part 2a and is drawn in colour G, ...  Returns
+ * PTL_UNKNOWN_UNIFORM (1) for an unknown name, a uniform of another kind, or text that does not decode. */
+int ptl_scene_set_trefoil(ptl_scene* s, const char* name, const char* text);
+int ptl_scene_get_trefoil(ptl_scene* s, const char* name, char* text, size_t cap);
 /* Formula time inputs (FormulasCache::set_time / set_total_time). */
 int ptl_scene_set_time(ptl_scene* s, double time, double total_time);
 

@@ -105,6 +105,8 @@ def _load() -> C.CDLL:
         "ptl_scene_free": (None, [vp]),
         "ptl_scene_set_uniform": (ci, [vp, cp, cd]),
         "ptl_scene_set_time": (ci, [vp, cd, cd]),
+        "ptl_scene_set_trefoil": (ci, [vp, cp, cp]),
+        "ptl_scene_get_trefoil": (ci, [vp, cp, cp, cs]),
         "ptl_scene_init_stage": (ci, [vp, cp, cp, cs]),
         "ptl_scene_stage_name": (ci, [vp, ci, cp, cs]),
         "ptl_scene_camera_name": (ci, [vp, ci, cp, cs]),
@@ -248,6 +250,17 @@ class Scene:
         """What Matrix::Camera evaluates to: 4x4, m[row][col] (a renderer sends its camera's matrix itself)."""
         a = (C.c_double * 16)(*np.asarray(m, np.float64).reshape(4, 4).T.reshape(-1))
         _check(lib().ptl_scene_set_camera_matrix(self._h, a), "set_camera_matrix")
+
+    def set_trefoil(self, name: str, text: str) -> None:
+        """A Trefoil uniform from the reference's text form, e.g. "1a 2a G,1b 3b B,2a 1a S" (TrefoilSpecial::decode)."""
+        if _check(lib().ptl_scene_set_trefoil(self._h, name.encode(), text.encode()), "set_trefoil") != 0:
+            raise PortalError(f"`{name}` is not a Trefoil uniform, or `{text}` does not decode")
+
+    def get_trefoil(self, name: str) -> str:
+        buf = C.create_string_buffer(512)
+        if _check(lib().ptl_scene_get_trefoil(self._h, name.encode(), buf, 512), "get_trefoil") != 0:
+            raise PortalError(f"`{name}` is not a Trefoil uniform")
+        return buf.value.decode()
 
     def to_ron(self) -> str:
         """The scene as a .ron document in the reference's layout (its writer: serialize_scene_new_format + pretty RON)."""

@@ -251,6 +251,19 @@ extern "C" int ptl_scene_set_uniform(ptl_scene* s, const char* name, double valu
     if (!s || !name) return PTL_ERR_INVALID;
     return s->scene->set_uniform_value(name, value) ? PTL_OK : PTL_UNKNOWN_UNIFORM;
 }
+extern "C" int ptl_scene_set_trefoil(ptl_scene* s, const char* name, const char* text) {
+    if (!s || !name || !text) return PTL_ERR_INVALID;
+    return guarded([&] { return s->scene->set_trefoil(name, text) ? PTL_OK : PTL_UNKNOWN_UNIFORM; });
+}
+extern "C" int ptl_scene_get_trefoil(ptl_scene* s, const char* name, char* text, size_t cap) {
+    if (!s || !name) return PTL_ERR_INVALID;
+    return guarded([&] {
+        auto t = s->scene->get_trefoil(name);
+        if (!t) return (int)PTL_UNKNOWN_UNIFORM;
+        copy_str(text, cap, *t);
+        return (int)PTL_OK;
+    });
+}
 extern "C" int ptl_scene_set_time(ptl_scene* s, double time, double total_time) {
     if (!s) return PTL_ERR_INVALID;
     if (s->scene->time != time || s->scene->total_time != total_time) ++s->scene->version;

@@ -1,6 +1,7 @@
 // scene.cpp -- RON document -> Scene, and evaluation of uniforms / matrices (see scene.h).
 #include "scene.h"
 
+#include <cstring>
 #include <fstream>
 #include <sstream>
 
@@ -726,6 +727,109 @@ bool Scene::set_uniform_value(const std::string& name, double v) {
     }
     write_uniform_to_doc(doc, name, u);
     return true;
+}
+
+bool Scene::trefoil_decode(const std::string& text, int out[18][3]) {
+    int parts[18][3] = {};
+    auto name_to_index = [](const std::string& n) -> int {  // "1a" .. "6c"
+        if (n.size() != 2 || n[1] < 'a' || n[1] > 'c' || n[0] < '1' || n[0] > '6') return -1;
+        return (n[1] - 'a') + (n[0] - '1') * 3;
+    };
+    static const char* kColors[6] = {"R", "G", "B", "Y", "V", "S"};
+    size_t pos = 0;
+    while (pos <= text.size()) {
+        size_t comma = text.find(',', pos);
+        if (comma == std::string::npos) comma = text.size();
+        std::string item = text.substr(pos, comma - pos);
+        pos = comma + 1;
+        if (item.empty()) continue;
+        std::vector<std::string> words;  // split(" "): exactly three words, no tolerance for double spaces (like the reference)
+        size_t w = 0;
+        for (;;) {
+            size_t sp = item.find(' ', w);
+            words.push_back(item.substr(w, sp == std::string::npos ? std::string::npos : sp - w));
+            if (sp == std::string::npos) break;
+            w = sp + 1;
+        }
+        if (words.size() != 3) return false;
+        int index = name_to_index(words[0]), to = name_to_index(words[1]), color = -1;
+        for (int c = 0; c < 6; ++c)
+            if (words[2] == kColors[c]) color = c;
+        if (index < 0 || to < 0 || color < 0) return false;
+        parts[index][0] = 1;
+        parts[index][1] = to;
+        parts[index][2] = color;
+    }
+    std::memcpy(out, parts, sizeof parts);
+    return true;
+}
+
+std::string Scene::trefoil_encode(const int parts[18][3]) {
+    static const char* kColors[6] = {"R", "G", "B", "Y", "V", "S"};
+    auto index_to_name = [](int i) { return std::string(1, (char)('1' + i / 3)) + (char)('a' + i % 3); };
+    std::string out;
+    for (int i = 0; i < 18; ++i) {
+        if (!parts[i][0]) continue;
+        if (!out.empty()) out += ',';
+        out += index_to_name(i) + " " + index_to_name(parts[i][1]) + " " + kColors[parts[i][2] % 6];
+    }
+    return out;
+}
+
+bool Scene::set_trefoil(const std::string& name, const std::string& text) {
+    int idx = find_uniform(name);
+    if (idx < 0) return false;
+    int parts[18][3];
+    if (!trefoil_decode(text, parts)) return false;
+    if (idx < (int)uniform_alias.size() && uniform_alias[idx] >= 0) {
+        uniforms[idx].value = uniforms[uniform_alias[idx]].value;
+        uniform_alias[idx] = -1;
+    }
+    Uniform& u = uniforms[idx].value;
+    if (u.kind != Uniform::Trefoil) return false;
+    std::memcpy(u.trefoil, parts, sizeof parts);
+    ++version;
+    // the document: TrefoilSpecial(( ((enabled, to, colour), ... x18) ))
+    for (auto& field : doc.fields) {
+        if (field.first != "uniforms") continue;
+        ron::Value* list = &field.second;
+        while (list->kind == ron::Value::Tuple && list->items.size() == 1 && list->s.empty()) list = &list->items[0];
+        for (ron::Value& item : list->items) {
+            const ron::Value* n = item.find("name");
+            if (!n || n->s != name) continue;
+            for (auto& f : item.fields) {
+                if (f.first != "data") continue;
+                ron::Value tuple;
+                tuple.kind = ron::Value::Tuple;
+                for (int i = 0; i < 18; ++i) {
+                    ron::Value e, b, to, col;
+                    e.kind = ron::Value::Tuple;
+                    b.kind = ron::Value::Bool;
+                    b.b = parts[i][0] != 0;
+                    to.kind = col.kind = ron::Value::Int;
+                    to.i = parts[i][1];
+                    col.i = parts[i][2];
+                    e.items = {b, to, col};
+                    tuple.items.push_back(e);
+                }
+                ron::Value inner;
+                inner.kind = ron::Value::Tuple;
+                inner.items.push_back(tuple);
+                ron::Value outer;
+                outer.kind = ron::Value::Tuple;
+                outer.s = "TrefoilSpecial";
+                outer.items.push_back(inner);
+                f.second = outer;
+            }
+        }
+    }
+    return true;
+}
+
+std::optional<std::string> Scene::get_trefoil(const std::string& name) const {
+    const Uniform* u = resolved_uniform(find_uniform(name));
+    if (!u || u->kind != Uniform::Trefoil) return std::nullopt;
+    return trefoil_encode(u->trefoil);
 }
 
 int Scene::find_camera(const std::string& name) const {

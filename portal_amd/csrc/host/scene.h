@@ -225,6 +225,12 @@ public:
 
     // overrides (what a stage / animation / user slider does): set the stored value
     bool set_uniform_value(const std::string& name, double v);
+    // TrefoilSpecial::decode / encode (src/gui/uniform.rs:23-98): "1a 2a G,1b 3b B" = part 1a teleports to 2a with colour G ...
+    // set_trefoil returns false for an unknown uniform, a uniform of another kind, or text that does not decode.
+    static bool trefoil_decode(const std::string& text, int out[18][3]);
+    static std::string trefoil_encode(const int parts[18][3]);
+    bool set_trefoil(const std::string& name, const std::string& text);
+    std::optional<std::string> get_trefoil(const std::string& name) const;
 
     // Scene::init_stage_by_name (src/gui/scene.rs:1237-1250): apply an animation stage's overrides.
     // Returns false if there is no such stage; *camera = index into `cameras` the stage selects, or -1.

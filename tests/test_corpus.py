@@ -135,3 +135,21 @@ def test_corpus_scene_writer_reproduces_the_file(pa, path):
     text = open(path, encoding="utf-8").read()
     assert pa.ron_format(text) == text
     assert pa.Scene.from_file(path).to_ron() == text
+
+
+def test_trefoil_text_form_reference_vector(pa):
+    """The reference's own unit test (src/gui/uniform.rs:258-264): "1a 2a G,1b 3b B,2a 1a S" decodes and encodes back to itself;
+    on trefoil.ron it lands in the 18 packed `ts_<i>_trefoil_u` ints (value + enabled * 10000 + colour * 1000) and in the written file."""
+    s = pa.Scene.from_file(os.path.join(CORPUS, "trefoil.ron"))
+    text = "1a 2a G,1b 3b B,2a 1a S"
+    s.set_trefoil("trefoil", text)
+    assert s.get_trefoil("trefoil") == text
+    v = s.uniform_values()
+    assert int(v["ts_0_trefoil_u"]) == 3 + 10000 + 1000 and int(v["ts_1_trefoil_u"]) == 7 + 10000 + 2000 and int(v["ts_3_trefoil_u"]) == 0 + 10000 + 5000
+    assert int(v["ts_2_trefoil_u"]) == 0 and int(v["ts_17_trefoil_u"]) == 0
+    assert "TrefoilSpecial((((true, 3, 1), (true, 7, 2), (false, 0, 0), (true, 0, 5), (false, 0, 0)," in s.to_ron()
+    for bad in ("1a 2a", "1a 2a Q", "7a 1a G", "1a  2a G"):
+        with pytest.raises(pa.PortalError):
+            s.set_trefoil("trefoil", bad)
+    with pytest.raises(pa.PortalError):
+        s.set_trefoil("use_origin_room", text)

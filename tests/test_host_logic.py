@@ -650,3 +650,16 @@ def test_scene_writer_materialises_stages_and_clips(pa, name):
         for k, v in named(a).items():
             assert np.array_equal(np.asarray(v), np.asarray(named(b)[k]), equal_nan=True), (kind, n, k)
         assert unnamed(a) == unnamed(b), (kind, n)
+
+
+def test_trefoil_text_codec_reference_vector(pa):
+    """The reference's unit test `trefoil` (src/gui/uniform.rs:258-264): "1a 2a G,1b 3b B,2a 1a S" -> decode -> encode is the same text."""
+    from tests import synthetic
+
+    zeros = ", ".join(["(false, 0, 0)"] * 18)
+    text = synthetic.wall_scene().replace('uniforms: ([', f'uniforms: ([ (name: "knot", data: TrefoilSpecial((({zeros})))),')
+    s = pa.Scene.from_text(text)
+    assert s.get_trefoil("knot") == ""
+    s.set_trefoil("knot", "1a 2a G,1b 3b B,2a 1a S")
+    assert s.get_trefoil("knot") == "1a 2a G,1b 3b B,2a 1a S"
+    assert int(s.uniform_values()["ts_3_knot_u"]) == 15000 and pa.Scene.from_text(s.to_ron()).get_trefoil("knot") == "1a 2a G,1b 3b B,2a 1a S"
