@@ -36,6 +36,15 @@ VARIANTS = {
     "all_w5": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=5",
     "all_nomisched": "SPECIALIZE_ALL -mllvm -enable-misched=false",
     "all_O0ish": "SPECIALIZE_ALL -O1 -mllvm -disable-licm-promotion -mllvm -enable-gvn-hoist=false",
+    "all_ifcvt": "SPECIALIZE_ALL -mllvm -amdgpu-early-ifcvt=1",
+    "all_skip4": "SPECIALIZE_ALL -mllvm -amdgpu-skip-threshold=4",
+    "all_skip64": "SPECIALIZE_ALL -mllvm -amdgpu-skip-threshold=64",
+    "all_bias0": "SPECIALIZE_ALL -mllvm -amdgpu-schedule-metric-bias=0",
+    "all_bias100": "SPECIALIZE_ALL -mllvm -amdgpu-schedule-metric-bias=100",
+    "all_nopostsched": "SPECIALIZE_ALL -mllvm -enable-post-misched=0",
+    "all_minreg_w4": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg -DPTL_WAVES_PER_EU=4",
+    "all_minreg_ifcvt": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg -mllvm -amdgpu-early-ifcvt=1",
+    "all_relaxocc": "SPECIALIZE_ALL -mllvm -amdgpu-schedule-relaxed-occupancy=true",
     "all_Os": "SPECIALIZE_ALL -Os",
     "all_Oz": "SPECIALIZE_ALL -Oz",
     "base_Os": "-Os",
@@ -72,11 +81,13 @@ def run_one(case, vname, flags):
 
 
 if __name__ == "__main__":
+    if sys.argv[1:2] == ["--one"]:  # child: one (case, variant); an unknown -mllvm option makes LLVM exit() the whole process
+        print(json.dumps(run_one(sys.argv[2], sys.argv[3], VARIANTS[sys.argv[3]])), flush=True)
+        sys.exit(0)
     cases = [a for a in sys.argv[1:] if ":" in a] or CASES
     names = [a for a in sys.argv[1:] if ":" not in a] or list(VARIANTS)
     for case in cases:
         for v in names:
-            try:
-                print(json.dumps(run_one(case, v, VARIANTS[v])), flush=True)
-            except Exception as e:
-                print(json.dumps({"case": case, "variant": v, "error": str(e)[:400]}), flush=True)
+            done = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", case, v], capture_output=True, text=True)
+            line = [l for l in done.stdout.splitlines() if l.startswith("{")]
+            print(line[-1] if line else json.dumps({"case": case, "variant": v, "error": (done.stderr or done.stdout)[-300:]}), flush=True)
