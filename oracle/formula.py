@@ -116,7 +116,7 @@ def _neg(n):
 
 
 def _inv(n):
-    return ("const", 1.0 / n[1]) if _is_const(n) else ("inv", n)
+    return ("const", _fdiv(1.0, n[1])) if _is_const(n) else ("inv", n)
 
 
 def _chain(kind, nodes, identity):
@@ -146,40 +146,74 @@ BUILTIN_ARITY = {"int": (1, 1), "ceil": (1, 1), "floor": (1, 1), "abs": (1, 1), 
                  "asinh": (1, 1), "acosh": (1, 1), "atanh": (1, 1)}
 
 
+# ---- IEEE binary64 semantics where Python raises instead (Rust, like C, returns inf / NaN) ----------------------
+def _fdiv(a, b):
+    try:
+        return a / b
+    except ZeroDivisionError:
+        if a == 0 or a != a:
+            return float("nan")
+        return math.copysign(math.inf, a) * math.copysign(1.0, b)
+
+
+def _ln(x, fn=math.log):
+    if x != x or x < 0:
+        return float("nan")
+    if x == 0:
+        return float("-inf")
+    return fn(x)
+
+
+def _is_odd_integer(p):
+    return math.isfinite(p) and p == math.floor(p) and math.fmod(p, 2.0) != 0.0
+
+
+def _libm(name, x):
+    """math.<name>(x) with C's results where Python raises: domain errors are NaN, except the poles (atanh(+-1) = +-inf);
+    overflow is +-inf with the sign the function has there."""
+    try:
+        return getattr(math, name)(x)
+    except ValueError:
+        if name == "atanh" and abs(x) == 1.0:
+            return math.copysign(math.inf, x)
+        return float("nan")
+    except OverflowError:
+        return math.copysign(math.inf, x) if name in ("sinh", "tan") else math.inf
+
+
 def _builtin(name, a):
-    if name == "int":
-        return float(math.trunc(a[0])) if math.isfinite(a[0]) else a[0]
-    if name == "ceil":
-        return float(math.ceil(a[0])) if math.isfinite(a[0]) else a[0]
-    if name == "floor":
-        return float(math.floor(a[0])) if math.isfinite(a[0]) else a[0]
+    if name in ("int", "ceil", "floor"):  # Python's versions return ints: restore the IEEE sign of a zero result (ceil(-0.5) = -0.0)
+        if not math.isfinite(a[0]):
+            return a[0]
+        r = float({"int": math.trunc, "ceil": math.ceil, "floor": math.floor}[name](a[0]))
+        return math.copysign(0.0, a[0]) if r == 0.0 else r
     if name == "abs":
         return abs(a[0])
     if name == "sign":
         return a[0] if math.isnan(a[0]) else math.copysign(1.0, a[0])
     if name == "log":
         base, n = (a[0], a[1]) if len(a) == 2 else (10.0, a[0])
-        try:
-            if base == 2.0:
-                return math.log2(n)
-            if base == 10.0:
-                return math.log10(n)
-            return math.log(n) / math.log(base)
-        except ValueError:
-            return float("nan") if n < 0 else float("-inf")
+        if base == 2.0:
+            return _ln(n, math.log2)
+        if base == 10.0:
+            return _ln(n, math.log10)
+        return _fdiv(_ln(n), _ln(base))  # f64::log(self, base) = self.ln() / base.ln()
     if name == "round":
         modulus, n = (a[0], a[1]) if len(a) == 2 else (1.0, a[0])
-        q = n / modulus
+        q = _fdiv(n, modulus)
         r = math.floor(abs(q) + 0.5) * math.copysign(1.0, q) if math.isfinite(q) else q  # half away from zero
         return r * modulus
-    if name == "min":
-        return min(a)
+    if name == "min":  # f64::min folded left to right: NaN operands are ignored, the earlier argument keeps a +-0 tie
+        m = a[0]
+        for x in a[1:]:
+            m = _fmin(m, x)
+        return m
     if name == "max":
-        return max(a)
-    try:
-        return getattr(math, name)(a[0])
-    except (ValueError, OverflowError):
-        return float("nan")
+        m = a[0]
+        for x in a[1:]:
+            m = _fmax(m, x)
+        return m
+    return _libm(name, a[0])
 
 
 def _compile_value(v):
@@ -267,13 +301,15 @@ def _compile_slice(first, pairs):
 
 
 def _pow(b, p):
+    """C pow(): Python raises for the poles and on overflow."""
     try:
-        r = math.pow(b, p)
+        return math.pow(b, p)
     except OverflowError:
-        return float("inf")
+        return -math.inf if b < 0 and _is_odd_integer(p) else math.inf
     except ValueError:
-        return float("nan")
-    return r
+        if b == 0 and p < 0:  # pow(+-0, negative) = inf, carrying the zero's sign for odd integer exponents
+            return math.copysign(math.inf, b) if _is_odd_integer(p) else math.inf
+        return float("nan")  # negative base, non-integer exponent
 
 
 def compile_formula(text: str):
@@ -284,11 +320,7 @@ def compile_formula(text: str):
     return _compile_expr(e)
 
 
-def _div(a, b):
-    try:
-        return a / b
-    except ZeroDivisionError:
-        return math.copysign(math.inf, a) * math.copysign(1.0, b) if a != 0 else float("nan")
+_div = _fdiv
 
 
 def evaluate(node, ns):
@@ -340,17 +372,25 @@ def evaluate(node, ns):
     raise FormulaError(k)
 
 
+def _fmax(a, b):  # f64::max: the other operand if one is NaN; a tie keeps the first
+    return b if a != a else (b if b > a else a)
+
+
+def _fmin(a, b):
+    return b if a != a else (b if b < a else a)
+
+
 # ---- the reference's callback table (src/gui/uniform.rs:1014-1124) ----------------------------
 def _is1(v):
     return abs(v - 1.0) < 1e-6
 
 
 def _easing_in(t):
-    return 1.0 - math.cos(t * math.pi * 0.5)
+    return 1.0 - _libm('cos', t * math.pi * 0.5)
 
 
 def _easing_in_out(t):
-    return (1.0 - math.cos(t * math.pi)) * 0.5
+    return (1.0 - _libm('cos', t * math.pi)) * 0.5
 
 
 def custom_function(name, a):
@@ -369,11 +409,11 @@ def custom_function(name, a):
         if name == "rad2deg":
             return True, a[0] * 180.0 / math.pi
         if name == "switch":
-            k = int(a[0]) if a[0] > 0 else 0
+            k = (len(a) if a[0] >= 1e18 else int(a[0])) if a[0] > 0 else 0  # Rust `as usize`: NaN and negatives are 0, huge saturates
             return True, (a[k] if k < len(a) else None)
         if name == "on":
             v, lo, hi = a[0], a[1], a[2]
-            return True, (0.0 if v < lo else 1.0 if v > hi else (v - lo) / (hi - lo))
+            return True, (0.0 if v < lo else 1.0 if v > hi else _fdiv(v - lo, hi - lo))
         if name == "inv":
             return True, 1.0 - a[0]
         if name == "sqrt":
@@ -393,19 +433,19 @@ def custom_function(name, a):
         if name == "easing_plus_minus":
             t = a[0] * (2.0 * math.pi)
             t2 = 2.0 * t
-            return True, math.sin(t) * (3.0 - math.cos(t) - math.cos(t2) - math.cos(t) * math.cos(t2)) / 4.0
+            return True, _libm('sin', t) * (3.0 - _libm('cos', t) - _libm('cos', t2) - _libm('cos', t) * _libm('cos', t2)) / 4.0
         if name == "easing_elastic_out":
             x = a[0]
             c4 = (2.0 * math.pi) / 3.0
-            return True, (0.0 if x == 0.0 else 1.0 if x == 1.0 else math.pow(2.0, -10.0 * x) * math.sin((x * 10.0 - 0.75) * c4) + 1.0)
+            return True, (0.0 if x == 0.0 else 1.0 if x == 1.0 else _pow(2.0, -10.0 * x) * _libm('sin', (x * 10.0 - 0.75) * c4) + 1.0)
         if name == "bump":
-            x = (a[0] - a[1]) / a[2]
-            return True, (0.5 * (1.0 + math.cos(math.pi * x)) if abs(x) < 1.0 else 0.0)
+            x = _fdiv(a[0] - a[1], a[2])
+            return True, (0.5 * (1.0 + _libm('cos', math.pi * x)) if abs(x) < 1.0 else 0.0)
         if name == "later_start":
             t, time = a[0], 1.0 - a[1]
-            return True, max(0.0, t / time - (1.0 - time) / time)
+            return True, _fmax(0.0, _fdiv(t, time) - _fdiv(1.0 - time, time))
         if name == "early_finish":
-            return True, min(1.0, a[0] / a[1])
+            return True, _fmin(1.0, _fdiv(a[0], a[1]))
         if name == "lerp":
             return True, (1.0 - a[2]) * a[0] + a[2] * a[1]
     except IndexError:

@@ -375,14 +375,18 @@ double eval_builtin(Node::Kind k, const std::vector<double>& a) {
             double modulus = a.size() == 2 ? a[0] : 1.0;
             return std::round(a.back() / modulus) * modulus;
         }
+        // f64::min / max folded over the arguments: a NaN operand is ignored; which of +0 / -0 wins a tie is not defined by
+        // Rust (llvm.minnum) -- here, as in the oracle, the earlier argument stays
         case Node::FMin: {
             double m = a[0];
-            for (size_t i = 1; i < a.size(); ++i) m = std::fmin(m, a[i]);
+            for (size_t i = 1; i < a.size(); ++i)
+                if (std::isnan(m) || a[i] < m) m = a[i];
             return m;
         }
         case Node::FMax: {
             double m = a[0];
-            for (size_t i = 1; i < a.size(); ++i) m = std::fmax(m, a[i]);
+            for (size_t i = 1; i < a.size(); ++i)
+                if (std::isnan(m) || a[i] > m) m = a[i];
             return m;
         }
         case Node::FSin: return std::sin(a[0]);
@@ -575,11 +579,13 @@ std::optional<double> formula_custom_function(const std::string& name, const std
     if (name == "later_start") {
         if (!need(2)) return std::nullopt;
         double t = a[0], time = 1.0 - a[1];
-        return std::fmax(0.0, t / time - (1.0 - time) / time);
+        double v = t / time - (1.0 - time) / time;
+        return v > 0.0 ? v : 0.0;  // f64::max(0.0, v): NaN -> 0, a +-0 tie keeps the first operand
     }
     if (name == "early_finish") {
         if (!need(2)) return std::nullopt;
-        return std::fmin(1.0, a[0] / a[1]);
+        double v = a[0] / a[1];
+        return v < 1.0 ? v : 1.0;  // f64::min(1.0, v)
     }
     if (name == "lerp") {  // egui::lerp(a..=b, t)
         if (!need(3)) return std::nullopt;
