@@ -476,6 +476,16 @@ PTL_FN vec3 mix(const vec3& a, const vec3& b, const vec3& t) { return vec3(mix(a
 PTL_FN vec4 mix(const vec4& a, const vec4& b, const vec4& t) { return vec4(mix(a.x, b.x, t.x), mix(a.y, b.y, t.y), mix(a.z, b.z, t.z), mix(a.w, b.w, t.w)); }
 PTL_FN vec2 smoothstep(float e0, float e1, const vec2& a) { return vec2(smoothstep(e0, e1, a.x), smoothstep(e0, e1, a.y)); }
 PTL_FN vec3 smoothstep(float e0, float e1, const vec3& a) { return vec3(smoothstep(e0, e1, a.x), smoothstep(e0, e1, a.y), smoothstep(e0, e1, a.z)); }
+PTL_FN vec4 smoothstep(float e0, float e1, const vec4& a) {
+    return vec4(smoothstep(e0, e1, a.x), smoothstep(e0, e1, a.y), smoothstep(e0, e1, a.z), smoothstep(e0, e1, a.w));
+}
+PTL_FN vec2 smoothstep(const vec2& e0, const vec2& e1, const vec2& a) { return vec2(smoothstep(e0.x, e1.x, a.x), smoothstep(e0.y, e1.y, a.y)); }
+PTL_FN vec3 smoothstep(const vec3& e0, const vec3& e1, const vec3& a) {
+    return vec3(smoothstep(e0.x, e1.x, a.x), smoothstep(e0.y, e1.y, a.y), smoothstep(e0.z, e1.z, a.z));
+}
+PTL_FN vec4 smoothstep(const vec4& e0, const vec4& e1, const vec4& a) {
+    return vec4(smoothstep(e0.x, e1.x, a.x), smoothstep(e0.y, e1.y, a.y), smoothstep(e0.z, e1.z, a.z), smoothstep(e0.w, e1.w, a.w));
+}
 
 // geometric -----------------------------------------------------------------------------
 PTL_FN float dot(const vec2& a, const vec2& b) { return fma(a.y, b.y, a.x * b.x); }

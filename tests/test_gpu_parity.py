@@ -704,3 +704,24 @@ def test_render_cli_sharded_equals_unsharded(gpu, tmp_path):
     assert names and names == sorted(os.listdir(frames(tmp_path / "parts")))
     for n in names:
         assert (frames(tmp_path / "whole") / n).read_bytes() == (frames(tmp_path / "parts") / n).read_bytes(), n
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_random_glsl_expressions_on_gpu(gpu, tmp_path, seed):
+    """tests/test_glsl_fuzz.py on the hardware leg: 48 random typed GLSL expressions per scene (builtins, swizzles, constructors,
+    matrix products, ternaries) through translator + prelude + hiprtc + gfx950 == the oracle's GLSL interpreter, bit for bit."""
+    from oracle.portal_oracle import Oracle
+    from tests.test_glsl_fuzz import N_EXPR, fuzz_scene
+
+    pa = gpu
+    text, _ = fuzz_scene(seed)
+    path = tmp_path / "fuzz.ron"
+    path.write_text(text)
+    w, h = 4 * N_EXPR, 12
+    r = pa.SceneRenderer(pa.Scene.from_file(str(path)), device=0)
+    r.set_option("render_depth", 2)
+    r.set_option("view_angle", 1.5)
+    got = r.draw(w, h, rgba32f=True)["rgba32f"]
+    o = Oracle(str(path))
+    o.options.update(render_depth=2, view_angle=1.5)
+    assert _bits_equal(got, o.render(w, h)["rgba32f"]).all()
