@@ -22,6 +22,29 @@ from . import ron
 # ---------------------------------------------------------------------------------------------
 # binary64 4x4 matrices as lists of 4 columns of 4 floats (glam: x_axis..w_axis)
 # ---------------------------------------------------------------------------------------------
+# ---- IEEE binary64 semantics where Python raises (Rust / C return inf or NaN): the graph evaluator must not die on a
+# singular matrix or an infinite angle, it must produce the same NaNs the product uploads
+def _sin(x):
+    return math.sin(x) if math.isfinite(x) else float("nan")
+
+
+def _cos(x):
+    return math.cos(x) if math.isfinite(x) else float("nan")
+
+
+def _sqrt(x):
+    return math.sqrt(x) if x >= 0 else (x if x == 0 else float("nan"))  # sqrt(-0.0) = -0.0, sqrt(negative / NaN) = NaN
+
+
+def _fdiv(a, b):
+    try:
+        return a / b
+    except ZeroDivisionError:
+        if a == 0 or a != a:
+            return float("nan")
+        return math.copysign(math.inf, a) * math.copysign(1.0, b)
+
+
 IDENT = [[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]]
 
 
@@ -68,9 +91,9 @@ def q_mul(a, b):
 
 
 def from_scale_rotation_translation(scale, rot_xyz, t):
-    qx = (math.sin(rot_xyz[0] * 0.5), 0.0, 0.0, math.cos(rot_xyz[0] * 0.5))
-    qy = (0.0, math.sin(rot_xyz[1] * 0.5), 0.0, math.cos(rot_xyz[1] * 0.5))
-    qz = (0.0, 0.0, math.sin(rot_xyz[2] * 0.5), math.cos(rot_xyz[2] * 0.5))
+    qx = (_sin(rot_xyz[0] * 0.5), 0.0, 0.0, _cos(rot_xyz[0] * 0.5))
+    qy = (0.0, _sin(rot_xyz[1] * 0.5), 0.0, _cos(rot_xyz[1] * 0.5))
+    qz = (0.0, 0.0, _sin(rot_xyz[2] * 0.5), _cos(rot_xyz[2] * 0.5))
     x, y, z, w = q_mul(q_mul(qx, qy), qz)
     x2, y2, z2 = x + x, y + y, z + z
     xx, xy, xz = x * x2, x * y2, x * z2
@@ -89,29 +112,30 @@ def to_scale_rotation_translation(m):
     a0323, a0223, a0123 = m20 * m33 - m23 * m30, m20 * m32 - m22 * m30, m20 * m31 - m21 * m30
     det = (m00 * (m11 * a2323 - m12 * a1323 + m13 * a1223) - m01 * (m10 * a2323 - m12 * a0323 + m13 * a0223)
            + m02 * (m10 * a1323 - m11 * a0323 + m13 * a0123) - m03 * (m10 * a1223 - m11 * a0223 + m12 * a0123))
-    length = lambda c: math.sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3])
-    scale = [length(m[0]) * math.copysign(1.0, det), length(m[1]), length(m[2])]
-    ax = [[m[c][r] * (1.0 / scale[c]) for r in range(3)] for c in range(3)]
+    length = lambda c: _sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3])
+    signum = det if det != det else math.copysign(1.0, det)  # f64::signum: NaN stays NaN
+    scale = [length(m[0]) * signum, length(m[1]), length(m[2])]
+    ax = [[m[c][r] * _fdiv(1.0, scale[c]) for r in range(3)] for c in range(3)]
     (x0, x1, x2), (y0, y1, y2), (z0, z1, z2) = ax
     if z2 <= 0.0:      # Mike Day's branches, as in glam's from_rotation_axes
         dif10, omm22 = y1 - x0, 1.0 - z2
         if dif10 <= 0.0:
             f = omm22 - dif10
-            i = 0.5 / math.sqrt(f)
+            i = _fdiv(0.5, _sqrt(f))
             q = [f * i, (x1 + y0) * i, (x2 + z0) * i, (y2 - z1) * i]
         else:
             f = omm22 + dif10
-            i = 0.5 / math.sqrt(f)
+            i = _fdiv(0.5, _sqrt(f))
             q = [(x1 + y0) * i, f * i, (y2 + z1) * i, (z0 - x2) * i]
     else:
         sum10, opm22 = y1 + x0, 1.0 + z2
         if sum10 <= 0.0:
             f = opm22 - sum10
-            i = 0.5 / math.sqrt(f)
+            i = _fdiv(0.5, _sqrt(f))
             q = [(x2 + z0) * i, (y2 + z1) * i, f * i, (x1 - y0) * i]
         else:
             f = opm22 + sum10
-            i = 0.5 / math.sqrt(f)
+            i = _fdiv(0.5, _sqrt(f))
             q = [(y2 - z1) * i, (z0 - x2) * i, (x1 - y0) * i, f * i]
     return scale, q, [m30, m31, m32]
 
@@ -395,7 +419,7 @@ class OracleScene:
         c = self.cameras[idx]
         if c["look_at"][0] == "matrix":
             m = self.eval_matrix(c["look_at"][1])
-            inv_w = 1.0 / m[3][3]
+            inv_w = _fdiv(1.0, m[3][3])
             look = [m[3][k] * inv_w + 0.001 for k in range(3)]
         else:
             look = list(c["look_at"][1])
@@ -468,7 +492,7 @@ class OracleScene:
         c = self.cameras[idx]
         if c["look_at"][0] == "matrix":
             m = self.eval_matrix(c["look_at"][1])
-            inv_w = 1.0 / m[3][3]
+            inv_w = _fdiv(1.0, m[3][3])
             look = [m[3][k] * inv_w + 0.001 for k in range(3)]
         else:
             look = list(c["look_at"][1])
@@ -667,7 +691,7 @@ class OracleScene:
             mix3 = lambda p, q: [p[k] + (q[k] - p[k]) * tt for k in range(3)]
             bias = 1.0 if sum(fr[k] * sr[k] for k in range(4)) >= 0.0 else -1.0
             q = [fr[k] + (sr[k] * bias - fr[k]) * tt for k in range(4)]
-            inv = 1.0 / math.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+            inv = _fdiv(1.0, _sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]))
             return compose_trs(mix3(fs, ss), [c * inv for c in q], mix3(ft, st))
         if t == "Camera":
             return self.camera_object_matrix  # formulas_cache.get_camera_matrix(): what SceneRenderer::update last sent
@@ -737,8 +761,8 @@ class OracleScene:
 # ---------------------------------------------------------------------------------------------
 def ease(kind, t):
     """Easing::ease (src/gui/easing.rs:6-101)."""
-    e_in = lambda x: 1.0 - math.cos(x * math.pi * 0.5)
-    e_io = lambda x: (1.0 - math.cos(x * math.pi)) * 0.5
+    e_in = lambda x: 1.0 - _cos(x * math.pi * 0.5)
+    e_io = lambda x: (1.0 - _cos(x * math.pi)) * 0.5
     if kind == "Linear":
         return t
     if kind == "In":
@@ -752,12 +776,12 @@ def ease(kind, t):
     if kind == "ElasticOut":
         if t == 0.0 or t == 1.0:
             return t
-        return 2.0 ** (-10.0 * t) * math.sin((t * 10.0 - 0.75) * (2.0 * math.pi) / 3.0) + 1.0
+        return 2.0 ** (-10.0 * t) * _sin((t * 10.0 - 0.75) * (2.0 * math.pi) / 3.0) + 1.0
     raise ValueError(kind)
 
 
 def _norm3(v):
-    inv = 1.0 / math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+    inv = _fdiv(1.0, _sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]))
     return [v[0] * inv, v[1] * inv, v[2] * inv]
 
 
@@ -766,7 +790,7 @@ def _cross(a, b):
 
 
 def _pos_vec(alpha, beta, r):
-    return [math.sin(beta) * math.cos(alpha) * r, math.cos(beta) * r, math.sin(beta) * math.sin(alpha) * r]
+    return [_sin(beta) * _cos(alpha) * r, _cos(beta) * r, _sin(beta) * _sin(alpha) * r]
 
 
 def camera_matrix(look_at, alpha, beta, r, teleport_matrix=None, free_movement=False):
@@ -787,7 +811,7 @@ def builtin_uniforms(scene: OracleScene, width, height, render_depth=100, aa_cou
         cam.update(camera)
     tele = cam.get("teleport_matrix") or IDENT
     m = camera_matrix(cam["look_at"], cam["alpha"], cam["beta"], cam["r"], tele, cam.get("free_movement", False))
-    calc_scale = lambda mm: sum(math.sqrt(sum(x * x for x in mm[c])) for c in range(3)) / 3.0  # src/main.rs:1325-1333
+    calc_scale = lambda mm: sum(_sqrt(sum(x * x for x in mm[c])) for c in range(3)) / 3.0  # src/main.rs:1325-1333
     scale = calc_scale(m)
     f, i = np.float32, np.int32
     left, right = cam.get("left_eye_matrix") or IDENT, cam.get("right_eye_matrix") or IDENT
