@@ -725,3 +725,26 @@ def test_random_glsl_expressions_on_gpu(gpu, tmp_path, seed):
     o = Oracle(str(path))
     o.options.update(render_depth=2, view_angle=1.5)
     assert _bits_equal(got, o.render(w, h)["rgba32f"]).all()
+
+
+@pytest.mark.parametrize("seed", [200, 201, 202, 203, 204, 205])
+def test_random_scenes_on_gpu(gpu, tmp_path, seed):
+    """tests/test_scene_fuzz.py on the hardware leg: a random scene (walls, portal pair, mirrors, glass, gizmo, mirrored matrices,
+    subspace) on gfx950 == the oracle, every float of the frame."""
+    from oracle.portal_oracle import Oracle
+    from tests.test_scene_fuzz import random_scene
+
+    pa = gpu
+    text, cam, in_subspace = random_scene(seed)
+    path = tmp_path / "random.ron"
+    path.write_text(text)
+    w, h = 40, 24
+    r = pa.SceneRenderer(pa.Scene.from_file(str(path)), device=0, flags=pa.FLAG_SPECIALIZE_STATIC)
+    r.set_option("render_depth", 10)
+    r.set_option("in_subspace", 1 if in_subspace else 0)
+    r.set_camera(cam["look_at"], cam["alpha"], cam["beta"], cam["r"])
+    got = r.draw(w, h, rgba32f=True)["rgba32f"]
+    o = Oracle(str(path))
+    o.options["render_depth"] = 10
+    o.camera = dict(cam, in_subspace=in_subspace)
+    assert _bits_equal(got, o.render(w, h)["rgba32f"]).all()

@@ -1,0 +1,77 @@
+"""Whole-scene differential fuzz: random small scenes -- walls, a portal pair (sometimes into the subspace), mirrors, glass, a
+DebugMatrix gizmo, random grid flags, random Simple / Parametrized matrices incl. mirrored ones -- rendered by the product
+(generated source, host build) and by the oracle (interpreted from the scene model), compared bit for bit.  Exercises what the
+generator emits per object kind, the teleport matrices and the material dispatch in combinations the corpus does not have."""
+import random
+
+import numpy as np
+import pytest
+
+from tests import synthetic
+
+
+def random_scene(seed):
+    r = random.Random(seed)
+    f = lambda lo, hi: repr(round(r.uniform(lo, hi), 3))
+    b = lambda: r.choice(["true", "false"])
+
+    def simple(dist=1.5):
+        return "Simple(offset: (%s, %s, %s), scale: %s, rotate: (%s, %s, %s), mirror: (%s, %s, %s))" % (
+            f(-dist, dist), f(-dist, dist), f(-dist, dist), f(0.4, 1.6), f(-3.1, 3.1), f(-3.1, 3.1), f(-3.1, 3.1), b(), b(), b())
+
+    matrices, objects, materials = [], [], []
+    n_walls = r.randint(2, 5)
+    for k in range(n_walls):
+        matrices.append(f'(name: "w{k}", data: {simple(2.0)}),')
+        mat = r.choice(["paint", "paint2", "mirror", "glass"])
+        shape = r.choice([f"abs(x) < {f(0.5, 2.0)} && abs(y) < {f(0.5, 2.0)}", f"x*x + y*y < {f(0.3, 3.0)}", "true"])
+        back = r.choice(["", " if (back) { return paint2_M; }"])
+        objects.append(f'(name: "w{k}", data: Flat(kind: Simple(Some(Named("w{k}"))), is_inside: (("if ({shape}) {{{back} return {mat}_M; }} return NOT_INSIDE;")), in_subspace: {r.choice(["Normal", "Normal", "Both", "Subspace"])})),')
+    matrices.append(f'(name: "pa", data: {simple(1.0)}),')
+    matrices.append('(name: "pb", data: Parametrized(offset: (x: Value(%s), y: Uniform(Some(Named("lift"))), z: Value(%s)), rotate: (x: Value(%s), y: Value(%s), z: Value(0.0)), '
+                    'mirror: (x: Value(%s), y: Value(0.0), z: Value(0.0)), scale: Value(%s))),' % (f(-1, 1), f(-1, 1), f(-3, 3), f(-3, 3), r.choice(["0.0", "1.0"]), f(0.5, 1.5)))
+    tele = r.choice(["TELEPORT", "TELEPORT", "TELEPORT_SUBSPACE"])
+    objects.append(f'(name: "gate", data: Flat(kind: Portal(Some(Named("pa")), Some(Named("pb"))), is_inside: (("if (x*x + y*y < {f(0.2, 1.2)}) {{ return {tele}; }} '
+                   f'if (x*x + y*y < {f(1.3, 1.8)}) {{ if (first) {{ return paint_M; }} return paint2_M; }} return NOT_INSIDE;")), in_subspace: Both)),')
+    if r.random() < 0.6:
+        objects.append('(name: "gizmo", data: DebugMatrix(Some(Named("pb")))),')
+    materials.append('(name: "paint", data: Simple(color: (%s, %s, %s), normal_coef: %s, grid: %s, grid_scale: %s, grid_coef: %s, grid2: %s, grid3: %s)),' % (
+        f(0, 1), f(0, 1), f(0, 1), f(0, 1), b(), f(0.5, 5), f(0, 0.6), b(), b()))
+    materials.append('(name: "paint2", data: Simple(color: (%s, %s, %s), normal_coef: %s, grid: %s, grid_scale: %s, grid_coef: %s, grid2: %s, grid3: %s)),' % (
+        f(0, 1), f(0, 1), f(0, 1), f(0, 1), b(), f(0.5, 5), f(0, 0.6), b(), b()))
+    materials.append('(name: "mirror", data: Reflect(add_to_color: (%s, %s, %s))),' % (f(0.5, 1), f(0.5, 1), f(0.5, 1)))
+    materials.append('(name: "glass", data: Refract(add_to_color: (%s, %s, %s), refractive_index: %s)),' % (f(0.5, 1), f(0.5, 1), f(0.5, 1), f(1.0, 1.8)))
+    text = synthetic.wall_scene(r=float(f(1.5, 4.0)), color=(0.7, 0.7, 0.7), grid=True, size=float(f(0.8, 3.0)), extra_objects="\n".join(objects),
+                                extra_matrices="\n".join(matrices), extra_materials="\n".join(materials))
+    text = text.replace('uniforms: ([', 'uniforms: ([ (name: "lift", data: Formula(("%s"))),' % r.choice(["0.3", "sin(2) * 0.5", "0.1 + 0.2 * 3"]))
+    cam = dict(look_at=(float(f(-0.5, 0.5)), float(f(-0.5, 0.5)), float(f(-0.5, 0.5))), alpha=float(f(-3.1, 3.1)), beta=float(f(0.3, 2.8)), r=float(f(0.8, 4.0)))
+    return text, cam, r.random() < 0.25
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scenes_product_equals_oracle(pa, tmp_path, seed):
+    from oracle import host_build as hb
+    from oracle.portal_oracle import Oracle
+
+    text, cam, in_subspace = random_scene(seed)
+    path = tmp_path / "random.ron"
+    path.write_text(text)
+    w, h = 40, 24
+    scene = pa.Scene.from_file(str(path))
+    r = pa.SceneRenderer(scene, device=-1)
+    r.set_option("render_depth", 10)
+    r.set_option("in_subspace", 1 if in_subspace else 0)
+    r.set_camera(cam["look_at"], cam["alpha"], cam["beta"], cam["r"])
+    hk = hb.HostKernel(scene.generate_source(pa.FLAG_COUNT_SEGMENTS), *scene.uniform_layout(), count_segments=True, opt="-O0")
+    for name, typ, _ in scene.uniform_layout()[0]:
+        if typ != pa.PTL_SAMPLER:
+            hk.set_uniform(name, r.uniform_value(name, w, h))
+    got = hk.render(w, h)
+    o = Oracle(str(path))
+    o.options["render_depth"] = 10
+    o.camera = dict(cam, in_subspace=in_subspace)
+    want = o.render(w, h)
+    a, b = got["rgba32f"], want["rgba32f"]
+    same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), f"seed {seed}: {int((~same).any(axis=2).sum())} of {w * h} pixels differ"
+    assert got["segments"] == int(want["segments"].sum())
