@@ -11,6 +11,14 @@ import pytest
 N_EXPR = 48
 
 
+@pytest.fixture(autouse=True)
+def _scratch_build_dir(tmp_path_factory, monkeypatch):
+    """one-off host builds: keep them out of oracle/_build (which travels to the GPU box)"""
+    from oracle import host_build as hb
+
+    monkeypatch.setattr(hb, "BUILD_DIR", str(tmp_path_factory.getbasetemp() / "fuzz_build"))
+
+
 class Gen:
     """Typed random GLSL expressions: gen(t, depth) -> text of type t in {"float", "vec2", "vec3", "vec4", "bool"}."""
 

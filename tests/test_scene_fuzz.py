@@ -10,6 +10,14 @@ import pytest
 from tests import synthetic
 
 
+@pytest.fixture(autouse=True)
+def _scratch_build_dir(tmp_path_factory, monkeypatch):
+    """one-off host builds: keep them out of oracle/_build (which travels to the GPU box)"""
+    from oracle import host_build as hb
+
+    monkeypatch.setattr(hb, "BUILD_DIR", str(tmp_path_factory.getbasetemp() / "fuzz_build"))
+
+
 def random_scene(seed):
     r = random.Random(seed)
     f = lambda lo, hi: repr(round(r.uniform(lo, hi), 3))
