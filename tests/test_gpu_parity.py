@@ -748,3 +748,37 @@ def test_random_scenes_on_gpu(gpu, tmp_path, seed):
     o.options["render_depth"] = 10
     o.camera = dict(cam, in_subspace=in_subspace)
     assert _bits_equal(got, o.render(w, h)["rgba32f"]).all()
+
+
+@pytest.mark.parametrize("scene_name,seed", [("basics", 1), ("basics", 2), ("triple_portal", 3), ("monoportal", 4)])
+def test_random_camera_walks_teleport_like_the_oracle(gpu, scene_name, seed):
+    """SceneRenderer::teleport_camera / teleport_matrix (src/main.rs:1174-1264) under a random walk of 40 orbit-camera steps, some of
+    them long enough to cross portals: after every step the product (ray queries on gfx950) and the oracle's CameraRig agree on
+    "teleported / blocked", on the teleport matrix bit for bit and on the subspace flag."""
+    import random
+
+    from oracle.portal_oracle import CameraRig, Oracle
+
+    pa = gpu
+    scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    r = pa.SceneRenderer(scene, device=0)
+    o = Oracle(pa.scene_path(scene_name))
+    rig = CameraRig(o)
+    rnd = random.Random(seed)
+    look, alpha, beta, rad = list(rig.look_at), rig.alpha, rig.beta, rig.r
+    crossings = 0
+    for step in range(40):
+        look = [rnd.uniform(-3.5, 3.5) for _ in look]   # jumps across the whole room: many segments cross a portal
+        alpha += rnd.uniform(-0.6, 0.6)
+        beta = min(2.9, max(0.2, beta + rnd.uniform(-0.3, 0.3)))
+        rad = min(6.0, max(0.3, rad + rnd.uniform(-0.8, 0.8)))
+        got, want = r.move_camera(tuple(look), alpha, beta, rad), rig.move(tuple(look), alpha, beta, rad)
+        assert got == want, (step, got, want)
+        crossings += got[0]
+        state = r.camera_state()
+        assert np.array_equal(state["teleport_matrix"], np.array(rig.teleport_matrix, np.float64).T), step
+        assert state["in_subspace"] == rig.in_subspace
+        if got[1]:  # blocked: both went back to the previous camera
+            look, alpha, beta, rad = list(rig.look_at), rig.alpha, rig.beta, rig.r
+    print(f"{scene_name}: {crossings} portal crossings in 40 steps")
+    assert crossings >= 1 or scene_name != "basics"
