@@ -141,10 +141,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the render path has no CPU fallback)")
+    # PTL_BENCH_BACKEND=gloo is a rehearsal hook: the multi-rank control flow on a box with ONE GPU (all ranks share it, the
+    # gather is staged through host memory).  The driver's runs use the default: one rank per GPU, RCCL.
+    backend = os.environ.get("PTL_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     W, H = args.width, args.height
     scene = pa.Scene.from_file(pa.scene_path(args.scene))
@@ -203,7 +211,7 @@ def main():
     # tracing of frame n+1; a buffer is reused only after its gather has been waited for
     depth = 2 if world > 1 else 1
     shards = [shard] + [parallel.alloc_shard(H, W, world, dev) for _ in range(depth - 1)]
-    gatherer = parallel.FrameGatherer(H, W, rank, world, dev, depth=depth)
+    gatherer = parallel.FrameGatherer(H, W, rank, world, dev, depth=depth, stage_through_host=backend != "nccl")
     pending = [None] * depth
     last_frame = [None]
     counter = [0]

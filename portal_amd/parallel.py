@@ -30,14 +30,24 @@ def alloc_shard(height: int, width: int, world: int, device) -> torch.Tensor:
     return torch.zeros((shard_blocks_max(height, world) * 8, width, 4), dtype=torch.uint8, device=device)
 
 
+class _Done:
+    """A finished collective (the host-staged path is synchronous)."""
+
+    def wait(self):
+        return True
+
+
 class FrameGatherer:
     """Pre-allocated buffers for gathering one frame per step on `dst`.
 
     `depth` > 1 double-buffers the gather target so that `gather_async` of frame n can overlap the
     tracing of frame n+1 (the collective runs on the process group's own stream)."""
 
-    def __init__(self, height: int, width: int, rank: int, world: int, device, dst: int = 0, depth: int = 1):
+    def __init__(self, height: int, width: int, rank: int, world: int, device, dst: int = 0, depth: int = 1, stage_through_host: bool = False):
         self.h, self.w, self.rank, self.world, self.dst = height, width, rank, world, dst
+        # a backend without device-to-device gather (gloo, used to rehearse the multi-rank control flow on one GPU): the shard
+        # goes through host memory, synchronously
+        self.stage_through_host = stage_through_host
         self.kmax = shard_blocks_max(height, world)
         self.slots = []
         for _ in range(depth):
@@ -59,14 +69,27 @@ class FrameGatherer:
         if self.world == 1:
             return shard[: self.h]
         gathered = self.slots[slot][1]
-        dist.gather(shard, list(gathered.unbind(0)) if self.rank == self.dst else None, dst=self.dst)
+        if self.stage_through_host:
+            self._gather_through_host(shard, gathered)
+        else:
+            dist.gather(shard, list(gathered.unbind(0)) if self.rank == self.dst else None, dst=self.dst)
         return self._assemble(slot) if self.rank == self.dst else None
+
+    def _gather_through_host(self, shard: torch.Tensor, gathered: Optional[torch.Tensor]) -> None:
+        host = shard.cpu()
+        parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
+        dist.gather(host, parts, dst=self.dst)
+        if self.rank == self.dst:
+            gathered.copy_(torch.stack(parts))
 
     def gather_async(self, shard: torch.Tensor, slot: int = 0):
         """Start the gather; returns a handle for `finish`."""
         if self.world == 1:
             return None
         gathered = self.slots[slot][1]
+        if self.stage_through_host:
+            self._gather_through_host(shard, gathered)
+            return _Done()
         return dist.gather(shard, list(gathered.unbind(0)) if self.rank == self.dst else None, dst=self.dst, async_op=True)
 
     def finish(self, work, shard: torch.Tensor, slot: int = 0) -> Optional[torch.Tensor]:

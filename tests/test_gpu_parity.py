@@ -782,3 +782,26 @@ def test_random_camera_walks_teleport_like_the_oracle(gpu, scene_name, seed):
             look, alpha, beta, rad = list(rig.look_at), rig.alpha, rig.beta, rig.r
     print(f"{scene_name}: {crossings} portal crossings in 40 steps")
     assert crossings >= 1 or scene_name != "basics"
+
+
+def test_bench_multi_rank_rehearsal_assembles_the_same_frame(gpu, tmp_path):
+    """bench.py's multi-rank path (row-block sharding, rank-0 build choice broadcast, double-buffered gather, de-interleave, JSON)
+    rehearsed on ONE GPU: PTL_BENCH_BACKEND=gloo lets 3 ranks share the device and stages the gather through host memory.
+    Everything but RCCL itself is the code the driver's 2/4/8-GPU runs execute; the assembled frame equals the 1-rank frame."""
+    import json
+    import subprocess
+    import sys
+
+    pa = gpu
+    root = pa.REPO_ROOT
+    common = ["--scene", "triple_portal", "--width", "1280", "--height", "720", "--depth", "24", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--waves", "0"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common, "--save-png", str(tmp_path / "one.png")], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-800:]
+    env = dict(os.environ, PTL_BENCH_BACKEND="gloo")
+    many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", "29517",
+                           os.path.join(root, "bench.py"), "--gpus", "3", *common, "--save-png", str(tmp_path / "three.png")],
+                          capture_output=True, text=True, timeout=900, env=env)
+    assert many.returncode == 0, many.stderr[-1500:]
+    line = json.loads([l for l in many.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["steps"] == 4 and line["scaling"] == "strong" and line["value"] > 0
+    assert np.array_equal(pa.png_read(str(tmp_path / "one.png")), pa.png_read(str(tmp_path / "three.png")))
