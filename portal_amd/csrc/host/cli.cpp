@@ -512,7 +512,9 @@ int render(const Options& o) {
             std::printf("Rendering animation %s, %zu/%zu\n", clip.c_str(), k + 1, todo.size());
             {
                 auto clip_start = std::chrono::steady_clock::now();
-                PinnedFrames pinned(bytes, threads + 2);
+                // frames in flight between download and encode: one per encoder thread, but no more than ~2 GB of page-locked memory
+                int in_flight = (int)std::max<size_t>(4, std::min<size_t>((size_t)threads + 2, ((size_t)2 << 30) / bytes));
+                PinnedFrames pinned(bytes, in_flight);
                 if (!pinned.ok()) return fail("pinned host memory");
                 EncoderPool pool(threads, (size_t)threads * 2);
                 int rc = render_clip(o, scene, r, scene_name, clip, todo[k].second, fps, width, o.height, subframes, pipe, pool, pinned);
