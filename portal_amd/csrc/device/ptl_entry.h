@@ -31,8 +31,24 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
     const int wave = t >> 6, lane = t & 63;
     const int lx = wave * 8 + (lane & 7);
     const int ly = lane >> 3;
-    const int local_block = (int)blockIdx.y;
-    const int px = (int)blockIdx.x * 32 + lx;
+#ifdef PTL_XCD_SWIZZLE
+    // Experiment (measured: no gain): workgroups are dealt round-robin to the 8 XCDs; this remap gives every XCD a
+    // contiguous band of the frame instead of every 8th block, for L2 locality of texture taps.
+    int block_x = (int)blockIdx.x, block_y = (int)blockIdx.y;
+    {
+        const int total = (int)(gridDim.x * gridDim.y);
+        if ((total & 7) == 0) {
+            const int id = block_y * (int)gridDim.x + block_x;
+            const int remapped = (id & 7) * (total >> 3) + (id >> 3);
+            block_x = remapped % (int)gridDim.x;
+            block_y = remapped / (int)gridDim.x;
+        }
+    }
+#else
+    const int block_x = (int)blockIdx.x, block_y = (int)blockIdx.y;
+#endif
+    const int local_block = block_y;
+    const int px = block_x * 32 + lx;
     const int py = (rb_phase + local_block * rb_stride) * 8 + ly;
     const bool live = px < width && py < height;
 
@@ -62,7 +78,7 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
         tile[ly][lx] = glsl::pack_rgba8(c);
         __syncthreads();
         const int row = t >> 5, col = t & 31;  // each wave now owns two full 32-pixel rows = 2 x 128 B
-        const int gx = (int)blockIdx.x * 32 + col;
+        const int gx = block_x * 32 + col;
         const int gy = (rb_phase + local_block * rb_stride) * 8 + row;
         if (gx < width && gy < height) out_rgba8[((long)local_block * 8 + row) * width + gx] = tile[row][col];
     }

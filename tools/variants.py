@@ -45,6 +45,8 @@ VARIANTS = {
     "all_minreg_w4": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg -DPTL_WAVES_PER_EU=4",
     "all_minreg_ifcvt": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg -mllvm -amdgpu-early-ifcvt=1",
     "all_relaxocc": "SPECIALIZE_ALL -mllvm -amdgpu-schedule-relaxed-occupancy=true",
+    "all_xcd": "SPECIALIZE_ALL -DPTL_XCD_SWIZZLE",
+    "base_xcd": "-DPTL_XCD_SWIZZLE",
     "all_Os": "SPECIALIZE_ALL -Os",
     "all_Oz": "SPECIALIZE_ALL -Oz",
     "base_Os": "-Os",
