@@ -48,7 +48,8 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
     const int block_x = (int)blockIdx.x, block_y = (int)blockIdx.y;
 #endif
     const int local_block = block_y;
-    const int px = block_x * 32 + lx;
+    const int block_px = (int)blockDim.x >> 3;  // 32 pixels per row block for the shipped 256-thread workgroup (experiments launch 64 / 128)
+    const int px = block_x * block_px + lx;
     const int py = (rb_phase + local_block * rb_stride) * 8 + ly;
     const bool live = px < width && py < height;
 
@@ -74,7 +75,9 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
 #ifdef PTL_DIRECT_STORE
     if (out_rgba8 != nullptr && live) out_rgba8[shard_row * width + px] = glsl::pack_rgba8(c);  // 8 lanes x 4 B = 32 B per tile row
 #else
-    if (out_rgba8 != nullptr) {
+    if (blockDim.x != 256) {  // narrower experimental workgroups: plain tile store
+        if (out_rgba8 != nullptr && live) out_rgba8[shard_row * width + px] = glsl::pack_rgba8(c);
+    } else if (out_rgba8 != nullptr) {
         tile[ly][lx] = glsl::pack_rgba8(c);
         __syncthreads();
         const int row = t >> 5, col = t & 31;  // each wave now owns two full 32-pixel rows = 2 x 128 B

@@ -325,9 +325,12 @@ extern "C" int ptl_kernel_render(ptl_kernel* k, const ptl_frame* frame, void* ou
     }
     int width = frame->width, height = frame->height, phase = frame->rb_phase, stride = frame->rb_stride;
     void* args[] = {&out_rgba8, &out_rgba32f, &width, &height, &phase, &stride, &segments};
-    unsigned gx = (unsigned)((width + 31) / 32), gy = (unsigned)nby;
+    // 256 threads = four 8x8 tiles side by side.  PTL_BLOCK_WAVES=1|2 (experiment, tools/variants.py) launches narrower workgroups.
+    unsigned waves = 4;
+    if (const char* e = std::getenv("PTL_BLOCK_WAVES")) waves = (e[0] == '1' || e[0] == '2') ? (unsigned)(e[0] - '0') : 4u;
+    unsigned gx = (unsigned)((width + 8 * waves - 1) / (8 * waves)), gy = (unsigned)nby;
     if (elapsed_ms) rt->hipEventRecord(k->ev0, stream);
-    if (!hip_ok(rt, rt->hipModuleLaunchKernel(k->fn, gx, gy, 1, 256, 1, 1, 0, stream, args, nullptr), "hipModuleLaunchKernel")) return PTL_ERR_HIP;
+    if (!hip_ok(rt, rt->hipModuleLaunchKernel(k->fn, gx, gy, 1, 64 * waves, 1, 1, 0, stream, args, nullptr), "hipModuleLaunchKernel")) return PTL_ERR_HIP;
     if (elapsed_ms) {
         rt->hipEventRecord(k->ev1, stream);
         if (!hip_ok(rt, rt->hipEventSynchronize(k->ev1), "hipEventSynchronize")) return PTL_ERR_HIP;

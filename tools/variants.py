@@ -46,6 +46,8 @@ VARIANTS = {
     "all_minreg_ifcvt": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg -mllvm -amdgpu-early-ifcvt=1",
     "all_relaxocc": "SPECIALIZE_ALL -mllvm -amdgpu-schedule-relaxed-occupancy=true",
     "all_xcd": "SPECIALIZE_ALL -DPTL_XCD_SWIZZLE",
+    "all_bw1": "SPECIALIZE_ALL BLOCK_WAVES=1",
+    "all_bw2": "SPECIALIZE_ALL BLOCK_WAVES=2",
     "base_xcd": "-DPTL_XCD_SWIZZLE",
     "all_Os": "SPECIALIZE_ALL -Os",
     "all_Oz": "SPECIALIZE_ALL -Oz",
@@ -70,6 +72,9 @@ def run_one(case, vname, flags):
     toks = flags.split()
     rflags = (pa.FLAG_SPECIALIZE_INTS if "SPECIALIZE" in toks else 0) | (pa.FLAG_SPECIALIZE_ALL if "SPECIALIZE_ALL" in toks else 0)
     os.environ["PTL_HIPRTC_FLAGS"] = " ".join(t for t in toks if t.startswith("-"))
+    for t in toks:
+        if t.startswith("BLOCK_WAVES="):
+            os.environ["PTL_BLOCK_WAVES"] = t.split("=")[1]
     scene = pa.Scene.from_file(pa.scene_path(scene_name))
     r = pa.SceneRenderer(scene, device=0, flags=rflags)
     r.set_option("render_depth", d)
