@@ -204,7 +204,7 @@ void apply_clip_overrides(ptl_scene* scene, ptl_renderer* r, const std::string& 
     for (const ClipOverride& o : kClipOverrides) {
         if (clip != o.clip) continue;
         if (o.subspace_degree) ptl_scene_set_uniform(scene, "subspace_degree", o.subspace_degree);  // no such uniform: nothing happens
-        if (o.render_depth) ptl_renderer_set_option(r, "render_depth", o.render_depth);
+        if (o.render_depth && r) ptl_renderer_set_option(r, "render_depth", o.render_depth);
         if (o.fps && fps) *fps = o.fps;
     }
 }
@@ -449,6 +449,25 @@ int encode_video(const Options& o, const std::string& scene_name, const std::str
     return 0;
 }
 
+// Warm the code-object cache for the NEXT clip's specialised kernel while the current clip renders: a private copy of the scene
+// is taken through the same history (every clip initialised so far, with its overrides), then compiled for gfx950 without a
+// device.  When the main thread gets to that clip it generates the same source and finds the binary on disk; if the histories
+// ever disagree it just compiles as before.
+void prefetch_clip_kernel(std::string path, std::vector<std::string> history, std::string asset_root) {
+    ptl_scene* scene = nullptr;
+    if (ptl_scene_load_file(path.c_str(), &scene) != PTL_OK) return;
+    for (const std::string& clip : history) {
+        if (ptl_scene_init_animation(scene, clip.c_str()) != PTL_OK) {
+            ptl_scene_free(scene);
+            return;
+        }
+        apply_clip_overrides(scene, nullptr, clip, nullptr);
+    }
+    ptl_renderer* r = nullptr;
+    if (ptl_renderer_create(scene, -1, asset_root.c_str(), kRenderFlags | 8u, &r, nullptr, 0) == PTL_OK) ptl_renderer_destroy(r);
+    ptl_scene_free(scene);
+}
+
 int render(const Options& o) {
     int width = o.stereo ? o.width * 2 : o.width;  // src/main.rs:2822-2829
     auto total_start = std::chrono::steady_clock::now();
@@ -496,8 +515,55 @@ int render(const Options& o) {
                 if (o.starts_with.empty() || c.first.compare(0, o.starts_with.size(), o.starts_with) == 0) todo.push_back(c);
         }
         int threads = (int)std::min(64u, std::max(2u, std::thread::hardware_concurrency() * 3 / 4));
+        // Specialised kernels of the clips to come are compiled ahead by a few background threads (in clip order), so a run of
+        // many short clips is not a run of JIT waits; the main thread only waits if it reaches a clip before its binary is ready.
+        struct Prefetcher {
+            std::vector<std::thread> workers;
+            std::mutex mu;
+            std::condition_variable cv;
+            std::vector<char> done;
+            size_t next = 0;
+            bool stop = false;
+            ~Prefetcher() {
+                {
+                    std::unique_lock<std::mutex> lock(mu);
+                    stop = true;
+                }
+                for (auto& t : workers)
+                    if (t.joinable()) t.join();
+            }
+        } pf;
+        pf.done.assign(todo.size(), 0);
+        if (o.specialize != 0 && todo.size() > 1) {
+            int n_workers = (int)std::min<size_t>({(size_t)6, todo.size() - 1, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)});
+            pf.next = 1;  // the first clip is compiled by the main thread right away
+            for (int wk = 0; wk < n_workers; ++wk)
+                pf.workers.emplace_back([&pf, &todo, path, asset_root = o.asset_root] {
+                    for (;;) {
+                        size_t k;
+                        {
+                            std::unique_lock<std::mutex> lock(pf.mu);
+                            if (pf.stop || pf.next >= todo.size()) return;
+                            k = pf.next++;
+                        }
+                        std::vector<std::string> history;
+                        for (size_t c = 0; c <= k; ++c) history.push_back(todo[c].first);
+                        prefetch_clip_kernel(path, history, asset_root);
+                        {
+                            std::unique_lock<std::mutex> lock(pf.mu);
+                            pf.done[k] = 1;
+                        }
+                        pf.cv.notify_all();
+                    }
+                });
+        }
         for (size_t k = 0; k < todo.size(); ++k) {
             const std::string& clip = todo[k].first;
+            if (!pf.workers.empty() && k >= 1) {  // wait for this clip's binary only if a worker has already picked it up
+                std::unique_lock<std::mutex> lock(pf.mu);
+                pf.cv.wait(lock, [&] { return pf.done[k] || pf.next <= k; });
+                if (!pf.done[k] && pf.next <= k) pf.next = k + 1;  // nobody started it: the main thread compiles it itself below
+            }
             if (ptl_scene_init_animation(scene, clip.c_str()) != PTL_OK) return fail("init_animation");
             if (ptl_renderer_update(r, 0.0, nullptr, nullptr) != PTL_OK) return fail("update");
             int fps = o.fps;
