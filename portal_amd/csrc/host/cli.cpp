@@ -203,7 +203,7 @@ const ClipOverride kClipOverrides[] = {
 void apply_clip_overrides(ptl_scene* scene, ptl_renderer* r, const std::string& clip, int* fps) {
     for (const ClipOverride& o : kClipOverrides) {
         if (clip != o.clip) continue;
-        if (o.subspace_degree) ptl_scene_set_uniform(scene, "subspace_degree", o.subspace_degree);  // no such uniform: nothing happens
+        if (o.subspace_degree && scene) ptl_scene_set_uniform(scene, "subspace_degree", o.subspace_degree);  // no such uniform: nothing happens
         if (o.render_depth && r) ptl_renderer_set_option(r, "render_depth", o.render_depth);
         if (o.fps && fps) *fps = o.fps;
     }
@@ -534,11 +534,20 @@ int render(const Options& o) {
             }
         } pf;
         pf.done.assign(todo.size(), 0);
+        // which clips get a specialised kernel: it repays its extra JIT (~1 s) only on a clip with enough work
+        std::vector<char> specialise(todo.size(), 0);
+        for (size_t k = 0; k < todo.size(); ++k) {
+            int fps = o.fps;
+            apply_clip_overrides(nullptr, nullptr, todo[k].first, &fps);
+            int count = std::max(1, (int)((float)todo[k].second * (float)fps));
+            double samples = (double)width * o.height * o.aa * count * o.blur;
+            specialise[k] = o.specialize >= 0 ? o.specialize != 0 : samples >= 1e10;
+        }
         if (o.specialize != 0 && todo.size() > 1) {
             int n_workers = (int)std::min<size_t>({(size_t)6, todo.size() - 1, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)});
             pf.next = 1;  // the first clip is compiled by the main thread right away
             for (int wk = 0; wk < n_workers; ++wk)
-                pf.workers.emplace_back([&pf, &todo, path, asset_root = o.asset_root] {
+                pf.workers.emplace_back([&pf, &todo, &specialise, path, asset_root = o.asset_root] {
                     for (;;) {
                         size_t k;
                         {
@@ -546,9 +555,11 @@ int render(const Options& o) {
                             if (pf.stop || pf.next >= todo.size()) return;
                             k = pf.next++;
                         }
-                        std::vector<std::string> history;
-                        for (size_t c = 0; c <= k; ++c) history.push_back(todo[c].first);
-                        prefetch_clip_kernel(path, history, asset_root);
+                        if (specialise[k]) {
+                            std::vector<std::string> history;
+                            for (size_t c = 0; c <= k; ++c) history.push_back(todo[c].first);
+                            prefetch_clip_kernel(path, history, asset_root);
+                        }
                         {
                             std::unique_lock<std::mutex> lock(pf.mu);
                             pf.done[k] = 1;
@@ -569,12 +580,7 @@ int render(const Options& o) {
             int fps = o.fps;
             ptl_renderer_set_option(r, "render_depth", o.depth);
             apply_clip_overrides(scene, r, clip, &fps);
-            {  // clip-constant specialisation repays its extra JIT (~2 s) only on a clip with enough work
-                int count = std::max(1, (int)((float)todo[k].second * (float)fps));
-                double samples = (double)width * o.height * o.aa * count * o.blur;
-                bool on = o.specialize >= 0 ? o.specialize != 0 : samples >= 1e10;
-                if (ptl_renderer_set_option(r, "specialize_static", on ? 1 : 0) != PTL_OK) return fail("specialize");
-            }
+            if (ptl_renderer_set_option(r, "specialize_static", specialise[k] ? 1 : 0) != PTL_OK) return fail("specialize");
             std::printf("Rendering animation %s, %zu/%zu\n", clip.c_str(), k + 1, todo.size());
             {
                 auto clip_start = std::chrono::steady_clock::now();
