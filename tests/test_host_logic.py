@@ -663,3 +663,25 @@ def test_trefoil_text_codec_reference_vector(pa):
     s.set_trefoil("knot", "1a 2a G,1b 3b B,2a 1a S")
     assert s.get_trefoil("knot") == "1a 2a G,1b 3b B,2a 1a S"
     assert int(s.uniform_values()["ts_3_knot_u"]) == 15000 and pa.Scene.from_text(s.to_ron()).get_trefoil("knot") == "1a 2a G,1b 3b B,2a 1a S"
+
+
+def test_cli_fails_loudly_without_a_gpu_and_has_no_cpu_fallback(pa, tmp_path):
+    """On a machine without a HIP device the render commands stop with a message and a non-zero status (no silent CPU path); the
+    commands that need no device (version, emit-source, check, write) work."""
+    import subprocess
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("this machine has a GPU")
+    exe = os.path.join(os.path.dirname(pa.__file__), "portal-amd")
+    run = lambda *a: subprocess.run([exe, *a], capture_output=True, text=True, timeout=300)
+    frame = run("render-frame", pa.scene_path("basics"), "--width", "32", "--height", "32", "--output", str(tmp_path / "f.png"))
+    assert frame.returncode != 0 and "no ROCm-capable device" in (frame.stderr + frame.stdout) and not (tmp_path / "f.png").exists()
+    clip = run("render", pa.scene_path("basics"), "--width", "32", "--height", "32", "--out-dir", str(tmp_path))
+    assert clip.returncode != 0 and not (tmp_path / "anim").exists()
+    assert run("version").returncode == 0 and "devices: 0" in run("version").stdout
+    src = run("emit-source", pa.scene_path("basics"))
+    assert src.returncode == 0 and "ptl_render_kernel" in src.stdout
+    assert run("write", pa.scene_path("basics")).stdout == open(pa.scene_path("basics"), encoding="utf-8").read()
+    assert run("render-frame", pa.scene_path("basics"), "--stage", "a", "--animation", "b").returncode == 2
