@@ -75,7 +75,8 @@ std::string dir_of(const std::string& path) {
 
 // The reference compiles its scene list in (src/gui/scenes.rs); here a scene is a path, or a bare name under --scenes-dir.
 std::string scene_file(const std::string& arg, const std::string& scenes_dir) {
-    if (exists(arg)) return arg;
+    bool looks_like_a_path = arg.find('/') != std::string::npos || (arg.size() > 4 && arg.compare(arg.size() - 4, 4, ".ron") == 0);
+    if (exists(arg) || looks_like_a_path) return arg;
     return scenes_dir + "/" + arg + ".ron";
 }
 
