@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/gpu_fuzz_hunt.py -- a larger one-off run of the tests' differential fuzzers on the GPU (60 random scenes, half of them with
+"""tests/gpu_fuzz_hunt.py -- a larger one-off run of the tests' differential fuzzers on the GPU (60 random scenes, half of them with
 the clip-specialised kernel, and 30 x 48 random GLSL expressions): gfx950 against the numpy oracle, bit for bit.  Development aid."""
 import sys, os, tempfile, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
