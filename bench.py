@@ -4,8 +4,9 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
 torch.distributed.run with one rank per GPU.  A "step" is one full frame of the headline
 workload (BASELINE.json: scenes/portal_in_portal.ron, 3840x2160, aa 1, depth 40): every rank
-renders its interleaved row blocks (no data-path collective while tracing), then ONE gather of
-the RGBA8 shards to rank 0 over RCCL and a de-interleave copy assemble the image.  Inputs
+renders its interleaved row blocks (no data-path collective while tracing) and the image is
+assembled on rank 0 -- by ONE gather of the RGBA8 shards over RCCL plus a de-interleave copy, or
+by the kernels storing straight into rank 0's frame over xGMI (whichever is faster here).  Inputs
 (scene constants, portal matrices) are resident in device constant memory before the timed
 region; the frame stays in HBM (no host copy inside the timed region).
 
@@ -207,64 +208,101 @@ def main():
     best_waves = tried[best][3]
     tuning = {k: {"ms": round(v[0], 4), **v[2]} for k, v in tried.items()}
     del tried
-    # N > 1: two shard buffers; the gather of frame n (RCCL, on the process group's stream) overlaps the
-    # tracing of frame n+1; a buffer is reused only after its gather has been waited for
-    depth = 2 if world > 1 else 1
-    shards = [shard] + [parallel.alloc_shard(H, W, world, dev) for _ in range(depth - 1)]
-    gatherer = parallel.FrameGatherer(H, W, rank, world, dev, depth=depth, stage_through_host=backend != "nccl")
-    pending = [None] * depth
-    last_frame = [None]
-    counter = [0]
-
-    def drain(slot):
-        if pending[slot] is not None:
-            last_frame[0] = gatherer.finish(pending[slot], shards[slot], slot)
-            pending[slot] = None
-
-    def step(ev=None):
-        slot = counter[0] % depth
-        counter[0] += 1
-        drain(slot)
-        if ev is not None:
-            ev[0].record(stream)
-        renderer.draw_device(frame, out_rgba8=shards[slot].data_ptr(), stream=stream.cuda_stream)
-        if ev is not None:
-            ev[1].record(stream)
-        if world > 1:
-            pending[slot] = gatherer.gather_async(shards[slot], slot)
+    # N > 1: how a frame reaches rank 0.  Two transports, same pixels:
+    #   rccl-gather  packed shards, ONE dist.gather (RCCL send/recv group) + one strided de-interleave copy, double-buffered so
+    #                that the gather of frame n overlaps the tracing of frame n+1;
+    #   p2p-stores   rank 0's frame buffers are mapped into every rank (HIP IPC) and the kernel stores its row blocks straight
+    #                into rank 0's HBM over xGMI; the collective shrinks to a one-element all-reduce used as a fence.
+    # PTL_BENCH_TRANSPORT=gather|p2p|auto (default auto: set both up, check that they assemble the same bytes, time both
+    # untimed-region style like the kernel builds above, keep the faster).
+    staged = backend != "nccl"
+    mode = os.environ.get("PTL_BENCH_TRANSPORT", "auto")
+    transports = {}
+    transport_notes = {}
+    if world == 1 or mode in ("gather", "auto"):
+        transports["rccl-gather"] = parallel.GatherTransport(H, W, rank, world, dev, stage_through_host=staged)
+    if world > 1 and mode in ("p2p", "auto"):
+        ok, peer = 1, None
+        try:
+            peer = parallel.PeerTransport(H, W, rank, world, dev, host_fence=staged)
+        except Exception as e:  # no IPC between these devices / processes: the gather remains
+            ok = 0
+            transport_notes["p2p-stores"] = f"unavailable: {str(e)[:200]}"
+        agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 1:
+            transports["p2p-stores"] = peer
         else:
-            last_frame[0] = shards[slot][:H]  # a view: no copy, the frame stays in HBM
+            transport_notes.setdefault("p2p-stores", "unavailable on another rank")
+            if peer is not None:
+                peer.close()
+        if not transports:
+            raise SystemExit("PTL_BENCH_TRANSPORT=p2p but peer frame buffers are unavailable: " + transport_notes["p2p-stores"])
 
-    def drain_all():
-        for k in range(depth):
-            drain((counter[0] + k) % depth)
+    def run_steps(tr, n, events=None):
+        """n frames through transport `tr`; returns what tr.finish gave for the last one (the assembled frame on rank 0)."""
+        in_flight, last = [], None
+        for k in range(n):
+            slot = k % tr.depth
+            while len(in_flight) >= tr.depth:  # a buffer is reused only after its frame has been assembled
+                s0, work = in_flight.pop(0)
+                last = tr.finish(work, s0)
+            if events is not None:
+                events[k][0].record(stream)
+            renderer.draw_device(tr.frame, out_rgba8=tr.out_ptr(slot), stream=stream.cuda_stream)
+            if events is not None:
+                events[k][1].record(stream)
+            in_flight.append((slot, tr.submit(slot)))
+        for s0, work in in_flight:
+            last = tr.finish(work, s0)
+        return last
+
+    def timed_steps(tr, n, events=None):
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        last = run_steps(tr, n, events)  # every frame of the timed region is fully assembled on rank 0
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), last
 
     # untimed: keep the GPU busy for ~0.25 s so that the W warm-up steps and the timed region run at settled clocks
     # (a 20-step timed region is ~15 ms of work; without this it rides the power-management ramp)
     spin_until = time.perf_counter() + 0.25
     while time.perf_counter() < spin_until:
         for _ in range(16):
-            renderer.draw_device(frame, out_rgba8=shards[0].data_ptr(), stream=stream.cuda_stream)
+            renderer.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
-    for _ in range(args.warmup):
-        step()
-    drain_all()
+
+    if len(transports) > 1:
+        # untimed: both transports must assemble the same frame on rank 0, then the faster one is kept
+        images = {name: tr.download(run_steps(tr, 1)) for name, tr in transports.items()}
+        same = torch.tensor([1], dtype=torch.int32, device=dev)
+        if rank == 0 and not np.array_equal(images["rccl-gather"], images["p2p-stores"]):
+            same[0] = 0
+        dist.broadcast(same, 0)
+        del images
+        if int(same.item()) == 0:
+            transport_notes["p2p-stores"] = "dropped: its frame differs from the gathered one"
+            transports.pop("p2p-stores").close()
+    transport_ms = {}
+    if len(transports) > 1:
+        for name, tr in transports.items():
+            run_steps(tr, 4)
+            transport_ms[name] = round(timed_steps(tr, 12)[0] / 12 * 1e3, 4)
+        keep = min(transport_ms, key=transport_ms.get)  # the times are maxima over ranks: every rank picks the same
+        for name in [n for n in transports if n != keep]:
+            transports.pop(name).close()
+    transport = next(iter(transports.values()))
+
+    run_steps(transport, args.warmup)
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    drain_all()  # every frame of the timed region is fully assembled on rank 0
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, last = timed_steps(transport, args.steps, events)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
     if world > 1:
@@ -277,7 +315,7 @@ def main():
         counting = pa.SceneRenderer(scene, device=local_rank, flags=pa.FLAG_COUNT_SEGMENTS | spec_flags)
         configure(counting, args)
         seg = torch.zeros(1, dtype=torch.int64, device=dev)
-        counting.draw_device(frame, out_rgba8=shards[0].data_ptr(), segments=seg.data_ptr(), stream=stream.cuda_stream)
+        counting.draw_device(frame, out_rgba8=shard.data_ptr(), segments=seg.data_ptr(), stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.all_reduce(seg)
@@ -288,8 +326,7 @@ def main():
 
     if rank == 0:
         if args.save_png:
-            img = last_frame[0].cpu().numpy()
-            pa.png_write(args.save_png, img)
+            pa.png_write(args.save_png, transport.download(last))
         rays = W * H * args.aa
         ms_per_step = elapsed / args.steps * 1e3
         value = rays * args.steps / elapsed / 1e6
@@ -311,10 +348,13 @@ def main():
             "config": {
                 "workload": f"scenes/{args.scene}.ron {W}x{H} aa={args.aa} depth={args.depth}"
                             + (f" panini d={args.panini} fov={args.fov}" if args.panini >= 0 else ""),
-                "parallelism": f"row-block interleave x{world}" + (" + RCCL gather to rank 0, double-buffered (gather n overlaps trace n+1)" if world > 1 else ""),
+                "parallelism": f"row-block interleave x{world}" + ("" if world == 1 else {
+                    "rccl-gather": " + one RCCL gather to rank 0 + de-interleave copy, double-buffered (gather n overlaps trace n+1)",
+                    "p2p-stores": " + kernel stores straight into rank 0's frame over xGMI (HIP IPC mapping), fenced by a 1-element RCCL all-reduce"}[transport.name]),
                 "jit_specialisation": ["none", "int/bool scene uniforms baked", "all scene uniforms baked (camera dynamic)"][args.specialize],
                 "build": best, "waves_per_simd_hint": best_waves,
                 "tuning_ms": tuning,
+                **({"transport": transport.name, "transport_ms_per_frame": transport_ms, "transport_notes": transport_notes} if world > 1 else {}),
             },
             "kernel_ms": round(kernel_ms, 4),
         }
@@ -346,6 +386,7 @@ def main():
             except Exception as e:
                 out["cpu_baseline"] = {"error": str(e)[:300]}
         print(json.dumps(out), flush=True)
+    transport.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -93,13 +93,18 @@ int ptl_kernel_set_texture(ptl_kernel* k, const char* sampler, const uint8_t* rg
 typedef struct {
     int width, height;       /* full frame, used for the pixel -> ray mapping */
     int rb_phase, rb_stride; /* row-block interleave */
+    int in_place;            /* 0: the shard's rows are stored packed, in block order (out = shard_rows*width pixels);
+                              * 1: the out pointers address a FULL frame (height*width pixels) and every row is stored at its
+                              *    own position -- N launches with phase 0..N-1 fill one buffer between them, which may be
+                              *    another GPU's memory mapped with ptl_ipc_open */
 } ptl_frame;
 
-/* Rows rendered by a shard (they are stored packed, in block order, in the output buffers). */
+/* Rows rendered by a shard (with in_place = 0 they are stored packed, in block order, in the output buffers). */
 int ptl_frame_shard_rows(const ptl_frame* f);
 
 /* Launch on `stream` (a hipStream_t, NULL = default stream).  Outputs are DEVICE pointers, either
- * may be NULL: out_rgba8 = shard_rows*width*4 bytes, out_rgba32f = shard_rows*width*16 bytes.
+ * may be NULL: out_rgba8 = shard_rows*width*4 bytes, out_rgba32f = shard_rows*width*16 bytes
+ * (frame->in_place: height*width*4 and height*width*16 bytes).
  * segments (DEVICE pointer to one uint64, may be NULL) accumulates bounce-loop trips when the
  * kernel was compiled with PTL_COUNT_SEGMENTS.  If elapsed_ms is non-NULL the launch is bracketed
  * by HIP events on `stream` and the call waits for completion. */
@@ -282,6 +287,15 @@ int ptl_event_record(void* event, void* stream);
 int ptl_event_synchronize(void* event);
 int ptl_stream_wait_event(void* stream, void* event);
 int ptl_device_download_async(void* host_dst, const void* device_src, size_t bytes, void* stream);
+/* A frame buffer shared by the processes of one node (one process per GPU; the reference is single-GPU): the
+ * destination rank exports a ptl_device_alloc'ed buffer, the others map it and render into it with ptl_frame.in_place = 1
+ * (stores go over xGMI into the destination's HBM).  A handle is PTL_IPC_HANDLE_BYTES opaque bytes to hand to the other
+ * processes by any means; it cannot be opened in the exporting process.  Completion is the caller's business (a barrier
+ * behind the launches). */
+#define PTL_IPC_HANDLE_BYTES 64
+int ptl_ipc_export(void* device_ptr, unsigned char handle[PTL_IPC_HANDLE_BYTES]);
+int ptl_ipc_open(int device, const unsigned char handle[PTL_IPC_HANDLE_BYTES], void** device_ptr);
+int ptl_ipc_close(void* device_ptr);
 /* Page-locked host memory for those downloads (PCIe-rate copies; pageable memory works too, several times slower). */
 int ptl_host_alloc(size_t bytes, void** out);
 int ptl_host_free(void* p);

@@ -77,7 +77,7 @@ class CalculatedCam(C.Structure):
 class Frame(C.Structure):
     """Row-block sharding of one frame (ptl_frame)."""
 
-    _fields_ = [("width", C.c_int), ("height", C.c_int), ("rb_phase", C.c_int), ("rb_stride", C.c_int)]
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("rb_phase", C.c_int), ("rb_stride", C.c_int), ("in_place", C.c_int)]
 
 
 def _load() -> C.CDLL:
@@ -143,6 +143,9 @@ def _load() -> C.CDLL:
         "ptl_device_alloc": (ci, [ci, cs, P(vp)]),
         "ptl_device_free": (ci, [vp]),
         "ptl_device_download": (ci, [vp, vp, cs, vp]),
+        "ptl_ipc_export": (ci, [vp, cp]),
+        "ptl_ipc_open": (ci, [ci, cp, P(vp)]),
+        "ptl_ipc_close": (ci, [vp]),
         "ptl_host_alloc": (ci, [cs, P(vp)]),
         "ptl_host_free": (ci, [vp]),
         "ptl_ron_format": (vp, [cp]),
@@ -561,6 +564,46 @@ def average_images_device(frame_ptrs, out_ptr: int, width: int, height: int, dev
     _check(lib().ptl_average_images(device, arr, len(frame_ptrs), C.c_void_p(out_ptr), width, height, C.c_void_p(stream or None), C.byref(ms) if timed else None),
            "average_images")
     return ms.value if timed else None
+
+
+def device_alloc(nbytes: int, device: int = 0) -> int:
+    """A whole device allocation (hipMalloc), as an integer address.  What `ipc_export` needs."""
+    p = C.c_void_p()
+    _check(lib().ptl_device_alloc(device, nbytes, C.byref(p)), "device_alloc")
+    return int(p.value)
+
+
+def device_free(ptr: int) -> None:
+    _check(lib().ptl_device_free(C.c_void_p(ptr)), "device_free")
+
+
+def device_download(ptr: int, nbytes: int, stream: int = 0) -> np.ndarray:
+    out = np.empty(nbytes, dtype=np.uint8)
+    _check(lib().ptl_device_download(out.ctypes.data, C.c_void_p(ptr), nbytes, C.c_void_p(stream or None)), "device_download")
+    return out
+
+
+IPC_HANDLE_BYTES = 64
+
+
+def ipc_export(ptr: int) -> bytes:
+    """Handle of a `device_alloc` buffer for the other processes of the node (ptl_ipc_export)."""
+    buf = C.create_string_buffer(IPC_HANDLE_BYTES)
+    _check(lib().ptl_ipc_export(C.c_void_p(ptr), buf), "ipc_export")
+    return buf.raw
+
+
+def ipc_open(handle: bytes, device: int = 0) -> int:
+    """Map another process's exported buffer into this process (on `device`); returns the local address."""
+    if len(handle) != IPC_HANDLE_BYTES:
+        raise PortalError("an IPC handle is 64 bytes")
+    p = C.c_void_p()
+    _check(lib().ptl_ipc_open(device, handle, C.byref(p)), "ipc_open")
+    return int(p.value)
+
+
+def ipc_close(ptr: int) -> None:
+    _check(lib().ptl_ipc_close(C.c_void_p(ptr)), "ipc_close")
 
 
 def png_write(path: str, rgba8: np.ndarray) -> None:

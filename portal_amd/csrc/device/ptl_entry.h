@@ -23,7 +23,8 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
                   float* __restrict__ out_rgba32f,        // same, 4 floats per pixel, or null
                   int width, int height,                   // full frame size
                   int rb_phase, int rb_stride,             // row-block interleave
-                  unsigned long long* __restrict__ segment_counter) {
+                  unsigned long long* __restrict__ segment_counter,
+                  int in_place) {                          // 1: out_* address the full frame (maybe a peer GPU's), rows go where they belong
 #ifndef PTL_DIRECT_STORE
     __shared__ unsigned int tile[8][32 + 1];
 #endif
@@ -67,7 +68,8 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
     glsl::vec4 c = glsl::vec4(0.0f);
     if (live) c = glsl::shade_pixel(glsl::vec2((float)px + 0.5f, (float)py + 0.5f));
 
-    const long shard_row = (long)local_block * 8 + ly;
+    const int out_block = in_place ? rb_phase + local_block * rb_stride : local_block;  // wave-uniform
+    const long shard_row = (long)out_block * 8 + ly;
     if (out_rgba32f != nullptr && live) {
         float4 v = make_float4(c.x, c.y, c.z, c.w);
         *reinterpret_cast<float4*>(out_rgba32f + 4 * (shard_row * width + px)) = v;  // 8 lanes x 16 B = one 128 B line per tile row
@@ -83,7 +85,7 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
         const int row = t >> 5, col = t & 31;  // each wave now owns two full 32-pixel rows = 2 x 128 B
         const int gx = block_x * 32 + col;
         const int gy = (rb_phase + local_block * rb_stride) * 8 + row;
-        if (gx < width && gy < height) out_rgba8[((long)local_block * 8 + row) * width + gx] = tile[row][col];
+        if (gx < width && gy < height) out_rgba8[((long)out_block * 8 + row) * width + gx] = tile[row][col];
     }
 #endif
 #ifdef PTL_COUNT_SEGMENTS

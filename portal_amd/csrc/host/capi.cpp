@@ -785,7 +785,7 @@ extern "C" int ptl_renderer_teleport_ray(ptl_renderer* r, const double a[3], con
                                          int* changed_subspace, int* teleported) {
     if (!r || !a || !b) return PTL_ERR_INVALID;
     return guarded([&] {
-        ptl_frame zero{0, 0, 0, 1};  // the reference calls self.set_uniforms(0., 0.) here
+        ptl_frame zero{0, 0, 0, 1, 0};  // the reference calls self.set_uniforms(0., 0.) here
         int rc = prepare_draw(r, &zero);
         if (rc < 0) return rc;
         int one = 1;

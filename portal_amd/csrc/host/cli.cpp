@@ -252,7 +252,7 @@ int render_frame(const Options& o) {
     }
     ptl_renderer_set_option(r, "view_angle", o.fov / 180.0 * 3.14159265358979323846);
     if (ptl_renderer_update(r, o.time, nullptr, nullptr) != PTL_OK) return fail("update");  // src/main.rs:2928
-    ptl_frame frame{o.width, o.height, 0, 1};
+    ptl_frame frame{o.width, o.height, 0, 1, 0};
     std::vector<uint8_t> img((size_t)o.width * o.height * 4);
     float ms = 0.0f;
     if (ptl_renderer_draw_to_host(r, &frame, img.data(), nullptr, nullptr, &ms) != PTL_OK) return fail("render");
@@ -312,7 +312,7 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
     size_t frame_bytes = (size_t)width * height * 4;
     double gpu_ms = 0.0;
     long traced = 0, drawn_frames = 0;
-    ptl_frame frame{width, height, 0, 1};
+    ptl_frame frame{width, height, 0, 1, 0};
     int last = o.max_frames >= 0 ? std::min(count, o.max_frames) : count;
     for (int i = 0; i < last; ++i) {
         std::string name = anim_dir + "/frame_" + std::to_string(i) + ".png";

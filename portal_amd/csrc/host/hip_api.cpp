@@ -91,7 +91,8 @@ const Runtime* runtime(std::string* error) {
                  bind(h, "hipModuleUnload", rt.hipModuleUnload, &err) && bind(h, "hipModuleGetFunction", rt.hipModuleGetFunction, &err) &&
                  bind(h, "hipModuleGetGlobal", rt.hipModuleGetGlobal, &err) && bind(h, "hipFuncGetAttribute", rt.hipFuncGetAttribute, &err) &&
                  bind(h, "hipModuleLaunchKernel", rt.hipModuleLaunchKernel, &err) && bind(h, "hipGetErrorString", rt.hipGetErrorString, &err) &&
-                 bind(h, "hipGetLastError", rt.hipGetLastError, &err);
+                 bind(h, "hipIpcGetMemHandle", rt.hipIpcGetMemHandle, &err) && bind(h, "hipIpcOpenMemHandle", rt.hipIpcOpenMemHandle, &err) &&
+                 bind(h, "hipIpcCloseMemHandle", rt.hipIpcCloseMemHandle, &err) && bind(h, "hipGetLastError", rt.hipGetLastError, &err);
         }
     }
     if (!ok && error) *error = "HIP runtime unavailable: " + err;

@@ -20,6 +20,10 @@ using hipDeviceptr_t = void*;
 using hiprtcProgram = void*;
 using hiprtcResult = int;
 
+struct IpcMemHandle {  // hipIpcMemHandle_t: 64 opaque bytes, passed BY VALUE to hipIpcOpenMemHandle
+    char reserved[64];
+};
+
 struct Runtime {
     std::string path;
     hipError_t (*hipInit)(unsigned);
@@ -52,10 +56,13 @@ struct Runtime {
     hipError_t (*hipModuleLaunchKernel)(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned,
                                         hipStream_t, void**, void**);
     const char* (*hipGetErrorString)(hipError_t);
+    hipError_t (*hipIpcGetMemHandle)(IpcMemHandle*, void*);
+    hipError_t (*hipIpcOpenMemHandle)(void**, IpcMemHandle, unsigned);
+    hipError_t (*hipIpcCloseMemHandle)(void*);
     hipError_t (*hipGetLastError)();  // also CLEARS the thread's sticky error: call after a failure that was expected
 };
 constexpr int kFuncAttrSharedSizeBytes = 1, kFuncAttrLocalSizeBytes = 3, kFuncAttrNumRegs = 4;  // hipFunction_attribute
-constexpr unsigned kStreamNonBlocking = 1, kEventDisableTiming = 2;
+constexpr unsigned kStreamNonBlocking = 1, kEventDisableTiming = 2, kIpcMemLazyEnablePeerAccess = 1;
 constexpr int kMemcpyHostToDevice = 1;
 constexpr int kMemcpyDeviceToHost = 2;
 

@@ -324,7 +324,8 @@ extern "C" int ptl_kernel_render(ptl_kernel* k, const ptl_frame* frame, void* ou
         return PTL_OK;
     }
     int width = frame->width, height = frame->height, phase = frame->rb_phase, stride = frame->rb_stride;
-    void* args[] = {&out_rgba8, &out_rgba32f, &width, &height, &phase, &stride, &segments};
+    int in_place = frame->in_place ? 1 : 0;
+    void* args[] = {&out_rgba8, &out_rgba32f, &width, &height, &phase, &stride, &segments, &in_place};
     // 256 threads = four 8x8 tiles side by side.  PTL_BLOCK_WAVES=1|2 (experiment, tools/variants.py) launches narrower workgroups.
     unsigned waves = 4;
     if (const char* e = std::getenv("PTL_BLOCK_WAVES")) waves = (e[0] == '1' || e[0] == '2') ? (unsigned)(e[0] - '0') : 4u;
@@ -344,6 +345,10 @@ extern "C" int ptl_kernel_render_to_host(ptl_kernel* k, const ptl_frame* frame, 
     if (!k || !frame) return PTL_ERR_INVALID;
     int rows = ptl_frame_shard_rows(frame);
     if (rows < 0) return PTL_ERR_INVALID;
+    if (frame->in_place) {
+        set_last_error("in_place frames are rendered into a caller-owned full-frame DEVICE buffer (ptl_kernel_render / ptl_renderer_draw)");
+        return PTL_ERR_INVALID;
+    }
     if (k->device < 0) return PTL_ERR_NO_DEVICE;
     const hip::Runtime* rt = hip::runtime(nullptr);
     if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;

@@ -237,3 +237,43 @@ extern "C" int ptl_device_download_async(void* host_dst, const void* device_src,
     if (!rt) return PTL_ERR_NO_DEVICE;
     return hip_status(rt, rt->hipMemcpyAsync(host_dst, device_src, bytes, hip::kMemcpyDeviceToHost, stream), "hipMemcpyAsync(D2H)");
 }
+
+// Frame buffers shared between the processes of a node (one process per GPU): the destination rank allocates the full frame
+// with ptl_device_alloc, exports it, and every other rank maps it into its own address space; their render kernels then store
+// their row blocks straight into the destination GPU's HBM over xGMI (ptl_frame.in_place), no gather, no de-interleave copy.
+// 1:1 over hipIpcGetMemHandle / hipIpcOpenMemHandle / hipIpcCloseMemHandle.  The pointer must come from ptl_device_alloc
+// (a whole hipMalloc allocation), and a handle cannot be opened by the process that exported it.
+extern "C" int ptl_ipc_export(void* device_ptr, unsigned char handle[PTL_IPC_HANDLE_BYTES]) {
+    if (!device_ptr || !handle) return PTL_ERR_INVALID;
+    std::string err;
+    const hip::Runtime* rt = hip::runtime(&err);
+    if (!rt) {
+        set_last_error(err);
+        return PTL_ERR_NO_DEVICE;
+    }
+    hip::IpcMemHandle h;
+    static_assert(sizeof h == PTL_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+    int e = rt->hipIpcGetMemHandle(&h, device_ptr);
+    if (e == 0) std::memcpy(handle, &h, sizeof h);
+    return hip_status(rt, e, "hipIpcGetMemHandle");
+}
+
+extern "C" int ptl_ipc_open(int device, const unsigned char handle[PTL_IPC_HANDLE_BYTES], void** device_ptr) {
+    if (!handle || !device_ptr) return PTL_ERR_INVALID;
+    std::string err;
+    const hip::Runtime* rt = hip::runtime(&err);
+    if (!rt) {
+        set_last_error(err);
+        return PTL_ERR_NO_DEVICE;
+    }
+    hip::IpcMemHandle h;
+    std::memcpy(&h, handle, sizeof h);
+    int e = rt->hipSetDevice(device);
+    if (e == 0) e = rt->hipIpcOpenMemHandle(device_ptr, h, hip::kIpcMemLazyEnablePeerAccess);
+    return hip_status(rt, e, "hipIpcOpenMemHandle");
+}
+
+extern "C" int ptl_ipc_close(void* device_ptr) {
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    return rt ? hip_status(rt, rt->hipIpcCloseMemHandle(device_ptr), "hipIpcCloseMemHandle") : PTL_ERR_NO_DEVICE;
+}

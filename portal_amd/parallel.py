@@ -97,3 +97,131 @@ class FrameGatherer:
             return shard[: self.h]
         work.wait()
         return self._assemble(slot) if self.rank == self.dst else None
+
+
+class PeerFrames:
+    """Full-frame buffers in the destination GPU's HBM that every rank renders into directly.
+
+    The destination rank allocates `depth` frames (whole hipMalloc allocations), exports them (`ptl_ipc_export`) and every other
+    rank maps them (`ptl_ipc_open`); a rank then launches its row blocks with `Frame(..., in_place=1)` and the kernel's 128-byte
+    row stores travel over xGMI into the destination's memory -- no gather, no staging shard, no de-interleave copy.  What is
+    left of the collective is a *fence*: a one-element all-reduce enqueued behind the launch on every rank, so that once it has
+    completed on the destination every rank's kernel (and with it its stores) has completed.
+
+    `host_fence` is for a backend without device collectives (gloo: rehearsing N ranks on one GPU): synchronise + barrier."""
+
+    def __init__(self, height: int, width: int, rank: int, world: int, device, dst: int = 0, depth: int = 2, host_fence: bool = False):
+        import portal_amd as pa
+
+        self._pa = pa
+        self.h, self.w, self.rank, self.world, self.dst = height, width, rank, world, dst
+        self.device = torch.device(device)
+        self.host_fence = host_fence
+        self.nbytes = height * width * 4
+        index = self.device.index or 0
+        self.owned, self.ptrs = [], []
+        handles = [None]
+        if rank == dst:
+            self.owned = [pa.device_alloc(self.nbytes, index) for _ in range(depth)]
+            self.ptrs = list(self.owned)
+            handles = [[pa.ipc_export(p) for p in self.owned]]
+        if world > 1:
+            dist.broadcast_object_list(handles, src=dst)
+            if rank != dst:
+                self.ptrs = [pa.ipc_open(h, index) for h in handles[0]]
+        self.token = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def frame(self, rank: Optional[int] = None, world: Optional[int] = None):
+        """The ptl_frame a rank launches with: its interleaved row blocks, stored where they belong."""
+        return self._pa.Frame(self.w, self.h, self.rank if rank is None else rank, self.world if world is None else world, 1)
+
+    def fence_async(self):
+        """Enqueue the completion fence behind what this rank has launched on the current stream."""
+        if self.world == 1:
+            return None
+        if self.host_fence:
+            torch.cuda.synchronize(self.device)
+            dist.barrier()
+            return _Done()
+        return dist.all_reduce(self.token, async_op=True)
+
+    def finish(self, work) -> None:
+        if work is not None:
+            work.wait()
+
+    def download(self, slot: int = 0):
+        """The assembled (H, W, 4) frame as a numpy array (destination rank only; waits for the current stream)."""
+        if self.rank != self.dst:
+            return None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        return self._pa.device_download(self.ptrs[slot], self.nbytes, stream).reshape(self.h, self.w, 4)
+
+    def close(self) -> None:
+        if self.world > 1:
+            torch.cuda.synchronize(self.device)
+            dist.barrier()  # nobody unmaps or frees while a peer may still be storing
+        if self.rank != self.dst:
+            for p in self.ptrs:
+                self._pa.ipc_close(p)
+        for p in self.owned:
+            self._pa.device_free(p)
+        self.ptrs, self.owned = [], []
+
+
+class GatherTransport:
+    """One frame per step through packed shards + ONE gather to `dst` + the de-interleave copy (FrameGatherer)."""
+
+    name = "rccl-gather"
+
+    def __init__(self, height, width, rank, world, device, depth=2, stage_through_host=False):
+        import portal_amd as pa
+
+        self.depth = depth if world > 1 else 1
+        self.rank, self.world, self.h = rank, world, height
+        self.frame = pa.Frame(width, height, rank, world)
+        self.shards = [alloc_shard(height, width, world, device) for _ in range(self.depth)]
+        self.gatherer = FrameGatherer(height, width, rank, world, device, depth=self.depth, stage_through_host=stage_through_host)
+
+    def out_ptr(self, slot):
+        return self.shards[slot].data_ptr()
+
+    def submit(self, slot):
+        return self.gatherer.gather_async(self.shards[slot], slot) if self.world > 1 else None
+
+    def finish(self, work, slot):
+        """The assembled frame (a device tensor) on the destination rank, None elsewhere."""
+        return self.gatherer.finish(work, self.shards[slot], slot)
+
+    def download(self, assembled):
+        return assembled.cpu().numpy() if assembled is not None else None
+
+    def close(self):
+        pass
+
+
+class PeerTransport:
+    """One frame per step through stores into the destination's HBM + a fence (PeerFrames)."""
+
+    name = "p2p-stores"
+
+    def __init__(self, height, width, rank, world, device, depth=2, host_fence=False):
+        self.depth = depth
+        self.rank, self.world = rank, world
+        self.frames = PeerFrames(height, width, rank, world, device, depth=depth, host_fence=host_fence)
+        self.frame = self.frames.frame()
+
+    def out_ptr(self, slot):
+        return self.frames.ptrs[slot]
+
+    def submit(self, slot):
+        return self.frames.fence_async()
+
+    def finish(self, work, slot):
+        self.frames.finish(work)
+        return slot if self.rank == self.frames.dst else None
+
+    def download(self, assembled):
+        return self.frames.download(assembled) if assembled is not None else None
+
+    def close(self):
+        self.frames.close()

@@ -784,10 +784,13 @@ def test_random_camera_walks_teleport_like_the_oracle(gpu, scene_name, seed):
     assert crossings >= 1 or scene_name != "basics"
 
 
-def test_bench_multi_rank_rehearsal_assembles_the_same_frame(gpu, tmp_path):
-    """bench.py's multi-rank path (row-block sharding, rank-0 build choice broadcast, double-buffered gather, de-interleave, JSON)
-    rehearsed on ONE GPU: PTL_BENCH_BACKEND=gloo lets 3 ranks share the device and stages the gather through host memory.
-    Everything but RCCL itself is the code the driver's 2/4/8-GPU runs execute; the assembled frame equals the 1-rank frame."""
+@pytest.mark.parametrize("transport", ["gather", "p2p", "auto"])
+def test_bench_multi_rank_rehearsal_assembles_the_same_frame(gpu, tmp_path, transport):
+    """bench.py's multi-rank path (row-block sharding, rank-0 build choice broadcast, both frame transports, JSON) rehearsed on ONE
+    GPU: PTL_BENCH_BACKEND=gloo lets 3 ranks share the device.  `gather`: double-buffered gather (staged through host memory here,
+    RCCL in the driver's runs) + de-interleave; `p2p`: rank 0's frame buffers mapped into the other PROCESSES through HIP IPC and
+    filled in place by their kernels, fenced by a barrier; `auto`: both, compared byte for byte, the faster kept.  Everything but
+    RCCL itself is the code the driver's 2/4/8-GPU runs execute; the assembled frame equals the 1-rank frame."""
     import json
     import subprocess
     import sys
@@ -795,13 +798,93 @@ def test_bench_multi_rank_rehearsal_assembles_the_same_frame(gpu, tmp_path):
     pa = gpu
     root = pa.REPO_ROOT
     common = ["--scene", "triple_portal", "--width", "1280", "--height", "720", "--depth", "24", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--waves", "0"]
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common, "--save-png", str(tmp_path / "one.png")], capture_output=True, text=True, timeout=600)
+    one_png = tmp_path / "one.png"
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common, "--save-png", str(one_png)], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-800:]
-    env = dict(os.environ, PTL_BENCH_BACKEND="gloo")
+    env = dict(os.environ, PTL_BENCH_BACKEND="gloo", PTL_BENCH_TRANSPORT=transport)
     many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", "29517",
                            os.path.join(root, "bench.py"), "--gpus", "3", *common, "--save-png", str(tmp_path / "three.png")],
                           capture_output=True, text=True, timeout=900, env=env)
     assert many.returncode == 0, many.stderr[-1500:]
     line = json.loads([l for l in many.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 3 and line["steps"] == 4 and line["scaling"] == "strong" and line["value"] > 0
-    assert np.array_equal(pa.png_read(str(tmp_path / "one.png")), pa.png_read(str(tmp_path / "three.png")))
+    cfg = line["config"]
+    print(transport, cfg["transport"], cfg["transport_ms_per_frame"], cfg["transport_notes"])
+    if transport == "gather":
+        assert cfg["transport"] == "rccl-gather"
+    elif transport == "p2p":
+        assert cfg["transport"] == "p2p-stores"
+    else:
+        assert set(cfg["transport_ms_per_frame"]) == {"rccl-gather", "p2p-stores"} and not cfg["transport_notes"]
+    assert np.array_equal(pa.png_read(str(one_png)), pa.png_read(str(tmp_path / "three.png")))
+
+
+def test_in_place_launches_fill_one_frame(gpu):
+    """ptl_frame.in_place: N launches with phase 0..N-1 into ONE full-frame buffer give the bytes of the whole-frame launch
+    (ragged height: the last row block is partial), for RGBA8 and the float buffer; the packed layout is untouched."""
+    import torch
+
+    pa = gpu
+    W, H = 333, 203
+    r = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("monoportal")), device=0)
+    r.set_option("render_depth", 12)
+    whole8 = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    whole32 = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    r.draw_device(pa.Frame(W, H, 0, 1), out_rgba8=whole8.data_ptr(), out_rgba32f=whole32.data_ptr())
+    for world in (1, 2, 3, 5):
+        full8 = torch.full((H, W, 4), 7, dtype=torch.uint8, device="cuda")
+        full32 = torch.full((H, W, 4), -1.0, dtype=torch.float32, device="cuda")
+        for rank in range(world):
+            r.draw_device(pa.Frame(W, H, rank, world, 1), out_rgba8=full8.data_ptr(), out_rgba32f=full32.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(full8, whole8), world
+        assert torch.equal(full32.view(torch.int32), whole32.view(torch.int32)), world
+    import ctypes as C
+
+    a8 = np.empty((H, W, 4), np.uint8)
+    frame = pa.Frame(W, H, 0, 2, 1)  # the host-copy convenience has no full-frame device buffer to offer: refused, not overrun
+    assert pa.lib().ptl_renderer_draw_to_host(r._h, C.byref(frame), a8.ctypes.data, None, None, None) == -1  # PTL_ERR_INVALID
+
+
+_IPC_CHILD = r"""
+import sys
+import portal_amd as pa
+handle = bytes.fromhex(sys.argv[1]); W, H, rank, world = map(int, sys.argv[2:6])
+ptr = pa.ipc_open(handle, 0)
+r = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("monoportal")), device=0)
+r.set_option("render_depth", 12)
+ms = r.draw_device(pa.Frame(W, H, rank, world, 1), out_rgba8=ptr, timed=True)   # timed: waits for completion
+pa.ipc_close(ptr)
+print("child done", ms)
+"""
+
+
+def test_peer_process_renders_into_an_exported_frame(gpu, tmp_path):
+    """ptl_ipc_export / ptl_ipc_open: ANOTHER process maps this process's frame buffer and its kernel stores two of three row-block
+    phases into it; this process renders the third.  The frame equals the single-launch frame.  (On one GPU the stores stay in
+    local HBM; across GPUs the same mapping sends them over xGMI.)"""
+    import subprocess
+    import sys
+
+    pa = gpu
+    W, H = 640, 360
+    r = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("monoportal")), device=0)
+    r.set_option("render_depth", 12)
+    want = r.draw(W, H)["rgba8"]
+    buf = pa.device_alloc(W * H * 4, 0)
+    try:
+        handle = pa.ipc_export(buf)
+        assert len(handle) == pa.IPC_HANDLE_BYTES
+        with pytest.raises(pa.PortalError):
+            pa.ipc_open(handle, 0)  # a handle cannot be opened where it was made
+        r.draw_device(pa.Frame(W, H, 1, 3, 1), out_rgba8=buf, timed=True)
+        script = tmp_path / "child.py"
+        script.write_text(_IPC_CHILD)
+        env = dict(os.environ, PYTHONPATH=pa.REPO_ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        for rank in (0, 2):
+            out = subprocess.run([sys.executable, str(script), handle.hex(), str(W), str(H), str(rank), "3"], capture_output=True, text=True, timeout=300, env=env)
+            assert out.returncode == 0 and "child done" in out.stdout, out.stderr[-800:]
+        got = pa.device_download(buf, W * H * 4).reshape(H, W, 4)
+        assert np.array_equal(got, want)
+    finally:
+        pa.device_free(buf)

@@ -37,6 +37,15 @@ def test_version_and_no_gpu_paths_fail_loudly(pa):
     assert len(r.code_object()) > 1000 and r.code_object()[:4] == b"\x7fELF"
     with pytest.raises(pa.PortalError):  # no CPU fallback for rendering
         r.draw(16, 16)
+    frame = pa.Frame(64, 20, 1, 2, 1)  # in_place only changes where rows are stored, not which rows a launch renders
+    assert frame.in_place == 1 and pa.shard_rows(frame) == pa.shard_rows(pa.Frame(64, 20, 1, 2)) == 8
+    import torch
+
+    if not torch.cuda.is_available():  # peer frame buffers are device memory: nothing to hand out here
+        with pytest.raises(pa.PortalError):
+            pa.ipc_export(pa.device_alloc(4096, 0))
+        with pytest.raises(pa.PortalError):
+            pa.ipc_open(bytes(64), 0)
 
 
 def test_unknown_scene_and_bad_ron(pa):
