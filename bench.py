@@ -235,7 +235,7 @@ def main():
         else:
             transport_notes.setdefault("p2p-stores", "unavailable on another rank")
             if peer is not None:
-                peer.close()
+                peer.abandon()  # not close(): that is collective, and the rank that failed is not taking part
         if not transports:
             raise SystemExit("PTL_BENCH_TRANSPORT=p2p but peer frame buffers are unavailable: " + transport_notes["p2p-stores"])
 

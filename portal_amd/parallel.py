@@ -122,13 +122,26 @@ class PeerFrames:
         self.owned, self.ptrs = [], []
         handles = [None]
         if rank == dst:
-            self.owned = [pa.device_alloc(self.nbytes, index) for _ in range(depth)]
-            self.ptrs = list(self.owned)
-            handles = [[pa.ipc_export(p) for p in self.owned]]
+            try:
+                self.owned = [pa.device_alloc(self.nbytes, index) for _ in range(depth)]
+                self.ptrs = list(self.owned)
+                handles = [[pa.ipc_export(p) for p in self.owned]]
+            except Exception as e:  # the others are waiting in the broadcast: tell them instead of leaving them there
+                handles = [f"export failed: {e}"]
         if world > 1:
             dist.broadcast_object_list(handles, src=dst)
+            if isinstance(handles[0], str):
+                self._release()
+                raise RuntimeError(handles[0])
             if rank != dst:
-                self.ptrs = [pa.ipc_open(h, index) for h in handles[0]]
+                try:
+                    for h in handles[0]:
+                        self.ptrs.append(pa.ipc_open(h, index))
+                except Exception:
+                    self._release()
+                    raise
+        elif isinstance(handles[0], str):
+            raise RuntimeError(handles[0])
         self.token = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def frame(self, rank: Optional[int] = None, world: Optional[int] = None):
@@ -160,6 +173,9 @@ class PeerFrames:
         if self.world > 1:
             torch.cuda.synchronize(self.device)
             dist.barrier()  # nobody unmaps or frees while a peer may still be storing
+        self._release()
+
+    def _release(self) -> None:
         if self.rank != self.dst:
             for p in self.ptrs:
                 self._pa.ipc_close(p)
@@ -225,3 +241,7 @@ class PeerTransport:
 
     def close(self):
         self.frames.close()
+
+    def abandon(self):
+        """Release without the collective shutdown (set-up failed on another rank; nothing has been launched)."""
+        self.frames._release()
