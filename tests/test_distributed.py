@@ -82,3 +82,48 @@ def test_gatherer_single_rank_is_identity():
     shard[:] = torch.arange(shard.numel(), dtype=torch.int64).reshape(shard.shape).to(torch.uint8)
     g = parallel.FrameGatherer(20, 5, 0, 1, "cpu")
     assert torch.equal(g.gather(shard), shard[:20])
+
+
+def _transport_worker(rank, world, port):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from portal_amd import parallel
+
+        # no GPU here: rank 0 cannot allocate the shared frame.  The failure must reach EVERY rank (through the broadcast the
+        # others are waiting in) so that bench.py's "did all ranks get it?" all-reduce still lines up -- nobody is left hanging.
+        ok = 1
+        try:
+            parallel.PeerTransport(H, W, rank, world, "cpu", host_fence=True)
+        except RuntimeError as e:
+            assert "export failed" in str(e)
+            ok = 0
+        agreed = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        assert int(agreed.item()) == 0
+        # the gather transport drives the same buffers as FrameGatherer: two frames through both slots
+        tr = parallel.GatherTransport(H, W, rank, world, "cpu")
+        assert tr.depth == 2 and tr.frame.in_place == 0 and tr.frame.rb_phase == rank
+        for slot, value in ((0, 11), (1, 22)):
+            tr.shards[slot][:] = value + rank
+        works = [tr.submit(0), tr.submit(1)]
+        frames = [tr.finish(works[0], 0), tr.finish(works[1], 1)]
+        if rank == 0:
+            for f, value in zip(frames, (11, 22)):
+                got = tr.download(f)
+                assert got.shape == (H, W, 4)
+                for b in range(parallel.blocks_of(H)):  # block b came from rank b % world
+                    assert (got[8 * b : 8 * b + 8] == value + b % world).all()
+        else:
+            assert frames == [None, None]
+        tr.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the no-device failure path")
+def test_transports_on_cpu_ranks_fail_together_and_gather():
+    mp.spawn(_transport_worker, args=(2, _free_port()), nprocs=2, join=True)
