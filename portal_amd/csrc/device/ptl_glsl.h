@@ -30,7 +30,43 @@ namespace glsl {
 // scalar primitives
 // ---------------------------------------------------------------------------------------
 PTL_FN float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// sqrt(x) and 1/x are IEEE correctly rounded -- on either compiler, for every input.  The host build uses the language's
+// operators.  The gfx950 build reaches the same bits in fewer instructions than the compiler's general-purpose expansions
+// (16 and 11 VALU instructions), branch-free, from the same hardware estimates (v_sqrt_f32 / v_rcp_f32, ~1 ulp):
+//   1/x    : the compiler refines the estimate three times; ONE exact FMA residual step is already correctly rounded on this
+//            hardware.  Range scaling (v_div_scale / v_div_fmas) and the zero / infinity / NaN cases (v_div_fixup) stay: 7.
+//   sqrt(x): the correctly rounded root is the estimate s, s - 1 ulp or s + 1 ulp; the signs of x - s*(s -/+ ulp), each one
+//            FMA, tell which.  With the comparisons ordered as below the special values (+-0, +inf, NaN, negatives) fall
+//            through unchanged, so the compiler's separate class test and select are not needed: 14.
+// "Correctly rounded" here is not an argument but a measurement: both are compared with the compiler's IEEE expansions for ALL
+// 2^32 bit patterns on the GPU (tests/test_gpu_parity.py::test_sqrt_and_reciprocal_are_exact_for_every_input, 6 ms).
+// PTL_PLAIN_SQRT_RCP restores the operators (tools/variants.py measures the difference).
+#if PTL_DEVICE_BUILD && !defined(PTL_PLAIN_SQRT_RCP)
+PTL_FN float sqrt(float x) {
+    const bool tiny = x < 0x1p-96f;                // below, the residuals would underflow: work on x * 2^32, give back s * 2^-16
+    const float xs = tiny ? x * 0x1p+32f : x;
+    float s = __builtin_amdgcn_sqrtf(xs);
+    const int bits = __builtin_bit_cast(int, s);
+    const float below = __builtin_bit_cast(float, bits - 1), above = __builtin_bit_cast(float, bits + 1);
+    const float r_below = __builtin_fmaf(-below, s, xs), r_above = __builtin_fmaf(-above, s, xs);
+    s = r_below <= 0.0f ? below : s;               // (false for a NaN residual: +-0, +inf and NaN keep s)
+    s = r_above > 0.0f ? above : s;
+    return tiny ? s * 0x1p-16f : s;
+}
+PTL_FN float ptl_rcp(float x) {
+    bool unused, rescale;
+    const float d = __builtin_amdgcn_div_scalef(1.0f, x, false, &unused);  // x, or x * 2^+-64 when 1/x needs the room
+    const float n = __builtin_amdgcn_div_scalef(1.0f, x, true, &rescale);  // 1, scaled to match
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q = n * r;
+    const float residual = __builtin_fmaf(-d, q, n);                        // exact
+    return __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(residual, r, q, rescale), x, 1.0f);
+}
+#else
 PTL_FN float sqrt(float x) { return __builtin_sqrtf(x); }
+PTL_FN float ptl_rcp(float x) { return 1.0f / x; }
+#endif
 PTL_FN float abs(float x) { return __builtin_fabsf(x); }
 PTL_FN int abs(int x) { return x < 0 ? -x : x; }
 PTL_FN float floor(float x) { return __builtin_floorf(x); }
@@ -38,7 +74,7 @@ PTL_FN float ceil(float x) { return __builtin_ceilf(x); }
 PTL_FN float trunc(float x) { return __builtin_truncf(x); }
 PTL_FN float roundEven(float x) { return __builtin_rintf(x); }
 PTL_FN float round(float x) { return __builtin_rintf(x); }
-PTL_FN float inversesqrt(float x) { return 1.0f / sqrt(x); }
+PTL_FN float inversesqrt(float x) { return ptl_rcp(sqrt(x)); }
 PTL_FN float fract(float x) { return x - floor(x); }
 PTL_FN float mod(float x, float y) { return x - y * floor(x / y); }
 PTL_FN float min(float a, float b) { return b < a ? b : a; }
@@ -113,7 +149,7 @@ PTL_FN float atan(float x0) {
     float y = 0.0f;
     if (x > 2.414213562373095f) {
         y = 0x1.921fb6p+0f;
-        x = -(1.0f / x);
+        x = -ptl_rcp(x);
     } else if (x > 0.4142135623730950f) {
         y = 0x1.921fb6p-1f;
         x = (x - 1.0f) / (x + 1.0f);
@@ -405,9 +441,9 @@ PTL_FN vec4 operator/(const vec4& a, const vec4& b) { return vec4(a.x / b.x, a.y
 PTL_FN vec2 operator/(float a, const vec2& b) { return vec2(a / b.x, a / b.y); }
 PTL_FN vec3 operator/(float a, const vec3& b) { return vec3(a / b.x, a / b.y, a / b.z); }
 PTL_FN vec4 operator/(float a, const vec4& b) { return vec4(a / b.x, a / b.y, a / b.z, a / b.w); }
-PTL_FN vec2 operator/(const vec2& a, float b) { float i = 1.0f / b; return vec2(a.x * i, a.y * i); }
-PTL_FN vec3 operator/(const vec3& a, float b) { float i = 1.0f / b; return vec3(a.x * i, a.y * i, a.z * i); }
-PTL_FN vec4 operator/(const vec4& a, float b) { float i = 1.0f / b; return vec4(a.x * i, a.y * i, a.z * i, a.w * i); }
+PTL_FN vec2 operator/(const vec2& a, float b) { float i = ptl_rcp(b); return vec2(a.x * i, a.y * i); }
+PTL_FN vec3 operator/(const vec3& a, float b) { float i = ptl_rcp(b); return vec3(a.x * i, a.y * i, a.z * i); }
+PTL_FN vec4 operator/(const vec4& a, float b) { float i = ptl_rcp(b); return vec4(a.x * i, a.y * i, a.z * i, a.w * i); }
 
 PTL_FN vec2 operator-(const vec2& a) { return vec2(-a.x, -a.y); }
 PTL_FN vec3 operator-(const vec3& a) { return vec3(-a.x, -a.y, -a.z); }
@@ -610,12 +646,12 @@ template <class PtlBuiltin = void> PTL_FN mat4 transpose(const mat4& m) {
 template <class PtlBuiltin = void> PTL_FN float determinant(const mat2& m) { return m.c[0].x * m.c[1].y - m.c[1].x * m.c[0].y; }
 template <class PtlBuiltin = void> PTL_FN float determinant(const mat3& m) { return dot(m.c[0], cross(m.c[1], m.c[2])); }
 template <class PtlBuiltin = void> PTL_FN mat2 inverse(const mat2& m) {
-    float i = 1.0f / determinant(m);
+    float i = ptl_rcp(determinant(m));
     return mat2(m.c[1].y * i, -m.c[0].y * i, -m.c[1].x * i, m.c[0].x * i);
 }
 template <class PtlBuiltin = void> PTL_FN mat3 inverse(const mat3& m) {
     vec3 r0 = cross(m.c[1], m.c[2]), r1 = cross(m.c[2], m.c[0]), r2 = cross(m.c[0], m.c[1]);
-    float i = 1.0f / dot(m.c[0], r0);
+    float i = ptl_rcp(dot(m.c[0], r0));
     return mat3(r0.x * i, r1.x * i, r2.x * i, r0.y * i, r1.y * i, r2.y * i, r0.z * i, r1.z * i, r2.z * i);
 }
 

@@ -57,7 +57,7 @@ PTL_FN vec3 my_refract(vec3 dir, vec3 normal, float refractive_index) {
     float ri = refractive_index;
     bool from_outside = dot(normal, dir) > 0.0f;
     if (!from_outside) {
-        ri = 1.0f / ri;
+        ri = ptl_rcp(ri);
     } else {
         normal = -normal;
     }
@@ -302,7 +302,7 @@ PTL_FN SurfaceIntersection triangle(Ray r, vec3 v0, vec3 v1, vec3 v2) {
     vec3 rov0 = ro - v0;
     vec3 n = cross(v1v0, v2v0);
     vec3 q = cross(rov0, rd);
-    float d = 1.0f / dot(rd, n);
+    float d = ptl_rcp(dot(rd, n));
     float u = d * dot(-q, v2v0);
     float v = d * dot(q, v1v0);
     float t = d * dot(-n, rov0);

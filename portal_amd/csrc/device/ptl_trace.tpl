@@ -415,7 +415,7 @@ PTL_FN vec4 shade_pixel(vec2 position) {
     float coef = min(_resolution.x, _resolution.y);
     vec2 uv_screen = (position - _resolution / 2.0f) / coef * 2.0f;
     vec3 result = vec3(0.0f);
-    float pixel_size = 1.0f / min(_resolution.x, _resolution.y);
+    float pixel_size = ptl_rcp(min(_resolution.x, _resolution.y));
     for (int a = _aa_start; a < _aa_count + _aa_start; a++) {
         vec2 offset = quasi_random(a);
         result += get_color(uv_screen + offset * pixel_size * 2.0f);

@@ -888,3 +888,43 @@ def test_peer_process_renders_into_an_exported_frame(gpu, tmp_path):
         assert np.array_equal(got, want)
     finally:
         pa.device_free(buf)
+
+
+_EXHAUSTIVE = r"""
+#define PTL_COUNT_SEGMENT() ((void)0)
+#define PTL_NO_TELEPORT_ENTRY 1
+namespace glsl {
+struct ptl_uniform_block { int what_u; int pad_u; };
+__constant__ ptl_uniform_block ptl_u;
+PTL_FN bool same(float a, float b) { return __builtin_bit_cast(unsigned, a) == __builtin_bit_cast(unsigned, b) || (a != a && b != b); }
+// pixel (x, y) of a 4096 x 256 frame = one of 2^20 threads, each walking 4096 consecutive bit patterns: all 2^32 floats.
+PTL_FN vec4 shade_pixel(vec2 position) {
+    const unsigned base = ((unsigned)position.y * 4096u + (unsigned)position.x) << 12;
+    unsigned bad_sqrt = 0, bad_rcp = 0, bad_inversesqrt = 0, first = 0;
+    for (unsigned k = 0; k < 4096u; ++k) {
+        const float x = __builtin_bit_cast(float, base + k);
+        const float want_sqrt = __builtin_sqrtf(x), want_rcp = 1.0f / x;   // the compiler's IEEE expansions
+        const bool b0 = !same(sqrt(x), want_sqrt), b1 = !same(ptl_rcp(x), want_rcp), b2 = !same(inversesqrt(x), 1.0f / want_sqrt);
+        bad_sqrt += b0; bad_rcp += b1; bad_inversesqrt += b2;
+        if ((b0 || b1 || b2) && first == 0) first = base + k;
+    }
+    return vec4((float)bad_sqrt, (float)bad_rcp, (float)bad_inversesqrt, __builtin_bit_cast(float, first));
+}
+PTL_FN unsigned int pack_rgba8(vec4 c) { return 0u; }
+}  // namespace glsl
+"""
+
+
+def test_sqrt_and_reciprocal_are_exact_for_every_input(gpu):
+    """The gfx950 build computes sqrt(x) and 1/x with shorter instruction sequences than the compiler's expansions (ptl_glsl.h: one
+    exact FMA correction of the hardware estimate).  ALL 2^32 bit patterns go through them here -- normals, subnormals, zeros,
+    infinities, every NaN -- against the compiler's IEEE expansions (which the numerics-contract test ties to numpy, and numpy to
+    the host build): not one mismatch."""
+    pa = gpu
+    k = pa.Kernel(pa.device_source("glsl") + _EXHAUSTIVE + pa.device_source("entry"), [("what_u", 2, 0), ("pad_u", 2, 4)], 8, device=0)
+    out = k.render(4096, 256, rgba8=False, rgba32f=True)
+    got = out["rgba32f"].reshape(-1, 4)
+    bad = got[:, :3].astype(np.float64).sum(axis=0)
+    first = got[:, 3].view(np.uint32)
+    assert not bad.any(), f"mismatches (sqrt, 1/x, inversesqrt) = {bad}; e.g. bit pattern {hex(int(first[first != 0][0]))}"
+    print(f"sqrt, 1/x and inversesqrt exact on all 2^32 inputs ({out['ms']:.1f} ms)")

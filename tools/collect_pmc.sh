@@ -1,0 +1,19 @@
+#!/bin/bash
+# tools/collect_pmc.sh BUILD [OUT_NAME] -- run ON the GPU box (through gpurun): rocprofv3 PMC passes of the headline bench for one
+# candidate build, ONE counter group per run (never combined with trace domains), folded into gpurun_out/OUT_NAME.json by
+# tools/pmc_summary.py.  Extra hiprtc flags come from the environment (PTL_HIPRTC_FLAGS), extra bench arguments from BENCH_ARGS.
+set -u
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+BUILD=${1:-minreg}
+NAME=${2:-pmc_pip4k_spec_$BUILD}
+mkdir -p $O
+cd /tmp
+rm -rf /tmp/pmc_$NAME
+i=0
+for group in "SQ_WAVES SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_THREAD_CYCLES_VALU" "SQ_INSTS_SALU SQ_INSTS_VALU_TRANS" "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i + 1))
+    rocprofv3 --pmc $group --output-format csv -d /tmp/pmc_$NAME/p$i -o p -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --build $BUILD ${BENCH_ARGS:-} > /tmp/pmc_$NAME.log 2>&1 || tail -3 /tmp/pmc_$NAME.log
+done
+python $R/tools/pmc_summary.py $O/$NAME.json "${WORKLOAD:-portal_in_portal 3840x2160 depth 40, all scene uniforms baked, build $BUILD, flags '${PTL_HIPRTC_FLAGS:-}', 1 GPU; the 5 timed launches of each pass; FETCH_SIZE / WRITE_SIZE in KB}" 5 /tmp/pmc_$NAME/p*

@@ -22,3 +22,5 @@ python $R/tools/stub_profile.py mobius_monoportal 3840 2160 64 2> /dev/null >> $
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_vid -o v -- $R/portal_amd/portal-amd render $R/scenes/portal_in_portal.ron intro.1 --fps 60 --motion-blur-frames 4 --out-dir /tmp/vid_prof > $O/video_prof.log 2>&1
 cp /tmp/prof_vid/*kernel_stats.csv $O/kernel_stats_video_pip_intro1_4k_aa4_blur4_clip_specialised.csv
 head -3 $O/kernel_stats_pip4k_bench.csv; cat $O/bench_pip4k_1gpu.json | cut -c1-300
+python $R/tools/valu_rates.py > $O/valu_rates.jsonl 2> /dev/null
+for b in w0 minreg; do bash $R/tools/collect_pmc.sh $b > /dev/null 2>&1; done

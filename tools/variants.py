@@ -53,6 +53,9 @@ VARIANTS = {
     "all_Oz": "SPECIALIZE_ALL -Oz",
     "base_Os": "-Os",
     "base_O1_w3": "-O1 -DPTL_WAVES_PER_EU=3",
+    "all_plain": "SPECIALIZE_ALL -DPTL_PLAIN_SQRT_RCP",
+    "base_plain": "-DPTL_PLAIN_SQRT_RCP",
+    "all_minreg_plain": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg -DPTL_PLAIN_SQRT_RCP",
 }
 CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
 
