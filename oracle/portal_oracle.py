@@ -6,7 +6,9 @@ leg may import anything under oracle/; the product (portal_amd/) never does.
 PARITY UNPINNED: the reference ships no CPU tracer, no golden image and no known-answer vector
 for this path, and it cannot be built or run here
 (no Rust toolchain, no GL context).  This oracle is therefore a restatement, pinned only by
-the hand-derived known-answer tests in tests/test_oracle_kat.py.
+the hand-derived known-answer tests in tests/test_oracle_kat.py and, qualitatively, by the one
+capture of the real program whose camera is known (tests/test_reference_screenshot.py: the same
+hue class on 92.5 % of the pixels outside the GUI -- where things are, not their bits).
 
 What it restates, in numpy over "lanes" (one lane = one pixel sample), independently of the
 product's C++ host code, of its GLSL->C++ translator and of its device prelude:

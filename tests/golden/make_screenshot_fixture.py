@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""tests/golden/make_screenshot_fixture.py -- turn a screenshot the reference's README shows into a small test fixture.
+
+/root/reference/img/panini.webp is a window capture of the reference program itself (monoportal scene, Panini projection,
+the camera panel open: look-at (0,0,0), alpha -116.7 deg, beta 70.3 deg, R 1.80, parameter 1.0, view angle 220 deg).  It is
+the only output of the real renderer this build can be held against (no Rust, no GL here), so it is kept -- cropped to the
+client area the scene is drawn into and reduced to 262 x 188 -- together with the parameters read off the panel.  The capture
+is older than the scene files (the walls were more saturated then, the ceiling tiles lighter), lossy and partly covered by the
+GUI, so tests/test_reference_screenshot.py compares WHERE things are (hue classes), not pixel values.
+
+Run in the build container (needs /root/reference and PIL):  python tests/golden/make_screenshot_fixture.py
+"""
+import json
+import os
+
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "reference_screenshots")
+SIZE = (262, 188)
+
+if __name__ == "__main__":
+    shot = Image.open("/root/reference/img/panini.webp").convert("RGB")
+    w, h = shot.size
+    client = (10, 44, w - 9, h - 10)  # inside the window frame, below the title bar: what draw_texture(0, 0, screen_w, screen_h) covers
+    crop = shot.crop(client)
+    cw, ch = crop.size
+    crop.resize(SIZE, Image.BOX).save(os.path.join(OUT, "panini.png"))
+    sx, sy = SIZE[0] / cw, SIZE[1] / ch
+    covered = [  # GUI drawn over the scene, in fixture pixels: x0, y0, x1, y1
+        [0, 0, SIZE[0], int((80 - 44) * sy) + 2],                                                       # menu bar
+        [int((30 - 10) * sx), int((98 - 44) * sy), int((548 - 10) * sx) + 1, int((482 - 44) * sy) + 1],  # camera panel
+    ]
+    meta = {
+        "source": "img/panini.webp of the reference repository (README screenshot of the running program)",
+        "client_size": [cw, ch],
+        "scene": "monoportal",
+        "uniforms": {"triangle_x": -0.5},
+        "camera": {"look_at": [0.0, 0.0, 0.0], "alpha_deg": -116.7, "beta_deg": 70.3, "r": 1.80},
+        "options": {"use_panini_projection": 1, "panini_param": 1.0, "view_angle_deg": 220.0},
+        "covered": covered,
+    }
+    json.dump(meta, open(os.path.join(OUT, "panini.json"), "w"), indent=1)
+    print("wrote", OUT, crop.size, "->", SIZE)

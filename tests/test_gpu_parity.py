@@ -928,3 +928,39 @@ def test_sqrt_and_reciprocal_are_exact_for_every_input(gpu):
     first = got[:, 3].view(np.uint32)
     assert not bad.any(), f"mismatches (sqrt, 1/x, inversesqrt) = {bad}; e.g. bit pattern {hex(int(first[first != 0][0]))}"
     print(f"sqrt, 1/x and inversesqrt exact on all 2^32 inputs ({out['ms']:.1f} ms)")
+
+
+def test_gpu_frame_agrees_with_the_reference_screenshot(gpu):
+    """The README screenshot of the reference program (tests/test_reference_screenshot.py, fixture in tests/golden/) against the
+    frame the GPU renders for the camera its panel shows: same hue class outside the GUI on >= 92 % of the pixels."""
+    import json
+    import math
+    import os
+
+    from PIL import Image
+
+    from tests.test_reference_screenshot import SHOTS, hue_classes
+
+    pa = gpu
+    meta = json.load(open(os.path.join(SHOTS, "panini.json")))
+    shot = np.asarray(Image.open(os.path.join(SHOTS, "panini.png")).convert("RGB"))
+    size = (shot.shape[1], shot.shape[0])
+    scene = pa.Scene.from_file(pa.scene_path(meta["scene"]))
+    for k, v in meta["uniforms"].items():
+        scene.set_uniform(k, v)
+    r = pa.SceneRenderer(scene, device=0, flags=pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
+    r.set_option("render_depth", 20)
+    r.set_option("aa_count", 2)
+    o, cam = meta["options"], meta["camera"]
+    r.set_option("use_panini_projection", o["use_panini_projection"])
+    r.set_option("panini_param", o["panini_param"])
+    r.set_option("view_angle", math.radians(o["view_angle_deg"]))
+    r.set_camera(cam["look_at"], math.radians(cam["alpha_deg"]), math.radians(cam["beta_deg"]), cam["r"])
+    frame = r.draw(2 * size[0], 2 * size[1])["rgba8"]
+    got = hue_classes(np.asarray(Image.fromarray(frame[:, :, :3]).resize(size, Image.BOX)))
+    visible = np.ones(shot.shape[:2], bool)
+    for x0, y0, x1, y1 in meta["covered"]:
+        visible[y0:y1, x0:x1] = False
+    agree = float((got == hue_classes(shot))[visible].mean())
+    print(f"GPU frame vs reference screenshot: hue-class agreement {agree:.3f}")
+    assert agree >= 0.92
