@@ -42,3 +42,23 @@ if __name__ == "__main__":
     }
     json.dump(meta, open(os.path.join(OUT, "panini.json"), "w"), indent=1)
     print("wrote", OUT, crop.size, "->", SIZE)
+
+    # img/interface.webp: the program's editor on an (almost) empty scene -- the only thing drawn is the gizmo of the identity matrix
+    # `id` (DebugMatrix capsules: x red, y green, z blue) on the sky colour, with the camera panel open (look-at (0, 0.61, 0),
+    # alpha 44.9, beta 56.4, R 4.24, view angle 90).  Kept: the part of the client area between the panels, at half size.
+    shot = Image.open("/root/reference/img/interface.webp").convert("RGB")
+    w, h = shot.size
+    crop = shot.crop((10, 44, w - 9, h - 10))
+    cw, ch = crop.size
+    half = crop.resize((cw // 2, ch // 2), Image.BOX)
+    box = [(700 - 10) // 2, (475 - 44) // 2, (1150 - 10) // 2, (765 - 44) // 2]  # x0, y0, x1, y1 in half-size client pixels
+    half.crop(box).save(os.path.join(OUT, "interface_gizmo.png"))
+    meta = {
+        "source": "img/interface.webp of the reference repository (README screenshot of the running program)",
+        "render_size": [cw // 2, ch // 2],
+        "box": box,
+        "camera": {"look_at": [0.0, 0.61, 0.0], "alpha_deg": 44.9, "beta_deg": 56.4, "r": 4.24},
+        "view_angle_deg": 90.0,
+    }
+    json.dump(meta, open(os.path.join(OUT, "interface_gizmo.json"), "w"), indent=1)
+    print("wrote interface_gizmo", box)

@@ -108,3 +108,52 @@ def test_numpy_oracle_agrees_with_the_reference_screenshot(pa):
     agree = float((got == want)[visible].mean())
     print(f"numpy oracle vs reference screenshot: hue-class agreement {agree:.3f}")
     assert agree >= 0.91
+
+
+GIZMO_SCENE = """(
+    desc: (eng: "", rus: ""),
+    cam: (look_at: (%(x)r, %(y)r, %(z)r), alpha: %(alpha)r, beta: %(beta)r, r: %(r)r, offset_after_material: 0.005),
+    uniforms: ([]),
+    matrices: ([ (name: "id", data: Simple(offset: (0.0, 0.0, 0.0), scale: 1.0, rotate: (0.0, 0.0, 0.0), mirror: (false, false, false))) ]),
+    objects: ([ (name: "gizmo", data: DebugMatrix(Some(Named("id")))) ]),
+    cameras: ([]), textures: ([]), materials: ([]), intersection_materials: ([]), library: ([]),
+    animation_stages: ([]),
+)"""
+
+
+def test_editor_screenshot_gizmo_and_sky_colour(pa):
+    """img/interface.webp: the editor on an empty scene.  What the real program drew there is the gizmo of the identity matrix
+    (x red, y green, z blue capsules) on the sky colour, and the camera panel gives the view.  The same three axes come out at the
+    same pixels (intersection over union per colour at half size, lines ~4 px wide), which pins the axis convention and the
+    handedness of the camera; and the sky is the same VALUE -- not_found_color = color(0.6, 0.6, 0.6), gamma-2 encoded, is 153,
+    the capture has 152-155."""
+    from PIL import Image
+
+    from oracle import host_build as hb
+
+    meta = json.load(open(os.path.join(SHOTS, "interface_gizmo.json")))
+    shot = np.asarray(Image.open(os.path.join(SHOTS, "interface_gizmo.png")).convert("RGB"))
+    cam = meta["camera"]
+    text = GIZMO_SCENE % dict(x=cam["look_at"][0], y=cam["look_at"][1], z=cam["look_at"][2], alpha=math.radians(cam["alpha_deg"]),
+                              beta=math.radians(cam["beta_deg"]), r=cam["r"])
+    scene = pa.Scene.from_text(text)
+    r = pa.SceneRenderer(scene, device=-1)
+    r.set_option("aa_count", 2)
+    r.set_option("view_angle", math.radians(meta["view_angle_deg"]))
+    w, h = meta["render_size"]
+    frame = hb.host_kernel_for(r, scene, w, h).render(w, h, rgba32f=False)["rgba8"][:, :, :3]
+    x0, y0, x1, y1 = meta["box"]
+    mine = frame[y0:y1, x0:x1]
+    want, got = hue_classes(shot), hue_classes(mine)
+    assert float((want == got).mean()) >= 0.99
+    iou = {}
+    for k, name in ((1, "red"), (3, "green"), (4, "blue")):
+        a, b = want == k, got == k
+        assert a.sum() > 150 and b.sum() > 150, name  # each axis is there, in both
+        iou[name] = float((a & b).sum() / (a | b).sum())
+    print("gizmo axes, intersection over union with the capture:", iou)
+    assert min(iou.values()) >= 0.7
+    sky_want = np.median(shot[want == 0].reshape(-1, 3), axis=0)
+    sky_got = np.median(mine[got == 0].reshape(-1, 3), axis=0)
+    print("sky colour: capture", sky_want, "ours", sky_got)
+    assert np.all(np.abs(sky_want - sky_got) <= 3) and np.all(sky_got == 153)
