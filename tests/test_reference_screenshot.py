@@ -45,7 +45,7 @@ def render_view(pa, meta, size, alpha_offset_deg=0.0, panini=True):
     r.set_option("render_depth", 20)
     r.set_option("aa_count", 2)
     o = meta["options"]
-    if panini:
+    if panini and "use_panini_projection" in o:
         r.set_option("use_panini_projection", o["use_panini_projection"])
         r.set_option("panini_param", o["panini_param"])
     r.set_option("view_angle", math.radians(o["view_angle_deg"] if panini else 90.0))
@@ -157,3 +157,30 @@ def test_editor_screenshot_gizmo_and_sky_colour(pa):
     sky_got = np.median(mine[got == 0].reshape(-1, 3), axis=0)
     print("sky colour: capture", sky_want, "ours", sky_got)
     assert np.all(np.abs(sky_want - sky_got) <= 3) and np.all(sky_got == 153)
+
+
+def test_monoportal_screenshot_with_a_fitted_camera(pa):
+    """img/monoportal.webp shows the scene state (triangle at -0.5, 0, -1) but not the camera: alpha, beta and R were FITTED
+    (tests/golden/make_screenshot_fixture.py says how).  With those three numbers 94 % of the pixels outside the GUI land in the
+    capture's hue class -- portal ellipse, lettering, the triangle and its copy seen through the portal -- and moving any of the
+    three away from the fit loses agreement, i.e. the picture determines the camera and the renderer reproduces the picture."""
+    from PIL import Image
+
+    meta = json.load(open(os.path.join(SHOTS, "monoportal.json")))
+    assert meta["camera_fitted"]
+    shot = np.asarray(Image.open(os.path.join(SHOTS, "monoportal.png")).convert("RGB"))
+    size = (shot.shape[1], shot.shape[0])
+    visible = np.ones(shot.shape[:2], bool)
+    for x0, y0, x1, y1 in meta["covered"]:
+        visible[y0:y1, x0:x1] = False
+    want = hue_classes(shot)
+
+    def agreement(**cam):
+        m = dict(meta, camera=dict(meta["camera"], **cam))
+        return float((hue_classes(render_view(pa, m, size)) == want)[visible].mean())
+
+    fit = agreement()
+    away = {"alpha +8": agreement(alpha_deg=meta["camera"]["alpha_deg"] + 8), "beta -8": agreement(beta_deg=meta["camera"]["beta_deg"] - 8),
+            "r x1.3": agreement(r=meta["camera"]["r"] * 1.3)}
+    print(f"monoportal screenshot, fitted camera: agreement {fit:.3f}; away from the fit: {away}")
+    assert fit >= 0.93 and all(v < fit - 0.02 for v in away.values())
