@@ -87,3 +87,27 @@ if __name__ == "__main__":
     }
     json.dump(meta, open(os.path.join(OUT, "monoportal.json"), "w"), indent=1)
     print("wrote monoportal", size)
+
+    # img/mobius_monoportal.webp: the Moebius-band portal (a Complex object whose intersection is a numerical search written in the
+    # scene file), stage "Explore", no camera panel: alpha 88.5, beta 71.0 degrees, R 3.475 fitted the same way.
+    shot = Image.open("/root/reference/img/mobius_monoportal.webp").convert("RGB")
+    w, h = shot.size
+    crop = shot.crop((10, 44, w - 9, h - 10))
+    cw, ch = crop.size
+    size = (cw // 6, ch // 6)
+    crop.resize(size, Image.BOX).save(os.path.join(OUT, "mobius_monoportal.png"))
+    sx, sy = size[0] / cw, size[1] / ch
+    meta = {
+        "source": "img/mobius_monoportal.webp of the reference repository (README screenshot of the running program)",
+        "client_size": [cw, ch],
+        "scene": "mobius_monoportal",
+        "stage": "explore",
+        "uniforms": {},
+        "camera": {"look_at": [0.0, 0.0, 0.0], "alpha_deg": 88.5, "beta_deg": 71.0, "r": 3.475},
+        "camera_fitted": True,
+        "options": {"view_angle_deg": 90.0},
+        "covered": [[0, 0, size[0], int((80 - 44) * sy) + 2],
+                    [int((30 - 10) * sx), int((98 - 44) * sy), int((548 - 10) * sx) + 1, int((760 - 44) * sy) + 1]],
+    }
+    json.dump(meta, open(os.path.join(OUT, "mobius_monoportal.json"), "w"), indent=1)
+    print("wrote mobius_monoportal", size)
