@@ -181,7 +181,7 @@ def test_compile_error_is_reported_with_scene_element(gpu):
 ])
 def test_full_size_properties(gpu, scene_name, w, h, depth, aa):
     """The BASELINE configs at full size: no oracle run is affordable there, so check size-independent properties:
-    8 interleaved shards == whole frame, alpha == 255 everywhere, trip count within [samples, samples * depth], three
+    8 interleaved shards == whole frame (packed + de-interleave, and stored in place), alpha == 255 everywhere, trip count within [samples, samples * depth], three
     rows (top, middle, bottom) bit-equal to the host build, and the clip-constant / fully baked kernel == the dynamic one."""
     from oracle import host_build
 
@@ -197,6 +197,14 @@ def test_full_size_properties(gpu, scene_name, w, h, depth, aa):
     for phase in range(8):
         pa.deinterleave_rows(r.draw(w, h, rb_phase=phase, rb_stride=8)["rgba8"], pa.Frame(w, h, phase, 8), full)
     assert np.array_equal(full, whole["rgba8"])
+    import torch
+
+    placed = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")  # the peer-frame layout: 8 launches fill ONE buffer in place
+    for phase in range(8):
+        r.draw_device(pa.Frame(w, h, phase, 8, 1), out_rgba8=placed.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(placed.cpu().numpy(), whole["rgba8"])
+    del placed
     rows = [0, h // 2 - 1, h - 1]
     ref = host_build.host_kernel_for(r, scene, w, h).render(w, h, rows=rows)
     assert _bits_equal(whole["rgba32f"][rows], ref["rgba32f"]).all()
