@@ -145,8 +145,9 @@ def main():
     # PTL_BENCH_BACKEND=gloo is a rehearsal hook: the multi-rank control flow on a box with ONE GPU (all ranks share it, the
     # gather is staged through host memory).  The driver's runs use the default: one rank per GPU, RCCL.
     backend = os.environ.get("PTL_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()
+    # one rank per GPU: LOCAL_RANK is the device index when every rank sees the whole node (torchrun's default); when the launcher
+    # narrows visibility to one GPU per process, or the gloo rehearsal shares one GPU, the modulo picks what is there
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
