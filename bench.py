@@ -325,6 +325,21 @@ def main():
     except Exception as e:  # the headline number does not depend on it
         print(f"[bench] segment count unavailable: {e}", file=sys.stderr)
 
+    # untimed, N = 1 only: the same frame with NO JIT specialisation (every scene uniform read at run time), for the record
+    dynamic_ms = None
+    if world == 1 and args.specialize != 0:
+        try:
+            for waves in (0, 4):  # the two register budgets that matter for this kernel; keep the faster
+                plain = pa.SceneRenderer(scene, device=local_rank, flags=pa.flag_waves(waves))
+                configure(plain, args)
+                for _ in range(8):
+                    plain.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream)
+                ms = float(np.median([plain.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(16)]))
+                dynamic_ms = ms if dynamic_ms is None else min(dynamic_ms, ms)
+                del plain
+        except Exception as e:
+            print(f"[bench] dynamic-uniform timing unavailable: {e}", file=sys.stderr)
+
     if rank == 0:
         if args.save_png:
             pa.png_write(args.save_png, transport.download(last))
@@ -359,6 +374,8 @@ def main():
             },
             "kernel_ms": round(kernel_ms, 4),
         }
+        if dynamic_ms is not None:
+            out["kernel_ms_without_jit_specialisation"] = round(dynamic_ms, 4)
         hbm = {
             "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": profiled_traffic(args, best),
