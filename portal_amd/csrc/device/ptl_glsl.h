@@ -42,7 +42,11 @@ PTL_FN float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // "Correctly rounded" here is not an argument but a measurement: both are compared with the compiler's IEEE expansions for ALL
 // 2^32 bit patterns on the GPU (tests/test_gpu_parity.py::test_sqrt_and_reciprocal_are_exact_for_every_input, 6 ms).
 // PTL_PLAIN_SQRT_RCP restores the operators (tools/variants.py measures the difference).
-#if PTL_DEVICE_BUILD && !defined(PTL_PLAIN_SQRT_RCP)
+#if defined(PTL_PLAIN_SQRT_RCP)
+#define PTL_PLAIN_SQRT 1
+#define PTL_PLAIN_RCP 1
+#endif
+#if PTL_DEVICE_BUILD && !defined(PTL_PLAIN_SQRT)
 PTL_FN float sqrt(float x) {
     const bool tiny = x < 0x1p-96f;                // below, the residuals would underflow: work on x * 2^32, give back s * 2^-16
     const float xs = tiny ? x * 0x1p+32f : x;
@@ -54,6 +58,10 @@ PTL_FN float sqrt(float x) {
     s = r_above > 0.0f ? above : s;
     return tiny ? s * 0x1p-16f : s;
 }
+#else
+PTL_FN float sqrt(float x) { return __builtin_sqrtf(x); }
+#endif
+#if PTL_DEVICE_BUILD && !defined(PTL_PLAIN_RCP)
 PTL_FN float ptl_rcp(float x) {
     bool unused, rescale;
     const float d = __builtin_amdgcn_div_scalef(1.0f, x, false, &unused);  // x, or x * 2^+-64 when 1/x needs the room
@@ -64,7 +72,6 @@ PTL_FN float ptl_rcp(float x) {
     return __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(residual, r, q, rescale), x, 1.0f);
 }
 #else
-PTL_FN float sqrt(float x) { return __builtin_sqrtf(x); }
 PTL_FN float ptl_rcp(float x) { return 1.0f / x; }
 #endif
 PTL_FN float abs(float x) { return __builtin_fabsf(x); }

@@ -57,7 +57,17 @@ std::vector<std::string> compile_options(const char* const* defines, int n_defin
                                   "-std=c++20",
                                   "-ffp-contract=off",  // FMAs only where device/ptl_glsl.h spells them
                                   "-fhip-fp32-correctly-rounded-divide-sqrt",
-                                  "-fno-gpu-approx-transcendentals" /* no-op on older clang, harmless */};
+                                  "-fno-gpu-approx-transcendentals" /* no-op on older clang, harmless */,
+                                  // LLVM's default ("greedy") VGPR allocator MISCOMPILES divergent control flow now and then on this
+                                  // toolchain (ROCm 7.2): a value that is live across an exec-masked inner block gets its registers
+                                  // handed to temporaries of that block, so the lanes that skip the block's redefinition read garbage.
+                                  // Found by the GLSL fuzzer on gfx950 (tests/test_gpu_parity.py::test_greedy_regalloc_miscompile_stays_fixed:
+                                  // seed 105219, three pixels, reproduced down to a 3-branch kernel; host build and oracle agree with each
+                                  // other, every -O level, scheduler and machine-pass switch keeps the fault, `-vgpr-regalloc=basic` and
+                                  // `=fast` remove it).  The basic allocator does no live-range splitting; it costs 0-3 % of kernel time
+                                  // (profiles/r01/variants15_regalloc.jsonl), same frames.  PTL_VGPR_REGALLOC=greedy restores the default.
+                                  "-mllvm",
+                                  std::string("-vgpr-regalloc=") + (std::getenv("PTL_VGPR_REGALLOC") ? std::getenv("PTL_VGPR_REGALLOC") : "basic")};
     if (const char* extra = std::getenv("PTL_HIPRTC_FLAGS")) {
         std::string e = extra;
         size_t pos = 0;

@@ -972,3 +972,32 @@ def test_gpu_frame_agrees_with_the_reference_screenshot(gpu):
     agree = float((got == hue_classes(shot))[visible].mean())
     print(f"GPU frame vs reference screenshot: hue-class agreement {agree:.3f}")
     assert agree >= 0.92
+
+
+def test_greedy_regalloc_miscompile_stays_fixed(gpu, tmp_path, monkeypatch):
+    """GLSL fuzz seed 105219, found by tests/gpu_fuzz_hunt.py: with LLVM's default (greedy) VGPR allocator the kernel of this scene gives
+    three wrong pixels on gfx950 -- the registers of a value that is live across an exec-masked inner block are handed to that
+    block's temporaries (host build and oracle agree with each other; the fault survives every -O level, scheduler and machine-pass
+    switch and goes away with -vgpr-regalloc=basic / fast).  The JIT therefore builds with the basic allocator (kernel.cpp); this
+    keeps the reproducer in the suite and reports whether the toolchain still has the bug."""
+    from oracle.portal_oracle import Oracle
+    from tests.test_glsl_fuzz import N_EXPR, fuzz_scene
+
+    pa = gpu
+    text, _ = fuzz_scene(105219)
+    path = tmp_path / "fuzz.ron"
+    path.write_text(text)
+    w, h = 4 * N_EXPR, 12
+    o = Oracle(str(path))
+    o.options.update(render_depth=2, view_angle=1.5)
+    want = o.render(w, h)["rgba32f"]
+
+    def bad_pixels():
+        r = pa.SceneRenderer(pa.Scene.from_file(str(path)), device=0)
+        r.set_option("render_depth", 2)
+        r.set_option("view_angle", 1.5)
+        return int((~_bits_equal(r.draw(w, h, rgba32f=True)["rgba32f"], want).all(axis=2)).sum())
+
+    assert bad_pixels() == 0
+    monkeypatch.setenv("PTL_VGPR_REGALLOC", "greedy")
+    print(f"with LLVM's default allocator this toolchain gives {bad_pixels()} wrong pixels (3 on ROCm 7.2)")

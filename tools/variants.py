@@ -53,6 +53,10 @@ VARIANTS = {
     "all_Oz": "SPECIALIZE_ALL -Oz",
     "base_Os": "-Os",
     "base_O1_w3": "-O1 -DPTL_WAVES_PER_EU=3",
+    "all_rabasic": "SPECIALIZE_ALL -mllvm -vgpr-regalloc=basic",
+    "all_minreg_rabasic": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg -mllvm -vgpr-regalloc=basic",
+    "all_w4_rabasic": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -vgpr-regalloc=basic",
+    "base_rabasic": "-mllvm -vgpr-regalloc=basic",
     "all_plain": "SPECIALIZE_ALL -DPTL_PLAIN_SQRT_RCP",
     "base_plain": "-DPTL_PLAIN_SQRT_RCP",
     "all_minreg_plain": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg -DPTL_PLAIN_SQRT_RCP",
