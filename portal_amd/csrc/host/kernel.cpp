@@ -57,7 +57,7 @@ std::vector<std::string> compile_options(const char* const* defines, int n_defin
                                   "-std=c++20",
                                   "-ffp-contract=off",  // FMAs only where device/ptl_glsl.h spells them
                                   "-fhip-fp32-correctly-rounded-divide-sqrt",
-                                  "-fno-gpu-approx-transcendentals" /* no-op on older clang, harmless */,
+                                  "-fno-gpu-approx-transcendentals" /* no-op on older clang, harmless */
                                   // LLVM's default ("greedy") VGPR allocator MISCOMPILES divergent control flow now and then on this
                                   // toolchain (ROCm 7.2): a value that is live across an exec-masked inner block gets its registers
                                   // handed to temporaries of that block, so the lanes that skip the block's redefinition read garbage.
@@ -65,9 +65,15 @@ std::vector<std::string> compile_options(const char* const* defines, int n_defin
                                   // seed 105219, three pixels, reproduced down to a 3-branch kernel; host build and oracle agree with each
                                   // other, every -O level, scheduler and machine-pass switch keeps the fault, `-vgpr-regalloc=basic` and
                                   // `=fast` remove it).  The basic allocator does no live-range splitting; it costs 0-3 % of kernel time
-                                  // (profiles/r01/variants15_regalloc.jsonl), same frames.  PTL_VGPR_REGALLOC=greedy restores the default.
-                                  "-mllvm",
-                                  std::string("-vgpr-regalloc=") + (std::getenv("PTL_VGPR_REGALLOC") ? std::getenv("PTL_VGPR_REGALLOC") : "basic")};
+                                  // (profiles/r01/variants15_regalloc.jsonl), same frames.  PTL_VGPR_REGALLOC=default leaves the choice to the toolchain again.
+                                  };
+    {
+        const char* ra = std::getenv("PTL_VGPR_REGALLOC");  // "default": say nothing, i.e. the toolchain's own choice (the faulty one)
+        if (!ra || std::string(ra) != "default") {
+            o.push_back("-mllvm");
+            o.push_back(std::string("-vgpr-regalloc=") + (ra ? ra : "basic"));
+        }
+    }
     if (const char* extra = std::getenv("PTL_HIPRTC_FLAGS")) {
         std::string e = extra;
         size_t pos = 0;
