@@ -167,7 +167,17 @@ def main():
     spec_flags = {0: 0, 1: pa.FLAG_SPECIALIZE_INTS, 2: pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL}[args.specialize]
 
     def make_renderer(waves, extra_flags=""):
-        # PTL_HIPRTC_FLAGS is read when the kernel is compiled (and is part of the code-object cache key)
+        # PTL_HIPRTC_FLAGS is read when the kernel is compiled (and is part of the code-object cache key).  LLVM's -mllvm options are
+        # process-wide and STICKY (a later compile that does not mention one keeps the earlier value), so a build with extra backend
+        # options is compiled in a child process into the code-object cache first; this process then only loads it.
+        if extra_flags:
+            import subprocess
+
+            child = ("import sys; sys.path.insert(0, sys.argv[1]); import portal_amd as pa; "
+                     "pa.SceneRenderer(pa.Scene.from_file(sys.argv[2]), device=-1, flags=int(sys.argv[3]))")
+            subprocess.run([sys.executable, "-c", child, HERE, pa.scene_path(args.scene), str(spec_flags | pa.flag_waves(waves))],
+                           env=dict(os.environ, PTL_HIPRTC_FLAGS=((os.environ.get("PTL_HIPRTC_FLAGS", "") + " ") if os.environ.get("PTL_HIPRTC_FLAGS") else "") + extra_flags),
+                           capture_output=True, timeout=600)
         saved = os.environ.get("PTL_HIPRTC_FLAGS")
         os.environ["PTL_HIPRTC_FLAGS"] = ((saved + " ") if saved else "") + extra_flags
         try:
