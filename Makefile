@@ -33,7 +33,7 @@ $(CLI): $(HOST)/cli.cpp $(LIB) include/portal_amd.h
 kernels: $(KERNELS)
 portal_amd/kernels/%.hsaco: portal_amd/csrc/kernels/%.hip
 	@mkdir -p portal_amd/kernels
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 --genco --no-gpu-bundle-output $< -o $@
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -mllvm -vgpr-regalloc=basic --genco --no-gpu-bundle-output $< -o $@  # allocator: see kernel.cpp
 
 clean:
 	rm -rf build $(LIB) $(CLI) portal_amd/kernels $(HOST)/embedded_device_sources.inc
