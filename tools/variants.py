@@ -53,6 +53,8 @@ VARIANTS = {
     "all_Oz": "SPECIALIZE_ALL -Oz",
     "base_Os": "-Os",
     "base_O1_w3": "-O1 -DPTL_WAVES_PER_EU=3",
+    "all_ra_default": "SPECIALIZE_ALL RA_DEFAULT",   # the toolchain's own (greedy) allocator: faster by 0-3 %, but it miscompiles
+    "base_ra_default": "RA_DEFAULT",
     "all_rabasic": "SPECIALIZE_ALL -mllvm -vgpr-regalloc=basic",
     "all_minreg_rabasic": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg -mllvm -vgpr-regalloc=basic",
     "all_w4_rabasic": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -vgpr-regalloc=basic",
@@ -78,6 +80,20 @@ def run_one(case, vname, flags):
     w, h, d, aa = int(w), int(h), int(d), int(aa)
     toks = flags.split()
     rflags = (pa.FLAG_SPECIALIZE_INTS if "SPECIALIZE" in toks else 0) | (pa.FLAG_SPECIALIZE_ALL if "SPECIALIZE_ALL" in toks else 0)
+    # the VGPR allocator is an option the JIT always passes (kernel.cpp): select it through its own switch, not a second -mllvm
+    ra = [t.split("=", 1)[1] for t in toks if t.startswith("-vgpr-regalloc=")]
+    if "RA_DEFAULT" in toks:
+        ra = ["default"]
+    if ra:
+        os.environ["PTL_VGPR_REGALLOC"] = ra[-1]
+        keep, skip = [], False
+        for i, t in enumerate(toks):
+            if t == "-mllvm" and i + 1 < len(toks) and toks[i + 1].startswith("-vgpr-regalloc="):
+                continue
+            if t.startswith("-vgpr-regalloc="):
+                continue
+            keep.append(t)
+        toks = keep
     os.environ["PTL_HIPRTC_FLAGS"] = " ".join(t for t in toks if t.startswith("-"))
     for t in toks:
         if t.startswith("BLOCK_WAVES="):
