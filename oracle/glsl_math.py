@@ -32,8 +32,27 @@ F64 = np.float64
 # ---------------------------------------------------------------------------------------
 # operation counter
 # ---------------------------------------------------------------------------------------
-STATS = {"flops": 0.0, "div": 0.0, "sqrt": 0.0, "fma": 0.0}
+STATS = {"flops": 0.0, "div": 0.0, "sqrt": 0.0, "fma": 0.0,
+         # the same, restricted to operations with at least one lane-varying (per-ray) operand: what a kernel with every
+         # scene uniform baked in (FLAG_SPECIALIZE_ALL) still has to execute -- uniform-only subexpressions fold at JIT time
+         "flops_varying": 0.0, "div_varying": 0.0, "sqrt_varying": 0.0, "fma_varying": 0.0}
 _active = 1.0
+
+
+COUNT_VARYING = False  # tools/count_flops.py switches it on; the per-operand test below costs about as much as the arithmetic
+
+
+def _lane_varying(x) -> bool:
+    """True when the operand differs between lanes.  Decided by VALUE, not by shape: the interpreter broadcasts uniforms to
+    lane arrays when it stores them in variables, so a lane-shaped operand whose elements are all the same bit pattern is
+    (with random pixels) a ray-independent quantity -- the kind a kernel with baked uniforms folds at compile time."""
+    a = np.asarray(x)
+    if a.ndim == 0 or a.size <= 1:
+        return False
+    flat = np.ascontiguousarray(a).reshape(-1)
+    if flat.dtype == F32:
+        flat = flat.view(np.uint32)
+    return bool((flat != flat[0]).any())
 
 
 def set_active(n: float) -> None:
@@ -46,10 +65,18 @@ def reset_stats() -> None:
         STATS[k] = 0.0
 
 
-def _count(n: float, kind: str | None = None) -> None:
+def _count(n: float, kind: str | None = None, operands=()) -> None:
     STATS["flops"] += n * _active
     if kind:
         STATS[kind] += _active
+    if not COUNT_VARYING:
+        return
+    for x in operands:
+        if _lane_varying(x):
+            STATS["flops_varying"] += n * _active
+            if kind:
+                STATS[kind + "_varying"] += _active
+            break
 
 
 # ---------------------------------------------------------------------------------------
@@ -82,25 +109,25 @@ _err = dict(over="ignore", invalid="ignore", divide="ignore", under="ignore")
 
 
 def add(a, b):
-    _count(1)
+    _count(1, None, (a, b,))
     with np.errstate(**_err):
         return np.add(a, b, dtype=F32)
 
 
 def sub(a, b):
-    _count(1)
+    _count(1, None, (a, b,))
     with np.errstate(**_err):
         return np.subtract(a, b, dtype=F32)
 
 
 def mul(a, b):
-    _count(1)
+    _count(1, None, (a, b,))
     with np.errstate(**_err):
         return np.multiply(a, b, dtype=F32)
 
 
 def div(a, b):
-    _count(1, "div")
+    _count(1, "div", (a, b,))
     with np.errstate(**_err):
         return np.divide(a, b, dtype=F32)
 
@@ -110,39 +137,39 @@ def neg(a):
 
 
 def sqrt(a):
-    _count(1, "sqrt")
+    _count(1, "sqrt", (a,))
     with np.errstate(**_err):
         return np.sqrt(f32(a))
 
 
 def absf(a):
-    _count(1)
+    _count(1, None, (a,))
     return np.abs(f32(a))
 
 
 def floor(a):
-    _count(1)
+    _count(1, None, (a,))
     return np.floor(f32(a))
 
 
 def ceil(a):
-    _count(1)
+    _count(1, None, (a,))
     return np.ceil(f32(a))
 
 
 def trunc(a):
-    _count(1)
+    _count(1, None, (a,))
     return np.trunc(f32(a))
 
 
 def rint(a):
-    _count(1)
+    _count(1, None, (a,))
     return np.rint(f32(a))
 
 
 def fma(a, b, c):
     """round_binary32(a*b + c) with a single rounding."""
-    _count(2, "fma")
+    _count(2, "fma", (a, b, c,))
     a64, b64, c64 = np.asarray(a, F32).astype(F64), np.asarray(b, F32).astype(F64), np.asarray(c, F32).astype(F64)
     with np.errstate(**_err):
         p = a64 * b64                     # exact
@@ -163,32 +190,32 @@ def fma(a, b, c):
 
 
 def lt(a, b):
-    _count(1)
+    _count(1, None, (a, b,))
     return np.less(a, b)
 
 
 def gt(a, b):
-    _count(1)
+    _count(1, None, (a, b,))
     return np.greater(a, b)
 
 
 def le(a, b):
-    _count(1)
+    _count(1, None, (a, b,))
     return np.less_equal(a, b)
 
 
 def ge(a, b):
-    _count(1)
+    _count(1, None, (a, b,))
     return np.greater_equal(a, b)
 
 
 def eq(a, b):
-    _count(1)
+    _count(1, None, (a, b,))
     return np.equal(a, b)
 
 
 def ne(a, b):
-    _count(1)
+    _count(1, None, (a, b,))
     return np.not_equal(a, b)
 
 
@@ -198,12 +225,12 @@ def select(c, a, b):
 
 # --- GLSL scalar builtins (contract: ptl_glsl.h "scalar primitives") -----------------------
 def fmin(a, b):  # min(a,b) = b < a ? b : a
-    _count(1)
+    _count(1, None, (a, b,))
     return np.where(np.less(b, a), f32(b), f32(a)).astype(F32)
 
 
 def fmax(a, b):  # max(a,b) = a < b ? b : a
-    _count(1)
+    _count(1, None, (a, b,))
     return np.where(np.less(a, b), f32(b), f32(a)).astype(F32)
 
 
@@ -221,12 +248,12 @@ def mod(x, y):
 
 def sign(x):
     x = f32(x)
-    _count(2)
+    _count(2, None, (x,))
     return np.where(x > 0, F32(1), np.where(x < 0, F32(-1), F32(0))).astype(F32)
 
 
 def step(edge, x):
-    _count(1)
+    _count(1, None, (edge, x,))
     return np.where(np.less(x, edge), F32(0), F32(1)).astype(F32)
 
 

@@ -702,6 +702,7 @@ extern "C" int ptl_renderer_use_camera(ptl_renderer* r, const char* camera) {
 extern "C" int ptl_renderer_uniform_value(ptl_renderer* r, int width, int height, const char* name, float out16[16], int* n_values) {
     if (!r || !name || !out16) return PTL_ERR_INVALID;
     return guarded([&] {
+        send_camera_matrix(r);  // Matrix::Camera uniforms: the value a draw would upload (prepare_draw does the same)
         auto all = builtin_uniforms(*r, width, height);
         auto scene_vals = evaluate_scene_uniforms(*r->scene, nullptr);
         all.insert(all.end(), scene_vals.begin(), scene_vals.end());
