@@ -189,7 +189,14 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * bit3 = clip-constant specialisation: bake every scene uniform whose evaluation reads no per-frame input (time,
  * total_time, the camera matrix) -- what stays fixed while a clip plays; a renderer checks the compiled-in values before
  * every draw and rebuilds (demoting what moved) if one no longer holds, so results never depend on the guess,
- * bit4 = compile the anaglyph stereo mode in (the reference's `disable_anaglyph = false`, src/main.rs:939).
+ * bit4 = compile the anaglyph stereo mode in (the reference's `disable_anaglyph = false`, src/main.rs:939),
+ * bit5 = NO derived uniforms: by default the ray-independent half of every generated plane test whose matrix is a run-time
+ * uniform (normalize(get_normal(X_mat)), both possible is_collinear verdicts) is evaluated once per uniform upload by the
+ * module's prologue kernel `ptl_derive_kernel` and read back as extra uniforms -- same operations, identical frames;
+ * this bit keeps the reference's per-call form (A/B measurements, tests),
+ * bit6 = FAST MATH, the tolerance mode (`--fast`): hardware rcp / sqrt / rsq estimates (1 ulp), a / b = a * rcp(b), FMA
+ * contraction.  Frames agree with the exact kernel to ~1e-6 per channel except at pixels where the last bit decides a path
+ * (object edges); the exact kernel stays the default and the parity reference.
  * ptl_renderer_create additionally reads bits 8-11 as an occupancy hint n (0 = none):
  * the kernel is built with __launch_bounds__(256, n), i.e. at least n waves per SIMD. */
 int ptl_scene_generate_source(ptl_scene* s, unsigned flags, char** source);
@@ -296,6 +303,32 @@ int ptl_device_download_async(void* host_dst, const void* device_src, size_t byt
 int ptl_ipc_export(void* device_ptr, unsigned char handle[PTL_IPC_HANDLE_BYTES]);
 int ptl_ipc_open(int device, const unsigned char handle[PTL_IPC_HANDLE_BYTES], void** device_ptr);
 int ptl_ipc_close(void* device_ptr);
+/* ---- layer 3: ONE frame across the GPUs of one node from ONE host process -------------------------------
+ * The draw it shards is SceneRenderer::draw_texture (src/main.rs:1411-1428): rank g of n renders the 8-row blocks b with
+ * b % n == g, with its own renderer (same scene, same flags) on devices[g]; the frame is assembled in devices[0]'s memory by
+ *   PTL_GROUP_PEER_STORES  the kernels' own row stores over xGMI (peer access, ptl_frame.in_place = 1): no staging, no gather;
+ *   PTL_GROUP_COPY_GATHER  a packed shard per rank + ONE strided peer copy per rank (hipMemcpy2DAsync) that gathers and
+ *                          de-interleaves in the same transfer -- what an RCCL gather to one root decomposes into.
+ * No torch, no RCCL, no second process: a Rust host binds exactly these.  One thread drives all ranks;
+ * the handle is not thread-safe.  A device may be listed more than once (rehearsal on a one-GPU machine).
+ * Options / camera / update are forwarded to every rank's renderer (ptl_frame_group_renderer gives the individual ones;
+ * keep them in step).  ptl_frame_group_draw returns after every rank has finished; *device_rgba8 is the width x height
+ * RGBA8 frame on devices[0] (owned by the group, valid until the next draw with another size or destroy);
+ * kernel_ms (n floats, may be NULL) receives each rank's trace-kernel time. */
+typedef struct ptl_frame_group ptl_frame_group;
+enum { PTL_GROUP_PEER_STORES = 0, PTL_GROUP_COPY_GATHER = 1 };
+int ptl_frame_group_create(ptl_scene* s, const int* devices, int n_devices, const char* asset_root, unsigned flags, int transport,
+                           ptl_frame_group** out, char* log, size_t log_cap);
+int ptl_frame_group_size(const ptl_frame_group* g);
+ptl_renderer* ptl_frame_group_renderer(ptl_frame_group* g, int rank);
+int ptl_frame_group_set_option(ptl_frame_group* g, const char* name, double value);
+int ptl_frame_group_use_camera(ptl_frame_group* g, const char* camera);
+int ptl_frame_group_set_camera(ptl_frame_group* g, const double look_at[3], double alpha, double beta, double radius);
+int ptl_frame_group_update(ptl_frame_group* g, double seconds);
+int ptl_frame_group_draw(ptl_frame_group* g, int width, int height, void** device_rgba8, float* kernel_ms);
+int ptl_frame_group_download(ptl_frame_group* g, uint8_t* host_rgba8);
+void ptl_frame_group_destroy(ptl_frame_group* g);
+
 /* Page-locked host memory for those downloads (PCIe-rate copies; pageable memory works too, several times slower). */
 int ptl_host_alloc(size_t bytes, void** out);
 int ptl_host_free(void* p);

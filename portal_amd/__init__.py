@@ -52,6 +52,8 @@ FLAG_COUNT_SEGMENTS = 2
 FLAG_SPECIALIZE_ALL = 4
 FLAG_SPECIALIZE_STATIC = 8  # bake what stays constant while a clip plays (checked before every draw, rebuilt if it moved)
 FLAG_ANAGLYPH = 16  # compile the anaglyph stereo mode in (the reference's `disable_anaglyph = false`)
+FLAG_NO_DERIVED_UNIFORMS = 32  # keep the per-call plane tests (default: ray-independent halves evaluated by the prologue kernel)
+FLAG_FAST_MATH = 64  # tolerance mode: hardware rcp / sqrt estimates, FMA contraction (not bit-exact; exact stays the default)
 
 
 def flag_waves(n: int) -> int:
@@ -146,6 +148,16 @@ def _load() -> C.CDLL:
         "ptl_ipc_export": (ci, [vp, cp]),
         "ptl_ipc_open": (ci, [ci, cp, P(vp)]),
         "ptl_ipc_close": (ci, [vp]),
+        "ptl_frame_group_create": (ci, [vp, P(ci), ci, cp, C.c_uint, ci, P(vp), cp, cs]),
+        "ptl_frame_group_size": (ci, [vp]),
+        "ptl_frame_group_renderer": (vp, [vp, ci]),
+        "ptl_frame_group_set_option": (ci, [vp, cp, cd]),
+        "ptl_frame_group_use_camera": (ci, [vp, cp]),
+        "ptl_frame_group_set_camera": (ci, [vp, P(cd), cd, cd, cd]),
+        "ptl_frame_group_update": (ci, [vp, cd]),
+        "ptl_frame_group_draw": (ci, [vp, ci, ci, P(vp), P(C.c_float)]),
+        "ptl_frame_group_download": (ci, [vp, vp]),
+        "ptl_frame_group_destroy": (None, [vp]),
         "ptl_host_alloc": (ci, [cs, P(vp)]),
         "ptl_host_free": (ci, [vp]),
         "ptl_ron_format": (vp, [cp]),
@@ -496,6 +508,52 @@ class SceneRenderer:
                                              C.byref(seg) if segments else None, C.byref(ms))
         _check(rc, "draw_texture")
         return {"rgba8": a8, "rgba32f": a32, "segments": seg.value if segments else None, "ms": ms.value}
+
+
+GROUP_PEER_STORES, GROUP_COPY_GATHER = 0, 1
+
+
+class FrameGroup:
+    """Layer 3: one frame across several GPUs from one process (include/portal_amd.h, csrc/host/multigpu.cpp).
+    `devices` may name a device more than once (rehearsal of the N-rank control flow on one GPU)."""
+
+    def __init__(self, scene: Scene, devices, asset_root: Optional[str] = None, flags: int = 0, transport: int = GROUP_PEER_STORES):
+        self.scene = scene
+        self.devices = list(devices)
+        h = C.c_void_p()
+        log = C.create_string_buffer(1 << 16)
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        rc = lib().ptl_frame_group_create(scene._h, arr, len(self.devices), (asset_root or REPO_ROOT).encode(), flags, transport, C.byref(h), log, len(log))
+        if rc != 0:
+            raise PortalError(f"ptl_frame_group_create failed ({rc}): {_err()}\n{log.value.decode(errors='replace')}")
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().ptl_frame_group_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_option(self, name: str, value: float) -> None:
+        _check(lib().ptl_frame_group_set_option(self._h, name.encode(), float(value)), "ptl_frame_group_set_option")
+
+    def set_camera(self, look_at, alpha: float, beta: float, r: float) -> None:
+        la = (C.c_double * 3)(*look_at)
+        _check(lib().ptl_frame_group_set_camera(self._h, la, alpha, beta, r), "ptl_frame_group_set_camera")
+
+    def update(self, seconds: float) -> None:
+        _check(lib().ptl_frame_group_update(self._h, float(seconds)), "ptl_frame_group_update")
+
+    def draw(self, width: int, height: int) -> dict:
+        """Returns dict(rgba8 (H, W, 4) uint8, kernel_ms per rank, device_ptr of the frame on devices[0])."""
+        ptr = C.c_void_p()
+        ms = (C.c_float * len(self.devices))()
+        _check(lib().ptl_frame_group_draw(self._h, width, height, C.byref(ptr), ms), "ptl_frame_group_draw")
+        img = np.empty((height, width, 4), np.uint8)
+        _check(lib().ptl_frame_group_download(self._h, img.ctypes.data_as(C.c_void_p)), "ptl_frame_group_download")
+        return {"rgba8": img, "kernel_ms": [float(x) for x in ms], "device_ptr": ptr.value}
 
 
 class Kernel:

@@ -10,6 +10,10 @@
 // the compiler's structurizer produces exactly that).  Row blocks (8 rows) are the
 // sharding unit: a launch renders blocks phase, phase+stride, ... so N GPUs interleave.
 
+#if defined(PTL_NO_TELEPORT_ENTRY) && !defined(PTL_NO_DERIVE_ENTRY)
+#define PTL_NO_DERIVE_ENTRY  // a hand-written kernel without a scene has neither a teleport query nor derived uniforms
+#endif
+
 #if PTL_DEVICE_BUILD
 
 #ifdef PTL_WAVES_PER_EU
@@ -116,6 +120,26 @@ extern "C" __global__ void __launch_bounds__(64) ptl_teleport_kernel(float* __re
 }
 #endif
 
+// Prologue: evaluates the derived uniforms (ptl_tracer::derive) into the tail of the uniform block.  The host launches it on
+// the render stream after every upload of the block; `block` is the address of ptl_u (a __constant__ object cannot be
+// written through its own name).  One thread: a few dozen planes, ~100 instructions each.
+#ifndef PTL_NO_DERIVE_ENTRY
+extern "C" __global__ void __launch_bounds__(64) ptl_derive_kernel(glsl::ptl_uniform_block* block) {
+#ifdef PTL_UNIFORMS_IN_LDS
+    {
+        const unsigned int* src = reinterpret_cast<const unsigned int*>(&glsl::ptl_u);
+        unsigned int* dst = reinterpret_cast<unsigned int*>(&glsl::ptl_lds_u);
+        for (int i = (int)threadIdx.x; i < (int)(sizeof(glsl::ptl_uniform_block) / 4); i += 64) dst[i] = src[i];
+        __syncthreads();
+    }
+#endif
+#ifdef PTL_COUNT_SEGMENTS
+    ptl_segments_lds[threadIdx.x] = 0u;
+#endif
+    if (threadIdx.x == 0 && blockIdx.x == 0) glsl::derive_uniforms(block);
+}
+#endif
+
 #else  // host build of the same source (oracle/host_build): rows [row_begin, row_end) of the frame
 
 #include <cstdint>
@@ -127,7 +151,12 @@ extern "C" void* ptl_host_uniform_block(unsigned long* size) {
 }
 
 #ifndef PTL_NO_TELEPORT_ENTRY
-extern "C" void ptl_host_teleport(float* out6) { glsl::teleport_external_ray_entry(out6); }
+extern "C" void ptl_host_teleport(float* out6) {
+#ifndef PTL_NO_DERIVE_ENTRY
+    glsl::derive_uniforms(&glsl::ptl_u);
+#endif
+    glsl::teleport_external_ray_entry(out6);
+}
 #else
 extern "C" void ptl_host_teleport(float*) {}
 #endif
@@ -141,6 +170,9 @@ extern "C" unsigned long long ptl_host_render(uint8_t* out_rgba8, float* out_rgb
     (void)width;
     (void)height;
     (void)threads;
+#ifndef PTL_NO_DERIVE_ENTRY
+    glsl::derive_uniforms(&glsl::ptl_u);  // the prologue the device build runs as ptl_derive_kernel
+#endif
     const int cols = col_end - col_begin;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : segments)
     for (int i = 0; i < n_rows; ++i) {

@@ -46,7 +46,17 @@ PTL_FN float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 #define PTL_PLAIN_SQRT 1
 #define PTL_PLAIN_RCP 1
 #endif
-#if PTL_DEVICE_BUILD && !defined(PTL_PLAIN_SQRT)
+// PTL_FAST_MATH (FLAG_FAST_MATH, `--fast`): the TOLERANCE mode.  What a GL driver does with the reference's shader: the
+// hardware estimates themselves (v_sqrt_f32 / v_rcp_f32 / v_rsq_f32, 1 ulp), a / b = a * rcp(b) and FMA contraction (the JIT
+// passes -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt).  Not part of the bit-exact contract: frames differ
+// from the exact kernel in the last bits, and a pixel on an edge can take another path (tests measure how many, vs 1e-5).
+#if PTL_DEVICE_BUILD && defined(PTL_FAST_MATH)
+PTL_FN float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+PTL_FN float ptl_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#define PTL_HAVE_SQRT_RCP 1
+#endif
+#if defined(PTL_HAVE_SQRT_RCP)
+#elif PTL_DEVICE_BUILD && !defined(PTL_PLAIN_SQRT)
 PTL_FN float sqrt(float x) {
     const bool tiny = x < 0x1p-96f;                // below, the residuals would underflow: work on x * 2^32, give back s * 2^-16
     const float xs = tiny ? x * 0x1p+32f : x;
@@ -61,7 +71,8 @@ PTL_FN float sqrt(float x) {
 #else
 PTL_FN float sqrt(float x) { return __builtin_sqrtf(x); }
 #endif
-#if PTL_DEVICE_BUILD && !defined(PTL_PLAIN_RCP)
+#if defined(PTL_HAVE_SQRT_RCP)
+#elif PTL_DEVICE_BUILD && !defined(PTL_PLAIN_RCP)
 PTL_FN float ptl_rcp(float x) {
     bool unused, rescale;
     const float d = __builtin_amdgcn_div_scalef(1.0f, x, false, &unused);  // x, or x * 2^+-64 when 1/x needs the room
@@ -81,7 +92,11 @@ PTL_FN float ceil(float x) { return __builtin_ceilf(x); }
 PTL_FN float trunc(float x) { return __builtin_truncf(x); }
 PTL_FN float roundEven(float x) { return __builtin_rintf(x); }
 PTL_FN float round(float x) { return __builtin_rintf(x); }
+#if PTL_DEVICE_BUILD && defined(PTL_FAST_MATH)
+PTL_FN float inversesqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
 PTL_FN float inversesqrt(float x) { return ptl_rcp(sqrt(x)); }
+#endif
 PTL_FN float fract(float x) { return x - floor(x); }
 PTL_FN float mod(float x, float y) { return x - y * floor(x / y); }
 PTL_FN float min(float a, float b) { return b < a ? b : a; }

@@ -115,6 +115,22 @@ PTL_FN SurfaceIntersection plane_intersect(Ray r, const mat4& plane_inv, vec3 no
     return result;
 }
 
+// plane_intersect with the ray-independent half done beforehand: `unit_normal` = normalize(normal) comes from the
+// prologue kernel (ptl_tracer::derive); `flipped` tells the caller which of the two precomputed is_collinear verdicts applies.
+PTL_FN SurfaceIntersection plane_intersect_derived(Ray r, const mat4& plane_inv, vec3 unit_normal, bool& flipped) {
+    flipped = dot(unit_normal, r.d.sw<0, 1, 2>()) > 0.0f;
+    if (flipped) unit_normal *= -1.0f;
+    r = transform(plane_inv, r);
+    float len = length(r.d);
+    r.d = normalize(r.d);
+    SurfaceIntersection result = plane_intersect_normalized(r);
+    if (result.hit) {
+        result.t /= len;
+        result.n = unit_normal;
+    }
+    return result;
+}
+
 // --- colours ------------------------------------------------------- library.glsl:169-288
 PTL_FN vec3 color(float r, float g, float b) { return vec3(r * r, g * g, b * b); }
 

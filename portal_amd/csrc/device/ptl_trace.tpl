@@ -82,11 +82,21 @@ PTL_FN SceneIntersection scene_intersect(const Ray& r) {
     int inside = NOT_INSIDE;
     float len = 1.0f;
     Ray transformed_ray = ray_none;
-    (void)ihit; (void)hit; (void)normal; (void)inside; (void)len; (void)transformed_ray;
+    bool flipped = false;  // plane tests with a derived entry: the unit normal was turned to face the ray
+    (void)ihit; (void)hit; (void)normal; (void)inside; (void)len; (void)transformed_ray; (void)flipped;
 
 //%intersections//%
 
     return i;
+}
+
+// Prologue (ptl_derive_kernel, once per uniform upload): the ray-independent part of the plane tests above whose matrices
+// are run-time uniforms -- the unit normal plane_intersect would normalise on every call and the two verdicts
+// is_collinear(hit.n, normal) can have (hit.n is that unit normal or its negation).  Same functions, same operations as the
+// plain form, evaluated once per frame instead of once per trip and lane; the results land behind the uploaded uniforms.
+PTL_FN void derive(ptl_uniform_block* out) {
+    (void)out;
+//%derive//%
 }
 
 // Material id -> what happens to the path. (reference shell: src/frag.glsl:33-50)
@@ -149,52 +159,77 @@ PTL_FN vec3 sample_depth_gradient(float depth) {  // frag.glsl:101-104
     return depth_gradient_inferno(1.0f - normalize_depth_value(depth));
 }
 
+// One pass of the bounce loop for one ray: nearest hit, material, advance.  Returns true when the path has ended (`out` is
+// its result), false when `r` / `current_color` / `all_t` have been advanced to the next segment.  (frag.glsl:113-156)
+PTL_FN bool trace_segment(Ray& r, vec3& current_color, float& all_t, float camera_scale, const vec3& not_found_color, RayTraceResult& out) {
+    SceneIntersection i = scene_intersect(r);
+    SceneIntersectionWithMaterial i2 = scene_intersect_material_process(r);
+
+    // `m` is left unset by the reference when a snippet reports hit with t <= 0 (GLSL:
+    // undefined value); this build defines that case as the all-zero MaterialProcessing.
+    MaterialProcessing m = MaterialProcessing{false, vec3(0.0f), ray_none};
+    if (nearer(i.hit, i2.scene.hit)) {
+        r.o += r.d * i2.scene.hit.t;
+        all_t += i2.scene.hit.t * r.tmul;
+        if (i2.scene.material == CUSTOM_MATERIAL) {
+            m = i2.material;
+        } else {
+            m = material_process(r, i2.scene);
+        }
+    } else if (i.hit.hit) {
+        r.o += r.d * i.hit.t;
+        all_t += i.hit.t * r.tmul;
+        m = material_process(r, i);
+    }
+
+    if (!(i.hit.hit || i2.scene.hit.hit)) {  // escaped the scene
+        out = r.in_subspace ? RayTraceResult{color(0.0f, 0.0f, 0.0f), 0.0f, false} : RayTraceResult{current_color * not_found_color, 0.0f, false};
+        return true;
+    }
+    current_color *= m.mul_to_color;
+    if (m.is_final) {
+        float depth = all_t / max(camera_scale, 1e-6f);
+        if (all_t > _t_start * camera_scale && _darken_by_distance == 1) {  // fade to black with distance
+            if (all_t > _t_end * camera_scale) all_t = _t_end * camera_scale;
+            float gray_t = (all_t - _t_start * camera_scale) / (_t_end - _t_start) / camera_scale;
+            out = RayTraceResult{color(0.0f, 0.0f, 0.0f) * sqr(sqr(gray_t)) + current_color * sqr(sqr(1.0f - gray_t)), depth, true};
+            return true;
+        }
+        out = RayTraceResult{current_color, depth, true};
+        return true;
+    }
+    r = m.new_ray;
+    return false;
+}
+
+// The bounce loop.  A wavefront owns an 8x8 pixel tile (ptl_entry.h); its 64 rays take different numbers of trips.  On the
+// device the loop is written for the wave: a lane whose path has ended drops out of `alive`, and the whole wave leaves as
+// soon as a ballot over `alive` comes back empty -- one scalar compare per trip, no lane ever waits for a loop counter it
+// no longer needs.  (-DPTL_NO_WAVE_LOOP: the per-lane form with returns, which the compiler turns into the same shape.)
 PTL_FN RayTraceResult ray_tracing(Ray r, float camera_scale) {
     //%skybox_processing//%
 
     vec3 current_color = vec3(1.0f);
     float all_t = 0.0f;
+    RayTraceResult result = RayTraceResult{color(0.0f, 0.0f, 0.0f), 0.0f, false};  // depth exhausted
+#if PTL_DEVICE_BUILD && !defined(PTL_NO_WAVE_LOOP)
+    bool alive = true;
+    for (int j = 0; j < _ray_tracing_depth; j++) {
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;  // every ray of the tile has terminated
+        PTL_RELAUNDER();
+        if (alive) {
+            PTL_COUNT_SEGMENT();
+            alive = !trace_segment(r, current_color, all_t, camera_scale, not_found_color, result);
+        }
+    }
+#else
     for (int j = 0; j < _ray_tracing_depth; j++) {
         PTL_RELAUNDER();
         PTL_COUNT_SEGMENT();
-        SceneIntersection i = scene_intersect(r);
-        SceneIntersectionWithMaterial i2 = scene_intersect_material_process(r);
-
-        // `m` is left unset by the reference when a snippet reports hit with t <= 0 (GLSL:
-        // undefined value); this build defines that case as the all-zero MaterialProcessing.
-        MaterialProcessing m = MaterialProcessing{false, vec3(0.0f), ray_none};
-        if (nearer(i.hit, i2.scene.hit)) {
-            r.o += r.d * i2.scene.hit.t;
-            all_t += i2.scene.hit.t * r.tmul;
-            if (i2.scene.material == CUSTOM_MATERIAL) {
-                m = i2.material;
-            } else {
-                m = material_process(r, i2.scene);
-            }
-        } else if (i.hit.hit) {
-            r.o += r.d * i.hit.t;
-            all_t += i.hit.t * r.tmul;
-            m = material_process(r, i);
-        }
-
-        if (!(i.hit.hit || i2.scene.hit.hit)) {  // escaped the scene
-            if (r.in_subspace) return RayTraceResult{color(0.0f, 0.0f, 0.0f), 0.0f, false};
-            return RayTraceResult{current_color * not_found_color, 0.0f, false};
-        }
-        current_color *= m.mul_to_color;
-        if (m.is_final) {
-            float depth = all_t / max(camera_scale, 1e-6f);
-            if (all_t > _t_start * camera_scale && _darken_by_distance == 1) {  // fade to black with distance
-                if (all_t > _t_end * camera_scale) all_t = _t_end * camera_scale;
-                float gray_t = (all_t - _t_start * camera_scale) / (_t_end - _t_start) / camera_scale;
-                return RayTraceResult{
-                    color(0.0f, 0.0f, 0.0f) * sqr(sqr(gray_t)) + current_color * sqr(sqr(1.0f - gray_t)), depth, true};
-            }
-            return RayTraceResult{current_color, depth, true};
-        }
-        r = m.new_ray;
+        if (trace_segment(r, current_color, all_t, camera_scale, not_found_color, result)) return result;
     }
-    return RayTraceResult{color(0.0f, 0.0f, 0.0f), 0.0f, false};  // depth exhausted
+#endif
+    return result;
 }
 
 // --- camera teleportation -------------------------------------------- src/frag.glsl:199-257
@@ -435,6 +470,10 @@ PTL_FN vec4 shade_pixel(vec2 position) {
 PTL_FN void teleport_external_ray_entry(float* out6) {
     ptl_tracer t{&ptl_u};
     t.teleport_external_ray_entry(out6);
+}
+PTL_FN void derive_uniforms(ptl_uniform_block* block) {
+    ptl_tracer t{&ptl_u};
+    t.derive(block);
 }
 
 // GL fixed-point conversion of one channel: clamp to [0,1], scale, round to nearest.

@@ -390,6 +390,8 @@ static KernelOptions options_from_flags(unsigned flags) {
     o.specialize_all = (flags & 4u) != 0;
     o.anaglyph = (flags & 16u) != 0;
     o.specialize_static = (flags & 8u) != 0;
+    o.derived_uniforms = (flags & 32u) == 0;  // PTL_FLAG_NO_DERIVED_UNIFORMS: the plain plane tests (A/B measurements, tests)
+    o.fast_math = (flags & 64u) != 0;         // PTL_FLAG_FAST_MATH: tolerance mode
     return o;
 }
 

@@ -33,6 +33,9 @@ void usage() {
     std::fprintf(stderr,
                  "usage: portal-amd render-frame <scene.ron> [--stage NAME | --animation NAME] [--camera NAME] [--time T] [--output out.png]\n"
                  "                  [--width W] [--height H] [--aa-count N] [--render-depth D] [--device I] [--asset-root DIR] [--panini D --fov DEG]\n"
+                 "                  [--gpus N | --devices a,b,..] [--transport stores|copy] [--multi-process]   one frame across the GPUs of a node\n"
+                 "                  [--specialize 1] bake the scene state into the kernel   [--fast] tolerance mode   [--timing] where the wall time went\n"
+                 "       portal-amd precompile <scene.ron> [--stage NAME] [--specialize 1]      fill the code-object cache (no GPU needed)\n"
                  "       portal-amd render <scene[,scene..]> [clip[,clip..]] [--width 3840] [--height 2160] [--fps 60] [--motion-blur-frames 1]\n"
                  "                  [--stereoimage] [--no-skip-existing] [--filter-starts-with P] [--aa-count 4] [--render-depth 150]\n"
                  "                  [--scenes-dir DIR] [--out-dir DIR] [--device I] [--shard K/N] [--max-frames N] [--asset-root DIR]\n"
@@ -181,6 +184,11 @@ struct Options {
     int specialize = -1;  // -1 auto: clip-constant specialisation when the clip has enough sub-frames to repay the extra JIT
     int width = 1920, height = 1080, aa = 1, depth = 100, device = 0, fps = 60, blur = 1, shard = 0, shards = 1, max_frames = -1;
     double time = 0.0, panini = -1.0, fov = 90.0;
+    // render-frame across GPUs: --gpus N (devices 0..N-1) or --devices a,b,.. ; --transport stores|copy ; --multi-process
+    int gpus = 1, rank = 0, world = 1;
+    std::string devices, transport = "stores", ipc_handle;
+    bool multi_process = false, fast = false;
+    std::vector<std::string> argv;  // the command line as given (handed on to shard processes)
 };
 
 // SceneRenderer::update_inner_variables (src/main.rs:1688-1756): per-clip settings the reference hard-codes for its
@@ -215,32 +223,22 @@ int fail(const char* what) {
     return 1;
 }
 
-int render_frame(const Options& o) {
-    ptl_scene* scene = nullptr;
-    if (ptl_scene_load_file(o.scene.c_str(), &scene) != PTL_OK) {
-        std::fprintf(stderr, "Failed to parse scene `%s`: %s\n", o.scene.c_str(), ptl_last_error());
-        return 1;
-    }
-    auto t0 = std::chrono::steady_clock::now();
-    std::vector<char> log(1 << 16);
-    ptl_renderer* r = nullptr;
-    if (ptl_renderer_create(scene, o.device, o.asset_root.c_str(), kRenderFlags, &r, log.data(), log.size()) != PTL_OK) {
-        std::fprintf(stderr, "renderer: %s\n%s\n", ptl_last_error(), log.data());
-        return 1;
-    }
+// Everything of `render-frame` between creating a renderer and drawing (src/main.rs:2893-2928): stage / clip, camera, options,
+// one SceneRenderer::update at --time.  `scene_state` = false for ranks 1.. of a multi-GPU frame, which share rank 0's scene.
+int setup_renderer(const Options& o, ptl_scene* scene, ptl_renderer* r, bool scene_state) {
     ptl_renderer_set_option(r, "aa_count", o.aa);
     ptl_renderer_set_option(r, "render_depth", o.depth);
     char stage_cam[256] = "";
-    if (!o.stage.empty() && ptl_scene_init_stage(scene, o.stage.c_str(), stage_cam, sizeof stage_cam) != PTL_OK) {  // src/main.rs:2900-2904
+    if (scene_state && !o.stage.empty() && ptl_scene_init_stage(scene, o.stage.c_str(), stage_cam, sizeof stage_cam) != PTL_OK) {  // src/main.rs:2900-2904
         std::fprintf(stderr, "Scene `%s` has no stage named `%s`\n", o.scene.c_str(), o.stage.c_str());
         return 1;
     }
     if (!o.animation.empty()) {  // src/main.rs:2905-2917
-        if (ptl_scene_init_animation(scene, o.animation.c_str()) != PTL_OK) {
+        if (scene_state && ptl_scene_init_animation(scene, o.animation.c_str()) != PTL_OK) {
             std::fprintf(stderr, "Scene `%s` has no animation named `%s`\n", o.scene.c_str(), o.animation.c_str());
             return 1;
         }
-        apply_clip_overrides(scene, r, o.animation, nullptr);
+        apply_clip_overrides(scene_state ? scene : nullptr, r, o.animation, nullptr);
     }
     if (o.have_camera && ptl_renderer_use_camera(r, o.camera.c_str()) != PTL_OK) {  // --camera wins (src/main.rs:2918-2926)
         std::fprintf(stderr, "Scene `%s` has no camera named `%s`\n", o.scene.c_str(), o.camera.c_str());
@@ -252,16 +250,230 @@ int render_frame(const Options& o) {
     }
     ptl_renderer_set_option(r, "view_angle", o.fov / 180.0 * 3.14159265358979323846);
     if (ptl_renderer_update(r, o.time, nullptr, nullptr) != PTL_OK) return fail("update");  // src/main.rs:2928
-    ptl_frame frame{o.width, o.height, 0, 1, 0};
-    std::vector<uint8_t> img((size_t)o.width * o.height * 4);
+    return 0;
+}
+
+unsigned frame_flags(const Options& o) {
+    unsigned f = kRenderFlags;
+    if (o.specialize > 0) f |= 1u | 4u;  // --specialize 1: bake the scene state into the kernel (1-2 s of JIT, cached; ~2x kernel speed)
+    if (o.fast) f |= 64u;                // --fast: tolerance mode (PTL_FLAG_FAST_MATH)
+    return f;
+}
+
+double seconds_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+
+std::string hex_of(const unsigned char* bytes, size_t n) {
+    static const char* digits = "0123456789abcdef";
+    std::string out;
+    for (size_t k = 0; k < n; ++k) {
+        out += digits[bytes[k] >> 4];
+        out += digits[bytes[k] & 15];
+    }
+    return out;
+}
+bool unhex(const std::string& hex, unsigned char* out, size_t n) {
+    if (hex.size() != 2 * n) return false;
+    auto val = [](char c) { return c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : -1; };
+    for (size_t k = 0; k < n; ++k) {
+        int hi = val(hex[2 * k]), lo = val(hex[2 * k + 1]);
+        if (hi < 0 || lo < 0) return false;
+        out[k] = (unsigned char)(hi * 16 + lo);
+    }
+    return true;
+}
+
+std::vector<int> frame_devices(const Options& o) {
+    std::vector<int> devices;
+    for (auto& d : split_list(o.devices)) devices.push_back(std::atoi(d.c_str()));
+    if (devices.empty())
+        for (int k = 0; k < std::max(1, o.gpus); ++k) devices.push_back(o.gpus > 1 ? k : o.device);
+    return devices;
+}
+
+// `render-frame --gpus N --multi-process`: rank 0 (this process) owns the frame in its GPU's memory and exports it (HIP IPC);
+// ranks 1.. are child processes (`portal-amd render-shard`, the same command line + rank / device / handle) that map it and
+// let their kernels store their row blocks straight into it over xGMI.  Completion = the children's exit.
+int render_frame_processes(const Options& o, const std::vector<int>& devices) {
+    const int n = (int)devices.size();
+    auto t0 = std::chrono::steady_clock::now();
+    ptl_scene* scene = nullptr;
+    if (ptl_scene_load_file(o.scene.c_str(), &scene) != PTL_OK) {
+        std::fprintf(stderr, "Failed to parse scene `%s`: %s\n", o.scene.c_str(), ptl_last_error());
+        return 1;
+    }
+    size_t bytes = (size_t)o.width * o.height * 4;
+    void* frame = nullptr;
+    unsigned char handle[PTL_IPC_HANDLE_BYTES];
+    if (ptl_device_alloc(devices[0], bytes, &frame) != PTL_OK || ptl_ipc_export(frame, handle) != PTL_OK) return fail("frame buffer / ipc export");
+    std::vector<pid_t> children;
+    for (int k = 1; k < n; ++k) {
+        std::vector<std::string> args = o.argv;
+        args[1] = "render-shard";
+        for (auto extra : {std::string("--rank"), std::to_string(k), std::string("--world"), std::to_string(n), std::string("--device"),
+                           std::to_string(devices[k]), std::string("--ipc-handle"), hex_of(handle, sizeof handle)})
+            args.push_back(extra);
+        pid_t pid = ::fork();
+        if (pid == 0) {
+            std::vector<char*> argv;
+            for (auto& a : args) argv.push_back(const_cast<char*>(a.c_str()));
+            argv.push_back(nullptr);
+            ::execv("/proc/self/exe", argv.data());
+            std::perror("execv");
+            ::_exit(127);
+        }
+        if (pid < 0) return fail("fork");
+        children.push_back(pid);
+    }
+    std::vector<char> log(1 << 16);
+    ptl_renderer* r = nullptr;
+    if (ptl_renderer_create(scene, devices[0], o.asset_root.c_str(), frame_flags(o), &r, log.data(), log.size()) != PTL_OK) {
+        std::fprintf(stderr, "renderer: %s\n%s\n", ptl_last_error(), log.data());
+        return 1;
+    }
+    if (int rc = setup_renderer(o, scene, r, true)) return rc;
+    ptl_frame f{o.width, o.height, 0, n, 1};
     float ms = 0.0f;
-    if (ptl_renderer_draw_to_host(r, &frame, img.data(), nullptr, nullptr, &ms) != PTL_OK) return fail("render");
+    if (ptl_renderer_draw(r, &f, frame, nullptr, nullptr, nullptr, &ms) != PTL_OK) return fail("render");
+    int failed = 0;
+    for (pid_t pid : children) {
+        int status = 0;
+        if (::waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) ++failed;
+    }
+    if (failed) {
+        std::fprintf(stderr, "%d of %d shard processes failed\n", failed, n - 1);
+        return 1;
+    }
+    std::vector<uint8_t> img(bytes);
+    if (ptl_device_download(img.data(), frame, bytes, nullptr) != PTL_OK) return fail("download");
     if (!dir_of(o.output).empty()) make_dirs(dir_of(o.output));
     if (ptl_png_write(o.output.c_str(), img.data(), o.width, o.height) != PTL_OK) return fail("png");
-    double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("Rendered `%s` to `%s` (%dx%d, aa %d, depth %d) with %d processes, one per GPU, storing into rank 0's frame (HIP IPC): rank 0 kernel %.3f ms; total %.2f s\n",
+                o.scene.c_str(), o.output.c_str(), o.width, o.height, o.aa, o.depth, n, ms, seconds_since(t0));
+    ptl_renderer_destroy(r);
+    ptl_device_free(frame);
+    ptl_scene_free(scene);
+    return 0;
+}
+
+// One of those child processes.
+int render_shard(const Options& o) {
+    unsigned char handle[PTL_IPC_HANDLE_BYTES];
+    if (o.world < 2 || o.rank < 1 || o.rank >= o.world || !unhex(o.ipc_handle, handle, sizeof handle)) {
+        std::fprintf(stderr, "render-shard is started by `render-frame --gpus N --multi-process`\n");
+        return 2;
+    }
+    ptl_scene* scene = nullptr;
+    if (ptl_scene_load_file(o.scene.c_str(), &scene) != PTL_OK) return fail("scene");
+    std::vector<char> log(1 << 16);
+    ptl_renderer* r = nullptr;
+    if (ptl_renderer_create(scene, o.device, o.asset_root.c_str(), frame_flags(o), &r, log.data(), log.size()) != PTL_OK) {
+        std::fprintf(stderr, "renderer: %s\n%s\n", ptl_last_error(), log.data());
+        return 1;
+    }
+    if (int rc = setup_renderer(o, scene, r, true)) return rc;
+    void* frame = nullptr;
+    if (ptl_ipc_open(o.device, handle, &frame) != PTL_OK) return fail("ipc open");
+    ptl_frame f{o.width, o.height, o.rank, o.world, 1};
+    float ms = 0.0f;
+    if (ptl_renderer_draw(r, &f, frame, nullptr, nullptr, nullptr, &ms) != PTL_OK) return fail("render");  // timed: returns when the kernel (and its stores) have completed
+    ptl_ipc_close(frame);
+    ptl_renderer_destroy(r);
+    ptl_scene_free(scene);
+    return 0;
+}
+
+int render_frame(const Options& o) {
+    std::vector<int> devices = frame_devices(o);
+    if (devices.size() > 1 && o.multi_process) return render_frame_processes(o, devices);
+    auto t0 = std::chrono::steady_clock::now();
+    ptl_scene* scene = nullptr;
+    if (ptl_scene_load_file(o.scene.c_str(), &scene) != PTL_OK) {
+        std::fprintf(stderr, "Failed to parse scene `%s`: %s\n", o.scene.c_str(), ptl_last_error());
+        return 1;
+    }
+    double t_load = seconds_since(t0);
+    std::vector<char> log(1 << 16);
+    std::vector<uint8_t> img((size_t)o.width * o.height * 4);
+    if (devices.size() > 1) {  // one process, one renderer per GPU (include/portal_amd.h layer 3)
+        ptl_frame_group* g = nullptr;
+        int transport = o.transport == "copy" ? PTL_GROUP_COPY_GATHER : PTL_GROUP_PEER_STORES;
+        if (ptl_frame_group_create(scene, devices.data(), (int)devices.size(), o.asset_root.c_str(), frame_flags(o), transport, &g, log.data(), log.size()) != PTL_OK) {
+            std::fprintf(stderr, "frame group: %s\n%s\n", ptl_last_error(), log.data());
+            return 1;
+        }
+        double t_build = seconds_since(t0);
+        for (int k = 0; k < ptl_frame_group_size(g); ++k)
+            if (int rc = setup_renderer(o, scene, ptl_frame_group_renderer(g, k), k == 0)) return rc;
+        std::vector<float> ms(devices.size(), 0.0f);
+        auto t_draw0 = std::chrono::steady_clock::now();
+        if (ptl_frame_group_draw(g, o.width, o.height, nullptr, ms.data()) != PTL_OK) return fail("render");
+        double draw_ms = seconds_since(t_draw0) * 1e3;
+        if (ptl_frame_group_download(g, img.data()) != PTL_OK) return fail("download");
+        if (!dir_of(o.output).empty()) make_dirs(dir_of(o.output));
+        if (ptl_png_write(o.output.c_str(), img.data(), o.width, o.height) != PTL_OK) return fail("png");
+        std::string per_rank;
+        for (float m : ms) per_rank += (per_rank.empty() ? "" : " ") + std::to_string(m).substr(0, 6);
+        std::printf("Rendered `%s` to `%s` (%dx%d, aa %d, depth %d) on %zu GPUs (%s): kernel ms per rank [%s], frame %.3f ms wall; build %.2f s, total %.2f s\n",
+                    o.scene.c_str(), o.output.c_str(), o.width, o.height, o.aa, o.depth, devices.size(),
+                    transport == PTL_GROUP_COPY_GATHER ? "packed shards + one strided peer copy each" : "kernels store into GPU 0's frame", per_rank.c_str(), draw_ms,
+                    t_build - t_load, seconds_since(t0));
+        ptl_frame_group_destroy(g);
+        ptl_scene_free(scene);
+        return 0;
+    }
+    ptl_renderer* r = nullptr;
+    if (ptl_renderer_create(scene, devices[0], o.asset_root.c_str(), frame_flags(o), &r, log.data(), log.size()) != PTL_OK) {
+        std::fprintf(stderr, "renderer: %s\n%s\n", ptl_last_error(), log.data());
+        return 1;
+    }
+    double t_build = seconds_since(t0);
+    if (int rc = setup_renderer(o, scene, r, true)) return rc;
+    ptl_frame frame{o.width, o.height, 0, 1, 0};
+    float ms = 0.0f;
+    if (ptl_renderer_draw_to_host(r, &frame, img.data(), nullptr, nullptr, &ms) != PTL_OK) return fail("render");
+    double t_draw = seconds_since(t0);
+    if (!dir_of(o.output).empty()) make_dirs(dir_of(o.output));
+    if (ptl_png_write(o.output.c_str(), img.data(), o.width, o.height) != PTL_OK) return fail("png");
+    double total = seconds_since(t0);
     std::printf("Rendered `%s` to `%s` (%dx%d, aa %d, depth %d): kernel %.3f ms, %.1f Mray/s; total %.2f s\n", o.scene.c_str(), o.output.c_str(),
                 o.width, o.height, o.aa, o.depth, ms, (double)o.width * o.height * o.aa / (ms * 1e3), total);
+    if (o.timing)  // where the wall time went: the JIT (or the code-object cache) dominates a single frame
+        std::printf("timing: scene load %.3f s, generate + compile/load kernel %.3f s, update + draw + download %.3f s, png %.3f s\n", t_load,
+                    t_build - t_load, t_draw - t_build, total - t_draw);
     ptl_renderer_destroy(r);
+    ptl_scene_free(scene);
+    return 0;
+}
+
+// `portal-amd precompile <scene>`: fill the code-object cache for a scene without a GPU (hiprtc only): the dynamic-uniform kernel
+// `render-frame` / `render` start with and, with --specialize 1, the kernel with the scene's current state baked in.  A later
+// run on a GPU box with the same toolchain finds them by source + option + toolchain hash and only loads them.
+int precompile(const Options& o) {
+    auto t0 = std::chrono::steady_clock::now();
+    ptl_scene* scene = nullptr;
+    if (ptl_scene_load_file(o.scene.c_str(), &scene) != PTL_OK) {
+        std::fprintf(stderr, "Failed to parse scene `%s`: %s\n", o.scene.c_str(), ptl_last_error());
+        return 1;
+    }
+    char stage_cam[256] = "";
+    if (!o.stage.empty() && ptl_scene_init_stage(scene, o.stage.c_str(), stage_cam, sizeof stage_cam) != PTL_OK) return fail("stage");
+    std::vector<char> log(1 << 16);
+    std::vector<unsigned> variants = {frame_flags(o)};
+    if (o.specialize > 0) variants.push_back(kRenderFlags | (o.fast ? 64u : 0u));
+    for (unsigned flags : variants) {
+        auto t1 = std::chrono::steady_clock::now();
+        ptl_renderer* r = nullptr;
+        if (ptl_renderer_create(scene, -1, o.asset_root.c_str(), flags, &r, log.data(), log.size()) != PTL_OK) {
+            std::fprintf(stderr, "compile: %s\n%s\n", ptl_last_error(), log.data());
+            return 1;
+        }
+        const void* code = nullptr;
+        size_t size = 0;
+        ptl_kernel_code_object(ptl_renderer_kernel(r), &code, &size);
+        std::printf("flags 0x%x: %zu B code object in %.2f s\n", flags, size, seconds_since(t1));
+        ptl_renderer_destroy(r);
+    }
+    std::printf("precompiled `%s` in %.2f s\n", o.scene.c_str(), seconds_since(t0));
     ptl_scene_free(scene);
     return 0;
 }
@@ -706,12 +918,14 @@ int main(int argc, char** argv) {
         std::printf("%s\ndevices: %d\n", ptl_version(), ptl_device_count());
         return 0;
     }
-    if (argc < 3 || (cmd != "render-frame" && cmd != "render" && cmd != "emit-source" && cmd != "check" && cmd != "write")) {
+    if (argc < 3 || (cmd != "render-frame" && cmd != "render" && cmd != "emit-source" && cmd != "check" && cmd != "write" && cmd != "precompile" &&
+                     cmd != "render-shard")) {
         usage();
         return 2;
     }
     Options o;
     o.scene = argv[2];
+    o.argv.assign(argv, argv + argc);
     if (cmd == "render") {  // CLI defaults of RenderCliOptions (src/main.rs:2757-2805)
         o.width = 3840;
         o.height = 2160;
@@ -751,6 +965,14 @@ int main(int argc, char** argv) {
         else if (a == "--max-frames") o.max_frames = std::atoi(next());
         else if (a == "--specialize") o.specialize = std::atoi(next());
         else if (a == "--timing") o.timing = true;
+        else if (a == "--gpus") o.gpus = std::atoi(next());
+        else if (a == "--devices") o.devices = next();
+        else if (a == "--transport") o.transport = next();
+        else if (a == "--multi-process") o.multi_process = true;
+        else if (a == "--fast") o.fast = true;
+        else if (a == "--rank") o.rank = std::atoi(next());
+        else if (a == "--world") o.world = std::atoi(next());
+        else if (a == "--ipc-handle") o.ipc_handle = next();
         else if (a == "--set") {
             std::string kv = next();
             size_t eq = kv.find('=');
@@ -780,7 +1002,13 @@ int main(int argc, char** argv) {
         return 2;
     }
     if (cmd == "render") return render(o);
+    if (o.transport != "stores" && o.transport != "copy") {
+        std::fprintf(stderr, "--transport stores|copy\n");
+        return 2;
+    }
     if (cmd == "render-frame") return render_frame(o);
+    if (cmd == "render-shard") return render_shard(o);
+    if (cmd == "precompile") return precompile(o);
     if (cmd == "check") return check(o);
     if (cmd == "write") return write_scene(o);
     // emit-source

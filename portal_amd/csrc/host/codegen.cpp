@@ -349,21 +349,6 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         gk.uniforms = list;
 
         StringStorage s;
-        s.add_string("struct ptl_uniform_block {\n");
-        for (auto& u : list) s.add_string(std::string("    ") + cxx_type(u.type) + " " + u.name + ";\n");
-        s.add_string("};\n");
-        s.add_string("#if PTL_DEVICE_BUILD\n__constant__ ptl_uniform_block ptl_u;\n#else\nptl_uniform_block ptl_u;\n#endif\n");
-        // where the kernel reads uniforms from: the __constant__ block through the scalar cache
-        // (default), or a per-workgroup LDS copy (-DPTL_UNIFORMS_IN_LDS, staged in ptl_entry.h)
-        s.add_string("#if PTL_DEVICE_BUILD && defined(PTL_UNIFORMS_IN_LDS)\n__shared__ ptl_uniform_block ptl_lds_u;\n#define PTL_U ptl_lds_u\n"
-                     "#elif PTL_DEVICE_BUILD && defined(PTL_UNIFORM_RELOAD)\n"
-                     "// every access goes through a pointer the optimiser cannot see through: scalar loads stay where they are\n"
-                     "// used instead of being hoisted out of the bounce loop and spilled (SGPR -> VGPR lanes)\n"
-                     "PTL_FN const ptl_uniform_block& ptl_ublock() { const ptl_uniform_block* p = &ptl_u; asm volatile(\"\" : \"+s\"(p)); return *p; }\n"
-                     "#define PTL_U (ptl_ublock())\n"
-                     "#else\n#define PTL_U ptl_u\n#endif\n");
-        for (auto& u : list)
-            s.add_string("static_assert(__builtin_offsetof(ptl_uniform_block, " + u.name + ") == " + std::to_string(u.offset) + ", \"uniform layout\");\n");
         // JIT-time specialisation: current values baked in as literals (same arithmetic, the
         // compiler folds branches on mode switches / ray-independent subexpressions)
         std::map<std::string, std::string> baked;
@@ -394,6 +379,47 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 gk.baked.push_back(up);
             }
         }
+        // --- derived uniforms: one entry per plane test of a Flat object whose matrix is a run-time uniform -------------
+        if (opts.derived_uniforms) {
+            for (size_t pos = 0; pos < scene.objects.size(); ++pos) {
+                const Object& o = scene.objects[pos];
+                if (o.kind != Object::Flat) continue;
+                auto add = [&](int midx, int side, const std::string& normal_expr, const std::string& arg_expr) {
+                    const std::string& m = matrix_name(scene, midx, o);
+                    if (baked.count(normal_name(m))) return;  // literal matrix: the compiler folds all of this
+                    DerivedPlane d;
+                    d.object = (int)pos;
+                    d.side = side;
+                    d.member = "ptl_dv_" + std::to_string(pos) + "_" + std::to_string(side);
+                    d.normal_expr = normal_expr + normal_name(m) + ")";
+                    d.arg_expr = arg_expr + normal_name(m) + ")";
+                    gk.derived.push_back(d);
+                };
+                if (!o.portal) {
+                    add(o.m0, 0, "-get_normal(", "get_normal(");
+                } else {
+                    add(o.m0, 0, "-get_normal(", "-get_normal(");
+                    add(o.m1, 1, "get_normal(", "get_normal(");
+                }
+            }
+        }
+        s.add_string("struct ptl_uniform_block {\n");
+        for (auto& u : list) s.add_string(std::string("    ") + cxx_type(u.type) + " " + u.name + ";\n");
+        // written by ptl_derive_kernel (never by the host: uploads stop at uniform_block_size)
+        for (auto& d : gk.derived) s.add_string("    vec3 " + d.member + "_nrm;\n    int " + d.member + "_col;\n");
+        s.add_string("};\n");
+        s.add_string("#if PTL_DEVICE_BUILD\n__constant__ ptl_uniform_block ptl_u;\n#else\nptl_uniform_block ptl_u;\n#endif\n");
+        // where the kernel reads uniforms from: the __constant__ block through the scalar cache
+        // (default), or a per-workgroup LDS copy (-DPTL_UNIFORMS_IN_LDS, staged in ptl_entry.h)
+        s.add_string("#if PTL_DEVICE_BUILD && defined(PTL_UNIFORMS_IN_LDS)\n__shared__ ptl_uniform_block ptl_lds_u;\n#define PTL_U ptl_lds_u\n"
+                     "#elif PTL_DEVICE_BUILD && defined(PTL_UNIFORM_RELOAD)\n"
+                     "// every access goes through a pointer the optimiser cannot see through: scalar loads stay where they are\n"
+                     "// used instead of being hoisted out of the bounce loop and spilled (SGPR -> VGPR lanes)\n"
+                     "PTL_FN const ptl_uniform_block& ptl_ublock() { const ptl_uniform_block* p = &ptl_u; asm volatile(\"\" : \"+s\"(p)); return *p; }\n"
+                     "#define PTL_U (ptl_ublock())\n"
+                     "#else\n#define PTL_U ptl_u\n#endif\n");
+        for (auto& u : list)
+            s.add_string("static_assert(__builtin_offsetof(ptl_uniform_block, " + u.name + ") == " + std::to_string(u.offset) + ", \"uniform layout\");\n");
         for (auto& u : list) {
             auto it = baked.find(u.name);
             if (it != baked.end()) s.add_string("#define " + u.name + " (" + it->second + ")\n");
@@ -493,14 +519,35 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 s.add_string("if (nearer(i, ihit)) { i = ihit; i.hit.n = normalize(adjugate(" + inverse_name(m) + ") * i.hit.n); }\n\n");
             } else if (o.kind == Object::Flat) {
                 open_guard();
+                auto derived_of = [&](int side) -> const DerivedPlane* {
+                    for (auto& d : gk.derived)
+                        if (d.object == (int)pos && d.side == side) return &d;
+                    return nullptr;
+                };
+                // with a derived entry: the unit normal and both is_collinear verdicts come from the prologue kernel
+                // (ptl_tracer::derive below evaluates exactly the expressions of the plain form)
+                auto derived_test = [&](const DerivedPlane& d, const std::string& inv, const std::string& process_open, const std::string& extra_args,
+                                        const std::string& process_close) {
+                    s.add_string("hit = plane_intersect_derived(r, " + inv + ", PTL_U." + d.member + "_nrm, flipped);\n");
+                    s.add_string("if (nearer(i, hit)) { i = " + process_open + "is_inside_" + p + "(r.o + r.d * hit.t, hit.u, hit.v, ((PTL_U." + d.member +
+                                 "_col >> (flipped ? 1 : 0)) & 1) != 0" + extra_args + ")" + process_close + "; }\n\n");
+                };
                 if (!o.portal) {
                     const std::string& m = matrix_name(scene, o.m0, o);
-                    s.add_string("normal = -get_normal(" + normal_name(m) + ");\n");
-                    s.add_string("hit = plane_intersect(r, " + inverse_name(m) + ", get_normal(" + normal_name(m) + "));\n");
-                    s.add_string("if (nearer(i, hit)) { i = process_plane_intersection(i, hit, is_inside_" + p +
-                                 "(r.o + r.d * hit.t, hit.u, hit.v, is_collinear(hit.n, normal))); }\n\n");
+                    if (const DerivedPlane* d = derived_of(0)) {
+                        derived_test(*d, inverse_name(m), "process_plane_intersection(i, hit, ", "", ")");
+                    } else {
+                        s.add_string("normal = -get_normal(" + normal_name(m) + ");\n");
+                        s.add_string("hit = plane_intersect(r, " + inverse_name(m) + ", get_normal(" + normal_name(m) + "));\n");
+                        s.add_string("if (nearer(i, hit)) { i = process_plane_intersection(i, hit, is_inside_" + p +
+                                     "(r.o + r.d * hit.t, hit.u, hit.v, is_collinear(hit.n, normal))); }\n\n");
+                    }
                 } else {
                     auto side = [&](const std::string& m, bool first, const std::string& material) {
+                        if (const DerivedPlane* d = derived_of(first ? 0 : 1)) {
+                            derived_test(*d, inverse_name(m), "process_portal_intersection(i, hit, ", std::string(", ") + bool_lit(first), ", " + material + ")");
+                            return;
+                        }
                         s.add_string(std::string("normal = ") + (first ? "-" : "") + "get_normal(" + normal_name(m) + ");\n");
                         s.add_string("hit = plane_intersect(r, " + inverse_name(m) + ", normal);\n");
                         s.add_string("if (nearer(i, hit)) { i = process_portal_intersection(i, hit, is_inside_" + p +
@@ -537,6 +584,17 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             s.add_string("\n");
         }
         storages["intersections"] = std::move(s);
+    }
+
+    // --- prologue: the ray-independent part of every derived plane test, once per uniform upload ----------
+    {
+        StringStorage s;
+        for (auto& d : gk.derived) {
+            s.add_string("    {\n        vec3 normal = " + d.normal_expr + ";\n        vec3 unit = normalize(" + d.arg_expr + ");\n");
+            s.add_string("        out->" + d.member + "_nrm = unit;\n");
+            s.add_string("        out->" + d.member + "_col = (is_collinear(unit, normal) ? 1 : 0) | (is_collinear(unit * -1.0f, normal) ? 2 : 0);\n    }\n");
+        }
+        storages["derive"] = std::move(s);
     }
 
     // --- intersection materials (scene.rs:1011-1035) --------------------------------------
@@ -604,6 +662,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     gk.line_numbers = std::move(body.line_numbers);
     if (opts.count_segments) gk.defines.push_back("PTL_COUNT_SEGMENTS");
     if (opts.anaglyph) gk.defines.push_back("PTL_ANAGLYPH");
+    if (opts.fast_math) gk.defines.push_back("PTL_FAST_MATH");
     return gk;
 }
 

@@ -78,6 +78,20 @@ struct KernelOptions {
     bool anaglyph = false;         // compile the !ANAGLYPH! code in (the reference's `disable_anaglyph = false`)
     bool specialize_static = false;  // bake every scene uniform whose evaluation does not read a per-frame input ...
     std::set<std::string> keep_dynamic;  // ... except these (values that changed after all: demoted by the renderer)
+    // Ray-independent work of the generated plane code (normalize(get_normal(X_mat)), both possible is_collinear verdicts) is
+    // evaluated once per uniform upload by the module's prologue kernel `ptl_derive_kernel` and read back as extra uniforms,
+    // instead of once per bounce-loop trip by every lane.  Same functions, same binary32 operations: identical frames.
+    // Applies to matrices that are run-time uniforms (a baked matrix folds at JIT time anyway).
+    bool derived_uniforms = true;
+    bool fast_math = false;  // PTL_FAST_MATH: hardware rcp / sqrt / rsq (1 ulp), a/b = a * rcp(b), FMA contraction: tolerance mode, not bit-exact
+};
+
+// One plane test of a Flat object whose ray-independent part is evaluated by the prologue kernel (KernelOptions::derived_uniforms).
+struct DerivedPlane {
+    int object = 0, side = 0;   // scene object index; 0 = the object's (first) matrix, 1 = a portal's second matrix
+    std::string member;         // ptl_uniform_block members `<member>_nrm` (vec3) and `<member>_col` (int, two verdict bits)
+    std::string normal_expr;    // the generated code's `normal` (what is_collinear compares hit.n with)
+    std::string arg_expr;       // the vector plane_intersect normalises
 };
 
 struct GeneratedKernel {
@@ -87,6 +101,7 @@ struct GeneratedKernel {
     size_t uniform_block_size = 0;
     std::vector<std::string> defines;   // e.g. "PTL_COUNT_SEGMENTS"
     std::vector<UniformUpload> baked;   // the values compiled in as literals (specialised builds)
+    std::vector<DerivedPlane> derived;  // members appended to the block behind uniform_block_size, written on the device
 };
 
 // Scene::uniforms (scene.rs:424-543): names and types, in the reference's order.

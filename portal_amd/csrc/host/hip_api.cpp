@@ -92,7 +92,9 @@ const Runtime* runtime(std::string* error) {
                  bind(h, "hipModuleGetGlobal", rt.hipModuleGetGlobal, &err) && bind(h, "hipFuncGetAttribute", rt.hipFuncGetAttribute, &err) &&
                  bind(h, "hipModuleLaunchKernel", rt.hipModuleLaunchKernel, &err) && bind(h, "hipGetErrorString", rt.hipGetErrorString, &err) &&
                  bind(h, "hipIpcGetMemHandle", rt.hipIpcGetMemHandle, &err) && bind(h, "hipIpcOpenMemHandle", rt.hipIpcOpenMemHandle, &err) &&
-                 bind(h, "hipIpcCloseMemHandle", rt.hipIpcCloseMemHandle, &err) && bind(h, "hipGetLastError", rt.hipGetLastError, &err);
+                 bind(h, "hipIpcCloseMemHandle", rt.hipIpcCloseMemHandle, &err) && bind(h, "hipGetLastError", rt.hipGetLastError, &err) &&
+                 bind(h, "hipDeviceCanAccessPeer", rt.hipDeviceCanAccessPeer, &err) && bind(h, "hipDeviceEnablePeerAccess", rt.hipDeviceEnablePeerAccess, &err) &&
+                 bind(h, "hipMemcpy2DAsync", rt.hipMemcpy2DAsync, &err);
         }
     }
     if (!ok && error) *error = "HIP runtime unavailable: " + err;
@@ -116,7 +118,8 @@ const Rtc* rtc(std::string* error) {
             ok = bind(h, "hiprtcCreateProgram", r.hiprtcCreateProgram, &err) && bind(h, "hiprtcCompileProgram", r.hiprtcCompileProgram, &err) &&
                  bind(h, "hiprtcGetProgramLogSize", r.hiprtcGetProgramLogSize, &err) && bind(h, "hiprtcGetProgramLog", r.hiprtcGetProgramLog, &err) &&
                  bind(h, "hiprtcGetCodeSize", r.hiprtcGetCodeSize, &err) && bind(h, "hiprtcGetCode", r.hiprtcGetCode, &err) &&
-                 bind(h, "hiprtcDestroyProgram", r.hiprtcDestroyProgram, &err) && bind(h, "hiprtcGetErrorString", r.hiprtcGetErrorString, &err);
+                 bind(h, "hiprtcDestroyProgram", r.hiprtcDestroyProgram, &err) && bind(h, "hiprtcGetErrorString", r.hiprtcGetErrorString, &err) &&
+                 bind(h, "hiprtcVersion", r.hiprtcVersion, &err);
         }
     }
     if (!ok && error) *error = "hiprtc unavailable: " + err;

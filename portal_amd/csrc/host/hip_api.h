@@ -60,11 +60,16 @@ struct Runtime {
     hipError_t (*hipIpcOpenMemHandle)(void**, IpcMemHandle, unsigned);
     hipError_t (*hipIpcCloseMemHandle)(void*);
     hipError_t (*hipGetLastError)();  // also CLEARS the thread's sticky error: call after a failure that was expected
+    hipError_t (*hipDeviceCanAccessPeer)(int*, int, int);
+    hipError_t (*hipDeviceEnablePeerAccess)(int, unsigned);
+    hipError_t (*hipMemcpy2DAsync)(void*, size_t, const void*, size_t, size_t, size_t, int, hipStream_t);
 };
 constexpr int kFuncAttrSharedSizeBytes = 1, kFuncAttrLocalSizeBytes = 3, kFuncAttrNumRegs = 4;  // hipFunction_attribute
 constexpr unsigned kStreamNonBlocking = 1, kEventDisableTiming = 2, kIpcMemLazyEnablePeerAccess = 1;
 constexpr int kMemcpyHostToDevice = 1;
 constexpr int kMemcpyDeviceToHost = 2;
+constexpr int kMemcpyDefault = 4;  // direction (and peer routing) from the pointers' own attributes
+constexpr int kErrorPeerAccessAlreadyEnabled = 704;
 
 struct Rtc {
     std::string path;
@@ -76,6 +81,7 @@ struct Rtc {
     hiprtcResult (*hiprtcGetCode)(hiprtcProgram, char*);
     hiprtcResult (*hiprtcDestroyProgram)(hiprtcProgram*);
     const char* (*hiprtcGetErrorString)(hiprtcResult);
+    hiprtcResult (*hiprtcVersion)(int*, int*);
 };
 
 // nullptr (and *error filled) if the library cannot be found / lacks a symbol.

@@ -48,6 +48,8 @@ std::string cache_dir() {
 
 std::vector<std::string> compile_options(const char* const* defines, int n_defines) {
     const char* arch = std::getenv("PTL_OFFLOAD_ARCH");
+    bool fast = false;  // the tolerance mode (device/ptl_glsl.h, PTL_FAST_MATH): contraction and approximate / and sqrt allowed
+    for (int k = 0; k < n_defines; ++k) fast = fast || std::string(defines[k]) == "PTL_FAST_MATH";
     std::vector<std::string> o = {std::string("--offload-arch=") + (arch ? arch : "gfx950"),
                                   // -O1, measured (profiles/r01/variants7_O1.jsonl, variants8_O1.jsonl): against -O3 the baked kernels
                                   // are 10-16 % FASTER (portal_in_portal 4K 0.86 -> 0.72 ms, 136 -> 110 VGPRs, SGPR spills 20 -> 0),
@@ -55,8 +57,8 @@ std::vector<std::string> compile_options(const char* const* defines, int n_defin
                                   // hoist and unroll the straight-line per-object code into long live ranges; results are identical.
                                   "-O1",
                                   "-std=c++20",
-                                  "-ffp-contract=off",  // FMAs only where device/ptl_glsl.h spells them
-                                  "-fhip-fp32-correctly-rounded-divide-sqrt",
+                                  fast ? "-ffp-contract=fast" : "-ffp-contract=off",  // exact mode: FMAs only where device/ptl_glsl.h spells them
+                                  fast ? "-fno-hip-fp32-correctly-rounded-divide-sqrt" : "-fhip-fp32-correctly-rounded-divide-sqrt",
                                   "-fno-gpu-approx-transcendentals" /* no-op on older clang, harmless */
                                   // LLVM's default ("greedy") VGPR allocator MISCOMPILES divergent control flow now and then on this
                                   // toolchain (ROCm 7.2): a value that is live across an exec-masked inner block gets its registers
@@ -99,6 +101,7 @@ struct ptl_kernel {
     hip::hipModule_t module = nullptr;
     hip::hipFunction_t fn = nullptr;
     hip::hipFunction_t teleport_fn = nullptr;  // optional: ptl_teleport_kernel
+    hip::hipFunction_t derive_fn = nullptr;    // optional: ptl_derive_kernel, the uniform prologue (runs after every upload)
     void* dev_block = nullptr;  // address of __constant__ ptl_u
     size_t dev_block_size = 0;
     std::vector<unsigned char> shadow;  // host copy of the uniform block
@@ -238,6 +241,10 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
         rt->hipGetLastError();      // ... and the expected hipErrorNotFound must not stay behind as the thread's sticky
                                     // error: the next HIP user in the process (PyTorch) would report it as its own
     }
+    if (rt->hipModuleGetFunction(&k->derive_fn, k->module, "ptl_derive_kernel") != 0) {
+        k->derive_fn = nullptr;
+        rt->hipGetLastError();
+    }
     if (!hip_ok(rt, rt->hipModuleGetGlobal(&k->dev_block, &k->dev_block_size, k->module, "_ZN4glsl5ptl_uE"), "hipModuleGetGlobal(ptl_u)"))
         return PTL_ERR_HIP;
     if (k->dev_block_size < uniform_block_size) {
@@ -320,20 +327,30 @@ static int shard_blocks(const ptl_frame* f) {
     return blocks > f->rb_phase ? (blocks - f->rb_phase + f->rb_stride - 1) / f->rb_stride : 0;
 }
 
+// Stream-ordered upload of the host's copy of the uniform block (one copy, a few KB) followed by the module's prologue
+// kernel, which fills the derived uniforms behind it.
+static int upload_uniforms(ptl_kernel* k, const hip::Runtime* rt, void* stream) {
+    if (!k->dirty) return PTL_OK;
+    if (!hip_ok(rt, rt->hipMemcpyAsync(k->dev_block, k->shadow.data(), k->shadow.size(), hip::kMemcpyHostToDevice, stream), "hipMemcpyAsync(uniform block)"))
+        return PTL_ERR_HIP;
+    // the shadow buffer is pageable host memory: the async copy has staged it before returning
+    if (k->derive_fn) {
+        void* block = k->dev_block;
+        void* args[] = {&block};
+        if (!hip_ok(rt, rt->hipModuleLaunchKernel(k->derive_fn, 1, 1, 1, 64, 1, 1, 0, stream, args, nullptr), "hipModuleLaunchKernel(ptl_derive_kernel)"))
+            return PTL_ERR_HIP;
+    }
+    k->dirty = false;
+    return PTL_OK;
+}
+
 extern "C" int ptl_kernel_render(ptl_kernel* k, const ptl_frame* frame, void* out_rgba8, void* out_rgba32f, void* segments,
                                  void* stream, float* elapsed_ms) {
     if (!k || !frame || ptl_frame_shard_rows(frame) < 0) return PTL_ERR_INVALID;
     if (k->device < 0 || !k->fn) return PTL_ERR_NO_DEVICE;
     const hip::Runtime* rt = hip::runtime(nullptr);
     if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;
-    if (k->dirty) {
-        // stream-ordered upload of the whole block: one copy, a few KB
-        if (!hip_ok(rt, rt->hipMemcpyAsync(k->dev_block, k->shadow.data(), k->shadow.size(), hip::kMemcpyHostToDevice, stream),
-                    "hipMemcpyAsync(uniform block)"))
-            return PTL_ERR_HIP;
-        // the shadow buffer is pageable host memory: the async copy has staged it before returning
-        k->dirty = false;
-    }
+    if (int rc = upload_uniforms(k, rt, stream); rc != PTL_OK) return rc;
     int nby = shard_blocks(frame);
     if (nby == 0) {
         if (elapsed_ms) *elapsed_ms = 0.0f;
@@ -405,11 +422,7 @@ extern "C" int ptl_kernel_teleport_ray(ptl_kernel* k, const float a[3], const fl
     if (rc < 0) return rc;
     const hip::Runtime* rt = hip::runtime(nullptr);
     if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;
-    if (k->dirty) {
-        if (!hip_ok(rt, rt->hipMemcpyAsync(k->dev_block, k->shadow.data(), k->shadow.size(), hip::kMemcpyHostToDevice, nullptr), "hipMemcpyAsync(uniform block)"))
-            return PTL_ERR_HIP;
-        k->dirty = false;
-    }
+    if (int rc2 = upload_uniforms(k, rt, nullptr); rc2 != PTL_OK) return rc2;
     void* dev_out = nullptr;
     if (!hip_ok(rt, rt->hipMalloc(&dev_out, 8 * sizeof(float)), "hipMalloc(teleport result)")) return PTL_ERR_HIP;
     void* args[] = {&dev_out};

@@ -1,0 +1,244 @@
+// multigpu.cpp -- layer 3 of the C ABI: ONE frame across the GPUs of one node, from one host process, without Python,
+// torch or RCCL (the draw it shards is SceneRenderer::draw_texture, src/main.rs:1411-1428).
+//
+// Pixels are independent, so the frame shards with no exchange while tracing: rank g of G renders the 8-row blocks b with
+// b % G == g (interleaved: cost is spatially clustered -- portal interiors take many trips, walls one).  What is left is
+// getting every rank's rows into ONE frame buffer on devices[0].  Two transports, same bytes:
+//
+//   PTL_GROUP_PEER_STORES   rank g's kernel stores its rows straight into the frame in devices[0]'s HBM (peer access inside
+//                           the process, hipDeviceEnablePeerAccess; ptl_frame.in_place = 1).  The 128-byte row stores of
+//                           the trace kernel travel over the direct xGMI link g -> 0 while the kernel is still tracing:
+//                           no staging shard, no gather, no de-interleave pass.
+//   PTL_GROUP_COPY_GATHER   every rank renders a packed shard in its own HBM; ONE strided peer copy per rank
+//                           (hipMemcpy2DAsync: source pitch = one 8-row block, destination pitch = G blocks) moves it over
+//                           the same link with the SDMA engine and puts every block where it belongs -- the gather and the
+//                           de-interleave in one transfer.  This is what an RCCL gather to one root decomposes into
+//                           (G - 1 point-to-point transfers into rank 0, no ring), minus the collective launch.
+//
+// One thread drives all ranks: launches are asynchronous, each rank has its own non-blocking stream on its own device, and
+// the call returns after every rank's event has completed.  The same device may be listed more than once (rehearsal of the
+// N-rank control flow on a 1-GPU box; tests/test_gpu_parity.py).  bench.py's multi-process variant (torch.distributed, one
+// process per GPU, RCCL) lives in portal_amd/parallel.py; the CLI's `render-frame --gpus N` uses this file.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/portal_amd.h"
+#include "hip_api.h"
+#include "internal.h"
+
+using namespace ptl;
+
+struct ptl_frame_group {
+    std::vector<int> devices;
+    std::vector<ptl_renderer*> renderers;
+    std::vector<hip::hipStream_t> streams;
+    std::vector<hip::hipEvent_t> begin, end;
+    std::vector<void*> shards;  // PTL_GROUP_COPY_GATHER: packed rows of rank g in devices[g]'s memory
+    size_t shard_bytes = 0;
+    void* frame = nullptr;      // the assembled RGBA8 frame, devices[0]
+    size_t frame_bytes = 0;
+    int width = 0, height = 0;
+    int transport = PTL_GROUP_PEER_STORES;
+};
+
+namespace {
+
+int hip_fail(const hip::Runtime* rt, int e, const char* what) {
+    if (e == 0) return PTL_OK;
+    set_last_error(std::string(what) + ": " + rt->hipGetErrorString(e) + " (" + std::to_string(e) + ")");
+    rt->hipGetLastError();
+    return PTL_ERR_HIP;
+}
+
+void release_buffers(ptl_frame_group* g, const hip::Runtime* rt) {
+    if (g->frame) {
+        rt->hipSetDevice(g->devices[0]);
+        rt->hipFree(g->frame);
+        g->frame = nullptr;
+    }
+    for (size_t k = 0; k < g->shards.size(); ++k)
+        if (g->shards[k]) {
+            rt->hipSetDevice(g->devices[k]);
+            rt->hipFree(g->shards[k]);
+            g->shards[k] = nullptr;
+        }
+    g->frame_bytes = g->shard_bytes = 0;
+}
+
+}  // namespace
+
+extern "C" int ptl_frame_group_create(ptl_scene* scene, const int* devices, int n_devices, const char* asset_root, unsigned flags, int transport,
+                                      ptl_frame_group** out, char* log, size_t log_cap) {
+    if (!scene || !devices || n_devices < 1 || n_devices > 64 || !out) return PTL_ERR_INVALID;
+    if (transport != PTL_GROUP_PEER_STORES && transport != PTL_GROUP_COPY_GATHER) return PTL_ERR_INVALID;
+    *out = nullptr;
+    std::string err;
+    const hip::Runtime* rt = hip::runtime(&err);
+    if (!rt) {
+        set_last_error(err);
+        return PTL_ERR_NO_DEVICE;
+    }
+    auto g = std::make_unique<ptl_frame_group>();
+    g->transport = transport;
+    g->devices.assign(devices, devices + n_devices);
+    int rc = PTL_OK;
+    // every rank must be able to address devices[0]'s memory (stores, or the peer copy's destination)
+    for (int k = 1; k < n_devices && rc == PTL_OK; ++k) {
+        if (devices[k] == devices[0]) continue;
+        int can = 0;
+        rc = hip_fail(rt, rt->hipDeviceCanAccessPeer(&can, devices[k], devices[0]), "hipDeviceCanAccessPeer");
+        if (rc == PTL_OK && !can) {
+            set_last_error("device " + std::to_string(devices[k]) + " cannot access the memory of device " + std::to_string(devices[0]));
+            rc = PTL_ERR_HIP;
+        }
+        if (rc == PTL_OK) rc = hip_fail(rt, rt->hipSetDevice(devices[k]), "hipSetDevice");
+        if (rc == PTL_OK) {
+            int e = rt->hipDeviceEnablePeerAccess(devices[0], 0);
+            if (e == hip::kErrorPeerAccessAlreadyEnabled) {
+                rt->hipGetLastError();
+                e = 0;
+            }
+            rc = hip_fail(rt, e, "hipDeviceEnablePeerAccess");
+        }
+    }
+    for (int k = 0; k < n_devices && rc == PTL_OK; ++k) {
+        ptl_renderer* r = nullptr;
+        rc = ptl_renderer_create(scene, devices[k], asset_root, flags, &r, log, log_cap);  // the code-object cache makes ranks 1.. a module load
+        if (rc != PTL_OK) break;
+        g->renderers.push_back(r);
+        hip::hipStream_t s = nullptr;
+        hip::hipEvent_t b = nullptr, e = nullptr;
+        rc = hip_fail(rt, rt->hipSetDevice(devices[k]), "hipSetDevice");
+        if (rc == PTL_OK) rc = hip_fail(rt, rt->hipStreamCreateWithFlags(&s, hip::kStreamNonBlocking), "hipStreamCreateWithFlags");
+        if (rc == PTL_OK) rc = hip_fail(rt, rt->hipEventCreate(&b), "hipEventCreate");
+        if (rc == PTL_OK) rc = hip_fail(rt, rt->hipEventCreate(&e), "hipEventCreate");
+        g->streams.push_back(s);
+        g->begin.push_back(b);
+        g->end.push_back(e);
+    }
+    g->shards.assign(n_devices, nullptr);
+    if (rc != PTL_OK) {
+        ptl_frame_group_destroy(g.release());
+        return rc;
+    }
+    *out = g.release();
+    return PTL_OK;
+}
+
+extern "C" int ptl_frame_group_size(const ptl_frame_group* g) { return g ? (int)g->renderers.size() : 0; }
+extern "C" ptl_renderer* ptl_frame_group_renderer(ptl_frame_group* g, int rank) {
+    return (g && rank >= 0 && rank < (int)g->renderers.size()) ? g->renderers[rank] : nullptr;
+}
+
+extern "C" int ptl_frame_group_set_option(ptl_frame_group* g, const char* name, double value) {
+    if (!g) return PTL_ERR_INVALID;
+    for (ptl_renderer* r : g->renderers)
+        if (int rc = ptl_renderer_set_option(r, name, value); rc != PTL_OK) return rc;
+    return PTL_OK;
+}
+extern "C" int ptl_frame_group_use_camera(ptl_frame_group* g, const char* camera) {
+    if (!g) return PTL_ERR_INVALID;
+    for (ptl_renderer* r : g->renderers)
+        if (int rc = ptl_renderer_use_camera(r, camera); rc != PTL_OK) return rc;
+    return PTL_OK;
+}
+extern "C" int ptl_frame_group_set_camera(ptl_frame_group* g, const double look_at[3], double alpha, double beta, double radius) {
+    if (!g) return PTL_ERR_INVALID;
+    for (ptl_renderer* r : g->renderers)
+        if (int rc = ptl_renderer_set_camera(r, look_at, alpha, beta, radius); rc != PTL_OK) return rc;
+    return PTL_OK;
+}
+// SceneRenderer::update on every rank: each keeps its own camera state and runs its own (identical) portal-crossing query,
+// so all ranks agree on the camera without exchanging anything.
+extern "C" int ptl_frame_group_update(ptl_frame_group* g, double seconds) {
+    if (!g) return PTL_ERR_INVALID;
+    for (ptl_renderer* r : g->renderers)
+        if (int rc = ptl_renderer_update(r, seconds, nullptr, nullptr); rc != PTL_OK) return rc;
+    return PTL_OK;
+}
+
+extern "C" int ptl_frame_group_draw(ptl_frame_group* g, int width, int height, void** device_rgba8, float* kernel_ms) {
+    if (!g || width <= 0 || height <= 0) return PTL_ERR_INVALID;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!rt) return PTL_ERR_NO_DEVICE;
+    const int n = (int)g->renderers.size();
+    const size_t pitch = (size_t)width * 4;
+    const int blocks = (height + 7) / 8;
+    const size_t frame_bytes = (size_t)blocks * 8 * pitch;  // whole blocks: the strided copy of a ragged last block stays inside
+    const size_t shard_bytes = (size_t)((blocks + n - 1) / n) * 8 * pitch;
+    if (frame_bytes != g->frame_bytes || (g->transport == PTL_GROUP_COPY_GATHER && shard_bytes != g->shard_bytes)) {
+        release_buffers(g, rt);
+        int rc = hip_fail(rt, rt->hipSetDevice(g->devices[0]), "hipSetDevice");
+        if (rc == PTL_OK) rc = hip_fail(rt, rt->hipMalloc(&g->frame, frame_bytes), "hipMalloc(frame)");
+        for (int k = 0; k < n && rc == PTL_OK && g->transport == PTL_GROUP_COPY_GATHER; ++k) {
+            rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice");
+            if (rc == PTL_OK) rc = hip_fail(rt, rt->hipMalloc(&g->shards[k], shard_bytes), "hipMalloc(shard)");
+        }
+        if (rc != PTL_OK) {
+            release_buffers(g, rt);
+            return rc;
+        }
+        g->frame_bytes = frame_bytes;
+        g->shard_bytes = g->transport == PTL_GROUP_COPY_GATHER ? shard_bytes : 0;
+    }
+    g->width = width;
+    g->height = height;
+    for (int k = 0; k < n; ++k) {
+        if (int rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice"); rc != PTL_OK) return rc;
+        rt->hipEventRecord(g->begin[k], g->streams[k]);
+        if (g->transport == PTL_GROUP_PEER_STORES) {
+            ptl_frame f{width, height, k, n, 1};
+            if (int rc = ptl_renderer_draw(g->renderers[k], &f, g->frame, nullptr, nullptr, g->streams[k], nullptr); rc != PTL_OK) return rc;
+            rt->hipEventRecord(g->end[k], g->streams[k]);
+        } else {
+            ptl_frame f{width, height, k, n, 0};
+            if (int rc = ptl_renderer_draw(g->renderers[k], &f, g->shards[k], nullptr, nullptr, g->streams[k], nullptr); rc != PTL_OK) return rc;
+            rt->hipEventRecord(g->end[k], g->streams[k]);  // kernel time; the copy below is behind it on the same stream
+            const int my_blocks = blocks > k ? (blocks - k + n - 1) / n : 0;
+            if (my_blocks > 0) {
+                // shard block j -> frame block j * n + k: source pitch one block, destination pitch n blocks, `my_blocks` rows of 8 * pitch bytes
+                char* dst = static_cast<char*>(g->frame) + (size_t)k * 8 * pitch;
+                if (int rc = hip_fail(rt, rt->hipMemcpy2DAsync(dst, (size_t)n * 8 * pitch, g->shards[k], 8 * pitch, 8 * pitch, (size_t)my_blocks,
+                                                               hip::kMemcpyDefault, g->streams[k]),
+                                      "hipMemcpy2DAsync(shard -> frame)");
+                    rc != PTL_OK)
+                    return rc;
+            }
+        }
+    }
+    for (int k = 0; k < n; ++k) {
+        if (int rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice"); rc != PTL_OK) return rc;
+        if (int rc = hip_fail(rt, rt->hipStreamSynchronize(g->streams[k]), "hipStreamSynchronize(rank)"); rc != PTL_OK) return rc;
+        if (kernel_ms) rt->hipEventElapsedTime(&kernel_ms[k], g->begin[k], g->end[k]);
+    }
+    if (device_rgba8) *device_rgba8 = g->frame;
+    return PTL_OK;
+}
+
+extern "C" int ptl_frame_group_download(ptl_frame_group* g, uint8_t* host_rgba8) {
+    if (!g || !host_rgba8 || !g->frame) return PTL_ERR_INVALID;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (int rc = hip_fail(rt, rt->hipSetDevice(g->devices[0]), "hipSetDevice"); rc != PTL_OK) return rc;
+    return hip_fail(rt, rt->hipMemcpy(host_rgba8, g->frame, (size_t)g->width * g->height * 4, hip::kMemcpyDeviceToHost), "hipMemcpy(frame)");
+}
+
+extern "C" void ptl_frame_group_destroy(ptl_frame_group* g) {
+    if (!g) return;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (rt) {
+        for (size_t k = 0; k < g->streams.size(); ++k) {
+            rt->hipSetDevice(g->devices[k]);
+            if (g->streams[k]) {
+                rt->hipStreamSynchronize(g->streams[k]);
+                rt->hipStreamDestroy(g->streams[k]);
+            }
+            if (k < g->begin.size() && g->begin[k]) rt->hipEventDestroy(g->begin[k]);
+            if (k < g->end.size() && g->end[k]) rt->hipEventDestroy(g->end[k]);
+        }
+        release_buffers(g, rt);
+    }
+    for (ptl_renderer* r : g->renderers) ptl_renderer_destroy(r);
+    delete g;
+}

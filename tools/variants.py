@@ -62,6 +62,21 @@ VARIANTS = {
     "all_plain": "SPECIALIZE_ALL -DPTL_PLAIN_SQRT_RCP",
     "base_plain": "-DPTL_PLAIN_SQRT_RCP",
     "all_minreg_plain": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg -DPTL_PLAIN_SQRT_RCP",
+    # round 2: uniform prologue (derived uniforms), explicit wave loop, tolerance mode
+    "r2_dyn": "",
+    "r2_dyn_w4": "-DPTL_WAVES_PER_EU=4",
+    "r2_dyn_noderived": "NO_DERIVED",
+    "r2_dyn_noderived_w4": "NO_DERIVED -DPTL_WAVES_PER_EU=4",
+    "r2_dyn_nowaveloop": "-DPTL_NO_WAVE_LOOP",
+    "r2_dyn_nowaveloop_noderived": "NO_DERIVED -DPTL_NO_WAVE_LOOP",
+    "r2_all": "SPECIALIZE_ALL",
+    "r2_all_nowaveloop": "SPECIALIZE_ALL -DPTL_NO_WAVE_LOOP",
+    "r2_ints": "SPECIALIZE",
+    "r2_ints_noderived": "SPECIALIZE NO_DERIVED",
+    "r2_fast_dyn": "FAST",
+    "r2_fast_dyn_w4": "FAST -DPTL_WAVES_PER_EU=4",
+    "r2_fast_all": "FAST SPECIALIZE_ALL",
+    "r2_fast_all_w4": "FAST SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4",
 }
 CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
 
@@ -79,7 +94,8 @@ def run_one(case, vname, flags):
     scene_name, w, h, d, aa = case.split(":")
     w, h, d, aa = int(w), int(h), int(d), int(aa)
     toks = flags.split()
-    rflags = (pa.FLAG_SPECIALIZE_INTS if "SPECIALIZE" in toks else 0) | (pa.FLAG_SPECIALIZE_ALL if "SPECIALIZE_ALL" in toks else 0)
+    rflags = (pa.FLAG_SPECIALIZE_INTS if ("SPECIALIZE" in toks or "SPECIALIZE_ALL" in toks) else 0) | (pa.FLAG_SPECIALIZE_ALL if "SPECIALIZE_ALL" in toks else 0)
+    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0)
     # the VGPR allocator is an option the JIT always passes (kernel.cpp): select it through its own switch, not a second -mllvm
     ra = [t.split("=", 1)[1] for t in toks if t.startswith("-vgpr-regalloc=")]
     if "RA_DEFAULT" in toks:
