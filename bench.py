@@ -10,12 +10,16 @@ by the kernels storing straight into rank 0's frame over xGMI (whichever is fast
 (scene constants, portal matrices) are resident in device constant memory before the timed
 region; the frame stays in HBM (no host copy inside the timed region).
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (ptl_render_kernel):
-algorithmic bytes = the RGBA8 framebuffer this launch stores (W*H*4 / N), divided by the
-kernel's mean launch time measured with HIP events on the launch stream.  The kernel is
-FP32-VALU- and divergence-bound (SURVEY.md 8d), so that HBM fraction is tiny by construction;
-`roofline_valu` reports the figure that actually bounds it.  `cpu_baseline` times the same
-generated source compiled for the host (oracle/host_build.py, "port") on a bounded sample.
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (ptl_render_kernel).  The kernel is FP32-VALU-bound
+(~10^3 flop per framebuffer byte), so `roofline.bound` is "valu": achieved = algorithmic binary32 operations
+per bounce-loop trip -- counted by the numpy oracle on a >= 1 % pixel sample of THIS full-size frame, restricted to operations
+with a ray-dependent operand when the timed kernel has the scene uniforms baked in (tools/count_flops.py ->
+profiles/r02/flops_per_segment.json) -- x the trips of this launch (counted on the GPU) / the kernel's mean launch time
+(HIP events on the launch stream).  `roofline.valu_issue_frac` is the share of the SIMDs' VALU issue cycles the kernel uses
+(SQ_INSTS_VALU from the committed rocprofv3 PMC pass of the same build) and `roofline.traffic` the HBM bytes per launch from the
+FETCH_SIZE / WRITE_SIZE passes: STORED figures, named in `roofline.pmc_source`, not re-measured by this run.  `roofline_hbm` is
+the framebuffer store (4 B/pixel) against HBM peak: tiny by construction.  `cpu_baseline` times the same generated source
+compiled for the host (oracle/host_build.py, "port") on a bounded sample.
 """
 from __future__ import annotations
 
@@ -35,27 +39,53 @@ FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 
 
 
-def profiled_traffic(args, build):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_*.json: FETCH_SIZE and
-    WRITE_SIZE are collected in separate passes, KB units, FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md) -- only when that profile is of exactly this workload and build, else None."""
-    if (args.scene, args.width, args.height, args.depth, args.aa, args.specialize) != ("portal_in_portal", 3840, 2160, 40, 1, 2):
-        return None
+def workload_key(args):
+    key = f"{args.scene}_{args.width}x{args.height}_d{args.depth}" + (f"_aa{args.aa}" if args.aa != 1 else "")
+    if args.panini >= 0.0:
+        key += "_panini" if (args.panini == 1.0 and args.fov == 140.0) else f"_panini{args.panini}_fov{args.fov}"
+    elif args.fov != 90.0:
+        key += f"_fov{args.fov}"
+    return key
+
+
+def stored_pmc(args, build):
+    """The committed rocprofv3 PMC passes of exactly this workload and build (profiles/r02/pmc_<workload>_<spec>_<build>.json, one
+    counter group per pass, tools/collect_pmc.sh): HBM bytes per launch (FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md, + WRITE_SIZE, KB units) and SQ_INSTS_VALU per launch.  None when there is no such file."""
+    spec = {0: "dynamic", 1: "ints", 2: "spec"}[args.specialize]
+    for rnd in ("r02", "r01"):
+        name = f"pmc_{workload_key(args)}_{spec}_{build}.json" if rnd == "r02" else f"pmc_pip4k_spec_{build}.json"
+        if rnd == "r01" and (workload_key(args), args.specialize) != ("portal_in_portal_3840x2160_d40", 2):
+            continue
+        path = os.path.join(HERE, "profiles", rnd, name)
+        try:
+            c = json.load(open(path))["counters"]
+            return {"traffic": int((2 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024),
+                    "insts_valu": float(c["SQ_INSTS_VALU"]["mean_per_launch"]), "source": os.path.relpath(path, HERE)}
+        except Exception:
+            continue
+    return None
+
+
+def flops_per_segment(args):
+    """Binary32 operations per bounce-loop trip (fma = 2) on a pixel sample of this full-size frame (tools/count_flops.py):
+    (`flops_varying`, the ray-dependent ones, when the timed kernel has every scene uniform baked in and so folds the rest;
+    `flops`, all of them, for a kernel that reads the uniforms at run time).  Data file only."""
     try:
-        c = json.load(open(os.path.join(HERE, "profiles", "r01", f"pmc_pip4k_spec_{build}.json")))["counters"]
-        return int((2 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+        entry = json.load(open(os.path.join(HERE, "profiles", "r02", "flops_per_segment.json")))[workload_key(args)]
     except Exception:
         return None
+    which = "flops_varying" if args.specialize == 2 else "flops"
+    return {"flops": float(entry["per_segment"][which]), "which": which, "sampled_pixels": entry["sampled_pixels"],
+            "sampled_fraction_of_frame": entry["sampled_fraction_of_frame"], "all_flops": float(entry["per_segment"]["flops"])}
 
 
-def flops_per_segment(scene: str):
-    """Executed binary32 operations per bounce-loop trip (fma = 2), counted by the numpy oracle
-    on the scaled-down golden frame of the scene (tests/golden/make_golden.py).  Data file only."""
-    import glob
-
-    for path in glob.glob(os.path.join(HERE, "tests", "golden", scene + "_*.npz")):
-        return float(np.load(path)["flops_per_segment"])
-    return None
+WORKLOADS = {  # --workload NAME: BASELINE.json configs by name
+    "c2": dict(scene="monoportal", width=1920, height=1080, depth=20, aa=1),
+    "c3": dict(scene="triple_portal", width=3840, height=2160, depth=40, aa=1),
+    "c4": dict(scene="portal_in_portal", width=3840, height=2160, depth=40, aa=1),
+    "c5": dict(scene="mobius_monoportal", width=7680, height=4320, depth=64, aa=4),  # the divergent-ray stress config: ~17 ms per frame on one GPU
+}
 
 
 def parse_args():
@@ -63,6 +93,8 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--workload", default="", choices=[""] + sorted(WORKLOADS), help="a BASELINE.json config by name (c4 = the headline = the default; "
+                   "c5 = mobius_monoportal 8K aa 4 depth 64, the second scaling workload: its per-rank trace stays far above collective latency at 8 GPUs)")
     p.add_argument("--scene", default="portal_in_portal")
     p.add_argument("--width", type=int, default=3840)
     p.add_argument("--height", type=int, default=2160)
@@ -76,7 +108,10 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     p.add_argument("--save-png", default="")
-    return p.parse_args()
+    args = p.parse_args()
+    for k, v in WORKLOADS.get(args.workload, {}).items():
+        setattr(args, k, v)
+    return args
 
 
 def cpu_baseline(args, pa):
@@ -231,7 +266,7 @@ def main():
     transports = {}
     transport_notes = {}
     if world == 1 or mode in ("gather", "auto"):
-        transports["rccl-gather"] = parallel.GatherTransport(H, W, rank, world, dev, stage_through_host=staged)
+        transports["rccl-gather"] = parallel.GatherTransport(H, W, rank, world, dev, depth=3, stage_through_host=staged)  # two gathers in flight behind the trace
     if world > 1 and mode in ("p2p", "auto"):
         ok, peer = 1, None
         try:
@@ -315,10 +350,29 @@ def main():
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     elapsed, last = timed_steps(transport, args.steps, events)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
-    kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+    per_rank_ms = [kernel_ms]
+    if world > 1:  # every rank's own kernel time: load balance of the interleave, and the slowest sets the frame
+        gathered = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([kernel_ms], dtype=torch.float64, device=dev))
+        per_rank_ms = [float(t.item()) for t in gathered]
+    kernel_ms = max(per_rank_ms)
+
+    # untimed, N > 1: the LAST frame of the timed region, as assembled on rank 0 by the kept transport, against the same frame
+    # rendered by rank 0 alone (one launch, no sharding, no transport).  On one GPU the transports were rehearsed with every rank on
+    # the same device; this is the check that a fence / visibility problem on real xGMI cannot get past.
+    frame_check = None
     if world > 1:
-        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
-    kernel_ms = float(kms.item())
+        assembled = transport.download(last) if rank == 0 else None
+        ok = torch.tensor([1], dtype=torch.int32, device=dev)
+        if rank == 0:
+            whole = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
+            renderer.draw_device(pa.Frame(W, H, 0, 1), out_rgba8=whole.data_ptr(), stream=stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            same = bool(np.array_equal(assembled, whole.cpu().numpy()))
+            ok[0] = 1 if same else 0
+            del whole
+        dist.broadcast(ok, 0)
+        frame_check = {"last_timed_frame_equals_the_frame_rendered_by_rank0_alone": bool(int(ok.item()) == 1)}
 
     # bounce-loop trips per frame (untimed, separate kernel variant with the counter compiled in)
     segments = None
@@ -353,6 +407,43 @@ def main():
         except Exception as e:
             print(f"[bench] dynamic-uniform timing unavailable: {e}", file=sys.stderr)
 
+    # untimed, N = 1 only: the tolerance mode (FLAG_FAST_MATH) on the same frame: kernel time and how far its picture is from the exact one
+    fast = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            f32 = torch.empty((2, H, W, 4), dtype=torch.float32, device=dev)
+            exact_r = pa.SceneRenderer(scene, device=local_rank, flags=spec_flags)
+            fast_r = pa.SceneRenderer(scene, device=local_rank, flags=spec_flags | pa.FLAG_FAST_MATH)
+            for k, rr in enumerate((exact_r, fast_r)):
+                configure(rr, args)
+                rr.draw_device(frame, out_rgba8=shard.data_ptr(), out_rgba32f=f32[k].data_ptr(), stream=stream.cuda_stream)
+            for _ in range(8):
+                fast_r.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream)
+            fast_ms = float(np.median([fast_r.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(16)]))
+            torch.cuda.synchronize(dev)
+            err = (f32[0, :, :, :3] - f32[1, :, :, :3]).abs().amax(dim=2)
+            fast = {"kernel_ms": round(fast_ms, 4), "pixels_beyond_1e-5": int((err > 1e-5).sum().item()), "pixels": W * H,
+                    "median_abs_error": float(err.median().item()), "note": "hardware rcp/sqrt estimates, a/b = a*rcp(b), FMA contraction; NOT the measured value above"}
+            del f32, exact_r, fast_r
+        except Exception as e:
+            print(f"[bench] fast-math timing unavailable: {e}", file=sys.stderr)
+
+    # untimed, N = 1 only: what the JIT of the timed build costs on a cold cache (child process, private empty cache, comgr cache off)
+    jit_seconds = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        try:
+            import subprocess
+            import tempfile
+
+            child = ("import sys, time; sys.path.insert(0, sys.argv[1]); import portal_amd as pa; s = pa.Scene.from_file(sys.argv[2]); t = time.perf_counter(); "
+                     "pa.SceneRenderer(s, device=-1, flags=int(sys.argv[3])); print(time.perf_counter() - t)")
+            with tempfile.TemporaryDirectory() as tmp:
+                done = subprocess.run([sys.executable, "-c", child, HERE, pa.scene_path(args.scene), str(spec_flags | pa.flag_waves(best_waves))],
+                                      env=dict(os.environ, PTL_CACHE_DIR=tmp, AMD_COMGR_CACHE="0"), capture_output=True, text=True, timeout=300)
+            jit_seconds = round(float(done.stdout.strip().splitlines()[-1]), 3)
+        except Exception as e:
+            print(f"[bench] jit timing unavailable: {e}", file=sys.stderr)
+
     if rank == 0:
         if args.save_png:
             pa.png_write(args.save_png, transport.download(last))
@@ -386,28 +477,51 @@ def main():
                 **({"transport": transport.name, "transport_ms_per_frame": transport_ms, "transport_notes": transport_notes} if world > 1 else {}),
             },
             "kernel_ms": round(kernel_ms, 4),
+            # per rank: the interleave's load balance; ms_per_step - max(kernel_ms_per_rank) = what assembling the frame costs on top of tracing
+            "kernel_ms_per_rank": [round(x, 4) for x in per_rank_ms],
+            "kernel_ms_min_max": [round(min(per_rank_ms), 4), round(max(per_rank_ms), 4)],
+            "transport_ms": round(max(0.0, ms_per_step - max(per_rank_ms)), 4),
         }
+        if frame_check is not None:
+            out["frame_check"] = frame_check
+        if jit_seconds is not None:
+            out["jit_seconds"] = jit_seconds  # cold compile of the timed build (hiprtc, -O1); cached on disk by source + options + toolchain hash afterwards
+        if fast is not None:
+            out["fast_math_mode"] = fast
         if dynamic_ms is not None:
             out["kernel_ms_without_jit_specialisation"] = round(dynamic_ms, 4)
+        pmc = stored_pmc(args, best)
         hbm = {
             "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-            "traffic": profiled_traffic(args, best),
+            "traffic": pmc["traffic"] if pmc else None,
             "note": "algorithmic bytes = the RGBA8 framebuffer store (4 B/pixel); constants and textures are cache-resident",
         }
         if segments is not None:
             out["segments_per_frame"] = segments
             out["segment_mray_s"] = round(segments / (ms_per_step * 1e-3) / 1e6, 3)
-        fl = flops_per_segment(args.scene)
+        fl = flops_per_segment(args)
         if segments is not None and fl:
-            # the binding roofline: binary32 arithmetic.  MI355X's f32 MFMA peak equals its f32 vector peak
-            # (157.3 TFLOP/s); this path has no contraction for the matrix cores, it runs on the VALU.
-            tf = segments / world * fl / (kernel_ms * 1e-3) / 1e12
-            out["roofline"] = {
-                "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5),
+            # the binding roofline: binary32 arithmetic on the vector ALU (157.3 TFLOP/s; the f32 MFMA instructions run on the same
+            # FMA lanes and do not overlap with VALU work: tools/mfma_probe.hip, profiles/r02/mfma_probe.jsonl)
+            tf = segments / world * fl["flops"] / (kernel_ms * 1e-3) / 1e12
+            roof = {
+                "bound": "valu", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5),
                 "traffic": hbm["traffic"],
-                "note": "compute-bound (FP32 VALU; f32 vector peak == f32 MFMA peak, no MFMA used). achieved = algorithmic binary32 ops per "
-                        f"bounce-loop trip ({fl:.0f}, fma=2, counted by the numpy oracle on the un-specialised arithmetic) x trips per launch / kernel time",
+                "flops_per_segment": round(fl["flops"], 1), "flops_counted": fl["which"], "flops_sample_pixels": fl["sampled_pixels"],
+                "flops_source": "profiles/r02/flops_per_segment.json (tools/count_flops.py: numpy oracle on a seeded pixel sample of this full-size frame)",
+                "note": "FP32-VALU-bound, no MFMA. achieved = binary32 operations per bounce-loop trip (fma = 2; / and sqrt = 1 each although they cost "
+                        "11 and 14 instructions) x trips of this launch (counted on the GPU) / kernel time."
+                        + (" Counted: operations with a ray-dependent operand -- the timed kernel has the scene uniforms baked in and folds the rest "
+                           f"({fl['all_flops']:.0f} per trip with them)." if fl["which"] == "flops_varying" else " Counted: every operation (uniforms are read at run time)."),
             }
+            if pmc:
+                # VALU issue: wave64 instructions x 2 cycles (the full-rate class) / (1024 SIMDs x kernel time x 2.4 GHz).  A floor: compares and
+                # division helpers take 4 cycles, transcendentals 8 (profiles/r01/valu_rates.jsonl), and the sustained clock is below 2.4 GHz.
+                roof["valu_issue_frac"] = round(pmc["insts_valu"] / world * 2.0 / 1024.0 / (kernel_ms * 1e-3 * 2.4e9), 4)
+                roof["valu_insts_per_launch"] = pmc["insts_valu"]
+                roof["frac_ceiling_from_pmc"] = round(64 * 2 * pmc["insts_valu"] / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)  # every VALU instruction a full-width FMA
+                roof["pmc_source"] = pmc["source"] + " (stored rocprofv3 PMC passes of this build, not re-measured by this run)"
+            out["roofline"] = roof
             out["roofline_hbm"] = hbm
         else:
             out["roofline"] = hbm

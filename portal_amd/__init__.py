@@ -691,6 +691,8 @@ def ron_format(text: str) -> str:
 
 def translate_glsl(code: str) -> str:
     p = lib().ptl_translate_glsl(code.encode("utf-8"))
+    if not p:
+        raise PortalError(_err())
     try:
         return C.string_at(p).decode("utf-8")
     finally:

@@ -115,6 +115,34 @@ PTL_FN SurfaceIntersection plane_intersect(Ray r, const mat4& plane_inv, vec3 no
     return result;
 }
 
+// Wave-level exact cull of a plane test.  A plane only matters to scene_intersect if its hit is NEARER than the best one so far
+// (nearer(): hit, t > 0, t < best).  Two things that follow from the z row of plane_inv * ray alone -- 8 FMAs that the full test
+// evaluates anyway -- settle that without the square root and the three correctly rounded divisions of plane_intersect:
+//   behind   o'.z and d'.z have the same sign: the quotient -o'.z / d'.z is negative (or rounds to -0), so t < 0 or t is not > 0;
+//   farther  a lower bound of t, -o'.z * rcp(d'.z) * (1 - 2^-16), is already above `best_t`.  (The exact chain and this estimate
+//            differ by less than a dozen rounding errors, < 2^-20 relative; NaN and infinity compare false / consistently.)
+// A cull decides nothing about the picture -- the culled test could never have been selected -- so frames stay bit-identical;
+// what it saves is the work.  It is taken per WAVE (ballot): the 64 rays of an 8x8 tile nearly always agree about which walls are
+// behind them or beyond the surface they have already found, and a uniform branch costs a scalar compare.
+PTL_FN bool ptl_plane_cull(const Ray& r, const mat4& plane_inv, float best_t) {
+#if defined(PTL_NO_PLANE_CULL)
+    (void)r; (void)plane_inv; (void)best_t;
+    return false;
+#else
+    const float oz = (plane_inv * r.o).z;
+    const float dz = (plane_inv * r.d).z;
+    const bool behind = (oz > 0.0f && dz > 0.0f) || (oz < 0.0f && dz < 0.0f);
+#if PTL_DEVICE_BUILD
+    const float t_low = (-oz * __builtin_amdgcn_rcpf(dz)) * (1.0f - 0x1p-16f);
+    return __builtin_amdgcn_ballot_w64(!(behind || t_low > best_t)) == 0ull;
+#else
+    const float t_low = (-oz * (1.0f / dz)) * (1.0f - 0x1p-16f);
+    return behind || t_low > best_t;
+#endif
+#endif
+}
+#define PTL_BEST_T(i) ((i).hit.hit ? (i).hit.t : __builtin_inff())
+
 // plane_intersect with the ray-independent half done beforehand: `unit_normal` = normalize(normal) comes from the
 // prologue kernel (ptl_tracer::derive); `flipped` tells the caller which of the two precomputed is_collinear verdicts applies.
 PTL_FN SurfaceIntersection plane_intersect_derived(Ray r, const mat4& plane_inv, vec3 unit_normal, bool& flipped) {

@@ -1102,7 +1102,13 @@ extern "C" const char* ptl_device_source(const char* which) {
 
 extern "C" char* ptl_translate_glsl(const char* glsl) {
     if (!glsl) return nullptr;
-    std::string out = translate_glsl(glsl);
+    std::string out;
+    try {
+        out = translate_glsl(glsl);
+    } catch (const std::exception& e) {  // e.g. a struct field that spells a swizzle: NULL + ptl_last_error()
+        set_last_error(e.what());
+        return nullptr;
+    }
     char* p = (char*)std::malloc(out.size() + 1);
     std::memcpy(p, out.c_str(), out.size() + 1);
     return p;

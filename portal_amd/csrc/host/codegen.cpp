@@ -528,19 +528,21 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 // (ptl_tracer::derive below evaluates exactly the expressions of the plain form)
                 auto derived_test = [&](const DerivedPlane& d, const std::string& inv, const std::string& process_open, const std::string& extra_args,
                                         const std::string& process_close) {
+                    s.add_string("if (!ptl_plane_cull(r, " + inv + ", PTL_BEST_T(i))) {\n");
                     s.add_string("hit = plane_intersect_derived(r, " + inv + ", PTL_U." + d.member + "_nrm, flipped);\n");
                     s.add_string("if (nearer(i, hit)) { i = " + process_open + "is_inside_" + p + "(r.o + r.d * hit.t, hit.u, hit.v, ((PTL_U." + d.member +
-                                 "_col >> (flipped ? 1 : 0)) & 1) != 0" + extra_args + ")" + process_close + "; }\n\n");
+                                 "_col >> (flipped ? 1 : 0)) & 1) != 0" + extra_args + ")" + process_close + "; }\n}\n\n");
                 };
                 if (!o.portal) {
                     const std::string& m = matrix_name(scene, o.m0, o);
                     if (const DerivedPlane* d = derived_of(0)) {
                         derived_test(*d, inverse_name(m), "process_plane_intersection(i, hit, ", "", ")");
                     } else {
+                        s.add_string("if (!ptl_plane_cull(r, " + inverse_name(m) + ", PTL_BEST_T(i))) {\n");
                         s.add_string("normal = -get_normal(" + normal_name(m) + ");\n");
                         s.add_string("hit = plane_intersect(r, " + inverse_name(m) + ", get_normal(" + normal_name(m) + "));\n");
                         s.add_string("if (nearer(i, hit)) { i = process_plane_intersection(i, hit, is_inside_" + p +
-                                     "(r.o + r.d * hit.t, hit.u, hit.v, is_collinear(hit.n, normal))); }\n\n");
+                                     "(r.o + r.d * hit.t, hit.u, hit.v, is_collinear(hit.n, normal))); }\n}\n\n");
                     }
                 } else {
                     auto side = [&](const std::string& m, bool first, const std::string& material) {
@@ -548,10 +550,11 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                             derived_test(*d, inverse_name(m), "process_portal_intersection(i, hit, ", std::string(", ") + bool_lit(first), ", " + material + ")");
                             return;
                         }
+                        s.add_string("if (!ptl_plane_cull(r, " + inverse_name(m) + ", PTL_BEST_T(i))) {\n");
                         s.add_string(std::string("normal = ") + (first ? "-" : "") + "get_normal(" + normal_name(m) + ");\n");
                         s.add_string("hit = plane_intersect(r, " + inverse_name(m) + ", normal);\n");
                         s.add_string("if (nearer(i, hit)) { i = process_portal_intersection(i, hit, is_inside_" + p +
-                                     "(r.o + r.d * hit.t, hit.u, hit.v, is_collinear(hit.n, normal), " + bool_lit(first) + "), " + material + "); }\n\n");
+                                     "(r.o + r.d * hit.t, hit.u, hit.v, is_collinear(hit.n, normal), " + bool_lit(first) + "), " + material + "); }\n}\n\n");
                     };
                     const std::string& a = matrix_name(scene, o.m0, o);
                     const std::string& b = matrix_name(scene, o.m1, o);

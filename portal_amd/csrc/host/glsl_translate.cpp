@@ -1,6 +1,8 @@
 // glsl_translate.cpp -- see glsl_translate.h.
 #include "glsl_translate.h"
 
+#include <stdexcept>
+
 #include <cctype>
 #include <cstring>
 #include <set>
@@ -182,6 +184,36 @@ std::string translate_glsl(const std::string& glsl) {
             if (toks[k].kind != Token::Space && toks[k].kind != Token::Comment) return &toks[k];
         return nullptr;
     };
+
+    // The translation works on tokens, not on types: `.xy` after ANY expression becomes a swizzle call.  A user struct with a field
+    // that spells a swizzle (`struct S { vec2 st; }` ... `s.st`) would silently turn into s.sw<0,1>(): refuse it with a message
+    // that names the field instead of leaving the scene author with a hiprtc error (or none).  The reference's corpus has no such field.
+    {
+        int brace = 0, struct_brace = -1;
+        bool struct_head = false;
+        for (size_t k = 0; k < toks.size(); ++k) {
+            const Token& t = toks[k];
+            if (t.kind == Token::Ident && t.text == "struct") struct_head = true;
+            if (t.kind != Token::Punct && t.kind != Token::Ident) continue;
+            if (t.kind == Token::Punct && t.text == "{") {
+                ++brace;
+                if (struct_head) {
+                    struct_brace = brace;
+                    struct_head = false;
+                }
+            } else if (t.kind == Token::Punct && t.text == "}") {
+                if (brace == struct_brace) struct_brace = -1;
+                --brace;
+            } else if (t.kind == Token::Punct && t.text == ";") {
+                struct_head = false;  // `struct S;` or a variable of struct type: no body
+            } else if (t.kind == Token::Ident && struct_brace == brace && brace > 0) {
+                const Token* nx = next_sig(k);
+                if (nx && nx->kind == Token::Punct && (nx->text == ";" || nx->text == "," || nx->text == "[") && !swizzle_indices(t.text).empty())
+                    throw std::runtime_error("struct field `" + t.text + "` spells a vector swizzle (xyzw / rgba / stpq): the GLSL -> HIP translation "
+                                             "cannot tell `value." + t.text + "` from a swizzle; rename the field");
+            }
+        }
+    }
 
     int paren_depth = 0;
     bool pending_ref = false;  // an `out` / `inout` qualifier was seen: next type name gets `&`

@@ -1,5 +1,10 @@
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE  // dlmopen
+#endif
 // hip_api.cpp -- see hip_api.h.
 #include "hip_api.h"
+
+#include <stdlib.h>
 
 #include <dlfcn.h>
 #include <link.h>
@@ -34,11 +39,18 @@ std::string loaded_library_path(const char* stem) {
     return ctx.found;
 }
 
-void* open_first(const std::vector<std::string>& candidates, std::string* chosen, std::string* error) {
+// `isolated`: load into a link-map namespace of its own (dlmopen).  For the COMPILER: hiprtc finds its code generator
+// (libamd_comgr, i.e. LLVM) by soname, so inside a PyTorch process -- which has loaded its own, older comgr -- /opt/rocm's hiprtc
+// would silently compile with PyTorch's LLVM, and the same source would give different code objects with and without
+// `import torch` (measured: 109 800 vs 110 568 bytes for scenes/basics.ron).  In a fresh namespace hiprtc resolves its
+// dependencies from its own directory: one compiler, whatever else the process has loaded.
+void* open_first(const std::vector<std::string>& candidates, std::string* chosen, std::string* error, bool isolated = false) {
     std::string errs;
     for (const std::string& c : candidates) {
         if (c.empty()) continue;
-        void* h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+        void* h = nullptr;
+        if (isolated && c[0] == '/') h = dlmopen(LM_ID_NEWLM, c.c_str(), RTLD_NOW);
+        if (!h) h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (h) {
             *chosen = c;
             return h;
@@ -111,15 +123,20 @@ const Rtc* rtc(std::string* error) {
         tried = true;
         const char* env = std::getenv("PTL_HIPRTC_LIB");
         std::string loaded_rt = loaded_library_path("libamdhip64.so");
-        std::vector<std::string> candidates = {env ? env : "", loaded_library_path("libhiprtc.so"), "/opt/rocm/lib/libhiprtc.so",
+        // The compiler is NOT shared state (unlike the runtime above, whose streams and pointers must be the process's own): always
+        // take the system toolchain when there is one, so that a kernel is built by the same compiler whether or not PyTorch -- which
+        // bundles an older hiprtc -- happens to be loaded.  The code-object cache key names the library that did the work.
+        std::vector<std::string> candidates = {env ? env : "", "/opt/rocm/lib/libhiprtc.so", loaded_library_path("libhiprtc.so"),
                                                loaded_rt.empty() ? "" : dir_of(loaded_rt) + "libhiprtc.so", "libhiprtc.so"};
-        void* h = open_first(candidates, &r.path, &err);
+        void* h = open_first(candidates, &r.path, &err, /*isolated=*/std::getenv("PTL_HIPRTC_SHARED") == nullptr);
         if (h) {
             ok = bind(h, "hiprtcCreateProgram", r.hiprtcCreateProgram, &err) && bind(h, "hiprtcCompileProgram", r.hiprtcCompileProgram, &err) &&
                  bind(h, "hiprtcGetProgramLogSize", r.hiprtcGetProgramLogSize, &err) && bind(h, "hiprtcGetProgramLog", r.hiprtcGetProgramLog, &err) &&
                  bind(h, "hiprtcGetCodeSize", r.hiprtcGetCodeSize, &err) && bind(h, "hiprtcGetCode", r.hiprtcGetCode, &err) &&
                  bind(h, "hiprtcDestroyProgram", r.hiprtcDestroyProgram, &err) && bind(h, "hiprtcGetErrorString", r.hiprtcGetErrorString, &err) &&
                  bind(h, "hiprtcVersion", r.hiprtcVersion, &err);
+            char resolved[4096];
+            r.real_path = ::realpath(r.path.c_str(), resolved) ? resolved : r.path;
         }
     }
     if (!ok && error) *error = "hiprtc unavailable: " + err;

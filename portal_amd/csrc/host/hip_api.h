@@ -73,6 +73,7 @@ constexpr int kErrorPeerAccessAlreadyEnabled = 704;
 
 struct Rtc {
     std::string path;
+    std::string real_path;  // symlinks resolved: ".../libhiprtc.so.7.2.70200" -- the toolchain's identity (hiprtcVersion() is a constant 9.0)
     hiprtcResult (*hiprtcCreateProgram)(hiprtcProgram*, const char*, const char*, int, const char**, const char**);
     hiprtcResult (*hiprtcCompileProgram)(hiprtcProgram, int, const char**);
     hiprtcResult (*hiprtcGetProgramLogSize)(hiprtcProgram, size_t*);

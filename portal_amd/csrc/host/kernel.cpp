@@ -113,6 +113,9 @@ struct ptl_kernel {
     std::map<std::string, Slot> slots;
     std::map<std::string, void*> textures;  // sampler -> device texel buffer
     hip::hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned block_waves = 4;       // PTL_BLOCK_WAVES (experiments with narrower workgroups), read once at compile time
+    void* last_stream = nullptr;    // the stream of the most recent render launch ...
+    bool launched = false;          // ... which may still be reading the uniform block
 };
 
 extern "C" const char* ptl_last_error(void) { return g_last_error.c_str(); }
@@ -122,7 +125,12 @@ extern "C" const char* ptl_version(void) {
     std::string e1, e2;
     const hip::Runtime* rt = hip::runtime(&e1);
     const hip::Rtc* rc = hip::rtc(&e2);
-    v = std::string("portal_amd 0.1; hip=") + (rt ? rt->path : "<none>") + "; hiprtc=" + (rc ? rc->path : "<none>");
+    std::string toolchain = "?";  // "7.2.70200" out of ".../libhiprtc.so.7.2.70200"
+    if (rc) {
+        size_t so = rc->real_path.rfind(".so.");
+        if (so != std::string::npos) toolchain = rc->real_path.substr(so + 4);
+    }
+    v = std::string("portal_amd 0.2; hip=") + (rt ? rt->path : "<none>") + "; hiprtc=" + (rc ? rc->path : "<none>") + "; hiprtc_version=" + toolchain;
     return v.c_str();
 }
 
@@ -151,7 +159,10 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
     if (log && log_cap) log[0] = '\0';
     if (!hip_source || !out) return PTL_ERR_INVALID;
     *out = nullptr;
-    auto k = std::make_unique<ptl_kernel>();
+    struct Destroy {
+        void operator()(ptl_kernel* p) const { ptl_kernel_destroy(p); }  // error paths below: unload the module, free events and textures
+    };
+    std::unique_ptr<ptl_kernel, Destroy> k(new ptl_kernel());
     k->device = device;
     for (int i = 0; i < n_uniforms; ++i) {
         k->slots[uniforms[i].name] = {uniforms[i].type, uniforms[i].offset};
@@ -169,12 +180,20 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
     if (!cdir.empty()) {
         unsigned long long h = fnv1a(hip_source);
         for (auto& o : opts) h = fnv1a(o, h);
+        // ... produced by THIS toolchain: the cache travels between machines (build container -> GPU box), and the options above exist to
+        // dodge a fault of one particular compiler.  hiprtc's version and the path it was loaded from go into the key.
+        std::string err;
+        if (const hip::Rtc* rc = hip::rtc(&err)) {
+            h = fnv1a("hiprtc " + rc->real_path, h);  // ".../libhiprtc.so.7.2.70200"
+        }
         char name[64];
         std::snprintf(name, sizeof name, "/ptl_%016llx.hsaco", h);
         cache_path = cdir + name;
         std::ifstream f(cache_path, std::ios::binary);
         if (f) k->code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        if (k->code.size() < 64 || std::memcmp(k->code.data(), "\x7f" "ELF", 4) != 0) k->code.clear();  // truncated or foreign file: compile again
     }
+    bool from_cache = !k->code.empty();
     if (k->code.empty()) {
         std::string err;
         const hip::Rtc* rc = hip::rtc(&err);
@@ -233,7 +252,14 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
         return PTL_ERR_NO_DEVICE;
     }
     if (!hip_ok(rt, rt->hipSetDevice(device), "hipSetDevice")) return PTL_ERR_HIP;
-    if (!hip_ok(rt, rt->hipModuleLoadData(&k->module, k->code.data()), "hipModuleLoadData")) return PTL_ERR_HIP;
+    if (!hip_ok(rt, rt->hipModuleLoadData(&k->module, k->code.data()), "hipModuleLoadData")) {
+        if (from_cache && !cache_path.empty()) {
+            // a cached code object this runtime refuses (other GPU, damaged file): drop it and build from source once
+            std::remove(cache_path.c_str());
+            return ptl_kernel_compile(device, hip_source, uniforms, n_uniforms, uniform_block_size, defines, n_defines, out, log, log_cap);
+        }
+        return PTL_ERR_HIP;
+    }
     if (!hip_ok(rt, rt->hipModuleGetFunction(&k->fn, k->module, "ptl_render_kernel"), "hipModuleGetFunction(ptl_render_kernel)"))
         return PTL_ERR_HIP;
     if (rt->hipModuleGetFunction(&k->teleport_fn, k->module, "ptl_teleport_kernel") != 0) {
@@ -253,6 +279,7 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
     }
     rt->hipEventCreate(&k->ev0);
     rt->hipEventCreate(&k->ev1);
+    if (const char* e = std::getenv("PTL_BLOCK_WAVES")) k->block_waves = (e[0] == '1' || e[0] == '2') ? (unsigned)(e[0] - '0') : 4u;
     *out = k.release();
     return PTL_OK;
 }
@@ -360,11 +387,12 @@ extern "C" int ptl_kernel_render(ptl_kernel* k, const ptl_frame* frame, void* ou
     int in_place = frame->in_place ? 1 : 0;
     void* args[] = {&out_rgba8, &out_rgba32f, &width, &height, &phase, &stride, &segments, &in_place};
     // 256 threads = four 8x8 tiles side by side.  PTL_BLOCK_WAVES=1|2 (experiment, tools/variants.py) launches narrower workgroups.
-    unsigned waves = 4;
-    if (const char* e = std::getenv("PTL_BLOCK_WAVES")) waves = (e[0] == '1' || e[0] == '2') ? (unsigned)(e[0] - '0') : 4u;
+    const unsigned waves = k->block_waves;
     unsigned gx = (unsigned)((width + 8 * waves - 1) / (8 * waves)), gy = (unsigned)nby;
     if (elapsed_ms) rt->hipEventRecord(k->ev0, stream);
     if (!hip_ok(rt, rt->hipModuleLaunchKernel(k->fn, gx, gy, 1, 64 * waves, 1, 1, 0, stream, args, nullptr), "hipModuleLaunchKernel")) return PTL_ERR_HIP;
+    k->last_stream = stream;
+    k->launched = true;
     if (elapsed_ms) {
         rt->hipEventRecord(k->ev1, stream);
         if (!hip_ok(rt, rt->hipEventSynchronize(k->ev1), "hipEventSynchronize")) return PTL_ERR_HIP;
@@ -422,6 +450,9 @@ extern "C" int ptl_kernel_teleport_ray(ptl_kernel* k, const float a[3], const fl
     if (rc < 0) return rc;
     const hip::Runtime* rt = hip::runtime(nullptr);
     if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;
+    // The query rewrites the module's ONE uniform block (segment end points, teleport_light_u) and runs on the NULL stream; a frame
+    // launched on a non-blocking stream may still be reading the block: wait for it first.
+    if (k->launched && k->last_stream != nullptr && !hip_ok(rt, rt->hipStreamSynchronize(k->last_stream), "hipStreamSynchronize(render stream)")) return PTL_ERR_HIP;
     if (int rc2 = upload_uniforms(k, rt, nullptr); rc2 != PTL_OK) return rc2;
     void* dev_out = nullptr;
     if (!hip_ok(rt, rt->hipMalloc(&dev_out, 8 * sizeof(float)), "hipMalloc(teleport result)")) return PTL_ERR_HIP;
@@ -443,6 +474,7 @@ extern "C" void ptl_kernel_destroy(ptl_kernel* k) {
     const hip::Runtime* rt = k->device >= 0 ? hip::runtime(nullptr) : nullptr;
     if (rt) {
         rt->hipSetDevice(k->device);
+        if (k->launched) rt->hipStreamSynchronize(k->last_stream);  // a re-JIT replaces the handle: nothing may still run from the old module
         for (auto& t : k->textures)
             if (t.second) rt->hipFree(t.second);
         if (k->ev0) rt->hipEventDestroy(k->ev0);

@@ -227,6 +227,8 @@ extern "C" int ptl_frame_group_download(ptl_frame_group* g, uint8_t* host_rgba8)
 extern "C" void ptl_frame_group_destroy(ptl_frame_group* g) {
     if (!g) return;
     const hip::Runtime* rt = hip::runtime(nullptr);
+    for (ptl_renderer* r : g->renderers) ptl_renderer_destroy(r);  // first: a kernel handle waits for its last launch's stream
+    g->renderers.clear();
     if (rt) {
         for (size_t k = 0; k < g->streams.size(); ++k) {
             rt->hipSetDevice(g->devices[k]);
@@ -239,6 +241,5 @@ extern "C" void ptl_frame_group_destroy(ptl_frame_group* g) {
         }
         release_buffers(g, rt);
     }
-    for (ptl_renderer* r : g->renderers) ptl_renderer_destroy(r);
     delete g;
 }

@@ -825,6 +825,13 @@ def test_bench_multi_rank_rehearsal_assembles_the_same_frame(gpu, tmp_path, tran
     else:
         assert set(cfg["transport_ms_per_frame"]) == {"rccl-gather", "p2p-stores"} and not cfg["transport_notes"]
     assert np.array_equal(pa.png_read(str(one_png)), pa.png_read(str(tmp_path / "three.png")))
+    # the diagnostics the first real 8-GPU run needs: every rank's kernel time, what assembling costs on top, and the
+    # in-run check of the last timed frame against rank 0 rendering it alone
+    assert len(line["kernel_ms_per_rank"]) == 3 and all(ms > 0 for ms in line["kernel_ms_per_rank"])
+    assert line["kernel_ms_min_max"] == [min(line["kernel_ms_per_rank"]), max(line["kernel_ms_per_rank"])] and line["transport_ms"] >= 0
+    assert line["frame_check"] == {"last_timed_frame_equals_the_frame_rendered_by_rank0_alone": True}
+    single = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert len(single["kernel_ms_per_rank"]) == 1 and "frame_check" not in single and single["roofline"]["bound"] in ("valu", "hbm")
 
 
 def test_in_place_launches_fill_one_frame(gpu):
@@ -1017,4 +1024,15 @@ def test_greedy_regalloc_miscompile_stays_fixed(gpu, tmp_path):
     child.write_text(_MISCOMPILE_CHILD)
     env = dict(os.environ, PTL_VGPR_REGALLOC="default", PTL_CACHE_DIR=str(tmp_path / "cache"))
     out = subprocess.run([sys.executable, str(child), pa.REPO_ROOT, str(path), str(tmp_path / "want.npy")], capture_output=True, text=True, timeout=600, env=env)
-    print("toolchain's own allocator choice:", out.stdout.strip() or out.stderr[-300:], "(3 on ROCm 7.2)")
+    print("toolchain's own allocator choice:", out.stdout.strip() or out.stderr[-300:])
+    # What the toolchain's default (greedy) allocator does to this kernel is RECORDED per hiprtc version, so that a ROCm that
+    # fixes the fault -- or makes it worse -- does not pass unnoticed: then the workaround (and its 0-15 % cost) can go / must stay.
+    recorded = {"7.2.70200": 3}  # libhiprtc.so.<version> -> wrong pixels with PTL_VGPR_REGALLOC=default (ROCm 7.2.0: 3 of 2304)
+    version = pa.version().split("hiprtc_version=")[-1].strip()
+    assert out.returncode == 0 and "wrong pixels:" in out.stdout, out.stderr[-500:]
+    wrong = int(out.stdout.strip().split("wrong pixels:")[-1])
+    if version not in recorded:
+        pytest.xfail(f"hiprtc {version} is not on record: its default VGPR allocator gives {wrong} wrong pixels here; add it to `recorded` "
+                     f"and, if that is 0 for good, drop -vgpr-regalloc=basic from kernel.cpp")
+    assert wrong == recorded[version], (f"hiprtc {version}: the default allocator now gives {wrong} wrong pixels, on record are {recorded[version]} -- "
+                                        "the toolchain (or the kernel's code shape) changed: re-examine the workaround in kernel.cpp")

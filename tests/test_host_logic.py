@@ -745,3 +745,78 @@ def test_a_c99_program_links_against_the_abi_and_runs(pa, tmp_path):
     run = subprocess.run([str(exe), pa.scene_path("monoportal")], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, (run.returncode, run.stderr)
     assert "source bytes" in run.stdout and "portal_amd" in run.stdout
+
+
+# ---------------------------------------------------------------------------------------------
+# round 2: uniform prologue, tolerance mode, cache hygiene, translator diagnostics, layer 3, precompile
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", SCENES)
+def test_derived_uniforms_cover_every_flat_plane_and_vanish_when_baked(pa, name):
+    """Dynamic-uniform source: every plane test of a Flat object goes through plane_intersect_derived with a `ptl_dv_<object>_<side>`
+    entry that ptl_tracer::derive fills; with the matrices baked in (FLAG_SPECIALIZE_ALL) or with FLAG_NO_DERIVED_UNIFORMS the
+    reference's per-call form is generated.  Derived members sit BEHIND the host-visible layout (uploads never touch them)."""
+    scene = pa.Scene.from_file(pa.scene_path(name))
+    src = scene.generate_source(0)
+    body = src[src.index("PTL_FN SceneIntersection scene_intersect(const Ray& r)"):src.index("// Prologue (ptl_derive_kernel")]
+    tests_in_body = body.count("plane_intersect_derived(")
+    assert tests_in_body > 0 and "plane_intersect(" not in body.replace("plane_intersect_derived(", "")
+    derive = src[src.index("PTL_FN void derive(ptl_uniform_block* out)"):src.index("// Material id -> what happens to the path.")]
+    assert derive.count("_nrm = unit;") == tests_in_body
+    layout, size = scene.uniform_layout()
+    block = src[src.index("struct ptl_uniform_block {"):src.index("};", src.index("struct ptl_uniform_block {"))]
+    members = [l.split()[-1].rstrip(";") for l in block.splitlines()[1:] if l.strip()]
+    first_derived = next(i for i, m in enumerate(members) if m.startswith("ptl_dv_"))
+    assert all(m.startswith("ptl_dv_") for m in members[first_derived:]) and first_derived == len(layout)
+    assert "plane_intersect_derived(r" not in scene.generate_source(pa.FLAG_NO_DERIVED_UNIFORMS)
+    assert "plane_intersect_derived(r" not in scene.generate_source(pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
+
+
+def test_fast_math_is_a_flag_not_a_default(pa, tmp_path, monkeypatch):
+    """FLAG_FAST_MATH only adds the PTL_FAST_MATH define (and with it other compile options): the generated source is the exact
+    kernel's, the code object differs, and the default build is the exact one."""
+    monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path))
+    scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+    assert scene.generate_source(pa.FLAG_FAST_MATH) == scene.generate_source(0)
+    exact = pa.SceneRenderer(scene, device=-1).code_object()
+    fast = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_FAST_MATH).code_object()
+    assert exact[:4] == fast[:4] == b"\x7fELF" and exact != fast and len(fast) < len(exact)  # no division / sqrt expansions
+    assert len(os.listdir(tmp_path)) == 2
+
+
+def test_code_object_cache_rejects_foreign_files_and_names_the_toolchain(pa, tmp_path, monkeypatch):
+    """The cache key covers source + options + the hiprtc library that compiled it; a truncated or non-ELF file under that name is
+    ignored and replaced by a fresh build."""
+    monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path))
+    scene = pa.Scene.from_file(pa.scene_path("basics"))
+    good = pa.SceneRenderer(scene, device=-1).code_object()
+    (name,) = os.listdir(tmp_path)
+    assert re.fullmatch(r"ptl_[0-9a-f]{16}\.hsaco", name)
+    path = tmp_path / name
+    path.write_bytes(b"not a code object")
+    again = pa.SceneRenderer(scene, device=-1).code_object()
+    assert again[:4] == b"\x7fELF" and len(again) == len(good) and path.read_bytes()[:4] == b"\x7fELF"
+    assert re.search(r"hiprtc_version=\d+\.\d+", pa.version())
+
+
+def test_translator_refuses_struct_fields_that_spell_swizzles(pa):
+    assert "a.uv" in pa.translate_glsl("struct A { vec2 uv; float t; }; float f(A a) { return a.uv.x + a.t; }")
+    for field in ("st", "xy", "rgb", "pq"):
+        with pytest.raises(pa.PortalError, match="spells a vector swizzle"):
+            pa.translate_glsl("struct A { vec3 %s; }; float f(A a) { return a.%s.x; }" % (field, field))
+    assert "sw<0,1>()" in pa.translate_glsl("vec2 f(vec4 v) { return v.xy; }")  # ordinary swizzles are untouched
+
+
+def test_frame_group_and_precompile_without_a_gpu(pa, tmp_path):
+    """Layer 3 needs devices: on a box without one it fails with a message, not a crash; `portal-amd precompile` needs none."""
+    import subprocess
+
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(pa.PortalError):
+            pa.FrameGroup(pa.Scene.from_file(pa.scene_path("basics")), [0, 0])
+    exe = os.path.join(ROOT, "portal_amd", "portal-amd")
+    env = dict(os.environ, PTL_CACHE_DIR=str(tmp_path))
+    done = subprocess.run([exe, "precompile", os.path.join(ROOT, "scenes", "basics.ron"), "--specialize", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert done.returncode == 0, done.stderr
+    assert done.stdout.count("code object in") == 2 and len(os.listdir(tmp_path)) == 2

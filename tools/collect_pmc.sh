@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 BUILD=${1:-minreg}
-NAME=${2:-pmc_pip4k_spec_$BUILD}
+NAME=${2:-pmc_portal_in_portal_3840x2160_d40_spec_$BUILD}   # bench.py looks the headline up under profiles/r02/<this name>.json
 mkdir -p $O
 cd /tmp
 rm -rf /tmp/pmc_$NAME

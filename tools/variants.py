@@ -73,6 +73,12 @@ VARIANTS = {
     "r2_all_nowaveloop": "SPECIALIZE_ALL -DPTL_NO_WAVE_LOOP",
     "r2_ints": "SPECIALIZE",
     "r2_ints_noderived": "SPECIALIZE NO_DERIVED",
+    "r2_dyn_nocull": "-DPTL_NO_PLANE_CULL",
+    "r2_all_nocull": "SPECIALIZE_ALL -DPTL_NO_PLANE_CULL",
+    "r2_ints_nocull": "SPECIALIZE -DPTL_NO_PLANE_CULL",
+    "r2_fast_all_nocull": "FAST SPECIALIZE_ALL -DPTL_NO_PLANE_CULL",
+    "r2_all_minreg": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg",
+    "r2_all_minreg_nocull": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg -DPTL_NO_PLANE_CULL",
     "r2_fast_dyn": "FAST",
     "r2_fast_dyn_w4": "FAST -DPTL_WAVES_PER_EU=4",
     "r2_fast_all": "FAST SPECIALIZE_ALL",
