@@ -170,9 +170,10 @@ private:
     std::condition_variable cv_;
 };
 
-// __launch_bounds__(256, 4): never slower than no hint on the BASELINE scenes, 18 % faster on the un-specialised
-// portal_in_portal kernel (profiles/r01/variants8_O1.jsonl, variants9_O1.jsonl)
-constexpr unsigned kRenderFlags = 4u << 8;
+// No occupancy hint: with the basic VGPR allocator (kernel.cpp) a 4-waves bound makes the un-specialised portal_in_portal kernel
+// spill (128 VGPRs + 240 B scratch: 2.19 ms against 1.52 ms at 4K, profiles/r02/variants1_prologue_waveloop_fast.jsonl); the
+// other scenes do not care.  (Round 1, greedy allocator: the hint was a 18 % gain on that kernel.)
+constexpr unsigned kRenderFlags = 0u;
 // frames of a clip are intermediates (ffmpeg reads them, then anim/ is removed): fast deflate, 2.3x the encode rate of level 6
 constexpr int kFrameDeflateLevel = 3;
 

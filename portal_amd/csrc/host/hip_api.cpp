@@ -44,12 +44,43 @@ std::string loaded_library_path(const char* stem) {
 // would silently compile with PyTorch's LLVM, and the same source would give different code objects with and without
 // `import torch` (measured: 109 800 vs 110 568 bytes for scenes/basics.ron).  In a fresh namespace hiprtc resolves its
 // dependencies from its own directory: one compiler, whatever else the process has loaded.
+// A namespace created by dlmopen gets its own copy of libc, whose `environ` is initialised with the address of the process's
+// environment ARRAY at that moment.  The array belongs to the main libc, which reallocates it on setenv/putenv (Python's
+// os.environ[...] = ...): the copy is then left pointing at freed memory and the next getenv inside the namespace (comgr and LLVM
+// read a dozen variables per compile) crashes.  Give the namespace a snapshot of its own, allocated with ITS malloc, that nobody
+// else touches.  (Reproduced and fixed: 400 assignments to os.environ between two compiles segfaulted every time.)
+extern "C" char** environ;
+void give_namespace_its_own_environ(void* handle) {
+    char*** ns_environ = reinterpret_cast<char***>(dlsym(handle, "environ"));
+    auto ns_malloc = reinterpret_cast<void* (*)(size_t)>(dlsym(handle, "malloc"));
+    if (!ns_environ || !ns_malloc || ns_environ == &environ) return;  // not a separate libc after all
+    size_t n = 0;
+    while (environ && environ[n]) ++n;
+    char** copy = static_cast<char**>(ns_malloc((n + 1) * sizeof(char*)));
+    if (!copy) return;
+    for (size_t k = 0; k < n; ++k) {
+        size_t len = std::strlen(environ[k]) + 1;
+        copy[k] = static_cast<char*>(ns_malloc(len));
+        if (!copy[k]) {
+            copy[k] = nullptr;
+            n = k;
+            break;
+        }
+        std::memcpy(copy[k], environ[k], len);
+    }
+    copy[n] = nullptr;
+    *ns_environ = copy;
+}
+
 void* open_first(const std::vector<std::string>& candidates, std::string* chosen, std::string* error, bool isolated = false) {
     std::string errs;
     for (const std::string& c : candidates) {
         if (c.empty()) continue;
         void* h = nullptr;
-        if (isolated && c[0] == '/') h = dlmopen(LM_ID_NEWLM, c.c_str(), RTLD_NOW);
+        if (isolated && c[0] == '/') {
+            h = dlmopen(LM_ID_NEWLM, c.c_str(), RTLD_NOW);
+            if (h) give_namespace_its_own_environ(h);
+        }
         if (!h) h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (h) {
             *chosen = c;

@@ -11,7 +11,7 @@ cd $R
 for variant in "" "--specialize 1" "--specialize 1 --fast"; do
     for run in cold warm; do
         echo "== render-frame portal_in_portal 3840x2160 depth 40 [$variant] $run"
-        /usr/bin/time -f "wall %e s" portal_amd/portal-amd render-frame scenes/portal_in_portal.ron --width 3840 --height 2160 --render-depth 40 --timing $variant --output /tmp/e2e.png 2>&1 | grep -v '^$'
+        portal_amd/portal-amd render-frame scenes/portal_in_portal.ron --width 3840 --height 2160 --render-depth 40 --timing $variant --output /tmp/e2e.png 2>&1 | grep -v '^$'
     done
 done
 echo "== precompile (no GPU needed), then render-frame with the cache it filled"
