@@ -106,6 +106,8 @@ def parse_args():
     p.add_argument("--waves", type=int, default=-1, help="occupancy hint (__launch_bounds__(256, n)); -1 = pick the fastest candidate build before timing")
     p.add_argument("--build", default="", help="pin one candidate build by name (w0, w3, w4, minreg) instead of picking the fastest")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-segments", action="store_true", help="skip the trip-counting launch after the timed region (PMC passes: the last launches of "
+                   "ptl_render_kernel are then exactly the timed ones)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     p.add_argument("--save-png", default="")
     args = p.parse_args()
@@ -377,6 +379,8 @@ def main():
     # bounce-loop trips per frame (untimed, separate kernel variant with the counter compiled in)
     segments = None
     try:
+        if args.no_segments:
+            raise RuntimeError("--no-segments")
         counting = pa.SceneRenderer(scene, device=local_rank, flags=pa.FLAG_COUNT_SEGMENTS | spec_flags)
         configure(counting, args)
         seg = torch.zeros(1, dtype=torch.int64, device=dev)

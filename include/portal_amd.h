@@ -270,7 +270,8 @@ int ptl_deinterleave_rows(const uint8_t* shard_rgba8, const ptl_frame* frame, ui
 /* average_images (src/main.rs:645-722), the motion-blur step of the video pipeline, on the GPU: N RGBA8
  * sub-frames (DEVICE pointers, 16-byte aligned, any width x height) -> one RGBA8 frame:
  * per channel mean of c*c over the sub-frames (integer division), then (u8)(sqrt(mean) + 0.5); alpha = 255.
- * HBM-bound: reads 4*N bytes and writes 4 bytes per pixel.  1 <= n_frames <= 64.  (For one image the reference
+ * HBM-bound: reads 4*N bytes and writes 4 bytes per pixel.  1 <= n_frames <= 256 (up to 64 the pointers travel in the kernel
+ * arguments, beyond in a device table; 256 is where the exact one-multiply integer mean ends: 65025 * 256 * 256 < 2^32).  (For one image the reference
  * hands it back untouched; callers skip the call then -- the kernel would still force alpha to 255.)  Launched on `stream`;
  * with elapsed_ms != NULL it is bracketed by HIP events and the call waits. */
 int ptl_average_images(int device, const void* const* frames_rgba8, int n_frames, void* out_rgba8, int width, int height, void* stream,

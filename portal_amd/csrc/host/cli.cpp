@@ -998,8 +998,8 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "--stage and --animation exclude each other\n");
         return 2;
     }
-    if (o.blur < 1 || o.blur > 64) {
-        std::fprintf(stderr, "--motion-blur-frames must be 1..64\n");
+    if (o.blur < 1 || o.blur > 256) {
+        std::fprintf(stderr, "--motion-blur-frames must be 1..256\n");
         return 2;
     }
     if (cmd == "render") return render(o);

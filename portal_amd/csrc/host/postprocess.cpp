@@ -25,7 +25,8 @@ using namespace ptl;
 
 namespace {
 
-constexpr int kMaxSubframes = 64;  // PTL_MAX_SUBFRAMES in average_images.hip
+constexpr int kMaxSubframes = 64;        // PTL_MAX_SUBFRAMES in average_images.hip: pointers in the kernel arguments
+constexpr int kMaxSubframesTable = 256;  // beyond: a pointer table in device memory; 256 is where the exact multiply-high mean ends
 
 struct LoadedKernel {
     hip::hipModule_t module = nullptr;
@@ -46,7 +47,7 @@ int load_kernel(int device, const char* file, const char* entry, LoadedKernel** 
     static std::mutex mu;
     static std::map<std::string, LoadedKernel> cache;
     std::lock_guard<std::mutex> lock(mu);
-    std::string key = std::to_string(device) + ":" + file;
+    std::string key = std::to_string(device) + ":" + file + ":" + entry;
     auto it = cache.find(key);
     if (it != cache.end()) {
         *out = &it->second;
@@ -81,23 +82,35 @@ int load_kernel(int device, const char* file, const char* entry, LoadedKernel** 
 
 extern "C" int ptl_average_images(int device, const void* const* frames_rgba8, int n_frames, void* out_rgba8, int width, int height,
                                   void* stream, float* elapsed_ms) {
-    if (!frames_rgba8 || !out_rgba8 || n_frames < 1 || n_frames > kMaxSubframes || width <= 0 || height <= 0) return PTL_ERR_INVALID;
+    if (!frames_rgba8 || !out_rgba8 || n_frames < 1 || n_frames > kMaxSubframesTable || width <= 0 || height <= 0) return PTL_ERR_INVALID;
     for (int k = 0; k < n_frames; ++k)
         if (!frames_rgba8[k] || (reinterpret_cast<uintptr_t>(frames_rgba8[k]) & 15u)) return PTL_ERR_INVALID;
     if (reinterpret_cast<uintptr_t>(out_rgba8) & 15u) return PTL_ERR_INVALID;
     LoadedKernel* k = nullptr;
     const char* variant = std::getenv("PTL_AVERAGE_IMAGES_HSACO");  // tuning only: another build of the same kernel (tools/average_variants.py)
-    int rc = load_kernel(device, variant && *variant ? variant : "average_images.hsaco", "ptl_average_images_kernel", &k);
+    const bool table = n_frames > kMaxSubframes;
+    int rc = load_kernel(device, variant && *variant ? variant : "average_images.hsaco", table ? "ptl_average_images_table_kernel" : "ptl_average_images_kernel", &k);
     if (rc != PTL_OK) return rc;
     const hip::Runtime* rt = hip::runtime(nullptr);
     rt->hipSetDevice(device);
     struct {
         const void* frame[kMaxSubframes];
     } list{};
-    for (int i = 0; i < n_frames; ++i) list.frame[i] = frames_rgba8[i];
+    for (int i = 0; i < n_frames && !table; ++i) list.frame[i] = frames_rgba8[i];
     long n_px = (long)width * height, n_vec = n_px / 4;
     int n = n_frames;
-    void* args[] = {&list, &n, &out_rgba8, &n_px};
+    void* dev_table = nullptr;
+    if (table) {  // rare (the reference's clips use <= 16): a pointer table per call, freed once the launch has gone through the stream
+        if (rt->hipMalloc(&dev_table, sizeof(void*) * (size_t)n_frames) != 0 ||
+            rt->hipMemcpyAsync(dev_table, frames_rgba8, sizeof(void*) * (size_t)n_frames, hip::kMemcpyHostToDevice, stream) != 0) {
+            if (dev_table) rt->hipFree(dev_table);
+            set_last_error("average_images: cannot stage the sub-frame pointer table");
+            return PTL_ERR_HIP;
+        }
+    }
+    void* args_list[] = {&list, &n, &out_rgba8, &n_px};
+    void* args_table[] = {&dev_table, &n, &out_rgba8, &n_px};
+    void** args = table ? args_table : args_list;
     long blocks = std::max(1L, (n_vec + 255) / 256);
     long cap = 256 * 16;  // grid-stride beyond 16 workgroups per CU
     if (const char* c = std::getenv("PTL_AVERAGE_IMAGES_GRID_CAP")) cap = std::atol(c) > 0 ? std::atol(c) : cap;
@@ -105,6 +118,7 @@ extern "C" int ptl_average_images(int device, const void* const* frames_rgba8, i
     if (elapsed_ms) rt->hipEventRecord(k->ev0, stream);
     int err = rt->hipModuleLaunchKernel(k->fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
     if (err != 0) {
+        if (dev_table) rt->hipFree(dev_table);
         set_last_error(std::string("hipModuleLaunchKernel(average_images): ") + rt->hipGetErrorString(err));
         return PTL_ERR_HIP;
     }
@@ -112,6 +126,10 @@ extern "C" int ptl_average_images(int device, const void* const* frames_rgba8, i
         rt->hipEventRecord(k->ev1, stream);
         rt->hipEventSynchronize(k->ev1);
         rt->hipEventElapsedTime(elapsed_ms, k->ev0, k->ev1);
+    }
+    if (dev_table) {
+        rt->hipStreamSynchronize(stream);  // hipFree would wait for the device anyway
+        rt->hipFree(dev_table);
     }
     return PTL_OK;
 }

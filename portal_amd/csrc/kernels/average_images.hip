@@ -19,8 +19,11 @@
 
 typedef unsigned int ptl_u32x4 __attribute__((ext_vector_type(4)));  // native vector: what the nontemporal builtins accept
 
-struct ptl_frame_list {
+struct ptl_frame_list {  // up to 64 sub-frames: the pointers travel in the kernel arguments
     const ptl_u32x4* frame[PTL_MAX_SUBFRAMES];
+};
+struct ptl_frame_table {  // 65..256 sub-frames: a pointer table in device memory (scalar loads)
+    const ptl_u32x4* const* frame;
 };
 
 __device__ __forceinline__ void ptl_accumulate(unsigned int (&sum)[12], ptl_u32x4 p) {
@@ -42,8 +45,9 @@ __device__ __forceinline__ unsigned int ptl_l_to_s(unsigned int linear) {
     return (unsigned int)(__builtin_amdgcn_sqrtf((float)linear) + 0.5f);  // truncation, like `as u8` on a value <= 255.5
 }
 
-// sum / n for sum <= 65025 * 64 < 2^22 and 2 <= n <= 64 as one multiply-high: with m = floor(2^32 / n) + 1,
-// m*n - 2^32 = e in (0, n], and floor(sum * m / 2^32) == floor(sum / n) whenever sum * e < 2^32 (here < 2^28).
+// sum / n for sum <= 65025 * n and 2 <= n <= 256 as one multiply-high: with m = floor(2^32 / n) + 1,
+// m*n - 2^32 = e in (0, n], and floor(sum * m / 2^32) == floor(sum / n) whenever sum * e < 2^32
+// (65025 * 256 * 256 = 4.26e9 < 2^32 = 4.29e9: n = 256 is the last one that fits; checked for every n in tests/test_host_logic.py).
 // A runtime `/` would be ~30 VALU instructions, twelve times per lane -- more than the whole rest of the kernel.
 __device__ __forceinline__ unsigned int ptl_div_n(unsigned int sum, unsigned int magic) {
     return magic ? __umulhi(sum, magic) : sum;  // magic == 0 encodes n == 1
@@ -69,7 +73,8 @@ __device__ __forceinline__ ptl_u32x4 ptl_stream_load(const ptl_u32x4* p) {
 #endif
 }
 
-__device__ __forceinline__ void ptl_average_one(const ptl_frame_list& frames, int n, unsigned int magic, ptl_u32x4* __restrict__ out, long i) {
+template <class Frames>
+__device__ __forceinline__ void ptl_average_one(const Frames& frames, int n, unsigned int magic, ptl_u32x4* __restrict__ out, long i) {
     unsigned int sum[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     int f = 0;
     for (; f + PTL_AVG_UNROLL <= n; f += PTL_AVG_UNROLL) {
@@ -97,7 +102,8 @@ __device__ __forceinline__ void ptl_average_one(const ptl_frame_list& frames, in
 }
 
 // One pixel with 4-byte accesses: the up-to-three pixels behind the last whole 16-byte vector of a frame.
-__device__ __forceinline__ void ptl_average_tail_pixel(const ptl_frame_list& frames, int n, unsigned int magic, unsigned int* __restrict__ out, long px) {
+template <class Frames>
+__device__ __forceinline__ void ptl_average_tail_pixel(const Frames& frames, int n, unsigned int magic, unsigned int* __restrict__ out, long px) {
     unsigned int r = 0u, g = 0u, b = 0u;
     for (int f = 0; f < n; ++f) {
         const unsigned int w = reinterpret_cast<const unsigned int*>(frames.frame[f])[px];
@@ -109,8 +115,8 @@ __device__ __forceinline__ void ptl_average_tail_pixel(const ptl_frame_list& fra
     out[px] = ptl_l_to_s(ptl_div_n(r, magic)) | (ptl_l_to_s(ptl_div_n(g, magic)) << 8) | (ptl_l_to_s(ptl_div_n(b, magic)) << 16) | 0xff000000u;
 }
 
-extern "C" __global__ void __launch_bounds__(256)
-ptl_average_images_kernel(ptl_frame_list frames, int n, ptl_u32x4* __restrict__ out, long n_px) {
+template <class Frames>
+__device__ __forceinline__ void ptl_average_all(const Frames& frames, int n, ptl_u32x4* __restrict__ out, long n_px) {
     const long stride = (long)gridDim.x * 256;
     const long n_vec = n_px >> 2;  // whole 4-pixel vectors
     const unsigned int magic = n > 1 ? 0xffffffffu / (unsigned)n + 1u : 0u;  // wave-uniform: one division on the scalar side of things
@@ -120,4 +126,15 @@ ptl_average_images_kernel(ptl_frame_list frames, int n, ptl_u32x4* __restrict__ 
             if (i + v * stride < n_vec) ptl_average_one(frames, n, magic, out, i + v * stride);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n_px & 3)) ptl_average_tail_pixel(frames, n, magic, reinterpret_cast<unsigned int*>(out), n_vec * 4 + threadIdx.x);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+ptl_average_images_kernel(ptl_frame_list frames, int n, ptl_u32x4* __restrict__ out, long n_px) {
+    ptl_average_all(frames, n, out, n_px);
+}
+
+// The reference takes any motion_blur_frames (src/main.rs:1766); beyond 64 the pointers no longer fit the kernel arguments.
+extern "C" __global__ void __launch_bounds__(256)
+ptl_average_images_table_kernel(const ptl_u32x4* const* table, int n, ptl_u32x4* __restrict__ out, long n_px) {
+    ptl_average_all(ptl_frame_table{table}, n, out, n_px);
 }

@@ -543,12 +543,17 @@ def test_check_command_attributes_compile_errors_to_scene_elements(pa, tmp_path)
 
 def test_average_images_multiply_high_is_the_integer_division():
     """average_images.hip divides the channel sums by the sub-frame count with one multiply-high (magic = floor(2^32/n) + 1);
-    every sum the kernel can see (0 .. 65025 n) for every n it accepts (2 .. 64) gives floor(sum / n).  Also the argument that
-    a 1-ulp sqrt cannot change L_TO_S: sqrt(l) stays >= 4.9e-4 away from every k + 0.5."""
-    for n in range(2, 65):
+    every sum the kernel can see (0 .. 65025 n) for every n it accepts (2 .. 256) gives floor(sum / n) -- and 257 is the first
+    count for which it does not (why 256 is the limit).  Also the argument that a 1-ulp sqrt cannot change L_TO_S: sqrt(l) stays
+    >= 4.9e-4 away from every k + 0.5."""
+    def exact(n):
         magic = np.uint64(0xFFFFFFFF // n + 1)
         x = np.arange(0, 65025 * n + 1, dtype=np.uint64)
-        assert np.array_equal((x * magic) >> np.uint64(32), x // np.uint64(n)), n
+        return np.array_equal((x * magic) >> np.uint64(32), x // np.uint64(n))
+
+    for n in range(2, 257):
+        assert exact(n), n
+    assert not all(exact(n) for n in range(257, 300))
     s = np.sqrt(np.arange(65026, dtype=np.float64))
     assert np.abs((s + 0.5) - np.rint(s + 0.5)).min() > 4.8e-4
 

@@ -14,6 +14,6 @@ rm -rf /tmp/pmc_$NAME
 i=0
 for group in "SQ_WAVES SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_THREAD_CYCLES_VALU" "SQ_INSTS_SALU SQ_INSTS_VALU_TRANS" "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i + 1))
-    rocprofv3 --pmc $group --output-format csv -d /tmp/pmc_$NAME/p$i -o p -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --build $BUILD ${BENCH_ARGS:-} > /tmp/pmc_$NAME.log 2>&1 || tail -3 /tmp/pmc_$NAME.log
+    rocprofv3 --pmc $group --output-format csv -d /tmp/pmc_$NAME/p$i -o p -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-segments --build $BUILD ${BENCH_ARGS:-} > /tmp/pmc_$NAME.log 2>&1 || tail -3 /tmp/pmc_$NAME.log
 done
 python $R/tools/pmc_summary.py $O/$NAME.json "${WORKLOAD:-portal_in_portal 3840x2160 depth 40, all scene uniforms baked, build $BUILD, flags '${PTL_HIPRTC_FLAGS:-}', 1 GPU; the 5 timed launches of each pass; FETCH_SIZE / WRITE_SIZE in KB}" 5 /tmp/pmc_$NAME/p*
