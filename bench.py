@@ -91,8 +91,8 @@ WORKLOADS = {  # --workload NAME: BASELINE.json configs by name
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=400)   # 400 x 0.6 ms: a quarter of a second of timed region (20 steps = 13 ms were invisible
+    p.add_argument("--warmup", type=int, default=20)   # to a once-per-second utilisation sampler)
     p.add_argument("--workload", default="", choices=[""] + sorted(WORKLOADS), help="a BASELINE.json config by name (c4 = the headline = the default; "
                    "c5 = mobius_monoportal 8K aa 4 depth 64, the second scaling workload: its per-rank trace stays far above collective latency at 8 GPUs)")
     p.add_argument("--scene", default="portal_in_portal")

@@ -18,14 +18,14 @@ PATCHES = {
     "no_material": [("m = material_process(r, i);", "m = MaterialProcessing{true, vec3(0.5f), ray_none};"),
                     ("m = material_process(r, i2.scene);", "m = MaterialProcessing{true, vec3(0.5f), ray_none};")],
     # planes never hit: what do the Flat objects cost (transform, early-out, sqrt, divisions, is_inside)?
-    "no_planes": [("    r = transform(plane_inv, r);\n", "    return intersection_none;\n    r = transform(plane_inv, r);\n")],
-    # planes without the exact early-out
-    "no_early_out": [("        return intersection_none;\n    float len = length(r.d);", "        {}\n    float len = length(r.d);")],
+    "no_planes": [("    r = transform(plane_inv, r);\n    float len = length(r.d);", "    return intersection_none;\n    r = transform(plane_inv, r);\n    float len = length(r.d);")],
+    # the snippet of the scene (intersection material) never hits
+    "no_snippet": [("hit = intersect_material_0(r);", "hit = SceneIntersectionWithMaterial{scene_intersection_none, material_empty()};")],
     # Complex objects (scene snippets intersect_<k>) skipped
     "no_complex": [("ihit = intersect_", "if (len < 0.0f) ihit = intersect_")],
     # no bounce loop at all: ray generation, AA loop, gamma, store
-    "no_trace": [("    for (int j = 0; j < _ray_tracing_depth; j++) {\n        PTL_RELAUNDER();\n        PTL_COUNT_SEGMENT();",
-                  "    if (r.d.x > 2.0f) return RayTraceResult{vec3(r.d.x, r.d.y, r.d.z), 0.0f, false};\n    for (int j = 0; j < 0; j++) {\n        PTL_RELAUNDER();\n        PTL_COUNT_SEGMENT();")],
+    "no_trace": [("    bool alive = true;\n    for (int j = 0; j < _ray_tracing_depth; j++) {",
+                  "    bool alive = true;\n    if (r.d.x > 2.0f) return RayTraceResult{vec3(r.d.x, r.d.y, r.d.z), 0.0f, false};\n    for (int j = 0; j < 0; j++) {")],
 }
 
 if __name__ == "__main__":
