@@ -197,6 +197,9 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * bit6 = FAST MATH, the tolerance mode (`--fast`): hardware rcp / sqrt / rsq estimates (1 ulp), a / b = a * rcp(b), FMA
  * contraction.  Frames agree with the exact kernel to ~1e-6 per channel except at pixels where the last bit decides a path
  * (object edges); the exact kernel stays the default and the parity reference.
+ * bit7 = NO deferred loop updates: by default a loop-carried ray transform in a scene snippet (`X = transform(A_mat, transform(B_mat_inv, X));`
+ * on every iteration, X read only where a hit is recorded) is replaced by a counter and applied right before X is read -- the same
+ * operations on the same values for the rays that read X, none for the others; identical frames (glsl_translate.h has the conditions).
  * ptl_renderer_create additionally reads bits 8-11 as an occupancy hint n (0 = none):
  * the kernel is built with __launch_bounds__(256, n), i.e. at least n waves per SIMD. */
 int ptl_scene_generate_source(ptl_scene* s, unsigned flags, char** source);

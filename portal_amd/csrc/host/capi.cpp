@@ -398,7 +398,9 @@ static KernelOptions options_from_flags(unsigned flags) {
 static void refresh_generated(ptl_scene* s, unsigned flags, const std::set<std::string>* keep_dynamic = nullptr) {
     KernelOptions opts = options_from_flags(flags);
     if (keep_dynamic) opts.keep_dynamic = *keep_dynamic;
-    s->last = generate_kernel_source(*s->scene, CodegenFlags{}, opts);
+    CodegenFlags cg;
+    cg.defer_loop_updates = (flags & 128u) == 0;  // PTL_FLAG_NO_DEFERRED_UPDATES: the snippets exactly as written (A/B measurements, tests)
+    s->last = generate_kernel_source(*s->scene, cg, opts);
     s->desc_names.clear();
     s->descs.clear();
     for (auto& u : s->last.uniforms) s->desc_names.push_back(u.name);

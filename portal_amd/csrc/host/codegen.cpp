@@ -321,7 +321,7 @@ std::vector<UniformUpload> evaluate_scene_uniforms(const Scene& scene, std::vect
 // ------------------------------------------------------------------------------------------
 namespace {
 
-std::string snippet(const std::string& glsl, const CodegenFlags& flags) { return translate_glsl(filter_tagged_lines(glsl, flags)); }
+std::string snippet(const std::string& glsl, const CodegenFlags& flags) { return translate_glsl(filter_tagged_lines(glsl, flags), flags.defer_loop_updates); }
 
 struct PortalMaterialNames {
     int pos;

@@ -3,6 +3,7 @@
 
 #include <stdexcept>
 
+#include <algorithm>
 #include <cctype>
 #include <cstring>
 #include <set>
@@ -34,7 +35,7 @@ std::string filter_tagged_lines(const std::string& text, const CodegenFlags& f) 
 namespace {
 
 struct Token {
-    enum Kind { Space, Comment, Ident, Number, Punct, Preproc } kind;
+    enum Kind { Space, Comment, Ident, Number, Punct, Preproc, Raw } kind;  // Raw: text inserted by a rewrite, emitted verbatim
     std::string text;
 };
 
@@ -167,10 +168,180 @@ const std::set<std::string>& cpp_only_keywords() {
     return k;
 }
 
+bool looks_like_a_uniform(const std::string& name) {
+    auto ends = [&](const char* suffix) {
+        size_t n = std::strlen(suffix);
+        return name.size() > n && name.compare(name.size() - n, n, suffix) == 0;
+    };
+    return ends("_mat") || ends("_mat_inv") || ends("_mat_teleport") || ends("_u") || (name.size() > 1 && name[0] == '_');
+}
+
+bool is_assign_op(const Token& t) {
+    return t.kind == Token::Punct && (t.text == "=" || t.text == "+=" || t.text == "-=" || t.text == "*=" || t.text == "/=" || t.text == "++" || t.text == "--");
+}
+
+// See glsl_translate.h (`defer_loop_updates`).  Works on the significant tokens; every check that fails leaves the loop untouched.
+void defer_loop_carried_updates(std::vector<Token>& toks) {
+    std::vector<size_t> sig;  // indices of the significant tokens
+    for (size_t k = 0; k < toks.size(); ++k)
+        if (toks[k].kind != Token::Space && toks[k].kind != Token::Comment && toks[k].kind != Token::Preproc) sig.push_back(k);
+    const size_t n = sig.size();
+    auto T = [&](size_t i) -> const Token& { return toks[sig[i]]; };
+    auto is = [&](size_t i, const char* text) { return i < n && T(i).kind == Token::Punct && T(i).text == text; };
+    auto ident = [&](size_t i, const char* text) { return i < n && T(i).kind == Token::Ident && T(i).text == text; };
+    auto match = [&](size_t open, const char* a, const char* b) -> size_t {  // index of the bracket closing the one at `open`, or n
+        int depth = 0;
+        for (size_t i = open; i < n; ++i) {
+            if (is(i, a)) ++depth;
+            else if (is(i, b) && --depth == 0) return i;
+        }
+        return n;
+    };
+    // identifiers the snippet assigns or declares somewhere: never treated as loop-invariant
+    std::set<std::string> written;
+    for (size_t i = 0; i < n; ++i) {
+        if (T(i).kind != Token::Ident) continue;
+        bool target = (i + 1 < n && is_assign_op(T(i + 1))) || (i > 0 && (is(i - 1, "++") || is(i - 1, "--")));
+        bool declared = i > 0 && T(i - 1).kind == Token::Ident && i + 1 < n && (is(i + 1, "=") || is(i + 1, ";") || is(i + 1, ",") || is(i + 1, ")") || is(i + 1, "["));
+        if (target || declared) written.insert(T(i).text);
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (ident(i, "do") || ident(i, "goto")) return;  // do-while bodies are not tracked as loops: leave such code alone
+    struct Loop {
+        size_t kw, header_open, header_close, body_open, body_close;
+    };
+    std::vector<Loop> loops;  // every loop with a braced body, `for` and `while`
+    for (size_t i = 0; i + 1 < n; ++i) {
+        if (!(ident(i, "for") || ident(i, "while")) || !is(i + 1, "(")) continue;
+        size_t close = match(i + 1, "(", ")");
+        if (close >= n || !is(close + 1, "{")) continue;
+        size_t end = match(close + 1, "{", "}");
+        if (end >= n) continue;
+        loops.push_back({i, i + 1, close, close + 1, end});
+    }
+    struct Insert {
+        size_t at;  // significant-token index the text goes in front of
+        std::string text;
+    };
+    std::vector<Insert> inserts;
+    std::vector<std::pair<size_t, size_t>> removed;  // [first, last] significant tokens replaced by the text of the insert at `first`
+    int counter = 0;
+    for (const Loop& L : loops) {
+        if (!ident(L.kw, "for")) continue;
+        bool nested = false;
+        for (const Loop& O : loops) nested = nested || (O.body_open < L.kw && L.kw < O.body_close);
+        if (nested) continue;
+        if (L.kw > 0 && !(is(L.kw - 1, ";") || is(L.kw - 1, "{") || is(L.kw - 1, "}"))) continue;  // `if (c) for ...`: nowhere to declare the counter
+        // the enclosing function: for a body-only snippet (loop at brace depth 0) the whole text, else from the brace that opens the
+        // function body to the one that closes it
+        size_t fn_begin = 0, fn_end = n;
+        {
+            int depth = 0;
+            for (size_t i = 0; i < L.kw; ++i) {
+                if (is(i, "{") && depth++ == 0) fn_begin = i + 1;
+                else if (is(i, "}")) --depth;
+            }
+            if (depth == 0) fn_begin = 0;
+            if (depth > 0) {
+                int d = depth;
+                for (size_t i = L.body_close + 1; i < n; ++i) {
+                    d += is(i, "{") ? 1 : is(i, "}") ? -1 : 0;
+                    if (d == 0) {
+                        fn_end = i;
+                        break;
+                    }
+                }
+            }
+        }
+        // statement starts inside the body, by paren depth 0 delimiters
+        int brace = 0, paren = 0;
+        size_t stmt_start = L.body_open + 1;
+        std::vector<size_t> start_of(n, 0);
+        std::vector<int> depth_of(n, 0);
+        for (size_t i = L.body_open + 1; i < L.body_close; ++i) {
+            start_of[i] = stmt_start;
+            depth_of[i] = brace;
+            if (is(i, "(")) ++paren;
+            else if (is(i, ")")) --paren;
+            else if (is(i, "{")) { ++brace; if (paren == 0) stmt_start = i + 1; }
+            else if (is(i, "}")) { --brace; if (paren == 0) stmt_start = i + 1; }
+            else if (is(i, ";") && paren == 0) stmt_start = i + 1;
+        }
+        for (size_t i = L.body_open + 1; i < L.body_close; ++i) {
+            if (depth_of[i] != 0 || start_of[i] != i || T(i).kind != Token::Ident || !is(i + 1, "=")) continue;
+            const std::string X = T(i).text;
+            size_t semi = i + 2;
+            int p = 0, x_in_rhs = 0;
+            bool ok = true;
+            for (; semi < L.body_close && !(is(semi, ";") && p == 0); ++semi) {
+                const Token& t = T(semi);
+                if (is(semi, "(")) ++p;
+                else if (is(semi, ")")) --p;
+                else if (is(semi, ",") || is(semi, "*")) {}
+                else if (t.kind == Token::Ident && t.text == X) ++x_in_rhs;
+                else if (t.kind == Token::Ident && t.text == "transform" && is(semi + 1, "(")) {}
+                else if (t.kind == Token::Ident && looks_like_a_uniform(t.text) && !written.count(t.text) && !(semi > 0 && is(semi - 1, "."))) {}
+                else ok = false;
+            }
+            if (!ok || x_in_rhs != 1 || semi >= L.body_close || p != 0) continue;
+            // X elsewhere: not in the header, only in nested blocks of the body, never written, never a member name
+            std::vector<size_t> uses;
+            for (size_t j = L.header_open; j <= L.header_close && ok; ++j) ok = !(T(j).kind == Token::Ident && T(j).text == X);
+            for (size_t j = L.body_open + 1; j < L.body_close && ok; ++j) {
+                if (j >= i && j <= semi) continue;
+                if (T(j).kind != Token::Ident || T(j).text != X) continue;
+                if (j > 0 && is(j - 1, ".")) { ok = false; break; }
+                bool target = is_assign_op(T(j + 1)) || is(j - 1, "++") || is(j - 1, "--");
+                if (depth_of[j] < 1 || target) { ok = false; break; }
+                if (ident(start_of[j], "else") || ident(start_of[j], "case") || ident(start_of[j], "default")) { ok = false; break; }
+                uses.push_back(start_of[j]);
+            }
+            if (!ok || uses.empty()) continue;
+            // X must be a LOCAL of this function, declared before the loop: an `out` / `inout` parameter or a global would have to carry
+            // its final value out of the function, which a deferred update does not guarantee
+            bool local = false;
+            for (size_t j = fn_begin + 1; j + 1 < L.kw && !local; ++j)
+                local = T(j).kind == Token::Ident && T(j).text == X && T(j - 1).kind == Token::Ident && (is(j + 1, "=") || is(j + 1, ";") || is(j + 1, ","));
+            if (!local) continue;
+            bool used_after = false;
+            for (size_t j = L.body_close + 1; j < fn_end; ++j) used_after = used_after || (T(j).kind == Token::Ident && T(j).text == X);
+            // the update statement as text, the counter, the flush
+            std::string update;
+            for (size_t j = i; j <= semi; ++j) update += T(j).text + (j < semi && T(j).kind == Token::Ident && T(j + 1).kind == Token::Ident ? " " : "");
+            const std::string pend = "ptl_pend_" + std::to_string(counter++);
+            const std::string flush = "for (; " + pend + " > 0; --" + pend + ") " + update + " ";
+            inserts.push_back({L.kw, "int " + pend + " = 0; "});
+            inserts.push_back({i, "++" + pend + ";"});
+            removed.push_back({i, semi});
+            std::sort(uses.begin(), uses.end());
+            uses.erase(std::unique(uses.begin(), uses.end()), uses.end());
+            for (size_t u : uses) inserts.push_back({u, flush});
+            if (used_after) inserts.push_back({L.body_close + 1, flush});
+            i = semi;
+        }
+    }
+    if (inserts.empty()) return;
+    // rebuild the token list: inserts go in front of their anchor, removed ranges keep only their line breaks
+    std::vector<bool> drop(toks.size(), false);
+    for (auto& r : removed)
+        for (size_t k = sig[r.first]; k <= sig[r.second]; ++k) drop[k] = true;
+    std::stable_sort(inserts.begin(), inserts.end(), [](const Insert& a, const Insert& b) { return a.at < b.at; });
+    std::vector<Token> out;
+    size_t next = 0;
+    for (size_t k = 0; k <= toks.size(); ++k) {
+        while (next < inserts.size() && (inserts[next].at >= n ? k == toks.size() : sig[inserts[next].at] == k)) out.push_back({Token::Raw, inserts[next++].text});
+        if (k == toks.size()) break;
+        if (!drop[k]) out.push_back(toks[k]);
+        else if (toks[k].kind == Token::Space && toks[k].text == "\n") out.push_back(toks[k]);  // line-preserving
+    }
+    toks.swap(out);
+}
+
 }  // namespace
 
-std::string translate_glsl(const std::string& glsl) {
+std::string translate_glsl(const std::string& glsl, bool defer_loop_updates) {
     std::vector<Token> toks = tokenize(glsl);
+    if (defer_loop_updates) defer_loop_carried_updates(toks);
     std::string out;
     out.reserve(glsl.size() + glsl.size() / 8);
 
@@ -223,6 +394,7 @@ std::string translate_glsl(const std::string& glsl) {
             case Token::Space:
             case Token::Comment:
             case Token::Preproc:
+            case Token::Raw:
                 out += t.text;
                 break;
             case Token::Number: {

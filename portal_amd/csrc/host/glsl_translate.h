@@ -24,12 +24,25 @@ struct CodegenFlags {
     bool disable_anaglyph = true;
     bool disable_camera_teleportation = false;
     bool use_300_version = true;
+    bool defer_loop_updates = true;  // translate_glsl's deferred loop-carried ray transforms (KernelOptions can switch it off)
 };
 
 // Drops (blanks) the lines whose tags are switched off; keeps the line count.
 std::string filter_tagged_lines(const std::string& text, const CodegenFlags& flags);
 
 // GLSL snippet -> C++ (line-preserving).
-std::string translate_glsl(const std::string& glsl);
+//
+// `defer_loop_updates` (default on): one optimisation on the way, exact by construction.  Scene snippets advance rays through a
+// pair of portal matrices on EVERY iteration of a loop -- `X = transform(A_mat, transform(B_mat_inv, X));` -- but read X only inside
+// nested blocks that few rays enter (where a portal hit is recorded: scenes/portal_in_portal.ron:1146-1147,1157,1178).  Such an
+// update is replaced by a counter increment, and the pending updates are applied right before every statement that reads X (and
+// behind the loop, if X is read there): the same operations on the same values in the same order for every ray that reads X,
+// none for the rays that never do.  Applied only when all of this holds -- otherwise the code is left exactly as written:
+//   * the update is a statement of a `for` body (not nested deeper, loop not inside another loop), of the form above: `transform`
+//     calls and `*` over X (once) and identifiers that name uniforms (`*_mat`, `*_mat_inv`, `*_mat_teleport`, `*_u`, `_*`) which the
+//     snippet never assigns or declares;
+//   * every other occurrence of X in the loop body sits in a nested block, is not an assignment target, and X does not appear in
+//     the loop header.
+std::string translate_glsl(const std::string& glsl, bool defer_loop_updates = true);
 
 }  // namespace ptl

@@ -825,3 +825,49 @@ def test_frame_group_and_precompile_without_a_gpu(pa, tmp_path):
     done = subprocess.run([exe, "precompile", os.path.join(ROOT, "scenes", "basics.ron"), "--specialize", "1"], capture_output=True, text=True, env=env, timeout=600)
     assert done.returncode == 0, done.stderr
     assert done.stdout.count("code object in") == 2 and len(os.listdir(tmp_path)) == 2
+
+
+def test_translator_defers_loop_carried_ray_transforms_only_when_it_is_safe(pa):
+    """glsl_translate.h `defer_loop_updates`: `X = transform(A_mat, transform(B_mat_inv, X));` at the top level of a `for` body, X read
+    only in nested blocks -> counter + flush before every reading statement (+ behind the loop when X is read there); every
+    violated condition leaves the text alone.  Line count is preserved either way."""
+    base = """Ray ra = r;
+Ray rb = r;
+for (int k = 0; k < n_u; k++) {
+    ra = transform(b0_mat, transform(a_mat_inv, ra));
+    rb = transform(a_mat, rb);
+    if (k > 2) {
+        if (hit.t > 0.) { out1 = f(ra, hit.t); }
+        out2 = g(rb);
+    }
+}
+"""
+    got = pa.translate_glsl(base)
+    assert got.count("\n") == base.count("\n")
+    assert "int ptl_pend_0 = 0; int ptl_pend_1 = 0; for (int k = 0;" in got
+    assert "++ptl_pend_0;" in got and "++ptl_pend_1;" in got
+    assert "{ for (; ptl_pend_0 > 0; --ptl_pend_0) ra=transform(b0_mat,transform(a_mat_inv,ra)); out1 = f(ra, hit.t); }" in got
+    assert "for (; ptl_pend_1 > 0; --ptl_pend_1) rb=transform(a_mat,rb); out2 = g(rb);" in got
+    assert got.count("ra=transform(") == 1 and "ra = transform(" not in got          # the eager update is gone, one flush site
+    # read behind the loop: one more flush there
+    after = pa.translate_glsl(base + "result = h(ra);\n")
+    assert after.count("ra=transform(") == 2 and "}\nfor (; ptl_pend_0 > 0; --ptl_pend_0) ra=transform(b0_mat,transform(a_mat_inv,ra)); result = h(ra);" in after
+    unchanged = [
+        base.replace("out2 = g(rb);", "out2 = g(rb); rb = r;"),                                    # X assigned elsewhere in the loop
+        base.replace("    if (k > 2) {", "    out0 = g(rb);\n    if (k > 2) {"),                     # X read at the top level of the body
+        base.replace("rb = transform(a_mat, rb);", "rb = transform(m_local, rb);"),                 # not a uniform name
+        base.replace("Ray rb = r;", "Ray rb = r; mat4 a_mat = mat4(1.);"),                          # a local that only looks like a uniform
+        base.replace("rb = transform(a_mat, rb);", "rb = normalize_ray(transform(a_mat, rb));"),    # another function in the chain
+        "for (int j = 0; j < 3; j++) {\n" + base + "}\n",                                          # loop nested in a loop
+        base.replace("for (int k = 0; k < n_u; k++) {", "for (int k = 0; k < int(rb.tmul); k++) {"),  # X in the loop header
+        base.replace("Ray rb = r;\n", "\n"),                                                        # X is not a local declared before the loop (a parameter, a global)
+        "do {\n" + base + "} while (again);\n",                                                    # inside a do-while: left alone altogether
+    ]
+    for text in unchanged:
+        out = pa.translate_glsl(text)
+        update = next(line.strip() for line in text.splitlines() if line.strip().startswith("rb = ") and "transform(" in line)
+        assert update.replace("1.)", "1.f)") in out and "ptl_pend_1" not in out and out.count("\n") == text.count("\n"), text
+    # the shipped scenes: the headline's snippet has two such chains (scenes/portal_in_portal.ron:1146-1147), the others none
+    counts = {name: pa.Scene.from_file(pa.scene_path(name)).generate_source(0).count("int ptl_pend_") for name in SCENES}
+    assert counts == {"basics": 0, "monoportal": 0, "triple_portal": 0, "portal_in_portal": 2, "mobius_monoportal": 0}
+    assert "ptl_pend_" not in pa.Scene.from_file(pa.scene_path("portal_in_portal")).generate_source(pa.FLAG_NO_DEFERRED_UPDATES)

@@ -14,6 +14,12 @@ counts per trip (one trip = one pass of the bounce loop for one sample):
 Counting is per ACTIVE lane (the oracle masks lanes exactly like the control flow does), so it is work the picture needs,
 not issue slots: divergence and the multi-instruction expansions of / and sqrt (11 and 14 VALU instructions) are not in it.
 
+The oracle evaluates the reference's GLSL as written.  The product's translator defers loop-carried ray transforms of scene snippets
+(glsl_translate.h `defer_loop_updates`): an update that no statement ever reads is never executed.  How many that is cannot come from the
+oracle; it is measured on the HOST BUILD of the generated source with two counters compiled in (updates scheduled / updates applied) on
+rows sampled over the same full-size frame, and `flops_*_executed` = the oracle's count minus (scheduled - applied) per trip x the
+operations of one update (56 per `transform`: two mat4 x vec4 of 4 x (1 mul + 3 fma)).  The plane cull and the early-outs are NOT subtracted.
+
     python tools/count_flops.py                      # the four GPU configs -> profiles/r02/flops_per_segment.json
 """
 from __future__ import annotations
@@ -58,13 +64,65 @@ def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None
         for k, v in o.stats.items():
             total[k] = total.get(k, 0.0) + float(v)
     seg = total.pop("segments")
+    per_segment = {k: v / seg for k, v in total.items()}
+    deferred = deferred_update_counts(scene, w, h, depth, aa, options)
+    if deferred:
+        skipped = deferred["flops_per_update"] * (deferred["scheduled_per_segment"] - deferred["applied_per_segment"])
+        per_segment["flops_executed"] = per_segment["flops"] - skipped
+        per_segment["flops_varying_executed"] = per_segment["flops_varying"] - skipped
     return {
         "scene": scene, "width": w, "height": h, "depth": depth, "aa": aa,
         "sampled_pixels": n, "sampled_fraction_of_frame": n / (w * h), "seed": seed,
         "segments_in_sample": int(seg), "segments_per_primary_sample": seg / (n * aa),
-        "per_segment": {k: v / seg for k, v in total.items()},
+        "per_segment": per_segment,
+        "deferred_updates": deferred,
         "oracle_seconds": round(time.time() - t0, 1),
     }
+
+
+def deferred_update_counts(scene_name, w, h, depth, aa, options=None, row_step=61):
+    """Deferred loop-carried updates of the generated source: scheduled vs applied per bounce-loop trip, counted on the host build
+    (rows row_step/2, +row_step, ... of the full-size frame).  None when the scene has no such update."""
+    import re
+
+    import portal_amd as pa
+    from oracle import host_build as hb
+
+    scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    source = scene.generate_source(pa.FLAG_COUNT_SEGMENTS)
+    updates = re.findall(r"for \(; (ptl_pend_\d+) > 0; --\1\) ([^;]*;)", source)
+    if not updates:
+        return None
+    flops_per_update = {name: 56 * stmt.count("transform(") for name, stmt in updates}
+    if len(set(flops_per_update.values())) != 1:
+        raise SystemExit(f"deferred updates of different sizes in {scene_name}: extend the accounting")
+    source = source.replace("namespace glsl {\n", "namespace glsl {\nstatic long ptl_deferred_stats[2] = {0, 0};\n", 1)
+    source = re.sub(r"\+\+(ptl_pend_\d+);", r"++\1; __atomic_fetch_add(&ptl_deferred_stats[0], 1, __ATOMIC_RELAXED);", source)
+    source = re.sub(r"for \(; (ptl_pend_\d+) > 0; --\1\) ", r"for (; \1 > 0; --\1, __atomic_fetch_add(&ptl_deferred_stats[1], 1, __ATOMIC_RELAXED)) ", source)
+    source += '\nextern "C" long* ptl_deferred_stats_ptr() { return glsl::ptl_deferred_stats; }\n'
+    renderer = pa.SceneRenderer(scene, device=-1)
+    renderer.set_option("render_depth", depth)
+    renderer.set_option("aa_count", aa)
+    for k, v in (options or {}).items():
+        name = {"use_panini": "use_panini_projection"}.get(k, k)
+        renderer.set_option(name, float(v))
+    layout, size = scene.uniform_layout()
+    hk = hb.HostKernel(source, layout, size, True)
+    for name, typ, _ in layout:
+        if typ == pa.PTL_SAMPLER:
+            continue
+        v = renderer.uniform_value(name, w, h)
+        if v is not None:
+            hk.set_uniform(name, v)
+    rows = list(range(row_step // 2, h, row_step))
+    out = hk.render(w, h, rows=rows, rgba32f=False)
+    import ctypes as C
+
+    hk.lib.ptl_deferred_stats_ptr.restype = C.POINTER(C.c_long)
+    st = hk.lib.ptl_deferred_stats_ptr()
+    seg = out["segments"]
+    return {"scheduled_per_segment": st[0] / seg, "applied_per_segment": st[1] / seg, "flops_per_update": next(iter(flops_per_update.values())),
+            "segments_in_sample": seg, "sampled_rows": len(rows), "counted_on": "host build of the generated source (oracle/host_build.py)"}
 
 
 def main():

@@ -79,6 +79,9 @@ VARIANTS = {
     "r2_fast_all_nocull": "FAST SPECIALIZE_ALL -DPTL_NO_PLANE_CULL",
     "r2_all_minreg": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg",
     "r2_all_minreg_nocull": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg -DPTL_NO_PLANE_CULL",
+    "r2_dyn_nodefer": "NO_DEFER",
+    "r2_all_nodefer": "SPECIALIZE_ALL NO_DEFER",
+    "r2_fast_all_nodefer": "FAST SPECIALIZE_ALL NO_DEFER",
     "r2_fast_dyn": "FAST",
     "r2_fast_dyn_w4": "FAST -DPTL_WAVES_PER_EU=4",
     "r2_fast_all": "FAST SPECIALIZE_ALL",
@@ -101,7 +104,7 @@ def run_one(case, vname, flags):
     w, h, d, aa = int(w), int(h), int(d), int(aa)
     toks = flags.split()
     rflags = (pa.FLAG_SPECIALIZE_INTS if ("SPECIALIZE" in toks or "SPECIALIZE_ALL" in toks) else 0) | (pa.FLAG_SPECIALIZE_ALL if "SPECIALIZE_ALL" in toks else 0)
-    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0)
+    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0) | (pa.FLAG_NO_DEFERRED_UPDATES if "NO_DEFER" in toks else 0)
     # the VGPR allocator is an option the JIT always passes (kernel.cpp): select it through its own switch, not a second -mllvm
     ra = [t.split("=", 1)[1] for t in toks if t.startswith("-vgpr-regalloc=")]
     if "RA_DEFAULT" in toks:
