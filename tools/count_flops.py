@@ -49,6 +49,7 @@ def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None
     from oracle.portal_oracle import Oracle
 
     M.COUNT_VARYING = True
+    _vary_the_camera_between_lanes()
     o = Oracle(pa.scene_path(scene))
     o.options.update(render_depth=depth, aa_count=aa)
     if options:
@@ -78,6 +79,35 @@ def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None
         "deferred_updates": deferred,
         "oracle_seconds": round(time.time() - t0, 1),
     }
+
+
+_camera_patched = False
+
+
+def _vary_the_camera_between_lanes():
+    """`flops_varying` is decided by VALUE (an operand whose lanes all hold the same bits counts as ray-independent).  All primary rays
+    start at the same point, so everything computed from the ray ORIGIN alone on the first trip -- `plane_inv * r.o` of every plane
+    test -- would pass as ray-independent although it depends on the camera, which no build bakes in.  For counting (not for parity)
+    every other lane therefore gets a camera moved by a millimetre: camera-dependent operands then differ between lanes, scene-uniform
+    ones still do not."""
+    global _camera_patched
+    if _camera_patched:
+        return
+    _camera_patched = True
+    from oracle import glsl_values as V
+    from oracle.portal_oracle import Oracle
+
+    original = Oracle.get_color2
+
+    def get_color2(self, image_position, camera, *args, **kwargs):
+        n = len(np.asarray(image_position.c[0]))
+        odd = (np.arange(n) % 2).astype(np.float32)
+        cols = [V.Vec([np.full(n, np.float32(x), np.float32) for x in col.c]) for col in camera.cols]
+        shift = (1e-3, -1e-3, 1e-3, 0.0)
+        cols[3] = V.Vec([np.asarray(c + np.float32(s) * odd, np.float32) for c, s in zip(cols[3].c, shift)])
+        return original(self, image_position, V.Mat(cols), *args, **kwargs)
+
+    Oracle.get_color2 = get_color2
 
 
 def deferred_update_counts(scene_name, w, h, depth, aa, options=None, row_step=61):
@@ -115,11 +145,12 @@ def deferred_update_counts(scene_name, w, h, depth, aa, options=None, row_step=6
         if v is not None:
             hk.set_uniform(name, v)
     rows = list(range(row_step // 2, h, row_step))
-    out = hk.render(w, h, rows=rows, rgba32f=False)
     import ctypes as C
 
     hk.lib.ptl_deferred_stats_ptr.restype = C.POINTER(C.c_long)
     st = hk.lib.ptl_deferred_stats_ptr()
+    st[0] = st[1] = 0  # the library (and its counters) is shared by every HostKernel of the same source in this process
+    out = hk.render(w, h, rows=rows, rgba32f=False)
     seg = out["segments"]
     return {"scheduled_per_segment": st[0] / seg, "applied_per_segment": st[1] / seg, "flops_per_update": next(iter(flops_per_update.values())),
             "segments_in_sample": seg, "sampled_rows": len(rows), "counted_on": "host build of the generated source (oracle/host_build.py)"}
