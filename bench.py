@@ -265,32 +265,36 @@ def main():
     #   rccl-gather  packed shards, ONE dist.gather (RCCL send/recv group) + one strided de-interleave copy, double-buffered so
     #                that the gather of frame n overlaps the tracing of frame n+1;
     #   p2p-stores   rank 0's frame buffers are mapped into every rank (HIP IPC) and the kernel stores its row blocks straight
-    #                into rank 0's HBM over xGMI; the collective shrinks to a one-element all-reduce used as a fence.
-    # PTL_BENCH_TRANSPORT=gather|p2p|auto (default auto: set both up, check that they assemble the same bytes, time both
-    # untimed-region style like the kernel builds above, keep the faster).
+    #                into rank 0's HBM over xGMI; the collective shrinks to a one-element all-reduce used as a fence;
+    #   p2p-copy     packed shard in the rank's own HBM + ONE strided hipMemcpy2DAsync into rank 0's mapped frame (SDMA over the rank's
+    #                xGMI link, de-interleaving on the way) + the same fence.
+    # PTL_BENCH_TRANSPORT=gather|p2p|copy|auto (default auto: set all up, check that they assemble the same bytes, time each
+    # untimed-region style like the kernel builds above, keep the fastest).
     staged = backend != "nccl"
     mode = os.environ.get("PTL_BENCH_TRANSPORT", "auto")
     transports = {}
     transport_notes = {}
     if world == 1 or mode in ("gather", "auto"):
         transports["rccl-gather"] = parallel.GatherTransport(H, W, rank, world, dev, depth=3, stage_through_host=staged)  # two gathers in flight behind the trace
-    if world > 1 and mode in ("p2p", "auto"):
+    peer_kinds = {"p2p-stores": parallel.PeerTransport, "p2p-copy": parallel.CopyTransport}
+    wanted = {"p2p": ["p2p-stores"], "copy": ["p2p-copy"], "auto": ["p2p-stores", "p2p-copy"]}.get(mode, [])
+    for kind in (wanted if world > 1 else []):
         ok, peer = 1, None
         try:
-            peer = parallel.PeerTransport(H, W, rank, world, dev, host_fence=staged)
+            peer = peer_kinds[kind](H, W, rank, world, dev, host_fence=staged)
         except Exception as e:  # no IPC between these devices / processes: the gather remains
             ok = 0
-            transport_notes["p2p-stores"] = f"unavailable: {str(e)[:200]}"
+            transport_notes[kind] = f"unavailable: {str(e)[:200]}"
         agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
         if int(agreed.item()) == 1:
-            transports["p2p-stores"] = peer
+            transports[kind] = peer
         else:
-            transport_notes.setdefault("p2p-stores", "unavailable on another rank")
+            transport_notes.setdefault(kind, "unavailable on another rank")
             if peer is not None:
                 peer.abandon()  # not close(): that is collective, and the rank that failed is not taking part
-        if not transports:
-            raise SystemExit("PTL_BENCH_TRANSPORT=p2p but peer frame buffers are unavailable: " + transport_notes["p2p-stores"])
+    if not transports:
+        raise SystemExit(f"PTL_BENCH_TRANSPORT={mode} but peer frame buffers are unavailable: {transport_notes}")
 
     def run_steps(tr, n, events=None):
         """n frames through transport `tr`; returns what tr.finish gave for the last one (the assembled frame on rank 0)."""
@@ -333,16 +337,20 @@ def main():
         torch.cuda.synchronize(dev)
 
     if len(transports) > 1:
-        # untimed: both transports must assemble the same frame on rank 0, then the faster one is kept
+        # untimed: every transport must assemble the same frame on rank 0 (reference: the first one set up), then the fastest is kept
         images = {name: tr.download(run_steps(tr, 1)) for name, tr in transports.items()}
-        same = torch.tensor([1], dtype=torch.int32, device=dev)
-        if rank == 0 and not np.array_equal(images["rccl-gather"], images["p2p-stores"]):
-            same[0] = 0
+        names = list(transports)
+        same = torch.ones(len(names), dtype=torch.int32, device=dev)
+        if rank == 0:
+            for k, name in enumerate(names[1:], start=1):
+                if not np.array_equal(images[names[0]], images[name]):
+                    same[k] = 0
         dist.broadcast(same, 0)
         del images
-        if int(same.item()) == 0:
-            transport_notes["p2p-stores"] = "dropped: its frame differs from the gathered one"
-            transports.pop("p2p-stores").close()
+        for k, name in enumerate(names):
+            if int(same[k].item()) == 0:
+                transport_notes[name] = f"dropped: its frame differs from the one `{names[0]}` assembled"
+                transports.pop(name).close()
     transport_ms = {}
     if len(transports) > 1:
         for name, tr in transports.items():
@@ -479,7 +487,8 @@ def main():
                             + (f" panini d={args.panini} fov={args.fov}" if args.panini >= 0 else ""),
                 "parallelism": f"row-block interleave x{world}" + ("" if world == 1 else {
                     "rccl-gather": " + one RCCL gather to rank 0 + de-interleave copy, double-buffered (gather n overlaps trace n+1)",
-                    "p2p-stores": " + kernel stores straight into rank 0's frame over xGMI (HIP IPC mapping), fenced by a 1-element RCCL all-reduce"}[transport.name]),
+                    "p2p-stores": " + kernel stores straight into rank 0's frame over xGMI (HIP IPC mapping), fenced by a 1-element RCCL all-reduce",
+                    "p2p-copy": " + packed shard per rank and ONE strided peer copy each into rank 0's frame (HIP IPC mapping), fenced by a 1-element RCCL all-reduce"}[transport.name]),
                 "jit_specialisation": ["none", "int/bool scene uniforms baked", "all scene uniforms baked (camera dynamic)"][args.specialize],
                 "build": best, "waves_per_simd_hint": best_waves,
                 "tuning_ms": tuning,

@@ -298,6 +298,10 @@ int ptl_event_record(void* event, void* stream);
 int ptl_event_synchronize(void* event);
 int ptl_stream_wait_event(void* stream, void* event);
 int ptl_device_download_async(void* host_dst, const void* device_src, size_t bytes, void* stream);
+/* Strided device-to-device copy on `stream` (1:1 over hipMemcpy2DAsync, pitches in bytes).  A rank's packed shard (source pitch =
+ * one 8-row block) into another GPU's frame (destination pitch = G blocks; a pointer from ptl_ipc_open or a peer-accessible one):
+ * the gather of that shard and its de-interleave in ONE transfer over the rank's own xGMI link. */
+int ptl_device_copy2d_async(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t rows, void* stream);
 /* A frame buffer shared by the processes of one node (one process per GPU; the reference is single-GPU): the
  * destination rank exports a ptl_device_alloc'ed buffer, the others map it and render into it with ptl_frame.in_place = 1
  * (stores go over xGMI into the destination's HBM).  A handle is PTL_IPC_HANDLE_BYTES opaque bytes to hand to the other

@@ -146,6 +146,7 @@ def _load() -> C.CDLL:
         "ptl_device_alloc": (ci, [ci, cs, P(vp)]),
         "ptl_device_free": (ci, [vp]),
         "ptl_device_download": (ci, [vp, vp, cs, vp]),
+        "ptl_device_copy2d_async": (ci, [vp, cs, vp, cs, cs, cs, vp]),
         "ptl_ipc_export": (ci, [vp, cp]),
         "ptl_ipc_open": (ci, [ci, cp, P(vp)]),
         "ptl_ipc_close": (ci, [vp]),
@@ -640,6 +641,11 @@ def device_download(ptr: int, nbytes: int, stream: int = 0) -> np.ndarray:
     out = np.empty(nbytes, dtype=np.uint8)
     _check(lib().ptl_device_download(out.ctypes.data, C.c_void_p(ptr), nbytes, C.c_void_p(stream or None)), "device_download")
     return out
+
+
+def device_copy2d_async(dst: int, dst_pitch: int, src: int, src_pitch: int, width_bytes: int, rows: int, stream: int = 0) -> None:
+    """Strided device-to-device copy on `stream` (hipMemcpy2DAsync): one packed shard into an interleaved frame, possibly on another GPU."""
+    _check(lib().ptl_device_copy2d_async(C.c_void_p(dst), dst_pitch, C.c_void_p(src), src_pitch, width_bytes, rows, C.c_void_p(stream or None)), "ptl_device_copy2d_async")
 
 
 IPC_HANDLE_BYTES = 64

@@ -256,6 +256,18 @@ extern "C" int ptl_device_download_async(void* host_dst, const void* device_src,
     return hip_status(rt, rt->hipMemcpyAsync(host_dst, device_src, bytes, hip::kMemcpyDeviceToHost, stream), "hipMemcpyAsync(D2H)");
 }
 
+// A strided device-to-device copy on `stream` (hipMemcpy2DAsync, direction from the pointers): `rows` rows of `width_bytes`, source
+// and destination pitches in bytes.  With a packed shard as the source (pitch = one 8-row block) and another GPU's frame as the
+// destination (pitch = G blocks, mapped through ptl_ipc_open or peer access) ONE such copy gathers a rank's shard over its xGMI link
+// with the SDMA engine and de-interleaves it in the same transfer.
+extern "C" int ptl_device_copy2d_async(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t rows, void* stream) {
+    if (!dst || !src || width_bytes == 0 || dst_pitch < width_bytes || src_pitch < width_bytes) return PTL_ERR_INVALID;
+    if (rows == 0) return PTL_OK;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!rt) return PTL_ERR_NO_DEVICE;
+    return hip_status(rt, rt->hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hip::kMemcpyDefault, stream), "hipMemcpy2DAsync");
+}
+
 // Frame buffers shared between the processes of a node (one process per GPU): the destination rank allocates the full frame
 // with ptl_device_alloc, exports it, and every other rank maps it into its own address space; their render kernels then store
 // their row blocks straight into the destination GPU's HBM over xGMI (ptl_frame.in_place), no gather, no de-interleave copy.

@@ -117,7 +117,8 @@ class PeerFrames:
         self.h, self.w, self.rank, self.world, self.dst = height, width, rank, world, dst
         self.device = torch.device(device)
         self.host_fence = host_fence
-        self.nbytes = height * width * 4
+        # whole 8-row blocks: a strided block copy (CopyTransport) of a ragged last block stays inside the allocation
+        self.nbytes = blocks_of(height) * 8 * width * 4
         index = self.device.index or 0
         self.owned, self.ptrs = [], []
         handles = [None]
@@ -167,7 +168,7 @@ class PeerFrames:
         if self.rank != self.dst:
             return None
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        return self._pa.device_download(self.ptrs[slot], self.nbytes, stream).reshape(self.h, self.w, 4)
+        return self._pa.device_download(self.ptrs[slot], self.h * self.w * 4, stream).reshape(self.h, self.w, 4)
 
     def close(self) -> None:
         if self.world > 1:
@@ -213,6 +214,53 @@ class GatherTransport:
 
     def close(self):
         pass
+
+
+class CopyTransport:
+    """One frame per step through a packed shard in the rank's OWN memory + ONE strided copy into the destination's frame (mapped
+    through HIP IPC like PeerTransport) + the fence.  The copy is a hipMemcpy2DAsync behind the kernel on the same stream: source
+    pitch one 8-row block, destination pitch `world` blocks -- the SDMA engine moves the shard over this rank's xGMI link and
+    de-interleaves it on the way.  Against `p2p-stores` the kernel writes local HBM; against `rccl-gather` there is no collective
+    launch and no second pass over the frame on rank 0."""
+
+    name = "p2p-copy"
+
+    def __init__(self, height, width, rank, world, device, depth=2, host_fence=False):
+        import portal_amd as pa
+
+        self._pa = pa
+        self.depth = depth
+        self.rank, self.world, self.h, self.w = rank, world, height, width
+        self.device = torch.device(device)
+        self.frames = PeerFrames(height, width, rank, world, device, depth=depth, host_fence=host_fence)
+        self.frame = pa.Frame(width, height, rank, world)  # packed shard layout
+        self.shards = [alloc_shard(height, width, world, device) for _ in range(depth)]
+        blocks = blocks_of(height)
+        self.my_blocks = (blocks - rank + world - 1) // world if blocks > rank else 0
+
+    def out_ptr(self, slot):
+        return self.shards[slot].data_ptr()
+
+    def submit(self, slot):
+        pitch = self.w * 4
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if self.my_blocks:
+            self._pa.device_copy2d_async(self.frames.ptrs[slot] + self.rank * 8 * pitch, self.world * 8 * pitch, self.shards[slot].data_ptr(), 8 * pitch,
+                                         8 * pitch, self.my_blocks, stream)
+        return self.frames.fence_async()
+
+    def finish(self, work, slot):
+        self.frames.finish(work)
+        return slot if self.rank == self.frames.dst else None
+
+    def download(self, assembled):
+        return self.frames.download(assembled) if assembled is not None else None
+
+    def close(self):
+        self.frames.close()
+
+    def abandon(self):
+        self.frames._release()
 
 
 class PeerTransport:

@@ -793,7 +793,7 @@ def test_random_camera_walks_teleport_like_the_oracle(gpu, scene_name, seed):
     assert crossings >= 1 or scene_name != "basics"
 
 
-@pytest.mark.parametrize("transport", ["gather", "p2p", "auto"])
+@pytest.mark.parametrize("transport", ["gather", "p2p", "copy", "auto"])
 def test_bench_multi_rank_rehearsal_assembles_the_same_frame(gpu, tmp_path, transport):
     """bench.py's multi-rank path (row-block sharding, rank-0 build choice broadcast, both frame transports, JSON) rehearsed on ONE
     GPU: PTL_BENCH_BACKEND=gloo lets 3 ranks share the device.  `gather`: double-buffered gather (staged through host memory here,
@@ -823,8 +823,10 @@ def test_bench_multi_rank_rehearsal_assembles_the_same_frame(gpu, tmp_path, tran
         assert cfg["transport"] == "rccl-gather"
     elif transport == "p2p":
         assert cfg["transport"] == "p2p-stores"
+    elif transport == "copy":
+        assert cfg["transport"] == "p2p-copy"
     else:
-        assert set(cfg["transport_ms_per_frame"]) == {"rccl-gather", "p2p-stores"} and not cfg["transport_notes"]
+        assert set(cfg["transport_ms_per_frame"]) == {"rccl-gather", "p2p-stores", "p2p-copy"} and not cfg["transport_notes"]
     assert np.array_equal(pa.png_read(str(one_png)), pa.png_read(str(tmp_path / "three.png")))
     # the diagnostics the first real 8-GPU run needs: every rank's kernel time, what assembling costs on top, and the
     # in-run check of the last timed frame against rank 0 rendering it alone
