@@ -141,7 +141,7 @@ PTL_FN bool ptl_plane_cull(const Ray& r, const mat4& plane_inv, float best_t) {
 #endif
 #endif
 }
-#define PTL_BEST_T(i) ((i).hit.hit ? (i).hit.t : __builtin_inff())
+#define PTL_BEST_T(i) (((i).hit.hit && (i).hit.t < ptl_far) ? (i).hit.t : ptl_far)  /* inside scene_intersect: best hit so far, capped by the caller's bound */
 
 // plane_intersect with the ray-independent half done beforehand: `unit_normal` = normalize(normal) comes from the
 // prologue kernel (ptl_tracer::derive); `flipped` tells the caller which of the two precomputed is_collinear verdicts applies.

@@ -72,9 +72,11 @@ struct ptl_tracer {
 #pragma clang force_cuda_host_device end
 #endif
 
-// Nearest object hit along r: one generated statement group per scene object.
-// (reference shell: src/frag.glsl:19-31)
-PTL_FN SceneIntersection scene_intersect(const Ray& r) {
+// Nearest object hit along r: one generated statement group per scene object.  (reference shell: src/frag.glsl:19-31)
+// `ptl_far`: a distance beyond which a hit cannot matter to the caller (the bounce loop passes the hit distance of the scene's
+// intersection-material snippet, which it evaluates first: a plane farther than that loses against the snippet whatever it is).  It
+// only tightens the bound of the wave-level plane cull (ptl_plane_cull): planes that are tested are tested in full.
+PTL_FN SceneIntersection scene_intersect(const Ray& r, float ptl_far = __builtin_inff()) {
     SceneIntersection i = SceneIntersection{0, intersection_none, false};
     SceneIntersection ihit = SceneIntersection{0, intersection_none, false};
     SurfaceIntersection hit = intersection_none;
@@ -162,8 +164,11 @@ PTL_FN vec3 sample_depth_gradient(float depth) {  // frag.glsl:101-104
 // One pass of the bounce loop for one ray: nearest hit, material, advance.  Returns true when the path has ended (`out` is
 // its result), false when `r` / `current_color` / `all_t` have been advanced to the next segment.  (frag.glsl:113-156)
 PTL_FN bool trace_segment(Ray& r, vec3& current_color, float& all_t, float camera_scale, const vec3& not_found_color, RayTraceResult& out) {
-    SceneIntersection i = scene_intersect(r);
+    // The reference evaluates scene_intersect first (frag.glsl:114-115); both are pure, and with the snippet's hit distance known the
+    // plane tests beyond it can be culled: `i` then is the nearest object in front of the snippet's hit, or whatever else survived --
+    // and whenever the two differ the snippet's hit is nearer than both and is what gets used below.
     SceneIntersectionWithMaterial i2 = scene_intersect_material_process(r);
+    SceneIntersection i = scene_intersect(r, (i2.scene.hit.hit && i2.scene.hit.t > 0.0f) ? i2.scene.hit.t : __builtin_inff());
 
     // `m` is left unset by the reference when a snippet reports hit with t <= 0 (GLSL:
     // undefined value); this build defines that case as the all-zero MaterialProcessing.
