@@ -56,7 +56,7 @@ def test_uniform_prologue_source_has_no_per_call_normalisation(gpu):
     pa = gpu
     scene = pa.Scene.from_file(pa.scene_path("triple_portal"))
     derived, plain = scene.generate_source(0), scene.generate_source(pa.FLAG_NO_DERIVED_UNIFORMS)
-    body = derived[derived.index("PTL_FN SceneIntersection scene_intersect(const Ray& r)"):derived.index("// Prologue (ptl_derive_kernel")]
+    body = derived[derived.index("PTL_FN SceneIntersection scene_intersect(const Ray& r"):derived.index("// Prologue (ptl_derive_kernel")]
     assert "plane_intersect_derived(" in body and "is_collinear(" not in body and "get_normal(" not in body
     assert "plane_intersect_derived(r," not in plain
     baked = scene.generate_source(pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)

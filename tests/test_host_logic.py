@@ -762,7 +762,7 @@ def test_derived_uniforms_cover_every_flat_plane_and_vanish_when_baked(pa, name)
     reference's per-call form is generated.  Derived members sit BEHIND the host-visible layout (uploads never touch them)."""
     scene = pa.Scene.from_file(pa.scene_path(name))
     src = scene.generate_source(0)
-    body = src[src.index("PTL_FN SceneIntersection scene_intersect(const Ray& r)"):src.index("// Prologue (ptl_derive_kernel")]
+    body = src[src.index("PTL_FN SceneIntersection scene_intersect(const Ray& r"):src.index("// Prologue (ptl_derive_kernel")]
     tests_in_body = body.count("plane_intersect_derived(")
     assert tests_in_body > 0 and "plane_intersect(" not in body.replace("plane_intersect_derived(", "")
     derive = src[src.index("PTL_FN void derive(ptl_uniform_block* out)"):src.index("// Material id -> what happens to the path.")]
