@@ -346,9 +346,15 @@ def main():
                 if not np.array_equal(images[names[0]], images[name]):
                     same[k] = 0
         dist.broadcast(same, 0)
+        # a transport whose transfer raised on ANY rank (it still took part in its fence, so nobody hangs) is dropped everywhere
+        broke = torch.tensor([1 if getattr(transports[name], "failed", None) else 0 for name in names], dtype=torch.int32, device=dev)
+        dist.all_reduce(broke, op=dist.ReduceOp.MAX)
         del images
         for k, name in enumerate(names):
-            if int(same[k].item()) == 0:
+            if int(broke[k].item()) == 1:
+                transport_notes[name] = "dropped: " + (getattr(transports[name], "failed", None) or "its transfer failed on another rank")
+                transports.pop(name).close()
+            elif int(same[k].item()) == 0:
                 transport_notes[name] = f"dropped: its frame differs from the one `{names[0]}` assembled"
                 transports.pop(name).close()
     transport_ms = {}

@@ -237,6 +237,7 @@ class CopyTransport:
         self.shards = [alloc_shard(height, width, world, device) for _ in range(depth)]
         blocks = blocks_of(height)
         self.my_blocks = (blocks - rank + world - 1) // world if blocks > rank else 0
+        self.failed = None  # the first error of a copy (the fence is still taken: the other ranks are waiting in it)
 
     def out_ptr(self, slot):
         return self.shards[slot].data_ptr()
@@ -244,9 +245,12 @@ class CopyTransport:
     def submit(self, slot):
         pitch = self.w * 4
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        if self.my_blocks:
-            self._pa.device_copy2d_async(self.frames.ptrs[slot] + self.rank * 8 * pitch, self.world * 8 * pitch, self.shards[slot].data_ptr(), 8 * pitch,
-                                         8 * pitch, self.my_blocks, stream)
+        if self.my_blocks and self.failed is None:
+            try:
+                self._pa.device_copy2d_async(self.frames.ptrs[slot] + self.rank * 8 * pitch, self.world * 8 * pitch, self.shards[slot].data_ptr(), 8 * pitch,
+                                             8 * pitch, self.my_blocks, stream)
+            except Exception as e:  # e.g. a runtime that refuses strided copies into an IPC mapping: reported by the caller, never a hang
+                self.failed = str(e)[:200]
         return self.frames.fence_async()
 
     def finish(self, work, slot):

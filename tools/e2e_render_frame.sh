@@ -3,12 +3,12 @@
 # --timing into scene load / kernel build (hiprtc or the code-object cache) / update + draw + download / PNG, for
 #   cold   empty code-object cache, comgr's own cache off: what a first frame of a new scene state costs
 #   warm   second run of the same command: the code object comes from portal_amd's cache
-# with the dynamic-uniform kernel (default), with --specialize 1 (scene state baked in) and with --fast.
+# with --specialize 0 (every scene uniform read at run time), by default (scene state baked in) and with --fast.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export AMD_COMGR_CACHE=0
 export PTL_CACHE_DIR=$(mktemp -d)
 cd $R
-for variant in "" "--specialize 1" "--specialize 1 --fast"; do
+for variant in "--specialize 0" "" "--fast"; do
     for run in cold warm; do
         echo "== render-frame portal_in_portal 3840x2160 depth 40 [$variant] $run"
         portal_amd/portal-amd render-frame scenes/portal_in_portal.ron --width 3840 --height 2160 --render-depth 40 --timing $variant --output /tmp/e2e.png 2>&1 | grep -v '^$'
@@ -16,8 +16,8 @@ for variant in "" "--specialize 1" "--specialize 1 --fast"; do
 done
 echo "== precompile (no GPU needed), then render-frame with the cache it filled"
 export PTL_CACHE_DIR=$(mktemp -d)
-portal_amd/portal-amd precompile scenes/portal_in_portal.ron --specialize 1
-portal_amd/portal-amd render-frame scenes/portal_in_portal.ron --width 3840 --height 2160 --render-depth 40 --timing --specialize 1 --output /tmp/e2e.png
+portal_amd/portal-amd precompile scenes/portal_in_portal.ron
+portal_amd/portal-amd render-frame scenes/portal_in_portal.ron --width 3840 --height 2160 --render-depth 40 --timing --output /tmp/e2e.png
 echo "== two ranks on this one GPU (control-flow rehearsal of --gpus N)"
 portal_amd/portal-amd render-frame scenes/portal_in_portal.ron --width 3840 --height 2160 --render-depth 40 --devices 0,0 --output /tmp/e2e2.png
 portal_amd/portal-amd render-frame scenes/portal_in_portal.ron --width 3840 --height 2160 --render-depth 40 --devices 0,0 --transport copy --output /tmp/e2e3.png
