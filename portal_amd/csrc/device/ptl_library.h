@@ -102,6 +102,19 @@ PTL_FN SurfaceIntersection plane_intersect_normalized(const Ray& r) {
 }
 
 // Ray against the z = 0 plane of `plane` given `plane_inv` = inverse(plane).
+#if PTL_DEVICE_BUILD && defined(PTL_FAST_MATH)
+// Tolerance mode: t = -o'.z / d'.z directly in the plane's frame.  The exact form normalises d' first and divides t by |d'| again
+// -- a square root, a reciprocal and two divisions that cancel algebraically.
+PTL_FN SurfaceIntersection ptl_plane_hit_fast(const Ray& r, const mat4& plane_inv, vec3 unit_normal) {
+    const vec4 o = plane_inv * r.o, d = plane_inv * r.d;
+    const float t = -o.z * __builtin_amdgcn_rcpf(d.z);
+    if (t < 0.0f) return intersection_none;
+    return SurfaceIntersection{true, t, fma(d.x, t, o.x), fma(d.y, t, o.y), unit_normal};
+}
+PTL_FN SurfaceIntersection plane_intersect(Ray r, const mat4& plane_inv, vec3 normal) {
+    return ptl_plane_hit_fast(r, plane_inv, normalize_normal(normal, r.d.sw<0, 1, 2>()));
+}
+#else
 PTL_FN SurfaceIntersection plane_intersect(Ray r, const mat4& plane_inv, vec3 normal) {
     normal = normalize_normal(normal, r.d.sw<0, 1, 2>());
     r = transform(plane_inv, r);
@@ -114,6 +127,7 @@ PTL_FN SurfaceIntersection plane_intersect(Ray r, const mat4& plane_inv, vec3 no
     }
     return result;
 }
+#endif
 
 // Wave-level exact cull of a plane test.  A plane only matters to scene_intersect if its hit is NEARER than the best one so far
 // (nearer(): hit, t > 0, t < best).  Two things that follow from the z row of plane_inv * ray alone -- 8 FMAs that the full test
@@ -148,6 +162,9 @@ PTL_FN bool ptl_plane_cull(const Ray& r, const mat4& plane_inv, float best_t) {
 PTL_FN SurfaceIntersection plane_intersect_derived(Ray r, const mat4& plane_inv, vec3 unit_normal, bool& flipped) {
     flipped = dot(unit_normal, r.d.sw<0, 1, 2>()) > 0.0f;
     if (flipped) unit_normal *= -1.0f;
+#if PTL_DEVICE_BUILD && defined(PTL_FAST_MATH)
+    return ptl_plane_hit_fast(r, plane_inv, unit_normal);
+#endif
     r = transform(plane_inv, r);
     float len = length(r.d);
     r.d = normalize(r.d);
