@@ -239,6 +239,17 @@ def main():
         candidates = {args.build: candidates[args.build]}
     elif args.waves >= 0:
         candidates = {f"w{args.waves}": (args.waves, "")}
+    # cold cache only: build the candidates side by side (hiprtc is thread-safe; a compile-only renderer needs no device) -- the loop
+    # below then finds every code object in the cache.  Builds with extra backend options go through their own child process anyway.
+    from concurrent.futures import ThreadPoolExecutor
+
+    def prebuild(item):
+        waves, extra = item
+        if not extra:
+            pa.SceneRenderer(pa.Scene.from_file(pa.scene_path(args.scene)), device=-1, flags=spec_flags | pa.flag_waves(waves))
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        list(pool.map(prebuild, candidates.values()))
     tried = {}
     for name, (waves, extra) in candidates.items():
         cand = make_renderer(waves, extra)
