@@ -169,3 +169,36 @@ def test_corpus_scene_on_gpu_matches_numpy_oracle(gpu, corpus_cache, path):
     ok = _bits_equal(out["rgba32f"], want["rgba32f"]).all(axis=2)
     assert ok.all(), f"{int((~ok).sum())} of {w*h} pixels differ from the oracle"
     assert np.array_equal(out["rgba8"], want["rgba8"])
+
+
+@pytest.mark.parametrize("build", ["dynamic", "specialised"])
+@pytest.mark.parametrize("name,views", [
+    ("portal_in_portal_plus_ultra", [None, ((0.4, 0.2, -0.3), 0.5, 1.3, 2.2)]),   # four deferred ray chains, subspace portals
+    ("portal_in_portal", [((0.0, 0.0, 0.0), 0.2, 1.5, 1.6), ((0.3, -0.1, 0.2), 2.8, 1.0, 2.4)]),  # close to / through the nested portals: the chains ARE read
+])
+def test_deferred_ray_chains_match_numpy_oracle_where_they_are_read(gpu, name, views, build):
+    """The translator applies loop-carried ray transforms of scene snippets lazily (glsl_translate.h); the oracle interprets the GLSL as
+    written.  Views that look into the nested portals -- where the deferred chains are flushed at many different iterations -- must
+    still be bit-equal: 320x180 frames, depth 30."""
+    from oracle.portal_oracle import Oracle
+
+    pa = gpu
+    path = os.path.join(CORPUS_ROOT, "scenes", name + ".ron")
+    w, h, depth = 320, 180, 30
+    flags = 0 if build == "dynamic" else (pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
+    scene = pa.Scene.from_file(path)
+    assert "ptl_pend_" in scene.generate_source(flags)
+    r = pa.SceneRenderer(scene, device=0, asset_root=CORPUS_ROOT, flags=flags)
+    r.set_option("render_depth", depth)
+    for view in views:
+        o = Oracle(path, asset_root=CORPUS_ROOT)
+        o.options["render_depth"] = depth
+        if view is not None:
+            look_at, alpha, beta, radius = view
+            r.set_camera(look_at, alpha, beta, radius)
+            o.camera = dict(look_at=look_at, alpha=alpha, beta=beta, r=radius)
+        out = r.draw(w, h, rgba8=True, rgba32f=True, segments=False)
+        want = o.render(w, h)
+        ok = _bits_equal(out["rgba32f"], want["rgba32f"]).all(axis=2)
+        assert ok.all(), f"{name} {view}: {int((~ok).sum())} of {w*h} pixels differ from the oracle"
+        assert int(want["segments"].max()) > 1  # rays do go through portals in this view
