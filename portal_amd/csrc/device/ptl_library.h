@@ -134,7 +134,9 @@ PTL_FN SurfaceIntersection plane_intersect(Ray r, const mat4& plane_inv, vec3 no
 // evaluates anyway -- settle that without the square root and the three correctly rounded divisions of plane_intersect:
 //   behind   o'.z and d'.z have the same sign: the quotient -o'.z / d'.z is negative (or rounds to -0), so t < 0 or t is not > 0;
 //   farther  a lower bound of t, -o'.z * rcp(d'.z) * (1 - 2^-16), is already above `best_t`.  (The exact chain and this estimate
-//            differ by less than a dozen rounding errors, < 2^-20 relative; NaN and infinity compare false / consistently.)
+//            differ by less than a dozen rounding errors, < 2^-20 relative; NaN and infinity compare false / consistently.  Only
+//            for |d'.z| >= 2^-100: below, the reciprocal estimate may overflow where the exact quotient of two tiny numbers is
+//            an ordinary distance.)
 // A cull decides nothing about the picture -- the culled test could never have been selected -- so frames stay bit-identical;
 // what it saves is the work.  It is taken per WAVE (ballot): the 64 rays of an 8x8 tile nearly always agree about which walls are
 // behind them or beyond the surface they have already found, and a uniform branch costs a scalar compare.
@@ -148,10 +150,10 @@ PTL_FN bool ptl_plane_cull(const Ray& r, const mat4& plane_inv, float best_t) {
     const bool behind = (oz > 0.0f && dz > 0.0f) || (oz < 0.0f && dz < 0.0f);
 #if PTL_DEVICE_BUILD
     const float t_low = (-oz * __builtin_amdgcn_rcpf(dz)) * (1.0f - 0x1p-16f);
-    return __builtin_amdgcn_ballot_w64(!(behind || t_low > best_t)) == 0ull;
+    return __builtin_amdgcn_ballot_w64(!(behind || (t_low > best_t && abs(dz) >= 0x1p-100f))) == 0ull;
 #else
     const float t_low = (-oz * (1.0f / dz)) * (1.0f - 0x1p-16f);
-    return behind || t_low > best_t;
+    return behind || (t_low > best_t && abs(dz) >= 0x1p-100f);
 #endif
 #endif
 }
