@@ -40,6 +40,7 @@ void usage() {
                  "                  [--stereoimage] [--no-skip-existing] [--filter-starts-with P] [--aa-count 4] [--render-depth 150]\n"
                  "                  [--scenes-dir DIR] [--out-dir DIR] [--device I] [--shard K/N] [--max-frames N] [--asset-root DIR]\n"
                  "                  [--specialize 0|1]   bake what is constant within a clip into the kernel (default: when it pays)\n"
+                 "                  [--fast]             tolerance mode for the whole clip (hardware rcp / sqrt, FMA contraction)\n"
                  "                  [--timing]           wait for every kernel and report GPU time (no host/GPU overlap)\n"
                  "       portal-amd emit-source <scene.ron> [--stage NAME]     print the generated HIP kernel source\n"
                  "       portal-amd check <scene.ron> [--stage NAME]           compile for gfx950 (no GPU needed); errors by scene element\n"
@@ -670,7 +671,7 @@ int encode_video(const Options& o, const std::string& scene_name, const std::str
 // is taken through the same history (every clip initialised so far, with its overrides), then compiled for gfx950 without a
 // device.  When the main thread gets to that clip it generates the same source and finds the binary on disk; if the histories
 // ever disagree it just compiles as before.
-void prefetch_clip_kernel(std::string path, std::vector<std::string> history, std::string asset_root) {
+void prefetch_clip_kernel(std::string path, std::vector<std::string> history, std::string asset_root, unsigned extra_flags) {
     ptl_scene* scene = nullptr;
     if (ptl_scene_load_file(path.c_str(), &scene) != PTL_OK) return;
     for (const std::string& clip : history) {
@@ -681,7 +682,7 @@ void prefetch_clip_kernel(std::string path, std::vector<std::string> history, st
         apply_clip_overrides(scene, nullptr, clip, nullptr);
     }
     ptl_renderer* r = nullptr;
-    if (ptl_renderer_create(scene, -1, asset_root.c_str(), kRenderFlags | 8u, &r, nullptr, 0) == PTL_OK) ptl_renderer_destroy(r);
+    if (ptl_renderer_create(scene, -1, asset_root.c_str(), kRenderFlags | 8u | extra_flags, &r, nullptr, 0) == PTL_OK) ptl_renderer_destroy(r);
     ptl_scene_free(scene);
 }
 
@@ -698,7 +699,7 @@ int render(const Options& o) {
         }
         std::vector<char> log(1 << 16);
         ptl_renderer* r = nullptr;
-        if (ptl_renderer_create(scene, o.device, o.asset_root.c_str(), kRenderFlags, &r, log.data(), log.size()) != PTL_OK) {
+        if (ptl_renderer_create(scene, o.device, o.asset_root.c_str(), kRenderFlags | (o.fast ? 64u : 0u), &r, log.data(), log.size()) != PTL_OK) {  // --fast: tolerance mode for the whole clip
             std::fprintf(stderr, "renderer: %s\n%s\n", ptl_last_error(), log.data());
             return 1;
         }
@@ -764,7 +765,7 @@ int render(const Options& o) {
             int n_workers = (int)std::min<size_t>({(size_t)6, todo.size() - 1, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)});
             pf.next = 1;  // the first clip is compiled by the main thread right away
             for (int wk = 0; wk < n_workers; ++wk)
-                pf.workers.emplace_back([&pf, &todo, &specialise, path, asset_root = o.asset_root] {
+                pf.workers.emplace_back([&pf, &todo, &specialise, path, asset_root = o.asset_root, extra_flags = o.fast ? 64u : 0u] {
                     for (;;) {
                         size_t k;
                         {
@@ -775,7 +776,7 @@ int render(const Options& o) {
                         if (specialise[k]) {
                             std::vector<std::string> history;
                             for (size_t c = 0; c <= k; ++c) history.push_back(todo[c].first);
-                            prefetch_clip_kernel(path, history, asset_root);
+                            prefetch_clip_kernel(path, history, asset_root, extra_flags);
                         }
                         {
                             std::unique_lock<std::mutex> lock(pf.mu);
