@@ -623,12 +623,26 @@ PTL_FN vec3 operator*(const mat3& m, const vec3& v) {
                 fma(m.c[2].y, v.z, fma(m.c[1].y, v.y, m.c[0].y * v.x)),
                 fma(m.c[2].z, v.z, fma(m.c[1].z, v.y, m.c[0].z * v.x)));
 }
+#if PTL_DEVICE_BUILD && defined(PTL_PACKED_MATVEC)
+// Two result components per instruction: v_pk_mul_f32 / v_pk_fma_f32 (gfx950 packed binary32: two IEEE operations per lane and
+// issue slot, each rounded exactly like its scalar form) on the column halves (c[k].x, c[k].y) and (c[k].z, c[k].w), the vector
+// component broadcast to both halves.  Same operations in the same order as the scalar form below.
+typedef float ptl_f2 __attribute__((ext_vector_type(2)));
+PTL_FN vec4 operator*(const mat4& m, const vec4& v) {
+    const ptl_f2 lo = __builtin_elementwise_fma(ptl_f2{m.c[3].x, m.c[3].y}, (ptl_f2)(v.w), __builtin_elementwise_fma(ptl_f2{m.c[2].x, m.c[2].y}, (ptl_f2)(v.z),
+                      __builtin_elementwise_fma(ptl_f2{m.c[1].x, m.c[1].y}, (ptl_f2)(v.y), ptl_f2{m.c[0].x, m.c[0].y} * (ptl_f2)(v.x))));
+    const ptl_f2 hi = __builtin_elementwise_fma(ptl_f2{m.c[3].z, m.c[3].w}, (ptl_f2)(v.w), __builtin_elementwise_fma(ptl_f2{m.c[2].z, m.c[2].w}, (ptl_f2)(v.z),
+                      __builtin_elementwise_fma(ptl_f2{m.c[1].z, m.c[1].w}, (ptl_f2)(v.y), ptl_f2{m.c[0].z, m.c[0].w} * (ptl_f2)(v.x))));
+    return vec4(lo[0], lo[1], hi[0], hi[1]);
+}
+#else
 PTL_FN vec4 operator*(const mat4& m, const vec4& v) {
     return vec4(fma(m.c[3].x, v.w, fma(m.c[2].x, v.z, fma(m.c[1].x, v.y, m.c[0].x * v.x))),
                 fma(m.c[3].y, v.w, fma(m.c[2].y, v.z, fma(m.c[1].y, v.y, m.c[0].y * v.x))),
                 fma(m.c[3].z, v.w, fma(m.c[2].z, v.z, fma(m.c[1].z, v.y, m.c[0].z * v.x))),
                 fma(m.c[3].w, v.w, fma(m.c[2].w, v.z, fma(m.c[1].w, v.y, m.c[0].w * v.x))));
 }
+#endif
 // row vector times matrix: component i is dot(v, column i)
 PTL_FN vec2 operator*(const vec2& v, const mat2& m) { return vec2(dot(v, m.c[0]), dot(v, m.c[1])); }
 PTL_FN vec3 operator*(const vec3& v, const mat3& m) { return vec3(dot(v, m.c[0]), dot(v, m.c[1]), dot(v, m.c[2])); }

@@ -69,9 +69,24 @@ PTL_FN vec3 my_refract(vec3 dir, vec3 normal, float refractive_index) {
 }
 
 // library.glsl:95-120
+#if PTL_DEVICE_BUILD && defined(PTL_PACKED_TRANSFORM)
+// Origin and direction go through the same matrix: the two products are computed as PAIRS (o.k, d.k) with the packed binary32
+// instructions of gfx950 (v_pk_mul_f32 / v_pk_fma_f32: two IEEE operations per lane and issue slot, each correctly rounded like its
+// scalar form), the matrix element broadcast to both halves.  Same operations in the same order as matrix * r.o and matrix * r.d.
+typedef float ptl_f2 __attribute__((ext_vector_type(2)));
+PTL_FN Ray transform(const mat4& m, const Ray& r) {
+    const ptl_f2 px = {r.o.x, r.d.x}, py = {r.o.y, r.d.y}, pz = {r.o.z, r.d.z}, pw = {r.o.w, r.d.w};
+#define PTL_ROW(k) __builtin_elementwise_fma((ptl_f2)(m.c[3].k), pw, __builtin_elementwise_fma((ptl_f2)(m.c[2].k), pz, \
+                   __builtin_elementwise_fma((ptl_f2)(m.c[1].k), py, (ptl_f2)(m.c[0].k) * px)))
+    const ptl_f2 x = PTL_ROW(x), y = PTL_ROW(y), z = PTL_ROW(z), w = PTL_ROW(w);
+#undef PTL_ROW
+    return Ray{vec4(x[0], y[0], z[0], w[0]), vec4(x[1], y[1], z[1], w[1]), r.tmul, r.in_subspace};
+}
+#else
 PTL_FN Ray transform(const mat4& matrix, const Ray& r) {
     return Ray{matrix * r.o, matrix * r.d, r.tmul, r.in_subspace};
 }
+#endif
 PTL_FN vec3 get_normal(const mat4& matrix) { return (matrix * vec4(0.0f, 0.0f, 1.0f, 0.0f)).sw<0, 1, 2>(); }
 PTL_FN Ray normalize_ray(Ray r) {
     float len = length(r.d);

@@ -43,12 +43,26 @@ struct ptl_tracer {
 #define PTL_U (*ptl_ubp)
 #endif
 #if PTL_DEVICE_BUILD && !defined(PTL_UNIFORMS_IN_LDS) && !defined(PTL_UNIFORM_RELOAD) && !defined(PTL_UNIFORM_HOIST)
+#if !defined(PTL_LAUNDER_POINTER)
+// What is laundered is an OFFSET (an opaque zero in an SGPR), not the pointer: the address stays visibly inside the __constant__
+// object, so the loads keep its address space and are SCALAR loads (s_load into SGPRs, operands of the VALU instructions as they
+// are).  Through a laundered POINTER (-DPTL_LAUNDER_POINTER, the round-1 form) the compiler only sees a generic address and reads
+// every uniform with a vector load -- one VGPR per dword, 185 VGPRs and two waves per SIMD for the un-specialised portal_in_portal
+// kernel: 1.30 ms against 0.84 ms (profiles/r02/variants7_scalar_uniform_loads.jsonl; same frames).
+#define PTL_RELAUNDER()                                   \
+    do {                                                  \
+        int ptl_zero = 0;                                 \
+        asm volatile("" : "+s"(ptl_zero));                \
+        ptl_ubp = reinterpret_cast<const ptl_uniform_block*>(reinterpret_cast<const char*>(&ptl_u) + ptl_zero); \
+    } while (0)
+#else
 #define PTL_RELAUNDER()                                   \
     do {                                                  \
         const ptl_uniform_block* ptl_fresh = &ptl_u;      \
         asm volatile("" : "+s"(ptl_fresh)); /* opaque, uniform (SGPR) */ \
         ptl_ubp = ptl_fresh;                              \
     } while (0)
+#endif
 #else
 #define PTL_RELAUNDER() ((void)0)
 #endif
@@ -98,6 +112,16 @@ PTL_FN SceneIntersection scene_intersect(const Ray& r, float ptl_far = __builtin
 // plain form, evaluated once per frame instead of once per trip and lane; the results land behind the uploaded uniforms.
 PTL_FN void derive(ptl_uniform_block* out) {
     (void)out;
+#ifdef PTL_DERIVED_BUILTINS
+    // per-PIXEL work that depends on nothing but the frame's builtins: the ray origins, tan(fov / 2), the reciprocal of the frame size
+    // -- ~100 VALU instructions every pixel would otherwise repeat (tan alone is two polynomial kernels and a division)
+    out->ptl_dv_origin = _camera * vec4(0.0f, 0.0f, 0.0f, 1.0f);
+    out->ptl_dv_origin_left = _camera_left_eye * vec4(0.0f, 0.0f, 0.0f, 1.0f);
+    out->ptl_dv_origin_right = _camera_right_eye * vec4(0.0f, 0.0f, 0.0f, 1.0f);
+    out->ptl_dv_tan_half_view = tan(_view_angle / 2.0f);
+    out->ptl_dv_pixel_size = ptl_rcp(min(_resolution.x, _resolution.y));
+    out->ptl_dv_half_resolution = _resolution / 2.0f;
+#endif
 //%derive//%
 }
 
@@ -339,10 +363,17 @@ PTL_FN vec3 PaniniProjection(vec2 tc, float fov, float d) {
 }
 
 // Primary ray for one image-plane position, then trace it.  (src/frag.glsl:408-464)
-PTL_FN vec3 get_color2(vec2 image_position, const mat4& camera_matrix, bool in_subspace, float camera_scale, vec2 resolution) {
+// `which_eye` (0 the camera, 1 / 2 the left / right eye matrix) only tells where the prologue kernel has put the ray origin
+// camera_matrix * (0, 0, 0, 1) of this frame.
+PTL_FN vec3 get_color2(vec2 image_position, const mat4& camera_matrix, bool in_subspace, float camera_scale, vec2 resolution, int which_eye) {
     const float Pi = 3.14159265359f;
     const float Pi05 = Pi * 0.5f;
+#ifdef PTL_DERIVED_BUILTINS
+    vec4 o = which_eye == 0 ? PTL_U.ptl_dv_origin : (which_eye == 1 ? PTL_U.ptl_dv_origin_left : PTL_U.ptl_dv_origin_right);
+#else
+    (void)which_eye;
     vec4 o = camera_matrix * vec4(0.0f, 0.0f, 0.0f, 1.0f);
+#endif
     vec4 d;
     if (_use_panini_projection == 1) {
         d = normalize(camera_matrix * vec4(PaniniProjection(vec2(image_position.x, image_position.y), _view_angle, _panini_param), 0.0f));
@@ -371,7 +402,11 @@ PTL_FN vec3 get_color2(vec2 image_position, const mat4& camera_matrix, bool in_s
         vec3 dir_local = vec3(sin(yaw) * cos(pitch), sin(pitch), cos(yaw) * cos(pitch));
         d = normalize(camera_matrix * vec4(dir_local, 0.0f));
     } else {  // pinhole
+#ifdef PTL_DERIVED_BUILTINS
+        float h = PTL_U.ptl_dv_tan_half_view;
+#else
         float h = tan(_view_angle / 2.0f);
+#endif
         d = normalize(camera_matrix * vec4(image_position.x * h, image_position.y * h, 1.0f, 0.0f));
     }
 
@@ -409,8 +444,8 @@ PTL_FN vec3 anaglyphCombineLinear(vec3 leftLin, vec3 rightLin, int mode) {
 PTL_FN vec3 get_color(vec2 image_position) {
 #ifdef PTL_ANAGLYPH
     if (_draw_anaglyph == 1) {
-        return anaglyphCombineLinear(get_color2(image_position, _camera_left_eye, _left_eye_in_subspace == 1, _left_eye_scale, _resolution),
-                                     get_color2(image_position, _camera_right_eye, _right_eye_in_subspace == 1, _right_eye_scale, _resolution),
+        return anaglyphCombineLinear(get_color2(image_position, _camera_left_eye, _left_eye_in_subspace == 1, _left_eye_scale, _resolution, 1),
+                                     get_color2(image_position, _camera_right_eye, _right_eye_in_subspace == 1, _right_eye_scale, _resolution, 2),
                                      _anaglyph_mode);
     }
 #endif
@@ -418,6 +453,7 @@ PTL_FN vec3 get_color(vec2 image_position) {
     bool final_in_subspace = _camera_in_subspace == 1;
     float final_scale = _camera_scale;
     vec2 final_resolution = _resolution;
+    int final_eye = 0;
 
     if (_draw_side_by_side == 1) {
         float coef = min(_resolution.x, _resolution.y);
@@ -429,15 +465,17 @@ PTL_FN vec3 get_color(vec2 image_position) {
             final_matrix = _camera_left_eye;
             final_in_subspace = _left_eye_in_subspace == 1;
             final_scale = _left_eye_scale;
+            final_eye = 1;
         } else {
             image_position = (position - vec2(resolution.x, 0.0f) - resolution / 2.0f) / coef2 * 2.0f;
             final_matrix = _camera_right_eye;
             final_in_subspace = _right_eye_in_subspace == 1;
             final_scale = _right_eye_scale;
+            final_eye = 2;
         }
         final_resolution = resolution;
     }
-    return get_color2(image_position, final_matrix, final_in_subspace, final_scale, final_resolution);
+    return get_color2(image_position, final_matrix, final_in_subspace, final_scale, final_resolution, final_eye);
 }
 
 // R2 low-discrepancy sub-pixel offsets.  (src/frag.glsl:506-513)
@@ -453,9 +491,14 @@ PTL_FN vec2 quasi_random(int i) {
 // FragColor, before the GL RGBA8 conversion.
 PTL_FN vec4 shade_pixel(vec2 position) {
     float coef = min(_resolution.x, _resolution.y);
+#ifdef PTL_DERIVED_BUILTINS
+    vec2 uv_screen = (position - PTL_U.ptl_dv_half_resolution) / coef * 2.0f;
+    float pixel_size = PTL_U.ptl_dv_pixel_size;
+#else
     vec2 uv_screen = (position - _resolution / 2.0f) / coef * 2.0f;
-    vec3 result = vec3(0.0f);
     float pixel_size = ptl_rcp(min(_resolution.x, _resolution.y));
+#endif
+    vec3 result = vec3(0.0f);
     for (int a = _aa_start; a < _aa_count + _aa_start; a++) {
         vec2 offset = quasi_random(a);
         result += get_color(uv_screen + offset * pixel_size * 2.0f);

@@ -403,9 +403,13 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 }
             }
         }
+        if (opts.derived_uniforms) s.add_string("#define PTL_DERIVED_BUILTINS 1\n");
         s.add_string("struct ptl_uniform_block {\n");
         for (auto& u : list) s.add_string(std::string("    ") + cxx_type(u.type) + " " + u.name + ";\n");
         // written by ptl_derive_kernel (never by the host: uploads stop at uniform_block_size)
+        if (opts.derived_uniforms)  // the per-pixel work that depends on the frame's builtins alone (ptl_trace.tpl derive())
+            s.add_string("    vec4 ptl_dv_origin;\n    vec4 ptl_dv_origin_left;\n    vec4 ptl_dv_origin_right;\n    vec2 ptl_dv_half_resolution;\n"
+                         "    float ptl_dv_tan_half_view;\n    float ptl_dv_pixel_size;\n");
         for (auto& d : gk.derived) s.add_string("    vec3 " + d.member + "_nrm;\n    int " + d.member + "_col;\n");
         s.add_string("};\n");
         s.add_string("#if PTL_DEVICE_BUILD\n__constant__ ptl_uniform_block ptl_u;\n#else\nptl_uniform_block ptl_u;\n#endif\n");

@@ -21,6 +21,28 @@ PATCHES = {
     "no_planes": [("    r = transform(plane_inv, r);\n    float len = length(r.d);", "    return intersection_none;\n    r = transform(plane_inv, r);\n    float len = length(r.d);")],
     # the snippet of the scene (intersection material) never hits
     "no_snippet": [("hit = intersect_material_0(r);", "hit = SceneIntersectionWithMaterial{scene_intersection_none, material_empty()};")],
+    # the scene snippet of portal_in_portal, piece by piece (scenes/portal_in_portal.ron:1127-1185): the nested copies of portal a ...
+    "pip_no_a_part": [("\tif (nearer(result.scene.hit, hit_a)) {", "\tif (false) {")],
+    # ... the nested copies of portal b: their inside test and material (the plane test and the ray chain stay)
+    "pip_no_b_inside": [("\tif (nearer(result.scene.hit, hit_b)) {", "\tif (false) {")],
+    # ... and the plane test of every copy of b as well: what remains is the chain r_b = a * (b0^-1 * r_b) and normal_b
+    "pip_no_b_test": [("\tif (nearer(result.scene.hit, hit_b)) {", "\tif (false) {"),
+                      ("\tSurfaceIntersection hit_b = plane_intersect_normalized(r3);", "\tSurfaceIntersection hit_b = intersection_none; if (len < 0.f) hit_b = plane_intersect_normalized(r3);")],
+    # ... b's plane test alive, its inside test and material never entered
+    "pip_b_plane_only": [("\tif (nearer(result.scene.hit, hit_b)) {", "\tif (nearer(result.scene.hit, hit_b) && hit_b.t < -1.0f) {")],
+    # ... the loop of is_inside_portal_advanced that walks a hit point back through the nested copies (O(size) per copy, both portals)
+    "pip_no_inner_loop": [("    for (int i = 0; i < size; i++) { // !FOR_VARIABLE!\n\t\tif (pos2.z > 0.f)", "    for (int i = 0; i < 0; i++) { // !FOR_VARIABLE!\n\t\tif (pos2.z > 0.f)")],
+    # ... b's material (with the deferred chain of r_teleport_b it flushes)
+    "pip_b_no_material": [("for (; ptl_pend_1 > 0; --ptl_pend_1) r_teleport_b=transform(a_mat,transform(b0_mat_inv,r_teleport_b)); result.material = material_teleport_transformed(offset_ray(r_teleport_b, hit_b.t), vec3(1.f));",
+                           "result.material = material_empty();")],
+    # EXPERIMENT (must draw the intact picture): the wave-level plane cull around the hand-inlined plane test of the copies of b
+    "pip_b_cull": [("\tRay r3 = transform(b0_mat_inv, r_b);\n\tfloat len = length(r3.d);\n\tr3 = normalize_ray(r3);\n\n\tSurfaceIntersection hit_b = plane_intersect_normalized(r3);\n\tif (hit_b.hit) {\n\t    hit_b.t /= len;\n\t    hit_b.n = normal3;\n\t}\n",
+                    "\tSurfaceIntersection hit_b = intersection_none;\n\tif (!ptl_plane_cull(r_b, b0_mat_inv, (result.scene.hit.hit ? result.scene.hit.t : __builtin_inff()))) {\n\tRay r3 = transform(b0_mat_inv, r_b);\n\tfloat len = length(r3.d);\n\tr3 = normalize_ray(r3);\n\thit_b = plane_intersect_normalized(r3);\n\tif (hit_b.hit) {\n\t    hit_b.t /= len;\n\t    hit_b.n = normal3;\n\t}\n\t}\n")],
+    # ... the ray-independent chain normal_b = b0 * (a^-1 * normal_b) of the loop (and with it the normalisation inside normalize_normal):
+    # does the specialised build fold it, or does every wave recompute it on every trip?
+    "pip_no_normal_chain": [("\tnormal_b = b0_mat * (a_mat_inv * normal_b);\n", "\n")],
+    # EXPERIMENT (intact picture): the loop over the nested copies fully unrolled -- the chain above becomes literals
+    "pip_unrolled": [("int ptl_pend_0 = 0; int ptl_pend_1 = 0; for (int size = 0; size < show_teleported_u; size++) {", "int ptl_pend_0 = 0; int ptl_pend_1 = 0;\n_Pragma(\"unroll\") for (int size = 0; size < show_teleported_u; size++) {")],
     # Complex objects (scene snippets intersect_<k>) skipped
     "no_complex": [("ihit = intersect_", "if (len < 0.0f) ihit = intersect_")],
     # no bounce loop at all: ray generation, AA loop, gamma, store
@@ -29,26 +51,43 @@ PATCHES = {
 }
 
 if __name__ == "__main__":
+    only = [a[2:] for a in sys.argv[1:] if a.startswith("--")]
+    sys.argv = [a for a in sys.argv if not a.startswith("--")]
+    if only:
+        PATCHES = {k: v for k, v in PATCHES.items() if k in only}
     name, w, h, depth = (sys.argv[1:] + ["portal_in_portal", "3840", "2160", "40"])[:4]
     w, h, depth = int(w), int(h), int(depth)
     scene = pa.Scene.from_file(pa.scene_path(name))
-    r = pa.SceneRenderer(scene, device=0, flags=pa.FLAG_SPECIALIZE_ALL)
+    device = -1 if os.environ.get("PTL_VARIANTS_PRECOMPILE") else 0  # -1: no GPU here, only fill the code-object cache
+    flags = int(os.environ.get("STUB_FLAGS", str(pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)))  # 0: the un-specialised kernel
+    r = pa.SceneRenderer(scene, device=device, flags=flags)
     r.set_option("render_depth", depth)
-    source = scene.generate_source(pa.FLAG_SPECIALIZE_ALL)
+    source = scene.generate_source(flags)
     layout, size = scene.uniform_layout()
     import ctypes as C
 
     for variant, subs in PATCHES.items():
         src = source
+        if variant.startswith("pip_") and name != "portal_in_portal":
+            continue
         for old, new in subs:
-            assert old in src, (variant, old)
+            if old not in src:
+                print(json.dumps({"scene": name, "variant": variant, "skipped": "pattern not in this build's source"}), flush=True)
+                src = None
+                break
             src = src.replace(old, new)
-        k = pa.Kernel(src, layout, size, device=0)
+        if src is None:
+            continue
+        k = pa.Kernel(src, layout, size, device=device)
+        if device < 0:
+            continue
         for uname, typ, _ in layout:
             if typ == pa.PTL_SAMPLER:
                 continue
             v = r.uniform_value(uname, w, h)
             if v is not None:
                 k.set_uniform(uname, typ, v)
-        times = [k.render(w, h)["ms"] for _ in range(8)]
-        print(json.dumps({"scene": name, "variant": variant, "ms": round(float(np.median(times[2:])), 4)}), flush=True)
+        outs = [k.render(w, h) for _ in range(8)]
+        times = [o["ms"] for o in outs]
+        import hashlib
+        print(json.dumps({"scene": name, "variant": variant, "ms": round(float(np.median(times[2:])), 4), "sha": hashlib.sha1(outs[-1]["rgba8"].tobytes()).hexdigest()[:10]}), flush=True)

@@ -71,6 +71,28 @@ VARIANTS = {
     "r2_dyn_nowaveloop_noderived": "NO_DERIVED -DPTL_NO_WAVE_LOOP",
     "r2_all": "SPECIALIZE_ALL",
     "r2_all_nowaveloop": "SPECIALIZE_ALL -DPTL_NO_WAVE_LOOP",
+    "r2_all_noderived": "SPECIALIZE_ALL NO_DERIVED",
+    "r2_all_pt": "SPECIALIZE_ALL -DPTL_PACKED_TRANSFORM",
+    "r2_all_pt_w3": "SPECIALIZE_ALL -DPTL_PACKED_TRANSFORM -DPTL_WAVES_PER_EU=3",
+    "r2_all_pt_w4": "SPECIALIZE_ALL -DPTL_PACKED_TRANSFORM -DPTL_WAVES_PER_EU=4",
+    "r2_all_pm": "SPECIALIZE_ALL -DPTL_PACKED_MATVEC",
+    "r2_all_pm_w3": "SPECIALIZE_ALL -DPTL_PACKED_MATVEC -DPTL_WAVES_PER_EU=3",
+    "r2_all_pm_w4": "SPECIALIZE_ALL -DPTL_PACKED_MATVEC -DPTL_WAVES_PER_EU=4",
+    "r2_all_w3": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=3",
+    "r2_all_w4": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4",
+    "r2_dyn_pt": "-DPTL_PACKED_TRANSFORM",
+    "r2_dyn_pm": "-DPTL_PACKED_MATVEC",
+    "r2_dyn_w3": "-DPTL_WAVES_PER_EU=3",
+    "r2_dyn_pt_w3": "-DPTL_PACKED_TRANSFORM -DPTL_WAVES_PER_EU=3",
+    "r2_dyn_pm_w3": "-DPTL_PACKED_MATVEC -DPTL_WAVES_PER_EU=3",
+    # scalar uniform loads (offset laundering, ptl_trace.tpl PTL_RELAUNDER) are the default since variants7; the round-1 form for A/B:
+    "r2_dyn_lp": "-DPTL_LAUNDER_POINTER",
+    "r2_dyn_lp_w3": "-DPTL_LAUNDER_POINTER -DPTL_WAVES_PER_EU=3",
+    "r2_ints_lp": "SPECIALIZE -DPTL_LAUNDER_POINTER",
+    "r2_all_lp": "SPECIALIZE_ALL -DPTL_LAUNDER_POINTER",
+    "r2_dyn_w4": "-DPTL_WAVES_PER_EU=4",
+    "r2_dyn_w5": "-DPTL_WAVES_PER_EU=5",
+    "r2_ints_w4": "SPECIALIZE -DPTL_WAVES_PER_EU=4",
     "r2_ints": "SPECIALIZE",
     "r2_ints_noderived": "SPECIALIZE NO_DERIVED",
     "r2_dyn_nocull": "-DPTL_NO_PLANE_CULL",
@@ -124,6 +146,9 @@ def run_one(case, vname, flags):
         if t.startswith("BLOCK_WAVES="):
             os.environ["PTL_BLOCK_WAVES"] = t.split("=")[1]
     scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    if os.environ.get("PTL_VARIANTS_PRECOMPILE"):  # no GPU here: fill the code-object cache that travels to the GPU box
+        r = pa.SceneRenderer(scene, device=-1, flags=rflags)
+        return {"case": case, "variant": vname, "regs": notes(r.code_object())}
     r = pa.SceneRenderer(scene, device=0, flags=rflags)
     r.set_option("render_depth", d)
     r.set_option("aa_count", aa)
