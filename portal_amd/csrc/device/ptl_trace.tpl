@@ -67,6 +67,12 @@ struct ptl_tracer {
 #define PTL_RELAUNDER() ((void)0)
 #endif
 
+#if defined(PTL_NO_PIXEL_RELAUNDER)
+#define PTL_PIXEL_RELAUNDER() ((void)0)
+#else
+#define PTL_PIXEL_RELAUNDER() PTL_RELAUNDER()
+#endif
+
 // Scene snippets are plain GLSL functions without HIP attributes: let clang treat every
 // function declared in this region as __host__ __device__.
 #if PTL_DEVICE_BUILD
@@ -362,6 +368,49 @@ PTL_FN vec3 PaniniProjection(vec2 tc, float fov, float d) {
     return vec3(sinPhi, tanTheta, cosPhi) * s;
 }
 
+// camera_matrix * v.  On the device the matrix is named, not passed: `which_eye` says which of the three uniform matrices it is (0 the
+// camera, 1 / 2 the left / right eye).  Side-by-side stereo picks the eye by pixel column, so `which_eye` can differ between the lanes
+// of a wave; as a per-lane POINTER the matrix would be read with 16 vector loads at the start of every pixel.  Instead the wave works
+// through the eyes its lanes ask for one at a time (nearly always one): the choice is then uniform and the matrix comes through
+// scalar loads.
+PTL_FN vec4 camera_times(const mat4& camera_matrix, int which_eye, vec4 v) {
+#if PTL_DEVICE_BUILD
+    (void)camera_matrix;
+    vec4 product = vec4(0.0f);
+    for (bool done = false; !done;) {
+        const int eye = __builtin_amdgcn_readfirstlane(which_eye);
+        if (which_eye == eye) {
+            const mat4& m = eye == 0 ? _camera : (eye == 1 ? _camera_left_eye : _camera_right_eye);
+            product = m * v;
+            done = true;
+        }
+    }
+    return product;
+#else
+    (void)which_eye;
+    return camera_matrix * v;
+#endif
+}
+
+#ifdef PTL_DERIVED_BUILTINS
+// camera_matrix * (0, 0, 0, 1), which the prologue kernel has left behind the uniforms; read like camera_times reads the matrix.
+PTL_FN vec4 camera_origin(int which_eye) {
+#if PTL_DEVICE_BUILD
+    vec4 o = vec4(0.0f);
+    for (bool done = false; !done;) {
+        const int eye = __builtin_amdgcn_readfirstlane(which_eye);
+        if (which_eye == eye) {
+            o = eye == 0 ? PTL_U.ptl_dv_origin : (eye == 1 ? PTL_U.ptl_dv_origin_left : PTL_U.ptl_dv_origin_right);
+            done = true;
+        }
+    }
+    return o;
+#else
+    return which_eye == 0 ? PTL_U.ptl_dv_origin : (which_eye == 1 ? PTL_U.ptl_dv_origin_left : PTL_U.ptl_dv_origin_right);
+#endif
+}
+#endif
+
 // Primary ray for one image-plane position, then trace it.  (src/frag.glsl:408-464)
 // `which_eye` (0 the camera, 1 / 2 the left / right eye matrix) only tells where the prologue kernel has put the ray origin
 // camera_matrix * (0, 0, 0, 1) of this frame.
@@ -369,14 +418,13 @@ PTL_FN vec3 get_color2(vec2 image_position, const mat4& camera_matrix, bool in_s
     const float Pi = 3.14159265359f;
     const float Pi05 = Pi * 0.5f;
 #ifdef PTL_DERIVED_BUILTINS
-    vec4 o = which_eye == 0 ? PTL_U.ptl_dv_origin : (which_eye == 1 ? PTL_U.ptl_dv_origin_left : PTL_U.ptl_dv_origin_right);
+    vec4 o = camera_origin(which_eye);
 #else
-    (void)which_eye;
-    vec4 o = camera_matrix * vec4(0.0f, 0.0f, 0.0f, 1.0f);
+    vec4 o = camera_times(camera_matrix, which_eye, vec4(0.0f, 0.0f, 0.0f, 1.0f));
 #endif
     vec4 d;
     if (_use_panini_projection == 1) {
-        d = normalize(camera_matrix * vec4(PaniniProjection(vec2(image_position.x, image_position.y), _view_angle, _panini_param), 0.0f));
+        d = normalize(camera_times(camera_matrix, which_eye, vec4(PaniniProjection(vec2(image_position.x, image_position.y), _view_angle, _panini_param), 0.0f)));
     } else if (_use_360_camera == 1) {  // equirectangular, 2:1, black bars outside
         float coef = min(resolution.x, resolution.y);
         float ax = resolution.x / coef;
@@ -394,20 +442,20 @@ PTL_FN vec3 get_color2(vec2 image_position, const mat4& camera_matrix, bool in_s
         float yaw = (image_position.x / rx) * Pi;
         float pitch = (image_position.y / ry) * Pi05;
         vec3 dir_local = vec3(sin(yaw) * cos(pitch), sin(pitch), cos(yaw) * cos(pitch));
-        d = normalize(camera_matrix * vec4(dir_local, 0.0f));
+        d = normalize(camera_times(camera_matrix, which_eye, vec4(dir_local, 0.0f)));
     } else if (_use_180_camera == 1) {  // VR180 front hemisphere
         if (abs(image_position.x) > 1.0f || abs(image_position.y) > 1.0f) return vec3(0.0f);
         float yaw = image_position.x * Pi05;
         float pitch = image_position.y * Pi05;
         vec3 dir_local = vec3(sin(yaw) * cos(pitch), sin(pitch), cos(yaw) * cos(pitch));
-        d = normalize(camera_matrix * vec4(dir_local, 0.0f));
+        d = normalize(camera_times(camera_matrix, which_eye, vec4(dir_local, 0.0f)));
     } else {  // pinhole
 #ifdef PTL_DERIVED_BUILTINS
         float h = PTL_U.ptl_dv_tan_half_view;
 #else
         float h = tan(_view_angle / 2.0f);
 #endif
-        d = normalize(camera_matrix * vec4(image_position.x * h, image_position.y * h, 1.0f, 0.0f));
+        d = normalize(camera_times(camera_matrix, which_eye, vec4(image_position.x * h, image_position.y * h, 1.0f, 0.0f)));
     }
 
     RayTraceResult trace = ray_tracing(Ray{o, d, 1.0f, in_subspace}, camera_scale);
@@ -490,6 +538,7 @@ PTL_FN vec2 quasi_random(int i) {
 // gamma-2 encode src/frag.glsl:515-527,550-551).  Returns the RGBA the reference writes to
 // FragColor, before the GL RGBA8 conversion.
 PTL_FN vec4 shade_pixel(vec2 position) {
+    PTL_PIXEL_RELAUNDER();  // the per-pixel part reads its builtins (camera matrix, projection) through scalar loads as well
     float coef = min(_resolution.x, _resolution.y);
 #ifdef PTL_DERIVED_BUILTINS
     vec2 uv_screen = (position - PTL_U.ptl_dv_half_resolution) / coef * 2.0f;
@@ -499,11 +548,13 @@ PTL_FN vec4 shade_pixel(vec2 position) {
     float pixel_size = ptl_rcp(min(_resolution.x, _resolution.y));
 #endif
     vec3 result = vec3(0.0f);
-    for (int a = _aa_start; a < _aa_count + _aa_start; a++) {
+    const int aa_count = _aa_count, aa_end = aa_count + _aa_start;  // read once: later reads would go through whatever the bounce loop left
+    for (int a = _aa_start; a < aa_end; a++) {
+        PTL_PIXEL_RELAUNDER();
         vec2 offset = quasi_random(a);
         result += get_color(uv_screen + offset * pixel_size * 2.0f);
     }
-    result = sqrt(result / float(_aa_count));
+    result = sqrt(result / float(aa_count));
     return vec4(result, 1.0f);
 }
 

@@ -93,6 +93,9 @@ VARIANTS = {
     "r2_dyn_w4": "-DPTL_WAVES_PER_EU=4",
     "r2_dyn_w5": "-DPTL_WAVES_PER_EU=5",
     "r2_ints_w4": "SPECIALIZE -DPTL_WAVES_PER_EU=4",
+    "r2_dyn_npr": "-DPTL_NO_PIXEL_RELAUNDER",
+    "r2_ints_npr": "SPECIALIZE -DPTL_NO_PIXEL_RELAUNDER",
+    "r2_all_npr": "SPECIALIZE_ALL -DPTL_NO_PIXEL_RELAUNDER",
     "r2_ints": "SPECIALIZE",
     "r2_ints_noderived": "SPECIALIZE NO_DERIVED",
     "r2_dyn_nocull": "-DPTL_NO_PLANE_CULL",
