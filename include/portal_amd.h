@@ -200,6 +200,10 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * bit7 = NO deferred loop updates: by default a loop-carried ray transform in a scene snippet (`X = transform(A_mat, transform(B_mat_inv, X));`
  * on every iteration, X read only where a hit is recorded) is replaced by a counter and applied right before X is read -- the same
  * operations on the same values for the rays that read X, none for the others; identical frames (glsl_translate.h has the conditions).
+ * bit12 = NO hoisted uniform work: by default every expression of a scene snippet that depends on run-time uniforms alone
+ * (`b0_mat * (a_mat_inv * normal_b)`, `d_mat * c_mat_inv`, normalize() of such a normal ...), loop-carried chains of them
+ * included, is computed by the prologue kernel of bit5 into members behind the derived uniforms, and the snippet reads it
+ * from there -- the same expression text compiled in the same module, identical frames (host/glsl_hoist.h).  Off with bit5.
  * ptl_renderer_create additionally reads bits 8-11 as an occupancy hint n (0 = none):
  * the kernel is built with __launch_bounds__(256, n), i.e. at least n waves per SIMD. */
 int ptl_scene_generate_source(ptl_scene* s, unsigned flags, char** source);

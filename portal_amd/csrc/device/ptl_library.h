@@ -193,6 +193,24 @@ PTL_FN SurfaceIntersection plane_intersect_derived(Ray r, const mat4& plane_inv,
     return result;
 }
 
+// Staged forms of three library functions for calls whose normal argument is a uniform-only expression of a scene snippet
+// (host/glsl_hoist.h re-targets such calls): the part that depends on that argument alone -- normalize(normal), length(b) -- is
+// evaluated by the prologue kernel and passed in; what is left is the original's remaining operations in the original's order.
+PTL_FN vec3 ptl_normalize_normal_unit(vec3 unit_normal, vec3 dir) {  // normalize_normal(n, dir) given normalize(n)
+    if (dot(unit_normal, dir) > 0.0f) unit_normal *= -1.0f;
+    return unit_normal;
+}
+PTL_FN SurfaceIntersection ptl_plane_intersect_unit(Ray r, const mat4& plane_inv, vec3 unit_normal) {  // plane_intersect(r, inv, n) given normalize(n)
+    bool flipped;
+    return plane_intersect_derived(r, plane_inv, unit_normal, flipped);
+}
+PTL_FN bool ptl_is_collinear_len(vec3 a, vec3 b, float length_b) {  // is_collinear(a, b) given length(b)
+    return abs(dot(a, b) / (length(a) * length_b) - 1.0f) < 0.01f;
+}
+PTL_FN bool ptl_is_collinear_len0(vec3 a, vec3 b, float length_a) {  // is_collinear(a, b) given length(a)
+    return abs(dot(a, b) / (length_a * length(b)) - 1.0f) < 0.01f;
+}
+
 // --- colours ------------------------------------------------------- library.glsl:169-288
 PTL_FN vec3 color(float r, float g, float b) { return vec3(r * r, g * g, b * b); }
 

@@ -116,6 +116,7 @@ PTL_FN SceneIntersection scene_intersect(const Ray& r, float ptl_far = __builtin
 // are run-time uniforms -- the unit normal plane_intersect would normalise on every call and the two verdicts
 // is_collinear(hit.n, normal) can have (hit.n is that unit normal or its negation).  Same functions, same operations as the
 // plain form, evaluated once per frame instead of once per trip and lane; the results land behind the uploaded uniforms.
+#define PTL_DV_OUT (*out)
 PTL_FN void derive(ptl_uniform_block* out) {
     (void)out;
 #ifdef PTL_DERIVED_BUILTINS

@@ -1,5 +1,6 @@
 // codegen.cpp -- see codegen.h.
 #include "codegen.h"
+#include "glsl_hoist.h"
 
 #include <cstring>
 
@@ -321,7 +322,61 @@ std::vector<UniformUpload> evaluate_scene_uniforms(const Scene& scene, std::vect
 // ------------------------------------------------------------------------------------------
 namespace {
 
-std::string snippet(const std::string& glsl, const CodegenFlags& flags) { return translate_glsl(filter_tagged_lines(glsl, flags), flags.defer_loop_updates); }
+// Scene snippets on their way into the kernel: tag filter, (optionally) uniform-only work moved to the prologue kernel
+// (glsl_hoist.h; prepared for all snippets at once by `prepare`, because the members it creates belong into the uniform block
+// that is emitted before any snippet), GLSL -> C++.
+struct SnippetTranslator {
+    const CodegenFlags& flags;
+    std::map<const std::string*, std::string> hoisted;  // source text of a snippet (by address) -> filtered + hoisted GLSL
+    std::vector<HoistedMember> members;
+    std::string prologue;  // GLSL
+    int next_member = 0;
+
+    void prepare(const std::string& code, const HoistParams& base, bool body_only, std::vector<std::string> params) {
+        HoistParams hp = base;
+        hp.body_only = body_only;
+        hp.body_params = std::move(params);
+        HoistResult r = hoist_uniform_work(filter_tagged_lines(code, flags), hp, next_member);
+        if (r.members.empty()) return;
+        hoisted[&code] = r.glsl;
+        members.insert(members.end(), r.members.begin(), r.members.end());
+        prologue += r.prologue;
+    }
+    std::string operator()(const std::string& code) const {
+        auto it = hoisted.find(&code);
+        return translate_glsl(it != hoisted.end() ? it->second : filter_tagged_lines(code, flags), flags.defer_loop_updates);
+    }
+};
+
+// names of the functions a GLSL text defines with an `out` / `inout` parameter
+void functions_with_out_params(const std::string& glsl, std::set<std::string>& names) {
+    size_t pos = 0;
+    while ((pos = glsl.find("out", pos)) != std::string::npos) {
+        const bool word_start = pos == 0 || !(std::isalnum((unsigned char)glsl[pos - 1]) || glsl[pos - 1] == '_');
+        const size_t after = pos + 3;
+        const bool word_end = after < glsl.size() && std::isspace((unsigned char)glsl[after]);
+        const bool inout = pos >= 2 && glsl.compare(pos - 2, 2, "in") == 0 && (pos == 2 || !(std::isalnum((unsigned char)glsl[pos - 3]) || glsl[pos - 3] == '_'));
+        if ((word_start || inout) && word_end) {
+            // walk back to the `(` that opens this parameter list; the identifier in front of it is the function
+            int depth = 0;
+            size_t k = pos;
+            while (k > 0) {
+                --k;
+                if (glsl[k] == ')') ++depth;
+                else if (glsl[k] == '(') {
+                    if (depth == 0) break;
+                    --depth;
+                }
+            }
+            size_t e = k;
+            while (e > 0 && std::isspace((unsigned char)glsl[e - 1])) --e;
+            size_t b = e;
+            while (b > 0 && (std::isalnum((unsigned char)glsl[b - 1]) || glsl[b - 1] == '_')) --b;
+            if (e > b) names.insert(glsl.substr(b, e - b));
+        }
+        pos = after;
+    }
+}
 
 struct PortalMaterialNames {
     int pos;
@@ -333,6 +388,7 @@ struct PortalMaterialNames {
 GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& flags, const KernelOptions& opts) {
     GeneratedKernel gk;
     std::map<std::string, StringStorage> storages;
+    SnippetTranslator snippet{flags, {}, {}, {}, 0};
 
     // --- uniform block --------------------------------------------------------------------
     {
@@ -403,6 +459,21 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 }
             }
         }
+        // --- uniform-only work of the scene snippets: members behind the derived planes, filled by the same prologue kernel -----
+        if (opts.derived_uniforms && opts.hoist_uniform_work) {
+            HoistParams hp;
+            for (auto& u : list)
+                if (u.type != UniformType::Sampler && !baked.count(u.name)) hp.uniforms[u.name] = cxx_type(u.type);
+            for (const NamedCode& lib : scene.library) functions_with_out_params(lib.code, hp.functions_with_out_params);
+            for (const NamedCode& lib : scene.library) snippet.prepare(lib.code, hp, false, {});
+            for (const Material& m : scene.materials)
+                if (m.kind == Material::Complex) snippet.prepare(m.code, hp, true, {"hit", "r", "i"});
+            for (const Object& o : scene.objects) {
+                if (o.kind == Object::Flat) snippet.prepare(o.code, hp, true, o.portal ? std::vector<std::string>{"pos", "x", "y", "back", "first"} : std::vector<std::string>{"pos", "x", "y", "back"});
+                else if (o.kind == Object::Complex) snippet.prepare(o.code, hp, true, o.portal ? std::vector<std::string>{"r", "first"} : std::vector<std::string>{"r"});
+            }
+            for (const NamedCode& im : scene.intersection_materials) snippet.prepare(im.code, hp, true, {"r"});
+        }
         if (opts.derived_uniforms) s.add_string("#define PTL_DERIVED_BUILTINS 1\n");
         s.add_string("struct ptl_uniform_block {\n");
         for (auto& u : list) s.add_string(std::string("    ") + cxx_type(u.type) + " " + u.name + ";\n");
@@ -411,6 +482,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             s.add_string("    vec4 ptl_dv_origin;\n    vec4 ptl_dv_origin_left;\n    vec4 ptl_dv_origin_right;\n    vec2 ptl_dv_half_resolution;\n"
                          "    float ptl_dv_tan_half_view;\n    float ptl_dv_pixel_size;\n");
         for (auto& d : gk.derived) s.add_string("    vec3 " + d.member + "_nrm;\n    int " + d.member + "_col;\n");
+        for (auto& m : snippet.members) s.add_string("    " + m.type + " " + m.name + (m.length ? "[" + std::to_string(m.length) + "]" : "") + ";\n");
         s.add_string("};\n");
         s.add_string("#if PTL_DEVICE_BUILD\n__constant__ ptl_uniform_block ptl_u;\n#else\nptl_uniform_block ptl_u;\n#endif\n");
         // where the kernel reads uniforms from: the __constant__ block through the scalar cache
@@ -455,7 +527,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                                           f32_literal(m.color[2]) + "), " + f32_literal(m.refractive_index) + ");\n");
                     break;
                 case Material::Complex:
-                    processing.add_identifier_string({"material", m.name}, snippet(m.code, flags));
+                    processing.add_identifier_string({"material", m.name}, snippet(m.code));
                     processing.add_string("\n");
                     break;
             }
@@ -487,12 +559,12 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             if (o.kind == Object::Flat) {
                 if (o.portal) s.add_string("PTL_FN int is_inside_" + p + "(vec4 pos, float x, float y, bool back, bool first) {\n");
                 else s.add_string("PTL_FN int is_inside_" + p + "(vec4 pos, float x, float y, bool back) {\n");
-                s.add_identifier_string({"object", o.name}, snippet(o.code, flags));
+                s.add_identifier_string({"object", o.name}, snippet(o.code));
                 s.add_string("\n}\n");
             } else if (o.kind == Object::Complex) {
                 if (o.portal) s.add_string("PTL_FN SceneIntersection intersect_" + p + "(Ray r, bool first) {\n");
                 else s.add_string("PTL_FN SceneIntersection intersect_" + p + "(Ray r) {\n");
-                s.add_identifier_string({"object", o.name}, snippet(o.code, flags));
+                s.add_identifier_string({"object", o.name}, snippet(o.code));
                 s.add_string("\n}\n");
             }
         }
@@ -601,6 +673,11 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             s.add_string("        out->" + d.member + "_nrm = unit;\n");
             s.add_string("        out->" + d.member + "_col = (is_collinear(unit, normal) ? 1 : 0) | (is_collinear(unit * -1.0f, normal) ? 2 : 0);\n    }\n");
         }
+        if (!snippet.prologue.empty()) {
+            s.add_string("    // uniform-only work of the scene snippets (host/glsl_hoist.h)\n");
+            s.add_string(translate_glsl(snippet.prologue, false));
+        }
+        gk.hoisted_members = (int)snippet.members.size();
         storages["derive"] = std::move(s);
     }
 
@@ -610,7 +687,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         for (size_t pos = 0; pos < scene.intersection_materials.size(); ++pos) {
             const NamedCode& im = scene.intersection_materials[pos];
             fns.add_string("PTL_FN SceneIntersectionWithMaterial intersect_material_" + std::to_string(pos) + "(Ray r) {\n");
-            fns.add_identifier_string({"intersection_material", im.name}, snippet(im.code, flags));
+            fns.add_identifier_string({"intersection_material", im.name}, snippet(im.code));
             fns.add_string("\n}\n");
             calls.add_string("hit = intersect_material_" + std::to_string(pos) + "(r);\n");
             calls.add_string("if (nearer(result.scene.hit, hit.scene.hit)) { result = hit; }\n\n");
@@ -625,7 +702,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         for (const NamedCode& lib : scene.library) {
             // scene functions are plain GLSL functions: give them the device attribute by defining
             // them inside a PTL_FN-aware region (see ptl_scene_fn below)
-            s.add_identifier_string({"library", lib.name}, snippet(lib.code, flags));
+            s.add_identifier_string({"library", lib.name}, snippet(lib.code));
         }
         storages["library"] = std::move(s);
     }

@@ -83,6 +83,8 @@ struct KernelOptions {
     // instead of once per bounce-loop trip by every lane.  Same functions, same binary32 operations: identical frames.
     // Applies to matrices that are run-time uniforms (a baked matrix folds at JIT time anyway).
     bool derived_uniforms = true;
+    // ... and the uniform-only work of the scene snippets with them (glsl_hoist.h); no effect without derived_uniforms
+    bool hoist_uniform_work = true;
     bool fast_math = false;  // PTL_FAST_MATH: hardware rcp / sqrt / rsq (1 ulp), a/b = a * rcp(b), FMA contraction: tolerance mode, not bit-exact
 };
 
@@ -101,6 +103,7 @@ struct GeneratedKernel {
     size_t uniform_block_size = 0;
     std::vector<std::string> defines;   // e.g. "PTL_COUNT_SEGMENTS"
     std::vector<UniformUpload> baked;   // the values compiled in as literals (specialised builds)
+    int hoisted_members = 0;            // ... plus this many members holding uniform-only work of the scene snippets (glsl_hoist.h)
     std::vector<DerivedPlane> derived;  // members appended to the block behind uniform_block_size, written on the device
 };
 

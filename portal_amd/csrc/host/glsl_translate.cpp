@@ -1,5 +1,6 @@
 // glsl_translate.cpp -- see glsl_translate.h.
 #include "glsl_translate.h"
+#include "glsl_tokens.h"
 
 #include <stdexcept>
 
@@ -32,14 +33,7 @@ std::string filter_tagged_lines(const std::string& text, const CodegenFlags& f) 
     return out;
 }
 
-namespace {
-
-struct Token {
-    enum Kind { Space, Comment, Ident, Number, Punct, Preproc, Raw } kind;  // Raw: text inserted by a rewrite, emitted verbatim
-    std::string text;
-};
-
-std::vector<Token> tokenize(const std::string& s) {
+std::vector<Token> tokenize_glsl(const std::string& s) {
     std::vector<Token> out;
     size_t i = 0, n = s.size();
     bool line_start = true;
@@ -129,6 +123,10 @@ std::vector<Token> tokenize(const std::string& s) {
     }
     return out;
 }
+
+namespace {
+
+std::vector<Token> tokenize(const std::string& s) { return tokenize_glsl(s); }
 
 bool is_float_literal(const std::string& t) {
     if (t.size() > 1 && t[0] == '0' && (t[1] == 'x' || t[1] == 'X')) return false;

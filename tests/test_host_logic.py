@@ -771,9 +771,9 @@ def test_derived_uniforms_cover_every_flat_plane_and_vanish_when_baked(pa, name)
     block = src[src.index("struct ptl_uniform_block {"):src.index("};", src.index("struct ptl_uniform_block {"))]
     members = [l.split()[-1].rstrip(";") for l in block.splitlines()[1:] if l.strip()]
     first_derived = next(i for i, m in enumerate(members) if m.startswith("ptl_dv_"))
-    assert all(m.startswith("ptl_dv_") for m in members[first_derived:]) and first_derived == len(layout)
-    assert "plane_intersect_derived(r" not in scene.generate_source(pa.FLAG_NO_DERIVED_UNIFORMS)
-    assert "plane_intersect_derived(r" not in scene.generate_source(pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
+    assert all(m.startswith(("ptl_dv_", "ptl_hv")) for m in members[first_derived:]) and first_derived == len(layout)  # (ptl_hv*: glsl_hoist.h)
+    assert "hit = plane_intersect_derived(r" not in scene.generate_source(pa.FLAG_NO_DERIVED_UNIFORMS)
+    assert "hit = plane_intersect_derived(r" not in scene.generate_source(pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
 
 
 def test_fast_math_is_a_flag_not_a_default(pa, tmp_path, monkeypatch):

@@ -96,6 +96,9 @@ VARIANTS = {
     "r2_dyn_npr": "-DPTL_NO_PIXEL_RELAUNDER",
     "r2_ints_npr": "SPECIALIZE -DPTL_NO_PIXEL_RELAUNDER",
     "r2_all_npr": "SPECIALIZE_ALL -DPTL_NO_PIXEL_RELAUNDER",
+    "r2_dyn_nohoist": "NO_HOIST",
+    "r2_ints_nohoist": "SPECIALIZE NO_HOIST",
+    "r2_dyn_nohoist_w5": "NO_HOIST -DPTL_WAVES_PER_EU=5",
     "r2_ints": "SPECIALIZE",
     "r2_ints_noderived": "SPECIALIZE NO_DERIVED",
     "r2_dyn_nocull": "-DPTL_NO_PLANE_CULL",
@@ -129,7 +132,7 @@ def run_one(case, vname, flags):
     w, h, d, aa = int(w), int(h), int(d), int(aa)
     toks = flags.split()
     rflags = (pa.FLAG_SPECIALIZE_INTS if ("SPECIALIZE" in toks or "SPECIALIZE_ALL" in toks) else 0) | (pa.FLAG_SPECIALIZE_ALL if "SPECIALIZE_ALL" in toks else 0)
-    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0) | (pa.FLAG_NO_DEFERRED_UPDATES if "NO_DEFER" in toks else 0)
+    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0) | (pa.FLAG_NO_DEFERRED_UPDATES if "NO_DEFER" in toks else 0) | (pa.FLAG_NO_UNIFORM_HOIST if "NO_HOIST" in toks else 0)
     # the VGPR allocator is an option the JIT always passes (kernel.cpp): select it through its own switch, not a second -mllvm
     ra = [t.split("=", 1)[1] for t in toks if t.startswith("-vgpr-regalloc=")]
     if "RA_DEFAULT" in toks:
