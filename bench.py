@@ -60,8 +60,13 @@ def stored_pmc(args, build):
         path = os.path.join(HERE, "profiles", rnd, name)
         try:
             c = json.load(open(path))["counters"]
-            return {"traffic": int((2 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024),
-                    "insts_valu": float(c["SQ_INSTS_VALU"]["mean_per_launch"]), "source": os.path.relpath(path, HERE)}
+            out = {"traffic": int((2 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024),
+                   "insts_valu": float(c["SQ_INSTS_VALU"]["mean_per_launch"]), "source": os.path.relpath(path, HERE)}
+            # instruction classes + the busy cycles of the same passes: what the VALU pipes were occupied with (valu_busy_bounds below)
+            classes = ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "GRBM_GUI_ACTIVE")
+            if all(k in c for k in classes):
+                out["classes"] = {k: float(c[k]["mean_per_launch"]) for k in classes}
+            return out
         except Exception:
             continue
     return None
@@ -75,7 +80,9 @@ def flops_per_segment(args):
         entry = json.load(open(os.path.join(HERE, "profiles", "r02", "flops_per_segment.json")))[workload_key(args)]
     except Exception:
         return None
-    which = "flops_varying" if args.specialize == 2 else "flops"
+    # Ray-dependent operations only, for every build: a specialised build folds the uniform-only ones at JIT time; the others get most of
+    # them from the prologue kernel (derived plane normals, glsl_hoist.h) -- what is left of them per ray is executed but NOT counted.
+    which = "flops_varying"
     algorithmic = float(entry["per_segment"][which])
     # the translator defers loop-carried ray transforms nobody reads (glsl_translate.h): the kernel does not execute them, so they
     # are not counted as achieved work either (`..._executed`, tools/count_flops.py)
@@ -425,19 +432,25 @@ def main():
 
     # untimed, N = 1 only: the same frame with NO JIT specialisation (every scene uniform read at run time), for the record.
     # (Skipped together with the CPU baseline, i.e. in the profiling runs: their per-kernel statistics are about the timed launches.)
-    dynamic_ms = None
+    # ... and with only the Bool / Int scene uniforms baked (FLAG_SPECIALIZE_INTS): what an animation whose float uniforms and matrices
+    # move every frame runs on without a rebuild per frame.
+    dynamic_ms = ints_ms = None
     if world == 1 and args.specialize != 0 and not args.no_cpu_baseline:
         try:
-            timings = []
-            for waves in (0, 4):  # the two register budgets that matter for this kernel
-                plain = pa.SceneRenderer(scene, device=local_rank, flags=pa.flag_waves(waves))
-                configure(plain, args)
-                for _ in range(8):
-                    plain.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream)
-                ms = float(np.median([plain.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(16)]))
-                timings.append((plain.resources()["scratch_bytes"] > 0, ms))
-                del plain
-            dynamic_ms = min(timings)[1]  # a spill-free build first, then the faster
+            for base_flags in (0, pa.FLAG_SPECIALIZE_INTS):
+                timings = []
+                for waves in (0, 4):  # the two register budgets that matter for this kernel
+                    plain = pa.SceneRenderer(scene, device=local_rank, flags=base_flags | pa.flag_waves(waves))
+                    configure(plain, args)
+                    for _ in range(8):
+                        plain.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream)
+                    ms = float(np.median([plain.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(16)]))
+                    timings.append((plain.resources()["scratch_bytes"] > 0, ms))
+                    del plain
+                if base_flags == 0:
+                    dynamic_ms = min(timings)[1]  # a spill-free build first, then the faster
+                else:
+                    ints_ms = min(timings)[1]
         except Exception as e:
             print(f"[bench] dynamic-uniform timing unavailable: {e}", file=sys.stderr)
 
@@ -525,6 +538,8 @@ def main():
             out["fast_math_mode"] = fast
         if dynamic_ms is not None:
             out["kernel_ms_without_jit_specialisation"] = round(dynamic_ms, 4)
+        if ints_ms is not None:
+            out["kernel_ms_with_only_int_uniforms_baked"] = round(ints_ms, 4)
         pmc = stored_pmc(args, best)
         hbm = {
             "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
@@ -551,7 +566,9 @@ def main():
                 "note": "FP32-VALU-bound, no MFMA. achieved = binary32 operations per bounce-loop trip (fma = 2; / and sqrt = 1 each although they cost "
                         "11 and 14 instructions) x trips of this launch (counted on the GPU) / kernel time."
                         + (" Counted: operations with a ray-dependent operand -- the timed kernel has the scene uniforms baked in and folds the rest "
-                           f"({fl['all_flops']:.0f} per trip with them)." if fl["which"].startswith("flops_varying") else " Counted: every operation (uniforms are read at run time).")
+                           f"({fl['all_flops']:.0f} per trip with them)." if args.specialize == 2 else
+                           " Counted: operations with a ray-dependent operand; most uniform-only ones come from the prologue kernel, the remainder is executed per ray "
+                           f"but not counted ({fl['all_flops']:.0f} per trip with all of them).")
                         + (f" Of the reference algorithm's {fl['algorithmic']:.0f} the kernel executes {fl['flops']:.0f}: loop-carried ray transforms of the scene "
                            "snippet that no statement reads are deferred away (counted on the host build); the plane cull's savings are not subtracted."
                            if fl["flops"] != fl["algorithmic"] else ""),
@@ -561,6 +578,20 @@ def main():
                 # division helpers take 4 cycles, transcendentals 8 (profiles/r01/valu_rates.jsonl), and the sustained clock is below 2.4 GHz.
                 roof["valu_issue_frac"] = round(pmc["insts_valu"] / world * 2.0 / 1024.0 / (kernel_ms * 1e-3 * 2.4e9), 4)
                 roof["valu_insts_per_launch"] = pmc["insts_valu"]
+                if "classes" in pmc:
+                    # What the pipes were busy with, from the instruction classes of the same PMC passes and the measured issue cost of each
+                    # (profiles/r01/valu_rates.jsonl: fma / mul / add / integer add 2 cycles per wave64 instruction, v_rcp / v_sqrt / v_rsq 8,
+                    # compares, selects, division helpers, floor ... 4).  The rest (moves, compares, selects, v_div_*) is not split further by
+                    # the counters: priced at 2 cycles it gives the lower bound, at 4 the upper one.  Denominator: GRBM_GUI_ACTIVE (busy
+                    # cycles per XCD, summed over the 8 XCDs by the collector) x 1024 SIMDs / 8.
+                    k = pmc["classes"]
+                    full = k["SQ_INSTS_VALU_FMA_F32"] + k["SQ_INSTS_VALU_MUL_F32"] + k["SQ_INSTS_VALU_ADD_F32"] + k["SQ_INSTS_VALU_INT32"]
+                    rest = max(0.0, pmc["insts_valu"] - full - k["SQ_INSTS_VALU_TRANS_F32"])
+                    simd_cycles = k["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+                    busy = [(2.0 * full + 8.0 * k["SQ_INSTS_VALU_TRANS_F32"] + price * rest) / simd_cycles for price in (2.0, 4.0)]
+                    roof["valu_busy_bounds"] = [round(busy[0], 3), round(busy[1], 3)]
+                    roof["valu_class_share"] = {"fma_mul_add_int": round(full / pmc["insts_valu"], 3), "transcendental": round(k["SQ_INSTS_VALU_TRANS_F32"] / pmc["insts_valu"], 3),
+                                                "moves_compares_selects_division_helpers": round(rest / pmc["insts_valu"], 3)}
                 roof["frac_ceiling_from_pmc"] = round(64 * 2 * pmc["insts_valu"] / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)  # every VALU instruction a full-width FMA
                 roof["pmc_source"] = pmc["source"] + " (stored rocprofv3 PMC passes of this build, not re-measured by this run)"
             out["roofline"] = roof

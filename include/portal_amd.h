@@ -382,6 +382,13 @@ const char* ptl_device_source(const char* which);
 
 /* GLSL snippet -> C++ (malloc'ed, ptl_free) and the formula evaluator, exposed for tests. */
 char* ptl_translate_glsl(const char* glsl);
+/* The uniform-work hoister on one snippet, exposed for tests (the code generator runs it on every scene snippet unless flags
+ * bit12 / bit5 say otherwise).  `uniforms` lists the run-time uniforms as "type name;type name;..." (GLSL types), `out_functions`
+ * the functions that write through an argument ("f;g"), `body_only` != 0 says the text is a function BODY whose parameters are
+ * `params` ("r;first").  Returns the rewritten GLSL (malloc'ed, ptl_free; the input itself when nothing was hoisted) and, in
+ * *prologue (may be NULL), the GLSL statements for the prologue kernel, one line per created member in front as
+ * "// member: type name[count]". */
+char* ptl_hoist_glsl(const char* glsl, const char* uniforms, const char* out_functions, int body_only, const char* params, char** prologue);
 /* names/values: free variables; returns 0 and *out, 1 if the formula is invalid or unresolvable */
 int ptl_formula_eval(const char* text, const char* const* names, const double* values, int n, double time, double* out);
 

@@ -707,6 +707,22 @@ def translate_glsl(code: str) -> str:
         lib().ptl_free(p)
 
 
+def hoist_glsl(code: str, uniforms: dict, out_functions=(), body_only: bool = True, params=()):
+    """glsl_hoist.h on one snippet (for tests): `uniforms` maps name -> GLSL type.  Returns (rewritten GLSL, prologue text with one
+    "// member: type name" line per created member in front)."""
+    L = lib()
+    L.ptl_hoist_glsl.restype = C.c_void_p
+    L.ptl_hoist_glsl.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+    prologue = C.c_void_p()
+    p = L.ptl_hoist_glsl(code.encode("utf-8"), ";".join(f"{t} {n}" for n, t in uniforms.items()).encode(), ";".join(out_functions).encode(),
+                         1 if body_only else 0, ";".join(params).encode(), C.byref(prologue))
+    try:
+        return C.string_at(p).decode("utf-8"), C.string_at(prologue.value).decode("utf-8")
+    finally:
+        L.ptl_free(p)
+        L.ptl_free(prologue.value)
+
+
 def formula_eval(text: str, variables: Optional[dict] = None, time: float = 0.0) -> Optional[float]:
     variables = variables or {}
     names = (C.c_char_p * len(variables))(*[k.encode() for k in variables])

@@ -20,6 +20,7 @@
 #include "../../../include/portal_amd.h"
 #include "codegen.h"
 #include "formula.h"
+#include "glsl_hoist.h"
 #include "glsl_translate.h"
 #include "internal.h"
 #include "scene.h"
@@ -1115,6 +1116,41 @@ extern "C" char* ptl_translate_glsl(const char* glsl) {
     char* p = (char*)std::malloc(out.size() + 1);
     std::memcpy(p, out.c_str(), out.size() + 1);
     return p;
+}
+
+extern "C" char* ptl_hoist_glsl(const char* glsl, const char* uniforms, const char* out_functions, int body_only, const char* params, char** prologue) {
+    if (!glsl) return nullptr;
+    auto split = [](const char* text) {
+        std::vector<std::string> parts;
+        std::string cur;
+        for (const char* c = text ? text : ""; *c; ++c) {
+            if (*c == ';') {
+                if (!cur.empty()) parts.push_back(cur);
+                cur.clear();
+            } else {
+                cur += *c;
+            }
+        }
+        if (!cur.empty()) parts.push_back(cur);
+        return parts;
+    };
+    HoistParams hp;
+    for (const std::string& u : split(uniforms)) {
+        size_t sp = u.find(' ');
+        if (sp != std::string::npos) hp.uniforms[u.substr(sp + 1)] = u.substr(0, sp);
+    }
+    for (const std::string& f : split(out_functions)) hp.functions_with_out_params.insert(f);
+    hp.body_only = body_only != 0;
+    hp.body_params = split(params);
+    int counter = 0;
+    HoistResult r = hoist_uniform_work(glsl, hp, counter);
+    if (prologue) {
+        std::string text;
+        for (auto& m : r.members) text += "// member: " + m.type + " " + m.name + (m.length ? "[" + std::to_string(m.length) + "]" : "") + "\n";
+        text += r.prologue;
+        *prologue = strdup(text.c_str());
+    }
+    return strdup(r.glsl.c_str());
 }
 
 extern "C" int ptl_scene_to_ron(ptl_scene* s, char** text) {

@@ -58,9 +58,39 @@ def test_uniform_prologue_source_has_no_per_call_normalisation(gpu):
     derived, plain = scene.generate_source(0), scene.generate_source(pa.FLAG_NO_DERIVED_UNIFORMS)
     body = derived[derived.index("PTL_FN SceneIntersection scene_intersect(const Ray& r"):derived.index("// Prologue (ptl_derive_kernel")]
     assert "plane_intersect_derived(" in body and "is_collinear(" not in body and "get_normal(" not in body
-    assert "plane_intersect_derived(r," not in plain
+    assert "hit = plane_intersect_derived(r," not in plain
     baked = scene.generate_source(pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
-    assert "plane_intersect_derived(r" not in baked  # literal matrices fold at JIT time: nothing to derive
+    assert "hit = plane_intersect_derived(r" not in baked  # literal matrices fold at JIT time: nothing to derive
+
+
+@pytest.mark.parametrize("scene_file,w,h,depth,moves", [
+    ("scenes/portal_in_portal.ron", 640, 360, 40, [("progress", 0.37), ("show_teleported", 70)]),  # 70 nested copies: past the 64-entry tables
+    ("tests/corpus/scenes/portal_in_portal_plus_ultra.ron", 320, 180, 20, []),
+    ("tests/corpus/scenes/matryoshka.ron", 320, 180, 20, []),
+    ("tests/corpus/scenes/recursive_space.ron", 320, 180, 20, []),
+    ("tests/corpus/scenes/trefoil.ron", 320, 180, 20, [])])
+def test_hoisted_uniform_work_changes_no_bit(gpu, scene_file, w, h, depth, moves):
+    """glsl_hoist: uniform-only expressions of the scene snippets (and tabulated loop-carried chains of them) come from the
+    prologue kernel; FLAG_NO_UNIFORM_HOIST evaluates them per ray as the reference does.  Same expression text in the same
+    module: identical float frames, also after uniforms moved and where a loop outruns its tables (the guarded fallback)."""
+    pa = gpu
+    path = os.path.join(ROOT, scene_file)
+    extra = {"asset_root": os.path.join(ROOT, "tests", "corpus")} if "corpus" in scene_file else {}
+    frames = {}
+    for label, flags in (("hoisted", 0), ("plain", pa.FLAG_NO_UNIFORM_HOIST)):
+        scene = pa.Scene.from_file(path)
+        assert ("ptl_hv" in scene.generate_source(flags)) == (label == "hoisted")
+        r = pa.SceneRenderer(scene, device=0, flags=flags, **extra)
+        r.set_option("render_depth", depth)
+        got = [r.draw(w, h, rgba32f=True)["rgba32f"].copy()]
+        for name, value in moves:
+            assert scene.set_uniform(name, value)
+            got.append(r.draw(w, h, rgba32f=True)["rgba32f"].copy())
+        frames[label] = got
+    for a, b in zip(frames["hoisted"], frames["plain"]):
+        assert np.array_equal(_bits(a), _bits(b))
+    if moves:
+        assert not np.array_equal(_bits(frames["plain"][0]), _bits(frames["plain"][1]))
 
 
 # ---- layer 3: one frame across GPUs, one process ------------------------------------------------------------------------------

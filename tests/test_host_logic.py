@@ -871,3 +871,133 @@ for (int k = 0; k < n_u; k++) {
     counts = {name: pa.Scene.from_file(pa.scene_path(name)).generate_source(0).count("int ptl_pend_") for name in SCENES}
     assert counts == {"basics": 0, "monoportal": 0, "triple_portal": 0, "portal_in_portal": 2, "mobius_monoportal": 0}
     assert "ptl_pend_" not in pa.Scene.from_file(pa.scene_path("portal_in_portal")).generate_source(pa.FLAG_NO_DEFERRED_UPDATES)
+
+
+# ---------------------------------------------------------------------------------------------
+# uniform-work hoisting of scene snippets (portal_amd/csrc/host/glsl_hoist.h)
+# ---------------------------------------------------------------------------------------------
+_HOIST_UNIFORMS = {"a_mat": "mat4", "a_mat_inv": "mat4", "b_mat": "mat4", "b_mat_inv": "mat4", "scale_u": "float", "n_u": "int", "dir_u": "vec3"}
+
+
+def test_hoister_moves_maximal_uniform_expressions_and_keeps_the_lines(pa):
+    code = "vec4 pos = r.o;\npos = b_mat * a_mat_inv * pos; // comment\nfloat k = length(dir_u) * scale_u + r.d.x;\nreturn pos * k;"
+    out, prologue = pa.hoist_glsl(code, _HOIST_UNIFORMS, params=["r"])
+    assert out.count("\n") == code.count("\n")
+    assert "pos = PTL_U.ptl_hv0 * pos;" in out and "float k = PTL_U.ptl_hv1 + r.d.x;" in out
+    assert "// member: mat4 ptl_hv0" in prologue and "// member: float ptl_hv1" in prologue
+    assert "PTL_DV_OUT.ptl_hv0 = b_mat * a_mat_inv;" in prologue and "PTL_DV_OUT.ptl_hv1 = length(dir_u) * scale_u;" in prologue
+    assert pa.hoist_glsl(code, _HOIST_UNIFORMS, params=["r"]) == (out, prologue)  # deterministic: the source text keys the code-object cache
+
+
+@pytest.mark.parametrize("code,why", [
+    ("float k = scale_u * 2.0;\nreturn r.o * k;", "one multiplication costs less than the load that would replace it"),
+    ("float k = 1.0 + 2.0 * 3.0;\nreturn r.o * k;", "literals only: the compiler folds it"),
+    ("mat4 a_mat = mat4(1.0);\nvec4 p = a_mat * (b_mat * vec4(1.0));\nreturn p + r.o;".replace("(b_mat * vec4(1.0))", "r.o"), "a local shadows the uniform's name"),
+    ("vec3 n = normalize(dir_u);\nn = -n;\nreturn vec4(n * r.d.x, 0.0);", None),  # (n written twice: only its initialiser is uniform)
+    ("vec3 n = normalize(dir_u) * r.d.x;\nreturn vec4(n, 0.0);", None),
+    ("int q = n_u / 2;\nreturn r.o * float(q);", "an integer quotient may trap where the snippet guards it"),
+    ("#define K 2.0\nfloat k = length(dir_u) * K;\nreturn r.o * k;", "macros: the text is not what the compiler sees"),
+    ("float k = length(dir_u) * ;\nreturn r.o;", "unparsable"),
+    ("do { x = 1; } while (false);\nfloat k = length(dir_u) * scale_u;\nreturn r.o * k;", "do-while"),
+])
+def test_hoister_leaves_alone_what_it_must(pa, code, why):
+    out, prologue = pa.hoist_glsl(code, _HOIST_UNIFORMS, params=["r"])
+    if why is None:  # the uniform PART is still moved; the varying rest stays
+        assert "PTL_U.ptl_hv0" in out and "normalize(dir_u)" in prologue and "r.d.x" in out
+    else:
+        assert out == code and "member" not in prologue, why
+
+
+def test_hoister_respects_out_parameters(pa):
+    code = "vec3 n = normalize(dir_u);\nturn(n);\nreturn vec4(n * length(dir_u), 0.0);"
+    out, _ = pa.hoist_glsl(code, _HOIST_UNIFORMS, out_functions=["turn"], params=["r"])
+    assert "vec3 n = PTL_U.ptl_hv0;" in out and "n * PTL_U.ptl_hv1" in out  # normalize(dir_u), length(dir_u): still uniform expressions ...
+    assert "PTL_U.ptl_hv2" not in out                                        # ... but n itself is not a uniform local any more
+    plain, _ = pa.hoist_glsl(code, _HOIST_UNIFORMS, params=["r"])
+    assert "PTL_U.ptl_hv1" in plain and "n * length(dir_u)" not in plain     # without the out parameter the product is one uniform value
+
+
+_CHAIN = """vec4 nb = b_mat * vec4(0., 0., 1., 0.);
+vec4 acc = r.o;
+for (int i = 0; i < n_u; i++) {
+	vec3 unit = normalize_normal(nb.xyz, r.d.xyz);
+	acc += vec4(unit, 0.) * float(i);
+%s	nb = b_mat * (a_mat_inv * nb);
+	if (is_collinear(unit, nb.xyz)) { acc.w += 1.; }
+}
+return acc;"""
+
+
+def test_hoister_tabulates_loop_carried_uniform_chains(pa):
+    out, prologue = pa.hoist_glsl(_CHAIN % "", _HOIST_UNIFORMS, params=["r"])
+    assert out.count("\n") == (_CHAIN % "").count("\n")
+    assert "const bool ptl_tab_ok_" in out and "(n_u) <= 64" in out
+    # the chain itself: a table read under the guard, the original update otherwise
+    assert "nb = PTL_U.ptl_hv" in out and "[i + 1]; else nb = b_mat * (a_mat_inv * nb);" in out
+    # normalize(nb.xyz) BEFORE the update reads entry i, length(nb.xyz) AFTER it entry i + 1; both keep their fallback
+    assert "ptl_normalize_normal_unit((ptl_tab_ok_" in out and "[i] : (normalize(nb.xyz)))" in out
+    assert "ptl_is_collinear_len(unit, nb.xyz, (ptl_tab_ok_" in out and "[i + 1] : (length(nb.xyz)))" in out
+    assert "for (int ptl_k = 0; ptl_k < 66; ptl_k++) {" in prologue and prologue.rstrip().endswith("}")
+    body = prologue[prologue.index("for (int ptl_k"):]
+    assert body.index("[ptl_k] = nb;") < body.index("nb = b_mat * (a_mat_inv * nb);")  # tables first, the update last
+    assert body.count("[ptl_k] = ") == 3
+
+
+@pytest.mark.parametrize("edit,why", [
+    (("for (int i = 0; i < n_u; i++)", "for (int i = 0; i < n_u; i += 1)"), "not the canonical loop header"),
+    (("%s", "	if (acc.x > 1.) continue;\n"), "a continue can skip the update"),
+    (("return acc;", "return acc + nb;"), "the chain's value is read behind the loop"),
+    (("	nb = b_mat * (a_mat_inv * nb);", "	nb = b_mat * (a_mat_inv * nb) + r.d;"), "the update is not uniform"),
+    (("	nb = b_mat * (a_mat_inv * nb);", "	if (acc.x > 0.) { nb = b_mat * (a_mat_inv * nb); }"), "the update is conditional"),
+    (("	nb = b_mat * (a_mat_inv * nb);", "	nb = b_mat * (a_mat_inv * nb) * float(i);"), "the update depends on the trip number"),
+])
+def test_hoister_does_not_tabulate_what_is_not_a_function_of_the_trip_number(pa, edit, why):
+    code = _CHAIN.replace(edit[0], edit[1]) if edit[0] != "%s" else _CHAIN % edit[1]
+    code = code % "" if "%s" in code else code
+    out, prologue = pa.hoist_glsl(code, _HOIST_UNIFORMS, params=["r"])
+    assert "ptl_tab_ok_" not in out and "ptl_k" not in prologue, why
+
+
+def test_hoisted_scene_source_is_selfconsistent(pa):
+    """Every member the snippets read exists in the block (behind the uploaded part) and is written by derive(); with the scene
+    uniforms baked in, or with FLAG_NO_UNIFORM_HOIST / FLAG_NO_DERIVED_UNIFORMS, nothing is hoisted."""
+    import re
+    scene = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    src = scene.generate_source(0)
+    block = src[src.index("struct ptl_uniform_block {"):src.index("};", src.index("struct ptl_uniform_block {"))]
+    members = set(re.findall(r"\b(ptl_hv\d+)(?:\[\d+\])?;", block))
+    assert len(members) >= 7 and "vec4 ptl_hv" in block and "[66];" in block
+    derive = src[src.index("PTL_FN void derive(ptl_uniform_block* out)"):src.index("// Material id -> what happens to the path.")]
+    assert set(re.findall(r"PTL_DV_OUT\.(ptl_hv\d+)", derive)) == members
+    assert set(re.findall(r"PTL_U\.(ptl_hv\d+)", src)) == members
+    for flags in (pa.FLAG_NO_UNIFORM_HOIST, pa.FLAG_NO_DERIVED_UNIFORMS, pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL):
+        assert "ptl_hv" not in scene.generate_source(flags)
+
+
+@pytest.mark.parametrize("scene_file,moves", [
+    ("scenes/portal_in_portal.ron", [("progress", 0.37), ("show_teleported", 70)]),   # 70 copies: past the tables, the guarded fallback runs
+    ("tests/corpus/scenes/matryoshka.ron", []),
+    ("tests/corpus/scenes/recursive_space.ron", []),
+    ("tests/corpus/scenes/trefoil.ron", []),
+])
+def test_hoisted_and_plain_host_builds_draw_the_same_bits(pa, scene_file, moves):
+    """The checker's host build of the generated source runs derive() too: frames with the uniform work hoisted and frames of
+    the source as the reference wrote it must agree bit for bit -- also after uniforms have moved, also where a loop runs longer
+    than its tables."""
+    from oracle import host_build as hb
+    path = os.path.join(ROOT, scene_file)
+    root = os.path.join(ROOT, "tests", "corpus") if "corpus" in scene_file else None
+    frames = {}
+    for label, flags in (("hoisted", 0), ("plain", pa.FLAG_NO_UNIFORM_HOIST)):
+        scene = pa.Scene.from_file(path)
+        r = pa.SceneRenderer(scene, device=-1, flags=flags, **({"asset_root": root} if root else {}))
+        r.set_option("render_depth", 12)
+        got = [hb.host_kernel_for(r, scene, 48, 27).render(48, 27)["rgba32f"].copy()]
+        for name, value in moves:
+            assert scene.set_uniform(name, value)
+            got.append(hb.host_kernel_for(r, scene, 48, 27).render(48, 27)["rgba32f"].copy())
+        frames[label] = got
+        if label == "hoisted":
+            assert "ptl_hv" in scene.generate_source(flags)
+    for a, b in zip(frames["hoisted"], frames["plain"]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -14,7 +14,7 @@ rm -rf /tmp/pmc_$NAME
 i=0
 # PMC_GROUPS="A B;C;D E" replaces the default groups (one rocprofv3 run per ';'-separated group), e.g. the stall anatomy of
 # profiles/r02/pmc_stalls_*.json: "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY;SQ_WAIT_ANY SQ_ACTIVE_INST_ANY;SQ_INSTS_BRANCH SQ_IFETCH;SQC_ICACHE_REQ SQC_ICACHE_MISSES;..."
-IFS=';' read -r -a GROUPS_ <<< "${PMC_GROUPS:-SQ_WAVES SQ_INSTS_VALU;SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES;SQ_THREAD_CYCLES_VALU;SQ_INSTS_SALU SQ_INSTS_VALU_TRANS;FETCH_SIZE;WRITE_SIZE}"
+IFS=';' read -r -a GROUPS_ <<< "${PMC_GROUPS:-SQ_WAVES SQ_INSTS_VALU;SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES;SQ_THREAD_CYCLES_VALU;SQ_INSTS_SALU SQ_INSTS_VALU_TRANS_F32;SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32;SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32;GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY;SQ_WAVE_CYCLES SQ_INSTS_BRANCH;FETCH_SIZE;WRITE_SIZE}"
 for group in "${GROUPS_[@]}"; do
     i=$((i + 1))
     rocprofv3 --pmc $group --output-format csv -d /tmp/pmc_$NAME/p$i -o p -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-segments --build $BUILD ${BENCH_ARGS:-} > /tmp/pmc_$NAME.log 2>&1 || tail -3 /tmp/pmc_$NAME.log
