@@ -7,7 +7,7 @@ import sys, os, tempfile, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import portal_amd as pa
 from tests.test_scene_fuzz import random_scene
-from tests.test_glsl_fuzz import fuzz_scene, N_EXPR
+from tests.test_glsl_fuzz import fuzz_scene, fuzz_scene_with_uniforms, N_EXPR
 from oracle.portal_oracle import Oracle
 def same(a,b): return ((a.view(np.uint32)==b.view(np.uint32))|(np.isnan(a)&np.isnan(b))).all()
 bad=0
@@ -22,7 +22,7 @@ for seed in range(300+BASE,300+BASE+N_SCENES):
     o=Oracle(path); o.options["render_depth"]=10; o.camera=dict(cam,in_subspace=sub)
     if not same(got,o.render(40,24)["rgba32f"]): bad+=1; print("scene seed",seed,"DIFF")
 for seed in range(100000+BASE,100000+BASE+N_GLSL) if BASE else range(400,430):
-    text,_=fuzz_scene(seed); d=tempfile.mkdtemp(); path=os.path.join(d,'f.ron'); open(path,'w').write(text)
+    text,_=(fuzz_scene_with_uniforms if seed%2 else fuzz_scene)(seed); d=tempfile.mkdtemp()  # every other one with uniform leaves (glsl_hoist); path=os.path.join(d,'f.ron'); open(path,'w').write(text)
     w,h=4*N_EXPR,12
     r=pa.SceneRenderer(pa.Scene.from_file(path),device=0); r.set_option("render_depth",2); r.set_option("view_angle",1.5)
     got=r.draw(w,h,rgba32f=True)["rgba32f"]

@@ -22,8 +22,11 @@ def _scratch_build_dir(tmp_path_factory, monkeypatch):
 class Gen:
     """Typed random GLSL expressions: gen(t, depth) -> text of type t in {"float", "vec2", "vec3", "vec4", "bool"}."""
 
-    def __init__(self, seed):
+    def __init__(self, seed, uniforms=False):
         self.r = random.Random(seed)
+        # with `uniforms`: leaves that depend on run-time uniforms alone (scene uniforms, a portal-style matrix pair, locals initialised
+        # from them, a loop-carried chain `cb`) next to the varying ones -- food for the uniform-work hoister (glsl_hoist.h)
+        self.uniforms = uniforms
 
     def lit(self):
         return self.r.choice(["0.0", "1.0", "0.5", "2.0", "-1.5", "0.25", "3.0", "1e-3", "7.5", "0.1", "-0.3", "10.", ".75"])
@@ -37,6 +40,9 @@ class Gen:
             n = int(t[3])
             if d <= 0 or r.random() < 0.25:
                 base = {2: ["vec2(x, y)", "vec2(y, 0.5)", "p.xy", "p.zx"], 3: ["p", "vec3(x, y, 1.0)", "vec3(y + 0.0)", "p.zyx", "q.xyz"], 4: ["q", "vec4(p, 1.0)", "vec4(x, y, y, x)", "q.wzyx"]}[n]
+                if self.uniforms and r.random() < 0.5:
+                    base = {2: ["vec2(ua_u, ub_u)", "un.xy", "cb.zw", "vec2(uk, 0.3)"], 3: ["un", "vec3(ua_u, 0.4, ub_u)", "get_normal(tilt_mat)", "cb.xyz", "(tilt_mat * vec4(un, 0.0)).xyz"],
+                            4: ["cb", "vec4(un, ua_u)", "(tilt_mat_inv * vec4(ub_u, 0.2, ua_u, 1.0))", "(tilt_mat * (back_mat_inv * cb))"]}[n]
                 return r.choice(base)
             k = r.randrange(11)
             a, b = self.gen(t, d - 1), self.gen(t, d - 1)
@@ -68,6 +74,8 @@ class Gen:
             return f"(-({a}))"
         # float
         if d <= 0 or r.random() < 0.2:
+            if self.uniforms and r.random() < 0.5:
+                return r.choice(["ua_u", "ub_u", "uk", "un.y", "cb.x", "size_u"])
             return r.choice(["x", "y", "p.z", "q.w", self.lit(), self.lit()])
         k = r.randrange(14)
         a, b = self.gen("float", d - 1), self.gen("float", d - 1)
@@ -99,6 +107,35 @@ class Gen:
         if k == 12:
             return f"(-({a}))"
         return f"({self.gen('vec3', d - 1)}).{r.choice(['x', 'y', 'z', 'r', 'b'])}"
+
+
+def fuzz_scene_with_uniforms(seed):
+    """Like fuzz_scene, but the expressions also draw on run-time uniforms, on locals that are uniform values, and on a loop-carried
+    uniform chain (tabulated by the hoister); the bands are evaluated inside the loop, before and behind the chain's update."""
+    from tests import synthetic
+
+    g = Gen(seed, uniforms=True)
+    n_loop = 3
+    exprs = [g.gen("vec3", 3) for _ in range(N_EXPR)]
+    body = ["float x = hit.u;", "float y = hit.v;", "vec3 p = vec3(x * 1.3 - 0.2, y + 0.35, x * y + 0.6);", "vec4 q = vec4(y, -x, 0.4, x - y);",
+            f"int band = int(floor((x * 0.5 + 0.5) * {N_EXPR}.0));", "vec3 c = vec3(0.0);",
+            "float uk = ua_u * ub_u + sqrt(abs(ua_u)) / (ub_u + 2.0);", "vec3 un = normalize(get_normal(tilt_mat) * ua_u + vec3(0.1, ub_u, 0.3));",
+            "vec4 cb = tilt_mat * vec4(0.3, ub_u, 1.0, 0.0);",
+            f"for (int it = 0; it < reps_u; it++) {{"]
+    for k, e in enumerate(exprs):
+        if k == N_EXPR // 2:
+            body.append("cb = tilt_mat * (back_mat_inv * cb);")
+        body.append(f"if (band == {k}) {{ c += {e}; }}")
+    body.append("}")
+    body.append("return material_simple(hit, r, abs(c) * 0.125, 0.0, false, 1.0, 0.0);")
+    code = "\n".join(body)
+    mat = f'(name: "fuzz", data: Complex(code: (("{code}")))),'
+    matrices = ('(name: "tilt", data: Simple(offset: (0.3, -0.2, 0.5), scale: 1.25, rotate: (0.3, 0.9, -0.4), mirror: (false, false, false))),'
+                '(name: "back", data: Simple(offset: (-0.1, 0.4, 0.2), scale: 0.8, rotate: (-0.5, 0.2, 0.7), mirror: (false, true, false))),')
+    text = synthetic.wall_scene(r=1.0, size=1.0, extra_materials=mat, extra_matrices=matrices).replace("return wall_M; }", "return fuzz_M; }")
+    text = text.replace('uniforms: ([', 'uniforms: ([ (name: "ua", data: Float((min: None, max: None, value: 0.7))), (name: "ub", data: Float((min: None, max: None, value: -0.35))), '
+                        f'(name: "reps", data: Int((min: None, max: None, value: {n_loop}))), ')
+    return text, exprs
 
 
 def fuzz_scene(seed):
@@ -144,3 +181,37 @@ def test_random_glsl_expressions_product_equals_oracle(pa, tmp_path, seed):
         bands = sorted({int(x * N_EXPR / w) for x in xs})
         raise AssertionError(f"seed {seed}: {len(xs)} pixels differ, around bands {bands[:6]}: " + " | ".join(exprs[b] for b in bands[:3] if b < len(exprs)))
     assert len(np.unique(got.reshape(-1, 4), axis=0)) > N_EXPR       # the bands really show different values
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_random_glsl_expressions_over_uniforms_survive_the_hoister(pa, tmp_path, seed):
+    """The same differential test with uniform leaves, uniform locals and a tabulated loop-carried chain: the hoister moves a good part
+    of every snippet into the prologue (the source must show it), and the host build -- which runs derive() -- still equals the oracle,
+    which evaluates the snippet as written, bit for bit."""
+    from oracle import host_build as hb
+    from oracle.portal_oracle import Oracle
+
+    text, exprs = fuzz_scene_with_uniforms(seed)
+    path = tmp_path / "fuzz.ron"
+    path.write_text(text)
+    w, h = 4 * N_EXPR, 12
+    scene = pa.Scene.from_file(str(path))
+    source = scene.generate_source(0)
+    assert source.count("PTL_U.ptl_hv") >= 10 and "ptl_tab_ok_" in source and "for (int ptl_k = 0;" in source
+    r = pa.SceneRenderer(scene, device=-1)
+    r.set_option("render_depth", 2)
+    r.set_option("view_angle", 1.5)
+    hk = hb.HostKernel(source, *scene.uniform_layout(), opt="-O0")
+    for name, typ, _ in scene.uniform_layout()[0]:
+        if typ != pa.PTL_SAMPLER:
+            hk.set_uniform(name, r.uniform_value(name, w, h))
+    got = hk.render(w, h)["rgba32f"]
+    o = Oracle(str(path))
+    o.options.update(render_depth=2, view_angle=1.5)
+    want = o.render(w, h)["rgba32f"]
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    if not same.all():
+        ys, xs = np.nonzero(~same.all(axis=2))
+        bands = sorted({int(x * N_EXPR / w) for x in xs})
+        raise AssertionError(f"seed {seed}: {len(xs)} pixels differ, around bands {bands[:6]}: " + " | ".join(exprs[b] for b in bands[:3] if b < len(exprs)))
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) > N_EXPR // 2

@@ -736,6 +736,29 @@ def test_random_glsl_expressions_on_gpu(gpu, tmp_path, seed):
     assert _bits_equal(got, o.render(w, h)["rgba32f"]).all()
 
 
+@pytest.mark.parametrize("seed", [111, 112, 113])
+def test_random_glsl_expressions_over_uniforms_on_gpu(gpu, tmp_path, seed):
+    """The same with uniform leaves, uniform locals and a tabulated loop-carried chain (tests/test_glsl_fuzz.py::fuzz_scene_with_uniforms):
+    the hoister moves those parts into ptl_derive_kernel; the frame still equals the oracle, which evaluates the snippet as written."""
+    from oracle.portal_oracle import Oracle
+    from tests.test_glsl_fuzz import N_EXPR, fuzz_scene_with_uniforms
+
+    pa = gpu
+    text, _ = fuzz_scene_with_uniforms(seed)
+    path = tmp_path / "fuzz.ron"
+    path.write_text(text)
+    w, h = 4 * N_EXPR, 12
+    scene = pa.Scene.from_file(str(path))
+    assert scene.generate_source(0).count("PTL_U.ptl_hv") >= 10
+    r = pa.SceneRenderer(scene, device=0)
+    r.set_option("render_depth", 2)
+    r.set_option("view_angle", 1.5)
+    got = r.draw(w, h, rgba32f=True)["rgba32f"]
+    o = Oracle(str(path))
+    o.options.update(render_depth=2, view_angle=1.5)
+    assert _bits_equal(got, o.render(w, h)["rgba32f"]).all()
+
+
 @pytest.mark.parametrize("seed", [200, 201, 202, 203, 204, 205])
 def test_random_scenes_on_gpu(gpu, tmp_path, seed):
     """tests/test_scene_fuzz.py on the hardware leg: a random scene (walls, portal pair, mirrors, glass, gizmo, mirrored matrices,
