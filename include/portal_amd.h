@@ -384,7 +384,8 @@ const char* ptl_device_source(const char* which);
 char* ptl_translate_glsl(const char* glsl);
 /* The uniform-work hoister on one snippet, exposed for tests (the code generator runs it on every scene snippet unless flags
  * bit12 / bit5 say otherwise).  `uniforms` lists the run-time uniforms as "type name;type name;..." (GLSL types), `out_functions`
- * the functions that write through an argument ("f;g"), `body_only` != 0 says the text is a function BODY whose parameters are
+ * the functions that write through an argument ("f;g"; "=f" marks a function the scene merely defines itself, which is then never
+ * taken for the built-in of that name), `body_only` != 0 says the text is a function BODY whose parameters are
  * `params` ("r;first").  Returns the rewritten GLSL (malloc'ed, ptl_free; the input itself when nothing was hoisted) and, in
  * *prologue (may be NULL), the GLSL statements for the prologue kernel, one line per created member in front as
  * "// member: type name[count]". */

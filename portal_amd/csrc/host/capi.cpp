@@ -1139,7 +1139,10 @@ extern "C" char* ptl_hoist_glsl(const char* glsl, const char* uniforms, const ch
         size_t sp = u.find(' ');
         if (sp != std::string::npos) hp.uniforms[u.substr(sp + 1)] = u.substr(0, sp);
     }
-    for (const std::string& f : split(out_functions)) hp.functions_with_out_params.insert(f);
+    for (const std::string& f : split(out_functions)) {  // "name" may write through an argument; "=name" is merely defined by the scene
+        if (f[0] == '=') hp.scene_functions.insert(f.substr(1));
+        else hp.functions_with_out_params.insert(f);
+    }
     hp.body_only = body_only != 0;
     hp.body_params = split(params);
     int counter = 0;

@@ -348,6 +348,26 @@ struct SnippetTranslator {
     }
 };
 
+// names of the functions a GLSL text defines (`type name(...) {` at brace depth 0)
+void defined_functions(const std::string& glsl, std::set<std::string>& names) {
+    int depth = 0;
+    for (size_t i = 0; i < glsl.size(); ++i) {
+        const char c = glsl[i];
+        if (c == '{') ++depth;
+        else if (c == '}') --depth;
+        else if (c == '(' && depth == 0) {
+            size_t e = i;
+            while (e > 0 && std::isspace((unsigned char)glsl[e - 1])) --e;
+            size_t b = e;
+            while (b > 0 && (std::isalnum((unsigned char)glsl[b - 1]) || glsl[b - 1] == '_')) --b;
+            size_t t = b;
+            while (t > 0 && std::isspace((unsigned char)glsl[t - 1])) --t;
+            const bool has_type = t > 0 && (std::isalnum((unsigned char)glsl[t - 1]) || glsl[t - 1] == '_');
+            if (e > b && has_type) names.insert(glsl.substr(b, e - b));
+        }
+    }
+}
+
 // names of the functions a GLSL text defines with an `out` / `inout` parameter
 void functions_with_out_params(const std::string& glsl, std::set<std::string>& names) {
     size_t pos = 0;
@@ -465,6 +485,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             for (auto& u : list)
                 if (u.type != UniformType::Sampler && !baked.count(u.name)) hp.uniforms[u.name] = cxx_type(u.type);
             for (const NamedCode& lib : scene.library) functions_with_out_params(lib.code, hp.functions_with_out_params);
+            for (const NamedCode& lib : scene.library) defined_functions(lib.code, hp.scene_functions);
             for (const NamedCode& lib : scene.library) snippet.prepare(lib.code, hp, false, {});
             for (const Material& m : scene.materials)
                 if (m.kind == Material::Complex) snippet.prepare(m.code, hp, true, {"hit", "r", "i"});

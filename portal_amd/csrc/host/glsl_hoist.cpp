@@ -689,7 +689,7 @@ class Hoister {
                     break;
                 }
                 auto f = pure_functions().find(nd.text);
-                if (f == pure_functions().end() || declared_.count(nd.text) || nd.kids.empty()) {
+                if (f == pure_functions().end() || declared_.count(nd.text) || P.scene_functions.count(nd.text) || nd.kids.empty()) {
                     nd.leaf = nd.op = false;
                     nd.loop = 0;
                     nd.cost = 0;
@@ -763,7 +763,7 @@ class Hoister {
             replacements_.push_back({nd.b, nd.e, member_for(nd.type, nd, text)});
             return;
         }
-        if (nd.kind == Node::Call && !declared_.count(nd.text)) {
+        if (nd.kind == Node::Call && !declared_.count(nd.text) && !P.scene_functions.count(nd.text)) {
             auto staged_arg = [&](int k) { return k < (int)nd.kids.size() && placeable(nodes_[nd.kids[k]]) && nodes_[nd.kids[k]].type == "vec3"; };
             if ((nd.text == "normalize_normal" && nd.kids.size() == 2 && staged_arg(0)) || (nd.text == "plane_intersect" && nd.kids.size() == 3 && staged_arg(2))) {
                 const int which = nd.text == "normalize_normal" ? 0 : 2;

@@ -40,6 +40,7 @@ struct HoistedMember {
 struct HoistParams {
     std::map<std::string, std::string> uniforms;      // uniforms READ AT RUN TIME: name -> GLSL type (baked ones must not be listed)
     std::set<std::string> functions_with_out_params;  // functions of the scene that may write through an argument
+    std::set<std::string> scene_functions;            // every function the scene defines itself: never taken for a built-in of that name
     bool body_only = false;                           // the text is the body of a function the code generator wraps, not definitions
     std::vector<std::string> body_params;             // that function's parameter names
 };

@@ -1001,3 +1001,16 @@ def test_hoisted_and_plain_host_builds_draw_the_same_bits(pa, scene_file, moves)
             assert "ptl_hv" in scene.generate_source(flags)
     for a, b in zip(frames["hoisted"], frames["plain"]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_hoister_does_not_take_a_scene_function_for_a_builtin(pa):
+    """A scene may define `sqr`, `normalize_normal` ... itself (any signature): such calls are neither typed like the built-in nor
+    re-targeted to a staged form."""
+    code = "float k = sqr(scale_u + 1.0) * length(dir_u);\nvec3 n = normalize_normal(dir_u, r.d.xyz);\nreturn vec4(n * k, 0.0);"
+    plain, _ = pa.hoist_glsl(code, _HOIST_UNIFORMS, params=["r"])
+    assert "float k = PTL_U.ptl_hv0;" in plain and "ptl_normalize_normal_unit(PTL_U.ptl_hv1, r.d.xyz)" in plain
+    own, prologue = pa.hoist_glsl(code, _HOIST_UNIFORMS, out_functions=["=sqr", "=normalize_normal"], params=["r"])
+    assert "sqr(scale_u + 1.0) * PTL_U.ptl_hv0" in own and "length(dir_u)" in prologue     # only the part that IS a built-in moves
+    assert "normalize_normal(dir_u, r.d.xyz)" in own and "ptl_normalize_normal_unit" not in own
+    src = pa.Scene.from_file(pa.scene_path("portal_in_portal")).generate_source(0)
+    assert "ptl_normalize_normal_unit(" in src and "ptl_is_collinear_len(" in src        # the reference's scenes define neither

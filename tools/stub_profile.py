@@ -43,6 +43,10 @@ PATCHES = {
     "pip_no_normal_chain": [("\tnormal_b = b0_mat * (a_mat_inv * normal_b);\n", "\n")],
     # EXPERIMENT (intact picture): the loop over the nested copies fully unrolled -- the chain above becomes literals
     "pip_unrolled": [("int ptl_pend_0 = 0; int ptl_pend_1 = 0; for (int size = 0; size < show_teleported_u; size++) {", "int ptl_pend_0 = 0; int ptl_pend_1 = 0;\n_Pragma(\"unroll\") for (int size = 0; size < show_teleported_u; size++) {")],
+    # WHAT IF (wrong picture): the ORIGIN half of the snippet's ray chain cost nothing -- on the first trip every ray of the frame starts
+    # at the camera, so r_b.o, r3.o are functions of the iteration number alone and could come from the prologue kernel
+    "pip_origin_chain_free": [("\tRay r3 = transform(b0_mat_inv, r_b);\n", "\tRay r3 = r_b; r3.d = b0_mat_inv * r_b.d; r3.o = r.o + vec4(float(size));\n"),
+                              ("\tr_b = transform(a_mat, transform(b0_mat_inv, r_b));\n", "\tr_b.d = a_mat * (b0_mat_inv * r_b.d);\n")],
     # Complex objects (scene snippets intersect_<k>) skipped
     "no_complex": [("ihit = intersect_", "if (len < 0.0f) ihit = intersect_")],
     # no bounce loop at all: ray generation, AA loop, gamma, store
