@@ -195,7 +195,8 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * module's prologue kernel `ptl_derive_kernel` and read back as extra uniforms -- same operations, identical frames;
  * this bit keeps the reference's per-call form (A/B measurements, tests),
  * bit6 = FAST MATH, the tolerance mode (`--fast`): hardware rcp / sqrt / rsq estimates (1 ulp), a / b = a * rcp(b), FMA
- * contraction, plane tests as t = -o'.z * rcp(d'.z) without normalising the transformed direction.  Frames agree with the exact kernel to ~1e-6 per channel except at pixels where the last bit decides a path
+ * contraction, plane tests as t = -o'.z * rcp(d'.z) without normalising the transformed direction, products with a literal zero folded
+ * (-fno-signed-zeros -fno-honor-nans: with the scene state baked in, most portal matrices are mostly zeros).  Frames agree with the exact kernel to ~1e-6 per channel except at pixels where the last bit decides a path
  * (object edges); the exact kernel stays the default and the parity reference.
  * bit7 = NO deferred loop updates: by default a loop-carried ray transform in a scene snippet (`X = transform(A_mat, transform(B_mat_inv, X));`
  * on every iteration, X read only where a hit is recorded) is replaced by a counter and applied right before X is read -- the same

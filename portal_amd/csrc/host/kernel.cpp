@@ -76,6 +76,14 @@ std::vector<std::string> compile_options(const char* const* defines, int n_defin
             o.push_back(std::string("-vgpr-regalloc=") + (ra ? ra : "basic"));
         }
     }
+    if (fast && !std::getenv("PTL_FAST_KEEP_ZEROS")) {
+        // Tolerance mode only: a product with a literal zero is zero.  With the scene state baked in, the portal matrices of most scenes are
+        // translations and axis rotations -- 41 % of the multiplications in the headline snippet's loop have a literal +-0 operand, and
+        // IEEE keeps every one of them alive (0 * x is -0, or NaN for an infinite x).  What this gives up beyond the rest of the mode:
+        // the sign of exact zeros and NaN propagation through such products.
+        o.push_back("-fno-signed-zeros");
+        o.push_back("-fno-honor-nans");
+    }
     if (const char* extra = std::getenv("PTL_HIPRTC_FLAGS")) {
         std::string e = extra;
         size_t pos = 0;

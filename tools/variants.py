@@ -99,6 +99,9 @@ VARIANTS = {
     "r2_dyn_nohoist": "NO_HOIST",
     "r2_ints_nohoist": "SPECIALIZE NO_HOIST",
     "r2_dyn_nohoist_w5": "NO_HOIST -DPTL_WAVES_PER_EU=5",
+    "r2_dyn_O2": "-O2", "r2_dyn_O3": "-O3", "r2_dyn_Os": "-Os", "r2_dyn_minreg": "-mllvm -amdgpu-sched-strategy=iterative-minreg", "r2_dyn_ilp": "-mllvm -amdgpu-sched-strategy=max-ilp",
+    "r2_ints_O2": "SPECIALIZE -O2", "r2_ints_O3": "SPECIALIZE -O3", "r2_ints_Os": "SPECIALIZE -Os", "r2_ints_minreg": "SPECIALIZE -mllvm -amdgpu-sched-strategy=iterative-minreg",
+    "r2_all_O2": "SPECIALIZE_ALL -O2", "r2_all_O3": "SPECIALIZE_ALL -O3",
     "r2_ints": "SPECIALIZE",
     "r2_ints_noderived": "SPECIALIZE NO_DERIVED",
     "r2_dyn_nocull": "-DPTL_NO_PLANE_CULL",
