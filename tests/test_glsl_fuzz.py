@@ -215,3 +215,60 @@ def test_random_glsl_expressions_over_uniforms_survive_the_hoister(pa, tmp_path,
         bands = sorted({int(x * N_EXPR / w) for x in xs})
         raise AssertionError(f"seed {seed}: {len(xs)} pixels differ, around bands {bands[:6]}: " + " | ".join(exprs[b] for b in bands[:3] if b < len(exprs)))
     assert len(np.unique(got.reshape(-1, 4), axis=0)) > N_EXPR // 2
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_hoister_survives_mutated_corpus_snippets(pa, seed):
+    """The hoister runs on every snippet of every scene a user loads: whatever the text (here: the reference's ~1 600 snippets with
+    random token deletions, duplications, swaps, truncations and stray punctuation), it must come back with a string that has the
+    same number of lines -- never crash, never throw -- and the translator must accept or refuse that string in an orderly way."""
+    import glob
+    import os
+    import re
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "corpus", "scenes")
+    texts = []
+    for f in sorted(glob.glob(os.path.join(root, "*.ron"))):
+        for m in re.finditer(r'\(\("(.*?)"\)\)', open(f).read(), re.S):
+            if len(m.group(1)) > 40:
+                texts.append(m.group(1).replace('\\"', '"'))
+    assert len(texts) > 1000
+    uniforms = {}
+    for t in texts:
+        for w in set(re.findall(r"\b\w+_mat(?:_inv|_teleport)?\b", t)):
+            uniforms.setdefault(w, "mat4")
+        for w in set(re.findall(r"\b\w+_u\b", t)):
+            uniforms.setdefault(w, "float")
+    rng = random.Random(seed)
+    tok = re.compile(r"\s+|\w+|[^\w\s]")
+    stray = ["(", ")", "{", "}", ";", ",", "for", "if", "else", "=", "++", "?", ":", "[", "]", "return", "continue", "break", ".", "*"]
+    hoisted = 0
+    for _ in range(400):
+        t = rng.choice(texts)
+        toks = tok.findall(t)
+        for _ in range(rng.randrange(0, 6)):
+            if not toks:
+                break
+            i, op = rng.randrange(len(toks)), rng.randrange(6)
+            if op == 0:
+                del toks[i]
+            elif op == 1:
+                toks.insert(i, toks[rng.randrange(len(toks))])
+            elif op == 2:
+                j = rng.randrange(len(toks))
+                toks[i], toks[j] = toks[j], toks[i]
+            elif op == 3:
+                toks = toks[:i]
+            elif op == 4:
+                toks.insert(i, rng.choice(stray))
+            else:
+                toks[i] = rng.choice(list(uniforms))
+        code = "".join(toks)
+        out, _ = pa.hoist_glsl(code, uniforms, body_only=not re.search(r"^\s*\w+\s+\w+\s*\(", t), params=["r", "pos", "x", "y", "back", "first", "hit", "i"])
+        assert out.count("\n") == code.count("\n")
+        hoisted += "ptl_hv" in out
+        try:
+            pa.translate_glsl(out)
+        except pa.PortalError:
+            pass
+    assert hoisted > 0
