@@ -154,11 +154,18 @@ def run_one(case, vname, flags):
     for t in toks:
         if t.startswith("BLOCK_WAVES="):
             os.environ["PTL_BLOCK_WAVES"] = t.split("=")[1]
-    scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    # a case may name a scene FILE (tests/corpus/scenes/matryoshka.ron:W:H:depth:aa): its assets are looked up beside its `scenes` directory
+    extra = {}
+    if scene_name.endswith(".ron"):
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), scene_name)
+        extra["asset_root"] = os.path.dirname(os.path.dirname(path))
+    else:
+        path = pa.scene_path(scene_name)
+    scene = pa.Scene.from_file(path)
     if os.environ.get("PTL_VARIANTS_PRECOMPILE"):  # no GPU here: fill the code-object cache that travels to the GPU box
-        r = pa.SceneRenderer(scene, device=-1, flags=rflags)
+        r = pa.SceneRenderer(scene, device=-1, flags=rflags, **extra)
         return {"case": case, "variant": vname, "regs": notes(r.code_object())}
-    r = pa.SceneRenderer(scene, device=0, flags=rflags)
+    r = pa.SceneRenderer(scene, device=0, flags=rflags, **extra)
     r.set_option("render_depth", d)
     r.set_option("aa_count", aa)
     times, digest = [], None
