@@ -205,6 +205,10 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * (`b0_mat * (a_mat_inv * normal_b)`, `d_mat * c_mat_inv`, normalize() of such a normal ...), loop-carried chains of them
  * included, is computed by the prologue kernel of bit5 into members behind the derived uniforms, and the snippet reads it
  * from there -- the same expression text compiled in the same module, identical frames (host/glsl_hoist.h).  Off with bit5.
+ * bit13 = NO first-trip variants: by default every intersection-material snippet is compiled twice, and the copy that runs while a
+ * ray still starts at the camera (the first trip of the bounce loop: nine trips in ten) takes the ORIGIN half of its
+ * `transform(uniform matrix, ray)` chains from the prologue kernel -- the origin of every primary ray is the same uniform value --
+ * while the direction half stays per ray; same operations on the same values, identical frames.  Off with bit5 / bit12.
  * ptl_renderer_create additionally reads bits 8-11 as an occupancy hint n (0 = none):
  * the kernel is built with __launch_bounds__(256, n), i.e. at least n waves per SIMD. */
 int ptl_scene_generate_source(ptl_scene* s, unsigned flags, char** source);
@@ -387,7 +391,7 @@ char* ptl_translate_glsl(const char* glsl);
  * bit12 / bit5 say otherwise).  `uniforms` lists the run-time uniforms as "type name;type name;..." (GLSL types), `out_functions`
  * the functions that write through an argument ("f;g"; "=f" marks a function the scene merely defines itself, which is then never
  * taken for the built-in of that name), `body_only` != 0 says the text is a function BODY whose parameters are
- * `params` ("r;first").  Returns the rewritten GLSL (malloc'ed, ptl_free; the input itself when nothing was hoisted) and, in
+ * `params` ("r;first"; "@r" marks a ray whose origin is the camera's, as in the first-trip variant of a snippet).  Returns the rewritten GLSL (malloc'ed, ptl_free; the input itself when nothing was hoisted) and, in
  * *prologue (may be NULL), the GLSL statements for the prologue kernel, one line per created member in front as
  * "// member: type name[count]". */
 char* ptl_hoist_glsl(const char* glsl, const char* uniforms, const char* out_functions, int body_only, const char* params, char** prologue);

@@ -53,6 +53,7 @@ FLAG_SPECIALIZE_ALL = 4
 FLAG_SPECIALIZE_STATIC = 8  # bake what stays constant while a clip plays (checked before every draw, rebuilt if it moved)
 FLAG_ANAGLYPH = 16  # compile the anaglyph stereo mode in (the reference's `disable_anaglyph = false`)
 FLAG_NO_DERIVED_UNIFORMS = 32  # keep the per-call plane tests (default: ray-independent halves evaluated by the prologue kernel)
+FLAG_NO_FIRST_TRIP = 8192  # no first-trip copies of the intersection-material snippets (default: on the first trip the origin half of their ray chains comes from the prologue)
 FLAG_NO_UNIFORM_HOIST = 4096  # scene snippets evaluate their uniform-only expressions per ray (default: once per upload, in the prologue kernel)
 FLAG_NO_DEFERRED_UPDATES = 128  # translate scene snippets exactly as written (default: loop-carried ray transforms are applied lazily)
 FLAG_FAST_MATH = 64  # tolerance mode: hardware rcp / sqrt estimates, FMA contraction (not bit-exact; exact stays the default)

@@ -204,6 +204,10 @@ PTL_FN SurfaceIntersection ptl_plane_intersect_unit(Ray r, const mat4& plane_inv
     bool flipped;
     return plane_intersect_derived(r, plane_inv, unit_normal, flipped);
 }
+PTL_FN Ray ptl_ray_o(Ray r, vec4 origin) {  // r with its origin taken from the prologue's table: r's own origin arithmetic becomes dead code
+    r.o = origin;
+    return r;
+}
 PTL_FN bool ptl_is_collinear_len(vec3 a, vec3 b, float length_b) {  // is_collinear(a, b) given length(b)
     return abs(dot(a, b) / (length(a) * length_b) - 1.0f) < 0.01f;
 }

@@ -161,6 +161,23 @@ PTL_FN SceneIntersectionWithMaterial scene_intersect_material_process(const Ray&
     return result;
 }
 
+#ifdef PTL_FIRST_TRIP
+// First-trip variants (KernelOptions::first_trip, flags bit 13).  Every primary ray of the frame starts at the camera: on the first
+// trip of the bounce loop -- nine trips in ten on the headline frame -- the ORIGIN half of whatever the scene's intersection-material
+// snippets do to the ray depends on uniforms alone.  The code generator emits a second copy of each snippet, `intersect_material_<N>_first`,
+// in which the hoister (host/glsl_hoist.h) knows that about `r`: origins of `transform(uniform matrix, ray)` chains come from the
+// prologue kernel's tables, the direction half stays per ray.  Same operations on the same values; later trips use the general copy.
+PTL_FN SceneIntersectionWithMaterial scene_intersect_material_process_first(const Ray& r) {
+    SceneIntersectionWithMaterial result = SceneIntersectionWithMaterial{scene_intersection_none, material_empty()};
+    SceneIntersectionWithMaterial hit = SceneIntersectionWithMaterial{scene_intersection_none, material_empty()};
+    (void)hit;
+
+//%intersection_material_processing_first//%
+
+    return result;
+}
+#endif
+
 // --- the bounce loop -------------------------------------------------- src/frag.glsl:74-159
 struct RayTraceResult {
     vec3 color;
@@ -194,11 +211,20 @@ PTL_FN vec3 sample_depth_gradient(float depth) {  // frag.glsl:101-104
 
 // One pass of the bounce loop for one ray: nearest hit, material, advance.  Returns true when the path has ended (`out` is
 // its result), false when `r` / `current_color` / `all_t` have been advanced to the next segment.  (frag.glsl:113-156)
+#ifdef PTL_FIRST_TRIP
+// (`first_form`, wave-uniform: r still starts at the camera, so the snippets run in their first-trip form -- see scene_intersect_material_process_first)
+PTL_FN bool trace_segment(Ray& r, vec3& current_color, float& all_t, float camera_scale, const vec3& not_found_color, RayTraceResult& out, bool first_form) {
+#else
 PTL_FN bool trace_segment(Ray& r, vec3& current_color, float& all_t, float camera_scale, const vec3& not_found_color, RayTraceResult& out) {
+#endif
     // The reference evaluates scene_intersect first (frag.glsl:114-115); both are pure, and with the snippet's hit distance known the
     // plane tests beyond it can be culled: `i` then is the nearest object in front of the snippet's hit, or whatever else survived --
     // and whenever the two differ the snippet's hit is nearer than both and is what gets used below.
+#ifdef PTL_FIRST_TRIP
+    SceneIntersectionWithMaterial i2 = first_form ? scene_intersect_material_process_first(r) : scene_intersect_material_process(r);
+#else
     SceneIntersectionWithMaterial i2 = scene_intersect_material_process(r);
+#endif
     SceneIntersection i = scene_intersect(r, (i2.scene.hit.hit && i2.scene.hit.t > 0.0f) ? i2.scene.hit.t : __builtin_inff());
 
     // `m` is left unset by the reference when a snippet reports hit with t <= 0 (GLSL:
@@ -238,11 +264,16 @@ PTL_FN bool trace_segment(Ray& r, vec3& current_color, float& all_t, float camer
     return false;
 }
 
+
 // The bounce loop.  A wavefront owns an 8x8 pixel tile (ptl_entry.h); its 64 rays take different numbers of trips.  On the
 // device the loop is written for the wave: a lane whose path has ended drops out of `alive`, and the whole wave leaves as
 // soon as a ballot over `alive` comes back empty -- one scalar compare per trip, no lane ever waits for a loop counter it
 // no longer needs.  (-DPTL_NO_WAVE_LOOP: the per-lane form with returns, which the compiler turns into the same shape.)
+#ifdef PTL_FIRST_TRIP
+PTL_FN RayTraceResult ray_tracing(Ray r, float camera_scale, bool origin_is_camera) {  // origin_is_camera: r.o is PTL_U.ptl_dv_origin, bit for bit
+#else
 PTL_FN RayTraceResult ray_tracing(Ray r, float camera_scale) {
+#endif
     //%skybox_processing//%
 
     vec3 current_color = vec3(1.0f);
@@ -250,19 +281,30 @@ PTL_FN RayTraceResult ray_tracing(Ray r, float camera_scale) {
     RayTraceResult result = RayTraceResult{color(0.0f, 0.0f, 0.0f), 0.0f, false};  // depth exhausted
 #if PTL_DEVICE_BUILD && !defined(PTL_NO_WAVE_LOOP)
     bool alive = true;
+#ifdef PTL_FIRST_TRIP
+    const bool first_form = __builtin_amdgcn_ballot_w64(!origin_is_camera) == 0ull;  // one decision per wave (side-by-side stereo mixes eyes)
+#endif
     for (int j = 0; j < _ray_tracing_depth; j++) {
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;  // every ray of the tile has terminated
         PTL_RELAUNDER();
         if (alive) {
             PTL_COUNT_SEGMENT();
+#ifdef PTL_FIRST_TRIP
+            alive = !trace_segment(r, current_color, all_t, camera_scale, not_found_color, result, j == 0 && first_form);
+#else
             alive = !trace_segment(r, current_color, all_t, camera_scale, not_found_color, result);
+#endif
         }
     }
 #else
     for (int j = 0; j < _ray_tracing_depth; j++) {
         PTL_RELAUNDER();
         PTL_COUNT_SEGMENT();
+#ifdef PTL_FIRST_TRIP
+        if (trace_segment(r, current_color, all_t, camera_scale, not_found_color, result, j == 0 && origin_is_camera)) return result;
+#else
         if (trace_segment(r, current_color, all_t, camera_scale, not_found_color, result)) return result;
+#endif
     }
 #endif
     return result;
@@ -459,7 +501,11 @@ PTL_FN vec3 get_color2(vec2 image_position, const mat4& camera_matrix, bool in_s
         d = normalize(camera_times(camera_matrix, which_eye, vec4(image_position.x * h, image_position.y * h, 1.0f, 0.0f)));
     }
 
+#ifdef PTL_FIRST_TRIP
+    RayTraceResult trace = ray_tracing(Ray{o, d, 1.0f, in_subspace}, camera_scale, which_eye == 0);
+#else
     RayTraceResult trace = ray_tracing(Ray{o, d, 1.0f, in_subspace}, camera_scale);
+#endif
     if (_draw_depth_map == 1) {
         if (trace.has_depth) return sample_depth_gradient(trace.depth);
         return vec3(0.0f);

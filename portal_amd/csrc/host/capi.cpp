@@ -393,6 +393,7 @@ static KernelOptions options_from_flags(unsigned flags) {
     o.specialize_static = (flags & 8u) != 0;
     o.derived_uniforms = (flags & 32u) == 0;  // PTL_FLAG_NO_DERIVED_UNIFORMS: the plain plane tests (A/B measurements, tests)
     o.fast_math = (flags & 64u) != 0;         // PTL_FLAG_FAST_MATH: tolerance mode
+    o.first_trip = (flags & 8192u) == 0;          // PTL_FLAG_NO_FIRST_TRIP: no first-trip copies of the intersection-material snippets
     o.hoist_uniform_work = (flags & 4096u) == 0;  // PTL_FLAG_NO_UNIFORM_HOIST: snippets evaluate their uniform-only expressions per ray
     return o;
 }
@@ -1144,7 +1145,15 @@ extern "C" char* ptl_hoist_glsl(const char* glsl, const char* uniforms, const ch
         else hp.functions_with_out_params.insert(f);
     }
     hp.body_only = body_only != 0;
-    hp.body_params = split(params);
+    for (const std::string& name : split(params)) {  // "@r": a ray parameter whose origin is the camera's (first-trip variant)
+        if (name[0] == '@') {
+            hp.origin_uniform_rays.push_back(name.substr(1));
+            hp.body_params.push_back(name.substr(1));
+        } else {
+            hp.body_params.push_back(name);
+        }
+    }
+    hp.origin_expr = "PTL_DV_OUT.ptl_dv_origin";
     int counter = 0;
     HoistResult r = hoist_uniform_work(glsl, hp, counter);
     if (prologue) {

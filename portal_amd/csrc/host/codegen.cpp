@@ -328,6 +328,7 @@ namespace {
 struct SnippetTranslator {
     const CodegenFlags& flags;
     std::map<const std::string*, std::string> hoisted;  // source text of a snippet (by address) -> filtered + hoisted GLSL
+    std::map<const std::string*, std::string> hoisted_first;  // ... and its first-trip variant (intersection materials, KernelOptions::first_trip)
     std::vector<HoistedMember> members;
     std::string prologue;  // GLSL
     int next_member = 0;
@@ -342,6 +343,21 @@ struct SnippetTranslator {
         members.insert(members.end(), r.members.begin(), r.members.end());
         prologue += r.prologue;
     }
+    // the first-trip variant of an intersection-material snippet: parameter `r` starts at the camera
+    void prepare_first(const std::string& code, const HoistParams& base) {
+        HoistParams hp = base;
+        hp.body_only = true;
+        hp.body_params = {"r"};
+        hp.origin_uniform_rays = {"r"};
+        hp.origin_expr = "PTL_DV_OUT.ptl_dv_origin";
+        HoistResult r = hoist_uniform_work(filter_tagged_lines(code, flags), hp, next_member);
+        if (r.members.empty()) return;
+        hoisted_first[&code] = r.glsl;
+        members.insert(members.end(), r.members.begin(), r.members.end());
+        prologue += r.prologue;
+    }
+    bool has_first(const std::string& code) const { return hoisted_first.count(&code) != 0; }
+    std::string first(const std::string& code) const { return translate_glsl(hoisted_first.at(&code), flags.defer_loop_updates); }
     std::string operator()(const std::string& code) const {
         auto it = hoisted.find(&code);
         return translate_glsl(it != hoisted.end() ? it->second : filter_tagged_lines(code, flags), flags.defer_loop_updates);
@@ -408,7 +424,7 @@ struct PortalMaterialNames {
 GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& flags, const KernelOptions& opts) {
     GeneratedKernel gk;
     std::map<std::string, StringStorage> storages;
-    SnippetTranslator snippet{flags, {}, {}, {}, 0};
+    SnippetTranslator snippet{flags, {}, {}, {}, {}, 0};
 
     // --- uniform block --------------------------------------------------------------------
     {
@@ -482,8 +498,11 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         // --- uniform-only work of the scene snippets: members behind the derived planes, filled by the same prologue kernel -----
         if (opts.derived_uniforms && opts.hoist_uniform_work) {
             HoistParams hp;
-            for (auto& u : list)
-                if (u.type != UniformType::Sampler && !baked.count(u.name)) hp.uniforms[u.name] = cxx_type(u.type);
+            for (auto& u : list) {
+                if (u.type == UniformType::Sampler) continue;
+                if (baked.count(u.name)) hp.constants[u.name] = cxx_type(u.type);
+                else hp.uniforms[u.name] = cxx_type(u.type);
+            }
             for (const NamedCode& lib : scene.library) functions_with_out_params(lib.code, hp.functions_with_out_params);
             for (const NamedCode& lib : scene.library) defined_functions(lib.code, hp.scene_functions);
             for (const NamedCode& lib : scene.library) snippet.prepare(lib.code, hp, false, {});
@@ -494,6 +513,8 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 else if (o.kind == Object::Complex) snippet.prepare(o.code, hp, true, o.portal ? std::vector<std::string>{"r", "first"} : std::vector<std::string>{"r"});
             }
             for (const NamedCode& im : scene.intersection_materials) snippet.prepare(im.code, hp, true, {"r"});
+            if (opts.first_trip)
+                for (const NamedCode& im : scene.intersection_materials) snippet.prepare_first(im.code, hp);
         }
         if (opts.derived_uniforms) s.add_string("#define PTL_DERIVED_BUILTINS 1\n");
         s.add_string("struct ptl_uniform_block {\n");
@@ -704,7 +725,9 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
 
     // --- intersection materials (scene.rs:1011-1035) --------------------------------------
     {
-        StringStorage fns, calls;
+        StringStorage fns, calls, calls_first;
+        bool any_first = false;
+        for (size_t pos = 0; pos < scene.intersection_materials.size(); ++pos) any_first = any_first || snippet.has_first(scene.intersection_materials[pos].code);
         for (size_t pos = 0; pos < scene.intersection_materials.size(); ++pos) {
             const NamedCode& im = scene.intersection_materials[pos];
             fns.add_string("PTL_FN SceneIntersectionWithMaterial intersect_material_" + std::to_string(pos) + "(Ray r) {\n");
@@ -712,9 +735,20 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             fns.add_string("\n}\n");
             calls.add_string("hit = intersect_material_" + std::to_string(pos) + "(r);\n");
             calls.add_string("if (nearer(result.scene.hit, hit.scene.hit)) { result = hit; }\n\n");
+            if (!any_first) continue;
+            const bool own = snippet.has_first(im.code);  // (a snippet without ray chains: its general form serves the first trip too)
+            if (own) {
+                fns.add_string("PTL_FN SceneIntersectionWithMaterial intersect_material_" + std::to_string(pos) + "_first(Ray r) {\n");
+                fns.add_string(snippet.first(im.code));
+                fns.add_string("\n}\n");
+            }
+            calls_first.add_string("hit = intersect_material_" + std::to_string(pos) + (own ? "_first" : "") + "(r);\n");
+            calls_first.add_string("if (nearer(result.scene.hit, hit.scene.hit)) { result = hit; }\n\n");
         }
+        gk.first_trip_variants = any_first;
         storages["intersection_material_functions"] = std::move(fns);
         storages["intersection_material_processing"] = std::move(calls);
+        storages["intersection_material_processing_first"] = std::move(calls_first);
     }
 
     // --- library (scene.rs:1037-1044) -----------------------------------------------------
@@ -768,6 +802,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     if (opts.count_segments) gk.defines.push_back("PTL_COUNT_SEGMENTS");
     if (opts.anaglyph) gk.defines.push_back("PTL_ANAGLYPH");
     if (opts.fast_math) gk.defines.push_back("PTL_FAST_MATH");
+    if (gk.first_trip_variants) gk.defines.push_back("PTL_FIRST_TRIP");
     return gk;
 }
 

@@ -85,6 +85,9 @@ struct KernelOptions {
     bool derived_uniforms = true;
     // ... and the uniform-only work of the scene snippets with them (glsl_hoist.h); no effect without derived_uniforms
     bool hoist_uniform_work = true;
+    // first-trip variants of the intersection-material snippets (ptl_trace.tpl PTL_FIRST_TRIP): the origin half of their ray arithmetic
+    // comes from the prologue while the ray still starts at the camera.  Needs derived_uniforms and hoist_uniform_work.
+    bool first_trip = true;
     bool fast_math = false;  // PTL_FAST_MATH: hardware rcp / sqrt / rsq (1 ulp), a/b = a * rcp(b), FMA contraction: tolerance mode, not bit-exact
 };
 
@@ -103,6 +106,7 @@ struct GeneratedKernel {
     size_t uniform_block_size = 0;
     std::vector<std::string> defines;   // e.g. "PTL_COUNT_SEGMENTS"
     std::vector<UniformUpload> baked;   // the values compiled in as literals (specialised builds)
+    bool first_trip_variants = false;   // the kernel has first-trip copies of its intersection-material snippets (define PTL_FIRST_TRIP)
     int hoisted_members = 0;            // ... plus this many members holding uniform-only work of the scene snippets (glsl_hoist.h)
     std::vector<DerivedPlane> derived;  // members appended to the block behind uniform_block_size, written on the device
 };

@@ -22,6 +22,7 @@ struct Node {
     bool leaf = false;  // reads at least one run-time uniform (directly or through a local)
     bool op = false;    // does arithmetic
     int cost = 0;       // ... roughly this many VALU instructions of it
+    bool half = false;  // a Ray whose origin is uniform and whose direction is not (first-trip variants); then `uniform` is false
     int loop = 0;       // > 0: depends on the carried variables of that loop ...
     int phase = 0;      // ... 0 as they are before their updates in the iteration, 1 after, -1 mixed
 };
@@ -85,6 +86,7 @@ struct LoopInfo {
 };
 
 struct Carried {  // a local that is a function of the iteration number alone
+    bool leaf = true;  // ... and of at least one run-time uniform (a chain of baked constants is the compiler's business)
     std::string name, type;
     int loop = 0;
     int update_site = -1;
@@ -189,6 +191,8 @@ class Hoister {
     };
     std::map<std::string, UniformLocal> ulocals_;
     std::map<std::string, Carried> carried_;
+    std::map<std::string, size_t> hlocals_;   // Ray locals with a uniform origin, written once: name -> index of the declared name
+    std::map<std::string, Carried> hcarried_;  // ... and those a canonical loop advances by `V = transform(U, ... V ...)`
 
     const Token& T(size_t i) const { return toks_[sig_[i]]; }
     bool is(size_t i, const char* text) const { return i < n_ && T(i).kind == Token::Punct && T(i).text == text; }
@@ -594,6 +598,7 @@ class Hoister {
         nd.loop = 0;
         nd.phase = 0;
         nd.cost = 0;
+        nd.half = false;
         auto kid = [&](int i) -> const Node& { return nodes_[nodes_[id].kids[i]]; };
         switch (nd.kind) {
             case Node::Lit:
@@ -611,12 +616,37 @@ class Hoister {
                     const LoopInfo& L = loops_[c->second.loop - 1];
                     if (nd.b >= L.body_b && nd.b < L.body_e) {
                         const Site& upd = sites_[c->second.update_site];
-                        nd.uniform = nd.leaf = true;
+                        nd.uniform = true;
+                        nd.leaf = c->second.leaf;
                         nd.type = c->second.type;
                         nd.loop = c->second.loop;
                         nd.phase = nd.b < upd.stmt_b ? 0 : (nd.b >= upd.stmt_e ? 1 : 0);
                         break;
                     }
+                }
+                auto hc = hcarried_.find(nd.text);
+                if (hc != hcarried_.end()) {
+                    const LoopInfo& L = loops_[hc->second.loop - 1];
+                    if (nd.b >= L.body_b && nd.b < L.body_e) {
+                        const Site& upd = sites_[hc->second.update_site];
+                        nd.half = nd.leaf = true;
+                        nd.type = "Ray";
+                        nd.loop = hc->second.loop;
+                        nd.phase = nd.b < upd.stmt_b ? 0 : (nd.b >= upd.stmt_e ? 1 : 0);
+                        break;
+                    }
+                }
+                auto hl = hlocals_.find(nd.text);
+                if (hl != hlocals_.end() && nd.b > hl->second) {
+                    nd.half = nd.leaf = true;
+                    nd.type = "Ray";
+                    break;
+                }
+                if (std::find(P.origin_uniform_rays.begin(), P.origin_uniform_rays.end(), nd.text) != P.origin_uniform_rays.end() && writes_[nd.text] == 1 &&
+                    !hlocals_.count(nd.text)) {
+                    nd.half = nd.leaf = true;  // a parameter whose origin is the camera's
+                    nd.type = "Ray";
+                    break;
                 }
                 auto u = ulocals_.find(nd.text);
                 if (u != ulocals_.end() && nd.b > u->second.name_at) {
@@ -630,11 +660,18 @@ class Hoister {
                 if (g != P.uniforms.end()) {
                     nd.uniform = nd.leaf = true;
                     nd.type = g->second;
+                    break;
+                }
+                auto k = P.constants.find(nd.text);
+                if (k != P.constants.end()) {
+                    nd.uniform = true;
+                    nd.type = k->second;
                 }
                 break;
             }
             case Node::Paren:
                 nd.uniform = kid(0).uniform;
+                nd.half = kid(0).half;
                 nd.type = kid(0).type;
                 combine(nd, kid(0));
                 break;
@@ -683,6 +720,14 @@ class Hoister {
                     all = all && kid((int)i).uniform;
                     combine(nd, kid((int)i));
                 }
+                if (nd.text == "transform" && nd.kids.size() == 2 && !declared_.count("transform") && !P.scene_functions.count("transform") &&
+                    kid(0).uniform && kid(0).type == "mat4" && kid(1).half) {
+                    nd.half = true;  // (combine() above has merged leaf / loop / phase / cost of both arguments)
+                    nd.type = "Ray";
+                    nd.op = true;
+                    nd.cost += 16;
+                    break;
+                }
                 if (type_name(nd.text)) {
                     nd.uniform = all && !nd.kids.empty();
                     nd.type = nd.text;
@@ -706,6 +751,12 @@ class Hoister {
                 break;
             }
             case Node::Member:
+                if (kid(0).half && nd.text == "o") {
+                    nd.uniform = true;
+                    nd.type = "vec4";
+                    combine(nd, kid(0));
+                    break;
+                }
                 if (kid(0).uniform && vec_size(kid(0).type) && swizzle(nd.text)) {
                     nd.uniform = true;
                     nd.type = vec_of((int)nd.text.size());
@@ -721,7 +772,7 @@ class Hoister {
                 }
                 break;
         }
-        if (!nd.uniform) {
+        if (!nd.uniform && !nd.half) {
             nd.leaf = nd.op = false;
             nd.loop = 0;
             nd.phase = 0;
@@ -729,12 +780,15 @@ class Hoister {
         }
     }
     static bool placeable(const Node& nd) { return nd.uniform && nd.leaf && (nd.loop == 0 || nd.phase >= 0); }
+    // a Ray with a uniform origin that is more than a name: its origin arithmetic can come from the prologue
+    static bool half_hoistable(const Node& nd) { return nd.half && nd.leaf && nd.op && (nd.loop == 0 || nd.phase >= 0); }
     // worth a member: a scalar load replaces it, so one multiplication alone is not
     static bool hoistable(const Node& nd) { return placeable(nd) && nd.op && nd.cost >= 3 && float_type(nd.type); }
 
     // ---- rewriting -----------------------------------------------------------------------------------------------------------
     std::string guard_name(int loop) const { return "ptl_tab_ok_" + std::to_string(loop_tags_.at(loop)); }
     std::map<int, int> loop_tags_;  // loop id (per function) -> number unique in the kernel
+    bool half_used_ = false;        // this function got members that hold ray origins: the prologue needs the rays themselves
 
     // a new member holding `expr_text` (evaluated where `like` stands); returns the expression that reads it
     std::string member_for(const std::string& type, const Node& like, const std::string& expr_text) {
@@ -758,6 +812,29 @@ class Hoister {
     }
     void hoist_in(int id) {
         const Node& nd = nodes_[id];
+        if (half_hoistable(nd)) {
+            const std::string text = text_of(nd.b, nd.e);
+            HoistedMember m;
+            m.type = "vec4";
+            m.name = "ptl_hv" + std::to_string(next_member_++);
+            m.length = nd.loop > 0 ? kTableEntries : 0;
+            members_.push_back(m);
+            half_used_ = true;
+            PrologueItem it;
+            it.at = nd.b;
+            it.loop = nd.loop;
+            if (nd.loop > 0) {
+                it.text = "PTL_DV_OUT." + m.name + "[ptl_k] = (" + text + ").o;";
+                items_.push_back(it);
+                const std::string index = loops_[nd.loop - 1].var + (nd.phase == 1 ? " + 1" : "");
+                replacements_.push_back({nd.b, nd.e, "(" + guard_name(nd.loop) + " ? ptl_ray_o(" + text + ", PTL_U." + m.name + "[" + index + "]) : (" + text + "))"});
+            } else {
+                it.text = "PTL_DV_OUT." + m.name + " = (" + text + ").o;";
+                items_.push_back(it);
+                replacements_.push_back({nd.b, nd.e, "ptl_ray_o(" + text + ", PTL_U." + m.name + ")"});
+            }
+            return;
+        }
         if (hoistable(nd)) {
             const std::string text = text_of(nd.b, nd.e);
             replacements_.push_back({nd.b, nd.e, member_for(nd.type, nd, text)});
@@ -786,6 +863,51 @@ class Hoister {
         for (int k : nd.kids) hoist_in(k);
     }
 
+    // `Ray V = <ray with a uniform origin>;` at the top level of the function: V keeps that property if nothing else writes it, or if
+    // the one other write is `V = <such a ray built from V>;` directly in the body of a canonical loop that also READS V directly in
+    // its body (a chain that is only read in nested blocks is left to the translator's deferred updates, which skip it altogether).
+    void half_ray_local(size_t si, size_t body_e) {
+        const Site& s = sites_[si];
+        const int w = writes_[s.decl_name];
+        if (w != 1 && w != 2) return;
+        classify(s.root);
+        if (!nodes_[s.root].half || nodes_[s.root].loop != 0) return;
+        if (w == 1) {
+            hlocals_[s.decl_name] = s.name_at;
+            return;
+        }
+        for (size_t ui = si + 1; ui < sites_.size(); ++ui) {
+            const Site& u = sites_[ui];
+            if (u.kind != Site::Expr || u.header || u.loop == 0 || u.stmt_e == 0) continue;
+            const Node& root = nodes_[u.root];
+            if (root.kind != Node::Assign || root.text != "=" || nodes_[root.kids[0]].kind != Node::Ident || nodes_[root.kids[0]].text != s.decl_name) continue;
+            const LoopInfo& L = loops_[u.loop - 1];
+            if (!L.canonical || !L.braced || L.outer != 0 || L.depth != 0 || L.has_continue || u.depth != L.depth + 1) return;
+            if (writes_[L.var] != 2 || (declared_.count(L.bound) && writes_[L.bound] != 1)) return;
+            if (!(is(L.kw - 1, ";") || is(L.kw - 1, "{") || is(L.kw - 1, "}"))) return;
+            if (tokens_mention(L.header_open, L.header_close, s.decl_name) || tokens_mention(L.body_e, body_e, s.decl_name)) return;
+            bool read_in_the_body = false;
+            for (size_t k = 0; k < sites_.size(); ++k)
+                read_in_the_body = read_in_the_body || (k != ui && sites_[k].root >= 0 && !sites_[k].header && sites_[k].loop == u.loop &&
+                                                        sites_[k].depth == L.depth + 1 && mentions(sites_[k].root, s.decl_name));
+            if (!read_in_the_body) return;
+            Carried c;
+            c.name = s.decl_name;
+            c.type = "Ray";
+            c.loop = u.loop;
+            c.update_site = (int)ui;
+            hcarried_[c.name] = c;
+            hlocals_[c.name] = s.name_at;  // between its declaration and the loop: an ordinary ray with a uniform origin
+            classify(root.kids[1]);
+            const Node& rhs = nodes_[root.kids[1]];
+            if (!rhs.half || (rhs.loop != 0 && rhs.loop != u.loop) || rhs.phase < 0 || mentions(root.kids[1], L.var)) {
+                hcarried_.erase(c.name);
+                hlocals_.erase(c.name);
+            }
+            return;
+        }
+    }
+
     void function(size_t body_b, size_t body_e, const std::vector<std::string>& params) {
         sites_.clear();
         loops_.clear();
@@ -793,7 +915,10 @@ class Hoister {
         writes_.clear();
         ulocals_.clear();
         carried_.clear();
+        hlocals_.clear();
+        hcarried_.clear();
         loop_tags_.clear();
+        half_used_ = false;
         const size_t first_item = items_.size();
         for (auto& p : params) {
             declared_.insert(p);
@@ -806,6 +931,10 @@ class Hoister {
         // locals that are uniform values (written once: their declaration) or uniform sequences (once more: their update in a loop)
         for (size_t si = 0; si < sites_.size(); ++si) {
             const Site& s = sites_[si];
+            if (s.kind == Site::DeclInit && s.depth == 0 && s.loop == 0 && s.decl_type == "Ray" && !P.origin_uniform_rays.empty()) {
+                half_ray_local(si, body_e);
+                continue;
+            }
             if (s.kind != Site::DeclInit || s.depth != 0 || s.loop != 0 || !type_name(s.decl_type)) continue;
             const int w = writes_[s.decl_name];
             if (w != 1 && w != 2) continue;
@@ -833,13 +962,17 @@ class Hoister {
                 c.type = s.decl_type;
                 c.loop = u.loop;
                 c.update_site = (int)ui;
+                c.leaf = false;  // (first without: does the chain read a run-time uniform besides itself?)
                 carried_[c.name] = c;
-                ulocals_[c.name] = {s.decl_type, s.name_at, true};  // between its declaration and the loop it is an ordinary uniform local
+                ulocals_[c.name] = {s.decl_type, s.name_at, init.leaf};  // between its declaration and the loop it is an ordinary uniform local
                 classify(root.kids[1]);
                 const Node& rhs = nodes_[root.kids[1]];
-                if (!rhs.uniform || rhs.type != s.decl_type || (rhs.loop != 0 && rhs.loop != u.loop) || rhs.phase < 0 || mentions(root.kids[1], L.var)) {
+                if (!rhs.uniform || rhs.type != s.decl_type || (rhs.loop != 0 && rhs.loop != u.loop) || rhs.phase < 0 || mentions(root.kids[1], L.var) ||
+                    !(init.leaf || rhs.leaf)) {
                     carried_.erase(c.name);
                     ulocals_.erase(c.name);
+                } else {
+                    carried_[c.name].leaf = true;
                 }
                 break;
             }
@@ -860,6 +993,8 @@ class Hoister {
         }
         for (auto& c : carried_)
             if (!loop_tags_.count(c.second.loop)) loop_tags_[c.second.loop] = next_member_++;  // (a number unique in the kernel)
+        for (auto& c : hcarried_)
+            if (!loop_tags_.count(c.second.loop)) loop_tags_[c.second.loop] = next_member_++;
 
         // the hoist itself
         const size_t members_before = members_.size();
@@ -868,11 +1003,12 @@ class Hoister {
             if (s.root < 0 || s.header) continue;
             bool is_update = false;
             for (auto& c : carried_) is_update = is_update || c.second.update_site == (int)si;
+            for (auto& c : hcarried_) is_update = is_update || c.second.update_site == (int)si;
             if (is_update) continue;
             classify(s.root);
             hoist_in(s.root);
         }
-        if (members_.size() == members_before && carried_.empty()) {  // nothing to do here: drop what the analysis has prepared
+        if (members_.size() == members_before && carried_.empty() && hcarried_.empty()) {  // nothing to do here: drop what the analysis has prepared
             items_.resize(first_item);
             return;
         }
@@ -904,6 +1040,31 @@ class Hoister {
             items_.push_back(step);
             replacements_.push_back({u.stmt_b, u.stmt_e, "if (" + guard_name(c.loop) + ") " + c.name + " = PTL_U." + m.name + "[" + L.var + " + 1]; else " + c.name + " = " + rhs + ";"});
         }
+        for (auto& entry : hcarried_) {  // the same for rays that carry a uniform origin: a table of origins, the update keeps its direction half
+            const Carried& c = entry.second;
+            const Site& u = sites_[c.update_site];
+            const LoopInfo& L = loops_[c.loop - 1];
+            const Node& root = nodes_[u.root];
+            const std::string rhs = text_of(nodes_[root.kids[1]].b, nodes_[root.kids[1]].e);
+            HoistedMember m;
+            m.type = "vec4";
+            m.name = "ptl_hv" + std::to_string(next_member_++);
+            m.length = kTableEntries;
+            members_.push_back(m);
+            used_loops.insert(c.loop);
+            half_used_ = true;
+            PrologueItem table;
+            table.at = L.body_b;
+            table.loop = c.loop;
+            table.text = "PTL_DV_OUT." + m.name + "[ptl_k] = " + c.name + ".o;";
+            items_.push_back(table);
+            PrologueItem step;
+            step.at = u.stmt_b;
+            step.loop = -c.loop;
+            step.text = c.name + " = " + rhs + ";";
+            items_.push_back(step);
+            replacements_.push_back({u.stmt_b, u.stmt_e, "if (" + guard_name(c.loop) + ") " + c.name + " = ptl_ray_o(" + rhs + ", PTL_U." + m.name + "[" + L.var + " + 1]); else " + c.name + " = " + rhs + ";"});
+        }
         for (int l : used_loops) {
             const LoopInfo& L = loops_[l - 1];
             replacements_.push_back({L.kw, L.kw, "const bool " + guard_name(l) + " = (" + L.bound + ") <= " + std::to_string(kTableLoop) + "; "});
@@ -916,6 +1077,23 @@ class Hoister {
                 decl.at = s.name_at;
                 decl.text = s.decl_type + " " + s.decl_name + " = " + text_of(nodes_[s.root].b, nodes_[s.root].e) + ";";
                 items_.push_back(decl);
+            }
+        }
+        if (half_used_) {  // the rays themselves: the parameters as dummies with the right origin, the locals as declared
+            for (const std::string& p : P.origin_uniform_rays) {
+                PrologueItem param;
+                param.at = body_b;
+                param.text = "Ray " + p + " = Ray(" + P.origin_expr + ", vec4(0.0), 1.0, false);";
+                items_.push_back(param);
+            }
+            for (auto& h : hlocals_) {
+                for (const Site& s : sites_) {
+                    if (s.kind != Site::DeclInit || s.decl_name != h.first || s.name_at != h.second) continue;
+                    PrologueItem decl;
+                    decl.at = s.name_at;
+                    decl.text = "Ray " + s.decl_name + " = " + text_of(nodes_[s.root].b, nodes_[s.root].e) + ";";
+                    items_.push_back(decl);
+                }
             }
         }
         // assemble this function's block: source order; the items of a loop inside one table loop at the loop's place, updates last

@@ -39,8 +39,16 @@ struct HoistedMember {
 
 struct HoistParams {
     std::map<std::string, std::string> uniforms;      // uniforms READ AT RUN TIME: name -> GLSL type (baked ones must not be listed)
+    std::map<std::string, std::string> constants;     // uniforms BAKED into the source as literals: uniform values the compiler folds by itself
+                                                      // (an expression of these alone is never hoisted; one that also reads `uniforms` is)
     std::set<std::string> functions_with_out_params;  // functions of the scene that may write through an argument
     std::set<std::string> scene_functions;            // every function the scene defines itself: never taken for a built-in of that name
+    // First-trip variant of a snippet (KernelOptions::first_trip): these parameters are rays whose ORIGIN is the uniform value
+    // `origin_expr` (every primary ray starts at the camera).  A `Ray` expression built from them with `transform(uniform matrix, ray)`
+    // keeps a uniform origin: that half -- and a loop-carried chain of it -- comes from the prologue (the direction half stays per ray),
+    // the expression is wrapped as ptl_ray_o(<expression>, <member>) and the compiler drops the now dead origin arithmetic.
+    std::vector<std::string> origin_uniform_rays;
+    std::string origin_expr;                          // in the prologue's terms, e.g. "PTL_DV_OUT.ptl_dv_origin"
     bool body_only = false;                           // the text is the body of a function the code generator wraps, not definitions
     std::vector<std::string> body_params;             // that function's parameter names
 };

@@ -93,6 +93,40 @@ def test_hoisted_uniform_work_changes_no_bit(gpu, scene_file, w, h, depth, moves
         assert not np.array_equal(_bits(frames["plain"][0]), _bits(frames["plain"][1]))
 
 
+@pytest.mark.parametrize("scene_file,spec", [
+    ("scenes/portal_in_portal.ron", 0), ("scenes/portal_in_portal.ron", 1), ("scenes/portal_in_portal.ron", 5),
+    ("tests/corpus/scenes/portal_in_portal_plus_ultra.ron", 0), ("tests/corpus/scenes/portal_in_portal_plus_ultra.ron", 5)])
+def test_first_trip_snippet_variants_change_no_bit(gpu, scene_file, spec):
+    """While a ray still starts at the camera the intersection-material snippets run in a copy whose ray-origin chains come from the
+    prologue kernel (tables indexed by the loop counter); FLAG_NO_FIRST_TRIP keeps the one general copy.  Same operations on the
+    same values: identical float frames -- also after the CAMERA has moved (the tables depend on it: the prologue must run again),
+    after a scene uniform has moved, with 70 nested copies (past the tables) and in side-by-side stereo (eyes mixed in a wave)."""
+    pa = gpu
+    path = os.path.join(ROOT, scene_file)
+    extra = {"asset_root": os.path.join(ROOT, "tests", "corpus")} if "corpus" in scene_file else {}
+    w, h = 320, 180
+    frames = {}
+    for label, flags in (("first", spec), ("general", spec | pa.FLAG_NO_FIRST_TRIP)):
+        scene = pa.Scene.from_file(path)
+        assert ("_first(Ray r) {" in scene.generate_source(flags)) == (label == "first")
+        r = pa.SceneRenderer(scene, device=0, flags=flags, **extra)
+        r.set_option("render_depth", 20)
+        got = [r.draw(w, h, rgba32f=True)["rgba32f"].copy()]
+        r.set_camera((0.3, 0.2, -0.4), 1.9, 1.2, 3.5)
+        got.append(r.draw(w, h, rgba32f=True)["rgba32f"].copy())
+        if "plus_ultra" not in scene_file:
+            assert scene.set_uniform("progress", 0.37)
+            got.append(r.draw(w, h, rgba32f=True)["rgba32f"].copy())
+            assert scene.set_uniform("show_teleported", 70)
+            got.append(r.draw(w, h, rgba32f=True)["rgba32f"].copy())
+        r.set_option("draw_side_by_side", 1)
+        got.append(r.draw(w, h, rgba32f=True)["rgba32f"].copy())
+        frames[label] = got
+    for a, b in zip(frames["first"], frames["general"]):
+        assert np.array_equal(_bits(a), _bits(b))
+    assert not np.array_equal(_bits(frames["general"][0]), _bits(frames["general"][1]))  # the camera really moved the picture
+
+
 # ---- layer 3: one frame across GPUs, one process ------------------------------------------------------------------------------
 @pytest.mark.parametrize("transport", ["stores", "copy"])
 @pytest.mark.parametrize("ranks", [2, 3])

@@ -868,8 +868,10 @@ for (int k = 0; k < n_u; k++) {
         update = next(line.strip() for line in text.splitlines() if line.strip().startswith("rb = ") and "transform(" in line)
         assert update.replace("1.)", "1.f)") in out and "ptl_pend_1" not in out and out.count("\n") == text.count("\n"), text
     # the shipped scenes: the headline's snippet has two such chains (scenes/portal_in_portal.ron:1146-1147), the others none
-    counts = {name: pa.Scene.from_file(pa.scene_path(name)).generate_source(0).count("int ptl_pend_") for name in SCENES}
+    counts = {name: pa.Scene.from_file(pa.scene_path(name)).generate_source(pa.FLAG_NO_FIRST_TRIP).count("int ptl_pend_") for name in SCENES}
     assert counts == {"basics": 0, "monoportal": 0, "triple_portal": 0, "portal_in_portal": 2, "mobius_monoportal": 0}
+    # (by default the headline's snippet is compiled twice -- the copy for the first trip defers the same two chains)
+    assert pa.Scene.from_file(pa.scene_path("portal_in_portal")).generate_source(0).count("int ptl_pend_") == 4
     assert "ptl_pend_" not in pa.Scene.from_file(pa.scene_path("portal_in_portal")).generate_source(pa.FLAG_NO_DEFERRED_UPDATES)
 
 
@@ -970,8 +972,14 @@ def test_hoisted_scene_source_is_selfconsistent(pa):
     derive = src[src.index("PTL_FN void derive(ptl_uniform_block* out)"):src.index("// Material id -> what happens to the path.")]
     assert set(re.findall(r"PTL_DV_OUT\.(ptl_hv\d+)", derive)) == members
     assert set(re.findall(r"PTL_U\.(ptl_hv\d+)", src)) == members
-    for flags in (pa.FLAG_NO_UNIFORM_HOIST, pa.FLAG_NO_DERIVED_UNIFORMS, pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL):
+    baked = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
+    for flags in (pa.FLAG_NO_UNIFORM_HOIST, pa.FLAG_NO_DERIVED_UNIFORMS, baked | pa.FLAG_NO_FIRST_TRIP):
         assert "ptl_hv" not in scene.generate_source(flags)
+    # with everything baked only the camera is left: the first-trip copy of the snippet reads two tables of ray origins, nothing else
+    src = scene.generate_source(baked)
+    block = src[src.index("struct ptl_uniform_block {"):src.index("};", src.index("struct ptl_uniform_block {"))]
+    assert re.findall(r"(\w+) ptl_hv\d+(\[\d+\])?;", block) == [("vec4", "[66]"), ("vec4", "[66]")]
+    assert src.count("ptl_ray_o(") == 3 and "intersect_material_0_first(Ray r) {" in src and "#define PTL_FIRST_TRIP" not in src
 
 
 @pytest.mark.parametrize("scene_file,moves", [
@@ -992,10 +1000,10 @@ def test_hoisted_and_plain_host_builds_draw_the_same_bits(pa, scene_file, moves)
         scene = pa.Scene.from_file(path)
         r = pa.SceneRenderer(scene, device=-1, flags=flags, **({"asset_root": root} if root else {}))
         r.set_option("render_depth", 12)
-        got = [hb.host_kernel_for(r, scene, 48, 27).render(48, 27)["rgba32f"].copy()]
+        got = [hb.host_kernel_for(r, scene, 48, 27, flags=flags, **({"asset_root": root} if root else {})).render(48, 27)["rgba32f"].copy()]
         for name, value in moves:
             assert scene.set_uniform(name, value)
-            got.append(hb.host_kernel_for(r, scene, 48, 27).render(48, 27)["rgba32f"].copy())
+            got.append(hb.host_kernel_for(r, scene, 48, 27, flags=flags, **({"asset_root": root} if root else {})).render(48, 27)["rgba32f"].copy())
         frames[label] = got
         if label == "hoisted":
             assert "ptl_hv" in scene.generate_source(flags)

@@ -102,6 +102,9 @@ VARIANTS = {
     "r2_dyn_O2": "-O2", "r2_dyn_O3": "-O3", "r2_dyn_Os": "-Os", "r2_dyn_minreg": "-mllvm -amdgpu-sched-strategy=iterative-minreg", "r2_dyn_ilp": "-mllvm -amdgpu-sched-strategy=max-ilp",
     "r2_ints_O2": "SPECIALIZE -O2", "r2_ints_O3": "SPECIALIZE -O3", "r2_ints_Os": "SPECIALIZE -Os", "r2_ints_minreg": "SPECIALIZE -mllvm -amdgpu-sched-strategy=iterative-minreg",
     "r2_all_O2": "SPECIALIZE_ALL -O2", "r2_all_O3": "SPECIALIZE_ALL -O3",
+    # first-trip snippet variants are the default since variants13 (there: "_ft" = with them); the general form alone for A/B:
+    "r2_all_noft": "SPECIALIZE_ALL NO_FIRST_TRIP", "r2_all_noft_w4": "SPECIALIZE_ALL NO_FIRST_TRIP -DPTL_WAVES_PER_EU=4",
+    "r2_ints_noft": "SPECIALIZE NO_FIRST_TRIP", "r2_dyn_noft": "NO_FIRST_TRIP",
     "r2_ints": "SPECIALIZE",
     "r2_ints_noderived": "SPECIALIZE NO_DERIVED",
     "r2_dyn_nocull": "-DPTL_NO_PLANE_CULL",
@@ -135,7 +138,7 @@ def run_one(case, vname, flags):
     w, h, d, aa = int(w), int(h), int(d), int(aa)
     toks = flags.split()
     rflags = (pa.FLAG_SPECIALIZE_INTS if ("SPECIALIZE" in toks or "SPECIALIZE_ALL" in toks) else 0) | (pa.FLAG_SPECIALIZE_ALL if "SPECIALIZE_ALL" in toks else 0)
-    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0) | (pa.FLAG_NO_DEFERRED_UPDATES if "NO_DEFER" in toks else 0) | (pa.FLAG_NO_UNIFORM_HOIST if "NO_HOIST" in toks else 0)
+    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0) | (pa.FLAG_NO_DEFERRED_UPDATES if "NO_DEFER" in toks else 0) | (pa.FLAG_NO_UNIFORM_HOIST if "NO_HOIST" in toks else 0) | (pa.FLAG_NO_FIRST_TRIP if "NO_FIRST_TRIP" in toks else 0)
     # the VGPR allocator is an option the JIT always passes (kernel.cpp): select it through its own switch, not a second -mllvm
     ra = [t.split("=", 1)[1] for t in toks if t.startswith("-vgpr-regalloc=")]
     if "RA_DEFAULT" in toks:
