@@ -570,7 +570,8 @@ def main():
                            " Counted: operations with a ray-dependent operand; most uniform-only ones come from the prologue kernel, the remainder is executed per ray "
                            f"but not counted ({fl['all_flops']:.0f} per trip with all of them).")
                         + (f" Of the reference algorithm's {fl['algorithmic']:.0f} the kernel executes {fl['flops']:.0f}: loop-carried ray transforms of the scene "
-                           "snippet that no statement reads are deferred away (counted on the host build); the plane cull's savings are not subtracted."
+                           "snippet that no statement reads are deferred away (counted on the host build), and while a ray still starts at the camera the origin "
+                           "half of the snippet's ray chains comes from the prologue kernel (read off the generated source); the plane cull's savings are not subtracted."
                            if fl["flops"] != fl["algorithmic"] else ""),
             }
             if pmc:

@@ -71,7 +71,16 @@ def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None
         skipped = deferred["flops_per_update"] * (deferred["scheduled_per_segment"] - deferred["applied_per_segment"])
         per_segment["flops_executed"] = per_segment["flops"] - skipped
         per_segment["flops_varying_executed"] = per_segment["flops_varying"] - skipped
+    first = first_trip_origin_flops(scene, w, h, options)
+    if first:
+        # the share of trips that ARE first trips: one per primary sample
+        saved = first["flops_per_first_trip"] * (n * aa) / seg
+        first["flops_per_segment"] = saved
+        for k in ("flops_executed", "flops_varying_executed"):
+            base = per_segment.get(k, per_segment[k.replace("_executed", "")])
+            per_segment[k] = base - saved
     return {
+        "first_trip_origin_arithmetic": first,
         "scene": scene, "width": w, "height": h, "depth": depth, "aa": aa,
         "sampled_pixels": n, "sampled_fraction_of_frame": n / (w * h), "seed": seed,
         "segments_in_sample": int(seg), "segments_per_primary_sample": seg / (n * aa),
@@ -108,6 +117,43 @@ def _vary_the_camera_between_lanes():
         return original(self, image_position, V.Mat(cols), *args, **kwargs)
 
     Oracle.get_color2 = get_color2
+
+
+def first_trip_origin_flops(scene_name, w, h, options=None):
+    """The first-trip copies of the intersection-material snippets (ptl_trace.tpl PTL_FIRST_TRIP) take the ORIGIN half of their
+    `transform(uniform matrix, ray)` chains from the prologue kernel: a ray that still starts at the camera does not execute it.  Read
+    off the generated source: every `ptl_ray_o(<expression>, <table>)` inside the loop of a `_first` function drops one mat4 x vec4
+    (28 operations) per `transform(` of its expression, once per loop iteration; iterations = the value of the loop bound.  None when
+    the scene has no such copy."""
+    import re
+
+    import portal_amd as pa
+
+    scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    source = scene.generate_source(pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
+    total, sites = 0, []
+    for m in re.finditer(r"PTL_FN SceneIntersectionWithMaterial intersect_material_\d+_first\(Ray r\) \{", source):
+        body = source[m.end():source.index("\n}\n", m.end())]
+        bound = re.search(r"const bool ptl_tab_ok_\d+ = \((\w+)\) <= \d+;", body)
+        if not bound:
+            continue
+        value = re.search(r"#define " + re.escape(bound.group(1)) + r" \((-?\d+)\)", source)
+        iterations = int(value.group(1)) if value else None
+        if iterations is None:
+            continue
+        for k in [x.start() for x in re.finditer(r"ptl_ray_o\(", body)]:
+            depth, i = 0, k + len("ptl_ray_o(")
+            start = i
+            while i < len(body) and not (body[i] == "," and depth == 0):
+                depth += body[i] == "("
+                depth -= body[i] == ")"
+                i += 1
+            transforms = body[start:i].count("transform(")
+            sites.append({"expression": " ".join(body[start:i].split()), "transforms": transforms})
+            total += 28 * transforms * iterations
+    if not sites:
+        return None
+    return {"flops_per_first_trip": total, "sites": sites, "iterations": iterations, "note": "28 binary32 operations per mat4 x vec4 (4 x (1 mul + 3 fma))"}
 
 
 def deferred_update_counts(scene_name, w, h, depth, aa, options=None, row_step=61):
