@@ -99,7 +99,14 @@ class Parser:
         if self.at("struct"):
             return self.parse_struct()
         quals = []
-        while self.peek()[1] in QUALIFIERS:
+        while self.peek()[1] in QUALIFIERS or self.at("layout"):
+            if self.at("layout"):  # layout(location=0) out vec4 FragColor;  (src/frag.glsl:286)
+                self.eat()
+                self.eat("(")
+                while not self.at(")"):
+                    self.eat()
+                self.eat(")")
+                continue
             quals.append(self.eat()[1])
         ty = self.parse_type()
         name = self.eat()
@@ -112,7 +119,7 @@ class Parser:
             self.eat()
             init = self.parse_assignment()
         self.eat(";")
-        return ("global", ty, name[1], init)
+        return ("global", ty, name[1], init, tuple(quals))
 
     def parse_struct(self):
         self.eat("struct")
@@ -380,11 +387,13 @@ class Interp:
         self.n = n
         if program is not None:  # share the parsed program, run it on a different lane count
             self.globals, self.natives, self.funcs, self.structs = program.globals, program.natives, program.funcs, program.structs
+            self.out_globals = program.out_globals
         else:
             self.globals = {}
             self.natives = {}
             self.funcs = {}    # name -> [(param_types, ast)]
             self.structs = {}  # name -> [(type, field)]
+            self.out_globals = set()  # `out` globals of a whole shader (FragColor): the only globals code may assign
         self.frames = []
         self.loops = []
 
@@ -405,7 +414,11 @@ class Interp:
         elif item[0] == "func":
             self.funcs.setdefault(item[2], []).append((tuple(t for _, t, _ in item[3]), item))
         elif item[0] == "global":
-            _, ty, name, init = item
+            _, ty, name, init, quals = item
+            if "out" in quals:
+                self.out_globals.add(name)
+            if ("uniform" in quals or "in" in quals) and name in self.globals:
+                return  # the host bound a value before the shader text was loaded
             frame = Frame(self.n, ty)
             self.frames.append(frame)
             try:
@@ -714,6 +727,9 @@ class Interp:
             if name in scope:
                 scope[name] = new_value
                 return rhs
+        if name in self.out_globals:
+            self.globals[name] = new_value
+            return rhs
         raise GlslError(f"assignment to `{name}` which is not a local variable")
 
     # ---- calls

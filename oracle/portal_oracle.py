@@ -3,12 +3,19 @@
 TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
 leg may import anything under oracle/; the product (portal_amd/) never does.
 
-PARITY UNPINNED: the reference ships no CPU tracer, no golden image and no known-answer vector
-for this path, and it cannot be built or run here
-(no Rust toolchain, no GL context).  This oracle is therefore a restatement, pinned only by
-the hand-derived known-answer tests in tests/test_oracle_kat.py and, qualitatively, by the one
-capture of the real program whose camera is known (tests/test_reference_screenshot.py: the same
-hue class on 92.5 % of the pixels outside the GUI -- where things are, not their bits).
+PARITY: PINNED TO THE REFERENCE'S SOURCE TEXT; BUILTIN PRECISION BY CONTRACT.  The reference ships no CPU
+tracer, no golden image and no known-answer vector for this path and
+cannot be built or run here (no Rust toolchain, no GL context), so this file is a hand restatement.  Since round 3
+it is checked against the reference's OWN definition of the arithmetic: oracle/reference_shader.py executes
+/root/reference/src/library.glsl + src/frag.glsl (slots filled as src/gui/scene.rs:693-1075 fills them) with
+oracle/glsl_interp.py, and tests/test_reference_text.py requires every function below == that text on 16 384
+seeded + special lanes, whole frames of the five configs and six camera / mode variants == that text, the
+camera-teleport query == that text (incl. its encode_float -> RGBA8 -> from_le_bytes route), and all 82 corpus
+scenes == that text -- bit for bit.  What stays unpinned is what GLSL ES 3.00 itself leaves open: the precision a
+GL driver gives `/`, sqrt, sin ... (oracle/glsl_math.py fixes one contract, shared by both oracles and the kernel),
+the rasteriser's varying interpolation and RGBA8 rounding (third-party), plus glam / fasteval on the host side
+(restated from their published algorithms).  Further pins: the hand-derived known answers of tests/test_oracle_kat.py
+and, qualitatively, the captures of the real program (tests/test_reference_screenshot.py).
 
 What it restates, in numpy over "lanes" (one lane = one pixel sample), independently of the
 product's C++ host code, of its GLSL->C++ translator and of its device prelude:

@@ -1,0 +1,396 @@
+"""The oracle pinned to the reference's OWN shader text (VERDICT r2 "Next #1").
+
+`oracle/reference_shader.py` executes `/root/reference/src/library.glsl` + `src/frag.glsl` (slots filled as
+`src/gui/scene.rs:693-1075` fills them, `void main()` included) with the oracle's GLSL interpreter.  Three layers:
+
+  1. LIVE (needs the text: /root/reference here, oracle/_ref/reference_shader.bin on the GPU box):
+     every function of the two files on 16 384 seeded lanes (random, scene-range, exact halves, +-0 / inf /
+     NaN / denormals) == the hand restatement `oracle.portal_oracle.Natives` / `Oracle`, bit for bit; whole frames
+     and `teleport_external_ray` (incl. the reference's encode_float -> RGBA8 -> from_le_bytes route) == `Oracle`;
+     the whole 82-scene corpus == `Oracle`.
+  2. COMMITTED VECTORS (tests/golden/reference_text/, outputs of the reference text, written by
+     tests/golden/make_reference_text_fixtures.py): `Oracle` / `Natives` reproduce them without the text present.
+  3. -m gpu: the HIP kernel reproduces the committed reference-text frames bit for bit, for the dynamic, the baked
+     and the occupancy-hinted builds bench.py times, and -- when the text travelled -- fresh random views live.
+"""
+import glob
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from tests import reftext as T
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CORPUS_ROOT = os.path.join(HERE, "corpus")
+
+
+def _have_text():
+    from oracle import reference_shader as RS
+
+    return RS.available()
+
+
+needs_text = pytest.mark.skipif(not _have_text(), reason="reference shader text not present (neither /root/reference nor oracle/_ref)")
+
+
+@pytest.fixture(scope="module")
+def shader_and_oracle():
+    from oracle.portal_oracle import Oracle
+    from oracle.reference_shader import ReferenceShader
+
+    rs = ReferenceShader(os.path.join(T.ROOT, "scenes", "basics.ron"))
+    rs.build(64, 64)
+    o = Oracle(os.path.join(T.ROOT, "scenes", "basics.ron"))
+    o.build(64, 64)
+    return rs, o
+
+
+@pytest.fixture(autouse=True)
+def _quiet():
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        yield
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the generator half (Rust in the reference): known answers
+# ---------------------------------------------------------------------------------------------------------
+def test_rust_lower_exp_formatting():
+    """`{:e}` of f64 (src/gui/scene.rs:750-773 prints material constants with it)."""
+    from oracle.reference_shader import rust_lower_exp as e
+
+    assert [e(x) for x in (0.6, 1.0, 0.25, 100.0, 1234.5, 0.0, -0.0, -0.6, 1e-7, 2.5e-5, 1.0 / 3.0)] == [
+        "6e-1", "1e0", "2.5e-1", "1e2", "1.2345e3", "0e0", "-0e0", "-6e-1", "1e-7", "2.5e-5", "3.333333333333333e-1"]
+
+
+def test_template_engine_and_line_filter_known_answers():
+    """`apply_template` (src/code_generation.rs:82-98, its own test vectors :100-184) and the tagged-line filter
+    (src/gui/scene.rs:1076-1107) at the native defaults (src/main.rs:935-941)."""
+    from oracle.reference_shader import NATIVE_DATA, apply_template, filter_tagged_lines
+
+    assert apply_template("a\n//%x//%\nb//%y//%c", {"x": "1\n2", "y": ""}) == "a\n1\n2\nbc"
+    text = "keep\nfor (;;) { // !FOR_NUMBER!\nfor (;;) { // !FOR_VARIABLE!\nold // !GLSL100!\nnew // !GLSL300!\nana // !ANAGLYPH!\naa // !ANTIALIASING!\ntp // !CAMERA_TELEPORTATION!"
+    kept = filter_tagged_lines(text, NATIVE_DATA).split("\n")
+    assert kept == ["keep", "", "for (;;) { // !FOR_VARIABLE!", "", "new // !GLSL300!", "", "aa // !ANTIALIASING!", "tp // !CAMERA_TELEPORTATION!"]
+    assert "ana // !ANAGLYPH!" in filter_tagged_lines(text, dict(NATIVE_DATA, disable_anaglyph=False))
+
+
+@needs_text
+def test_assembled_source_is_the_reference_template_with_the_generated_slots(shader_and_oracle):
+    """The unit that is executed: library.glsl verbatim at the top, the generated plane test of scene.rs:912-927 in
+    `scene_intersect`, material defines counted from USER_MATERIAL_OFFSET, no slot marker left."""
+    rs, _ = shader_and_oracle
+    src = rs.source
+    assert "//%" not in src
+    assert "vec3 normalize_normal(vec3 normal, vec3 dir) {" in src and "RayTraceResult ray_tracing(Ray r, float camera_scale) {" in src
+    assert "for (int j = 0; j < _ray_tracing_depth; j++) { // !FOR_VARIABLE!" in src and "!FOR_NUMBER!" not in src
+    first_flat = next(pos for pos, o in enumerate(rs.scene.objects) if o["kind"] == "flat" and not o["portal"])
+    name = rs.scene.matrices[rs.scene.objects[first_flat]["m0"]][0]
+    assert f"normal = -get_normal({name}_mat);\nhit = plane_intersect(r, {name}_mat_inv, get_normal({name}_mat));\n" in src
+    assert f"#define {rs.scene.materials[0]['name']}_M (USER_MATERIAL_OFFSET + 0)" in src
+    assert "vec3 not_found_color = color(0.6, 0.6, 0.6);" in src
+
+
+@needs_text
+def test_artifact_carries_the_text_to_a_box_without_the_reference_tree(tmp_path, monkeypatch):
+    """oracle/_ref/reference_shader.bin (what __graft_entry__.build() writes) gives back exactly the text it was built from."""
+    from oracle import reference_shader as RS
+
+    here = RS.reference_texts()
+    art = RS.build_artifact(out=str(tmp_path / "reference_shader.bin")) if os.path.isdir(RS.REFERENCE_SRC) else RS.ARTIFACT
+    monkeypatch.setattr(RS, "REFERENCE_SRC", str(tmp_path / "nowhere"))
+    monkeypatch.setattr(RS, "ARTIFACT", art)
+    there = RS.reference_texts()
+    assert there["origin"] == art and all(there[n] == here[n] for n in RS.FILES)
+    monkeypatch.setattr(RS, "ARTIFACT", str(tmp_path / "missing.bin"))
+    assert not RS.available()
+    with pytest.raises(FileNotFoundError):
+        RS.reference_texts()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# layer 1: live, function by function
+# ---------------------------------------------------------------------------------------------------------
+LIVE_LANES = 16384
+
+
+@needs_text
+def test_every_function_of_the_reference_text_equals_the_restatement(shader_and_oracle):
+    """library.glsl:19-589 and the scene-independent functions of frag.glsl, interpreted from the reference's text,
+    against `Natives` / `Oracle` on the same 16 384 lanes each: every output leaf, every lane, bit for bit."""
+    from oracle import glsl_values as V
+
+    rs, o = shader_and_oracle
+    table = T.function_table(rs)
+    compared, unrestated = 0, []
+    for name, ptypes, _ret in table:
+        args = T.make_args(name, ptypes, LIVE_LANES, rs._program.structs)
+        want = T.restated(o, name, ptypes, args, LIVE_LANES)
+        if want is None:
+            unrestated.append(name)
+            continue
+        got = T.leaves_array(V.expand(rs.call(name, args, LIVE_LANES), LIVE_LANES), LIVE_LANES)
+        ref = T.leaves_array(V.expand(want, LIVE_LANES), LIVE_LANES)
+        assert got.shape == ref.shape, name
+        bad = (got != ref).any(axis=1)
+        assert not bad.any(), f"{name}({', '.join(ptypes)}): {int(bad.sum())} of {LIVE_LANES} lanes differ from the reference text"
+        compared += 1
+    # what the hand restatement does not have as a function of its own: the depth-map helpers (inlined in
+    # Oracle.sample_depth_gradient, which IS compared) and the float -> RGBA8 packing of the camera-teleport query,
+    # which the product replaces by a float read-back (checked by the framebuffer-route test below)
+    assert set(unrestated) <= {"normalize_depth_value", "depth_gradient_inferno", "shift_right", "shift_left", "mask_last", "extract_bits", "encode_float"}
+    assert compared >= 45
+
+
+@needs_text
+def test_encode_float_round_trips_through_rgba8(shader_and_oracle):
+    """frag.glsl:180-199 + src/main.rs:1397-1399: encode_float -> GL RGBA8 quantisation -> f32::from_le_bytes([b0,b1,b2,b4])
+    gives back the float, which is why reading the position back as floats (the product) changes nothing."""
+    from oracle import glsl_values as V
+    from oracle.portal_oracle import to_rgba8
+
+    rs, _ = shader_and_oracle
+    rng = np.random.default_rng(7)
+    vals = np.concatenate([rng.uniform(-8, 8, 4000), rng.standard_normal(2000) * 1e-3, rng.standard_normal(2000) * 1e3,
+                           [0.0, 1.0, -1.0, np.pi, -np.pi, 1e-6, -1e-6, 1e6, -1e6, 0.5, 2.0, 3.0]]).astype(np.float32)
+    n = len(vals)
+    enc = V.expand(rs.call("encode_float", [vals], n), n)
+    b = to_rgba8(np.stack([np.asarray(c) for c in enc.c], axis=1))  # x, y, z, w = byte4, byte3, byte2, byte1
+    back = (b[:, 0].astype(np.uint32) | (b[:, 1].astype(np.uint32) << 8) | (b[:, 2].astype(np.uint32) << 16) | (b[:, 3].astype(np.uint32) << 24)).view(np.float32)
+    exact = back.view(np.uint32) == vals.view(np.uint32)
+    # the packing goes through exp2(floor(log2(v))): exact for every value here under the builtin contract
+    assert exact.all(), f"{int((~exact).sum())} of {n} values do not survive encode_float"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# layer 2: committed vectors of the reference text, checked without the text
+# ---------------------------------------------------------------------------------------------------------
+def test_restatement_reproduces_the_committed_function_vectors(shader_and_oracle_no_text):
+    from oracle import glsl_values as V
+
+    o, structs, table = shader_and_oracle_no_text
+    store = np.load(os.path.join(T.GOLDEN_DIR, "functions.npz"))
+    n = 1024
+    checked = 0
+    for key in store.files:
+        if key == "text_digest":
+            continue
+        name, sig = key[:-1].split("(", 1)
+        ptypes = tuple(t for t in sig.split(",") if t)
+        args = T.make_args(name, ptypes, n, structs)
+        want = T.restated(o, name, ptypes, args, n)
+        if want is None:
+            continue
+        got = T.leaves_array(V.expand(want, n), n)
+        assert got.shape == store[key].shape and np.array_equal(got, store[key]), f"{key}: the oracle's restatement no longer gives the reference text's values"
+        checked += 1
+    assert checked >= 45
+
+
+@pytest.fixture(scope="module")
+def shader_and_oracle_no_text():
+    """Oracle + the struct table, without touching the reference text (layer 2 must run where the text is absent)."""
+    from oracle.portal_oracle import STRUCTS, Oracle
+
+    o = Oracle(os.path.join(T.ROOT, "scenes", "basics.ron"))
+    o.build(64, 64)
+    structs = dict(STRUCTS)
+    return o, structs, None
+
+
+@pytest.mark.parametrize("case", list(T.FRAME_CASES))
+def test_oracle_reproduces_the_committed_reference_text_frames(case):
+    """`Oracle.render` (hand restatement) == the frame the reference's text produced (committed), float bits and RGBA8."""
+    from oracle.portal_oracle import Oracle
+
+    g = np.load(os.path.join(T.GOLDEN_DIR, case + ".npz"))
+    out = T.render_case(Oracle, case)
+    ok = T.bits_equal(out["rgba32f"], g["rgba32f_bits"].view(np.float32))
+    assert ok.all(), f"{int((~ok).any(axis=2).sum())} pixels differ from the reference-text frame"
+    assert np.array_equal(out["rgba8"], g["rgba8"])
+    assert len(np.unique(g["rgba8"].reshape(-1, 4), axis=0)) > 50  # a picture, not a flat fill
+
+
+def test_reference_text_frames_equal_the_round_one_goldens():
+    """The five golden frames committed in round 1 came from the hand restatement; the reference text gives the same bits."""
+    for case in ("basics_64x64_d4_aa1", "monoportal_96x54_d20_aa1", "triple_portal_96x54_d40_aa1", "portal_in_portal_96x54_d40_aa1", "mobius_monoportal_64x36_d64_aa2"):
+        a = np.load(os.path.join(T.GOLDEN_DIR, case + ".npz"))
+        b = np.load(os.path.join(T.ROOT, "tests", "golden", case + ".npz"))
+        assert np.array_equal(a["rgba32f_bits"], b["rgba32f_bits"]) and np.array_equal(a["rgba8"], b["rgba8"]), case
+
+
+def _unpack(row):
+    pos = None if row[0] == 0 else row[3:6].astype(np.uint32).view(np.float32)
+    return pos, bool(row[1]), bool(row[2])
+
+
+@pytest.mark.parametrize("scene", ["monoportal", "triple_portal", "portal_in_portal"])
+def test_oracle_teleport_query_reproduces_the_reference_text(scene):
+    """a11: `teleport_external_ray` (frag.glsl:209-257).  Committed rows hold the reference text's answer twice: the function's
+    result and the host's decode of the 2x3 RGBA8 target (src/main.rs:1361-1409).  Both == `Oracle.teleport_external_ray`."""
+    from oracle.portal_oracle import Oracle
+
+    rows = np.load(os.path.join(T.GOLDEN_DIR, "teleport.npz"))[scene]
+    o = Oracle(os.path.join(T.ROOT, "scenes", scene + ".ron"))
+    teleported = 0
+    for (a, b), row in zip(T.teleport_segments(scene), rows):
+        pos, hit, sub = o.teleport_external_ray(a, b)
+        for want in (_unpack(row[:6]), _unpack(row[6:])):
+            assert (hit, sub) == want[1:]
+            assert (pos is None) == (want[0] is None)
+            if pos is not None:
+                assert np.array_equal(pos.view(np.uint32), want[0].view(np.uint32))
+        teleported += pos is not None
+    assert teleported >= 2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# layer 1 again: live frames, live teleport queries, the corpus
+# ---------------------------------------------------------------------------------------------------------
+@needs_text
+@pytest.mark.parametrize("case", ["basics_64x64_d4_aa1", "portal_in_portal_96x54_d40_aa1", "portal_in_portal_deep_96x54_d40_aa1", "monoportal_sidebyside_96x54_d20_aa1",
+                                  "monoportal_360_96x54_d20_aa3"])
+def test_live_reference_text_reproduces_its_committed_frames(case):
+    """The fixtures are what the text gives TODAY (a changed reference, interpreter or contract shows up here)."""
+    from oracle.reference_shader import ReferenceShader
+
+    g = np.load(os.path.join(T.GOLDEN_DIR, case + ".npz"))
+    out = T.render_case(ReferenceShader, case)
+    assert T.bits_equal(out["rgba32f"], g["rgba32f_bits"].view(np.float32)).all()
+    assert np.array_equal(out["rgba8"], g["rgba8"])
+
+
+@needs_text
+def test_live_reference_text_on_random_views_equals_the_oracle():
+    """Views no fixture holds: random cameras, a moved scene uniform, aa 2, on the headline scene and on triple_portal."""
+    from oracle.portal_oracle import Oracle
+    from oracle.reference_shader import ReferenceShader
+
+    rng = np.random.default_rng(20260926)
+    for scene, depth in (("portal_in_portal", 40), ("triple_portal", 40), ("monoportal", 20)):
+        for _ in range(2):
+            cam = dict(look_at=tuple(rng.uniform(-0.5, 0.5, 3)), alpha=float(rng.uniform(0, 6.28)), beta=float(rng.uniform(0.4, 2.7)), r=float(rng.uniform(0.8, 4.0)))
+            frames = []
+            for cls in (ReferenceShader, Oracle):
+                o = cls(os.path.join(T.ROOT, "scenes", scene + ".ron"))
+                o.options.update(render_depth=depth, aa_count=2)
+                o.camera = dict(cam)
+                if scene == "portal_in_portal":
+                    o.scene.uniforms[o.scene.find_uniform("progress")][2] = 0.35
+                frames.append(o.render(48, 27)["rgba32f"])
+            assert T.bits_equal(*frames).all(), (scene, cam)
+
+
+@needs_text
+def test_live_teleport_query_function_and_framebuffer_route_agree_with_the_oracle():
+    from oracle.portal_oracle import Oracle
+    from oracle.reference_shader import ReferenceShader
+
+    rs, o = ReferenceShader(os.path.join(T.ROOT, "scenes", "triple_portal.ron")), Oracle(os.path.join(T.ROOT, "scenes", "triple_portal.ron"))
+    rng = np.random.default_rng(11)
+    hits = 0
+    for _ in range(16):
+        a = rng.uniform(-3, 3, 3)
+        b = -a * rng.uniform(0.2, 1.0)
+        want = o.teleport_external_ray(a, b)
+        for got in (rs.teleport_external_ray(a, b), rs.teleport_external_ray_through_framebuffer(a, b)):
+            assert got[1:] == want[1:] and (got[0] is None) == (want[0] is None)
+            if want[0] is not None:
+                assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+        hits += want[0] is not None
+    assert hits >= 2
+
+
+CORPUS = sorted(glob.glob(os.path.join(CORPUS_ROOT, "scenes", "*.ron")))
+
+
+@needs_text
+@pytest.mark.parametrize("chunk", range(4))
+def test_live_reference_text_equals_the_oracle_on_the_scene_corpus(chunk):
+    """All 82 scene files of the reference (Complex objects, subspaces, skybox, DebugMatrix, Trefoil, user materials ...):
+    the generated slots for every object kind + the reference text == the hand restatement, 24x14 frames, depth 8."""
+    from oracle.portal_oracle import Oracle
+    from oracle.reference_shader import ReferenceShader
+
+    files = [f for f in CORPUS if os.path.getsize(f) > 0][chunk::4]
+    assert len(files) >= 20
+    for path in files:
+        frames = []
+        for cls in (ReferenceShader, Oracle):
+            o = cls(path, asset_root=CORPUS_ROOT)
+            o.options.update(render_depth=8)
+            frames.append(o.render(24, 14)["rgba32f"])
+        ok = T.bits_equal(*frames)
+        assert ok.all(), f"{os.path.basename(path)}: {int((~ok).any(axis=2).sum())} of 336 pixels differ"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# layer 3: the HIP kernel against the reference text
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gpu(pa):
+    if pa.device_count() < 1:
+        pytest.fail("no HIP device visible: the render path has no CPU fallback")
+    return pa
+
+
+def _builds(pa):
+    spec = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
+    return {"dynamic": 0, "ints_baked": pa.FLAG_SPECIALIZE_INTS, "baked": spec, "baked_w3": spec | pa.flag_waves(3), "baked_w4": spec | pa.flag_waves(4)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("build", ["dynamic", "ints_baked", "baked", "baked_w3", "baked_w4"])
+@pytest.mark.parametrize("case", list(T.FRAME_CASES))
+def test_gpu_reproduces_the_reference_text_frames(gpu, case, build):
+    """HIP kernel (through the C ABI) == the frame the reference's own shader text produced: float bits and RGBA8,
+    for every build flavour bench.py may time (un-specialised, Int-baked, all-baked, and the occupancy-hinted binaries)."""
+    pa = gpu
+    g = np.load(os.path.join(T.GOLDEN_DIR, case + ".npz"))
+    r, w, h = T.make_product_renderer(pa, case, flags=_builds(pa)[build])
+    out = r.draw(w, h, rgba8=True, rgba32f=True)
+    ok = T.bits_equal(out["rgba32f"], g["rgba32f_bits"].view(np.float32))
+    assert ok.all(), f"{int((~ok).any(axis=2).sum())} of {w * h} pixels differ from the reference-text frame"
+    assert np.array_equal(out["rgba8"], g["rgba8"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["monoportal", "triple_portal", "portal_in_portal"])
+def test_gpu_teleport_query_reproduces_the_reference_text(gpu, scene):
+    pa = gpu
+    rows = np.load(os.path.join(T.GOLDEN_DIR, "teleport.npz"))[scene]
+    r = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path(scene)), device=0)
+    for (a, b), row in zip(T.teleport_segments(scene), rows):
+        pos, hit, sub = r.teleport_external_ray(a, b)
+        want = _unpack(row[6:])  # what the reference's host decodes from its RGBA8 target
+        assert (hit, sub) == want[1:] and (pos is None) == (want[0] is None)
+        if pos is not None:
+            assert np.array_equal(np.asarray(pos, np.float64).astype(np.float32).view(np.uint32), want[0].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_gpu_equals_the_live_reference_text_on_fresh_views(gpu):
+    """Needs the text on the GPU box (oracle/_ref/reference_shader.bin, written by __graft_entry__.build()): random
+    cameras no fixture has seen, the reference text interpreted on the spot == the kernel, dynamic and baked."""
+    from oracle import reference_shader as RS
+
+    if not RS.available():
+        pytest.fail("oracle/_ref/reference_shader.bin did not travel: run __graft_entry__.build() where /root/reference is mounted")
+    pa = gpu
+    rng = np.random.default_rng(31337)
+    for scene, depth in (("portal_in_portal", 40), ("triple_portal", 40), ("basics", 6)):
+        cam = dict(look_at=tuple(rng.uniform(-0.4, 0.4, 3)), alpha=float(rng.uniform(0, 6.28)), beta=float(rng.uniform(0.5, 2.6)), r=float(rng.uniform(1.0, 3.5)))
+        o = RS.ReferenceShader(pa.scene_path(scene))
+        o.options.update(render_depth=depth, aa_count=2)
+        o.camera = dict(cam)
+        want = o.render(64, 36)
+        for flags in (0, pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL):
+            r = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path(scene)), device=0, flags=flags)
+            r.set_option("render_depth", depth)
+            r.set_option("aa_count", 2)
+            r.set_camera(cam["look_at"], cam["alpha"], cam["beta"], cam["r"])
+            out = r.draw(64, 36, rgba8=True, rgba32f=True)
+            assert T.bits_equal(out["rgba32f"], want["rgba32f"]).all(), (scene, flags)
+            assert np.array_equal(out["rgba8"], want["rgba8"])
