@@ -1079,7 +1079,10 @@ class Hoister {
                 items_.push_back(decl);
             }
         }
-        if (half_used_) {  // the rays themselves: the parameters as dummies with the right origin, the locals as declared
+        // The rays themselves: the parameters as dummies with the right origin, the locals as declared.  Not only when a ray
+        // expression was rewritten (half_used_): a plain uniform expression or uniform local may read `r.o` -- or `q.o` of a copy
+        // `Ray q = r;` -- of an origin-uniform ray (Member-on-half is classed uniform), and then the prologue names the ray too.
+        if (half_used_ || (!P.origin_uniform_rays.empty() && items_.size() > first_item)) {
             for (const std::string& p : P.origin_uniform_rays) {
                 PrologueItem param;
                 param.at = body_b;

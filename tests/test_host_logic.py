@@ -1022,3 +1022,46 @@ def test_hoister_does_not_take_a_scene_function_for_a_builtin(pa):
     assert "normalize_normal(dir_u, r.d.xyz)" in own and "ptl_normalize_normal_unit" not in own
     src = pa.Scene.from_file(pa.scene_path("portal_in_portal")).generate_source(0)
     assert "ptl_normalize_normal_unit(" in src and "ptl_is_collinear_len(" in src        # the reference's scenes define neither
+
+
+_SPHERE_SNIPPET = """vec3 rel = r.o.xyz - vec3(0.3, 0.2, 0.1) * _t_start;
+Ray q = r;
+float c = dot(rel, rel) - 0.25 + q.o.x * 0.0;
+float b = dot(rel, r.d.xyz);
+float h = b * b - c;
+SceneIntersectionWithMaterial result = SceneIntersectionWithMaterial(scene_intersection_none, material_empty());
+if (h > 0.) {
+  float t = -b - sqrt(h);
+  if (t > 0.) {
+    result.scene = SceneIntersection(CUSTOM_MATERIAL, SurfaceIntersection(true, t, 0., 0., normalize(rel + r.d.xyz * t)), false);
+    result.material = material_final(color(0.9, 0.4, 0.1));
+  }
+}
+return result;"""
+
+
+def test_first_trip_copy_declares_the_rays_a_plain_uniform_expression_reads(pa):
+    """in the first-trip copy of an intersection-material snippet `r.o` is the prologue's camera origin, so
+    `r.o.xyz - vec3(..) * _t_start` (the head of a canonical sphere test) and `q.o` of a copy `Ray q = r;` are uniform-only and
+    get hoisted -- the prologue must then declare `r` / `q` even though no ray EXPRESSION was rewritten.  The scene has to compile
+    at the default flags and draw the same bits as the general copy."""
+    from oracle import host_build as hb
+
+    text = open(pa.scene_path("basics")).read()
+    assert "intersection_materials: ([])," in text
+    text = text.replace("intersection_materials: ([]),", 'intersection_materials: ([\n        (\n            name: "ball",\n            data: ((("' + _SPHERE_SNIPPET + '"))),\n        ),\n    ]),')
+    frames = {}
+    for label, flags in (("first", 0), ("general", pa.FLAG_NO_FIRST_TRIP), ("first_baked", pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)):
+        scene = pa.Scene.from_text(text)
+        src = scene.generate_source(flags)
+        if label == "first":
+            assert "intersect_material_0_first(Ray r) {" in src
+            derive = src[src.index("PTL_FN void derive(ptl_uniform_block* out)"):src.index("// Material id -> what happens to the path.")]
+            assert "Ray r = Ray(PTL_DV_OUT.ptl_dv_origin" in derive  # the dummy parameter the hoisted `r.o...` expression names
+        r = pa.SceneRenderer(scene, device=-1, flags=flags)  # hiprtc for gfx950: used to fail with "use of undeclared identifier 'r'"
+        assert len(r.code_object()) > 1000
+        r.set_option("render_depth", 6)
+        frames[label] = hb.host_kernel_for(r, scene, 48, 27, flags=flags).render(48, 27)["rgba32f"].copy()
+    assert np.array_equal(frames["first"].view(np.uint32), frames["general"].view(np.uint32))
+    assert np.array_equal(frames["first_baked"].view(np.uint32), frames["general"].view(np.uint32))
+    assert len(np.unique(frames["first"].reshape(-1, 4), axis=0)) > 30
