@@ -194,6 +194,9 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * uniform (normalize(get_normal(X_mat)), both possible is_collinear verdicts) is evaluated once per uniform upload by the
  * module's prologue kernel `ptl_derive_kernel` and read back as extra uniforms -- same operations, identical frames;
  * this bit keeps the reference's per-call form (A/B measurements, tests),
+ * bit14 = EXACT CR (`--exact-cr`): numerics contract 1 of rounds 1-2 -- `/`, 1/x and sqrt IEEE correctly rounded on every input --
+ * instead of contract 2 (device/ptl_glsl.h: 1/x correctly rounded with the extremes flushed, a / b = a * (1/b), sqrt correctly rounded
+ * with |x| < 2^-100 flushed); both are bit-exact against the oracle run with the same contract,
  * bit6 = FAST MATH, the tolerance mode (`--fast`): hardware rcp / sqrt / rsq estimates (1 ulp), a / b = a * rcp(b), FMA
  * contraction, plane tests as t = -o'.z * rcp(d'.z) without normalising the transformed direction, products with a literal zero folded
  * (-fno-signed-zeros -fno-honor-nans: with the scene state baked in, most portal matrices are mostly zeros).  Frames agree with the exact kernel to ~1e-6 per channel except at pixels where the last bit decides a path

@@ -31,32 +31,54 @@ namespace glsl {
 // ---------------------------------------------------------------------------------------
 PTL_FN float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// sqrt(x) and 1/x are IEEE correctly rounded -- on either compiler, for every input.  The host build uses the language's
-// operators.  The gfx950 build reaches the same bits in fewer instructions than the compiler's general-purpose expansions
-// (16 and 11 VALU instructions), branch-free, from the same hardware estimates (v_sqrt_f32 / v_rcp_f32, ~1 ulp):
-//   1/x    : the compiler refines the estimate three times; ONE exact FMA residual step is already correctly rounded on this
-//            hardware.  Range scaling (v_div_scale / v_div_fmas) and the zero / infinity / NaN cases (v_div_fixup) stay: 7.
-//   sqrt(x): the correctly rounded root is the estimate s, s - 1 ulp or s + 1 ulp; the signs of x - s*(s -/+ ulp), each one
-//            FMA, tell which.  With the comparisons ordered as below the special values (+-0, +inf, NaN, negatives) fall
-//            through unchanged, so the compiler's separate class test and select are not needed: 14.
-// "Correctly rounded" here is not an argument but a measurement: both are compared with the compiler's IEEE expansions for ALL
-// 2^32 bit patterns on the GPU (tests/test_gpu_parity.py::test_sqrt_and_reciprocal_are_exact_for_every_input, 6 ms).
-// PTL_PLAIN_SQRT_RCP restores the operators (tools/variants.py measures the difference).
+// ---- division, reciprocal, square root: CONTRACT 2 (round 3, the default) ----------------------------------------------------
+// Every scalar division of the generated kernel is ptl_div(a, b); the scene snippets' `/` and `/=` are rewritten to it by the
+// translator (host/glsl_translate.cpp), the prelude and the template spell it.  The definitions, for every input:
+//   1/x   = the IEEE correctly rounded reciprocal, with the extremes FLUSHED: |x| < 2^-126 (zero or subnormal) gives +-inf,
+//           |x| > 2^126 (the quotient would be subnormal; also +-inf) gives +-0, NaN gives NaN.
+//   a / b = a * (1/b): ONE more rounding (<= 1.5 ulp; GLSL ES 3.00 4.5.1 allows 2.5 for a / b).  int / int is integer division.
+//   sqrt(x) = the IEEE correctly rounded root for x >= 2^-100, +inf and NaN; |x| < 2^-100 (zeros, subnormals, the smallest
+//           normals of either sign) gives +0; other negatives give NaN.
+//   inversesqrt(x) = 1 / sqrt(x), normalize(v) = v * (1 / length(v)), v / s = v * (1/s): as in contract 1.
+// Why: contract 1 (below, `PTL_CONTRACT_V1` / FLAG_EXACT_CR / `--exact-cr`) asked for IEEE results on EVERY input, and on gfx950
+// that costs 26 (1/x), 37 (a/b) and 45 (sqrt) issue cycles per wave -- the range scaling (v_div_scale, v_div_fmas), v_div_fixup
+// and compare / select pairs are 4-cycle instructions -- ~40 % of the headline kernel's VALU cycles.  Portability pins the
+// MIDDLE of the range to correct rounding (a result computed from a ~1 ulp hardware estimate is seed-independent only if it is
+// the correctly rounded one), and there two exact FMA steps suffice; what the long forms bought was the extremes.  Contract 2
+// says what the SHORT forms do at the extremes -- the transcendental unit flushes subnormals, so they come out as the flushes
+// above -- in words numpy can restate (oracle/glsl_math.py: `rcp`, `sqrt`) and the host build spells with the language's own
+// operators (below).  Measured (tools/contract_probe.py, profiles/r03/contract_probe.jsonl): 18 / 18 / 31 cycles.
+// Not an argument but a measurement: tests/test_gpu_parity.py::test_sqrt_and_reciprocal_match_the_contract_for_every_input runs
+// ALL 2^32 bit patterns through both definitions on the GPU (the device sequences against the operator forms).
+PTL_FN float ptl_rcp_model(float x) {   // the definition in the language's own operators (host build; constant folding on the GPU)
+    const float m = __builtin_fabsf(x);
+    if (m < 0x1p-126f) return __builtin_copysignf(__builtin_inff(), x);
+    if (m > 0x1p+126f) return __builtin_copysignf(0.0f, x);
+    return 1.0f / x;
+}
+PTL_FN float ptl_sqrt_model(float x) {
+    if (__builtin_fabsf(x) < 0x1p-100f) return 0.0f;
+    return __builtin_sqrtf(x);
+}
 #if defined(PTL_PLAIN_SQRT_RCP)
 #define PTL_PLAIN_SQRT 1
 #define PTL_PLAIN_RCP 1
 #endif
 // PTL_FAST_MATH (FLAG_FAST_MATH, `--fast`): the TOLERANCE mode.  What a GL driver does with the reference's shader: the
 // hardware estimates themselves (v_sqrt_f32 / v_rcp_f32 / v_rsq_f32, 1 ulp), a / b = a * rcp(b) and FMA contraction (the JIT
-// passes -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt).  Not part of the bit-exact contract: frames differ
-// from the exact kernel in the last bits, and a pixel on an edge can take another path (tests measure how many, vs 1e-5).
+// passes -ffp-contract=fast).  Not part of the bit-exact contract: frames differ from the exact kernel in the last bits, and a
+// pixel on an edge can take another path (tests measure how many, vs 1e-5).
 #if PTL_DEVICE_BUILD && defined(PTL_FAST_MATH)
 PTL_FN float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 PTL_FN float ptl_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-#define PTL_HAVE_SQRT_RCP 1
-#endif
-#if defined(PTL_HAVE_SQRT_RCP)
-#elif PTL_DEVICE_BUILD && !defined(PTL_PLAIN_SQRT)
+#elif defined(PTL_CONTRACT_V1)
+// ---- contract 1 (rounds 1-2): IEEE correctly rounded for every input -------------------------------------------------------
+//   1/x    : the compiler refines the estimate three times; ONE exact FMA residual step is already correctly rounded on this
+//            hardware.  Range scaling (v_div_scale / v_div_fmas) and the zero / infinity / NaN cases (v_div_fixup) stay: 7.
+//   sqrt(x): the correctly rounded root is the estimate s, s - 1 ulp or s + 1 ulp; the signs of x - s*(s -/+ ulp), each one
+//            FMA, tell which.  With the comparisons ordered as below the special values (+-0, +inf, NaN, negatives) fall
+//            through unchanged, so the compiler's separate class test and select are not needed: 14.
+#if PTL_DEVICE_BUILD && !defined(PTL_PLAIN_SQRT)
 PTL_FN float sqrt(float x) {
     const bool tiny = x < 0x1p-96f;                // below, the residuals would underflow: work on x * 2^32, give back s * 2^-16
     const float xs = tiny ? x * 0x1p+32f : x;
@@ -71,8 +93,7 @@ PTL_FN float sqrt(float x) {
 #else
 PTL_FN float sqrt(float x) { return __builtin_sqrtf(x); }
 #endif
-#if defined(PTL_HAVE_SQRT_RCP)
-#elif PTL_DEVICE_BUILD && !defined(PTL_PLAIN_RCP)
+#if PTL_DEVICE_BUILD && !defined(PTL_PLAIN_RCP)
 PTL_FN float ptl_rcp(float x) {
     bool unused, rescale;
     const float d = __builtin_amdgcn_div_scalef(1.0f, x, false, &unused);  // x, or x * 2^+-64 when 1/x needs the room
@@ -85,6 +106,45 @@ PTL_FN float ptl_rcp(float x) {
 #else
 PTL_FN float ptl_rcp(float x) { return 1.0f / x; }
 #endif
+#elif PTL_DEVICE_BUILD && !defined(PTL_PLAIN_SQRT)
+// ---- contract 2 on gfx950 -----------------------------------------------------------------------------------------------------
+//   1/x    : y0 = v_rcp_f32(x) (1 ulp; +-inf for zeros AND subnormals, +-0 for |x| > 2^126 AND infinities); one exact residual
+//            e = 1 - x*y0 and y = y0 + y0*e is the correctly rounded reciprocal wherever y0 is a normal number.  At the flushed
+//            ends the residual is 1 (y stays +-0) or not a number (y is NaN: the estimate itself is the answer).  5 instructions.
+//   sqrt(x): g = v_sqrt_f32 (1 ulp), h = v_rsq_f32 / 2; d = x - g*g is exact above 2^-103 (a multiple of ulp(g)^2) and
+//            s = g + d*h rounds correctly (Markstein).  Inputs below 2^-100 are flushed to +0 first (a select on |x|, so negative
+//            numbers of ordinary size still give NaN); +0 and +inf make the correction NaN and keep the estimate (0, inf).
+PTL_FN float ptl_rcp(float x) {
+    if (__builtin_constant_p(x)) return ptl_rcp_model(x);  // after JIT specialisation: the compiler folds the operator form
+    const float y0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, y0, 1.0f);
+    const float y = __builtin_fmaf(y0, e, y0);
+    return y == y ? y : y0;
+}
+PTL_FN float sqrt(float x) {
+    if (__builtin_constant_p(x)) return ptl_sqrt_model(x);
+    const float xe = __builtin_fabsf(x) < 0x1p-100f ? 0.0f : x;
+    const float g = __builtin_amdgcn_sqrtf(xe);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(xe);
+    const float d = __builtin_fmaf(-g, g, xe);
+    const float s = __builtin_fmaf(d, h, g);
+    return s == s ? s : g;
+}
+#else
+PTL_FN float ptl_rcp(float x) { return ptl_rcp_model(x); }
+PTL_FN float sqrt(float x) { return ptl_sqrt_model(x); }
+#endif
+// a / b.  Overloads, not a template: `int / int` has to stay an integer division, and a call with an int and a float operand
+// (which desktop GLSL accepts) must not fall back to the language's own division.
+#if defined(PTL_CONTRACT_V1) && !(PTL_DEVICE_BUILD && defined(PTL_FAST_MATH))
+PTL_FN float ptl_div(float a, float b) { return a / b; }
+#else
+PTL_FN float ptl_div(float a, float b) { return a * ptl_rcp(b); }
+#endif
+PTL_FN float ptl_div(float a, int b) { return ptl_div(a, (float)b); }
+PTL_FN float ptl_div(int a, float b) { return ptl_div((float)a, b); }
+PTL_FN int ptl_div(int a, int b) { return a / b; }
+PTL_FN unsigned ptl_div(unsigned a, unsigned b) { return a / b; }
 PTL_FN float abs(float x) { return __builtin_fabsf(x); }
 PTL_FN int abs(int x) { return x < 0 ? -x : x; }
 PTL_FN float floor(float x) { return __builtin_floorf(x); }
@@ -98,7 +158,7 @@ PTL_FN float inversesqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 PTL_FN float inversesqrt(float x) { return ptl_rcp(sqrt(x)); }
 #endif
 PTL_FN float fract(float x) { return x - floor(x); }
-PTL_FN float mod(float x, float y) { return x - y * floor(x / y); }
+PTL_FN float mod(float x, float y) { return x - y * floor(ptl_div(x, y)); }
 PTL_FN float min(float a, float b) { return b < a ? b : a; }
 PTL_FN float max(float a, float b) { return a < b ? b : a; }
 PTL_FN int min(int a, int b) { return b < a ? b : a; }
@@ -109,7 +169,7 @@ PTL_FN float sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
 PTL_FN float step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
 PTL_FN float mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 PTL_FN float smoothstep(float e0, float e1, float x) {
-    float t = clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    float t = clamp(ptl_div(x - e0, e1 - e0), 0.0f, 1.0f);
     return t * t * (3.0f - 2.0f * t);
 }
 PTL_FN float radians(float d) { return d * 0x1.1df46ap-6f; }
@@ -161,7 +221,7 @@ PTL_FN float cos(float x) {
     float v = (q == 1.0f || q == 3.0f) ? k.s : k.c;
     return (q == 1.0f || q == 2.0f) ? -v : v;
 }
-PTL_FN float tan(float x) { return sin(x) / cos(x); }
+PTL_FN float tan(float x) { return ptl_div(sin(x), cos(x)); }
 
 // ---------------------------------------------------------------------------------------
 // atan / atan2 (Cephes atanf): reduce to [0, tan(pi/8)], degree-9 odd kernel.
@@ -174,7 +234,7 @@ PTL_FN float atan(float x0) {
         x = -ptl_rcp(x);
     } else if (x > 0.4142135623730950f) {
         y = 0x1.921fb6p-1f;
-        x = (x - 1.0f) / (x + 1.0f);
+        x = ptl_div(x - 1.0f, x + 1.0f);
     }
     float z = x * x;
     float p = fma(z, 8.05374449538e-2f, -1.38776856032e-1f);
@@ -189,7 +249,7 @@ PTL_FN float atan(float y, float x) {
     }
     float w = 0.0f;
     if (x < 0.0f) w = y < 0.0f ? -0x1.921fb6p+1f : 0x1.921fb6p+1f;
-    return w + atan(y / x);
+    return w + atan(ptl_div(y, x));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -457,15 +517,19 @@ PTL_VEC_BINOP(*)
 #undef PTL_VEC_BINOP
 // division: vec/vec and float/vec are true component divisions; vec/float multiplies by
 // the correctly-rounded reciprocal (contract, see header comment).
-PTL_FN vec2 operator/(const vec2& a, const vec2& b) { return vec2(a.x / b.x, a.y / b.y); }
-PTL_FN vec3 operator/(const vec3& a, const vec3& b) { return vec3(a.x / b.x, a.y / b.y, a.z / b.z); }
-PTL_FN vec4 operator/(const vec4& a, const vec4& b) { return vec4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
-PTL_FN vec2 operator/(float a, const vec2& b) { return vec2(a / b.x, a / b.y); }
-PTL_FN vec3 operator/(float a, const vec3& b) { return vec3(a / b.x, a / b.y, a / b.z); }
-PTL_FN vec4 operator/(float a, const vec4& b) { return vec4(a / b.x, a / b.y, a / b.z, a / b.w); }
+PTL_FN vec2 operator/(const vec2& a, const vec2& b) { return vec2(ptl_div(a.x, b.x), ptl_div(a.y, b.y)); }
+PTL_FN vec3 operator/(const vec3& a, const vec3& b) { return vec3(ptl_div(a.x, b.x), ptl_div(a.y, b.y), ptl_div(a.z, b.z)); }
+PTL_FN vec4 operator/(const vec4& a, const vec4& b) { return vec4(ptl_div(a.x, b.x), ptl_div(a.y, b.y), ptl_div(a.z, b.z), ptl_div(a.w, b.w)); }
+PTL_FN vec2 operator/(float a, const vec2& b) { return vec2(ptl_div(a, b.x), ptl_div(a, b.y)); }
+PTL_FN vec3 operator/(float a, const vec3& b) { return vec3(ptl_div(a, b.x), ptl_div(a, b.y), ptl_div(a, b.z)); }
+PTL_FN vec4 operator/(float a, const vec4& b) { return vec4(ptl_div(a, b.x), ptl_div(a, b.y), ptl_div(a, b.z), ptl_div(a, b.w)); }
 PTL_FN vec2 operator/(const vec2& a, float b) { float i = ptl_rcp(b); return vec2(a.x * i, a.y * i); }
 PTL_FN vec3 operator/(const vec3& a, float b) { float i = ptl_rcp(b); return vec3(a.x * i, a.y * i, a.z * i); }
 PTL_FN vec4 operator/(const vec4& a, float b) { float i = ptl_rcp(b); return vec4(a.x * i, a.y * i, a.z * i, a.w * i); }
+
+// what the translator turns `a / b` and `a /= b` of a scene snippet into when an operand is not a scalar
+template <class A, class B> PTL_FN auto ptl_div(const A& a, const B& b) -> decltype(a / b) { return a / b; }
+template <class A, class B> PTL_FN void ptl_div_assign(A& a, const B& b) { a = ptl_div(a, b); }
 
 PTL_FN vec2 operator-(const vec2& a) { return vec2(-a.x, -a.y); }
 PTL_FN vec3 operator-(const vec3& a) { return vec3(-a.x, -a.y, -a.z); }
@@ -704,7 +768,7 @@ PTL_FN vec4 ptl_texel(const sampler2D& s, int ix, int iy) {
     ix = clamp(ix, 0, s.width - 1);
     iy = clamp(iy, 0, s.height - 1);
     const unsigned char* p = s.texels + 4 * ((long)iy * s.width + ix);
-    return vec4((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f);
+    return vec4(ptl_div((float)p[0], 255.0f), ptl_div((float)p[1], 255.0f), ptl_div((float)p[2], 255.0f), ptl_div((float)p[3], 255.0f));
 }
 PTL_FN vec4 texture(const sampler2D& s, const vec2& uv) {
     if (s.texels == nullptr || s.width <= 0 || s.height <= 0) return vec4(0.0f, 0.0f, 0.0f, 1.0f);

@@ -13,7 +13,7 @@
 namespace glsl {
 
 #define PI acos(-1.0f)            /* src/library.glsl:15 */
-#define PI2 (acos(-1.0f) / 2.0f)  /* src/library.glsl:16 */
+#define PI2 ptl_div(acos(-1.0f), 2.0f)  /* src/library.glsl:16 */
 
 // src/library.glsl:19-34
 PTL_FN bool between(float a, float x, float b) { return a <= x && x <= b; }
@@ -44,12 +44,12 @@ PTL_FN vec3 normalize_normal(vec3 normal, vec3 dir) {
 
 // library.glsl:65-67
 PTL_FN bool is_collinear(vec3 a, vec3 b) {
-    return abs(dot(a, b) / (length(a) * length(b)) - 1.0f) < 0.01f;
+    return abs(ptl_div(dot(a, b), length(a) * length(b)) - 1.0f) < 0.01f;
 }
 
 // library.glsl:70-72
 PTL_FN vec3 my_reflect(vec3 dir, vec3 normal) {
-    return dir - normal * dot(dir, normal) / dot(normal, normal) * 2.0f;
+    return dir - normal * dot(dir, normal) / dot(normal, normal) * 2.0f;  // vec3 / float: multiplies by 1 / dot(normal, normal)
 }
 
 // library.glsl:75-92
@@ -91,7 +91,7 @@ PTL_FN vec3 get_normal(const mat4& matrix) { return (matrix * vec4(0.0f, 0.0f, 1
 PTL_FN Ray normalize_ray(Ray r) {
     float len = length(r.d);
     r.d /= len;
-    r.tmul /= len;
+    r.tmul = ptl_div(r.tmul, len);
     return r;
 }
 PTL_FN mat3 adjugate(const mat4& m) {
@@ -110,7 +110,7 @@ PTL_FN SurfaceIntersection ptl_intersection_none() { return SurfaceIntersection{
 #define intersection_none (ptl_intersection_none())
 
 PTL_FN SurfaceIntersection plane_intersect_normalized(const Ray& r) {
-    float t = -r.o.z / r.d.z;
+    float t = ptl_div(-r.o.z, r.d.z);
     if (t < 0.0f) return intersection_none;
     vec4 pos = r.o + r.d * t;
     return SurfaceIntersection{true, t, pos.x, pos.y, vec3(0.0f, 0.0f, 1.0f)};
@@ -137,7 +137,7 @@ PTL_FN SurfaceIntersection plane_intersect(Ray r, const mat4& plane_inv, vec3 no
     r.d = normalize(r.d);
     SurfaceIntersection result = plane_intersect_normalized(r);
     if (result.hit) {
-        result.t /= len;
+        result.t = ptl_div(result.t, len);
         result.n = normal;
     }
     return result;
@@ -187,7 +187,7 @@ PTL_FN SurfaceIntersection plane_intersect_derived(Ray r, const mat4& plane_inv,
     r.d = normalize(r.d);
     SurfaceIntersection result = plane_intersect_normalized(r);
     if (result.hit) {
-        result.t /= len;
+        result.t = ptl_div(result.t, len);
         result.n = unit_normal;
     }
     return result;
@@ -209,10 +209,10 @@ PTL_FN Ray ptl_ray_o(Ray r, vec4 origin) {  // r with its origin taken from the 
     return r;
 }
 PTL_FN bool ptl_is_collinear_len(vec3 a, vec3 b, float length_b) {  // is_collinear(a, b) given length(b)
-    return abs(dot(a, b) / (length(a) * length_b) - 1.0f) < 0.01f;
+    return abs(ptl_div(dot(a, b), length(a) * length_b) - 1.0f) < 0.01f;
 }
 PTL_FN bool ptl_is_collinear_len0(vec3 a, vec3 b, float length_a) {  // is_collinear(a, b) given length(a)
-    return abs(dot(a, b) / (length_a * length(b)) - 1.0f) < 0.01f;
+    return abs(ptl_div(dot(a, b), length_a * length(b)) - 1.0f) < 0.01f;
 }
 
 // --- colours ------------------------------------------------------- library.glsl:169-288
@@ -336,7 +336,7 @@ PTL_FN bool nearer(const SceneIntersection& result, const SceneIntersection& cur
 PTL_FN vec3 cap_normal(vec3 pos, vec3 a, vec3 b, float radius) {
     vec3 ba = b - a;
     vec3 pa = pos - a;
-    float h = clamp(dot(pa, ba) / dot(ba, ba), 0.0f, 1.0f);
+    float h = clamp(ptl_div(dot(pa, ba), dot(ba, ba)), 0.0f, 1.0f);
     return (pa - h * ba) / radius;
 }
 PTL_FN SurfaceIntersection cap(Ray r, vec3 pa, vec3 pb, float radius) {
@@ -354,7 +354,7 @@ PTL_FN SurfaceIntersection cap(Ray r, vec3 pa, vec3 pb, float radius) {
     float c = baba * oaoa - baoa * baoa - radius * radius * baba;
     float h = b * b - a * c;
     if (h >= 0.0f) {
-        float t = (-b - sqrt(h)) / a;
+        float t = ptl_div(-b - sqrt(h), a);
         float y = baoa + t * bard;
         if (y > 0.0f && y < baba) {  // body
             vec3 pos = ro + rd * t;
@@ -386,10 +386,10 @@ PTL_FN SurfaceIntersection cylinder(Ray r, vec3 pa, vec3 pb, float ra) {
     float h = k1 * k1 - k2 * k0;
     if (h < 0.0f) return intersection_none;
     h = sqrt(h);
-    float t = (-k1 - h) / k2;  // near side
+    float t = ptl_div(-k1 - h, k2);  // near side
     float y = baoc + t * bard;
     if (y > 0.0f && y < baba) return SurfaceIntersection{true, t, 0.0f, 0.0f, (oc + t * rd - ba * y / baba) / ra};
-    t = (-k1 + h) / k2;  // far side
+    t = ptl_div(-k1 + h, k2);  // far side
     y = baoc + t * bard;
     if (y > 0.0f && y < baba) return SurfaceIntersection{true, t, 0.0f, 0.0f, (oc + t * rd - ba * y / baba) / ra};
     return intersection_none;

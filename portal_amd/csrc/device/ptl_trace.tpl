@@ -125,7 +125,7 @@ PTL_FN void derive(ptl_uniform_block* out) {
     out->ptl_dv_origin = _camera * vec4(0.0f, 0.0f, 0.0f, 1.0f);
     out->ptl_dv_origin_left = _camera_left_eye * vec4(0.0f, 0.0f, 0.0f, 1.0f);
     out->ptl_dv_origin_right = _camera_right_eye * vec4(0.0f, 0.0f, 0.0f, 1.0f);
-    out->ptl_dv_tan_half_view = tan(_view_angle / 2.0f);
+    out->ptl_dv_tan_half_view = tan(ptl_div(_view_angle, 2.0f));
     out->ptl_dv_pixel_size = ptl_rcp(min(_resolution.x, _resolution.y));
     out->ptl_dv_half_resolution = _resolution / 2.0f;
 #endif
@@ -188,7 +188,7 @@ struct RayTraceResult {
 PTL_FN float normalize_depth_value(float depth) {  // frag.glsl:80-84
     float depth_min = min(_depth_map_min, _depth_map_max);
     float depth_max = max(_depth_map_min, _depth_map_max);
-    return clamp((depth - depth_min) / max(1e-6f, depth_max - depth_min), 0.0f, 1.0f);
+    return clamp(ptl_div(depth - depth_min, max(1e-6f, depth_max - depth_min)), 0.0f, 1.0f);
 }
 
 PTL_FN vec3 depth_gradient_inferno(float t) {  // frag.glsl:86-99
@@ -198,11 +198,11 @@ PTL_FN vec3 depth_gradient_inferno(float t) {  // frag.glsl:86-99
     vec3 c3 = sqrvec(vec3(0.865006f, 0.316822f, 0.226055f));
     vec3 c4 = sqrvec(vec3(0.987622f, 0.645320f, 0.039886f));
     vec3 c5 = sqrvec(vec3(0.988362f, 0.998364f, 0.644924f));
-    if (t < 0.2f) return mix(c0, c1, t / 0.2f);
-    if (t < 0.4f) return mix(c1, c2, (t - 0.2f) / 0.2f);
-    if (t < 0.6f) return mix(c2, c3, (t - 0.4f) / 0.2f);
-    if (t < 0.8f) return mix(c3, c4, (t - 0.6f) / 0.2f);
-    return mix(c4, c5, (t - 0.8f) / 0.2f);
+    if (t < 0.2f) return mix(c0, c1, ptl_div(t, 0.2f));
+    if (t < 0.4f) return mix(c1, c2, ptl_div(t - 0.2f, 0.2f));
+    if (t < 0.6f) return mix(c2, c3, ptl_div(t - 0.4f, 0.2f));
+    if (t < 0.8f) return mix(c3, c4, ptl_div(t - 0.6f, 0.2f));
+    return mix(c4, c5, ptl_div(t - 0.8f, 0.2f));
 }
 
 PTL_FN vec3 sample_depth_gradient(float depth) {  // frag.glsl:101-104
@@ -250,10 +250,10 @@ PTL_FN bool trace_segment(Ray& r, vec3& current_color, float& all_t, float camer
     }
     current_color *= m.mul_to_color;
     if (m.is_final) {
-        float depth = all_t / max(camera_scale, 1e-6f);
+        float depth = ptl_div(all_t, max(camera_scale, 1e-6f));
         if (all_t > _t_start * camera_scale && _darken_by_distance == 1) {  // fade to black with distance
             if (all_t > _t_end * camera_scale) all_t = _t_end * camera_scale;
-            float gray_t = (all_t - _t_start * camera_scale) / (_t_end - _t_start) / camera_scale;
+            float gray_t = ptl_div(ptl_div(all_t - _t_start * camera_scale, _t_end - _t_start), camera_scale);
             out = RayTraceResult{color(0.0f, 0.0f, 0.0f) * sqr(sqr(gray_t)) + current_color * sqr(sqr(1.0f - gray_t)), depth, true};
             return true;
         }
@@ -391,20 +391,20 @@ PTL_FN vec3 PaniniProjection(vec2 tc, float fov, float d) {
     float d2 = d * d;
     {
         float fo = Pi05 - fov * 0.5f;
-        float f = cos(fo) / sin(fo);
+        float f = ptl_div(cos(fo), sin(fo));
         float f2 = f * f;
-        float b = (sqrt(max(0.0f, Pow2(d + d2) * (f2 + f2 * f2))) - (d * f + f)) / (d2 + d2 * f2 - 1.0f);
+        float b = ptl_div(sqrt(max(0.0f, Pow2(d + d2) * (f2 + f2 * f2))) - (d * f + f), d2 + d2 * f2 - 1.0f);
         tc *= b;
     }
     float h = tc.x;
     float v = tc.y;
     float h2 = h * h;
-    float k = h2 / Pow2(d + 1.0f);
+    float k = ptl_div(h2, Pow2(d + 1.0f));
     float k2 = k * k;
     float discr = max(0.0f, k2 * d2 - (k + 1.0f) * (k * d2 - 1.0f));
-    float cosPhi = (-k * d + sqrt(discr)) / (k + 1.0f);
-    float S = (d + 1.0f) / (d + cosPhi);
-    float tanTheta = v / S;
+    float cosPhi = ptl_div(-k * d + sqrt(discr), k + 1.0f);
+    float S = ptl_div(d + 1.0f, d + cosPhi);
+    float tanTheta = ptl_div(v, S);
     float sinPhi = sqrt(max(0.0f, 1.0f - Pow2(cosPhi)));
     if (tc.x < 0.0f) sinPhi *= -1.0f;
     float s = inversesqrt(1.0f + Pow2(tanTheta));
@@ -470,8 +470,8 @@ PTL_FN vec3 get_color2(vec2 image_position, const mat4& camera_matrix, bool in_s
         d = normalize(camera_times(camera_matrix, which_eye, vec4(PaniniProjection(vec2(image_position.x, image_position.y), _view_angle, _panini_param), 0.0f)));
     } else if (_use_360_camera == 1) {  // equirectangular, 2:1, black bars outside
         float coef = min(resolution.x, resolution.y);
-        float ax = resolution.x / coef;
-        float ay = resolution.y / coef;
+        float ax = ptl_div(resolution.x, coef);
+        float ay = ptl_div(resolution.y, coef);
         float rx;
         float ry;
         if (ax >= 2.0f * ay) {
@@ -479,11 +479,11 @@ PTL_FN vec3 get_color2(vec2 image_position, const mat4& camera_matrix, bool in_s
             rx = 2.0f * ay;
         } else {
             rx = ax;
-            ry = ax / 2.0f;
+            ry = ptl_div(ax, 2.0f);
         }
         if (abs(image_position.x) > rx || abs(image_position.y) > ry) return vec3(0.0f);
-        float yaw = (image_position.x / rx) * Pi;
-        float pitch = (image_position.y / ry) * Pi05;
+        float yaw = ptl_div(image_position.x, rx) * Pi;
+        float pitch = ptl_div(image_position.y, ry) * Pi05;
         vec3 dir_local = vec3(sin(yaw) * cos(pitch), sin(pitch), cos(yaw) * cos(pitch));
         d = normalize(camera_times(camera_matrix, which_eye, vec4(dir_local, 0.0f)));
     } else if (_use_180_camera == 1) {  // VR180 front hemisphere
@@ -496,7 +496,7 @@ PTL_FN vec3 get_color2(vec2 image_position, const mat4& camera_matrix, bool in_s
 #ifdef PTL_DERIVED_BUILTINS
         float h = PTL_U.ptl_dv_tan_half_view;
 #else
-        float h = tan(_view_angle / 2.0f);
+        float h = tan(ptl_div(_view_angle, 2.0f));
 #endif
         d = normalize(camera_times(camera_matrix, which_eye, vec4(image_position.x * h, image_position.y * h, 1.0f, 0.0f)));
     }
@@ -526,11 +526,11 @@ PTL_FN vec3 anaglyphCombineLinear(vec3 leftLin, vec3 rightLin, int mode) {
     float l = dot(leftLin, LUMA);
     float r = dot(rightLin, LUMA);
     float denom = max(1e-6f, 1.0f - P * Q);
-    float Rout = (l - P * r) / denom;
-    float Cout = (r - Q * l) / denom;
+    float Rout = ptl_div(l - P * r, denom);
+    float Cout = ptl_div(r - Q * l, denom);
     if (mode == 0) return clamp(vec3(Rout, Cout, Cout), 0.0f, 1.0f);
     float sumGB = rightLin.g + rightLin.b;
-    float k = (sumGB > 1e-6f) ? (2.0f * Cout / sumGB) : 0.0f;
+    float k = (sumGB > 1e-6f) ? ptl_div(2.0f * Cout, sumGB) : 0.0f;
     return clamp(vec3(Rout, rightLin.g * k, rightLin.b * k), 0.0f, 1.0f);
 }
 #endif
@@ -553,7 +553,7 @@ PTL_FN vec3 get_color(vec2 image_position) {
     if (_draw_side_by_side == 1) {
         float coef = min(_resolution.x, _resolution.y);
         vec2 position = image_position / 2.0f * coef + _resolution / 2.0f;
-        vec2 resolution = vec2(_resolution.x / 2.0f, _resolution.y);
+        vec2 resolution = vec2(ptl_div(_resolution.x, 2.0f), _resolution.y);
         float coef2 = min(resolution.x, resolution.y);
         if (position.x < resolution.x) {
             image_position = (position - resolution / 2.0f) / coef2 * 2.0f;

@@ -34,7 +34,7 @@ void usage() {
                  "usage: portal-amd render-frame <scene.ron> [--stage NAME | --animation NAME] [--camera NAME] [--time T] [--output out.png]\n"
                  "                  [--width W] [--height H] [--aa-count N] [--render-depth D] [--device I] [--asset-root DIR] [--panini D --fov DEG]\n"
                  "                  [--gpus N | --devices a,b,..] [--transport stores|copy] [--multi-process]   one frame across the GPUs of a node\n"
-                 "                  [--specialize 0] do NOT bake the scene state into the kernel   [--fast] tolerance mode   [--timing] where the wall time went\n"
+                 "                  [--specialize 0] do NOT bake the scene state into the kernel   [--fast] tolerance mode   [--exact-cr] numerics contract 1   [--timing] where the wall time went\n"
                  "       portal-amd precompile <scene.ron> [--stage NAME] [--specialize 0]      fill the code-object cache (no GPU needed)\n"
                  "       portal-amd render <scene[,scene..]> [clip[,clip..]] [--width 3840] [--height 2160] [--fps 60] [--motion-blur-frames 1]\n"
                  "                  [--stereoimage] [--no-skip-existing] [--filter-starts-with P] [--aa-count 4] [--render-depth 150]\n"
@@ -189,7 +189,7 @@ struct Options {
     // render-frame across GPUs: --gpus N (devices 0..N-1) or --devices a,b,.. ; --transport stores|copy ; --multi-process
     int gpus = 1, rank = 0, world = 1;
     std::string devices, transport = "stores", ipc_handle;
-    bool multi_process = false, fast = false;
+    bool multi_process = false, fast = false, exact_cr = false;
     std::vector<std::string> argv;  // the command line as given (handed on to shard processes)
 };
 
@@ -262,6 +262,7 @@ unsigned frame_flags(const Options& o) {
     // scene uniform a run-time value (profiles/r02/render_frame_e2e.log).
     if (o.specialize != 0) f |= 1u | 4u;
     if (o.fast) f |= 64u;                // --fast: tolerance mode (PTL_FLAG_FAST_MATH)
+    if (o.exact_cr) f |= 16384u;         // --exact-cr: numerics contract 1 (PTL_FLAG_EXACT_CR)
     return f;
 }
 
@@ -464,7 +465,7 @@ int precompile(const Options& o) {
     if (!o.stage.empty() && ptl_scene_init_stage(scene, o.stage.c_str(), stage_cam, sizeof stage_cam) != PTL_OK) return fail("stage");
     std::vector<char> log(1 << 16);
     std::vector<unsigned> variants = {frame_flags(o)};
-    if (o.specialize != 0) variants.push_back(kRenderFlags | (o.fast ? 64u : 0u));  // + the dynamic-uniform kernel `render` starts clips with
+    if (o.specialize != 0) variants.push_back(kRenderFlags | (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u));  // + the dynamic-uniform kernel `render` starts clips with
     for (unsigned flags : variants) {
         auto t1 = std::chrono::steady_clock::now();
         ptl_renderer* r = nullptr;
@@ -699,7 +700,7 @@ int render(const Options& o) {
         }
         std::vector<char> log(1 << 16);
         ptl_renderer* r = nullptr;
-        if (ptl_renderer_create(scene, o.device, o.asset_root.c_str(), kRenderFlags | (o.fast ? 64u : 0u), &r, log.data(), log.size()) != PTL_OK) {  // --fast: tolerance mode for the whole clip
+        if (ptl_renderer_create(scene, o.device, o.asset_root.c_str(), kRenderFlags | (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u), &r, log.data(), log.size()) != PTL_OK) {  // --fast: tolerance mode for the whole clip
             std::fprintf(stderr, "renderer: %s\n%s\n", ptl_last_error(), log.data());
             return 1;
         }
@@ -765,7 +766,7 @@ int render(const Options& o) {
             int n_workers = (int)std::min<size_t>({(size_t)6, todo.size() - 1, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)});
             pf.next = 1;  // the first clip is compiled by the main thread right away
             for (int wk = 0; wk < n_workers; ++wk)
-                pf.workers.emplace_back([&pf, &todo, &specialise, path, asset_root = o.asset_root, extra_flags = o.fast ? 64u : 0u] {
+                pf.workers.emplace_back([&pf, &todo, &specialise, path, asset_root = o.asset_root, extra_flags = (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u)] {
                     for (;;) {
                         size_t k;
                         {
@@ -975,6 +976,7 @@ int main(int argc, char** argv) {
         else if (a == "--transport") o.transport = next();
         else if (a == "--multi-process") o.multi_process = true;
         else if (a == "--fast") o.fast = true;
+        else if (a == "--exact-cr") o.exact_cr = true;
         else if (a == "--rank") o.rank = std::atoi(next());
         else if (a == "--world") o.world = std::atoi(next());
         else if (a == "--ipc-handle") o.ipc_handle = next();

@@ -632,7 +632,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             if (o.kind == Object::DebugMatrix) {
                 const std::string& m = matrix_name(scene, o.m0, o);
                 transformed(inverse_name(m));
-                s.add_string("ihit = debug_intersect(transformed_ray);\nihit.hit.t /= len;\n");
+                s.add_string("ihit = debug_intersect(transformed_ray);\nihit.hit.t = ptl_div(ihit.hit.t, len);\n");
                 // quirk kept from the reference: the normal uses adjugate of the *inverse* matrix here
                 s.add_string("if (nearer(i, ihit)) { i = ihit; i.hit.n = normalize(adjugate(" + inverse_name(m) + ") * i.hit.n); }\n\n");
             } else if (o.kind == Object::Flat) {
@@ -685,12 +685,12 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 if (!o.portal) {
                     const std::string& m = matrix_name(scene, o.m0, o);
                     transformed(inverse_name(m));
-                    s.add_string("ihit = intersect_" + p + "(transformed_ray);\nihit.hit.t /= len;\n");
+                    s.add_string("ihit = intersect_" + p + "(transformed_ray);\nihit.hit.t = ptl_div(ihit.hit.t, len);\n");
                     s.add_string("if (nearer(i, ihit)) { i = ihit; i.hit.n = normalize(adjugate(" + normal_name(m) + ") * i.hit.n); }\n\n");
                 } else {
                     auto side = [&](const std::string& m, bool first, const std::string& material) {
                         transformed(inverse_name(m));
-                        s.add_string("ihit = intersect_" + p + "(transformed_ray, " + bool_lit(first) + ");\nihit.hit.t /= len;\n");
+                        s.add_string("ihit = intersect_" + p + "(transformed_ray, " + bool_lit(first) + ");\nihit.hit.t = ptl_div(ihit.hit.t, len);\n");
                         s.add_string("if (nearer(i, ihit) && ihit.material != NOT_INSIDE) { if (ihit.material == TELEPORT) { ihit.material = " + material +
                                      "; } if (ihit.material == TELEPORT_SUBSPACE) { ihit.material = " + material +
                                      "; ihit.in_subspace = true; } i = ihit; i.hit.n = normalize(adjugate(" + normal_name(m) + ") * i.hit.n); }\n\n");
@@ -775,7 +775,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             s.add_string("vec4 rd2 = _camera_mul_inv * r.d;");
             s.add_string("float u = atan(rd2.z, rd2.x);");
             s.add_string("float v = atan(sqrt(rd2.x * rd2.x + rd2.z * rd2.z), rd2.y);");
-            s.add_string("vec3 not_found_color = sqrvec(texture(" + *scene.skybox + "_tex, vec2((u/PI+1.0f)/2.0f, v/PI)).sw<0,1,2>());");
+            s.add_string("vec3 not_found_color = sqrvec(texture(" + *scene.skybox + "_tex, vec2(ptl_div(ptl_div(u, PI) + 1.0f, 2.0f), ptl_div(v, PI))).sw<0,1,2>());");
         } else {
             s.add_string("vec3 not_found_color = color(0.6f, 0.6f, 0.6f);");
         }
@@ -802,6 +802,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     if (opts.count_segments) gk.defines.push_back("PTL_COUNT_SEGMENTS");
     if (opts.anaglyph) gk.defines.push_back("PTL_ANAGLYPH");
     if (opts.fast_math) gk.defines.push_back("PTL_FAST_MATH");
+    if (opts.exact_cr) gk.defines.push_back("PTL_CONTRACT_V1");
     if (gk.first_trip_variants) gk.defines.push_back("PTL_FIRST_TRIP");
     return gk;
 }

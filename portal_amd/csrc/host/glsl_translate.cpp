@@ -335,11 +335,175 @@ void defer_loop_carried_updates(std::vector<Token>& toks) {
     toks.swap(out);
 }
 
+// `a / b` -> `ptl_div(a, b)`, `a /= b` -> `ptl_div_assign(a, b)` (device/ptl_glsl.h, "CONTRACT 2"): C++ cannot overload the division
+// of two scalars, and the numerics contract defines it (a * (1/b) with the contract's reciprocal), so every division of a snippet
+// becomes a call; the overload set of ptl_div keeps int / int an integer division and sends vector operands to the vector operators.
+// Operand extents follow GLSL's grammar: the right operand is ONE unary expression (prefix operators, a primary, its postfix chain),
+// the left operand the whole multiplicative chain in front (`a * b / c` is `(a * b) / c`; `*`, `/`, `%` associate to the left --
+// earlier divisions of the chain have already been rewritten when a later one is reached, so their text is part of that operand).
+// `x.yz /= e` (a multi-component swizzle as target) stays: the swizzle proxy's own operator/= does the same arithmetic.
+void rewrite_divisions(std::vector<Token>& toks) {
+    std::vector<size_t> sig;
+    for (size_t k = 0; k < toks.size(); ++k)
+        if (toks[k].kind != Token::Space && toks[k].kind != Token::Comment && toks[k].kind != Token::Preproc) sig.push_back(k);
+    const size_t n = sig.size();
+    auto T = [&](size_t i) -> const Token& { return toks[sig[i]]; };
+    auto is = [&](size_t i, const char* text) { return i < n && T(i).kind == Token::Punct && T(i).text == text; };
+    auto operand_end = [&](size_t i) {  // can a (sub)expression end with this token?
+        if (i >= n) return false;
+        const Token& t = T(i);
+        if (t.kind == Token::Ident) {
+            static const std::set<std::string> kw = {"return", "if", "else", "for", "while", "do", "case", "in", "out", "inout", "const"};
+            return kw.count(t.text) == 0;
+        }
+        if (t.kind == Token::Number) return true;
+        return t.kind == Token::Punct && (t.text == ")" || t.text == "]");
+    };
+    auto open_of = [&](size_t close) -> size_t {  // index of the bracket the one at `close` closes, or n
+        const std::string c = T(close).text, o = c == ")" ? "(" : "[";
+        int depth = 0;
+        for (size_t i = close + 1; i-- > 0;) {
+            if (is(i, c.c_str())) ++depth;
+            else if (is(i, o.c_str()) && --depth == 0) return i;
+        }
+        return n;
+    };
+    auto close_of = [&](size_t open) -> size_t {
+        const std::string o = T(open).text, c = o == "(" ? ")" : "]";
+        int depth = 0;
+        for (size_t i = open; i < n; ++i) {
+            if (is(i, o.c_str())) ++depth;
+            else if (is(i, c.c_str()) && --depth == 0) return i;
+        }
+        return n;
+    };
+    auto is_prefix_op = [&](size_t i) {  // a unary operator: one of - + ! ~ ++ -- that does not follow an operand
+        if (i >= n || T(i).kind != Token::Punct) return false;
+        const std::string& t = T(i).text;
+        if (!(t == "-" || t == "+" || t == "!" || t == "~" || t == "++" || t == "--")) return false;
+        return i == 0 || !operand_end(i - 1);
+    };
+    // start of the unary expression that ends at `e` (inclusive); n when the text is not understood
+    auto unary_start = [&](size_t e) -> size_t {
+        size_t p = e;
+        if ((is(p, "++") || is(p, "--")) && p > 0 && operand_end(p - 1)) --p;  // postfix increment
+        for (;;) {
+            if (p >= n) return n;
+            const Token& t = T(p);
+            if (t.kind == Token::Punct && (t.text == ")" || t.text == "]")) {
+                const size_t o = open_of(p);
+                if (o == n) return n;
+                if (t.text == "]") {  // base[...]: go on with the base
+                    if (o == 0) return n;
+                    p = o - 1;
+                    continue;
+                }
+                p = o;
+                if (o > 0 && T(o - 1).kind == Token::Ident && operand_end(o - 1)) p = o - 1;  // a call or a constructor
+                else break;  // a parenthesised expression
+            } else if (t.kind != Token::Ident && t.kind != Token::Number) {
+                return n;
+            }
+            if (p > 0 && is(p - 1, ".")) {  // member of something: go on with the object
+                if (p < 2) return n;
+                p -= 2;
+                continue;
+            }
+            break;
+        }
+        while (p > 0 && is_prefix_op(p - 1)) --p;
+        return p;
+    };
+    // end (inclusive) of the unary expression that starts at `b`
+    auto unary_end = [&](size_t b) -> size_t {
+        size_t p = b;
+        while (is_prefix_op(p)) ++p;
+        if (p >= n) return n;
+        if (is(p, "(")) {
+            p = close_of(p);
+            if (p == n) return n;
+        } else if (T(p).kind != Token::Ident && T(p).kind != Token::Number) {
+            return n;
+        }
+        for (;;) {  // postfix chain
+            if (is(p + 1, "(") || is(p + 1, "[")) {
+                p = close_of(p + 1);
+                if (p == n) return n;
+            } else if (is(p + 1, ".") && p + 2 < n && T(p + 2).kind == Token::Ident) {
+                p += 2;
+            } else if ((is(p + 1, "++") || is(p + 1, "--"))) {
+                p += 1;
+            } else {
+                return p;
+            }
+        }
+    };
+    struct Insert { size_t at; int order; std::string text; };  // `at`: significant-token index the text goes in FRONT of (n: the end)
+    std::vector<Insert> inserts;
+    std::vector<std::pair<size_t, std::string>> retext;  // significant-token index -> replacement text of that token
+    for (size_t k = 0; k < n; ++k) {
+        auto fail = [&](const char* what) {
+            std::string near;
+            for (size_t i = k > 4 ? k - 4 : 0; i < n && i < k + 5; ++i) near += T(i).text + " ";
+            throw std::runtime_error(std::string("GLSL -> HIP translation: cannot find the ") + what + " operand of the division near `" + near + "`");
+        };
+        auto ends_operand = [&](size_t i) { return operand_end(i) || ((is(i, "++") || is(i, "--")) && i > 0 && operand_end(i - 1)); };
+        if (is(k, "/")) {
+            if (k == 0 || !ends_operand(k - 1)) fail("left");
+            size_t left = unary_start(k - 1);
+            if (left == n) fail("left");
+            while (left > 1 && (is(left - 1, "*") || is(left - 1, "/") || is(left - 1, "%")) && operand_end(left - 2)) {
+                const size_t prev = unary_start(left - 2);
+                if (prev == n) break;
+                left = prev;
+            }
+            const size_t right = unary_end(k + 1);
+            if (right == n) fail("right");
+            inserts.push_back({left, 0, "ptl_div("});
+            retext.push_back({k, ","});
+            inserts.push_back({right + 1, 1, ")"});
+        } else if (is(k, "/=")) {
+            if (k == 0 || !operand_end(k - 1)) fail("left");
+            if (T(k - 1).kind == Token::Ident && k >= 2 && is(k - 2, ".") && !swizzle_indices(T(k - 1).text).empty()) continue;  // v.xy /= e
+            const size_t left = unary_start(k - 1);
+            if (left == n) fail("left");
+            size_t end = k + 1;  // the assignment expression: up to the `;`, `,` or closing bracket of this nesting level
+            int depth = 0;
+            for (; end < n; ++end) {
+                if (is(end, "(") || is(end, "[")) ++depth;
+                else if (is(end, ")") || is(end, "]")) {
+                    if (depth == 0) break;
+                    --depth;
+                } else if (depth == 0 && (is(end, ";") || is(end, ","))) break;
+            }
+            if (end == k + 1) fail("right");
+            inserts.push_back({left, 0, "ptl_div_assign("});
+            retext.push_back({k, ","});
+            inserts.push_back({end, 1, ")"});
+        }
+    }
+    if (inserts.empty()) return;
+    // an opener and a closer never share a position; several openers or several closers at one place keep their order
+    std::stable_sort(inserts.begin(), inserts.end(), [](const Insert& a, const Insert& b) { return a.at < b.at || (a.at == b.at && a.order > b.order); });
+    for (auto& r : retext) toks[sig[r.first]].text = r.second;
+    std::vector<Token> out;
+    out.reserve(toks.size() + inserts.size());
+    size_t next = 0;
+    for (size_t k = 0; k <= toks.size(); ++k) {
+        // a closer belongs right behind the last token of its operand, not behind the white space and comments that follow it
+        while (next < inserts.size() && (inserts[next].at >= n ? k == toks.size() : (inserts[next].order == 1 ? sig[inserts[next].at - 1] + 1 == k : sig[inserts[next].at] == k)))
+            out.push_back({Token::Raw, inserts[next++].text});
+        if (k < toks.size()) out.push_back(toks[k]);
+    }
+    toks.swap(out);
+}
+
 }  // namespace
 
 std::string translate_glsl(const std::string& glsl, bool defer_loop_updates) {
     std::vector<Token> toks = tokenize(glsl);
     if (defer_loop_updates) defer_loop_carried_updates(toks);
+    rewrite_divisions(toks);
     std::string out;
     out.reserve(glsl.size() + glsl.size() / 8);
 

@@ -28,7 +28,7 @@ def functions():
         ("pow", "pow(abs(a), b)", lambda a, b, c: M.pow(M.absf(a), b)),
         ("sqrt", "sqrt(a)", lambda a, b, c: M.sqrt(a)),
         ("inversesqrt", "inversesqrt(a)", lambda a, b, c: M.inversesqrt(a)),
-        ("div", "a / b", lambda a, b, c: M.div(a, b)),
+        ("div", "ptl_div(a, b)", lambda a, b, c: M.div(a, b)),  # what the translator turns a scalar `a / b` into
         ("fma", "fma(a, b, c)", lambda a, b, c: M.fma(a, b, c)),
         ("mod", "mod(a, b)", lambda a, b, c: M.mod(a, b)),
         ("fract", "fract(a)", lambda a, b, c: M.fract(a)),

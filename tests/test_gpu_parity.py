@@ -938,16 +938,38 @@ namespace glsl {
 struct ptl_uniform_block { int what_u; int pad_u; };
 __constant__ ptl_uniform_block ptl_u;
 PTL_FN bool same(float a, float b) { return __builtin_bit_cast(unsigned, a) == __builtin_bit_cast(unsigned, b) || (a != a && b != b); }
+#if defined(PTL_CONTRACT_V1)
+PTL_FN float want_sqrt(float x) { return __builtin_sqrtf(x); }   // contract 1: the compiler's IEEE expansions
+PTL_FN float want_rcp(float x) { return 1.0f / x; }
+PTL_FN float want_div(float a, float b) { return a / b; }
+#else
+PTL_FN float want_sqrt(float x) { return ptl_sqrt_model(x); }    // contract 2: the definition in the language's own operators
+PTL_FN float want_rcp(float x) { return ptl_rcp_model(x); }      // (device/ptl_glsl.h; what the host build and numpy compute)
+PTL_FN float want_div(float a, float b) { return a * ptl_rcp_model(b); }
+#endif
 // pixel (x, y) of a 4096 x 256 frame = one of 2^20 threads, each walking 4096 consecutive bit patterns: all 2^32 floats.
 PTL_FN vec4 shade_pixel(vec2 position) {
     const unsigned base = ((unsigned)position.y * 4096u + (unsigned)position.x) << 12;
     unsigned bad_sqrt = 0, bad_rcp = 0, bad_inversesqrt = 0, first = 0;
-    for (unsigned k = 0; k < 4096u; ++k) {
-        const float x = __builtin_bit_cast(float, base + k);
-        const float want_sqrt = __builtin_sqrtf(x), want_rcp = 1.0f / x;   // the compiler's IEEE expansions
-        const bool b0 = !same(sqrt(x), want_sqrt), b1 = !same(ptl_rcp(x), want_rcp), b2 = !same(inversesqrt(x), 1.0f / want_sqrt);
-        bad_sqrt += b0; bad_rcp += b1; bad_inversesqrt += b2;
-        if ((b0 || b1 || b2) && first == 0) first = base + k;
+    if (ptl_u.what_u == 0) {
+        for (unsigned k = 0; k < 4096u; ++k) {
+            float x = __builtin_bit_cast(float, base + k);
+            asm volatile("" : "+v"(x));   // a run-time value: the sequences, not the compiler's constant folding
+            const float ws = want_sqrt(x);
+            const bool b0 = !same(sqrt(x), ws), b1 = !same(ptl_rcp(x), want_rcp(x)), b2 = !same(inversesqrt(x), want_rcp(ws));
+            bad_sqrt += b0; bad_rcp += b1; bad_inversesqrt += b2;
+            if ((b0 || b1 || b2) && first == 0) first = base + k;
+        }
+    } else {  // a / b on 2^32 pairs: this thread's 4096 numerators against denominators from a bit-mixing sequence (incl. specials)
+        unsigned h = base * 2654435761u + 0x9e3779b9u * (unsigned)ptl_u.what_u;
+        for (unsigned k = 0; k < 4096u; ++k) {
+            h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+            float a = __builtin_bit_cast(float, base + k), b = __builtin_bit_cast(float, h);
+            asm volatile("" : "+v"(a), "+v"(b));
+            const bool b1 = !same(ptl_div(a, b), want_div(a, b));
+            bad_rcp += b1;
+            if (b1 && first == 0) first = base + k;
+        }
     }
     return vec4((float)bad_sqrt, (float)bad_rcp, (float)bad_inversesqrt, __builtin_bit_cast(float, first));
 }
@@ -956,19 +978,26 @@ PTL_FN unsigned int pack_rgba8(vec4 c) { return 0u; }
 """
 
 
-def test_sqrt_and_reciprocal_are_exact_for_every_input(gpu):
-    """The gfx950 build computes sqrt(x) and 1/x with shorter instruction sequences than the compiler's expansions (ptl_glsl.h: one
-    exact FMA correction of the hardware estimate).  ALL 2^32 bit patterns go through them here -- normals, subnormals, zeros,
-    infinities, every NaN -- against the compiler's IEEE expansions (which the numerics-contract test ties to numpy, and numpy to
-    the host build): not one mismatch."""
+@pytest.mark.parametrize("contract", [2, 1])
+def test_sqrt_and_reciprocal_match_the_contract_for_every_input(gpu, contract):
+    """The gfx950 build computes sqrt(x), 1/x and a / b with short instruction sequences from the hardware estimates (ptl_glsl.h).
+    ALL 2^32 bit patterns go through sqrt, 1/x and inversesqrt here -- normals, subnormals, zeros, infinities, every NaN -- and
+    2 x 2^32 (numerator, denominator) pairs through a / b, against the contract's definition in the language's own operators
+    (contract 2: correctly rounded with the flushed extremes, ptl_*_model -- the very functions the host build runs and numpy
+    restates; contract 1, FLAG_EXACT_CR: the compiler's IEEE expansions): not one mismatch."""
     pa = gpu
-    k = pa.Kernel(pa.device_source("glsl") + _EXHAUSTIVE + pa.device_source("entry"), [("what_u", 2, 0), ("pad_u", 2, 4)], 8, device=0)
+    k = pa.Kernel(pa.device_source("glsl") + _EXHAUSTIVE + pa.device_source("entry"), [("what_u", 2, 0), ("pad_u", 2, 4)], 8, device=0,
+                  defines=("PTL_CONTRACT_V1",) if contract == 1 else ())
     out = k.render(4096, 256, rgba8=False, rgba32f=True)
     got = out["rgba32f"].reshape(-1, 4)
     bad = got[:, :3].astype(np.float64).sum(axis=0)
     first = got[:, 3].view(np.uint32)
-    assert not bad.any(), f"mismatches (sqrt, 1/x, inversesqrt) = {bad}; e.g. bit pattern {hex(int(first[first != 0][0]))}"
-    print(f"sqrt, 1/x and inversesqrt exact on all 2^32 inputs ({out['ms']:.1f} ms)")
+    assert not bad.any(), f"contract {contract}: mismatches (sqrt, 1/x, inversesqrt) = {bad}; e.g. bit pattern {hex(int(first[first != 0][0]))}"
+    for round_ in (1, 2):
+        k.set_uniform("what_u", 2, round_)
+        got = k.render(4096, 256, rgba8=False, rgba32f=True)["rgba32f"].reshape(-1, 4)
+        assert not got[:, 1].astype(np.float64).sum(), f"contract {contract}: a / b differs from its definition on {got[:, 1].sum():.0f} of 2^32 pairs"
+    print(f"contract {contract}: sqrt, 1/x, inversesqrt exact on all 2^32 inputs ({out['ms']:.1f} ms), a / b on 2^33 pairs")
 
 
 def test_gpu_frame_agrees_with_the_reference_screenshot(gpu):

@@ -259,16 +259,63 @@ def test_translate_glsl_rewrites(pa):
     t = pa.translate_glsl
     assert t("float x = 1.;") == "float x = 1.f;"
     assert t("x = 2.5e-3 + 1e5 + 3 + 0x10;") == "x = 2.5e-3f + 1e5f + 3 + 0x10;"
-    assert t("vec3 m = 1.0/r.d.xyz;") == "vec3 m = 1.0f/r.d.sw<0,1,2>();"
+    assert t("vec3 m = 1.0/r.d.xyz;") == "vec3 m = ptl_div(1.0f,r.d.sw<0,1,2>());"
     assert t("step(t1.yzx,t1.xyz)") == "step(t1.sw<1,2,0>(),t1.sw<0,1,2>())"
     assert t("c.rgb *= 2.0;") == "c.swr<0,1,2>() *= 2.0f;"
     assert t("p.xy = q.yx;") == "p.swr<0,1>() = q.sw<1,0>();"
-    assert t("hit.t /= len; best.u == r.x") == "hit.t /= len; best.u == r.x"   # single components / struct fields untouched
+    assert t("hit.t *= len; best.u == r.x") == "hit.t *= len; best.u == r.x"   # single components / struct fields untouched
     assert t("void f(in vec3 a, out float b, inout vec2 c)") == "void f( vec3 a,  float& b,  vec2& c)"
     assert t("float new = delete;") == "float new_ = delete_;"
     assert t("a // 1.0 .xyz\nb") == "a // 1.0 .xyz\nb"                        # comments are not rewritten
     src = "line1\n  x = 1.0; // !FOR_NUMBER!\nline3"
     assert t(src).count("\n") == src.count("\n")
+
+
+def test_translate_glsl_turns_every_division_into_a_contract_call(pa):
+    """Numerics contract 2 (device/ptl_glsl.h) DEFINES a / b (a * (1/b) with the contract's reciprocal) and C++ cannot overload the
+    division of two scalars, so the translator rewrites `/` and `/=` into ptl_div / ptl_div_assign calls.  Operand extents follow
+    GLSL's grammar: the right operand is one unary expression, the left one the multiplicative chain in front (left-associative)."""
+    t = pa.translate_glsl
+    cases = {
+        "float t = -r.o.z/r.d.z;": "float t = ptl_div(-r.o.z,r.d.z);",
+        "x = a * b / c;": "x = ptl_div(a * b , c);",
+        "x = a / b / c;": "x = ptl_div(ptl_div(a , b) , c);",
+        "x = a / (b + c) * d / e;": "x = ptl_div(ptl_div(a , (b + c)) * d , e);",
+        "q = a + b / c - d;": "q = a + ptl_div(b , c) - d;",
+        "z = -a / -b;": "z = ptl_div(-a , -b);",
+        "w = (a + b) / float(n);": "w = ptl_div((a + b) , float(n));",
+        "y = f(a / b, c) / g(d)[2].x;": "y = ptl_div(f(ptl_div(a , b), c) , g(d)[2].x);",
+        "k = cond ? a / b : c / d;": "k = cond ? ptl_div(a , b) : ptl_div(c , d);",
+        "return normal * dot(d, n) / dot(n, n) * 2.;": "return ptl_div(normal * dot(d, n) , dot(n, n)) * 2.f;",   # src/library.glsl:71
+        "int k = i++ / 2;": "int k = ptl_div(i++ , 2);",                                                          # int / int stays an integer division (overload)
+        "r.tmul /= len;": "ptl_div_assign(r.tmul , len);",
+        "a /= b / c;": "ptl_div_assign(a , ptl_div(b , c));",
+        "if (a / b > c) { e /= f; }": "if (ptl_div(a , b) > c) { ptl_div_assign(e , f); }",
+        "v.xy /= s;": "v.swr<0,1>() /= s;",                      # a swizzle target keeps the proxy's own operator/= (same arithmetic)
+        "x = a /* c */ / b; // a / b": "x = ptl_div(a /* c */ , b); // a / b",
+        "p = x.y / z.w / 2.0;\nq /= p * 2.;": "p = ptl_div(ptl_div(x.y , z.w) , 2.0f);\nptl_div_assign(q , p * 2.f);",
+    }
+    for glsl, want in cases.items():
+        assert t(glsl) == want, glsl
+    with pytest.raises(pa.PortalError, match="operand of the division"):
+        t("x = / 2.;")
+    # every snippet of the reference's 82 scenes: after translation no division operator is left outside comments
+    # (`/=` survives only behind a swizzle target)
+    import glob, re
+    from oracle.scene_eval import OracleScene
+    seen = 0
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "corpus", "scenes", "*.ron"))):
+        if os.path.getsize(path) == 0:
+            continue
+        sc = OracleScene(path)
+        snippets = [c for _, c in sc.library] + [o["code"] for o in sc.objects] + [m["code"] for m in sc.materials if m["kind"] == "Complex"] + [c for _, c in sc.intersection_materials]
+        for code in snippets:
+            out = re.sub(r"//[^\n]*|/\*.*?\*/", "", t(code), flags=re.S)
+            assert not re.search(r"/(?!=)", out), (path, out[max(0, out.find("/") - 60):out.find("/") + 40])
+            for m in re.finditer(r"/=", out):
+                assert re.search(r"swr<[0-9,]+>\(\)\s*$", out[:m.start()]), (path, out[max(0, m.start() - 60):m.start() + 20])
+            seen += code.count("/")
+    assert seen > 800
 
 
 def test_generated_source_line_bookkeeping(pa):

@@ -120,6 +120,11 @@ VARIANTS = {
     "r2_fast_dyn_w4": "FAST -DPTL_WAVES_PER_EU=4",
     "r2_fast_all": "FAST SPECIALIZE_ALL",
     "r2_fast_all_w4": "FAST SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4",
+    # round 3: numerics contract 2 is the default; EXACT_CR = contract 1 (FLAG_EXACT_CR), the round-2 arithmetic
+    "r3_all": "SPECIALIZE_ALL", "r3_all_w3": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=3", "r3_all_w4": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4", "r3_all_w5": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=5",
+    "r3_v1_all": "EXACT_CR SPECIALIZE_ALL", "r3_v1_all_w4": "EXACT_CR SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4",
+    "r3_dyn": "", "r3_v1_dyn": "EXACT_CR", "r3_ints": "SPECIALIZE", "r3_v1_ints": "EXACT_CR SPECIALIZE",
+    "r3_fast_all_w4": "FAST SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4",
 }
 CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
 
@@ -138,7 +143,7 @@ def run_one(case, vname, flags):
     w, h, d, aa = int(w), int(h), int(d), int(aa)
     toks = flags.split()
     rflags = (pa.FLAG_SPECIALIZE_INTS if ("SPECIALIZE" in toks or "SPECIALIZE_ALL" in toks) else 0) | (pa.FLAG_SPECIALIZE_ALL if "SPECIALIZE_ALL" in toks else 0)
-    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0) | (pa.FLAG_NO_DEFERRED_UPDATES if "NO_DEFER" in toks else 0) | (pa.FLAG_NO_UNIFORM_HOIST if "NO_HOIST" in toks else 0) | (pa.FLAG_NO_FIRST_TRIP if "NO_FIRST_TRIP" in toks else 0)
+    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0) | (pa.FLAG_NO_DEFERRED_UPDATES if "NO_DEFER" in toks else 0) | (pa.FLAG_NO_UNIFORM_HOIST if "NO_HOIST" in toks else 0) | (pa.FLAG_NO_FIRST_TRIP if "NO_FIRST_TRIP" in toks else 0) | (pa.FLAG_EXACT_CR if "EXACT_CR" in toks else 0)
     # the VGPR allocator is an option the JIT always passes (kernel.cpp): select it through its own switch, not a second -mllvm
     ra = [t.split("=", 1)[1] for t in toks if t.startswith("-vgpr-regalloc=")]
     if "RA_DEFAULT" in toks:
