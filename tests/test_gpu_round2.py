@@ -3,6 +3,7 @@
 All through the C ABI (ctypes mirror) or the CLI binary; the checker is the numpy oracle or, where two builds of the product
 must agree with EACH OTHER bit for bit (prologue on/off, 1 rank vs N ranks), the other build.
 """
+import glob
 import os
 import subprocess
 
@@ -192,3 +193,25 @@ def test_fast_math_mode_stays_within_tolerance_almost_everywhere(gpu, scene_name
     assert not np.array_equal(_bits(frames["exact"]), _bits(frames["fast"]))  # it is a different arithmetic
     assert beyond < 0.02
     assert np.median(err) < 1e-5
+
+
+CONTRACT1 = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "contract1", "*.npz")))
+
+
+@pytest.mark.parametrize("build", ["dynamic", "baked"])
+@pytest.mark.parametrize("path", CONTRACT1, ids=[os.path.basename(p) for p in CONTRACT1])
+def test_exact_cr_kernel_reproduces_the_contract_1_goldens(gpu, path, build):
+    """FLAG_EXACT_CR (`--exact-cr`): the kernel built with the numerics contract of rounds 1-2 still gives the golden frames
+    committed in round 1 -- bit for bit, trip counts included."""
+    pa = gpu
+    base = os.path.basename(path)[: -len(".npz")]
+    scene_name, dims, depth, aa = base.rsplit("_", 3)
+    w, h = (int(x) for x in dims.split("x"))
+    g = np.load(path)
+    flags = pa.FLAG_EXACT_CR | pa.FLAG_COUNT_SEGMENTS | (pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL if build == "baked" else 0)
+    r = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path(scene_name)), device=0, flags=flags)
+    r.set_option("render_depth", int(depth[1:]))
+    r.set_option("aa_count", int(aa[2:]))
+    out = r.draw(w, h, rgba8=True, rgba32f=True, segments=True)
+    assert np.array_equal(out["rgba32f"].view(np.uint32), g["rgba32f_bits"]) and np.array_equal(out["rgba8"], g["rgba8"])
+    assert out["segments"] == int(g["segments"].sum())

@@ -261,3 +261,40 @@ def test_kitchen_sink_scene_matches_oracle(pa, tmp_path, in_subspace):
     want = o.render(w, h)
     assert bits_equal(got["rgba32f"], want["rgba32f"]).all()
     assert len(np.unique(got["rgba8"].reshape(-1, 4), axis=0)) > 50       # a real picture, not a flat fill
+
+
+CONTRACT1 = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "contract1", "*.npz")))
+
+
+@pytest.mark.parametrize("path", CONTRACT1[:4], ids=[os.path.basename(p) for p in CONTRACT1[:4]])
+def test_exact_cr_build_and_oracle_reproduce_the_contract_1_goldens(pa, path):
+    """FLAG_EXACT_CR / `--exact-cr` keeps the numerics contract of rounds 1-2 (IEEE `/` and sqrt on every input): the host build of
+    that kernel source and the numpy oracle switched to contract 1 both give the golden frames committed in round 1, bit for bit --
+    and the default (contract 2) differs from them in the last bits only."""
+    from oracle import glsl_math as M
+    from oracle import host_build as hb
+    from oracle.portal_oracle import Oracle
+
+    base = os.path.basename(path)[: -len(".npz")]
+    scene_name, dims, depth, aa = base.rsplit("_", 3)
+    w, h = (int(x) for x in dims.split("x"))
+    depth, aa = int(depth[1:]), int(aa[2:])
+    g = np.load(path)
+    scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    r = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_EXACT_CR)
+    r.set_option("render_depth", depth)
+    r.set_option("aa_count", aa)
+    got = hb.host_kernel_for(r, scene, w, h, flags=pa.FLAG_EXACT_CR).render(w, h)
+    assert np.array_equal(got["rgba32f"].view(np.uint32), g["rgba32f_bits"])
+    previous = M.set_contract(1)
+    try:
+        o = Oracle(pa.scene_path(scene_name))
+        o.options.update(render_depth=depth, aa_count=aa)
+        want = o.render(w, h)
+    finally:
+        M.set_contract(previous)
+    assert np.array_equal(want["rgba32f"].view(np.uint32), g["rgba32f_bits"]) and np.array_equal(want["rgba8"], g["rgba8"])
+    now = np.load(os.path.join(os.path.dirname(os.path.dirname(path)), os.path.basename(path)))["rgba32f_bits"].view(np.float32)
+    old = g["rgba32f_bits"].view(np.float32)
+    moved = np.abs(now - old) > 1e-5
+    assert moved.any(axis=2).sum() <= 0.005 * w * h  # pixels on an edge whose path a last bit decides (the Moebius strip's Newton search: 5 of 2 304)
