@@ -18,9 +18,13 @@ The oracle evaluates the reference's GLSL as written.  The product's translator 
 (glsl_translate.h `defer_loop_updates`): an update that no statement ever reads is never executed.  How many that is cannot come from the
 oracle; it is measured on the HOST BUILD of the generated source with two counters compiled in (updates scheduled / updates applied) on
 rows sampled over the same full-size frame, and `flops_*_executed` = the oracle's count minus (scheduled - applied) per trip x the
-operations of one update (56 per `transform`: two mat4 x vec4 of 4 x (1 mul + 3 fma)).  The plane cull and the early-outs are NOT subtracted.
+operations of one update (56 per `transform`: two mat4 x vec4 of 4 x (1 mul + 3 fma)).
+Round 3: the generated plane tests the wave-level cull skips (ptl_library.h::ptl_plane_cull) are subtracted the same way -- tests and
+culled tests per trip counted on the host build (per ray; on the GPU the decision is per wave and the 64 rays of a tile agree in 99.9 %
+of the cases, so this slightly OVER-subtracts), times what the oracle spends per generated plane test (`plane_intersect` + `nearer`,
+measured inside Oracle.scene_intersect).  The z row the cull itself evaluates is not claimed as work.
 
-    python tools/count_flops.py                      # the four GPU configs -> profiles/r02/flops_per_segment.json
+    python tools/count_flops.py                      # the four GPU configs -> profiles/r03/flops_per_segment.json
 """
 from __future__ import annotations
 
@@ -50,6 +54,8 @@ def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None
 
     M.COUNT_VARYING = True
     _vary_the_camera_between_lanes()
+    _meter_the_generated_plane_tests()
+    PLANE_METER.update(flops=0.0, flops_varying=0.0, lane_tests=0.0)
     o = Oracle(pa.scene_path(scene))
     o.options.update(render_depth=depth, aa_count=aa)
     if options:
@@ -71,6 +77,14 @@ def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None
         skipped = deferred["flops_per_update"] * (deferred["scheduled_per_segment"] - deferred["applied_per_segment"])
         per_segment["flops_executed"] = per_segment["flops"] - skipped
         per_segment["flops_varying_executed"] = per_segment["flops_varying"] - skipped
+    culls = plane_cull_counts(scene, w, h, depth, aa, options)
+    if culls and PLANE_METER["lane_tests"]:
+        per_test = {k: PLANE_METER[k] / PLANE_METER["lane_tests"] for k in ("flops", "flops_varying")}
+        culls["oracle_flops_per_plane_test"] = per_test
+        culls["oracle_plane_tests_per_segment"] = PLANE_METER["lane_tests"] / seg
+        for k in ("flops", "flops_varying"):
+            base = per_segment.get(k + "_executed", per_segment[k])
+            per_segment[k + "_executed"] = base - culls["culled_per_segment"] * per_test[k]
     first = first_trip_origin_flops(scene, w, h, options)
     if first:
         # the share of trips that ARE first trips: one per primary sample
@@ -86,6 +100,7 @@ def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None
         "segments_in_sample": int(seg), "segments_per_primary_sample": seg / (n * aa),
         "per_segment": per_segment,
         "deferred_updates": deferred,
+        "plane_cull": culls,
         "oracle_seconds": round(time.time() - t0, 1),
     }
 
@@ -117,6 +132,89 @@ def _vary_the_camera_between_lanes():
         return original(self, image_position, V.Mat(cols), *args, **kwargs)
 
     Oracle.get_color2 = get_color2
+
+
+PLANE_METER = {"flops": 0.0, "flops_varying": 0.0, "lane_tests": 0.0}
+_plane_patched = False
+
+
+def _meter_the_generated_plane_tests():
+    """What the oracle spends on ONE generated plane test (scene.rs:912-948: `plane_intersect` + `nearer`), per active lane: the work
+    a culled test skips.  Only the calls made from Oracle.scene_intersect are metered -- a scene snippet's own plane_intersect calls
+    are never culled."""
+    global _plane_patched
+    if _plane_patched:
+        return
+    _plane_patched = True
+    from oracle import glsl_math as M
+    from oracle.portal_oracle import Natives, Oracle
+
+    inside = {"on": False}
+    original_si, original_pi, original_nearer = Oracle.scene_intersect, Natives.plane_intersect, Natives.nearer
+
+    def scene_intersect(self, *a, **k):
+        inside["on"] = True
+        try:
+            return original_si(self, *a, **k)
+        finally:
+            inside["on"] = False
+
+    def plane_intersect(self, *a, **k):
+        if not inside["on"]:
+            return original_pi(self, *a, **k)
+        before = (M.STATS["flops"], M.STATS["flops_varying"])
+        out = original_pi(self, *a, **k)
+        PLANE_METER["flops"] += M.STATS["flops"] - before[0] + 3.0 * M._active            # + nearer(): three compares
+        PLANE_METER["flops_varying"] += M.STATS["flops_varying"] - before[1] + 3.0 * M._active
+        PLANE_METER["lane_tests"] += M._active
+        return out
+
+    Oracle.scene_intersect = scene_intersect
+    Natives.plane_intersect = plane_intersect
+
+
+def plane_cull_counts(scene_name, w, h, depth, aa, options=None, row_step=61):
+    """Generated plane tests and how many of them ptl_plane_cull skips, per bounce-loop trip, counted per ray on the host build of the
+    baked source (rows row_step/2, +row_step, ... of the full-size frame).  None when the source has no culled test."""
+    import ctypes as C
+
+    import portal_amd as pa
+    from oracle import host_build as hb
+
+    scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    source = scene.generate_source(pa.FLAG_COUNT_SEGMENTS)
+    needle = "    return behind || (t_low > best_t && abs(dz) >= 0x1p-100f);"
+    if needle not in source or "ptl_plane_cull(r," not in source:
+        return None
+    source = source.replace("namespace glsl {\n", "namespace glsl {\nstatic long ptl_cull_stats[2] = {0, 0};\n", 1)
+    source = source.replace(needle, "    { const bool ptl_c = behind || (t_low > best_t && abs(dz) >= 0x1p-100f); __atomic_fetch_add(&ptl_cull_stats[ptl_c ? 1 : 0], 1, __ATOMIC_RELAXED); return ptl_c; }")
+    source += '\nextern "C" long* ptl_cull_stats_ptr() { return glsl::ptl_cull_stats; }\n'
+    renderer = pa.SceneRenderer(scene, device=-1)
+    renderer.set_option("render_depth", depth)
+    renderer.set_option("aa_count", aa)
+    for k, v in (options or {}).items():
+        renderer.set_option({"use_panini": "use_panini_projection"}.get(k, k), float(v))
+    layout, size = scene.uniform_layout()
+    hk = hb.HostKernel(source, layout, size, True)
+    for name, typ, _ in layout:
+        if typ == pa.PTL_SAMPLER:
+            continue
+        v = renderer.uniform_value(name, w, h)
+        if v is not None:
+            hk.set_uniform(name, v)
+    from PIL import Image
+
+    paths = scene.textures()
+    for name, typ, _ in layout:
+        if typ == pa.PTL_SAMPLER and paths.get(name[: -len("_tex")]) and os.path.exists(os.path.join(pa.REPO_ROOT, paths[name[: -len("_tex")]])):
+            hk.set_texture(name, np.array(Image.open(os.path.join(pa.REPO_ROOT, paths[name[: -len("_tex")]])).convert("RGBA")))
+    hk.lib.ptl_cull_stats_ptr.restype = C.POINTER(C.c_long)
+    st = hk.lib.ptl_cull_stats_ptr()
+    st[0] = st[1] = 0
+    rows = list(range(row_step // 2, h, row_step))
+    seg = hk.render(w, h, rows=rows, rgba32f=False)["segments"]
+    return {"tests_per_segment": (st[0] + st[1]) / seg, "culled_per_segment": st[1] / seg, "segments_in_sample": seg, "sampled_rows": len(rows),
+            "counted_on": "host build of the generated source, per ray (oracle/host_build.py)"}
 
 
 def first_trip_origin_flops(scene_name, w, h, options=None):
@@ -204,7 +302,7 @@ def deferred_update_counts(scene_name, w, h, depth, aa, options=None, row_step=6
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(HERE, "profiles", "r02", "flops_per_segment.json"))
+    ap.add_argument("--out", default=os.path.join(HERE, "profiles", "r03", "flops_per_segment.json"))
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     out = {}
