@@ -39,8 +39,18 @@ FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 
 
 
+def scene_of(args, pa):
+    """(path, SceneRenderer keyword arguments) of the workload's scene file"""
+    if args.scene_file:
+        path = os.path.join(HERE, args.scene_file)
+        return path, {"asset_root": os.path.dirname(os.path.dirname(path))}
+    return pa.scene_path(args.scene), {}
+
+
 def workload_key(args):
     key = f"{args.scene}_{args.width}x{args.height}_d{args.depth}" + (f"_aa{args.aa}" if args.aa != 1 else "")
+    if args.camera:
+        key += "_cam" + args.camera.replace(",", "_")
     if args.panini >= 0.0:
         key += "_panini" if (args.panini == 1.0 and args.fov == 140.0) else f"_panini{args.panini}_fov{args.fov}"
     elif args.fov != 90.0:
@@ -96,7 +106,12 @@ WORKLOADS = {  # --workload NAME: BASELINE.json configs by name
     "c2": dict(scene="monoportal", width=1920, height=1080, depth=20, aa=1),
     "c3": dict(scene="triple_portal", width=3840, height=2160, depth=40, aa=1),
     "c4": dict(scene="portal_in_portal", width=3840, height=2160, depth=40, aa=1),
-    "c5": dict(scene="mobius_monoportal", width=7680, height=4320, depth=64, aa=4),  # the divergent-ray stress config: ~17 ms per frame on one GPU
+    "c5": dict(scene="mobius_monoportal", width=7680, height=4320, depth=64, aa=4),  # the divergent-ray stress config: ~13 ms per frame on one GPU
+    # the deep-recursion regime the wave-level early-out exists for: the headline scene seen INTO the nested portals
+    # (the views tests/test_gpu_oracle_fullsize.py checks at 320x180), and the corpus scene with four nested chains
+    "c4-deep": dict(scene="portal_in_portal", width=3840, height=2160, depth=40, aa=1, camera="0,0,0,0.2,1.5,1.6"),
+    "c4-deep2": dict(scene="portal_in_portal", width=3840, height=2160, depth=40, aa=1, camera="0.3,-0.1,0.2,2.8,1.0,2.4"),
+    "plus-ultra": dict(scene="portal_in_portal_plus_ultra", scene_file="tests/corpus/scenes/portal_in_portal_plus_ultra.ron", width=3840, height=2160, depth=40, aa=1),
 }
 
 
@@ -108,6 +123,8 @@ def parse_args():
     p.add_argument("--workload", default="", choices=[""] + sorted(WORKLOADS), help="a BASELINE.json config by name (c4 = the headline = the default; "
                    "c5 = mobius_monoportal 8K aa 4 depth 64, the second scaling workload: its per-rank trace stays far above collective latency at 8 GPUs)")
     p.add_argument("--scene", default="portal_in_portal")
+    p.add_argument("--scene-file", default="", help="a .ron file outside scenes/ (repo-relative); its assets are looked up beside its `scenes` directory")
+    p.add_argument("--camera", default="", help="look_at x,y,z,alpha,beta,r instead of the scene's `cam` block")
     p.add_argument("--width", type=int, default=3840)
     p.add_argument("--height", type=int, default=2160)
     p.add_argument("--depth", type=int, default=40)
@@ -134,10 +151,11 @@ def cpu_baseline(args, pa):
     every `stride`-th 8-row block (so cheap and expensive image regions are both sampled)."""
     from oracle import host_build as hb
 
-    scene = pa.Scene.from_file(pa.scene_path(args.scene))
-    ref = pa.SceneRenderer(scene, device=-1)
+    scene_path, extra = scene_of(args, pa)
+    scene = pa.Scene.from_file(scene_path)
+    ref = pa.SceneRenderer(scene, device=-1, **extra)
     configure(ref, args)
-    hk = hb.host_kernel_for(ref, scene, args.width, args.height)
+    hk = hb.host_kernel_for(ref, scene, args.width, args.height, **extra)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     blocks = (args.height + 7) // 8
 
@@ -197,8 +215,12 @@ def oracle_check(args, pa, renderer, torch, dev, stream, n=2048):
     if len(edges):
         pick = edges[rng.choice(len(edges), size=n, replace=len(edges) < n)]
         ys, xs = np.concatenate([ys, pick[:, 0]]), np.concatenate([xs, pick[:, 1]])
-    o = Oracle(pa.scene_path(args.scene))
+    scene_path, extra = scene_of(args, pa)
+    o = Oracle(scene_path, **extra)
     o.options.update(render_depth=args.depth, aa_count=args.aa, view_angle=args.fov / 180.0 * np.pi)
+    if args.camera:
+        c = [float(x) for x in args.camera.split(",")]
+        o.camera = dict(look_at=tuple(c[:3]), alpha=c[3], beta=c[4], r=c[5])
     if args.panini >= 0.0:
         o.options.update(use_panini=True, panini_param=args.panini)
     t0 = time.perf_counter()
@@ -219,6 +241,9 @@ def configure(renderer, args):
         renderer.set_option("use_panini_projection", 1)
         renderer.set_option("panini_param", args.panini)
     renderer.set_option("view_angle", args.fov / 180.0 * np.pi)
+    if args.camera:
+        c = [float(x) for x in args.camera.split(",")]
+        renderer.set_camera(c[:3], c[3], c[4], c[5])
 
 
 def main():
@@ -260,7 +285,8 @@ def main():
             print(f"[bench r{rank}/{world} +{time.perf_counter() - t_start:6.1f}s] {what}", file=sys.stderr, flush=True)
 
     W, H = args.width, args.height
-    scene = pa.Scene.from_file(pa.scene_path(args.scene))
+    scene_path, scene_kw = scene_of(args, pa)
+    scene = pa.Scene.from_file(scene_path)
     from portal_amd import parallel
 
     frame = pa.Frame(W, H, rank, world)
@@ -278,13 +304,13 @@ def main():
 
             child = ("import sys; sys.path.insert(0, sys.argv[1]); import portal_amd as pa; "
                      "pa.SceneRenderer(pa.Scene.from_file(sys.argv[2]), device=-1, flags=int(sys.argv[3]))")
-            subprocess.run([sys.executable, "-c", child, HERE, pa.scene_path(args.scene), str(spec_flags | pa.flag_waves(waves))],
+            subprocess.run([sys.executable, "-c", child, HERE, scene_path, str(spec_flags | pa.flag_waves(waves))],
                            env=dict(os.environ, PTL_HIPRTC_FLAGS=((os.environ.get("PTL_HIPRTC_FLAGS", "") + " ") if os.environ.get("PTL_HIPRTC_FLAGS") else "") + extra_flags),
                            capture_output=True, timeout=600)
         saved = os.environ.get("PTL_HIPRTC_FLAGS")
         os.environ["PTL_HIPRTC_FLAGS"] = ((saved + " ") if saved else "") + extra_flags
         try:
-            r = pa.SceneRenderer(scene, device=local_rank, flags=spec_flags | pa.flag_waves(waves))
+            r = pa.SceneRenderer(scene, device=local_rank, flags=spec_flags | pa.flag_waves(waves), **scene_kw)
         finally:
             if saved is None:
                 os.environ.pop("PTL_HIPRTC_FLAGS", None)
@@ -309,7 +335,7 @@ def main():
     def prebuild(item):
         waves, extra = item
         if not extra:
-            pa.SceneRenderer(pa.Scene.from_file(pa.scene_path(args.scene)), device=-1, flags=spec_flags | pa.flag_waves(waves))
+            pa.SceneRenderer(pa.Scene.from_file(scene_path), device=-1, flags=spec_flags | pa.flag_waves(waves), **scene_kw)
 
     with ThreadPoolExecutor(max_workers=4) as pool:
         list(pool.map(prebuild, candidates.values()))
@@ -539,7 +565,7 @@ def main():
     try:
         if args.no_segments:
             raise RuntimeError("--no-segments")
-        counting = pa.SceneRenderer(scene, device=local_rank, flags=pa.FLAG_COUNT_SEGMENTS | spec_flags)
+        counting = pa.SceneRenderer(scene, device=local_rank, flags=pa.FLAG_COUNT_SEGMENTS | spec_flags, **scene_kw)
         configure(counting, args)
         seg = torch.zeros(1, dtype=torch.int64, device=dev)
         counting.draw_device(frame, out_rgba8=shard.data_ptr(), segments=seg.data_ptr(), stream=stream.cuda_stream)
@@ -561,7 +587,7 @@ def main():
             for base_flags in (0, pa.FLAG_SPECIALIZE_INTS):
                 timings = []
                 for waves in (0, 4):  # the two register budgets that matter for this kernel
-                    plain = pa.SceneRenderer(scene, device=local_rank, flags=base_flags | pa.flag_waves(waves))
+                    plain = pa.SceneRenderer(scene, device=local_rank, flags=base_flags | pa.flag_waves(waves), **scene_kw)
                     configure(plain, args)
                     for _ in range(8):
                         plain.draw_device(frame, out_rgba8=shard.data_ptr(), stream=stream.cuda_stream)
@@ -580,8 +606,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         try:
             f32 = torch.empty((2, H, W, 4), dtype=torch.float32, device=dev)
-            exact_r = pa.SceneRenderer(scene, device=local_rank, flags=spec_flags)
-            fast_r = pa.SceneRenderer(scene, device=local_rank, flags=spec_flags | pa.FLAG_FAST_MATH)
+            exact_r = pa.SceneRenderer(scene, device=local_rank, flags=spec_flags, **scene_kw)
+            fast_r = pa.SceneRenderer(scene, device=local_rank, flags=spec_flags | pa.FLAG_FAST_MATH, **scene_kw)
             for k, rr in enumerate((exact_r, fast_r)):
                 configure(rr, args)
                 rr.draw_device(frame, out_rgba8=shard.data_ptr(), out_rgba32f=f32[k].data_ptr(), stream=stream.cuda_stream)
@@ -606,7 +632,7 @@ def main():
             child = ("import sys, time; sys.path.insert(0, sys.argv[1]); import portal_amd as pa; s = pa.Scene.from_file(sys.argv[2]); t = time.perf_counter(); "
                      "pa.SceneRenderer(s, device=-1, flags=int(sys.argv[3])); print(time.perf_counter() - t)")
             with tempfile.TemporaryDirectory() as tmp:
-                done = subprocess.run([sys.executable, "-c", child, HERE, pa.scene_path(args.scene), str(spec_flags | pa.flag_waves(best_waves))],
+                done = subprocess.run([sys.executable, "-c", child, HERE, scene_path, str(spec_flags | pa.flag_waves(best_waves))],
                                       env=dict(os.environ, PTL_CACHE_DIR=tmp, AMD_COMGR_CACHE="0"), capture_output=True, text=True, timeout=300)
             jit_seconds = round(float(done.stdout.strip().splitlines()[-1]), 3)
         except Exception as e:
@@ -634,8 +660,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic: the reference's shipped scene file, no stage applied, camera from the scene `cam` block",
             "config": {
-                "workload": f"scenes/{args.scene}.ron {W}x{H} aa={args.aa} depth={args.depth}"
-                            + (f" panini d={args.panini} fov={args.fov}" if args.panini >= 0 else ""),
+                "workload": f"{args.scene_file or 'scenes/' + args.scene + '.ron'} {W}x{H} aa={args.aa} depth={args.depth}"
+                            + (f" panini d={args.panini} fov={args.fov}" if args.panini >= 0 else "") + (f" camera look_at,alpha,beta,r={args.camera}" if args.camera else ""),
+                "trips_per_primary_ray": None,
                 "parallelism": f"row-block interleave x{world}" + ("" if world == 1 else {
                     "rccl-gather": " + one RCCL gather to rank 0 + de-interleave copy, double-buffered (gather n overlaps trace n+1)",
                     "p2p-stores": " + kernel stores straight into rank 0's frame over xGMI (HIP IPC mapping), fenced by a 1-element RCCL all-reduce",
@@ -673,6 +700,7 @@ def main():
             "note": "algorithmic bytes = the RGBA8 framebuffer store (4 B/pixel); constants and textures are cache-resident",
         }
         if segments is not None:
+            out["config"]["trips_per_primary_ray"] = round(segments / rays, 4)
             out["segments_per_frame"] = segments
             out["segment_mray_s"] = round(segments / (ms_per_step * 1e-3) / 1e6, 3)
         fl = flops_per_segment(args)

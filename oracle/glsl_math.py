@@ -224,6 +224,19 @@ def fma(a, b, c):
     return out.reshape(shape) if shape != out.shape else out
 
 
+def term0(a, b):
+    """First term of a dot / matrix product chain.  Contract 2: fma(a, b, +0) -- the product, with an exact-zero result made +0
+    (portal_amd/csrc/device/ptl_glsl.h `ptl_term0`); contract 1: the bare product.  Counted as one multiplication."""
+    _count(1, None, (a, b,))
+    with np.errstate(**_err):
+        if CONTRACT == 1:
+            return np.multiply(a, b, dtype=F32)
+        # fma(a, b, +0): the exact product (binary64 holds it) plus +0, rounded once.  An exact zero product gives +0 whatever its
+        # sign; a non-zero product keeps its sign even when it underflows to zero.
+        p = np.asarray(a, F32).astype(F64) * np.asarray(b, F32).astype(F64)
+        return np.where(p == 0, F64(0), p).astype(F32)
+
+
 def lt(a, b):
     _count(1, None, (a, b,))
     return np.less(a, b)

@@ -252,7 +252,7 @@ def _scalar_binop(op, a, b):
 def mat_vec(m: Mat, v: Vec) -> Vec:
     out = []
     for i in range(m.n):
-        acc = M.mul(m.cols[0].c[i], v.c[0])
+        acc = M.term0(m.cols[0].c[i], v.c[0])  # contract 2: the chain starts from +0 (ptl_glsl.h `ptl_term`); contract 1: the bare product
         for j in range(1, m.n):
             acc = M.fma(m.cols[j].c[i], v.c[j], acc)
         out.append(acc)
@@ -260,7 +260,7 @@ def mat_vec(m: Mat, v: Vec) -> Vec:
 
 
 def dot(a: Vec, b: Vec):
-    acc = M.mul(a.c[0], b.c[0])
+    acc = M.term0(a.c[0], b.c[0])
     for i in range(1, a.n):
         acc = M.fma(a.c[i], b.c[i], acc)
     return acc
@@ -331,9 +331,14 @@ def normalize(a: Vec) -> Vec:
 
 
 def cross(a: Vec, b: Vec) -> Vec:
-    x = M.fma(a.c[1], b.c[2], M.neg(M.mul(a.c[2], b.c[1])))
-    y = M.fma(a.c[2], b.c[0], M.neg(M.mul(a.c[0], b.c[2])))
-    z = M.fma(a.c[0], b.c[1], M.neg(M.mul(a.c[1], b.c[0])))
+    if M.CONTRACT == 1:
+        x = M.fma(a.c[1], b.c[2], M.neg(M.mul(a.c[2], b.c[1])))
+        y = M.fma(a.c[2], b.c[0], M.neg(M.mul(a.c[0], b.c[2])))
+        z = M.fma(a.c[0], b.c[1], M.neg(M.mul(a.c[1], b.c[0])))
+        return Vec([x, y, z])
+    x = M.fma(a.c[1], b.c[2], M.term0(M.neg(a.c[2]), b.c[1]))
+    y = M.fma(a.c[2], b.c[0], M.term0(M.neg(a.c[0]), b.c[2]))
+    z = M.fma(a.c[0], b.c[1], M.term0(M.neg(a.c[1]), b.c[0]))
     return Vec([x, y, z])
 
 

@@ -31,6 +31,41 @@ namespace glsl {
 // ---------------------------------------------------------------------------------------
 PTL_FN float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// One term of a dot / matrix product chain: acc + a * b, rounded once.
+// CONTRACT 2: these chains START FROM +0 -- dot(a, b) = fma(a.z, b.z, fma(a.y, b.y, fma(a.x, b.x, +0))) -- where contract 1 took the bare
+// product a.x * b.x as the first term.  Same instruction count (a full-rate FMA for a full-rate MUL), same value; the only difference
+// is that an exact-zero result is +0, never -0.  What it buys: with an accumulator that is not -0, a term with a ZERO factor is an
+// exact no-op for every finite other factor (acc + (+-0) = acc, also when acc is +0).  So a MATRIX product may skip the terms whose
+// matrix element is zero -- `ptl_mterm` below, compiled in when the scene's matrices are baked into the source (PTL_DROP_ZERO_TERMS:
+// the comparison then folds at JIT time and the term is gone) -- which IEEE arithmetic alone never allows the compiler (0 * x is -0
+// for a negative x, NaN for an infinite one).  With the scene state baked in, 41 % of the floating-point instructions of the headline
+// snippet's loop were such products: portal matrices are mostly translations and quarter turns.
+// The deviation, stated: if the vector component of a skipped term is infinite or NaN, the full chain gives NaN and the shortened one
+// a number; and if a partial sum UNDERFLOWS to zero from a negative value (|a * b| < 2^-150: it is then -0 after all) the two can
+// differ in the sign of a zero.  The definition is the full chain (oracle/glsl_values.py; every build without PTL_DROP_ZERO_TERMS).
+PTL_FN float ptl_term(float a, float b, float acc) { return __builtin_fmaf(a, b, acc); }
+PTL_FN float ptl_term0(float a, float b) {  // the first term of a chain
+#if defined(PTL_CONTRACT_V1)
+    return a * b;
+#else
+    return __builtin_fmaf(a, b, 0.0f);
+#endif
+}
+PTL_FN float ptl_mterm(float m, float v, float acc) {  // m: a matrix element
+#if defined(PTL_DROP_ZERO_TERMS) && !defined(PTL_CONTRACT_V1)
+    return m == 0.0f ? acc : __builtin_fmaf(m, v, acc);
+#else
+    return __builtin_fmaf(m, v, acc);
+#endif
+}
+PTL_FN float ptl_mterm0(float m, float v) {
+#if defined(PTL_DROP_ZERO_TERMS) && !defined(PTL_CONTRACT_V1)
+    return m == 0.0f ? 0.0f : __builtin_fmaf(m, v, 0.0f);
+#else
+    return ptl_term0(m, v);
+#endif
+}
+
 // ---- division, reciprocal, square root: CONTRACT 2 (round 3, the default) ----------------------------------------------------
 // Every scalar division of the generated kernel is ptl_div(a, b); the scene snippets' `/` and `/=` are rewritten to it by the
 // translator (host/glsl_translate.cpp), the prelude and the template spell it.  The definitions, for every input:
@@ -610,9 +645,9 @@ PTL_FN vec4 smoothstep(const vec4& e0, const vec4& e1, const vec4& a) {
 }
 
 // geometric -----------------------------------------------------------------------------
-PTL_FN float dot(const vec2& a, const vec2& b) { return fma(a.y, b.y, a.x * b.x); }
-PTL_FN float dot(const vec3& a, const vec3& b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
-PTL_FN float dot(const vec4& a, const vec4& b) { return fma(a.w, b.w, fma(a.z, b.z, fma(a.y, b.y, a.x * b.x))); }
+PTL_FN float dot(const vec2& a, const vec2& b) { return ptl_term(a.y, b.y, ptl_term0(a.x, b.x)); }
+PTL_FN float dot(const vec3& a, const vec3& b) { return ptl_term(a.z, b.z, ptl_term(a.y, b.y, ptl_term0(a.x, b.x))); }
+PTL_FN float dot(const vec4& a, const vec4& b) { return ptl_term(a.w, b.w, ptl_term(a.z, b.z, ptl_term(a.y, b.y, ptl_term0(a.x, b.x)))); }
 PTL_FN float length(float a) { return abs(a); }
 PTL_FN float length(const vec2& a) { return sqrt(dot(a, a)); }
 PTL_FN float length(const vec3& a) { return sqrt(dot(a, a)); }
@@ -624,7 +659,11 @@ PTL_FN vec2 normalize(const vec2& a) { return a / length(a); }
 PTL_FN vec3 normalize(const vec3& a) { return a / length(a); }
 PTL_FN vec4 normalize(const vec4& a) { return a / length(a); }
 PTL_FN vec3 cross(const vec3& a, const vec3& b) {
+#if defined(PTL_CONTRACT_V1)
     return vec3(fma(a.y, b.z, -(a.z * b.y)), fma(a.z, b.x, -(a.x * b.z)), fma(a.x, b.y, -(a.y * b.x)));
+#else
+    return vec3(ptl_term(a.y, b.z, ptl_term0(-a.z, b.y)), ptl_term(a.z, b.x, ptl_term0(-a.x, b.z)), ptl_term(a.x, b.y, ptl_term0(-a.y, b.x)));
+#endif
 }
 PTL_FN vec2 reflect(const vec2& i, const vec2& n) { return i - n * (2.0f * dot(n, i)); }
 PTL_FN vec3 reflect(const vec3& i, const vec3& n) { return i - n * (2.0f * dot(n, i)); }
@@ -680,12 +719,12 @@ struct mat4 {
 PTL_FN mat3::mat3(const mat4& m) { c[0] = vec3(m.c[0]); c[1] = vec3(m.c[1]); c[2] = vec3(m.c[2]); }
 
 PTL_FN vec2 operator*(const mat2& m, const vec2& v) {
-    return vec2(fma(m.c[1].x, v.y, m.c[0].x * v.x), fma(m.c[1].y, v.y, m.c[0].y * v.x));
+    return vec2(ptl_mterm(m.c[1].x, v.y, ptl_mterm0(m.c[0].x, v.x)), ptl_mterm(m.c[1].y, v.y, ptl_mterm0(m.c[0].y, v.x)));
 }
 PTL_FN vec3 operator*(const mat3& m, const vec3& v) {
-    return vec3(fma(m.c[2].x, v.z, fma(m.c[1].x, v.y, m.c[0].x * v.x)),
-                fma(m.c[2].y, v.z, fma(m.c[1].y, v.y, m.c[0].y * v.x)),
-                fma(m.c[2].z, v.z, fma(m.c[1].z, v.y, m.c[0].z * v.x)));
+    return vec3(ptl_mterm(m.c[2].x, v.z, ptl_mterm(m.c[1].x, v.y, ptl_mterm0(m.c[0].x, v.x))),
+                ptl_mterm(m.c[2].y, v.z, ptl_mterm(m.c[1].y, v.y, ptl_mterm0(m.c[0].y, v.x))),
+                ptl_mterm(m.c[2].z, v.z, ptl_mterm(m.c[1].z, v.y, ptl_mterm0(m.c[0].z, v.x))));
 }
 #if PTL_DEVICE_BUILD && defined(PTL_PACKED_MATVEC)
 // Two result components per instruction: v_pk_mul_f32 / v_pk_fma_f32 (gfx950 packed binary32: two IEEE operations per lane and
@@ -701,12 +740,19 @@ PTL_FN vec4 operator*(const mat4& m, const vec4& v) {
 }
 #else
 PTL_FN vec4 operator*(const mat4& m, const vec4& v) {
-    return vec4(fma(m.c[3].x, v.w, fma(m.c[2].x, v.z, fma(m.c[1].x, v.y, m.c[0].x * v.x))),
-                fma(m.c[3].y, v.w, fma(m.c[2].y, v.z, fma(m.c[1].y, v.y, m.c[0].y * v.x))),
-                fma(m.c[3].z, v.w, fma(m.c[2].z, v.z, fma(m.c[1].z, v.y, m.c[0].z * v.x))),
-                fma(m.c[3].w, v.w, fma(m.c[2].w, v.z, fma(m.c[1].w, v.y, m.c[0].w * v.x))));
+    return vec4(ptl_mterm(m.c[3].x, v.w, ptl_mterm(m.c[2].x, v.z, ptl_mterm(m.c[1].x, v.y, ptl_mterm0(m.c[0].x, v.x)))),
+                ptl_mterm(m.c[3].y, v.w, ptl_mterm(m.c[2].y, v.z, ptl_mterm(m.c[1].y, v.y, ptl_mterm0(m.c[0].y, v.x)))),
+                ptl_mterm(m.c[3].z, v.w, ptl_mterm(m.c[2].z, v.z, ptl_mterm(m.c[1].z, v.y, ptl_mterm0(m.c[0].z, v.x)))),
+                ptl_mterm(m.c[3].w, v.w, ptl_mterm(m.c[2].w, v.z, ptl_mterm(m.c[1].w, v.y, ptl_mterm0(m.c[0].w, v.x)))));
 }
 #endif
+// the same product for a matrix that is a run-time value in every build (the camera): no zero tests (they would be executed)
+PTL_FN vec4 ptl_mul_runtime(const mat4& m, const vec4& v) {
+    return vec4(ptl_term(m.c[3].x, v.w, ptl_term(m.c[2].x, v.z, ptl_term(m.c[1].x, v.y, ptl_term0(m.c[0].x, v.x)))),
+                ptl_term(m.c[3].y, v.w, ptl_term(m.c[2].y, v.z, ptl_term(m.c[1].y, v.y, ptl_term0(m.c[0].y, v.x)))),
+                ptl_term(m.c[3].z, v.w, ptl_term(m.c[2].z, v.z, ptl_term(m.c[1].z, v.y, ptl_term0(m.c[0].z, v.x)))),
+                ptl_term(m.c[3].w, v.w, ptl_term(m.c[2].w, v.z, ptl_term(m.c[1].w, v.y, ptl_term0(m.c[0].w, v.x)))));
+}
 // row vector times matrix: component i is dot(v, column i)
 PTL_FN vec2 operator*(const vec2& v, const mat2& m) { return vec2(dot(v, m.c[0]), dot(v, m.c[1])); }
 PTL_FN vec3 operator*(const vec3& v, const mat3& m) { return vec3(dot(v, m.c[0]), dot(v, m.c[1]), dot(v, m.c[2])); }

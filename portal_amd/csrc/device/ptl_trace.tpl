@@ -122,7 +122,7 @@ PTL_FN void derive(ptl_uniform_block* out) {
 #ifdef PTL_DERIVED_BUILTINS
     // per-PIXEL work that depends on nothing but the frame's builtins: the ray origins, tan(fov / 2), the reciprocal of the frame size
     // -- ~100 VALU instructions every pixel would otherwise repeat (tan alone is two polynomial kernels and a division)
-    out->ptl_dv_origin = _camera * vec4(0.0f, 0.0f, 0.0f, 1.0f);
+    out->ptl_dv_origin = ptl_mul_runtime(_camera, vec4(0.0f, 0.0f, 0.0f, 1.0f));
     out->ptl_dv_origin_left = _camera_left_eye * vec4(0.0f, 0.0f, 0.0f, 1.0f);
     out->ptl_dv_origin_right = _camera_right_eye * vec4(0.0f, 0.0f, 0.0f, 1.0f);
     out->ptl_dv_tan_half_view = tan(ptl_div(_view_angle, 2.0f));
@@ -424,14 +424,14 @@ PTL_FN vec4 camera_times(const mat4& camera_matrix, int which_eye, vec4 v) {
         const int eye = __builtin_amdgcn_readfirstlane(which_eye);
         if (which_eye == eye) {
             const mat4& m = eye == 0 ? _camera : (eye == 1 ? _camera_left_eye : _camera_right_eye);
-            product = m * v;
+            product = ptl_mul_runtime(m, v);  // a run-time matrix in every build: the full chain, no zero tests (ptl_glsl.h `ptl_mterm`)
             done = true;
         }
     }
     return product;
 #else
     (void)which_eye;
-    return camera_matrix * v;
+    return ptl_mul_runtime(camera_matrix, v);
 #endif
 }
 

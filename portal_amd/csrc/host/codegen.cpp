@@ -772,7 +772,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     {
         StringStorage s;
         if (scene.skybox) {
-            s.add_string("vec4 rd2 = _camera_mul_inv * r.d;");
+            s.add_string("vec4 rd2 = ptl_mul_runtime(_camera_mul_inv, r.d);");
             s.add_string("float u = atan(rd2.z, rd2.x);");
             s.add_string("float v = atan(sqrt(rd2.x * rd2.x + rd2.z * rd2.z), rd2.y);");
             s.add_string("vec3 not_found_color = sqrvec(texture(" + *scene.skybox + "_tex, vec2(ptl_div(ptl_div(u, PI) + 1.0f, 2.0f), ptl_div(v, PI))).sw<0,1,2>());");
@@ -803,6 +803,8 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     if (opts.anaglyph) gk.defines.push_back("PTL_ANAGLYPH");
     if (opts.fast_math) gk.defines.push_back("PTL_FAST_MATH");
     if (opts.exact_cr) gk.defines.push_back("PTL_CONTRACT_V1");
+    // matrices baked into the source: a matrix product skips the terms whose matrix element is zero (device/ptl_glsl.h `ptl_mterm`)
+    if ((opts.specialize_all || opts.specialize_static) && !opts.exact_cr && !opts.fast_math) gk.defines.push_back("PTL_DROP_ZERO_TERMS");
     if (gk.first_trip_variants) gk.defines.push_back("PTL_FIRST_TRIP");
     return gk;
 }

@@ -125,6 +125,8 @@ VARIANTS = {
     "r3_v1_all": "EXACT_CR SPECIALIZE_ALL", "r3_v1_all_w4": "EXACT_CR SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4",
     "r3_dyn": "", "r3_v1_dyn": "EXACT_CR", "r3_ints": "SPECIALIZE", "r3_v1_ints": "EXACT_CR SPECIALIZE",
     "r3_fast_all_w4": "FAST SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4",
+    # upper bound of what folding products with literal zeros could give the EXACT kernel (not a shippable build: nnan also deletes the NaN selects of 1/x and sqrt)
+    "r3_all_w4_zerofold": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -fno-signed-zeros -fno-honor-nans",
 }
 CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
 
