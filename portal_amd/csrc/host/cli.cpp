@@ -312,6 +312,15 @@ int render_frame_processes(const Options& o, const std::vector<int>& devices) {
     unsigned char handle[PTL_IPC_HANDLE_BYTES];
     if (ptl_device_alloc(devices[0], bytes, &frame) != PTL_OK || ptl_ipc_export(frame, handle) != PTL_OK) return fail("frame buffer / ipc export");
     std::vector<pid_t> children;
+    // every failure path below reaps the shard processes already forked: they render into `frame`, which dies with this process
+    auto reap = [&](int rc) {
+        for (pid_t pid : children) {
+            int status = 0;
+            ::waitpid(pid, &status, 0);
+        }
+        children.clear();
+        return rc;
+    };
     for (int k = 1; k < n; ++k) {
         std::vector<std::string> args = o.argv;
         args[1] = "render-shard";
@@ -327,19 +336,19 @@ int render_frame_processes(const Options& o, const std::vector<int>& devices) {
             std::perror("execv");
             ::_exit(127);
         }
-        if (pid < 0) return fail("fork");
+        if (pid < 0) return reap(fail("fork"));
         children.push_back(pid);
     }
     std::vector<char> log(1 << 16);
     ptl_renderer* r = nullptr;
     if (ptl_renderer_create(scene, devices[0], o.asset_root.c_str(), frame_flags(o), &r, log.data(), log.size()) != PTL_OK) {
         std::fprintf(stderr, "renderer: %s\n%s\n", ptl_last_error(), log.data());
-        return 1;
+        return reap(1);
     }
-    if (int rc = setup_renderer(o, scene, r, true)) return rc;
+    if (int rc = setup_renderer(o, scene, r, true)) return reap(rc);
     ptl_frame f{o.width, o.height, 0, n, 1};
     float ms = 0.0f;
-    if (ptl_renderer_draw(r, &f, frame, nullptr, nullptr, nullptr, &ms) != PTL_OK) return fail("render");
+    if (ptl_renderer_draw(r, &f, frame, nullptr, nullptr, nullptr, &ms) != PTL_OK) return reap(fail("render"));
     int failed = 0;
     for (pid_t pid : children) {
         int status = 0;

@@ -560,7 +560,10 @@ class Hoister {
         const Node& nd = nodes_[id];
         if (nd.kind == Node::Assign) ++writes_[base_identifier(nd.kids[0])];
         if (nd.kind == Node::Post || (nd.kind == Node::Unary && (nd.text == "++" || nd.text == "--"))) ++writes_[base_identifier(nd.kids[0])];
-        if (nd.kind == Node::Call && P.functions_with_out_params.count(nd.text))
+        // ... and the GLSL built-ins that write through an argument (GLSL ES 3.00 8.3, 8.8): `float ip = 0.0; f = modf(x, ip);` leaves
+        // `ip` written twice, not a write-once uniform local (the prelude has no modf / frexp today; the day it gets one this must hold)
+        static const std::set<std::string> builtin_out = {"modf", "frexp", "umulExtended", "imulExtended", "uaddCarry", "usubBorrow"};
+        if (nd.kind == Node::Call && (P.functions_with_out_params.count(nd.text) || builtin_out.count(nd.text)))
             for (int k : nd.kids) ++writes_[base_identifier(k)];
         for (int k : nd.kids) count_writes(k);
     }

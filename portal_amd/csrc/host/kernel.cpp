@@ -121,6 +121,9 @@ struct ptl_kernel {
     std::map<std::string, Slot> slots;
     std::map<std::string, void*> textures;  // sampler -> device texel buffer
     hip::hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hip::hipEvent_t ev_done = nullptr;  // recorded behind every render launch: what destroy / a teleport query wait for.  Owned here, so it
+                                        // stays valid when the caller has already destroyed the stream it launched on (a torch stream, a
+                                        // user stream freed before the renderer: Python __del__ order is unspecified).
     unsigned block_waves = 4;       // PTL_BLOCK_WAVES (experiments with narrower workgroups), read once at compile time
     void* last_stream = nullptr;    // the stream of the most recent render launch ...
     bool launched = false;          // ... which may still be reading the uniform block
@@ -161,6 +164,8 @@ static size_t type_size(ptl_type t) {
     return 0;
 }
 
+static thread_local bool tl_skip_cache_read = false;  // set for the one retry after the runtime refused a cached code object
+
 extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_uniform_desc* uniforms, int n_uniforms,
                                   size_t uniform_block_size, const char* const* defines, int n_defines, ptl_kernel** out, char* log,
                                   size_t log_cap) {
@@ -198,7 +203,7 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
         std::snprintf(name, sizeof name, "/ptl_%016llx.hsaco", h);
         cache_path = cdir + name;
         std::ifstream f(cache_path, std::ios::binary);
-        if (f) k->code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        if (f && !tl_skip_cache_read) k->code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
         if (k->code.size() < 64 || std::memcmp(k->code.data(), "\x7f" "ELF", 4) != 0) k->code.clear();  // truncated or foreign file: compile again
     }
     bool from_cache = !k->code.empty();
@@ -262,9 +267,14 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
     if (!hip_ok(rt, rt->hipSetDevice(device), "hipSetDevice")) return PTL_ERR_HIP;
     if (!hip_ok(rt, rt->hipModuleLoadData(&k->module, k->code.data()), "hipModuleLoadData")) {
         if (from_cache && !cache_path.empty()) {
-            // a cached code object this runtime refuses (other GPU, damaged file): drop it and build from source once
+            // a cached code object this runtime refuses (other GPU, damaged file): drop it and build from source ONCE.  The retry does
+            // not read the cache again -- the file may be undeletable (a read-only or shared cache directory travels from the build
+            // container to the GPU box), and re-reading it would recurse without end.
             std::remove(cache_path.c_str());
-            return ptl_kernel_compile(device, hip_source, uniforms, n_uniforms, uniform_block_size, defines, n_defines, out, log, log_cap);
+            tl_skip_cache_read = true;
+            const int rc2 = ptl_kernel_compile(device, hip_source, uniforms, n_uniforms, uniform_block_size, defines, n_defines, out, log, log_cap);
+            tl_skip_cache_read = false;
+            return rc2;
         }
         return PTL_ERR_HIP;
     }
@@ -287,6 +297,7 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
     }
     rt->hipEventCreate(&k->ev0);
     rt->hipEventCreate(&k->ev1);
+    rt->hipEventCreateWithFlags(&k->ev_done, hip::kEventDisableTiming);
     if (const char* e = std::getenv("PTL_BLOCK_WAVES")) k->block_waves = (e[0] == '1' || e[0] == '2') ? (unsigned)(e[0] - '0') : 4u;
     *out = k.release();
     return PTL_OK;
@@ -401,6 +412,7 @@ extern "C" int ptl_kernel_render(ptl_kernel* k, const ptl_frame* frame, void* ou
     if (!hip_ok(rt, rt->hipModuleLaunchKernel(k->fn, gx, gy, 1, 64 * waves, 1, 1, 0, stream, args, nullptr), "hipModuleLaunchKernel")) return PTL_ERR_HIP;
     k->last_stream = stream;
     k->launched = true;
+    if (k->ev_done) rt->hipEventRecord(k->ev_done, stream);
     if (elapsed_ms) {
         rt->hipEventRecord(k->ev1, stream);
         if (!hip_ok(rt, rt->hipEventSynchronize(k->ev1), "hipEventSynchronize")) return PTL_ERR_HIP;
@@ -460,7 +472,7 @@ extern "C" int ptl_kernel_teleport_ray(ptl_kernel* k, const float a[3], const fl
     if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;
     // The query rewrites the module's ONE uniform block (segment end points, teleport_light_u) and runs on the NULL stream; a frame
     // launched on a non-blocking stream may still be reading the block: wait for it first.
-    if (k->launched && k->last_stream != nullptr && !hip_ok(rt, rt->hipStreamSynchronize(k->last_stream), "hipStreamSynchronize(render stream)")) return PTL_ERR_HIP;
+    if (k->launched && k->ev_done && !hip_ok(rt, rt->hipEventSynchronize(k->ev_done), "hipEventSynchronize(last render launch)")) return PTL_ERR_HIP;
     if (int rc2 = upload_uniforms(k, rt, nullptr); rc2 != PTL_OK) return rc2;
     void* dev_out = nullptr;
     if (!hip_ok(rt, rt->hipMalloc(&dev_out, 8 * sizeof(float)), "hipMalloc(teleport result)")) return PTL_ERR_HIP;
@@ -482,7 +494,8 @@ extern "C" void ptl_kernel_destroy(ptl_kernel* k) {
     const hip::Runtime* rt = k->device >= 0 ? hip::runtime(nullptr) : nullptr;
     if (rt) {
         rt->hipSetDevice(k->device);
-        if (k->launched) rt->hipStreamSynchronize(k->last_stream);  // a re-JIT replaces the handle: nothing may still run from the old module
+        if (k->launched && k->ev_done) rt->hipEventSynchronize(k->ev_done);  // a re-JIT replaces the handle: nothing may still run from the old module
+        if (k->ev_done) rt->hipEventDestroy(k->ev_done);
         for (auto& t : k->textures)
             if (t.second) rt->hipFree(t.second);
         if (k->ev0) rt->hipEventDestroy(k->ev0);

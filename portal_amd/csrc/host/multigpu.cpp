@@ -185,16 +185,25 @@ extern "C" int ptl_frame_group_draw(ptl_frame_group* g, int width, int height, v
     }
     g->width = width;
     g->height = height;
+    // A failure on rank k must not leave the launches of ranks 0..k-1 in flight into g->frame / g->shards: the next draw may free them
+    // (release_buffers on a size change).  Every early return below first drains what has been started.
+    auto drain = [&](int started, int rc) {
+        for (int j = 0; j < started; ++j) {
+            rt->hipSetDevice(g->devices[j]);
+            rt->hipStreamSynchronize(g->streams[j]);
+        }
+        return rc;
+    };
     for (int k = 0; k < n; ++k) {
-        if (int rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice"); rc != PTL_OK) return rc;
+        if (int rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice"); rc != PTL_OK) return drain(k, rc);
         rt->hipEventRecord(g->begin[k], g->streams[k]);
         if (g->transport == PTL_GROUP_PEER_STORES) {
             ptl_frame f{width, height, k, n, 1};
-            if (int rc = ptl_renderer_draw(g->renderers[k], &f, g->frame, nullptr, nullptr, g->streams[k], nullptr); rc != PTL_OK) return rc;
+            if (int rc = ptl_renderer_draw(g->renderers[k], &f, g->frame, nullptr, nullptr, g->streams[k], nullptr); rc != PTL_OK) return drain(k + 1, rc);
             rt->hipEventRecord(g->end[k], g->streams[k]);
         } else {
             ptl_frame f{width, height, k, n, 0};
-            if (int rc = ptl_renderer_draw(g->renderers[k], &f, g->shards[k], nullptr, nullptr, g->streams[k], nullptr); rc != PTL_OK) return rc;
+            if (int rc = ptl_renderer_draw(g->renderers[k], &f, g->shards[k], nullptr, nullptr, g->streams[k], nullptr); rc != PTL_OK) return drain(k + 1, rc);
             rt->hipEventRecord(g->end[k], g->streams[k]);  // kernel time; the copy below is behind it on the same stream
             const int my_blocks = blocks > k ? (blocks - k + n - 1) / n : 0;
             if (my_blocks > 0) {
@@ -204,13 +213,13 @@ extern "C" int ptl_frame_group_draw(ptl_frame_group* g, int width, int height, v
                                                                hip::kMemcpyDefault, g->streams[k]),
                                       "hipMemcpy2DAsync(shard -> frame)");
                     rc != PTL_OK)
-                    return rc;
+                    return drain(k + 1, rc);
             }
         }
     }
     for (int k = 0; k < n; ++k) {
-        if (int rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice"); rc != PTL_OK) return rc;
-        if (int rc = hip_fail(rt, rt->hipStreamSynchronize(g->streams[k]), "hipStreamSynchronize(rank)"); rc != PTL_OK) return rc;
+        if (int rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice"); rc != PTL_OK) return drain(n, rc);
+        if (int rc = hip_fail(rt, rt->hipStreamSynchronize(g->streams[k]), "hipStreamSynchronize(rank)"); rc != PTL_OK) return drain(n, rc);
         if (kernel_ms) rt->hipEventElapsedTime(&kernel_ms[k], g->begin[k], g->end[k]);
     }
     if (device_rgba8) *device_rgba8 = g->frame;

@@ -215,3 +215,23 @@ def test_exact_cr_kernel_reproduces_the_contract_1_goldens(gpu, path, build):
     out = r.draw(w, h, rgba8=True, rgba32f=True, segments=True)
     assert np.array_equal(out["rgba32f"].view(np.uint32), g["rgba32f_bits"]) and np.array_equal(out["rgba8"], g["rgba8"])
     assert out["segments"] == int(g["segments"].sum())
+
+
+def test_a_cached_code_object_the_runtime_refuses_is_rebuilt_once(gpu, tmp_path, monkeypatch):
+    """a cached .hsaco that passes the ELF check but that hipModuleLoadData refuses (another GPU, a damaged file) is dropped
+    and the kernel is built from source -- ONCE, without reading the cache again (a file that cannot be removed used to recurse)."""
+    pa = gpu
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    monkeypatch.setenv("PTL_CACHE_DIR", str(cache))
+    scene = pa.Scene.from_file(pa.scene_path("basics"))
+    first = pa.SceneRenderer(scene, device=0).draw(64, 36)["rgba8"]
+    files = sorted(cache.glob("*.hsaco"))
+    assert files
+    for f in files:  # keep the ELF magic, break the rest
+        data = bytearray(f.read_bytes())
+        data[64:] = bytes(len(data) - 64)
+        f.write_bytes(bytes(data))
+    again = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("basics")), device=0).draw(64, 36)["rgba8"]
+    assert np.array_equal(first, again)
+    assert any(f.read_bytes()[64:200] != bytes(136) for f in cache.glob("*.hsaco"))  # a fresh build took the damaged file's place

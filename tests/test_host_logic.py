@@ -1112,3 +1112,15 @@ def test_first_trip_copy_declares_the_rays_a_plain_uniform_expression_reads(pa):
     assert np.array_equal(frames["first"].view(np.uint32), frames["general"].view(np.uint32))
     assert np.array_equal(frames["first_baked"].view(np.uint32), frames["general"].view(np.uint32))
     assert len(np.unique(frames["first"].reshape(-1, 4), axis=0)) > 30
+
+
+def test_hoister_counts_the_out_arguments_of_glsl_builtins_as_writes(pa):
+    """`float ip = 0.0; f = modf(x, ip);` writes `ip` through an argument -- it is not a write-once uniform local, and
+    `ip * k_u * k_u * k_u` must not move to the prologue with ip = 0.0 (latent: the prelude has no modf / frexp yet)."""
+    uniforms = {"k_u": "float", "x_u": "float"}
+    code = "float ip = 0.0;\nfloat f = modf(x_u, ip);\nreturn vec4(ip * k_u * k_u * k_u + r.d.x, f, 0.0, 0.0);"
+    out, prologue = pa.hoist_glsl(code, uniforms, params=["r"])
+    assert "ip * k_u * k_u * k_u" in out and "ip" not in prologue
+    # the same shape without the call IS a uniform local and does move
+    plain, prologue = pa.hoist_glsl(code.replace("float f = modf(x_u, ip);", "float f = x_u;"), uniforms, params=["r"])
+    assert "PTL_U.ptl_hv" in plain and "ip * k_u * k_u * k_u" in prologue
