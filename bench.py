@@ -134,6 +134,7 @@ def parse_args():
     p.add_argument("--specialize", type=int, default=2, help="JIT specialisation: 0 none, 1 bake Bool/Int scene uniforms, 2 bake all scene uniforms")
     p.add_argument("--waves", type=int, default=-1, help="occupancy hint (__launch_bounds__(256, n)); -1 = pick the fastest candidate build before timing")
     p.add_argument("--build", default="", help="pin one candidate build by name (w0, w3, w4, minreg) instead of picking the fastest")
+    p.add_argument("--extra-flags", type=int, default=0, help="extra SceneRenderer flag bits for A/B measurements (e.g. 16384 = FLAG_EXACT_CR, the round-2 numerics contract)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-second-workload", action="store_true", help="skip the C5 frames that follow the headline's timed region (`second_workload` in the JSON line)")
     p.add_argument("--no-segments", action="store_true", help="skip the trip-counting launch after the timed region (PMC passes: the last launches of "
@@ -293,7 +294,7 @@ def main():
     rows = pa.shard_rows(frame)
     shard = parallel.alloc_shard(H, W, world, dev)
     stream = torch.cuda.current_stream(dev)
-    spec_flags = {0: 0, 1: pa.FLAG_SPECIALIZE_INTS, 2: pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL}[args.specialize]
+    spec_flags = {0: 0, 1: pa.FLAG_SPECIALIZE_INTS, 2: pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL}[args.specialize] | args.extra_flags
 
     def make_renderer(waves, extra_flags=""):
         # PTL_HIPRTC_FLAGS is read when the kernel is compiled (and is part of the code-object cache key).  LLVM's -mllvm options are

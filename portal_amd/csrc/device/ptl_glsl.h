@@ -45,21 +45,21 @@ PTL_FN float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // differ in the sign of a zero.  The definition is the full chain (oracle/glsl_values.py; every build without PTL_DROP_ZERO_TERMS).
 PTL_FN float ptl_term(float a, float b, float acc) { return __builtin_fmaf(a, b, acc); }
 PTL_FN float ptl_term0(float a, float b) {  // the first term of a chain
-#if defined(PTL_CONTRACT_V1)
+#if defined(PTL_CONTRACT_V1) || defined(PTL_CHAIN_FROM_PRODUCT)  /* (the second: an A/B switch for tools/variants.py, not a contract) */
     return a * b;
 #else
     return __builtin_fmaf(a, b, 0.0f);
 #endif
 }
 PTL_FN float ptl_mterm(float m, float v, float acc) {  // m: a matrix element
-#if defined(PTL_DROP_ZERO_TERMS) && !defined(PTL_CONTRACT_V1)
+#if defined(PTL_DROP_ZERO_TERMS) && !defined(PTL_CONTRACT_V1) && !defined(PTL_KEEP_ZERO_TERMS)  /* (the last: A/B switch, tools/variants.py) */
     return m == 0.0f ? acc : __builtin_fmaf(m, v, acc);
 #else
     return __builtin_fmaf(m, v, acc);
 #endif
 }
 PTL_FN float ptl_mterm0(float m, float v) {
-#if defined(PTL_DROP_ZERO_TERMS) && !defined(PTL_CONTRACT_V1)
+#if defined(PTL_DROP_ZERO_TERMS) && !defined(PTL_CONTRACT_V1) && !defined(PTL_KEEP_ZERO_TERMS)
     return m == 0.0f ? 0.0f : __builtin_fmaf(m, v, 0.0f);
 #else
     return ptl_term0(m, v);

@@ -126,6 +126,8 @@ VARIANTS = {
     "r3_dyn": "", "r3_v1_dyn": "EXACT_CR", "r3_ints": "SPECIALIZE", "r3_v1_ints": "EXACT_CR SPECIALIZE",
     "r3_fast_all_w4": "FAST SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4",
     # upper bound of what folding products with literal zeros could give the EXACT kernel (not a shippable build: nnan also deletes the NaN selects of 1/x and sqrt)
+    "r3_all_w6": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=6", "r3_all_minreg": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg",
+    "r3_dyn_mulfirst": "-DPTL_CHAIN_FROM_PRODUCT", "r3_all_mulfirst": "SPECIALIZE_ALL -DPTL_CHAIN_FROM_PRODUCT",
     "r3_all_w4_zerofold": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -fno-signed-zeros -fno-honor-nans",
 }
 CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
