@@ -8,6 +8,7 @@
 #include <charconv>
 #include <cmath>
 #include <cstdio>
+#include <regex>
 #include <set>
 #include <sstream>
 
@@ -332,6 +333,30 @@ struct SnippetTranslator {
     std::vector<HoistedMember> members;
     std::string prologue;  // GLSL
     int next_member = 0;
+    // Int uniforms baked into this build, with their values: a counting loop `for (int k = 0; k < NAME_u; k++)` of a snippet whose bound
+    // is one of them (and small) is unrolled.  The same operations in the same order -- identical frames -- but every iteration
+    // then has its own constants: the loop counter (`size` of scenes/portal_in_portal.ron:1144 drives an inner loop and a material
+    // index) and, with the matrices baked too, whatever the iteration does to loop-carried uniform values.  Measured on the headline
+    // (profiles/r03/stub_profile.jsonl `pip_unrolled`, variants5_unroll.jsonl): 0.409 -> 0.350 ms, same frame hash.
+    std::map<std::string, int> unroll_bounds;
+    static constexpr int kUnrollLimit = 16;
+
+    std::string unrolled(std::string cxx) const {
+        if (unroll_bounds.empty()) return cxx;
+        static const std::regex loop(R"(for \(int (\w+) = 0; (\w+) < (\w+); (\w+)\+\+\) \{)");
+        std::string out;
+        auto begin = std::sregex_iterator(cxx.begin(), cxx.end(), loop);
+        size_t last = 0;
+        for (auto it = begin; it != std::sregex_iterator(); ++it) {
+            const std::smatch& m = *it;
+            out.append(cxx, last, (size_t)m.position() - last);
+            last = (size_t)m.position();
+            auto b = unroll_bounds.find(m[3].str());
+            if (m[1] == m[2] && m[1] == m[4] && b != unroll_bounds.end() && b->second >= 2 && b->second <= kUnrollLimit) out += "_Pragma(\"unroll\") ";
+        }
+        out.append(cxx, last, std::string::npos);
+        return out;
+    }
 
     void prepare(const std::string& code, const HoistParams& base, bool body_only, std::vector<std::string> params) {
         HoistParams hp = base;
@@ -357,10 +382,10 @@ struct SnippetTranslator {
         prologue += r.prologue;
     }
     bool has_first(const std::string& code) const { return hoisted_first.count(&code) != 0; }
-    std::string first(const std::string& code) const { return translate_glsl(hoisted_first.at(&code), flags.defer_loop_updates); }
+    std::string first(const std::string& code) const { return unrolled(translate_glsl(hoisted_first.at(&code), flags.defer_loop_updates)); }
     std::string operator()(const std::string& code) const {
         auto it = hoisted.find(&code);
-        return translate_glsl(it != hoisted.end() ? it->second : filter_tagged_lines(code, flags), flags.defer_loop_updates);
+        return unrolled(translate_glsl(it != hoisted.end() ? it->second : filter_tagged_lines(code, flags), flags.defer_loop_updates));
     }
 };
 
@@ -424,7 +449,7 @@ struct PortalMaterialNames {
 GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& flags, const KernelOptions& opts) {
     GeneratedKernel gk;
     std::map<std::string, StringStorage> storages;
-    SnippetTranslator snippet{flags, {}, {}, {}, {}, 0};
+    SnippetTranslator snippet{flags, {}, {}, {}, {}, 0, {}};
 
     // --- uniform block --------------------------------------------------------------------
     {
@@ -459,6 +484,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 bool all = opts.specialize_all || opts.specialize_static;
                 if (up.type == UniformType::Int1) {
                     baked[up.name] = std::to_string(up.i);
+                    if (opts.unroll_baked_loops) snippet.unroll_bounds[up.name] = up.i;
                 } else if (all && up.type == UniformType::Float1) {
                     baked[up.name] = hexf(up.f[0]);
                 } else if (all && up.type == UniformType::Mat4) {

@@ -88,6 +88,8 @@ struct KernelOptions {
     // first-trip variants of the intersection-material snippets (ptl_trace.tpl PTL_FIRST_TRIP): the origin half of their ray arithmetic
     // comes from the prologue while the ray still starts at the camera.  Needs derived_uniforms and hoist_uniform_work.
     bool first_trip = true;
+    // snippet loops whose bound is a baked Int uniform (<= 16) are unrolled (codegen.cpp SnippetTranslator::unrolled): identical frames
+    bool unroll_baked_loops = true;
     bool exact_cr = false;   // PTL_CONTRACT_V1: the rounds-1-2 numerics contract (IEEE correctly rounded / and sqrt for every input) instead of contract 2 (device/ptl_glsl.h)
     bool fast_math = false;  // PTL_FAST_MATH: hardware rcp / sqrt / rsq (1 ulp), a/b = a * rcp(b), FMA contraction: tolerance mode, not bit-exact
 };

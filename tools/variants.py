@@ -128,6 +128,7 @@ VARIANTS = {
     # upper bound of what folding products with literal zeros could give the EXACT kernel (not a shippable build: nnan also deletes the NaN selects of 1/x and sqrt)
     "r3_all_w6": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=6", "r3_all_minreg": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg",
     "r3_dyn_mulfirst": "-DPTL_CHAIN_FROM_PRODUCT", "r3_all_mulfirst": "SPECIALIZE_ALL -DPTL_CHAIN_FROM_PRODUCT",
+    "r3_all_nounroll": "SPECIALIZE_ALL NO_UNROLL", "r3_all_w4_nounroll": "SPECIALIZE_ALL NO_UNROLL -DPTL_WAVES_PER_EU=4", "r3_ints_nounroll": "SPECIALIZE NO_UNROLL",
     "r3_all_w4_zerofold": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -fno-signed-zeros -fno-honor-nans",
 }
 CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
@@ -147,7 +148,7 @@ def run_one(case, vname, flags):
     w, h, d, aa = int(w), int(h), int(d), int(aa)
     toks = flags.split()
     rflags = (pa.FLAG_SPECIALIZE_INTS if ("SPECIALIZE" in toks or "SPECIALIZE_ALL" in toks) else 0) | (pa.FLAG_SPECIALIZE_ALL if "SPECIALIZE_ALL" in toks else 0)
-    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0) | (pa.FLAG_NO_DEFERRED_UPDATES if "NO_DEFER" in toks else 0) | (pa.FLAG_NO_UNIFORM_HOIST if "NO_HOIST" in toks else 0) | (pa.FLAG_NO_FIRST_TRIP if "NO_FIRST_TRIP" in toks else 0) | (pa.FLAG_EXACT_CR if "EXACT_CR" in toks else 0)
+    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0) | (pa.FLAG_NO_DEFERRED_UPDATES if "NO_DEFER" in toks else 0) | (pa.FLAG_NO_UNIFORM_HOIST if "NO_HOIST" in toks else 0) | (pa.FLAG_NO_FIRST_TRIP if "NO_FIRST_TRIP" in toks else 0) | (pa.FLAG_EXACT_CR if "EXACT_CR" in toks else 0) | (pa.FLAG_NO_UNROLL if "NO_UNROLL" in toks else 0)
     # the VGPR allocator is an option the JIT always passes (kernel.cpp): select it through its own switch, not a second -mllvm
     ra = [t.split("=", 1)[1] for t in toks if t.startswith("-vgpr-regalloc=")]
     if "RA_DEFAULT" in toks:
