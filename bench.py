@@ -97,7 +97,12 @@ def flops_per_segment(args):
     # the translator defers loop-carried ray transforms nobody reads (glsl_translate.h): the kernel does not execute them, so they
     # are not counted as achieved work either (`..._executed`, tools/count_flops.py)
     executed = float(entry["per_segment"].get(which + "_executed", algorithmic))
-    return {"flops": executed, "which": which + ("_executed" if executed != algorithmic else ""), "algorithmic": algorithmic,
+    label = which + ("_executed" if executed != algorithmic else "")
+    # ... and with the scene's matrices baked into the source (--specialize 2) a matrix product skips the terms whose matrix element is
+    # zero (device/ptl_glsl.h `ptl_mterm`): counted by the oracle (`zero_term_flops_varying`) and taken off as well
+    if args.specialize == 2 and not (args.extra_flags & 16384) and "flops_varying_executed_baked" in entry["per_segment"]:
+        executed, label = float(entry["per_segment"]["flops_varying_executed_baked"]), "flops_varying_executed_baked"
+    return {"flops": executed, "which": label, "algorithmic": algorithmic,
             "sampled_pixels": entry["sampled_pixels"], "sampled_fraction_of_frame": entry["sampled_fraction_of_frame"],
             "all_flops": float(entry["per_segment"]["flops"])}
 
@@ -186,6 +191,35 @@ def cpu_baseline(args, pa):
         "sample": f"{reps} x {len(picked)} of {blocks} 8-row blocks (every {stride}th) of the {args.width}x{args.height} frame, "
                   f"{rays} primary rays in {dt:.2f} s, same generated source (dynamic uniforms) built with g++ -O2 -ffp-contract=off -mfma -fopenmp",
     }
+
+
+def reference_text_baseline(args, pa, seconds=8.0):
+    """A second CPU figure that does not move when the product's translator improves: the reference's OWN shader text
+    (oracle/reference_shader.py: library.glsl + frag.glsl with the generated slots, executed by the numpy GLSL interpreter, one core) on a
+    seeded pixel sample of the same frame.  `kind: reference` -- the nearest thing to the reference's path that runs on a CPU at all."""
+    import zlib
+
+    from oracle import reference_shader as RS
+
+    if not RS.available():
+        return {"error": "reference shader text not present (oracle/_ref/reference_shader.bin: __graft_entry__.build() where /root/reference is mounted)"}
+    scene_path, extra = scene_of(args, pa)
+    o = RS.ReferenceShader(scene_path, **extra)
+    o.options.update(render_depth=args.depth, aa_count=args.aa, view_angle=args.fov / 180.0 * np.pi)
+    if args.panini >= 0.0:
+        o.options.update(use_panini=True, panini_param=args.panini)
+    if args.camera:
+        c = [float(x) for x in args.camera.split(",")]
+        o.camera = dict(look_at=tuple(c[:3]), alpha=c[3], beta=c[4], r=c[5])
+    rng = np.random.default_rng(zlib.crc32(args.scene.encode()) + 7)
+    n, done, t0 = 4096, 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        o.shade_pixels(args.width, args.height, rng.integers(0, args.width, n), rng.integers(0, args.height, n))
+        done += n
+    dt = time.perf_counter() - t0
+    return {"value": round(done * args.aa / dt / 1e6, 5), "unit": "Mray/s", "cores": 1, "kind": "reference",
+            "sample": f"{done} seeded pixels of the {args.width}x{args.height} frame in {dt:.1f} s: /root/reference/src/library.glsl + frag.glsl (text digest {RS.text_digest()}) "
+                      "with the slots of scene.rs:693-1075, interpreted by oracle/glsl_interp.py on numpy lanes, single thread"}
 
 
 def oracle_check(args, pa, renderer, torch, dev, stream, n=2048):
@@ -726,7 +760,7 @@ def main():
                            f"but not counted ({fl['all_flops']:.0f} per trip with all of them).")
                         + (f" Of the reference algorithm's {fl['algorithmic']:.0f} the kernel executes {fl['flops']:.0f}: loop-carried ray transforms of the scene "
                            "snippet that no statement reads are deferred away (counted on the host build), and while a ray still starts at the camera the origin "
-                           "half of the snippet's ray chains comes from the prologue kernel (read off the generated source); generated plane tests the wave-level cull skips are subtracted too (tests and culls per trip counted on the host build)."
+                           "half of the snippet's ray chains comes from the prologue kernel (read off the generated source); generated plane tests the wave-level cull skips are subtracted too (tests and culls per trip counted on the host build), and so are the matrix-product terms with a baked zero matrix element, which this build never executes."
                            if fl["flops"] != fl["algorithmic"] else ""),
             }
             if pmc:
@@ -771,6 +805,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, pa)
             except Exception as e:
                 out["cpu_baseline"] = {"error": str(e)[:300]}
+            try:
+                out["cpu_baseline_reference_text"] = reference_text_baseline(args, pa)
+            except Exception as e:
+                out["cpu_baseline_reference_text"] = {"error": str(e)[:300]}
             try:
                 out["oracle_check_of_the_timed_build"] = oracle_check(args, pa, renderer, torch, dev, stream)
             except Exception as e:

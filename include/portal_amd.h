@@ -212,6 +212,9 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * ray still starts at the camera (the first trip of the bounce loop: nine trips in ten) takes the ORIGIN half of its
  * `transform(uniform matrix, ray)` chains from the prologue kernel -- the origin of every primary ray is the same uniform value --
  * while the direction half stays per ray; same operations on the same values, identical frames.  Off with bit5 / bit12.
+ * bit15 = NO unrolling of baked loops: by default (with bit0) a counting loop of a scene snippet whose bound is a baked Int uniform
+ * (<= 16 iterations) is unrolled -- the same operations in the same order, identical frames; every iteration then has its own
+ * constants (scenes/portal_in_portal.ron's `size` drives an inner loop and a material index).
  * ptl_renderer_create additionally reads bits 8-11 as an occupancy hint n (0 = none):
  * the kernel is built with __launch_bounds__(256, n), i.e. at least n waves per SIMD. */
 int ptl_scene_generate_source(ptl_scene* s, unsigned flags, char** source);

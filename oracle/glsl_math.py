@@ -35,7 +35,10 @@ F64 = np.float64
 STATS = {"flops": 0.0, "div": 0.0, "sqrt": 0.0, "fma": 0.0,
          # the same, restricted to operations with at least one lane-varying (per-ray) operand: what a kernel with every
          # scene uniform baked in (FLAG_SPECIALIZE_ALL) still has to execute -- uniform-only subexpressions fold at JIT time
-         "flops_varying": 0.0, "div_varying": 0.0, "sqrt_varying": 0.0, "fma_varying": 0.0}
+         "flops_varying": 0.0, "div_varying": 0.0, "sqrt_varying": 0.0, "fma_varying": 0.0,
+         # of `flops_varying`: terms of matrix products whose matrix element is a uniform zero -- a build with the matrices baked in
+         # skips them (ptl_glsl.h `ptl_mterm`), so they are not executed work there (tools/count_flops.py subtracts them)
+         "zero_term_flops_varying": 0.0}
 _active = 1.0
 
 
@@ -235,6 +238,16 @@ def term0(a, b):
         # sign; a non-zero product keeps its sign even when it underflows to zero.
         p = np.asarray(a, F32).astype(F64) * np.asarray(b, F32).astype(F64)
         return np.where(p == 0, F64(0), p).astype(F32)
+
+
+def note_matrix_term(m, v, first: bool) -> None:
+    """Bookkeeping only (COUNT_VARYING): a matrix-product term with matrix element `m` and vector component `v`."""
+    if not COUNT_VARYING:
+        return
+    a = np.asarray(m)
+    uniform_zero = (a.ndim == 0 and a == 0) or (a.ndim > 0 and a.size > 0 and not _lane_varying(a) and a.reshape(-1)[0] == 0)
+    if uniform_zero and _lane_varying(v):
+        STATS["zero_term_flops_varying"] += (1.0 if first else 2.0) * _active
 
 
 def lt(a, b):

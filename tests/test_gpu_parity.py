@@ -860,6 +860,34 @@ def test_bench_multi_rank_rehearsal_assembles_the_same_frame(gpu, tmp_path, tran
     assert len(single["kernel_ms_per_rank"]) == 1 and "frame_check" not in single and single["roofline"]["bound"] in ("valu", "hbm")
 
 
+def test_bench_multi_rank_rehearsal_of_the_headline_line(gpu, tmp_path):
+    """The line the driver's 2/4/8-GPU runs will produce, rehearsed with 3 ranks on ONE GPU (gloo): the headline workload with its
+    defaults -- candidate builds checked to draw identical frames, the timed value through the single gather BASELINE.json names while
+    the peer transports are timed as extras, the last timed frame checked against rank 0 alone, and the second workload (C5, the
+    one whose scaling curve means something) in the same JSON line with every rank's kernel time."""
+    import json
+    import subprocess
+    import sys
+
+    pa = gpu
+    env = dict(os.environ, PTL_BENCH_BACKEND="gloo")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", "29519",
+                          os.path.join(pa.REPO_ROOT, "bench.py"), "--gpus", "3", "--steps", "6", "--warmup", "2"], capture_output=True, text=True, timeout=1200, env=env)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 3 and line["value"] > 0 and "portal_in_portal.ron 3840x2160" in cfg["workload"]
+    assert cfg["candidate_frames_identical"] is True and len(cfg["candidate_frame_sha256_16"]) == 16 and "candidates_excluded" not in cfg
+    assert "minreg" not in cfg["tuning_ms"] and {"w0", "w3", "w4"} <= set(cfg["tuning_ms"])   # no child-process builds at N > 1
+    assert cfg["transport"] == "rccl-gather" and set(cfg["transport_ms_per_frame"]) == {"rccl-gather", "p2p-stores", "p2p-copy"}
+    assert line["frame_check"] == {"last_timed_frame_equals_the_frame_rendered_by_rank0_alone": True}
+    second = line["second_workload"]
+    assert "mobius_monoportal.ron 7680x4320 aa=4 depth=64" in second["workload"] and second["transport"] == "rccl-gather"
+    assert len(second["kernel_ms_per_rank"]) == 3 and all(ms > 0 for ms in second["kernel_ms_per_rank"]) and second["ms_per_step"] >= max(second["kernel_ms_per_rank"]) * 0.3
+    assert second["value"] > 0 and second["transport_ms"] >= 0
+    assert "[bench r" in run.stderr and "second workload: c5" in run.stderr          # the stage markers that locate a hang
+
+
 def test_in_place_launches_fill_one_frame(gpu):
     """ptl_frame.in_place: N launches with phase 0..N-1 into ONE full-frame buffer give the bytes of the whole-frame launch
     (ragged height: the last row block is partial), for RGBA8 and the float buffer; the packed layout is untouched."""

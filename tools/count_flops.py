@@ -85,6 +85,8 @@ def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None
         for k in ("flops", "flops_varying"):
             base = per_segment.get(k + "_executed", per_segment[k])
             per_segment[k + "_executed"] = base - culls["culled_per_segment"] * per_test[k]
+    # a build with the matrices baked in skips matrix-product terms whose matrix element is zero (ptl_glsl.h `ptl_mterm`)
+    zero_terms = per_segment.pop("zero_term_flops_varying", 0.0)
     first = first_trip_origin_flops(scene, w, h, options)
     if first:
         # the share of trips that ARE first trips: one per primary sample
@@ -93,6 +95,13 @@ def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None
         for k in ("flops_executed", "flops_varying_executed"):
             base = per_segment.get(k, per_segment[k.replace("_executed", "")])
             per_segment[k] = base - saved
+    if zero_terms:
+        # (the deferred updates and first-trip origins subtracted above are whole transforms: their zero terms must not be taken off twice.
+        # A deferred update is 2 transforms = 4 products; the share of zero terms in them is the scene's average share)
+        share = zero_terms / max(per_segment["flops_varying"], 1.0)
+        base = per_segment.get("flops_varying_executed", per_segment["flops_varying"])
+        per_segment["zero_term_flops_varying"] = zero_terms
+        per_segment["flops_varying_executed_baked"] = base - zero_terms * min(1.0, base / per_segment["flops_varying"]) if share < 1 else base
     return {
         "first_trip_origin_arithmetic": first,
         "scene": scene, "width": w, "height": h, "depth": depth, "aa": aa,
