@@ -11,9 +11,9 @@ when PTL_DEVICE_BUILD is 0).  Compiled with `g++ -O2 -ffp-contract=off -mfma -fo
   * a cross-check of the *compiler and hardware* leg of parity: device/ptl_glsl.h fixes
     every operation in IEEE binary32, so gfx950 and x86-64 must agree bit for bit.
 What it is NOT: an independent check of the codegen or of the prelude's logic -- that is
-oracle/portal_oracle.py (numpy restatement, separate code path).  Parity status:
-"parity unpinned" -- the reference ships no golden image, known-answer vector or CPU
-tracer for this path.
+oracle/portal_oracle.py (numpy restatement, separate code path), which since round 3 is pinned to the reference's
+own shader text (oracle/reference_shader.py, tests/test_reference_text.py).  This host build is product source
+compiled by another compiler: agreement with it says "hipcc == g++ on this arithmetic", nothing more.
 """
 from __future__ import annotations
 

@@ -129,6 +129,8 @@ VARIANTS = {
     "r3_all_w6": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=6", "r3_all_minreg": "SPECIALIZE_ALL -mllvm -amdgpu-sched-strategy=iterative-minreg",
     "r3_dyn_mulfirst": "-DPTL_CHAIN_FROM_PRODUCT", "r3_all_mulfirst": "SPECIALIZE_ALL -DPTL_CHAIN_FROM_PRODUCT",
     "r3_all_nounroll": "SPECIALIZE_ALL NO_UNROLL", "r3_all_w4_nounroll": "SPECIALIZE_ALL NO_UNROLL -DPTL_WAVES_PER_EU=4", "r3_ints_nounroll": "SPECIALIZE NO_UNROLL",
+    "r3_all_w4_ra_default": "SPECIALIZE_ALL RA_DEFAULT -DPTL_WAVES_PER_EU=4", "r3_all_ra_default": "SPECIALIZE_ALL RA_DEFAULT", "r3_all_w4_ra_fast": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -vgpr-regalloc=fast",
+    "r3_dyn_ra_default": "RA_DEFAULT", "r3_ints_ra_default": "SPECIALIZE RA_DEFAULT",
     "r3_all_w4_zerofold": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -fno-signed-zeros -fno-honor-nans",
 }
 CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
