@@ -172,6 +172,25 @@ PTL_FN bool ptl_plane_cull(const Ray& r, const mat4& plane_inv, float best_t) {
 #endif
 #endif
 }
+// The cull for a ray whose origin in the plane's frame is already known (first-trip plane tests: `o_in_plane` = plane_inv * r.o from
+// the prologue kernel): the same two decisions from the same two numbers, half the products.
+PTL_FN bool ptl_plane_cull_o(const Ray& r, const mat4& plane_inv, const vec4& o_in_plane, float best_t) {
+#if defined(PTL_NO_PLANE_CULL)
+    (void)r; (void)plane_inv; (void)o_in_plane; (void)best_t;
+    return false;
+#else
+    const float oz = o_in_plane.z;
+    const float dz = (plane_inv * r.d).z;
+    const bool behind = (oz > 0.0f && dz > 0.0f) || (oz < 0.0f && dz < 0.0f);
+#if PTL_DEVICE_BUILD
+    const float t_low = (-oz * __builtin_amdgcn_rcpf(dz)) * (1.0f - 0x1p-16f);
+    return __builtin_amdgcn_ballot_w64(!(behind || (t_low > best_t && abs(dz) >= 0x1p-100f))) == 0ull;
+#else
+    const float t_low = (-oz * (1.0f / dz)) * (1.0f - 0x1p-16f);
+    return behind || (t_low > best_t && abs(dz) >= 0x1p-100f);
+#endif
+#endif
+}
 #define PTL_BEST_T(i) (((i).hit.hit && (i).hit.t < ptl_far) ? (i).hit.t : ptl_far)  /* inside scene_intersect: best hit so far, capped by the caller's bound */
 
 // plane_intersect with the ray-independent half done beforehand: `unit_normal` = normalize(normal) comes from the
@@ -183,6 +202,34 @@ PTL_FN SurfaceIntersection plane_intersect_derived(Ray r, const mat4& plane_inv,
     return ptl_plane_hit_fast(r, plane_inv, unit_normal);
 #endif
     r = transform(plane_inv, r);
+    float len = length(r.d);
+    r.d = normalize(r.d);
+    SurfaceIntersection result = plane_intersect_normalized(r);
+    if (result.hit) {
+        result.t = ptl_div(result.t, len);
+        result.n = unit_normal;
+    }
+    return result;
+}
+
+// plane_intersect / plane_intersect_derived for a ray whose origin in the plane's frame is already known (first-trip plane tests,
+// KernelOptions::first_trip_planes): `transform(plane_inv, r)` becomes (o_in_plane, plane_inv * r.d); every other operation as above.
+PTL_FN SurfaceIntersection plane_intersect_o(Ray r, const mat4& plane_inv, vec3 normal, const vec4& o_in_plane) {
+    normal = normalize_normal(normal, r.d.sw<0, 1, 2>());
+    r = Ray{o_in_plane, plane_inv * r.d, r.tmul, r.in_subspace};
+    float len = length(r.d);
+    r.d = normalize(r.d);
+    SurfaceIntersection result = plane_intersect_normalized(r);
+    if (result.hit) {
+        result.t = ptl_div(result.t, len);
+        result.n = normal;
+    }
+    return result;
+}
+PTL_FN SurfaceIntersection plane_intersect_derived_o(Ray r, const mat4& plane_inv, vec3 unit_normal, bool& flipped, const vec4& o_in_plane) {
+    flipped = dot(unit_normal, r.d.sw<0, 1, 2>()) > 0.0f;
+    if (flipped) unit_normal *= -1.0f;
+    r = Ray{o_in_plane, plane_inv * r.d, r.tmul, r.in_subspace};
     float len = length(r.d);
     r.d = normalize(r.d);
     SurfaceIntersection result = plane_intersect_normalized(r);

@@ -112,6 +112,27 @@ PTL_FN SceneIntersection scene_intersect(const Ray& r, float ptl_far = __builtin
     return i;
 }
 
+#ifdef PTL_FIRST_TRIP_PLANES
+// The same function for the trip on which every ray of the wave still starts at the camera (KernelOptions::first_trip_planes): the
+// generated plane tests take `plane_inv * r.o` -- one value for the whole frame -- from the prologue kernel's `ptl_dvo_<object>_<side>`
+// (derive() below: the same product of the same matrix and the same origin), everything else is the statement list above.
+PTL_FN SceneIntersection scene_intersect_first(const Ray& r, float ptl_far = __builtin_inff()) {
+    SceneIntersection i = SceneIntersection{0, intersection_none, false};
+    SceneIntersection ihit = SceneIntersection{0, intersection_none, false};
+    SurfaceIntersection hit = intersection_none;
+    vec3 normal = vec3(0.0f);
+    int inside = NOT_INSIDE;
+    float len = 1.0f;
+    Ray transformed_ray = ray_none;
+    bool flipped = false;
+    (void)ihit; (void)hit; (void)normal; (void)inside; (void)len; (void)transformed_ray; (void)flipped;
+
+//%intersections_first//%
+
+    return i;
+}
+#endif
+
 // Prologue (ptl_derive_kernel, once per uniform upload): the ray-independent part of the plane tests above whose matrices
 // are run-time uniforms -- the unit normal plane_intersect would normalise on every call and the two verdicts
 // is_collinear(hit.n, normal) can have (hit.n is that unit normal or its negation).  Same functions, same operations as the
@@ -161,7 +182,7 @@ PTL_FN SceneIntersectionWithMaterial scene_intersect_material_process(const Ray&
     return result;
 }
 
-#ifdef PTL_FIRST_TRIP
+#ifdef PTL_FIRST_TRIP_SNIPPETS
 // First-trip variants (KernelOptions::first_trip, flags bit 13).  Every primary ray of the frame starts at the camera: on the first
 // trip of the bounce loop -- nine trips in ten on the headline frame -- the ORIGIN half of whatever the scene's intersection-material
 // snippets do to the ray depends on uniforms alone.  The code generator emits a second copy of each snippet, `intersect_material_<N>_first`,
@@ -220,12 +241,20 @@ PTL_FN bool trace_segment(Ray& r, vec3& current_color, float& all_t, float camer
     // The reference evaluates scene_intersect first (frag.glsl:114-115); both are pure, and with the snippet's hit distance known the
     // plane tests beyond it can be culled: `i` then is the nearest object in front of the snippet's hit, or whatever else survived --
     // and whenever the two differ the snippet's hit is nearer than both and is what gets used below.
-#ifdef PTL_FIRST_TRIP
+#ifdef PTL_FIRST_TRIP_SNIPPETS
     SceneIntersectionWithMaterial i2 = first_form ? scene_intersect_material_process_first(r) : scene_intersect_material_process(r);
 #else
     SceneIntersectionWithMaterial i2 = scene_intersect_material_process(r);
 #endif
-    SceneIntersection i = scene_intersect(r, (i2.scene.hit.hit && i2.scene.hit.t > 0.0f) ? i2.scene.hit.t : __builtin_inff());
+    const float ptl_bound = (i2.scene.hit.hit && i2.scene.hit.t > 0.0f) ? i2.scene.hit.t : __builtin_inff();
+#ifdef PTL_FIRST_TRIP_PLANES
+    SceneIntersection i = first_form ? scene_intersect_first(r, ptl_bound) : scene_intersect(r, ptl_bound);
+#else
+    SceneIntersection i = scene_intersect(r, ptl_bound);
+#endif
+#if defined(PTL_FIRST_TRIP) && !defined(PTL_FIRST_TRIP_SNIPPETS) && !defined(PTL_FIRST_TRIP_PLANES)
+    (void)first_form;
+#endif
 
     // `m` is left unset by the reference when a snippet reports hit with t <= 0 (GLSL:
     // undefined value); this build defines that case as the all-zero MaterialProcessing.

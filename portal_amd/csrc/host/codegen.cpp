@@ -543,6 +543,15 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 for (const NamedCode& im : scene.intersection_materials) snippet.prepare_first(im.code, hp);
         }
         if (opts.derived_uniforms) s.add_string("#define PTL_DERIVED_BUILTINS 1\n");
+        {
+            bool any_flat = false;
+            for (const Object& o : scene.objects) any_flat = any_flat || o.kind == Object::Flat;
+            if (opts.derived_uniforms && opts.first_trip_planes && !opts.fast_math && any_flat)
+                s.add_string("#define PTL_FIRST_TRIP_PLANES 1\n#ifndef PTL_FIRST_TRIP\n#define PTL_FIRST_TRIP 1\n#endif\n");
+            bool any_first_snippet = false;
+            for (const NamedCode& im : scene.intersection_materials) any_first_snippet = any_first_snippet || snippet.has_first(im.code);
+            if (any_first_snippet) s.add_string("#define PTL_FIRST_TRIP_SNIPPETS 1\n#ifndef PTL_FIRST_TRIP\n#define PTL_FIRST_TRIP 1\n#endif\n");
+        }
         s.add_string("struct ptl_uniform_block {\n");
         for (auto& u : list) s.add_string(std::string("    ") + cxx_type(u.type) + " " + u.name + ";\n");
         // written by ptl_derive_kernel (never by the host: uploads stop at uniform_block_size)
@@ -550,6 +559,16 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             s.add_string("    vec4 ptl_dv_origin;\n    vec4 ptl_dv_origin_left;\n    vec4 ptl_dv_origin_right;\n    vec2 ptl_dv_half_resolution;\n"
                          "    float ptl_dv_tan_half_view;\n    float ptl_dv_pixel_size;\n");
         for (auto& d : gk.derived) s.add_string("    vec3 " + d.member + "_nrm;\n    int " + d.member + "_col;\n");
+        // first-trip plane tests: `plane_inv * camera origin` per generated plane test (KernelOptions::first_trip_planes)
+        const bool first_planes = opts.derived_uniforms && opts.first_trip_planes && !opts.fast_math;
+        if (first_planes)
+            for (size_t pos = 0; pos < scene.objects.size(); ++pos) {
+                const Object& o = scene.objects[pos];
+                if (o.kind != Object::Flat) continue;
+                s.add_string("    vec4 ptl_dvo_" + std::to_string(pos) + "_0;\n");
+                if (o.portal) s.add_string("    vec4 ptl_dvo_" + std::to_string(pos) + "_1;\n");
+                gk.first_trip_plane_tests += o.portal ? 2 : 1;
+            }
         for (auto& m : snippet.members) s.add_string("    " + m.type + " " + m.name + (m.length ? "[" + std::to_string(m.length) + "]" : "") + ";\n");
         s.add_string("};\n");
         s.add_string("#if PTL_DEVICE_BUILD\n__constant__ ptl_uniform_block ptl_u;\n#else\nptl_uniform_block ptl_u;\n#endif\n");
@@ -640,7 +659,10 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     }
 
     // --- per-object intersection statements (scene.rs:885-1009) ----------------------------
-    {
+    // Emitted once in the general form and, with KernelOptions::first_trip_planes, once more for the trip on which every ray of the wave
+    // still starts at the camera: there `plane_inv * r.o` of a Flat object is the prologue's `ptl_dvo_<object>_<side>` (derive() below
+    // evaluates the very product on the very origin), and the plane test / the cull take it instead of transforming the origin per lane.
+    auto emit_intersections = [&](bool first_form) {
         StringStorage s;
         for (size_t pos = 0; pos < scene.objects.size(); ++pos) {
             const Object& o = scene.objects[pos];
@@ -670,9 +692,16 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 };
                 // with a derived entry: the unit normal and both is_collinear verdicts come from the prologue kernel
                 // (ptl_tracer::derive below evaluates exactly the expressions of the plain form)
+                // first form: the transformed origin of this test, and the `_o` variants of the cull and the plane test that take it
+                auto origin_of = [&](int side) { return "PTL_U.ptl_dvo_" + p + "_" + std::to_string(side); };
+                auto cull_call = [&](const std::string& inv, int side) {
+                    return first_form ? "ptl_plane_cull_o(r, " + inv + ", " + origin_of(side) + ", PTL_BEST_T(i))" : "ptl_plane_cull(r, " + inv + ", PTL_BEST_T(i))";
+                };
                 auto derived_test = [&](const DerivedPlane& d, const std::string& inv, const std::string& process_open, const std::string& extra_args,
                                         const std::string& process_close) {
-                    s.add_string("if (!ptl_plane_cull(r, " + inv + ", PTL_BEST_T(i))) {\n");
+                    s.add_string("if (!" + cull_call(inv, d.side) + ") {\n");
+                    if (first_form) s.add_string("hit = plane_intersect_derived_o(r, " + inv + ", PTL_U." + d.member + "_nrm, flipped, " + origin_of(d.side) + ");\n");
+                    else
                     s.add_string("hit = plane_intersect_derived(r, " + inv + ", PTL_U." + d.member + "_nrm, flipped);\n");
                     s.add_string("if (nearer(i, hit)) { i = " + process_open + "is_inside_" + p + "(r.o + r.d * hit.t, hit.u, hit.v, ((PTL_U." + d.member +
                                  "_col >> (flipped ? 1 : 0)) & 1) != 0" + extra_args + ")" + process_close + "; }\n}\n\n");
@@ -682,8 +711,10 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                     if (const DerivedPlane* d = derived_of(0)) {
                         derived_test(*d, inverse_name(m), "process_plane_intersection(i, hit, ", "", ")");
                     } else {
-                        s.add_string("if (!ptl_plane_cull(r, " + inverse_name(m) + ", PTL_BEST_T(i))) {\n");
+                        s.add_string("if (!" + cull_call(inverse_name(m), 0) + ") {\n");
                         s.add_string("normal = -get_normal(" + normal_name(m) + ");\n");
+                        if (first_form) s.add_string("hit = plane_intersect_o(r, " + inverse_name(m) + ", get_normal(" + normal_name(m) + "), " + origin_of(0) + ");\n");
+                        else
                         s.add_string("hit = plane_intersect(r, " + inverse_name(m) + ", get_normal(" + normal_name(m) + "));\n");
                         s.add_string("if (nearer(i, hit)) { i = process_plane_intersection(i, hit, is_inside_" + p +
                                      "(r.o + r.d * hit.t, hit.u, hit.v, is_collinear(hit.n, normal))); }\n}\n\n");
@@ -694,8 +725,10 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                             derived_test(*d, inverse_name(m), "process_portal_intersection(i, hit, ", std::string(", ") + bool_lit(first), ", " + material + ")");
                             return;
                         }
-                        s.add_string("if (!ptl_plane_cull(r, " + inverse_name(m) + ", PTL_BEST_T(i))) {\n");
+                        s.add_string("if (!" + cull_call(inverse_name(m), first ? 0 : 1) + ") {\n");
                         s.add_string(std::string("normal = ") + (first ? "-" : "") + "get_normal(" + normal_name(m) + ");\n");
+                        if (first_form) s.add_string("hit = plane_intersect_o(r, " + inverse_name(m) + ", normal, " + origin_of(first ? 0 : 1) + ");\n");
+                        else
                         s.add_string("hit = plane_intersect(r, " + inverse_name(m) + ", normal);\n");
                         s.add_string("if (nearer(i, hit)) { i = process_portal_intersection(i, hit, is_inside_" + p +
                                      "(r.o + r.d * hit.t, hit.u, hit.v, is_collinear(hit.n, normal), " + bool_lit(first) + "), " + material + "); }\n}\n\n");
@@ -730,12 +763,23 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             }
             s.add_string("\n");
         }
-        storages["intersections"] = std::move(s);
-    }
+        return s;
+    };
+    storages["intersections"] = emit_intersections(false);
+    storages["intersections_first"] = gk.first_trip_plane_tests > 0 ? emit_intersections(true) : StringStorage();
 
     // --- prologue: the ray-independent part of every derived plane test, once per uniform upload ----------
     {
         StringStorage s;
+        if (gk.first_trip_plane_tests > 0) {
+            s.add_string("    // first-trip plane tests: plane_inv * (origin of every primary ray), the product transform() would evaluate per lane\n");
+            for (size_t pos = 0; pos < scene.objects.size(); ++pos) {
+                const Object& o = scene.objects[pos];
+                if (o.kind != Object::Flat) continue;
+                s.add_string("    out->ptl_dvo_" + std::to_string(pos) + "_0 = " + inverse_name(matrix_name(scene, o.m0, o)) + " * out->ptl_dv_origin;\n");
+                if (o.portal) s.add_string("    out->ptl_dvo_" + std::to_string(pos) + "_1 = " + inverse_name(matrix_name(scene, o.m1, o)) + " * out->ptl_dv_origin;\n");
+            }
+        }
         for (auto& d : gk.derived) {
             s.add_string("    {\n        vec3 normal = " + d.normal_expr + ";\n        vec3 unit = normalize(" + d.arg_expr + ");\n");
             s.add_string("        out->" + d.member + "_nrm = unit;\n");

@@ -91,6 +91,10 @@ struct KernelOptions {
     // snippet loops whose bound is a baked Int uniform (<= 16) are unrolled (codegen.cpp SnippetTranslator::unrolled): identical frames
     bool unroll_baked_loops = true;
     bool exact_cr = false;   // PTL_CONTRACT_V1: the rounds-1-2 numerics contract (IEEE correctly rounded / and sqrt for every input) instead of contract 2 (device/ptl_glsl.h)
+    // first-trip form of the GENERATED plane tests (scene.rs:912-948): a second copy of scene_intersect for the trip on which every ray of the
+    // wave still starts at the camera takes `plane_inv * r.o` of every Flat object from the prologue kernel (a vec4 per plane behind the
+    // derived uniforms) -- the same product of the same values, computed once per upload instead of per lane.  Needs derived_uniforms.
+    bool first_trip_planes = true;
     bool fast_math = false;  // PTL_FAST_MATH: hardware rcp / sqrt / rsq (1 ulp), a/b = a * rcp(b), FMA contraction: tolerance mode, not bit-exact
 };
 
@@ -109,6 +113,7 @@ struct GeneratedKernel {
     size_t uniform_block_size = 0;
     std::vector<std::string> defines;   // e.g. "PTL_COUNT_SEGMENTS"
     std::vector<UniformUpload> baked;   // the values compiled in as literals (specialised builds)
+    int first_trip_plane_tests = 0;     // generated plane tests that have a first-trip form (ptl_dvo_<object>_<side> members)
     bool first_trip_variants = false;   // the kernel has first-trip copies of its intersection-material snippets (define PTL_FIRST_TRIP)
     int hoisted_members = 0;            // ... plus this many members holding uniform-only work of the scene snippets (glsl_hoist.h)
     std::vector<DerivedPlane> derived;  // members appended to the block behind uniform_block_size, written on the device

@@ -235,3 +235,33 @@ def test_a_cached_code_object_the_runtime_refuses_is_rebuilt_once(gpu, tmp_path,
     again = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("basics")), device=0).draw(64, 36)["rgba8"]
     assert np.array_equal(first, again)
     assert any(f.read_bytes()[64:200] != bytes(136) for f in cache.glob("*.hsaco"))  # a fresh build took the damaged file's place
+
+
+@pytest.mark.parametrize("scene_name,spec", [("triple_portal", 0), ("triple_portal", 5), ("monoportal", 0), ("portal_in_portal", 5), ("basics", 1)])
+def test_first_trip_plane_tests_change_no_bit(gpu, scene_name, spec):
+    """Round 3: on the trip where every ray of a wave still starts at the camera, the generated plane tests take `plane_inv * r.o` from
+    the prologue kernel (`ptl_dvo_<object>_<side>`, scene_intersect_first) instead of transforming the origin per lane;
+    FLAG_NO_FIRST_TRIP_PLANES keeps the one general scene_intersect.  The same product of the same values: identical float frames --
+    after the camera has moved (the prologue must run again), after a scene uniform has moved a plane, and in side-by-side stereo
+    (eyes mixed in a wave: those waves take the general form)."""
+    pa = gpu
+    w, h = 320, 180
+    frames = {}
+    for label, flags in (("first", spec), ("general", spec | pa.FLAG_NO_FIRST_TRIP_PLANES)):
+        scene = pa.Scene.from_file(pa.scene_path(scene_name))
+        src = scene.generate_source(flags)
+        assert ("scene_intersect_first(const Ray& r" in src and "#define PTL_FIRST_TRIP_PLANES 1" in src) == (label == "first")
+        r = pa.SceneRenderer(scene, device=0, flags=flags)
+        r.set_option("render_depth", 20)
+        got = [r.draw(w, h, rgba32f=True)["rgba32f"].copy()]
+        r.set_camera((0.3, 0.2, -0.4), 1.9, 1.2, 3.5)
+        got.append(r.draw(w, h, rgba32f=True)["rgba32f"].copy())
+        if scene_name == "portal_in_portal":
+            assert scene.set_uniform("progress", 0.37)
+            got.append(r.draw(w, h, rgba32f=True)["rgba32f"].copy())
+        r.set_option("draw_side_by_side", 1)
+        got.append(r.draw(w, h, rgba32f=True)["rgba32f"].copy())
+        frames[label] = got
+    for a, b in zip(frames["first"], frames["general"]):
+        assert np.array_equal(_bits(a), _bits(b))
+    assert not np.array_equal(_bits(frames["general"][0]), _bits(frames["general"][1]))

@@ -1124,3 +1124,39 @@ def test_hoister_counts_the_out_arguments_of_glsl_builtins_as_writes(pa):
     # the same shape without the call IS a uniform local and does move
     plain, prologue = pa.hoist_glsl(code.replace("float f = modf(x_u, ip);", "float f = x_u;"), uniforms, params=["r"])
     assert "PTL_U.ptl_hv" in plain and "ip * k_u * k_u * k_u" in prologue
+
+
+def test_first_trip_plane_tests_are_selfconsistent_and_change_no_bit_on_the_host(pa):
+    """KernelOptions::first_trip_planes: one `vec4 ptl_dvo_<object>_<side>` per generated plane test behind the derived uniforms, written
+    by derive() as `<plane>_mat_inv * out->ptl_dv_origin`, read by scene_intersect_first only; the host build of both forms draws the
+    same bits (first trips take the first form there too), also with the scene state baked in and after a camera move."""
+    import re
+    from oracle import host_build as hb
+
+    scene = pa.Scene.from_file(pa.scene_path("triple_portal"))
+    src = scene.generate_source(0)
+    block = src[src.index("struct ptl_uniform_block {"):src.index("};", src.index("struct ptl_uniform_block {"))]
+    members = set(re.findall(r"vec4 (ptl_dvo_\d+_[01]);", block))
+    assert len(members) == 27
+    derive = src[src.index("PTL_FN void derive(ptl_uniform_block* out)"):src.index("// Material id -> what happens to the path.")]
+    assert set(re.findall(r"out->(ptl_dvo_\d+_[01]) = \w+_mat_inv \* out->ptl_dv_origin;", derive)) == members
+    first = src[src.index("PTL_FN SceneIntersection scene_intersect_first("):src.index("#define PTL_DV_OUT")]
+    general = src[src.index("PTL_FN SceneIntersection scene_intersect(const Ray& r"):src.index("PTL_FN SceneIntersection scene_intersect_first(")]
+    assert set(re.findall(r"PTL_U\.(ptl_dvo_\d+_[01])", first)) == members and "PTL_U.ptl_dvo_" not in general
+    assert first.count("ptl_plane_cull_o(") == 27 and general.count("ptl_plane_cull(") == 27
+    for flags in (pa.FLAG_NO_DERIVED_UNIFORMS, pa.FLAG_NO_FIRST_TRIP_PLANES, pa.FLAG_FAST_MATH):
+        off = scene.generate_source(flags)
+        assert "PTL_U.ptl_dvo_" not in off and "#define PTL_FIRST_TRIP_PLANES" not in off
+    frames = {}
+    for label, flags in (("first", 0), ("general", pa.FLAG_NO_FIRST_TRIP_PLANES), ("first_baked", pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)):
+        sc = pa.Scene.from_file(pa.scene_path("triple_portal"))
+        r = pa.SceneRenderer(sc, device=-1, flags=flags)
+        r.set_option("render_depth", 12)
+        got = [hb.host_kernel_for(r, sc, 64, 36, flags=flags).render(64, 36)["rgba32f"].copy()]
+        r.set_camera((0.2, -0.3, 0.4), 2.3, 1.1, 2.9)
+        got.append(hb.host_kernel_for(r, sc, 64, 36, flags=flags).render(64, 36)["rgba32f"].copy())
+        frames[label] = got
+    for k in range(2):
+        assert np.array_equal(frames["first"][k].view(np.uint32), frames["general"][k].view(np.uint32))
+        assert np.array_equal(frames["first_baked"][k].view(np.uint32), frames["general"][k].view(np.uint32))
+    assert not np.array_equal(frames["general"][0].view(np.uint32), frames["general"][1].view(np.uint32))

@@ -131,6 +131,7 @@ VARIANTS = {
     "r3_all_nounroll": "SPECIALIZE_ALL NO_UNROLL", "r3_all_w4_nounroll": "SPECIALIZE_ALL NO_UNROLL -DPTL_WAVES_PER_EU=4", "r3_ints_nounroll": "SPECIALIZE NO_UNROLL",
     "r3_all_w4_ra_default": "SPECIALIZE_ALL RA_DEFAULT -DPTL_WAVES_PER_EU=4", "r3_all_ra_default": "SPECIALIZE_ALL RA_DEFAULT", "r3_all_w4_ra_fast": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -vgpr-regalloc=fast",
     "r3_dyn_ra_default": "RA_DEFAULT", "r3_ints_ra_default": "SPECIALIZE RA_DEFAULT",
+    "r3_all_noftp": "SPECIALIZE_ALL NO_FTP", "r3_all_w4_noftp": "SPECIALIZE_ALL NO_FTP -DPTL_WAVES_PER_EU=4", "r3_ints_noftp": "SPECIALIZE NO_FTP", "r3_dyn_noftp": "NO_FTP",
     "r3_all_w4_zerofold": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -fno-signed-zeros -fno-honor-nans",
 }
 CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
@@ -150,7 +151,7 @@ def run_one(case, vname, flags):
     w, h, d, aa = int(w), int(h), int(d), int(aa)
     toks = flags.split()
     rflags = (pa.FLAG_SPECIALIZE_INTS if ("SPECIALIZE" in toks or "SPECIALIZE_ALL" in toks) else 0) | (pa.FLAG_SPECIALIZE_ALL if "SPECIALIZE_ALL" in toks else 0)
-    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0) | (pa.FLAG_NO_DEFERRED_UPDATES if "NO_DEFER" in toks else 0) | (pa.FLAG_NO_UNIFORM_HOIST if "NO_HOIST" in toks else 0) | (pa.FLAG_NO_FIRST_TRIP if "NO_FIRST_TRIP" in toks else 0) | (pa.FLAG_EXACT_CR if "EXACT_CR" in toks else 0) | (pa.FLAG_NO_UNROLL if "NO_UNROLL" in toks else 0)
+    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0) | (pa.FLAG_NO_DEFERRED_UPDATES if "NO_DEFER" in toks else 0) | (pa.FLAG_NO_UNIFORM_HOIST if "NO_HOIST" in toks else 0) | (pa.FLAG_NO_FIRST_TRIP if "NO_FIRST_TRIP" in toks else 0) | (pa.FLAG_EXACT_CR if "EXACT_CR" in toks else 0) | (pa.FLAG_NO_UNROLL if "NO_UNROLL" in toks else 0) | (pa.FLAG_NO_FIRST_TRIP_PLANES if "NO_FTP" in toks else 0)
     # the VGPR allocator is an option the JIT always passes (kernel.cpp): select it through its own switch, not a second -mllvm
     ra = [t.split("=", 1)[1] for t in toks if t.startswith("-vgpr-regalloc=")]
     if "RA_DEFAULT" in toks:
