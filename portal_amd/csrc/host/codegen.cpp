@@ -546,7 +546,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         {
             bool any_flat = false;
             for (const Object& o : scene.objects) any_flat = any_flat || o.kind == Object::Flat;
-            if (opts.derived_uniforms && opts.first_trip_planes && !opts.fast_math && any_flat)
+            if (opts.derived_uniforms && opts.first_trip_planes && !opts.fast_math && !opts.specialize_all && any_flat)
                 s.add_string("#define PTL_FIRST_TRIP_PLANES 1\n#ifndef PTL_FIRST_TRIP\n#define PTL_FIRST_TRIP 1\n#endif\n");
             bool any_first_snippet = false;
             for (const NamedCode& im : scene.intersection_materials) any_first_snippet = any_first_snippet || snippet.has_first(im.code);
@@ -560,7 +560,9 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                          "    float ptl_dv_tan_half_view;\n    float ptl_dv_pixel_size;\n");
         for (auto& d : gk.derived) s.add_string("    vec3 " + d.member + "_nrm;\n    int " + d.member + "_col;\n");
         // first-trip plane tests: `plane_inv * camera origin` per generated plane test (KernelOptions::first_trip_planes)
-        const bool first_planes = opts.derived_uniforms && opts.first_trip_planes && !opts.fast_math;
+        // (not with every scene uniform baked in: with the zero terms of the literal matrices skipped the origin half of a plane test
+        // is a couple of FMAs, and the second copy of scene_intersect measured no gain there -- profiles/r03/variants7_first_trip_planes.jsonl)
+        const bool first_planes = opts.derived_uniforms && opts.first_trip_planes && !opts.fast_math && !opts.specialize_all;
         if (first_planes)
             for (size_t pos = 0; pos < scene.objects.size(); ++pos) {
                 const Object& o = scene.objects[pos];

@@ -237,11 +237,12 @@ def test_a_cached_code_object_the_runtime_refuses_is_rebuilt_once(gpu, tmp_path,
     assert any(f.read_bytes()[64:200] != bytes(136) for f in cache.glob("*.hsaco"))  # a fresh build took the damaged file's place
 
 
-@pytest.mark.parametrize("scene_name,spec", [("triple_portal", 0), ("triple_portal", 5), ("monoportal", 0), ("portal_in_portal", 5), ("basics", 1)])
+@pytest.mark.parametrize("scene_name,spec", [("triple_portal", 0), ("triple_portal", 1), ("monoportal", 0), ("portal_in_portal", 1), ("basics", 1)])
 def test_first_trip_plane_tests_change_no_bit(gpu, scene_name, spec):
     """Round 3: on the trip where every ray of a wave still starts at the camera, the generated plane tests take `plane_inv * r.o` from
     the prologue kernel (`ptl_dvo_<object>_<side>`, scene_intersect_first) instead of transforming the origin per lane;
-    FLAG_NO_FIRST_TRIP_PLANES keeps the one general scene_intersect.  The same product of the same values: identical float frames --
+    FLAG_NO_FIRST_TRIP_PLANES keeps the one general scene_intersect (as does a build with every scene uniform baked in: nothing to gain
+    there).  The same product of the same values: identical float frames --
     after the camera has moved (the prologue must run again), after a scene uniform has moved a plane, and in side-by-side stereo
     (eyes mixed in a wave: those waves take the general form)."""
     pa = gpu

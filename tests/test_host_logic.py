@@ -1144,11 +1144,11 @@ def test_first_trip_plane_tests_are_selfconsistent_and_change_no_bit_on_the_host
     general = src[src.index("PTL_FN SceneIntersection scene_intersect(const Ray& r"):src.index("PTL_FN SceneIntersection scene_intersect_first(")]
     assert set(re.findall(r"PTL_U\.(ptl_dvo_\d+_[01])", first)) == members and "PTL_U.ptl_dvo_" not in general
     assert first.count("ptl_plane_cull_o(") == 27 and general.count("ptl_plane_cull(") == 27
-    for flags in (pa.FLAG_NO_DERIVED_UNIFORMS, pa.FLAG_NO_FIRST_TRIP_PLANES, pa.FLAG_FAST_MATH):
+    for flags in (pa.FLAG_NO_DERIVED_UNIFORMS, pa.FLAG_NO_FIRST_TRIP_PLANES, pa.FLAG_FAST_MATH, pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL):
         off = scene.generate_source(flags)
         assert "PTL_U.ptl_dvo_" not in off and "#define PTL_FIRST_TRIP_PLANES" not in off
     frames = {}
-    for label, flags in (("first", 0), ("general", pa.FLAG_NO_FIRST_TRIP_PLANES), ("first_baked", pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)):
+    for label, flags in (("first", 0), ("general", pa.FLAG_NO_FIRST_TRIP_PLANES), ("first_baked", pa.FLAG_SPECIALIZE_INTS)):
         sc = pa.Scene.from_file(pa.scene_path("triple_portal"))
         r = pa.SceneRenderer(sc, device=-1, flags=flags)
         r.set_option("render_depth", 12)
