@@ -212,6 +212,10 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * ray still starts at the camera (the first trip of the bounce loop: nine trips in ten) takes the ORIGIN half of its
  * `transform(uniform matrix, ray)` chains from the prologue kernel -- the origin of every primary ray is the same uniform value --
  * while the direction half stays per ray; same operations on the same values, identical frames.  Off with bit5 / bit12.
+ * bit16 = NO first-trip form of the generated plane tests: by default, where the scene's matrices are run-time uniforms, a second copy of
+ * scene_intersect serves the trip on which every ray of a wave still starts at the camera and takes `plane_inv * r.o` of every Flat
+ * object from the prologue kernel (ptl_dvo_<object>_<side>) -- the same product of the same values, identical frames.
+ * bit17 = ASYNC REJIT (ptl_renderer_create only): see ptl_renderer_rejit_pending.
  * bit15 = NO unrolling of baked loops: by default (with bit0) a counting loop of a scene snippet whose bound is a baked Int uniform
  * (<= 16 iterations) is unrolled -- the same operations in the same order, identical frames; every iteration then has its own
  * constants (scenes/portal_in_portal.ron's `size` drives an inner loop and a material index).
@@ -280,6 +284,12 @@ int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16], int* in_su
 ptl_kernel* ptl_renderer_kernel(ptl_renderer* r);
 /* how many times a draw had to rebuild the clip-specialised kernel (flags bit3) since the renderer was created */
 int ptl_renderer_rejit_count(ptl_renderer* r);
+/* flags bit17 (ASYNC REJIT) on a specialised renderer (bits 0/2 or 3): a draw that finds its compiled-in values stale does not wait for
+ * the rebuild (1-3 s of hiprtc) -- it draws with the un-specialised kernel of the scene (every build draws the same bits) while a worker
+ * thread compiles the specialised source of the current state; the first draw that finds it finished and still matching loads it and
+ * switches (counted by ptl_renderer_rejit_count).  Returns 1 while such a build is in flight or the un-specialised kernel is in use.
+ * Reference seam: the reference recompiles its shader synchronously when the scene changes (src/gui/scene.rs:1112-1176). */
+int ptl_renderer_rejit_pending(ptl_renderer* r);
 void ptl_renderer_destroy(ptl_renderer* r);
 
 /* Place the packed rows of shard (phase, stride) into a full-frame RGBA8 image (host memory). */

@@ -56,6 +56,7 @@ FLAG_NO_DERIVED_UNIFORMS = 32  # keep the per-call plane tests (default: ray-ind
 FLAG_NO_FIRST_TRIP = 8192  # no first-trip copies of the intersection-material snippets (default: on the first trip the origin half of their ray chains comes from the prologue)
 FLAG_NO_UNIFORM_HOIST = 4096  # scene snippets evaluate their uniform-only expressions per ray (default: once per upload, in the prologue kernel)
 FLAG_NO_DEFERRED_UPDATES = 128  # translate scene snippets exactly as written (default: loop-carried ray transforms are applied lazily)
+FLAG_ASYNC_REJIT = 131072  # a specialised renderer never stalls on a rebuild: it draws with the un-specialised kernel until a worker thread has the new one
 FLAG_NO_FIRST_TRIP_PLANES = 65536  # no first-trip copy of the generated plane tests (default: on the first trip `plane_inv * camera origin` comes from the prologue kernel)
 FLAG_NO_UNROLL = 32768  # keep snippet loops whose bound is a baked Int uniform as loops (default: unrolled up to 16 iterations; identical frames)
 FLAG_EXACT_CR = 16384  # numerics contract 1 of rounds 1-2: IEEE correctly rounded / and sqrt on EVERY input (default: contract 2, device/ptl_glsl.h)
@@ -124,6 +125,7 @@ def _load() -> C.CDLL:
         "ptl_scene_update": (ci, [vp, cd, P(cd), P(cd), P(ci), P(CalculatedCam)]),
         "ptl_renderer_update": (ci, [vp, cd, P(ci), P(ci)]),
         "ptl_renderer_rejit_count": (ci, [vp]),
+        "ptl_renderer_rejit_pending": (ci, [vp]),
         "ptl_scene_eval_uniform": (ci, [vp, cp, P(ci), P(cd)]),
         "ptl_scene_eval_matrix": (ci, [vp, cp, P(cd)]),
         "ptl_scene_cam": (ci, [vp, P(cd)]),
@@ -479,6 +481,10 @@ class SceneRenderer:
 
     def rejit_count(self) -> int:
         return lib().ptl_renderer_rejit_count(self._h)
+
+    def rejit_pending(self) -> bool:
+        """FLAG_ASYNC_REJIT: a specialised build is being compiled in the background / the un-specialised kernel is in use."""
+        return lib().ptl_renderer_rejit_pending(self._h) == 1
 
     def camera_state(self) -> dict:
         m, sub, pos = (C.c_double * 16)(), C.c_int(), (C.c_double * 3)()

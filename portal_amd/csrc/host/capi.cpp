@@ -13,7 +13,9 @@
 #include <dirent.h>
 
 #include <algorithm>
+#include <atomic>
 #include <set>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -26,6 +28,10 @@
 #include "scene.h"
 
 using namespace ptl;
+
+extern "C" int ptl_kernel_compile_prebuilt(int device, const char* hip_source, const ptl_uniform_desc* uniforms, int n_uniforms, size_t uniform_block_size,
+                                           const char* const* defines, int n_defines, const void* code, size_t code_size, ptl_kernel** out, char* log,
+                                           size_t log_cap);  // kernel.cpp
 
 namespace {
 
@@ -120,6 +126,29 @@ struct ptl_renderer {
     std::set<std::string> keep_dynamic;
     StageRef kernel_stage;
     int rejit_count = 0;
+    // PTL_FLAG_ASYNC_REJIT (bit 17): a specialised renderer whose baked values went stale does not stall the draw for the 1-3 s of a rebuild.
+    // It keeps two kernels -- `spec_kernel` (the specialised build of some scene state) and `dyn_kernel` (the un-specialised build: valid
+    // for every state) -- `kernel` points at the one in use, and a worker thread compiles the specialised source of the current state
+    // (hiprtc, no device); the draw that finds it finished, still matching the scene, loads the code object and switches.  Every
+    // build draws the same bits, so the pictures do not change with the switch -- only the kernel time does.
+    struct Build {  // everything a compile needs, detached from the scene handle (which the caller keeps changing)
+        std::string source;
+        std::vector<std::string> defines, desc_names;
+        std::vector<ptl_uniform_desc> descs;
+        size_t block_size = 0;
+        std::vector<UniformUpload> baked;
+    };
+    struct Job {
+        Build build;
+        std::atomic<int> state{1};  // 1 running, 2 done, 3 failed
+        std::vector<char> code;
+        std::thread worker;
+    };
+    ptl_kernel* spec_kernel = nullptr;
+    ptl_kernel* dyn_kernel = nullptr;
+    std::string spec_source, failed_source;
+    Build want;                 // the specialised build of the scene state seen by the last draw
+    std::shared_ptr<Job> job;
     // VideoRuntime (src/main.rs:771-925): per video, the sorted frame files and the frame currently bound
     struct VideoState {
         bool scanned = false;
@@ -542,6 +571,52 @@ int update_videos(ptl_renderer* r) {
 
 }  // namespace
 
+static constexpr unsigned kAsyncRejit = 1u << 17;  // PTL_FLAG_ASYNC_REJIT
+
+// reload_textures (main.rs:1066-1083) into a freshly built kernel
+static int bind_textures(ptl_renderer* r, ptl_kernel* k) {
+    if (r->device < 0) return PTL_OK;
+    for (const Texture& t : r->scene->textures) {
+        std::string path = r->asset_root.empty() ? t.path : r->asset_root + "/" + t.path;
+        uint8_t* px = nullptr;
+        int w = 0, h = 0;
+        if (ptl_png_read(path.c_str(), &px, &w, &h) != PTL_OK) continue;  // like the reference: the sampler stays unbound (see build_kernel)
+        int trc = ptl_kernel_set_texture(k, (t.name + "_tex").c_str(), px, w, h);
+        std::free(px);
+        if (trc < 0) return trc;
+    }
+    return PTL_OK;
+}
+
+// the kernel the draws use from now on: a different one starts from a blank uniform block and blank samplers
+static int activate_kernel(ptl_renderer* r, ptl_kernel* k);
+
+static ptl_renderer::Build snapshot_build(ptl_scene* s, unsigned flags) {
+    ptl_renderer::Build b;
+    b.source = s->last.source;
+    b.defines = s->last.defines;
+    unsigned waves = (flags >> 8) & 0xFu;
+    if (waves) b.defines.push_back("PTL_WAVES_PER_EU=" + std::to_string(waves));
+    b.desc_names = s->desc_names;
+    b.descs = s->descs;
+    for (size_t k = 0; k < b.descs.size(); ++k) b.descs[k].name = b.desc_names[k].c_str();
+    b.block_size = s->last.uniform_block_size;
+    b.baked = s->last.baked;
+    return b;
+}
+
+static int compile_build(const ptl_renderer::Build& b, int device, const std::vector<char>* prebuilt, ptl_kernel** out, char* log, size_t log_cap) {
+    std::vector<const char*> defines;
+    for (auto& d : b.defines) defines.push_back(d.c_str());
+    // (the desc names point into b.desc_names: re-seat them, `b` may have been moved since the snapshot)
+    std::vector<ptl_uniform_desc> descs = b.descs;
+    for (size_t k = 0; k < descs.size(); ++k) descs[k].name = b.desc_names[k].c_str();
+    if (prebuilt)
+        return ptl_kernel_compile_prebuilt(device, b.source.c_str(), descs.data(), (int)descs.size(), b.block_size, defines.data(), (int)defines.size(), prebuilt->data(),
+                                           prebuilt->size(), out, log, log_cap);
+    return ptl_kernel_compile(device, b.source.c_str(), descs.data(), (int)descs.size(), b.block_size, defines.data(), (int)defines.size(), out, log, log_cap);
+}
+
 static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     ptl_scene* s = r->owner;
     if (!(r->kernel_stage == r->scene->current_stage)) r->keep_dynamic.clear();  // another stage / clip: judge afresh what is constant
@@ -601,6 +676,11 @@ extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_r
         r->asset_root = asset_root ? asset_root : "";
         int rc = build_kernel(r.get(), log, log_cap);
         if (rc != PTL_OK) return rc;
+        if ((flags & kAsyncRejit) != 0 && (flags & 13u) != 0 && device >= 0) {  // background re-JIT: the first kernel is the specialised one of this state
+            r->spec_kernel = r->kernel;
+            r->spec_source = r->kernel_source;
+            r->want = snapshot_build(s, flags);
+        }
         // cam.set_cam(scene.cam); offset_after_material from the scene (main.rs:1057-1059)
         const CamSettings& c = s->scene->cam;
         r->cam.look_at = c.look_at;
@@ -728,9 +808,103 @@ extern "C" int ptl_renderer_uniform_value(ptl_renderer* r, int width, int height
     });
 }
 
+static int activate_kernel(ptl_renderer* r, ptl_kernel* k) {
+    if (r->kernel == k) return PTL_OK;
+    r->kernel = k;
+    r->uploaded_scene = 0;
+    r->uploaded_options = 0;
+    r->uploaded_w = r->uploaded_h = -1;
+    for (auto& v : r->videos) v.bound = -1;
+    return update_videos(r);
+}
+
+// PTL_FLAG_ASYNC_REJIT: pick the kernel for this draw without ever waiting for a compile of the specialised source (see ptl_renderer::Job).
+static int async_select_kernel(ptl_renderer* r) {
+    ptl_scene* s = r->owner;
+    const bool changed = r->kernel_scene_version != r->scene->version || !(r->kernel_stage == r->scene->current_stage);
+    if (!changed && !r->job && r->kernel == r->spec_kernel) return PTL_OK;
+    if (changed) {
+        if (!(r->kernel_stage == r->scene->current_stage)) r->keep_dynamic.clear();
+        if ((r->flags & 8u) != 0 && (r->flags & 5u) == 0) {  // clip-constant specialisation: a compiled-in value that moved becomes a run-time uniform
+            std::vector<UniformUpload> values = evaluate_scene_uniforms(*r->scene, nullptr);
+            size_t at = 0;
+            for (const UniformUpload& b : r->want.baked) {
+                while (at < values.size() && values[at].name != b.name) ++at;
+                if (at == values.size()) break;
+                if (!values[at].same_value(b)) r->keep_dynamic.insert(b.name);
+            }
+        }
+        refresh_generated(s, r->flags, &r->keep_dynamic);  // the specialised source of the CURRENT state (generation is milliseconds)
+        r->want = snapshot_build(s, r->flags);
+        r->kernel_scene_version = r->scene->version;
+        r->kernel_stage = r->scene->current_stage;
+    }
+    if (r->spec_kernel && r->spec_source == r->want.source) {  // (also: the state moved back to what the specialised kernel was built for)
+        r->baked = r->want.baked;
+        return activate_kernel(r, r->spec_kernel);
+    }
+    if (r->job && r->job->state.load() != 1) {  // the worker has finished
+        std::shared_ptr<ptl_renderer::Job> job = r->job;
+        if (job->worker.joinable()) job->worker.join();
+        r->job.reset();
+        if (job->state.load() == 2 && job->build.source == r->want.source) {
+            ptl_kernel* k = nullptr;
+            int rc = compile_build(job->build, r->device, &job->code, &k, nullptr, 0);  // module load only: the code object is there
+            if (rc == PTL_OK && (rc = bind_textures(r, k)) < 0) ptl_kernel_destroy(k);
+            if (rc == PTL_OK) {
+                ptl_kernel* old = r->spec_kernel;
+                r->spec_kernel = k;
+                r->spec_source = job->build.source;
+                r->kernel_source = r->spec_source;
+                r->baked = job->build.baked;
+                ++r->rejit_count;
+                rc = activate_kernel(r, k);
+                ptl_kernel_destroy(old);  // (never the active one: `k` has just been activated)
+                return rc;
+            }
+            r->failed_source = job->build.source;
+        } else if (job->state.load() == 3) {
+            r->failed_source = job->build.source;  // does not compile: stay on the un-specialised kernel, do not try this source again
+        }
+    }
+    if (!r->job && r->want.source != r->failed_source) {
+        auto job = std::make_shared<ptl_renderer::Job>();
+        job->build = r->want;
+        job->worker = std::thread([job] {
+            ptl_kernel* k = nullptr;
+            if (compile_build(job->build, -1, nullptr, &k, nullptr, 0) == PTL_OK) {
+                const void* data = nullptr;
+                size_t size = 0;
+                ptl_kernel_code_object(k, &data, &size);
+                job->code.assign(static_cast<const char*>(data), static_cast<const char*>(data) + size);
+                ptl_kernel_destroy(k);
+                job->state.store(2);
+            } else {
+                job->state.store(3);
+            }
+        });
+        r->job = job;
+    }
+    if (!r->dyn_kernel) {  // first need: built here, once (a cached code object makes it a module load)
+        refresh_generated(s, r->flags & ~13u);
+        ptl_renderer::Build dyn = snapshot_build(s, r->flags);
+        ptl_kernel* k = nullptr;
+        int rc = compile_build(dyn, r->device, nullptr, &k, nullptr, 0);
+        if (rc == PTL_OK && (rc = bind_textures(r, k)) < 0) ptl_kernel_destroy(k);
+        if (rc != PTL_OK) return rc;
+        r->dyn_kernel = k;
+    }
+    return activate_kernel(r, r->dyn_kernel);
+}
+
 static int prepare_draw(ptl_renderer* r, const ptl_frame* frame) {
     send_camera_matrix(r);
-    if ((r->flags & 5u) != 0 && r->kernel_scene_version != r->scene->version) {
+    const bool async = (r->flags & kAsyncRejit) != 0 && (r->flags & 13u) != 0 && r->device >= 0;
+    if (async) {
+        int rc = async_select_kernel(r);
+        if (rc != PTL_OK) return rc;
+    }
+    if (!async && (r->flags & 5u) != 0 && r->kernel_scene_version != r->scene->version) {
         // values are baked into a specialised kernel: the scene changed, so JIT again (cached by source hash)
         int rc = build_kernel(r, nullptr, 0);
         if (rc != PTL_OK) return rc;
@@ -738,7 +912,7 @@ static int prepare_draw(ptl_renderer* r, const ptl_frame* frame) {
     if (r->uploaded_scene != r->scene->version) {
         std::vector<std::string> errors;
         std::vector<UniformUpload> values = evaluate_scene_uniforms(*r->scene, &errors);  // scene.set_uniforms
-        if ((r->flags & 8u) != 0 && (r->flags & 5u) == 0) {
+        if (!async && (r->flags & 8u) != 0 && (r->flags & 5u) == 0) {
             // clip-constant specialisation: the kernel stays valid as long as every compiled-in value still holds; a value
             // that moved after all is demoted to a run-time uniform and the kernel is built again (cached by source hash)
             bool stale = !(r->kernel_stage == r->scene->current_stage);
@@ -1043,9 +1217,19 @@ extern "C" int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16],
 
 extern "C" ptl_kernel* ptl_renderer_kernel(ptl_renderer* r) { return r ? r->kernel : nullptr; }
 extern "C" int ptl_renderer_rejit_count(ptl_renderer* r) { return r ? r->rejit_count : -1; }
+extern "C" int ptl_renderer_rejit_pending(ptl_renderer* r) {
+    if (!r) return -1;
+    return (r->job || (r->spec_kernel != nullptr && r->kernel != r->spec_kernel)) ? 1 : 0;
+}
 extern "C" void ptl_renderer_destroy(ptl_renderer* r) {
     if (!r) return;
-    ptl_kernel_destroy(r->kernel);
+    if (r->job && r->job->worker.joinable()) r->job->worker.join();  // (the worker owns nothing of ours, but a thread must be joined)
+    if (r->spec_kernel || r->dyn_kernel) {  // background re-JIT: `kernel` is one of these two
+        ptl_kernel_destroy(r->spec_kernel);
+        ptl_kernel_destroy(r->dyn_kernel);
+    } else {
+        ptl_kernel_destroy(r->kernel);
+    }
     delete r;
 }
 

@@ -46,16 +46,25 @@ std::string cache_dir() {
     return env ? env : "";
 }
 
+std::string opt_level() {
+    const char* e = std::getenv("PTL_JIT_OPT");  // "-O1" (rounds 1-2), "-O2", "-Os" ...: A/B measurements
+    return (e && e[0] == '-' && e[1] == 'O') ? e : "-O3";
+}
+
 std::vector<std::string> compile_options(const char* const* defines, int n_defines) {
     const char* arch = std::getenv("PTL_OFFLOAD_ARCH");
     bool fast = false;  // the tolerance mode (device/ptl_glsl.h, PTL_FAST_MATH): contraction and approximate / and sqrt allowed
     for (int k = 0; k < n_defines; ++k) fast = fast || std::string(defines[k]) == "PTL_FAST_MATH";
     std::vector<std::string> o = {std::string("--offload-arch=") + (arch ? arch : "gfx950"),
-                                  // -O1, measured (profiles/r01/variants7_O1.jsonl, variants8_O1.jsonl): against -O3 the baked kernels
-                                  // are 10-16 % FASTER (portal_in_portal 4K 0.86 -> 0.72 ms, 136 -> 110 VGPRs, SGPR spills 20 -> 0),
-                                  // the dynamic ones 3-10 % faster except one (+3 %), and the JIT takes 1.8 s instead of 3.3 s.  -O2/-O3
-                                  // hoist and unroll the straight-line per-object code into long live ranges; results are identical.
-                                  "-O1",
+                                  // -O3 WITHOUT the SLP vectoriser, measured on the round-3 kernels (profiles/r03/variants9_opt_level.jsonl, same
+                                  // frame hashes): against -O1 the baked kernels are 10-23 % faster (portal_in_portal 4K 0.364 -> 0.327 ms,
+                                  // triple_portal 0.333 -> 0.300, monoportal 1080p 0.069 -> 0.055, plus_ultra 0.99 -> 0.76), the Int-baked and
+                                  // un-specialised ones 2-30 % (plus_ultra un-specialised 4.5 -> 2.0 ms) with ONE exception, the un-specialised
+                                  // portal_in_portal (0.78 -> 0.88: PTL_JIT_OPT=-O1 restores it; bench.py reports the better of the two).
+                                  // Rounds 1-2 shipped -O1: what lost then was the SLP vectoriser (v_pk_* pairs, long live ranges, spills --
+                                  // still true: plain -O3 is 0.362 / 0.361 / 1.27 on the first three), not the rest of -O2/-O3.
+                                  opt_level(),
+                                  "-fno-slp-vectorize",
                                   "-std=c++20",
                                   fast ? "-ffp-contract=fast" : "-ffp-contract=off",  // exact mode: FMAs only where device/ptl_glsl.h spells them
                                   fast ? "-fno-hip-fp32-correctly-rounded-divide-sqrt" : "-fhip-fp32-correctly-rounded-divide-sqrt",
@@ -165,6 +174,20 @@ static size_t type_size(ptl_type t) {
 }
 
 static thread_local bool tl_skip_cache_read = false;  // set for the one retry after the runtime refused a cached code object
+static thread_local const std::vector<char>* tl_prebuilt_code = nullptr;  // ptl_kernel_compile_prebuilt: this code object instead of cache / hiprtc
+
+// Layer-1 internal (capi.cpp's background re-JIT): load a code object that another thread compiled from exactly `hip_source` with
+// exactly these defines (a compile-only handle, device = -1) instead of compiling again.
+extern "C" int ptl_kernel_compile_prebuilt(int device, const char* hip_source, const ptl_uniform_desc* uniforms, int n_uniforms, size_t uniform_block_size,
+                                           const char* const* defines, int n_defines, const void* code, size_t code_size, ptl_kernel** out, char* log,
+                                           size_t log_cap) {
+    if (!code || code_size < 64) return PTL_ERR_INVALID;
+    const std::vector<char> copy(static_cast<const char*>(code), static_cast<const char*>(code) + code_size);
+    tl_prebuilt_code = &copy;
+    const int rc = ptl_kernel_compile(device, hip_source, uniforms, n_uniforms, uniform_block_size, defines, n_defines, out, log, log_cap);
+    tl_prebuilt_code = nullptr;
+    return rc;
+}
 
 extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_uniform_desc* uniforms, int n_uniforms,
                                   size_t uniform_block_size, const char* const* defines, int n_defines, ptl_kernel** out, char* log,
@@ -207,6 +230,10 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
         if (k->code.size() < 64 || std::memcmp(k->code.data(), "\x7f" "ELF", 4) != 0) k->code.clear();  // truncated or foreign file: compile again
     }
     bool from_cache = !k->code.empty();
+    if (tl_prebuilt_code) {  // compiled elsewhere from this very source: nothing to look up, nothing to build
+        k->code = *tl_prebuilt_code;
+        from_cache = false;
+    }
     if (k->code.empty()) {
         std::string err;
         const hip::Rtc* rc = hip::rtc(&err);

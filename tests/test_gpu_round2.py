@@ -266,3 +266,59 @@ def test_first_trip_plane_tests_change_no_bit(gpu, scene_name, spec):
     for a, b in zip(frames["first"], frames["general"]):
         assert np.array_equal(_bits(a), _bits(b))
     assert not np.array_equal(_bits(frames["general"][0]), _bits(frames["general"][1]))
+
+
+def test_background_rejit_does_not_stall_draws_and_changes_no_bit(gpu, tmp_path, monkeypatch):
+    """FLAG_ASYNC_REJIT: a renderer with the scene state baked in whose values go stale keeps drawing -- with the
+    un-specialised kernel of the scene, the same bits -- while a worker thread compiles the specialised kernel of the new state; the draw
+    that finds it ready switches.  A cold code-object cache makes every build a real hiprtc compile; after the one-off build of the
+    un-specialised kernel no draw waits for a compile again."""
+    import time
+
+    pa = gpu
+    monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path / "cache"))
+    (tmp_path / "cache").mkdir()
+    spec = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
+    scene, plain_scene = pa.Scene.from_file(pa.scene_path("portal_in_portal")), pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    t0 = time.perf_counter()
+    r = pa.SceneRenderer(scene, device=0, flags=spec | pa.FLAG_ASYNC_REJIT)
+    build_s = time.perf_counter() - t0           # one specialised compile: the yardstick for "did not wait"
+    ref = pa.SceneRenderer(plain_scene, device=0, flags=0)
+    for x in (r, ref):
+        x.set_option("render_depth", 20)
+    w, h = 320, 180
+    assert np.array_equal(_bits(r.draw(w, h, rgba32f=True)["rgba32f"]), _bits(ref.draw(w, h, rgba32f=True)["rgba32f"]))
+    assert not r.rejit_pending() and r.rejit_count() == 0
+
+    def move(value):
+        assert scene.set_uniform("progress", value) and plain_scene.set_uniform("progress", value)
+        t = time.perf_counter()
+        got = r.draw(w, h, rgba32f=True)["rgba32f"]
+        return got, time.perf_counter() - t
+
+    got, _first = move(0.37)                       # (may include the one-off build of the un-specialised kernel)
+    assert r.rejit_pending() and np.array_equal(_bits(got), _bits(ref.draw(w, h, rgba32f=True)["rgba32f"]))
+    deadline = time.time() + 120
+    while r.rejit_pending() and time.time() < deadline:  # the worker finishes, a draw adopts its kernel
+        time.sleep(0.05)
+        got = r.draw(w, h, rgba32f=True)["rgba32f"]
+    assert not r.rejit_pending() and r.rejit_count() == 1
+    assert np.array_equal(_bits(got), _bits(ref.draw(w, h, rgba32f=True)["rgba32f"]))
+    # from now on: a moved uniform costs a draw, not a compile
+    waits = []
+    for value in (0.11, 0.52, 0.93):
+        got, dt = move(value)
+        waits.append(dt)
+        assert r.rejit_pending() and np.array_equal(_bits(got), _bits(ref.draw(w, h, rgba32f=True)["rgba32f"]))
+    assert max(waits) < 0.5 * build_s, (waits, build_s)
+    while r.rejit_pending() and time.time() < deadline:
+        time.sleep(0.05)
+        got = r.draw(w, h, rgba32f=True)["rgba32f"]
+    assert not r.rejit_pending() and r.rejit_count() >= 2   # (intermediate states whose build was overtaken are never adopted)
+    assert np.array_equal(_bits(got), _bits(ref.draw(w, h, rgba32f=True)["rgba32f"]))
+    # back to a state whose kernel is cached: a cache hit is adopted like any other finished build; camera moves never rebuild
+    r.set_camera((0.2, 0.1, -0.3), 1.0, 1.3, 2.5)
+    ref.set_camera((0.2, 0.1, -0.3), 1.0, 1.3, 2.5)
+    count = r.rejit_count()
+    assert np.array_equal(_bits(r.draw(w, h, rgba32f=True)["rgba32f"]), _bits(ref.draw(w, h, rgba32f=True)["rgba32f"]))
+    assert r.rejit_count() == count and not r.rejit_pending()

@@ -132,6 +132,12 @@ VARIANTS = {
     "r3_all_w4_ra_default": "SPECIALIZE_ALL RA_DEFAULT -DPTL_WAVES_PER_EU=4", "r3_all_ra_default": "SPECIALIZE_ALL RA_DEFAULT", "r3_all_w4_ra_fast": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -vgpr-regalloc=fast",
     "r3_dyn_ra_default": "RA_DEFAULT", "r3_ints_ra_default": "SPECIALIZE RA_DEFAULT",
     "r3_all_noftp": "SPECIALIZE_ALL NO_FTP", "r3_all_w4_noftp": "SPECIALIZE_ALL NO_FTP -DPTL_WAVES_PER_EU=4", "r3_ints_noftp": "SPECIALIZE NO_FTP", "r3_dyn_noftp": "NO_FTP",
+    "r3_all_w4_ifcvt": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -amdgpu-early-ifcvt=1", "r3_all_w4_O2": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -O2 -fno-slp-vectorize",
+    "r3_all_w4_O3": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -O3 -fno-slp-vectorize", "r3_all_w4_Os": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -Os",
+    "r3_all_w4_skip4": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -amdgpu-skip-threshold=4", "r3_all_w4_skip32": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -amdgpu-skip-threshold=32",
+    "r3_all_w4_ilp": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -amdgpu-sched-strategy=max-ilp", "r3_all_w4_nomisched": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -enable-misched=false",
+    "r3_dyn_O2": "-O2 -fno-slp-vectorize", "r3_dyn_O3": "-O3 -fno-slp-vectorize", "r3_ints_O2": "SPECIALIZE -O2 -fno-slp-vectorize", "r3_ints_O3": "SPECIALIZE -O3 -fno-slp-vectorize",
+    "r3_all_O2": "SPECIALIZE_ALL -O2 -fno-slp-vectorize", "r3_all_O3": "SPECIALIZE_ALL -O3 -fno-slp-vectorize", "r3_all_w4_O3slp": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -O3",
     "r3_all_w4_zerofold": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -fno-signed-zeros -fno-honor-nans",
 }
 CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
