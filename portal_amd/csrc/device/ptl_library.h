@@ -215,6 +215,10 @@ PTL_FN SurfaceIntersection plane_intersect_derived(Ray r, const mat4& plane_inv,
 // plane_intersect / plane_intersect_derived for a ray whose origin in the plane's frame is already known (first-trip plane tests,
 // KernelOptions::first_trip_planes): `transform(plane_inv, r)` becomes (o_in_plane, plane_inv * r.d); every other operation as above.
 PTL_FN SurfaceIntersection plane_intersect_o(Ray r, const mat4& plane_inv, vec3 normal, const vec4& o_in_plane) {
+#if PTL_DEVICE_BUILD && defined(PTL_FAST_MATH)
+    (void)o_in_plane;
+    return plane_intersect(r, plane_inv, normal);  // the tolerance mode has its own plane test (same source as the exact build: FLAG_FAST_MATH only adds a define)
+#endif
     normal = normalize_normal(normal, r.d.sw<0, 1, 2>());
     r = Ray{o_in_plane, plane_inv * r.d, r.tmul, r.in_subspace};
     float len = length(r.d);
@@ -227,6 +231,10 @@ PTL_FN SurfaceIntersection plane_intersect_o(Ray r, const mat4& plane_inv, vec3 
     return result;
 }
 PTL_FN SurfaceIntersection plane_intersect_derived_o(Ray r, const mat4& plane_inv, vec3 unit_normal, bool& flipped, const vec4& o_in_plane) {
+#if PTL_DEVICE_BUILD && defined(PTL_FAST_MATH)
+    (void)o_in_plane;
+    return plane_intersect_derived(r, plane_inv, unit_normal, flipped);
+#endif
     flipped = dot(unit_normal, r.d.sw<0, 1, 2>()) > 0.0f;
     if (flipped) unit_normal *= -1.0f;
     r = Ray{o_in_plane, plane_inv * r.d, r.tmul, r.in_subspace};

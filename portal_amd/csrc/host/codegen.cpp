@@ -497,6 +497,16 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 gk.baked.push_back(up);
             }
         }
+        // first-trip plane tests (KernelOptions::first_trip_planes): only where some Flat object's matrix is a run-time value
+        auto first_trip_planes_wanted = [&]() {
+            if (!(opts.derived_uniforms && opts.first_trip_planes)) return false;
+            for (const Object& o : scene.objects) {
+                if (o.kind != Object::Flat) continue;
+                if (!baked.count(inverse_name(matrix_name(scene, o.m0, o)))) return true;
+                if (o.portal && !baked.count(inverse_name(matrix_name(scene, o.m1, o)))) return true;
+            }
+            return false;
+        };
         // --- derived uniforms: one entry per plane test of a Flat object whose matrix is a run-time uniform -------------
         if (opts.derived_uniforms) {
             for (size_t pos = 0; pos < scene.objects.size(); ++pos) {
@@ -544,9 +554,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         }
         if (opts.derived_uniforms) s.add_string("#define PTL_DERIVED_BUILTINS 1\n");
         {
-            bool any_flat = false;
-            for (const Object& o : scene.objects) any_flat = any_flat || o.kind == Object::Flat;
-            if (opts.derived_uniforms && opts.first_trip_planes && !opts.fast_math && !opts.specialize_all && any_flat)
+            if (first_trip_planes_wanted())
                 s.add_string("#define PTL_FIRST_TRIP_PLANES 1\n#ifndef PTL_FIRST_TRIP\n#define PTL_FIRST_TRIP 1\n#endif\n");
             bool any_first_snippet = false;
             for (const NamedCode& im : scene.intersection_materials) any_first_snippet = any_first_snippet || snippet.has_first(im.code);
@@ -562,7 +570,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         // first-trip plane tests: `plane_inv * camera origin` per generated plane test (KernelOptions::first_trip_planes)
         // (not with every scene uniform baked in: with the zero terms of the literal matrices skipped the origin half of a plane test
         // is a couple of FMAs, and the second copy of scene_intersect measured no gain there -- profiles/r03/variants7_first_trip_planes.jsonl)
-        const bool first_planes = opts.derived_uniforms && opts.first_trip_planes && !opts.fast_math && !opts.specialize_all;
+        const bool first_planes = first_trip_planes_wanted();
         if (first_planes)
             for (size_t pos = 0; pos < scene.objects.size(); ++pos) {
                 const Object& o = scene.objects[pos];

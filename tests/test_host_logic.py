@@ -818,7 +818,7 @@ def test_derived_uniforms_cover_every_flat_plane_and_vanish_when_baked(pa, name)
     block = src[src.index("struct ptl_uniform_block {"):src.index("};", src.index("struct ptl_uniform_block {"))]
     members = [l.split()[-1].rstrip(";") for l in block.splitlines()[1:] if l.strip()]
     first_derived = next(i for i, m in enumerate(members) if m.startswith("ptl_dv_"))
-    assert all(m.startswith(("ptl_dv_", "ptl_hv")) for m in members[first_derived:]) and first_derived == len(layout)  # (ptl_hv*: glsl_hoist.h)
+    assert all(m.startswith(("ptl_dv_", "ptl_dvo_", "ptl_hv")) for m in members[first_derived:]) and first_derived == len(layout)  # (ptl_hv*: glsl_hoist.h; ptl_dvo_*: first-trip plane tests)
     assert "hit = plane_intersect_derived(r" not in scene.generate_source(pa.FLAG_NO_DERIVED_UNIFORMS)
     assert "hit = plane_intersect_derived(r" not in scene.generate_source(pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
 
@@ -1026,7 +1026,9 @@ def test_hoisted_scene_source_is_selfconsistent(pa):
     src = scene.generate_source(baked)
     block = src[src.index("struct ptl_uniform_block {"):src.index("};", src.index("struct ptl_uniform_block {"))]
     assert re.findall(r"(\w+) ptl_hv\d+(\[\d+\])?;", block) == [("vec4", "[66]"), ("vec4", "[66]")]
-    assert src.count("ptl_ray_o(") == 3 and "intersect_material_0_first(Ray r) {" in src and "#define PTL_FIRST_TRIP" not in src
+    assert src.count("ptl_ray_o(") == 3 and "intersect_material_0_first(Ray r) {" in src
+    # (the generator says in the source itself which first-trip forms the kernel has; with the matrices baked: the snippets', not the planes')
+    assert "#define PTL_FIRST_TRIP_SNIPPETS 1" in src and "#define PTL_FIRST_TRIP_PLANES" not in src
 
 
 @pytest.mark.parametrize("scene_file,moves", [
@@ -1144,7 +1146,7 @@ def test_first_trip_plane_tests_are_selfconsistent_and_change_no_bit_on_the_host
     general = src[src.index("PTL_FN SceneIntersection scene_intersect(const Ray& r"):src.index("PTL_FN SceneIntersection scene_intersect_first(")]
     assert set(re.findall(r"PTL_U\.(ptl_dvo_\d+_[01])", first)) == members and "PTL_U.ptl_dvo_" not in general
     assert first.count("ptl_plane_cull_o(") == 27 and general.count("ptl_plane_cull(") == 27
-    for flags in (pa.FLAG_NO_DERIVED_UNIFORMS, pa.FLAG_NO_FIRST_TRIP_PLANES, pa.FLAG_FAST_MATH, pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL):
+    for flags in (pa.FLAG_NO_DERIVED_UNIFORMS, pa.FLAG_NO_FIRST_TRIP_PLANES, pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL):
         off = scene.generate_source(flags)
         assert "PTL_U.ptl_dvo_" not in off and "#define PTL_FIRST_TRIP_PLANES" not in off
     frames = {}
