@@ -594,9 +594,12 @@ def test_average_images_multiply_high_is_the_integer_division():
     count for which it does not (why 256 is the limit).  Also the argument that a 1-ulp sqrt cannot change L_TO_S: sqrt(l) stays
     >= 4.9e-4 away from every k + 0.5."""
     def exact(n):
+        # x -> (x * magic) >> 32 is monotone, so it equals floor(x / n) on a whole bucket [k n, k n + n - 1] iff it does at both ends:
+        # every bucket's two ends for k = 0 .. 65025 (the last bucket's upper end is beyond the largest sum, 65025 n: capped)
         magic = np.uint64(0xFFFFFFFF // n + 1)
-        x = np.arange(0, 65025 * n + 1, dtype=np.uint64)
-        return np.array_equal((x * magic) >> np.uint64(32), x // np.uint64(n))
+        k = np.arange(0, 65026, dtype=np.uint64)
+        lo, hi = k * np.uint64(n), np.minimum(k * np.uint64(n) + np.uint64(n - 1), np.uint64(65025 * n))
+        return all(np.array_equal((x * magic) >> np.uint64(32), x // np.uint64(n)) for x in (lo, hi))
 
     for n in range(2, 257):
         assert exact(n), n

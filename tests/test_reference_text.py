@@ -291,7 +291,7 @@ def test_live_teleport_query_function_and_framebuffer_route_agree_with_the_oracl
     rs, o = ReferenceShader(os.path.join(T.ROOT, "scenes", "triple_portal.ron")), Oracle(os.path.join(T.ROOT, "scenes", "triple_portal.ron"))
     rng = np.random.default_rng(11)
     hits = 0
-    for _ in range(16):
+    for _ in range(8):
         a = rng.uniform(-3, 3, 3)
         b = -a * rng.uniform(0.2, 1.0)
         want = o.teleport_external_ray(a, b)
@@ -310,7 +310,7 @@ CORPUS = sorted(glob.glob(os.path.join(CORPUS_ROOT, "scenes", "*.ron")))
 @pytest.mark.parametrize("chunk", range(4))
 def test_live_reference_text_equals_the_oracle_on_the_scene_corpus(chunk):
     """All 82 scene files of the reference (Complex objects, subspaces, skybox, DebugMatrix, Trefoil, user materials ...):
-    the generated slots for every object kind + the reference text == the hand restatement, 24x14 frames, depth 8."""
+    the generated slots for every object kind + the reference text == the hand restatement, 16x9 frames, depth 6."""
     from oracle.portal_oracle import Oracle
     from oracle.reference_shader import ReferenceShader
 
@@ -320,10 +320,10 @@ def test_live_reference_text_equals_the_oracle_on_the_scene_corpus(chunk):
         frames = []
         for cls in (ReferenceShader, Oracle):
             o = cls(path, asset_root=CORPUS_ROOT)
-            o.options.update(render_depth=8)
-            frames.append(o.render(24, 14)["rgba32f"])
+            o.options.update(render_depth=6)
+            frames.append(o.render(16, 9)["rgba32f"])
         ok = T.bits_equal(*frames)
-        assert ok.all(), f"{os.path.basename(path)}: {int((~ok).any(axis=2).sum())} of 336 pixels differ"
+        assert ok.all(), f"{os.path.basename(path)}: {int((~ok).any(axis=2).sum())} of 144 pixels differ"
 
 
 # ---------------------------------------------------------------------------------------------------------
