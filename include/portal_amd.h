@@ -216,6 +216,9 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * scene_intersect serves the trip on which every ray of a wave still starts at the camera and takes `plane_inv * r.o` of every Flat
  * object from the prologue kernel (ptl_dvo_<object>_<side>) -- the same product of the same values, identical frames.
  * bit17 = ASYNC REJIT (ptl_renderer_create only): see ptl_renderer_rejit_pending.
+ * bit18 = QUICK JIT: compile at -O1 instead of the shipped -O3 without SLP: half the hiprtc time for a 5-20 % slower kernel, identical
+ * frames -- for a build that is wanted now and used briefly (the CLI's render-frame; the kernel a clip starts on).  Implies bit15;
+ * ignored together with bit3 (a clip-constant build is asked for because many frames follow).
  * bit15 = NO unrolling of baked loops: by default (with bit0) a counting loop of a scene snippet whose bound is a baked Int uniform
  * (<= 16 iterations) is unrolled -- the same operations in the same order, identical frames; every iteration then has its own
  * constants (scenes/portal_in_portal.ron's `size` drives an inner loop and a material index).

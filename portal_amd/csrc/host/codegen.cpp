@@ -883,6 +883,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     if (opts.anaglyph) gk.defines.push_back("PTL_ANAGLYPH");
     if (opts.fast_math) gk.defines.push_back("PTL_FAST_MATH");
     if (opts.exact_cr) gk.defines.push_back("PTL_CONTRACT_V1");
+    if (opts.quick_jit) gk.defines.push_back("PTL_QUICK_JIT");
     // matrices baked into the source: a matrix product skips the terms whose matrix element is zero (device/ptl_glsl.h `ptl_mterm`)
     if ((opts.specialize_all || opts.specialize_static) && !opts.exact_cr && !opts.fast_math) gk.defines.push_back("PTL_DROP_ZERO_TERMS");
     if (gk.first_trip_variants) gk.defines.push_back("PTL_FIRST_TRIP");

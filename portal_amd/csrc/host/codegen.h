@@ -95,6 +95,7 @@ struct KernelOptions {
     // wave still starts at the camera takes `plane_inv * r.o` of every Flat object from the prologue kernel (a vec4 per plane behind the
     // derived uniforms) -- the same product of the same values, computed once per upload instead of per lane.  Needs derived_uniforms.
     bool first_trip_planes = true;
+    bool quick_jit = false;  // PTL_QUICK_JIT: compile at -O1 instead of the shipped -O3 (half the JIT time, a 5-20 % slower kernel)
     bool fast_math = false;  // PTL_FAST_MATH: hardware rcp / sqrt / rsq (1 ulp), a/b = a * rcp(b), FMA contraction: tolerance mode, not bit-exact
 };
 

@@ -46,15 +46,20 @@ std::string cache_dir() {
     return env ? env : "";
 }
 
-std::string opt_level() {
+std::string opt_level(bool quick) {
     const char* e = std::getenv("PTL_JIT_OPT");  // "-O1" (rounds 1-2), "-O2", "-Os" ...: A/B measurements
-    return (e && e[0] == '-' && e[1] == 'O') ? e : "-O3";
+    if (e && e[0] == '-' && e[1] == 'O') return e;
+    // PTL_QUICK_JIT (flags bit 18): the build is wanted NOW and used briefly -- one frame from the CLI (2.4 s of -O3 hiprtc for a 0.33 ms kernel
+    // that -O1 gives as a 0.36 ms one in 1.2 s), the un-specialised kernel a clip starts on while its specialised one compiles
+    return quick ? "-O1" : "-O3";
 }
 
 std::vector<std::string> compile_options(const char* const* defines, int n_defines) {
     const char* arch = std::getenv("PTL_OFFLOAD_ARCH");
     bool fast = false;  // the tolerance mode (device/ptl_glsl.h, PTL_FAST_MATH): contraction and approximate / and sqrt allowed
+    bool quick = false;
     for (int k = 0; k < n_defines; ++k) fast = fast || std::string(defines[k]) == "PTL_FAST_MATH";
+    for (int k = 0; k < n_defines; ++k) quick = quick || std::string(defines[k]) == "PTL_QUICK_JIT";
     std::vector<std::string> o = {std::string("--offload-arch=") + (arch ? arch : "gfx950"),
                                   // -O3 WITHOUT the SLP vectoriser, measured on the round-3 kernels (profiles/r03/variants9_opt_level.jsonl, same
                                   // frame hashes): against -O1 the baked kernels are 10-23 % faster (portal_in_portal 4K 0.364 -> 0.327 ms,
@@ -63,7 +68,7 @@ std::vector<std::string> compile_options(const char* const* defines, int n_defin
                                   // portal_in_portal (0.78 -> 0.88: PTL_JIT_OPT=-O1 restores it; bench.py reports the better of the two).
                                   // Rounds 1-2 shipped -O1: what lost then was the SLP vectoriser (v_pk_* pairs, long live ranges, spills --
                                   // still true: plain -O3 is 0.362 / 0.361 / 1.27 on the first three), not the rest of -O2/-O3.
-                                  opt_level(),
+                                  opt_level(quick),
                                   "-fno-slp-vectorize",
                                   "-std=c++20",
                                   fast ? "-ffp-contract=fast" : "-ffp-contract=off",  // exact mode: FMAs only where device/ptl_glsl.h spells them

@@ -838,6 +838,28 @@ def test_fast_math_is_a_flag_not_a_default(pa, tmp_path, monkeypatch):
     assert len(os.listdir(tmp_path)) == 2
 
 
+def test_quick_jit_is_a_build_option_for_the_unbaked_kernel_only(pa, tmp_path, monkeypatch):
+    """FLAG_QUICK_JIT (bit 18): same generated source, its own cache entry (-O1 instead of -O3), and no effect on a clip-constant
+    build (bit 3), which is asked for because many frames will run on it."""
+    monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path))
+    monkeypatch.delenv("PTL_JIT_OPT", raising=False)  # conftest pins -O1 for this suite; here the two levels are the point
+    scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+    assert scene.generate_source(pa.FLAG_QUICK_JIT) == scene.generate_source(0)
+    baked = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL  # with baked loop bounds the quick build also leaves the loops rolled
+    assert scene.generate_source(baked | pa.FLAG_QUICK_JIT) == scene.generate_source(baked | pa.FLAG_NO_UNROLL)
+    full = pa.SceneRenderer(scene, device=-1).code_object()
+    quick = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_QUICK_JIT).code_object()
+    assert full[:4] == quick[:4] == b"\x7fELF" and full != quick
+    assert len(os.listdir(tmp_path)) == 2
+    static = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_SPECIALIZE_STATIC).code_object()
+    assert pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_SPECIALIZE_STATIC | pa.FLAG_QUICK_JIT).code_object() == static
+    assert len(os.listdir(tmp_path)) == 3
+    r = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_QUICK_JIT)  # `render`: starts on the quick kernel, switches per clip
+    assert r.code_object() == quick
+    r.set_option("specialize_static", 1)
+    assert r.code_object() == static
+
+
 def test_code_object_cache_rejects_foreign_files_and_names_the_toolchain(pa, tmp_path, monkeypatch):
     """The cache key covers source + options + the hiprtc library that compiled it; a truncated or non-ELF file under that name is
     ignored and replaced by a fresh build."""
