@@ -531,6 +531,16 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 }
             }
         }
+        {  // out / inout arguments are lowered to references: refuse the scenes for which that is not GLSL's copy in / copy out
+            std::vector<std::string> file_scope, bodies;
+            for (const NamedCode& lib : scene.library) file_scope.push_back(filter_tagged_lines(lib.code, flags));
+            for (const Material& m : scene.materials)
+                if (m.kind == Material::Complex) bodies.push_back(filter_tagged_lines(m.code, flags));
+            for (const Object& o : scene.objects)
+                if (o.kind == Object::Flat || o.kind == Object::Complex) bodies.push_back(filter_tagged_lines(o.code, flags));
+            for (const NamedCode& im : scene.intersection_materials) bodies.push_back(filter_tagged_lines(im.code, flags));
+            check_out_argument_aliasing(file_scope, bodies);
+        }
         // --- uniform-only work of the scene snippets: members behind the derived planes, filled by the same prologue kernel -----
         if (opts.derived_uniforms && opts.hoist_uniform_work) {
             HoistParams hp;

@@ -13,6 +13,7 @@
 //   * the tagged-line filter of src/gui/scene.rs:1065-1107 (!FOR_NUMBER! etc.)
 #pragma once
 #include <string>
+#include <vector>
 
 namespace ptl {
 
@@ -44,5 +45,10 @@ std::string filter_tagged_lines(const std::string& text, const CodegenFlags& fla
 //   * every other occurrence of X in the loop body sits in a nested block, is not an assignment target, and X does not appear in
 //     the loop header.
 std::string translate_glsl(const std::string& glsl, bool defer_loop_updates = true);
+
+// Refuses (std::runtime_error) a scene in which passing `out` / `inout` arguments by reference could differ from GLSL's copy in /
+// copy out: a mutable global handed to a function that also names it, or one variable handed to two out parameters of a call.
+// `sources`: file-scope GLSL (the scene's library); `bodies`: statement lists that call into it (material / object / intersection snippets).
+void check_out_argument_aliasing(const std::vector<std::string>& sources, const std::vector<std::string>& bodies);
 
 }  // namespace ptl

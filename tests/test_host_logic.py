@@ -1141,6 +1141,44 @@ def test_first_trip_copy_declares_the_rays_a_plain_uniform_expression_reads(pa):
     assert len(np.unique(frames["first"].reshape(-1, 4), axis=0)) > 30
 
 
+def test_out_arguments_that_references_would_change_are_refused(pa):
+    """`out` / `inout` are lowered to C++ references, GLSL copies in and out.  The two differ only when the callee
+    reaches the argument under another name (a mutable global it also names) or one variable feeds two out parameters (undefined
+    order in GLSL).  Such a scene is refused at code generation; everything else -- the whole reference corpus -- goes through."""
+    import glob
+
+    base = open(pa.scene_path("basics")).read()
+    head = 'library: ([\n        (\n            name: "extra",\n            data: (("%s")),\n        ),'
+    snippet = """vec3 rel = r.o.xyz;
+float a = 1.0;
+%s
+return SceneIntersectionWithMaterial(scene_intersection_none, material_empty());"""
+    im = 'intersection_materials: ([\n        (\n            name: "probe",\n            data: ((("%s"))),\n        ),\n    ]),'
+
+    def scene(library, body):
+        text = base.replace("library: ([", head % library, 1).replace("intersection_materials: ([]),", im % (snippet % body), 1)
+        return pa.Scene.from_text(text)
+
+    counter = "float counter = 0.0;\nvoid bump(inout float x) { x += 1.0; counter += x; }\nvoid both(out float p, out float q) { p = 1.0; q = 2.0; }\nvoid outer(inout float x) { bump(x); }\n"
+    assert "bump(a)" in scene(counter, "bump(a);").generate_source(0)                  # a local: references == copy in / copy out
+    assert "both(a, rel.x)" in scene(counter, "both(a, rel.x);").generate_source(0)
+    with pytest.raises(RuntimeError, match="global `counter` is an out / inout argument"):
+        scene(counter, "bump(counter);").generate_source(0)
+    with pytest.raises(RuntimeError, match="global `counter` is an out / inout argument"):
+        scene(counter, "outer(counter);").generate_source(0)                           # through a call
+    with pytest.raises(RuntimeError, match="two out / inout parameters"):
+        scene(counter, "both(a, a);").generate_source(0)
+    assert "both(rel.x, rel.y)" in scene(counter, "both(rel.x, rel.y);").generate_source(0)  # two components: two objects
+    with pytest.raises(RuntimeError, match="two out / inout parameters"):
+        scene(counter, "both(rel.x, rel.x);").generate_source(0)
+    const_global = "const float k = 2.0;\nfloat scratch = 0.0;\nvoid setk(out float x) { x = k; }\n"
+    assert "setk(scratch)" in scene(const_global, "setk(scratch);").generate_source(0)  # the callee does not name `scratch`
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "corpus", "scenes", "**", "*.ron"), recursive=True))
+    assert len(files) >= 80
+    for path in files:
+        pa.Scene.from_file(path).generate_source(0)
+
+
 def test_hoister_counts_the_out_arguments_of_glsl_builtins_as_writes(pa):
     """`float ip = 0.0; f = modf(x, ip);` writes `ip` through an argument -- it is not a write-once uniform local, and
     `ip * k_u * k_u * k_u` must not move to the prologue with ip = 0.0 (latent: the prelude has no modf / frexp yet)."""
