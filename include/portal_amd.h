@@ -344,15 +344,19 @@ int ptl_ipc_close(void* device_ptr);
  * b % n == g, with its own renderer (same scene, same flags) on devices[g]; the frame is assembled in devices[0]'s memory by
  *   PTL_GROUP_PEER_STORES  the kernels' own row stores over xGMI (peer access, ptl_frame.in_place = 1): no staging, no gather;
  *   PTL_GROUP_COPY_GATHER  a packed shard per rank + ONE strided peer copy per rank (hipMemcpy2DAsync) that gathers and
- *                          de-interleaves in the same transfer -- what an RCCL gather to one root decomposes into.
- * No torch, no RCCL, no second process: a Rust host binds exactly these.  One thread drives all ranks;
- * the handle is not thread-safe.  A device may be listed more than once (rehearsal on a one-GPU machine).
+ *                          de-interleaves in the same transfer -- what an RCCL gather to one root decomposes into;
+ *   PTL_GROUP_RCCL_GATHER  the packed shards gathered by RCCL itself (ONE group of ncclSend x n / ncclRecv x n into devices[0], the
+ *                          "single RCCL gather" of BASELINE.json's north star), then one strided device-local copy per shard.
+ *                          librccl is bound at run time (dlopen; PTL_RCCL_LIB overrides the search): create fails with
+ *                          PTL_ERR_NO_DEVICE when it is absent.  Devices must be distinct for this transport.
+ * No torch, no second process: a Rust host binds exactly these.  One thread drives all ranks;
+ * the handle is not thread-safe.  A device may be listed more than once with the first two transports (rehearsal on a one-GPU machine).
  * Options / camera / update are forwarded to every rank's renderer (ptl_frame_group_renderer gives the individual ones;
  * keep them in step).  ptl_frame_group_draw returns after every rank has finished; *device_rgba8 is the width x height
  * RGBA8 frame on devices[0] (owned by the group, valid until the next draw with another size or destroy);
  * kernel_ms (n floats, may be NULL) receives each rank's trace-kernel time. */
 typedef struct ptl_frame_group ptl_frame_group;
-enum { PTL_GROUP_PEER_STORES = 0, PTL_GROUP_COPY_GATHER = 1 };
+enum { PTL_GROUP_PEER_STORES = 0, PTL_GROUP_COPY_GATHER = 1, PTL_GROUP_RCCL_GATHER = 2 };
 int ptl_frame_group_create(ptl_scene* s, const int* devices, int n_devices, const char* asset_root, unsigned flags, int transport,
                            ptl_frame_group** out, char* log, size_t log_cap);
 int ptl_frame_group_size(const ptl_frame_group* g);

@@ -524,7 +524,7 @@ class SceneRenderer:
         return {"rgba8": a8, "rgba32f": a32, "segments": seg.value if segments else None, "ms": ms.value}
 
 
-GROUP_PEER_STORES, GROUP_COPY_GATHER = 0, 1
+GROUP_PEER_STORES, GROUP_COPY_GATHER, GROUP_RCCL_GATHER = 0, 1, 2
 
 
 class FrameGroup:

@@ -33,7 +33,7 @@ void usage() {
     std::fprintf(stderr,
                  "usage: portal-amd render-frame <scene.ron> [--stage NAME | --animation NAME] [--camera NAME] [--time T] [--output out.png]\n"
                  "                  [--width W] [--height H] [--aa-count N] [--render-depth D] [--device I] [--asset-root DIR] [--panini D --fov DEG]\n"
-                 "                  [--gpus N | --devices a,b,..] [--transport stores|copy] [--multi-process]   one frame across the GPUs of a node\n"
+                 "                  [--gpus N | --devices a,b,..] [--transport stores|copy|rccl] [--multi-process]   one frame across the GPUs of a node\n"
                  "                  [--specialize 0] do NOT bake the scene state into the kernel   [--fast] tolerance mode   [--exact-cr] numerics contract 1   [--opt3] JIT at -O3 like the library default (render-frame: -O1)   [--timing] where the wall time went\n"
                  "       portal-amd precompile <scene.ron> [--stage NAME] [--specialize 0]      fill the code-object cache (no GPU needed)\n"
                  "       portal-amd render <scene[,scene..]> [clip[,clip..]] [--width 3840] [--height 2160] [--fps 60] [--motion-blur-frames 1]\n"
@@ -186,7 +186,7 @@ struct Options {
     int specialize = -1;  // -1 auto: clip-constant specialisation when the clip has enough sub-frames to repay the extra JIT
     int width = 1920, height = 1080, aa = 1, depth = 100, device = 0, fps = 60, blur = 1, shard = 0, shards = 1, max_frames = -1;
     double time = 0.0, panini = -1.0, fov = 90.0;
-    // render-frame across GPUs: --gpus N (devices 0..N-1) or --devices a,b,.. ; --transport stores|copy ; --multi-process
+    // render-frame across GPUs: --gpus N (devices 0..N-1) or --devices a,b,.. ; --transport stores|copy|rccl ; --multi-process
     int gpus = 1, rank = 0, world = 1;
     std::string devices, transport = "stores", ipc_handle;
     bool multi_process = false, fast = false, exact_cr = false, opt3 = false;
@@ -412,9 +412,9 @@ int render_frame(const Options& o) {
     double t_load = seconds_since(t0);
     std::vector<char> log(1 << 16);
     std::vector<uint8_t> img((size_t)o.width * o.height * 4);
-    if (devices.size() > 1) {  // one process, one renderer per GPU (include/portal_amd.h layer 3)
+    if (devices.size() > 1 || o.transport == "rccl") {  // one process, one renderer per GPU (include/portal_amd.h layer 3); `--transport rccl` also with one
         ptl_frame_group* g = nullptr;
-        int transport = o.transport == "copy" ? PTL_GROUP_COPY_GATHER : PTL_GROUP_PEER_STORES;
+        int transport = o.transport == "copy" ? PTL_GROUP_COPY_GATHER : o.transport == "rccl" ? PTL_GROUP_RCCL_GATHER : PTL_GROUP_PEER_STORES;
         if (ptl_frame_group_create(scene, devices.data(), (int)devices.size(), o.asset_root.c_str(), frame_flags(o), transport, &g, log.data(), log.size()) != PTL_OK) {
             std::fprintf(stderr, "frame group: %s\n%s\n", ptl_last_error(), log.data());
             return 1;
@@ -433,7 +433,7 @@ int render_frame(const Options& o) {
         for (float m : ms) per_rank += (per_rank.empty() ? "" : " ") + std::to_string(m).substr(0, 6);
         std::printf("Rendered `%s` to `%s` (%dx%d, aa %d, depth %d) on %zu GPUs (%s): kernel ms per rank [%s], frame %.3f ms wall; build %.2f s, total %.2f s\n",
                     o.scene.c_str(), o.output.c_str(), o.width, o.height, o.aa, o.depth, devices.size(),
-                    transport == PTL_GROUP_COPY_GATHER ? "packed shards + one strided peer copy each" : "kernels store into GPU 0's frame", per_rank.c_str(), draw_ms,
+                    transport == PTL_GROUP_COPY_GATHER ? "packed shards + one strided peer copy each" : transport == PTL_GROUP_RCCL_GATHER ? "packed shards + one RCCL gather" : "kernels store into GPU 0's frame", per_rank.c_str(), draw_ms,
                     t_build - t_load, seconds_since(t0));
         ptl_frame_group_destroy(g);
         ptl_scene_free(scene);
@@ -1032,8 +1032,8 @@ int main(int argc, char** argv) {
         return 2;
     }
     if (cmd == "render") return render(o);
-    if (o.transport != "stores" && o.transport != "copy") {
-        std::fprintf(stderr, "--transport stores|copy\n");
+    if (o.transport != "stores" && o.transport != "copy" && o.transport != "rccl") {
+        std::fprintf(stderr, "--transport stores|copy|rccl\n");
         return 2;
     }
     if (cmd == "render-frame") return render_frame(o);

@@ -174,4 +174,31 @@ const Rtc* rtc(std::string* error) {
     return ok ? &r : nullptr;
 }
 
+const Rccl* rccl(std::string* error) {
+    static std::mutex mu;
+    static Rccl r;
+    static bool tried = false, ok = false;
+    static std::string err;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tried) {
+        tried = true;
+        // The collectives run on streams and pointers of the HIP runtime this library is bound to: take the RCCL that goes with it
+        const Runtime* rt = runtime(&err);
+        if (rt) {
+            const char* env = std::getenv("PTL_RCCL_LIB");
+            std::string beside = dir_of(loaded_library_path("libamdhip64.so"));
+            std::vector<std::string> candidates = {env ? env : "", loaded_library_path("librccl.so"), beside.empty() ? "" : beside + "librccl.so",
+                                                   beside.empty() ? "" : beside + "librccl.so.1", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+            void* h = open_first(candidates, &r.path, &err);
+            if (h)
+                ok = bind(h, "ncclGetVersion", r.ncclGetVersion, &err) && bind(h, "ncclCommInitAll", r.ncclCommInitAll, &err) &&
+                     bind(h, "ncclCommDestroy", r.ncclCommDestroy, &err) && bind(h, "ncclGroupStart", r.ncclGroupStart, &err) &&
+                     bind(h, "ncclGroupEnd", r.ncclGroupEnd, &err) && bind(h, "ncclSend", r.ncclSend, &err) && bind(h, "ncclRecv", r.ncclRecv, &err) &&
+                     bind(h, "ncclGetErrorString", r.ncclGetErrorString, &err);
+        }
+    }
+    if (!ok && error) *error = "RCCL unavailable: " + err;
+    return ok ? &r : nullptr;
+}
+
 }  // namespace ptl::hip

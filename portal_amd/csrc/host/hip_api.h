@@ -85,8 +85,28 @@ struct Rtc {
     hiprtcResult (*hiprtcVersion)(int*, int*);
 };
 
+// RCCL (the NCCL API on ROCm), for the collective transport of layer 3 (multigpu.cpp).  Bound like the runtime: the copy the process has
+// already loaded (PyTorch ships one next to its HIP runtime), else the one beside the HIP runtime in use, else the system's.
+struct NcclUniqueId {
+    char internal[128];
+};
+using ncclComm_t = void*;
+constexpr int kNcclSuccess = 0, kNcclUint8 = 1;
+struct Rccl {
+    std::string path;
+    int (*ncclGetVersion)(int*);
+    int (*ncclCommInitAll)(ncclComm_t*, int, const int*);
+    int (*ncclCommDestroy)(ncclComm_t);
+    int (*ncclGroupStart)();
+    int (*ncclGroupEnd)();
+    int (*ncclSend)(const void*, size_t, int, int, ncclComm_t, hipStream_t);
+    int (*ncclRecv)(void*, size_t, int, int, ncclComm_t, hipStream_t);
+    const char* (*ncclGetErrorString)(int);
+};
+
 // nullptr (and *error filled) if the library cannot be found / lacks a symbol.
 const Runtime* runtime(std::string* error = nullptr);
 const Rtc* rtc(std::string* error = nullptr);
+const Rccl* rccl(std::string* error = nullptr);
 
 }  // namespace ptl::hip

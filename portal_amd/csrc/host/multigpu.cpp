@@ -1,9 +1,9 @@
-// multigpu.cpp -- layer 3 of the C ABI: ONE frame across the GPUs of one node, from one host process, without Python,
-// torch or RCCL (the draw it shards is SceneRenderer::draw_texture, src/main.rs:1411-1428).
+// multigpu.cpp -- layer 3 of the C ABI: ONE frame across the GPUs of one node, from one host process, without Python or
+// torch (the draw it shards is SceneRenderer::draw_texture, src/main.rs:1411-1428).
 //
 // Pixels are independent, so the frame shards with no exchange while tracing: rank g of G renders the 8-row blocks b with
 // b % G == g (interleaved: cost is spatially clustered -- portal interiors take many trips, walls one).  What is left is
-// getting every rank's rows into ONE frame buffer on devices[0].  Two transports, same bytes:
+// getting every rank's rows into ONE frame buffer on devices[0].  Three transports, same bytes:
 //
 //   PTL_GROUP_PEER_STORES   rank g's kernel stores its rows straight into the frame in devices[0]'s HBM (peer access inside
 //                           the process, hipDeviceEnablePeerAccess; ptl_frame.in_place = 1).  The 128-byte row stores of
@@ -14,6 +14,13 @@
 //                           the same link with the SDMA engine and puts every block where it belongs -- the gather and the
 //                           de-interleave in one transfer.  This is what an RCCL gather to one root decomposes into
 //                           (G - 1 point-to-point transfers into rank 0, no ring), minus the collective launch.
+//   PTL_GROUP_RCCL_GATHER   the transport BASELINE.json's north star names, spelled with the collective library itself: packed shards
+//                           as above, then ONE RCCL group -- ncclSend(shard -> rank 0) on every rank's communicator and stream,
+//                           ncclRecv x G on rank 0's -- i.e. ncclGather as RCCL's own documentation composes it, and one strided
+//                           device-local copy per shard on rank 0 to put the blocks where they belong.  Communicators come from
+//                           ncclCommInitAll (one process, G devices); librccl is bound with dlopen like the HIP runtime (hip_api.cpp),
+//                           so nothing links it and a box without it still has the other two transports.  Devices must be distinct
+//                           (RCCL refuses a device listed twice), G = 1 is a self send / receive.
 //
 // One thread drives all ranks: launches are asynchronous, each rank has its own non-blocking stream on its own device, and
 // the call returns after every rank's event has completed.  The same device may be listed more than once (rehearsal of the
@@ -35,12 +42,14 @@ struct ptl_frame_group {
     std::vector<ptl_renderer*> renderers;
     std::vector<hip::hipStream_t> streams;
     std::vector<hip::hipEvent_t> begin, end;
-    std::vector<void*> shards;  // PTL_GROUP_COPY_GATHER: packed rows of rank g in devices[g]'s memory
+    std::vector<void*> shards;  // PTL_GROUP_COPY_GATHER / RCCL_GATHER: packed rows of rank g in devices[g]'s memory
     size_t shard_bytes = 0;
     void* frame = nullptr;      // the assembled RGBA8 frame, devices[0]
     size_t frame_bytes = 0;
     int width = 0, height = 0;
     int transport = PTL_GROUP_PEER_STORES;
+    std::vector<hip::ncclComm_t> comms;  // PTL_GROUP_RCCL_GATHER: one communicator per rank (ncclCommInitAll)
+    void* gathered = nullptr;            //   the G packed shards side by side on devices[0], before the de-interleave copies
 };
 
 namespace {
@@ -64,7 +73,18 @@ void release_buffers(ptl_frame_group* g, const hip::Runtime* rt) {
             rt->hipFree(g->shards[k]);
             g->shards[k] = nullptr;
         }
+    if (g->gathered) {
+        rt->hipSetDevice(g->devices[0]);
+        rt->hipFree(g->gathered);
+        g->gathered = nullptr;
+    }
     g->frame_bytes = g->shard_bytes = 0;
+}
+
+int nccl_fail(const hip::Rccl* nc, int e, const char* what) {
+    if (e == hip::kNcclSuccess) return PTL_OK;
+    set_last_error(std::string(what) + ": " + nc->ncclGetErrorString(e) + " (" + std::to_string(e) + ")");
+    return PTL_ERR_HIP;
 }
 
 }  // namespace
@@ -72,7 +92,7 @@ void release_buffers(ptl_frame_group* g, const hip::Runtime* rt) {
 extern "C" int ptl_frame_group_create(ptl_scene* scene, const int* devices, int n_devices, const char* asset_root, unsigned flags, int transport,
                                       ptl_frame_group** out, char* log, size_t log_cap) {
     if (!scene || !devices || n_devices < 1 || n_devices > 64 || !out) return PTL_ERR_INVALID;
-    if (transport != PTL_GROUP_PEER_STORES && transport != PTL_GROUP_COPY_GATHER) return PTL_ERR_INVALID;
+    if (transport != PTL_GROUP_PEER_STORES && transport != PTL_GROUP_COPY_GATHER && transport != PTL_GROUP_RCCL_GATHER) return PTL_ERR_INVALID;
     *out = nullptr;
     std::string err;
     const hip::Runtime* rt = hip::runtime(&err);
@@ -119,6 +139,26 @@ extern "C" int ptl_frame_group_create(ptl_scene* scene, const int* devices, int 
         g->end.push_back(e);
     }
     g->shards.assign(n_devices, nullptr);
+    if (rc == PTL_OK && transport == PTL_GROUP_RCCL_GATHER) {
+        const hip::Rccl* nc = hip::rccl(&err);
+        if (!nc) {
+            set_last_error(err);
+            rc = PTL_ERR_NO_DEVICE;
+        } else {
+            for (int a = 0; a < n_devices && rc == PTL_OK; ++a)
+                for (int b = a + 1; b < n_devices; ++b)
+                    if (devices[a] == devices[b]) {
+                        set_last_error("PTL_GROUP_RCCL_GATHER: device " + std::to_string(devices[a]) + " is listed twice; an RCCL communicator has one rank per device");
+                        rc = PTL_ERR_INVALID;
+                        break;
+                    }
+            if (rc == PTL_OK) {
+                g->comms.assign(n_devices, nullptr);
+                rc = nccl_fail(nc, nc->ncclCommInitAll(g->comms.data(), n_devices, devices), "ncclCommInitAll");
+                if (rc != PTL_OK) g->comms.clear();
+            }
+        }
+    }
     if (rc != PTL_OK) {
         ptl_frame_group_destroy(g.release());
         return rc;
@@ -168,11 +208,13 @@ extern "C" int ptl_frame_group_draw(ptl_frame_group* g, int width, int height, v
     const int blocks = (height + 7) / 8;
     const size_t frame_bytes = (size_t)blocks * 8 * pitch;  // whole blocks: the strided copy of a ragged last block stays inside
     const size_t shard_bytes = (size_t)((blocks + n - 1) / n) * 8 * pitch;
-    if (frame_bytes != g->frame_bytes || (g->transport == PTL_GROUP_COPY_GATHER && shard_bytes != g->shard_bytes)) {
+    const bool packed = g->transport != PTL_GROUP_PEER_STORES;  // ranks render packed shards in their own memory
+    if (frame_bytes != g->frame_bytes || (packed && shard_bytes != g->shard_bytes)) {
         release_buffers(g, rt);
         int rc = hip_fail(rt, rt->hipSetDevice(g->devices[0]), "hipSetDevice");
         if (rc == PTL_OK) rc = hip_fail(rt, rt->hipMalloc(&g->frame, frame_bytes), "hipMalloc(frame)");
-        for (int k = 0; k < n && rc == PTL_OK && g->transport == PTL_GROUP_COPY_GATHER; ++k) {
+        if (rc == PTL_OK && g->transport == PTL_GROUP_RCCL_GATHER) rc = hip_fail(rt, rt->hipMalloc(&g->gathered, shard_bytes * (size_t)n), "hipMalloc(gathered shards)");
+        for (int k = 0; k < n && rc == PTL_OK && packed; ++k) {
             rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice");
             if (rc == PTL_OK) rc = hip_fail(rt, rt->hipMalloc(&g->shards[k], shard_bytes), "hipMalloc(shard)");
         }
@@ -181,7 +223,7 @@ extern "C" int ptl_frame_group_draw(ptl_frame_group* g, int width, int height, v
             return rc;
         }
         g->frame_bytes = frame_bytes;
-        g->shard_bytes = g->transport == PTL_GROUP_COPY_GATHER ? shard_bytes : 0;
+        g->shard_bytes = packed ? shard_bytes : 0;
     }
     g->width = width;
     g->height = height;
@@ -206,7 +248,7 @@ extern "C" int ptl_frame_group_draw(ptl_frame_group* g, int width, int height, v
             if (int rc = ptl_renderer_draw(g->renderers[k], &f, g->shards[k], nullptr, nullptr, g->streams[k], nullptr); rc != PTL_OK) return drain(k + 1, rc);
             rt->hipEventRecord(g->end[k], g->streams[k]);  // kernel time; the copy below is behind it on the same stream
             const int my_blocks = blocks > k ? (blocks - k + n - 1) / n : 0;
-            if (my_blocks > 0) {
+            if (my_blocks > 0 && g->transport == PTL_GROUP_COPY_GATHER) {
                 // shard block j -> frame block j * n + k: source pitch one block, destination pitch n blocks, `my_blocks` rows of 8 * pitch bytes
                 char* dst = static_cast<char*>(g->frame) + (size_t)k * 8 * pitch;
                 if (int rc = hip_fail(rt, rt->hipMemcpy2DAsync(dst, (size_t)n * 8 * pitch, g->shards[k], 8 * pitch, 8 * pitch, (size_t)my_blocks,
@@ -215,6 +257,30 @@ extern "C" int ptl_frame_group_draw(ptl_frame_group* g, int width, int height, v
                     rc != PTL_OK)
                     return drain(k + 1, rc);
             }
+        }
+    }
+    if (g->transport == PTL_GROUP_RCCL_GATHER) {
+        // ONE collective: every rank sends its packed shard to rank 0 (behind its kernel, on its stream), rank 0 receives them side by
+        // side -- a gather as RCCL composes it from point-to-point calls in a group; over xGMI that is G - 1 direct transfers into rank 0.
+        const hip::Rccl* nc = hip::rccl(nullptr);
+        int rc = nccl_fail(nc, nc->ncclGroupStart(), "ncclGroupStart");
+        for (int k = 0; k < n && rc == PTL_OK; ++k) rc = nccl_fail(nc, nc->ncclSend(g->shards[k], shard_bytes, hip::kNcclUint8, 0, g->comms[k], g->streams[k]), "ncclSend(shard)");
+        for (int k = 0; k < n && rc == PTL_OK; ++k)
+            rc = nccl_fail(nc, nc->ncclRecv(static_cast<char*>(g->gathered) + (size_t)k * shard_bytes, shard_bytes, hip::kNcclUint8, k, g->comms[0], g->streams[0]), "ncclRecv(shard)");
+        int end = nc->ncclGroupEnd();  // always closed, also after a failed call inside the group
+        if (rc == PTL_OK) rc = nccl_fail(nc, end, "ncclGroupEnd");
+        if (rc != PTL_OK) return drain(n, rc);
+        // de-interleave on rank 0, behind the receives on its stream: shard k's block j -> frame block j * n + k
+        if (int rc2 = hip_fail(rt, rt->hipSetDevice(g->devices[0]), "hipSetDevice"); rc2 != PTL_OK) return drain(n, rc2);
+        for (int k = 0; k < n; ++k) {
+            const int my_blocks = blocks > k ? (blocks - k + n - 1) / n : 0;
+            if (my_blocks == 0) continue;
+            char* dst = static_cast<char*>(g->frame) + (size_t)k * 8 * pitch;
+            const char* src = static_cast<const char*>(g->gathered) + (size_t)k * shard_bytes;
+            if (int rc2 = hip_fail(rt, rt->hipMemcpy2DAsync(dst, (size_t)n * 8 * pitch, src, 8 * pitch, 8 * pitch, (size_t)my_blocks, hip::kMemcpyDefault, g->streams[0]),
+                                   "hipMemcpy2DAsync(gathered shard -> frame)");
+                rc2 != PTL_OK)
+                return drain(n, rc2);
         }
     }
     for (int k = 0; k < n; ++k) {
@@ -238,6 +304,16 @@ extern "C" void ptl_frame_group_destroy(ptl_frame_group* g) {
     const hip::Runtime* rt = hip::runtime(nullptr);
     for (ptl_renderer* r : g->renderers) ptl_renderer_destroy(r);  // first: a kernel handle waits for its last launch's stream
     g->renderers.clear();
+    if (rt && !g->comms.empty()) {  // before the streams the collectives ran on
+        for (size_t k = 0; k < g->streams.size(); ++k) {
+            rt->hipSetDevice(g->devices[k]);
+            if (g->streams[k]) rt->hipStreamSynchronize(g->streams[k]);
+        }
+        if (const hip::Rccl* nc = hip::rccl(nullptr))
+            for (hip::ncclComm_t c : g->comms)
+                if (c) nc->ncclCommDestroy(c);
+        g->comms.clear();
+    }
     if (rt) {
         for (size_t k = 0; k < g->streams.size(); ++k) {
             rt->hipSetDevice(g->devices[k]);

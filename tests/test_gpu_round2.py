@@ -155,6 +155,32 @@ def test_frame_group_assembles_the_single_gpu_frame(gpu, transport, ranks):
     assert np.array_equal(big, single.draw(1920, 1080)["rgba8"])
 
 
+def test_frame_group_rccl_gather_on_the_devices_of_this_box(gpu):
+    """PTL_GROUP_RCCL_GATHER (the north star's "single RCCL gather", layer 3): librccl bound with dlopen, communicators from
+    ncclCommInitAll, one group of ncclSend / ncclRecv into rank 0, strided copies into the frame.  On this box the communicator has as
+    many ranks as there are GPUs (one: a self send / receive -- binding, group, streams, buffers, de-interleave all run); the frame
+    must be the single-renderer frame byte for byte, also for a ragged size and after a re-allocation.  A device listed twice is an error
+    that says why (an RCCL communicator has one rank per device), not a hang."""
+    pa = gpu
+    devices = list(range(pa.device_count()))
+    scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+    single = pa.SceneRenderer(scene, device=0)
+    single.set_option("render_depth", 20)
+    g = pa.FrameGroup(pa.Scene.from_file(pa.scene_path("monoportal")), devices, transport=pa.GROUP_RCCL_GATHER)
+    g.set_option("render_depth", 20)
+    for w, h in ((200, 100), (1920, 1080), (200, 100)):
+        out = g.draw(w, h)
+        assert np.array_equal(out["rgba8"], single.draw(w, h)["rgba8"])
+        assert len(out["kernel_ms"]) == len(devices) and all(ms > 0 for ms in out["kernel_ms"])
+    cam = ((0.2, 0.1, -0.3), 0.9, 1.2, 3.1)
+    single.set_camera(*cam)
+    g.set_camera(*cam)
+    assert np.array_equal(g.draw(640, 360)["rgba8"], single.draw(640, 360)["rgba8"])
+    del g
+    with pytest.raises(pa.PortalError, match="listed twice"):
+        pa.FrameGroup(pa.Scene.from_file(pa.scene_path("monoportal")), [0, 0], transport=pa.GROUP_RCCL_GATHER)
+
+
 def _cli(*args, timeout=600):
     exe = os.path.join(ROOT, "portal_amd", "portal-amd")
     done = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
@@ -162,8 +188,8 @@ def _cli(*args, timeout=600):
     return done.stdout
 
 
-@pytest.mark.parametrize("mode", [["--devices", "0,0"], ["--devices", "0,0,0", "--transport", "copy"], ["--devices", "0,0", "--multi-process"]],
-                         ids=["in-process-stores", "in-process-copy", "two-processes-ipc"])
+@pytest.mark.parametrize("mode", [["--devices", "0,0"], ["--devices", "0,0,0", "--transport", "copy"], ["--devices", "0,0", "--multi-process"], ["--devices", "0", "--transport", "rccl"]],
+                         ids=["in-process-stores", "in-process-copy", "two-processes-ipc", "in-process-rccl-one-rank"])
 def test_cli_render_frame_across_ranks_writes_the_same_png(gpu, tmp_path, mode):
     """`portal-amd render-frame --gpus N` (here: the same GPU listed twice / three times): in one process through layer 3, and as
     two PROCESSES where rank 1 (`render-shard`) maps rank 0's frame through HIP IPC and stores its rows into it."""

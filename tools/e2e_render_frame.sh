@@ -22,4 +22,5 @@ echo "== two ranks on this one GPU (control-flow rehearsal of --gpus N)"
 portal_amd/portal-amd render-frame scenes/portal_in_portal.ron --width 3840 --height 2160 --render-depth 40 --devices 0,0 --output /tmp/e2e2.png
 portal_amd/portal-amd render-frame scenes/portal_in_portal.ron --width 3840 --height 2160 --render-depth 40 --devices 0,0 --transport copy --output /tmp/e2e3.png
 portal_amd/portal-amd render-frame scenes/portal_in_portal.ron --width 3840 --height 2160 --render-depth 40 --devices 0,0 --multi-process --output /tmp/e2e4.png
-cmp /tmp/e2e2.png /tmp/e2e3.png && cmp /tmp/e2e2.png /tmp/e2e4.png && echo "all three multi-rank PNGs identical"
+portal_amd/portal-amd render-frame scenes/portal_in_portal.ron --width 3840 --height 2160 --render-depth 40 --devices 0 --transport rccl --output /tmp/e2e5.png
+cmp /tmp/e2e2.png /tmp/e2e3.png && cmp /tmp/e2e2.png /tmp/e2e4.png && cmp /tmp/e2e2.png /tmp/e2e5.png && echo "all four multi-rank PNGs identical"
