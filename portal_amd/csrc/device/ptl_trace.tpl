@@ -313,6 +313,26 @@ PTL_FN RayTraceResult ray_tracing(Ray r, float camera_scale) {
 #ifdef PTL_FIRST_TRIP
     const bool first_form = __builtin_amdgcn_ballot_w64(!origin_is_camera) == 0ull;  // one decision per wave (side-by-side stereo mixes eyes)
 #endif
+#if defined(PTL_FIRST_TRIP) && defined(PTL_PEEL_FIRST_TRIP)
+    // Trip 0 apart from the loop: it is the only trip that can take the first-trip forms, every lane is alive in it, and nine trips in
+    // ten are a trip 0 -- with it peeled, the loop body has the general forms only and trip 0 the first-trip forms only (when the wave
+    // agrees it starts at the camera), instead of one body that decides per trip.
+    int j = 0;
+    if (_ray_tracing_depth > 0) {
+        PTL_RELAUNDER();
+        PTL_COUNT_SEGMENT();
+        alive = !trace_segment(r, current_color, all_t, camera_scale, not_found_color, result, first_form);
+        j = 1;
+    }
+    for (; j < _ray_tracing_depth; j++) {
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
+        PTL_RELAUNDER();
+        if (alive) {
+            PTL_COUNT_SEGMENT();
+            alive = !trace_segment(r, current_color, all_t, camera_scale, not_found_color, result, false);
+        }
+    }
+#else
     for (int j = 0; j < _ray_tracing_depth; j++) {
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;  // every ray of the tile has terminated
         PTL_RELAUNDER();
@@ -325,6 +345,7 @@ PTL_FN RayTraceResult ray_tracing(Ray r, float camera_scale) {
 #endif
         }
     }
+#endif  // PTL_PEEL_FIRST_TRIP
 #else
     for (int j = 0; j < _ray_tracing_depth; j++) {
         PTL_RELAUNDER();

@@ -117,6 +117,7 @@ struct ptl_renderer {
     std::string asset_root;
     unsigned long long kernel_scene_version = 0;
     std::string kernel_source;
+    std::map<std::string, int> kernel_switches;  // the mode switches the current specialised kernel has compiled in (KernelOptions::baked_options)
     // SceneRenderer::update state (src/main.rs:1430-1538)
     Camera prev_cam;
     bool has_prev_cam = false;
@@ -435,9 +436,17 @@ static KernelOptions options_from_flags(unsigned flags) {
     return o;
 }
 
-static void refresh_generated(ptl_scene* s, unsigned flags, const std::set<std::string>* keep_dynamic = nullptr) {
+// The renderer's mode switches that a specialised build compiles in (KernelOptions::baked_options): the camera models and output modes.
+static std::map<std::string, int> mode_switches(const ptl_renderer& r) {
+    return {{"_use_panini_projection", r.cam.use_panini_projection ? 1 : 0}, {"_use_360_camera", r.cam.use_360_camera ? 1 : 0},
+            {"_use_180_camera", r.cam.use_180_camera ? 1 : 0},               {"_draw_depth_map", r.draw_depth_map ? 1 : 0},
+            {"_draw_anaglyph", r.draw_anaglyph ? 1 : 0},                     {"_draw_side_by_side", r.draw_side_by_side ? 1 : 0}};
+}
+
+static void refresh_generated(ptl_scene* s, unsigned flags, const std::set<std::string>* keep_dynamic = nullptr, const std::map<std::string, int>* switches = nullptr) {
     KernelOptions opts = options_from_flags(flags);
     if (keep_dynamic) opts.keep_dynamic = *keep_dynamic;
+    if (switches && (flags & 13u) != 0) opts.baked_options = *switches;
     CodegenFlags cg;
     cg.defer_loop_updates = (flags & 128u) == 0;  // PTL_FLAG_NO_DEFERRED_UPDATES: the snippets exactly as written (A/B measurements, tests)
     s->last = generate_kernel_source(*s->scene, cg, opts);
@@ -625,7 +634,8 @@ static int compile_build(const ptl_renderer::Build& b, int device, const std::ve
 static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     ptl_scene* s = r->owner;
     if (!(r->kernel_stage == r->scene->current_stage)) r->keep_dynamic.clear();  // another stage / clip: judge afresh what is constant
-    refresh_generated(s, r->flags, &r->keep_dynamic);
+    r->kernel_switches = mode_switches(*r);
+    refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches);
     r->baked = s->last.baked;
     r->kernel_stage = r->scene->current_stage;
     if (r->kernel && s->last.source == r->kernel_source) {  // nothing baked in changed
@@ -826,7 +836,7 @@ static int activate_kernel(ptl_renderer* r, ptl_kernel* k) {
 // PTL_FLAG_ASYNC_REJIT: pick the kernel for this draw without ever waiting for a compile of the specialised source (see ptl_renderer::Job).
 static int async_select_kernel(ptl_renderer* r) {
     ptl_scene* s = r->owner;
-    const bool changed = r->kernel_scene_version != r->scene->version || !(r->kernel_stage == r->scene->current_stage);
+    const bool changed = r->kernel_scene_version != r->scene->version || !(r->kernel_stage == r->scene->current_stage) || mode_switches(*r) != r->kernel_switches;
     if (!changed && !r->job && r->kernel == r->spec_kernel) return PTL_OK;
     if (changed) {
         if (!(r->kernel_stage == r->scene->current_stage)) r->keep_dynamic.clear();
@@ -839,7 +849,8 @@ static int async_select_kernel(ptl_renderer* r) {
                 if (!values[at].same_value(b)) r->keep_dynamic.insert(b.name);
             }
         }
-        refresh_generated(s, r->flags, &r->keep_dynamic);  // the specialised source of the CURRENT state (generation is milliseconds)
+        r->kernel_switches = mode_switches(*r);
+        refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches);  // the specialised source of the CURRENT state (generation is milliseconds)
         r->want = snapshot_build(s, r->flags);
         r->kernel_scene_version = r->scene->version;
         r->kernel_stage = r->scene->current_stage;
@@ -908,6 +919,12 @@ static int prepare_draw(ptl_renderer* r, const ptl_frame* frame) {
     if (async) {
         int rc = async_select_kernel(r);
         if (rc != PTL_OK) return rc;
+    }
+    if (!async && (r->flags & 13u) != 0 && mode_switches(*r) != r->kernel_switches) {
+        // a camera model / output mode was switched: the specialised kernel has the old one compiled in (and the new one compiled out)
+        int rc = build_kernel(r, nullptr, 0);
+        if (rc != PTL_OK) return rc;
+        ++r->rejit_count;
     }
     if (!async && (r->flags & 5u) != 0 && r->kernel_scene_version != r->scene->version) {
         // values are baked into a specialised kernel: the scene changed, so JIT again (cached by source hash)
@@ -1220,7 +1237,17 @@ extern "C" int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16],
     return PTL_OK;
 }
 
-extern "C" ptl_kernel* ptl_renderer_kernel(ptl_renderer* r) { return r ? r->kernel : nullptr; }
+extern "C" ptl_kernel* ptl_renderer_kernel(ptl_renderer* r) {
+    if (!r) return nullptr;
+    // the kernel the next draw would use: a specialised build follows the mode switches (also on a handle without a device, which never draws)
+    if ((r->flags & 13u) != 0 && !((r->flags & kAsyncRejit) != 0 && r->device >= 0) && mode_switches(*r) != r->kernel_switches)
+        guarded([&] {
+            int rc = build_kernel(r, nullptr, 0);
+            if (rc == PTL_OK) ++r->rejit_count;
+            return rc;
+        });
+    return r->kernel;
+}
 extern "C" int ptl_renderer_rejit_count(ptl_renderer* r) { return r ? r->rejit_count : -1; }
 extern "C" int ptl_renderer_rejit_pending(ptl_renderer* r) {
     if (!r) return -1;

@@ -497,6 +497,10 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 gk.baked.push_back(up);
             }
         }
+        if (opts.specialize_ints || opts.specialize_all || opts.specialize_static)
+            for (auto& [name, value] : opts.baked_options)
+                for (auto& u : list)
+                    if (u.name == name && u.type == UniformType::Int1) baked[name] = std::to_string(value);
         // first-trip plane tests (KernelOptions::first_trip_planes): only where some Flat object's matrix is a run-time value
         auto first_trip_planes_wanted = [&]() {
             if (!(opts.derived_uniforms && opts.first_trip_planes)) return false;

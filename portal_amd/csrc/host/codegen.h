@@ -78,6 +78,11 @@ struct KernelOptions {
     bool anaglyph = false;         // compile the !ANAGLYPH! code in (the reference's `disable_anaglyph = false`)
     bool specialize_static = false;  // bake every scene uniform whose evaluation does not read a per-frame input ...
     std::set<std::string> keep_dynamic;  // ... except these (values that changed after all: demoted by the renderer)
+    // The renderer's own mode switches (`_use_panini_projection`, `_use_360_camera`, `_use_180_camera`, `_draw_depth_map`, `_draw_anaglyph`,
+    // `_draw_side_by_side`) as literals, name -> value: with any specialisation on, the camera models and output modes a frame does not use
+    // are not compiled in at all -- 7-10 % of the kernel time of the BASELINE scenes (profiles/r03/stub_bake_switches.jsonl), although they
+    // are read once per ray: what they cost is registers and code around the bounce loop.  The renderer rebuilds when one changes.
+    std::map<std::string, int> baked_options;
     // Ray-independent work of the generated plane code (normalize(get_normal(X_mat)), both possible is_collinear verdicts) is
     // evaluated once per uniform upload by the module's prologue kernel `ptl_derive_kernel` and read back as extra uniforms,
     // instead of once per bounce-loop trip by every lane.  Same functions, same binary32 operations: identical frames.

@@ -860,6 +860,35 @@ def test_quick_jit_is_a_build_option_for_the_unbaked_kernel_only(pa, tmp_path, m
     assert r.code_object() == static
 
 
+def test_specialised_builds_compile_the_renderers_mode_switches_in(pa, tmp_path, monkeypatch):
+    """With any specialisation on, the camera models / output modes a frame does not use are not in the kernel at all
+    (KernelOptions::baked_options; 7-10 % of the BASELINE scenes' kernel time, profiles/r03/stub_bake_switches.jsonl): the specialised
+    build is a different code object from the one a switch flips to, the flip rebuilds (counted), flipping back finds the first one in
+    the cache; the un-specialised kernel reads the switches at run time and never rebuilds."""
+    monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path))
+    scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+    baked = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
+    pinhole = baked.code_object()
+    assert len(os.listdir(tmp_path)) == 1 and baked.rejit_count() == 0
+    baked.set_option("use_360_camera", 1)
+    sphere = baked.code_object()
+    assert sphere != pinhole and baked.rejit_count() == 1 and len(os.listdir(tmp_path)) == 2
+    assert len(sphere) != len(pinhole)  # another camera model's code, not a flipped literal
+    baked.set_option("render_depth", 7)   # not a mode switch: stays a run-time uniform
+    assert baked.code_object() == sphere and baked.rejit_count() == 1
+    baked.set_option("use_360_camera", 0)
+    assert baked.code_object() == pinhole and baked.rejit_count() == 2 and len(os.listdir(tmp_path)) == 2
+    dynamic = pa.SceneRenderer(scene, device=-1)
+    before = dynamic.code_object()
+    dynamic.set_option("use_360_camera", 1)
+    dynamic.set_option("draw_depth_map", 1)
+    assert dynamic.code_object() == before and dynamic.rejit_count() == 0
+    static = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_SPECIALIZE_STATIC)
+    flat = static.code_object()
+    static.set_option("draw_depth_map", 1)
+    assert static.code_object() != flat and static.rejit_count() == 1
+
+
 def test_code_object_cache_rejects_foreign_files_and_names_the_toolchain(pa, tmp_path, monkeypatch):
     """The cache key covers source + options + the hiprtc library that compiled it; a truncated or non-ELF file under that name is
     ignored and replaced by a fresh build."""

@@ -14,6 +14,27 @@ import portal_amd as pa  # noqa: E402
 
 PATCHES = {
     "intact": [],
+    # EXPERIMENTS (must draw the intact picture): uniforms that stay run-time values in a fully baked build, as literals.
+    # `teleport_light_u` is kept dynamic because the camera-teleport entry forces it to 1; the `_`-options are the renderer's own switches
+    "bake_teleport_light": [("#define teleport_light_u (PTL_U.teleport_light_u)", "#define teleport_light_u (1)")],
+    "bake_black_border": [("#define _black_border_disable (PTL_U._black_border_disable)", "#define _black_border_disable (0)")],
+    "bake_mode_switches": [("#define teleport_light_u (PTL_U.teleport_light_u)", "#define teleport_light_u (1)")] + [
+        ("#define %s (PTL_U.%s)" % (n, n), "#define %s (%s)" % (n, v)) for n, v in (
+            ("_black_border_disable", "0"), ("_grid_disable", "0"), ("_angle_color_disable", "0"), ("_darken_by_distance", "1"), ("_use_panini_projection", "0"),
+            ("_use_360_camera", "0"), ("_use_180_camera", "0"), ("_draw_depth_map", "0"), ("_draw_anaglyph", "0"), ("_draw_side_by_side", "0"), ("_aa_count", "1"),
+            ("_aa_start", "0"), ("_ray_tracing_depth", "40"), ("_teleport_external_ray", "0"))],
+    "bake_a_colour_switches": [("#define %s (PTL_U.%s)" % (n, n), "#define %s (%s)" % (n, v)) for n, v in (
+        ("_black_border_disable", "0"), ("_grid_disable", "0"), ("_angle_color_disable", "0"), ("_darken_by_distance", "1"))],
+    "bake_b_camera_modes": [("#define %s (PTL_U.%s)" % (n, n), "#define %s (%s)" % (n, v)) for n, v in (
+        ("_use_panini_projection", "0"), ("_use_360_camera", "0"), ("_use_180_camera", "0"), ("_draw_depth_map", "0"), ("_draw_anaglyph", "0"), ("_draw_side_by_side", "0"))],
+    "bake_c_aa_count": [("#define _aa_count (PTL_U._aa_count)", "#define _aa_count (1)")],
+    "bake_d_depth": [("#define _ray_tracing_depth (PTL_U._ray_tracing_depth)", "#define _ray_tracing_depth (40)")],
+    "bake_abc": [("#define %s (PTL_U.%s)" % (n, n), "#define %s (%s)" % (n, v)) for n, v in (
+        ("_black_border_disable", "0"), ("_grid_disable", "0"), ("_angle_color_disable", "0"), ("_darken_by_distance", "1"),
+        ("_use_panini_projection", "0"), ("_use_360_camera", "0"), ("_use_180_camera", "0"), ("_draw_depth_map", "0"), ("_draw_anaglyph", "0"), ("_draw_side_by_side", "0"),
+        ("_aa_count", "1"))],
+    "bake_both": [("#define teleport_light_u (PTL_U.teleport_light_u)", "#define teleport_light_u (1)"),
+                  ("#define _black_border_disable (PTL_U._black_border_disable)", "#define _black_border_disable (0)")],
     # every hit is final with a flat colour: ray generation + ONE scene_intersect per sample, no shading, no second trip
     "no_material": [("m = material_process(r, i);", "m = MaterialProcessing{true, vec3(0.5f), ray_none};"),
                     ("m = material_process(r, i2.scene);", "m = MaterialProcessing{true, vec3(0.5f), ray_none};")],
