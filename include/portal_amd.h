@@ -188,7 +188,11 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * bit2 = bake every scene uniform (ints, floats, matrices; camera and other builtins stay dynamic),
  * bit3 = clip-constant specialisation: bake every scene uniform whose evaluation reads no per-frame input (time,
  * total_time, the camera matrix) -- what stays fixed while a clip plays; a renderer checks the compiled-in values before
- * every draw and rebuilds (demoting what moved) if one no longer holds, so results never depend on the guess,
+ * every draw and rebuilds (demoting what moved) if one no longer holds, so results never depend on the guess.
+ * A RENDERER built with bit0, bit2 or bit3 also compiles its own mode switches in -- "use_panini_projection", "use_360_camera",
+ * "use_180_camera", "draw_depth_map", "draw_anaglyph", "draw_side_by_side": the camera models and output modes a frame does not use
+ * are then not in the kernel at all (7-10 % of the kernel time) -- and rebuilds when ptl_renderer_set_option flips one (counted by
+ * ptl_renderer_rejit_count; the code-object cache keeps both).  ptl_scene_generate_source leaves them run-time values,
  * bit4 = compile the anaglyph stereo mode in (the reference's `disable_anaglyph = false`, src/main.rs:939),
  * bit5 = NO derived uniforms: by default the ray-independent half of every generated plane test whose matrix is a run-time
  * uniform (normalize(get_normal(X_mat)), both possible is_collinear verdicts) is evaluated once per uniform upload by the
@@ -285,7 +289,8 @@ int ptl_renderer_update(ptl_renderer* r, double seconds, int* teleported, int* b
 /* Current teleport matrix (binary64, column-major), subspace flag and world position of the camera. */
 int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16], int* in_subspace, double position[3]);
 ptl_kernel* ptl_renderer_kernel(ptl_renderer* r);
-/* how many times a draw had to rebuild the clip-specialised kernel (flags bit3) since the renderer was created */
+/* how many times a draw had to rebuild a specialised kernel since the renderer was created: a clip-constant value that moved (flags bit3),
+ * a mode switch that was flipped (flags bit0 / bit2 / bit3) */
 int ptl_renderer_rejit_count(ptl_renderer* r);
 /* flags bit17 (ASYNC REJIT) on a specialised renderer (bits 0/2 or 3): a draw that finds its compiled-in values stale does not wait for
  * the rebuild (1-3 s of hiprtc) -- it draws with the un-specialised kernel of the scene (every build draws the same bits) while a worker
