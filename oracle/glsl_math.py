@@ -38,7 +38,9 @@ STATS = {"flops": 0.0, "div": 0.0, "sqrt": 0.0, "fma": 0.0,
          "flops_varying": 0.0, "div_varying": 0.0, "sqrt_varying": 0.0, "fma_varying": 0.0,
          # of `flops_varying`: terms of matrix products whose matrix element is a uniform zero -- a build with the matrices baked in
          # skips them (ptl_glsl.h `ptl_mterm`), so they are not executed work there (tools/count_flops.py subtracts them)
-         "zero_term_flops_varying": 0.0}
+         "zero_term_flops_varying": 0.0,
+         # of `flops`: comparisons, min / max, step -- VALU instructions without arithmetic (reported beside the totals, tools/count_flops.py)
+         "cmp": 0.0, "cmp_varying": 0.0}
 _active = 1.0
 
 
@@ -181,7 +183,8 @@ def sqrt(a):
 
 
 def absf(a):
-    _count(1, None, (a,))
+    # not counted as an operation: |x| is a sign-bit edit -- a free source modifier of the instruction that consumes it on gfx950 -- and
+    # counting it pushed `roofline.frac` above the hardware's own instruction ceiling (bench.py `frac_ceiling_valu_plus_fma`)
     return np.abs(f32(a))
 
 
@@ -251,32 +254,32 @@ def note_matrix_term(m, v, first: bool) -> None:
 
 
 def lt(a, b):
-    _count(1, None, (a, b,))
+    _count(1, "cmp", (a, b,))
     return np.less(a, b)
 
 
 def gt(a, b):
-    _count(1, None, (a, b,))
+    _count(1, "cmp", (a, b,))
     return np.greater(a, b)
 
 
 def le(a, b):
-    _count(1, None, (a, b,))
+    _count(1, "cmp", (a, b,))
     return np.less_equal(a, b)
 
 
 def ge(a, b):
-    _count(1, None, (a, b,))
+    _count(1, "cmp", (a, b,))
     return np.greater_equal(a, b)
 
 
 def eq(a, b):
-    _count(1, None, (a, b,))
+    _count(1, "cmp", (a, b,))
     return np.equal(a, b)
 
 
 def ne(a, b):
-    _count(1, None, (a, b,))
+    _count(1, "cmp", (a, b,))
     return np.not_equal(a, b)
 
 
@@ -286,12 +289,12 @@ def select(c, a, b):
 
 # --- GLSL scalar builtins (contract: ptl_glsl.h "scalar primitives") -----------------------
 def fmin(a, b):  # min(a,b) = b < a ? b : a
-    _count(1, None, (a, b,))
+    _count(1, "cmp", (a, b,))
     return np.where(np.less(b, a), f32(b), f32(a)).astype(F32)
 
 
 def fmax(a, b):  # max(a,b) = a < b ? b : a
-    _count(1, None, (a, b,))
+    _count(1, "cmp", (a, b,))
     return np.where(np.less(a, b), f32(b), f32(a)).astype(F32)
 
 
@@ -314,7 +317,7 @@ def sign(x):
 
 
 def step(edge, x):
-    _count(1, None, (edge, x,))
+    _count(1, "cmp", (edge, x,))
     return np.where(np.less(x, edge), F32(0), F32(1)).astype(F32)
 
 

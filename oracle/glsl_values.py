@@ -317,7 +317,7 @@ def compare(op, a, b):
         a, b = np.asarray(a), np.asarray(b)
     else:
         a, b = to_float(a), to_float(b)
-        M._count(1)
+        M._count(1, "cmp", (a, b,))
     return {"<": np.less, ">": np.greater, "<=": np.less_equal, ">=": np.greater_equal, "==": np.equal, "!=": np.not_equal}[op](a, b)
 
 
