@@ -43,8 +43,13 @@ class FrameGatherer:
     `depth` > 1 double-buffers the gather target so that `gather_async` of frame n can overlap the
     tracing of frame n+1 (the collective runs on the process group's own stream)."""
 
-    def __init__(self, height: int, width: int, rank: int, world: int, device, dst: int = 0, depth: int = 1, stage_through_host: bool = False):
+    def __init__(self, height: int, width: int, rank: int, world: int, device, dst: int = 0, depth: int = 1, stage_through_host: bool = False,
+                 collective_at_one_rank: bool = False):
         self.h, self.w, self.rank, self.world, self.dst = height, width, rank, world, dst
+        # world == 1 needs no collective and normally gets none.  `collective_at_one_rank` runs it anyway (a gather of one shard to
+        # oneself): the way a box with ONE GPU takes the real `dist.gather` over RCCL, buffers, the process group's stream and the
+        # de-interleave through the very code the N-rank bench runs (tests/test_gpu_round2.py)
+        self.shortcut = world == 1 and not collective_at_one_rank
         # a backend without device-to-device gather (gloo, used to rehearse the multi-rank control flow on one GPU): the shard
         # goes through host memory, synchronously
         self.stage_through_host = stage_through_host
@@ -54,7 +59,7 @@ class FrameGatherer:
             full = gathered = None
             if rank == dst:
                 full = torch.empty((self.kmax * world * 8, width, 4), dtype=torch.uint8, device=device)
-                if world > 1:
+                if not self.shortcut:
                     gathered = torch.empty((world, self.kmax * 8, width, 4), dtype=torch.uint8, device=device)
             self.slots.append((full, gathered))
 
@@ -66,7 +71,7 @@ class FrameGatherer:
 
     def gather(self, shard: torch.Tensor, slot: int = 0) -> Optional[torch.Tensor]:
         """shard: this rank's packed rows, shape (kmax*8, W, 4).  Returns the (H, W, 4) frame on dst."""
-        if self.world == 1:
+        if self.shortcut:
             return shard[: self.h]
         gathered = self.slots[slot][1]
         if self.stage_through_host:
@@ -84,7 +89,7 @@ class FrameGatherer:
 
     def gather_async(self, shard: torch.Tensor, slot: int = 0):
         """Start the gather; returns a handle for `finish`."""
-        if self.world == 1:
+        if self.shortcut:
             return None
         gathered = self.slots[slot][1]
         if self.stage_through_host:
@@ -93,7 +98,7 @@ class FrameGatherer:
         return dist.gather(shard, list(gathered.unbind(0)) if self.rank == self.dst else None, dst=self.dst, async_op=True)
 
     def finish(self, work, shard: torch.Tensor, slot: int = 0) -> Optional[torch.Tensor]:
-        if self.world == 1:
+        if self.shortcut:
             return shard[: self.h]
         work.wait()
         return self._assemble(slot) if self.rank == self.dst else None
@@ -190,20 +195,22 @@ class GatherTransport:
 
     name = "rccl-gather"
 
-    def __init__(self, height, width, rank, world, device, depth=2, stage_through_host=False):
+    def __init__(self, height, width, rank, world, device, depth=2, stage_through_host=False, collective_at_one_rank=False):
         import portal_amd as pa
 
-        self.depth = depth if world > 1 else 1
+        self.collective = world > 1 or collective_at_one_rank
+        self.depth = depth if self.collective else 1
         self.rank, self.world, self.h = rank, world, height
         self.frame = pa.Frame(width, height, rank, world)
         self.shards = [alloc_shard(height, width, world, device) for _ in range(self.depth)]
-        self.gatherer = FrameGatherer(height, width, rank, world, device, depth=self.depth, stage_through_host=stage_through_host)
+        self.gatherer = FrameGatherer(height, width, rank, world, device, depth=self.depth, stage_through_host=stage_through_host,
+                                      collective_at_one_rank=collective_at_one_rank)
 
     def out_ptr(self, slot):
         return self.shards[slot].data_ptr()
 
     def submit(self, slot):
-        return self.gatherer.gather_async(self.shards[slot], slot) if self.world > 1 else None
+        return self.gatherer.gather_async(self.shards[slot], slot) if self.collective else None
 
     def finish(self, work, slot):
         """The assembled frame (a device tensor) on the destination rank, None elsewhere."""

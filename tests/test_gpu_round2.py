@@ -6,6 +6,7 @@ must agree with EACH OTHER bit for bit (prologue on/off, 1 rank vs N ranks), the
 import glob
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -179,6 +180,60 @@ def test_frame_group_rccl_gather_on_the_devices_of_this_box(gpu):
     del g
     with pytest.raises(pa.PortalError, match="listed twice"):
         pa.FrameGroup(pa.Scene.from_file(pa.scene_path("monoportal")), [0, 0], transport=pa.GROUP_RCCL_GATHER)
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["PTL_ROOT"])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["PTL_PORT"], RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+from datetime import timedelta
+dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1, timeout=timedelta(seconds=120))   # as bench.py does at N > 1
+import portal_amd as pa
+from portal_amd import parallel
+W, H = 1920, 1080
+scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+r = pa.SceneRenderer(scene, device=0, flags=pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
+r.set_option("render_depth", 20)
+want = r.draw(W, H)["rgba8"]
+tr = parallel.GatherTransport(H, W, 0, 1, dev, depth=2, collective_at_one_rank=True)
+assert tr.depth == 2 and tr.gatherer.slots[0][1] is not None
+stream = torch.cuda.current_stream(dev)
+works = []
+for slot in (0, 1):                                   # two frames in flight, like the timed loop
+    r.draw_device(tr.frame, out_rgba8=tr.out_ptr(slot), stream=stream.cuda_stream)
+    works.append(tr.submit(slot))                     # dist.gather(..., async_op=True) over RCCL
+frames = [tr.finish(w, slot) for slot, w in enumerate(works)]
+for f in frames:
+    assert np.array_equal(tr.download(f), want)
+again = tr.gatherer.gather(tr.shards[0], 1)           # the synchronous form
+assert np.array_equal(again.cpu().numpy(), want)
+token = torch.zeros(1, dtype=torch.int32, device=dev)  # the fence of the peer transports
+dist.all_reduce(token, op=dist.ReduceOp.MAX, async_op=True).wait()
+t = torch.tensor([1.5], device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl-one-rank-ok", torch.cuda.nccl.version())
+"""
+
+
+def test_gather_transport_over_real_rccl_with_one_rank(gpu):
+    """bench.py's timed transport at N > 1 is `GatherTransport` over the "nccl" backend (= RCCL).  A box with one GPU cannot host two
+    RCCL ranks, but it can host ONE: `collective_at_one_rank` runs the real `dist.gather` (sync and async, double-buffered), the
+    de-interleave, the fence all-reduce and the barrier through RCCL on the process group bench.py would create -- every call the
+    N-rank run makes, with world_size 1 -- and the gathered frames must be the directly drawn frame byte for byte."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PTL_ROOT=ROOT, PTL_PORT=str(port))
+    done = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert done.returncode == 0 and "rccl-one-rank-ok" in done.stdout, done.stdout[-2000:] + done.stderr[-4000:]
 
 
 def _cli(*args, timeout=600):
