@@ -139,6 +139,7 @@ VARIANTS = {
     "r3_dyn_O2": "-O2 -fno-slp-vectorize", "r3_dyn_O3": "-O3 -fno-slp-vectorize", "r3_ints_O2": "SPECIALIZE -O2 -fno-slp-vectorize", "r3_ints_O3": "SPECIALIZE -O3 -fno-slp-vectorize",
     "r3_all_O2": "SPECIALIZE_ALL -O2 -fno-slp-vectorize", "r3_all_O3": "SPECIALIZE_ALL -O3 -fno-slp-vectorize", "r3_all_w4_O3slp": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -O3",
     "r3_ints_reload": "SPECIALIZE -DPTL_UNIFORM_RELOAD", "r3_dyn_reload": "-DPTL_UNIFORM_RELOAD", "r3_dyn_O1": "-O1", "r3_dyn_O1_reload": "-O1 -DPTL_UNIFORM_RELOAD",
+    "r3_all_modinl": "SPECIALIZE_ALL -mllvm -enable-module-inliner", "r3_ints_modinl": "SPECIALIZE -mllvm -enable-module-inliner", "r3_dyn_modinl": "-mllvm -enable-module-inliner",
     "r3_all_peel": "SPECIALIZE_ALL -DPTL_PEEL_FIRST_TRIP", "r3_ints_peel": "SPECIALIZE -DPTL_PEEL_FIRST_TRIP", "r3_dyn_peel": "-DPTL_PEEL_FIRST_TRIP",
     "r3_all_w4_zerofold": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -fno-signed-zeros -fno-honor-nans",
 }
