@@ -1240,12 +1240,14 @@ extern "C" int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16],
 extern "C" ptl_kernel* ptl_renderer_kernel(ptl_renderer* r) {
     if (!r) return nullptr;
     // the kernel the next draw would use: a specialised build follows the mode switches (also on a handle without a device, which never draws)
-    if ((r->flags & 13u) != 0 && !((r->flags & kAsyncRejit) != 0 && r->device >= 0) && mode_switches(*r) != r->kernel_switches)
-        guarded([&] {
-            int rc = build_kernel(r, nullptr, 0);
-            if (rc == PTL_OK) ++r->rejit_count;
-            return rc;
+    if ((r->flags & 13u) != 0 && !((r->flags & kAsyncRejit) != 0 && r->device >= 0) && mode_switches(*r) != r->kernel_switches) {
+        int rc = guarded([&] {
+            int rc2 = build_kernel(r, nullptr, 0);
+            if (rc2 == PTL_OK) ++r->rejit_count;
+            return rc2;
         });
+        if (rc != PTL_OK) return nullptr;  // ptl_last_error() says why; the old kernel has other switches compiled in
+    }
     return r->kernel;
 }
 extern "C" int ptl_renderer_rejit_count(ptl_renderer* r) { return r ? r->rejit_count : -1; }
