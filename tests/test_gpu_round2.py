@@ -182,6 +182,43 @@ def test_frame_group_rccl_gather_on_the_devices_of_this_box(gpu):
         pa.FrameGroup(pa.Scene.from_file(pa.scene_path("monoportal")), [0, 0], transport=pa.GROUP_RCCL_GATHER)
 
 
+def test_flipped_mode_switch_with_background_rejit_draws_the_same_bits_meanwhile(gpu, tmp_path, monkeypatch):
+    """A specialised renderer has its mode switches compiled in (KernelOptions::baked_options).  With FLAG_ASYNC_REJIT a flipped switch
+    must not stall the draw either: the un-specialised kernel (which reads the switches at run time) draws the new mode at once, the
+    worker compiles the specialised kernel of the new mode, and the adopted kernel draws the same bits."""
+    import time
+
+    pa = gpu
+    monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path / "cache"))
+    (tmp_path / "cache").mkdir()
+    spec = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
+    r = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("monoportal")), device=0, flags=spec | pa.FLAG_ASYNC_REJIT)
+    ref = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("monoportal")), device=0, flags=0)
+    for x in (r, ref):
+        x.set_option("render_depth", 20)
+    w, h = 320, 160
+    pinhole = r.draw(w, h, rgba32f=True)["rgba32f"].copy()
+    assert np.array_equal(_bits(pinhole), _bits(ref.draw(w, h, rgba32f=True)["rgba32f"]))
+    for x in (r, ref):
+        x.set_option("use_360_camera", 1)
+    want = ref.draw(w, h, rgba32f=True)["rgba32f"].copy()
+    got = r.draw(w, h, rgba32f=True)["rgba32f"]           # at once, on the un-specialised kernel
+    assert r.rejit_pending() and np.array_equal(_bits(got), _bits(want)) and not np.array_equal(_bits(want), _bits(pinhole))
+    deadline = time.time() + 120
+    while r.rejit_pending() and time.time() < deadline:
+        time.sleep(0.05)
+        got = r.draw(w, h, rgba32f=True)["rgba32f"]
+    assert not r.rejit_pending() and np.array_equal(_bits(got), _bits(want))   # the specialised 360-degree kernel
+    for x in (r, ref):
+        x.set_option("use_360_camera", 0)                  # back: the first specialised source again
+    deadline = time.time() + 120
+    got = r.draw(w, h, rgba32f=True)["rgba32f"]
+    while r.rejit_pending() and time.time() < deadline:
+        time.sleep(0.05)
+        got = r.draw(w, h, rgba32f=True)["rgba32f"]
+    assert np.array_equal(_bits(got), _bits(pinhole))
+
+
 _RCCL_ONE_RANK = r"""
 import os, sys
 import numpy as np, torch, torch.distributed as dist
