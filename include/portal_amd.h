@@ -223,6 +223,10 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * bit18 = QUICK JIT: compile at -O1 instead of the shipped -O3 without SLP: half the hiprtc time for a 5-20 % slower kernel, identical
  * frames -- for a build that is wanted now and used briefly (the CLI's render-frame; the kernel a clip starts on).  Implies bit15;
  * ignored together with bit3 (a clip-constant build is asked for because many frames follow).
+ * bit19 = NO ZERO MASKS: by default a build with bit0, bit2 or bit3 compiles in the ZERO PATTERN of every matrix uniform that stays a
+ * run-time value (only Bool / Int baked; animated within the clip -- its pattern then taken over probes of the clip's `time`; demoted):
+ * `transform(X_mat, ..)` of the scene snippets and the generated plane tests skip the terms whose element is zero, as a baked matrix's do
+ * (same results for finite operands); a renderer rebuilds when a masked element stops being zero.  This bit keeps the full products (A/B),
  * bit15 = NO unrolling of baked loops: by default (with bit0) a counting loop of a scene snippet whose bound is a baked Int uniform
  * (<= 16 iterations) is unrolled -- the same operations in the same order, identical frames; every iteration then has its own
  * constants (scenes/portal_in_portal.ron's `size` drives an inner loop and a material index).

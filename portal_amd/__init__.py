@@ -57,6 +57,7 @@ FLAG_NO_FIRST_TRIP = 8192  # no first-trip copies of the intersection-material s
 FLAG_NO_UNIFORM_HOIST = 4096  # scene snippets evaluate their uniform-only expressions per ray (default: once per upload, in the prologue kernel)
 FLAG_NO_DEFERRED_UPDATES = 128  # translate scene snippets exactly as written (default: loop-carried ray transforms are applied lazily)
 FLAG_QUICK_JIT = 262144  # compile at -O1 instead of the shipped -O3: half the JIT time, a 5-20 % slower kernel (one-off frames)
+FLAG_NO_ZERO_MASKS = 524288  # A/B: run-time matrices keep their full products although their zero pattern is known (KernelOptions::mask_zero_elements)
 FLAG_ASYNC_REJIT = 131072  # a specialised renderer never stalls on a rebuild: it draws with the un-specialised kernel until a worker thread has the new one
 FLAG_NO_FIRST_TRIP_PLANES = 65536  # no first-trip copy of the generated plane tests (default: on the first trip `plane_inv * camera origin` comes from the prologue kernel)
 FLAG_NO_UNROLL = 32768  # keep snippet loops whose bound is a baked Int uniform as loops (default: unrolled up to 16 iterations; identical frames)

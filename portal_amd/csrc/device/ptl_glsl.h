@@ -746,6 +746,32 @@ PTL_FN vec4 operator*(const mat4& m, const vec4& v) {
                 ptl_mterm(m.c[3].w, v.w, ptl_mterm(m.c[2].w, v.z, ptl_mterm(m.c[1].w, v.y, ptl_mterm0(m.c[0].w, v.x)))));
 }
 #endif
+// The product for a matrix whose VALUES are run-time uniforms but whose ZERO PATTERN was known when the kernel was generated
+// (KernelOptions::mask_zero_elements: bit 4 * column + row of MASK set = that element may be non-zero; the host rebuilds the kernel
+// if a masked element ever stops being zero).  It skips exactly the terms ptl_mterm skips for a baked matrix -- same chain from +0,
+// same deviation for non-finite vector components -- but decides at COMPILE time: no comparison is executed, and the skipped elements
+// are never loaded.  Contract 1 and the tolerance mode never get a mask other than 0xffff (codegen.cpp).
+template <int R> PTL_FN float ptl_comp(const vec4& v) {
+    if constexpr (R == 0) return v.x;
+    else if constexpr (R == 1) return v.y;
+    else if constexpr (R == 2) return v.z;
+    else return v.w;
+}
+template <unsigned MASK, int R> PTL_FN float ptl_row_m(const mat4& m, const vec4& v) {
+    if constexpr (MASK == 0xffffu) {  // nothing known: the ordinary chain of this build
+        return ptl_mterm(ptl_comp<R>(m.c[3]), v.w, ptl_mterm(ptl_comp<R>(m.c[2]), v.z, ptl_mterm(ptl_comp<R>(m.c[1]), v.y, ptl_mterm0(ptl_comp<R>(m.c[0]), v.x))));
+    } else {
+        float acc = 0.0f;
+        if constexpr ((MASK >> (0 + R)) & 1u) acc = __builtin_fmaf(ptl_comp<R>(m.c[0]), v.x, acc);
+        if constexpr ((MASK >> (4 + R)) & 1u) acc = __builtin_fmaf(ptl_comp<R>(m.c[1]), v.y, acc);
+        if constexpr ((MASK >> (8 + R)) & 1u) acc = __builtin_fmaf(ptl_comp<R>(m.c[2]), v.z, acc);
+        if constexpr ((MASK >> (12 + R)) & 1u) acc = __builtin_fmaf(ptl_comp<R>(m.c[3]), v.w, acc);
+        return acc;
+    }
+}
+template <unsigned MASK> PTL_FN vec4 ptl_mul_m(const mat4& m, const vec4& v) {
+    return vec4(ptl_row_m<MASK, 0>(m, v), ptl_row_m<MASK, 1>(m, v), ptl_row_m<MASK, 2>(m, v), ptl_row_m<MASK, 3>(m, v));
+}
 // the same product for a matrix that is a run-time value in every build (the camera): no zero tests (they would be executed)
 PTL_FN vec4 ptl_mul_runtime(const mat4& m, const vec4& v) {
     return vec4(ptl_term(m.c[3].x, v.w, ptl_term(m.c[2].x, v.z, ptl_term(m.c[1].x, v.y, ptl_term0(m.c[0].x, v.x)))),

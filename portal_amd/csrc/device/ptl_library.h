@@ -87,6 +87,12 @@ PTL_FN Ray transform(const mat4& matrix, const Ray& r) {
     return Ray{matrix * r.o, matrix * r.d, r.tmul, r.in_subspace};
 }
 #endif
+// transform() for a matrix with a known zero pattern (ptl_mul_m, device/ptl_glsl.h): what the generator writes for `transform(X_mat, ..)`
+// when X_mat is a run-time uniform whose pattern it knows (PTL_MASK_X_mat)
+template <unsigned MASK> PTL_FN Ray ptl_transform_m(const mat4& matrix, const Ray& r) {
+    if constexpr (MASK == 0xffffu) return transform(matrix, r);
+    else return Ray{ptl_mul_m<MASK>(matrix, r.o), ptl_mul_m<MASK>(matrix, r.d), r.tmul, r.in_subspace};
+}
 PTL_FN vec3 get_normal(const mat4& matrix) { return (matrix * vec4(0.0f, 0.0f, 1.0f, 0.0f)).sw<0, 1, 2>(); }
 PTL_FN Ray normalize_ray(Ray r) {
     float len = length(r.d);
@@ -155,13 +161,13 @@ PTL_FN SurfaceIntersection plane_intersect(Ray r, const mat4& plane_inv, vec3 no
 // A cull decides nothing about the picture -- the culled test could never have been selected -- so frames stay bit-identical;
 // what it saves is the work.  It is taken per WAVE (ballot): the 64 rays of an 8x8 tile nearly always agree about which walls are
 // behind them or beyond the surface they have already found, and a uniform branch costs a scalar compare.
-PTL_FN bool ptl_plane_cull(const Ray& r, const mat4& plane_inv, float best_t) {
+template <unsigned MASK = 0xffffu> PTL_FN bool ptl_plane_cull(const Ray& r, const mat4& plane_inv, float best_t) {
 #if defined(PTL_NO_PLANE_CULL)
     (void)r; (void)plane_inv; (void)best_t;
     return false;
 #else
-    const float oz = (plane_inv * r.o).z;
-    const float dz = (plane_inv * r.d).z;
+    const float oz = ptl_row_m<MASK, 2>(plane_inv, r.o);
+    const float dz = ptl_row_m<MASK, 2>(plane_inv, r.d);
     const bool behind = (oz > 0.0f && dz > 0.0f) || (oz < 0.0f && dz < 0.0f);
 #if PTL_DEVICE_BUILD
     const float t_low = (-oz * __builtin_amdgcn_rcpf(dz)) * (1.0f - 0x1p-16f);
@@ -174,13 +180,13 @@ PTL_FN bool ptl_plane_cull(const Ray& r, const mat4& plane_inv, float best_t) {
 }
 // The cull for a ray whose origin in the plane's frame is already known (first-trip plane tests: `o_in_plane` = plane_inv * r.o from
 // the prologue kernel): the same two decisions from the same two numbers, half the products.
-PTL_FN bool ptl_plane_cull_o(const Ray& r, const mat4& plane_inv, const vec4& o_in_plane, float best_t) {
+template <unsigned MASK = 0xffffu> PTL_FN bool ptl_plane_cull_o(const Ray& r, const mat4& plane_inv, const vec4& o_in_plane, float best_t) {
 #if defined(PTL_NO_PLANE_CULL)
     (void)r; (void)plane_inv; (void)o_in_plane; (void)best_t;
     return false;
 #else
     const float oz = o_in_plane.z;
-    const float dz = (plane_inv * r.d).z;
+    const float dz = ptl_row_m<MASK, 2>(plane_inv, r.d);
     const bool behind = (oz > 0.0f && dz > 0.0f) || (oz < 0.0f && dz < 0.0f);
 #if PTL_DEVICE_BUILD
     const float t_low = (-oz * __builtin_amdgcn_rcpf(dz)) * (1.0f - 0x1p-16f);
@@ -195,13 +201,13 @@ PTL_FN bool ptl_plane_cull_o(const Ray& r, const mat4& plane_inv, const vec4& o_
 
 // plane_intersect with the ray-independent half done beforehand: `unit_normal` = normalize(normal) comes from the
 // prologue kernel (ptl_tracer::derive); `flipped` tells the caller which of the two precomputed is_collinear verdicts applies.
-PTL_FN SurfaceIntersection plane_intersect_derived(Ray r, const mat4& plane_inv, vec3 unit_normal, bool& flipped) {
+template <unsigned MASK = 0xffffu> PTL_FN SurfaceIntersection plane_intersect_derived(Ray r, const mat4& plane_inv, vec3 unit_normal, bool& flipped) {
     flipped = dot(unit_normal, r.d.sw<0, 1, 2>()) > 0.0f;
     if (flipped) unit_normal *= -1.0f;
 #if PTL_DEVICE_BUILD && defined(PTL_FAST_MATH)
     return ptl_plane_hit_fast(r, plane_inv, unit_normal);
 #endif
-    r = transform(plane_inv, r);
+    r = ptl_transform_m<MASK>(plane_inv, r);
     float len = length(r.d);
     r.d = normalize(r.d);
     SurfaceIntersection result = plane_intersect_normalized(r);
@@ -230,14 +236,14 @@ PTL_FN SurfaceIntersection plane_intersect_o(Ray r, const mat4& plane_inv, vec3 
     }
     return result;
 }
-PTL_FN SurfaceIntersection plane_intersect_derived_o(Ray r, const mat4& plane_inv, vec3 unit_normal, bool& flipped, const vec4& o_in_plane) {
+template <unsigned MASK = 0xffffu> PTL_FN SurfaceIntersection plane_intersect_derived_o(Ray r, const mat4& plane_inv, vec3 unit_normal, bool& flipped, const vec4& o_in_plane) {
 #if PTL_DEVICE_BUILD && defined(PTL_FAST_MATH)
     (void)o_in_plane;
     return plane_intersect_derived(r, plane_inv, unit_normal, flipped);
 #endif
     flipped = dot(unit_normal, r.d.sw<0, 1, 2>()) > 0.0f;
     if (flipped) unit_normal *= -1.0f;
-    r = Ray{o_in_plane, plane_inv * r.d, r.tmul, r.in_subspace};
+    r = Ray{o_in_plane, ptl_mul_m<MASK>(plane_inv, r.d), r.tmul, r.in_subspace};
     float len = length(r.d);
     r.d = normalize(r.d);
     SurfaceIntersection result = plane_intersect_normalized(r);

@@ -118,6 +118,8 @@ struct ptl_renderer {
     unsigned long long kernel_scene_version = 0;
     std::string kernel_source;
     std::map<std::string, int> kernel_switches;  // the mode switches the current specialised kernel has compiled in (KernelOptions::baked_options)
+    std::vector<std::pair<std::string, unsigned>> masked;  // run-time matrices whose zero pattern the current kernel has compiled in (GeneratedKernel::masked)
+    std::set<std::string> keep_unmasked;                   // ... and those whose pattern did not hold (clip-constant builds: demoted like keep_dynamic)
     // SceneRenderer::update state (src/main.rs:1430-1538)
     Camera prev_cam;
     bool has_prev_cam = false;
@@ -427,6 +429,9 @@ static KernelOptions options_from_flags(unsigned flags) {
     // PTL_FLAG_QUICK_JIT: -O1 instead of -O3 (a build that is wanted now and used briefly).  Not for a clip-constant build (bit 3 /
     // "specialize_static"): that one is asked for because many frames will run on it, so it keeps the full optimisation level
     o.quick_jit = (flags & 262144u) != 0 && !o.specialize_static;
+    // zero patterns of the matrices that stay run-time values: with any specialisation (the un-specialised kernel has to be valid for every
+    // state of the scene -- the background re-JIT draws with it meanwhile); PTL_FLAG_NO_ZERO_MASKS (bit 19) for A/B measurements and tests
+    o.mask_zero_elements = (flags & 13u) != 0 && (flags & 524288u) == 0;
     o.first_trip_planes = (flags & 65536u) == 0;   // PTL_FLAG_NO_FIRST_TRIP_PLANES: one scene_intersect for every trip (A/B measurements, tests)
     // PTL_FLAG_NO_UNROLL: keep snippet loops with baked bounds as loops (A/B measurements).  The quick build keeps them too: unrolling
     // is half of its hiprtc time for the headline scene (3.4 -> 1.8 s on this container's cores) and buys 0.05 ms of kernel
@@ -443,9 +448,11 @@ static std::map<std::string, int> mode_switches(const ptl_renderer& r) {
             {"_draw_anaglyph", r.draw_anaglyph ? 1 : 0},                     {"_draw_side_by_side", r.draw_side_by_side ? 1 : 0}};
 }
 
-static void refresh_generated(ptl_scene* s, unsigned flags, const std::set<std::string>* keep_dynamic = nullptr, const std::map<std::string, int>* switches = nullptr) {
+static void refresh_generated(ptl_scene* s, unsigned flags, const std::set<std::string>* keep_dynamic = nullptr, const std::map<std::string, int>* switches = nullptr,
+                              const std::set<std::string>* keep_unmasked = nullptr) {
     KernelOptions opts = options_from_flags(flags);
     if (keep_dynamic) opts.keep_dynamic = *keep_dynamic;
+    if (keep_unmasked) opts.keep_unmasked = *keep_unmasked;
     if (switches && (flags & 13u) != 0) opts.baked_options = *switches;
     CodegenFlags cg;
     cg.defer_loop_updates = (flags & 128u) == 0;  // PTL_FLAG_NO_DEFERRED_UPDATES: the snippets exactly as written (A/B measurements, tests)
@@ -634,9 +641,11 @@ static int compile_build(const ptl_renderer::Build& b, int device, const std::ve
 static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     ptl_scene* s = r->owner;
     if (!(r->kernel_stage == r->scene->current_stage)) r->keep_dynamic.clear();  // another stage / clip: judge afresh what is constant
+    if (!(r->kernel_stage == r->scene->current_stage)) r->keep_unmasked.clear();
     r->kernel_switches = mode_switches(*r);
-    refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches);
+    refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches, &r->keep_unmasked);
     r->baked = s->last.baked;
+    r->masked = s->last.masked;
     r->kernel_stage = r->scene->current_stage;
     if (r->kernel && s->last.source == r->kernel_source) {  // nothing baked in changed
         r->kernel_scene_version = r->scene->version;
@@ -823,6 +832,24 @@ extern "C" int ptl_renderer_uniform_value(ptl_renderer* r, int width, int height
     });
 }
 
+// Zero patterns compiled into the current kernel (r->masked) against the values a draw is about to upload: a matrix with a non-zero where
+// the pattern says zero is demoted (keep_unmasked) and reported.
+static bool zero_patterns_broken(ptl_renderer* r, const std::vector<UniformUpload>& values) {
+    bool broken = false;
+    for (auto& [name, mask] : r->masked)
+        for (const UniformUpload& v : values) {
+            if (v.name != name || v.type != UniformType::Mat4) continue;
+            for (int k = 0; k < 16; ++k)
+                if (v.f[k] != 0.0f && !((mask >> k) & 1u)) {
+                    r->keep_unmasked.insert(name);
+                    broken = true;
+                    break;
+                }
+            break;
+        }
+    return broken;
+}
+
 static int activate_kernel(ptl_renderer* r, ptl_kernel* k) {
     if (r->kernel == k) return PTL_OK;
     r->kernel = k;
@@ -839,7 +866,10 @@ static int async_select_kernel(ptl_renderer* r) {
     const bool changed = r->kernel_scene_version != r->scene->version || !(r->kernel_stage == r->scene->current_stage) || mode_switches(*r) != r->kernel_switches;
     if (!changed && !r->job && r->kernel == r->spec_kernel) return PTL_OK;
     if (changed) {
-        if (!(r->kernel_stage == r->scene->current_stage)) r->keep_dynamic.clear();
+        if (!(r->kernel_stage == r->scene->current_stage)) {
+            r->keep_dynamic.clear();
+            r->keep_unmasked.clear();
+        }
         if ((r->flags & 8u) != 0 && (r->flags & 5u) == 0) {  // clip-constant specialisation: a compiled-in value that moved becomes a run-time uniform
             std::vector<UniformUpload> values = evaluate_scene_uniforms(*r->scene, nullptr);
             size_t at = 0;
@@ -848,9 +878,11 @@ static int async_select_kernel(ptl_renderer* r) {
                 if (at == values.size()) break;
                 if (!values[at].same_value(b)) r->keep_dynamic.insert(b.name);
             }
+            zero_patterns_broken(r, values);
         }
         r->kernel_switches = mode_switches(*r);
-        refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches);  // the specialised source of the CURRENT state (generation is milliseconds)
+        refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches, &r->keep_unmasked);  // the specialised source of the CURRENT state (generation is milliseconds)
+        r->masked = s->last.masked;
         r->want = snapshot_build(s, r->flags);
         r->kernel_scene_version = r->scene->version;
         r->kernel_stage = r->scene->current_stage;
@@ -950,6 +982,7 @@ static int prepare_draw(ptl_renderer* r, const ptl_frame* frame) {
                     stale = true;
                 }
             }
+            if (zero_patterns_broken(r, values)) stale = true;  // an animated matrix left the zero pattern its products were shortened for
             if (stale) {
                 int rc = build_kernel(r, nullptr, 0);
                 if (rc != PTL_OK) return rc;

@@ -446,6 +446,51 @@ struct PortalMaterialNames {
 
 }  // namespace
 
+// KernelOptions::mask_zero_elements: the calls that multiply by a masked matrix, in their masked forms (same line, so the line map holds).
+//   transform(NAME, ...)                                  -> ptl_transform_m<PTL_MASK_NAME>(NAME, ...)        (scene snippets, Complex objects)
+//   ptl_plane_cull[_o] / plane_intersect_derived[_o](r, NAME, ...) -> ...<PTL_MASK_NAME>(r, NAME, ...)     (generated plane tests)
+// Every other use of the matrix (a product written out in a snippet, a copy into a local) keeps the full chain: correct, just not shortened.
+static void apply_zero_masks(std::string& src, const std::vector<std::pair<std::string, unsigned>>& masked) {
+    auto ident = [](char c) { return std::isalnum((unsigned char)c) || c == '_'; };
+    for (auto& [name, mask] : masked) {
+        (void)mask;
+        // transform( NAME ,
+        for (size_t at = 0; (at = src.find("transform", at)) != std::string::npos;) {
+            size_t p = at + 9;
+            if ((at > 0 && ident(src[at - 1])) || p >= src.size() || src[p] != '(') {
+                at = p;
+                continue;
+            }
+            size_t q = p + 1;
+            while (q < src.size() && src[q] == ' ') ++q;
+            if (src.compare(q, name.size(), name) != 0) {
+                at = p;
+                continue;
+            }
+            size_t e = q + name.size();
+            while (e < src.size() && src[e] == ' ') ++e;
+            if (e >= src.size() || src[e] != ',' || ident(src[q + name.size()])) {
+                at = p;
+                continue;
+            }
+            std::string repl = "ptl_transform_m<PTL_MASK_" + name + ">";
+            src.replace(at, 9, repl);
+            at += repl.size();
+        }
+        for (const char* fn : {"ptl_plane_cull_o", "ptl_plane_cull", "plane_intersect_derived_o", "plane_intersect_derived"}) {
+            std::string from = std::string(fn) + "(r, " + name + ",", to = std::string(fn) + "<PTL_MASK_" + name + ">(r, " + name + ",";
+            for (size_t at = 0; (at = src.find(from, at)) != std::string::npos;) {
+                if (at > 0 && ident(src[at - 1])) {
+                    at += from.size();
+                    continue;
+                }
+                src.replace(at, from.size(), to);
+                at += to.size();
+            }
+        }
+    }
+}
+
 GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& flags, const KernelOptions& opts) {
     GeneratedKernel gk;
     std::map<std::string, StringStorage> storages;
@@ -496,6 +541,35 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 }
                 gk.baked.push_back(up);
             }
+        }
+        if (opts.mask_zero_elements && !opts.exact_cr && !opts.fast_math) {
+            auto nonzero_bits = [](const UniformUpload& up) {
+                unsigned mask = 0;
+                for (int k = 0; k < 16; ++k)
+                    if (up.f[k] != 0.0f) mask |= 1u << k;  // (column-major: k = 4 * column + row; a NaN element counts as non-zero)
+                return mask;
+            };
+            std::vector<std::pair<std::string, unsigned>> found;
+            bool any_animated = false;
+            for (auto& up : evaluate_scene_uniforms(scene, nullptr)) {
+                if (up.type != UniformType::Mat4 || baked.count(up.name) || opts.keep_unmasked.count(up.name)) continue;
+                found.emplace_back(up.name, nonzero_bits(up));
+                any_animated = any_animated || up.animated;
+            }
+            // A matrix that reads the formulas' `time` is identity-like exactly when a clip starts -- the moment a clip-constant kernel is
+            // generated.  Its pattern is therefore taken over the whole clip: the union over probes of `time` in [0, 1] (a copy of the scene;
+            // the pattern of an animation changes at its end points or nowhere, a probe that misses something costs one rebuild, not a pixel).
+            if (any_animated)
+                for (double t : {0.0, 0.0625, 0.271, 0.5, 0.729, 0.9375, 1.0}) {
+                    Scene probe = scene;
+                    probe.time = t;
+                    for (auto& up : evaluate_scene_uniforms(probe, nullptr))
+                        if (up.type == UniformType::Mat4 && up.animated)
+                            for (auto& f : found)
+                                if (f.first == up.name) f.second |= nonzero_bits(up);
+                }
+            for (auto& f : found)
+                if (f.second != 0xffffu) gk.masked.push_back(f);
         }
         if (opts.specialize_ints || opts.specialize_all || opts.specialize_static)
             for (auto& [name, value] : opts.baked_options)
@@ -611,6 +685,11 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             auto it = baked.find(u.name);
             if (it != baked.end()) s.add_string("#define " + u.name + " (" + it->second + ")\n");
             else s.add_string("#define " + u.name + " (PTL_U." + u.name + ")\n");
+        }
+        for (auto& [name, mask] : gk.masked) {
+            char hex[16];
+            std::snprintf(hex, sizeof hex, "0x%04xu", mask);
+            s.add_string("#define PTL_MASK_" + name + " " + hex + "\n");
         }
         storages["uniforms"] = std::move(s);
     }
@@ -893,6 +972,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     body.add_string(device_source_entry());
     gk.source = std::move(body.storage);
     gk.line_numbers = std::move(body.line_numbers);
+    apply_zero_masks(gk.source, gk.masked);
     if (opts.count_segments) gk.defines.push_back("PTL_COUNT_SEGMENTS");
     if (opts.anaglyph) gk.defines.push_back("PTL_ANAGLYPH");
     if (opts.fast_math) gk.defines.push_back("PTL_FAST_MATH");

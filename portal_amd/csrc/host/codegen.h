@@ -83,6 +83,14 @@ struct KernelOptions {
     // are not compiled in at all -- 7-10 % of the kernel time of the BASELINE scenes (profiles/r03/stub_bake_switches.jsonl), although they
     // are read once per ray: what they cost is registers and code around the bounce loop.  The renderer rebuilds when one changes.
     std::map<std::string, int> baked_options;
+    // A matrix uniform that stays a run-time value (nothing baked, only Bool / Int baked, animated within the clip, demoted) still has a ZERO
+    // PATTERN -- portal matrices are mostly translations and quarter turns -- and the pattern survives where the values move.  With this on
+    // the generator records the pattern of every such matrix (GeneratedKernel::masked, `#define PTL_MASK_<name>`) and writes the
+    // `transform(<name>, ..)` calls of the snippets and the generated plane tests in their masked forms (device/ptl_glsl.h `ptl_mul_m`):
+    // the terms with a zero element are neither executed nor loaded -- what a baked matrix gets from ptl_mterm.  Same deviation as there
+    // (non-finite vector components); the renderer rebuilds when a masked element stops being zero.  Off for contract 1 and the tolerance mode.
+    bool mask_zero_elements = false;
+    std::set<std::string> keep_unmasked;  // ... except these (a pattern that did not hold: demoted by the renderer)
     // Ray-independent work of the generated plane code (normalize(get_normal(X_mat)), both possible is_collinear verdicts) is
     // evaluated once per uniform upload by the module's prologue kernel `ptl_derive_kernel` and read back as extra uniforms,
     // instead of once per bounce-loop trip by every lane.  Same functions, same binary32 operations: identical frames.
@@ -123,6 +131,7 @@ struct GeneratedKernel {
     bool first_trip_variants = false;   // the kernel has first-trip copies of its intersection-material snippets (define PTL_FIRST_TRIP)
     int hoisted_members = 0;            // ... plus this many members holding uniform-only work of the scene snippets (glsl_hoist.h)
     std::vector<DerivedPlane> derived;  // members appended to the block behind uniform_block_size, written on the device
+    std::vector<std::pair<std::string, unsigned>> masked;  // run-time matrices whose zero pattern is compiled in: bit 4 * column + row set = may be non-zero
 };
 
 // Scene::uniforms (scene.rs:424-543): names and types, in the reference's order.

@@ -219,6 +219,45 @@ def test_flipped_mode_switch_with_background_rejit_draws_the_same_bits_meanwhile
     assert np.array_equal(_bits(got), _bits(pinhole))
 
 
+@pytest.mark.parametrize("flavour", ["ints", "static", "static+async"])
+def test_zero_patterns_of_runtime_matrices_follow_the_values(gpu, flavour):
+    """KernelOptions::mask_zero_elements: a specialised build shortens the products of matrices that stay run-time values by their ZERO
+    PATTERN.  `progress` of portal_in_portal turns a portal (rotation 0 at progress 0: zeros in the rotation block, none once it moves): the
+    frames must be the un-specialised kernel's bit for bit before, after and back -- the pattern that no longer holds is rebuilt (Bool / Int
+    builds: with the new pattern; clip-constant builds: the matrix is demoted) and never drawn with."""
+    import time
+
+    pa = gpu
+    path = pa.scene_path("portal_in_portal")
+    flags = {"ints": pa.FLAG_SPECIALIZE_INTS, "static": pa.FLAG_SPECIALIZE_STATIC, "static+async": pa.FLAG_SPECIALIZE_STATIC | pa.FLAG_ASYNC_REJIT}[flavour]
+    sa, sb = pa.Scene.from_file(path), pa.Scene.from_file(path)
+    ra, rb = pa.SceneRenderer(sa, device=0), pa.SceneRenderer(sb, device=0, flags=flags)
+    for r in (ra, rb):
+        r.set_option("render_depth", 12)
+    w, h = 160, 90
+    seen = []
+    for value in (0.0, 0.3, 0.0, 0.7, 0.3):
+        for s_ in (sa, sb):
+            assert s_.set_uniform("progress", value)
+        a = ra.draw(w, h, rgba32f=True)["rgba32f"]
+        b = rb.draw(w, h, rgba32f=True)["rgba32f"]
+        assert np.array_equal(_bits(a), _bits(b)), (flavour, value)
+        deadline = time.time() + 120
+        while rb.rejit_pending() and time.time() < deadline:   # (async: also the frame of the adopted kernel)
+            time.sleep(0.05)
+            b = rb.draw(w, h, rgba32f=True)["rgba32f"]
+        assert np.array_equal(_bits(a), _bits(b)), (flavour, value, "adopted")
+        seen.append(a.copy())
+    assert not np.array_equal(_bits(seen[0]), _bits(seen[1])) and np.array_equal(_bits(seen[0]), _bits(seen[2]))  # the portal really moved, and came back
+    # the masks are there to be followed: the Bool / Int build of the start state knows the zero rotation of the portal, the later one does not
+    if flavour == "ints":
+        start, moved = pa.Scene.from_file(path), pa.Scene.from_file(path)
+        moved.set_uniform("progress", 0.3)
+        m0 = {l.split()[1]: l.split()[2] for l in start.generate_source(flags).split("\n") if l.startswith("#define PTL_MASK_")}
+        m1 = {l.split()[1]: l.split()[2] for l in moved.generate_source(flags).split("\n") if l.startswith("#define PTL_MASK_")}
+        assert m0 and any(m1.get(k) != v for k, v in m0.items())
+
+
 _RCCL_ONE_RANK = r"""
 import os, sys
 import numpy as np, torch, torch.distributed as dist

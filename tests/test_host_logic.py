@@ -889,6 +889,37 @@ def test_specialised_builds_compile_the_renderers_mode_switches_in(pa, tmp_path,
     assert static.code_object() != flat and static.rejit_count() == 1
 
 
+def test_zero_patterns_of_runtime_matrices_shorten_their_products(pa):
+    """KernelOptions::mask_zero_elements: with any specialisation on, a matrix that stays a run-time uniform has its zero pattern compiled
+    in -- `transform(X_mat, ..)` of the snippets and the generated plane tests become the masked forms -- and the host build of that
+    source draws the same bits as the full products.  Not for the un-specialised kernel (valid for every state), contract 1 or --fast."""
+    import re
+
+    from oracle import host_build as hb
+
+    ints = pa.FLAG_SPECIALIZE_INTS
+    scene = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    src = scene.generate_source(ints)
+    masks = dict(re.findall(r"#define PTL_MASK_(\w+) (0x[0-9a-f]{4})u", src))
+    assert len(masks) > 20 and all(int(v, 16) != 0xFFFF for v in masks.values())
+    assert "ptl_transform_m<PTL_MASK_b0_mat_inv>(b0_mat_inv," in src and "transform(b0_mat_inv," not in src.replace("ptl_transform_m<PTL_MASK_b0_mat_inv>(b0_mat_inv,", "")
+    assert re.search(r"plane_intersect_derived(_o)?<PTL_MASK_\w+>\(r, ", src) and re.search(r"ptl_plane_cull(_o)?<PTL_MASK_\w+>\(r, ", src)
+    for flags in (0, ints | pa.FLAG_NO_ZERO_MASKS, ints | pa.FLAG_EXACT_CR, ints | pa.FLAG_FAST_MATH):
+        assert "#define PTL_MASK_" not in scene.generate_source(flags), flags
+    assert "#define PTL_MASK_" not in scene.generate_source(ints | pa.FLAG_SPECIALIZE_ALL)  # every matrix is a literal there: ptl_mterm does it
+    # the identity pattern of a pure translation: only the diagonal and the last column may be non-zero
+    ident_like = [v for v in masks.values() if int(v, 16) & ~0xF421 == 0]
+    assert ident_like, masks
+    frames = {}
+    for label, flags in (("masked", ints), ("full", ints | pa.FLAG_NO_ZERO_MASKS)):
+        sc = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+        r = pa.SceneRenderer(sc, device=-1, flags=flags)
+        r.set_option("render_depth", 8)
+        frames[label] = hb.host_kernel_for(r, sc, 64, 36, flags=flags).render(64, 36)["rgba32f"].copy()
+    assert np.array_equal(frames["masked"].view(np.uint32), frames["full"].view(np.uint32))
+    assert len(np.unique(frames["masked"].reshape(-1, 4), axis=0)) > 100
+
+
 def test_code_object_cache_rejects_foreign_files_and_names_the_toolchain(pa, tmp_path, monkeypatch):
     """The cache key covers source + options + the hiprtc library that compiled it; a truncated or non-ELF file under that name is
     ignored and replaced by a fresh build."""

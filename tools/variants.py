@@ -140,6 +140,7 @@ VARIANTS = {
     "r3_all_O2": "SPECIALIZE_ALL -O2 -fno-slp-vectorize", "r3_all_O3": "SPECIALIZE_ALL -O3 -fno-slp-vectorize", "r3_all_w4_O3slp": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -O3",
     "r3_ints_reload": "SPECIALIZE -DPTL_UNIFORM_RELOAD", "r3_dyn_reload": "-DPTL_UNIFORM_RELOAD", "r3_dyn_O1": "-O1", "r3_dyn_O1_reload": "-O1 -DPTL_UNIFORM_RELOAD",
     "r3_all_modinl": "SPECIALIZE_ALL -mllvm -enable-module-inliner", "r3_ints_modinl": "SPECIALIZE -mllvm -enable-module-inliner", "r3_dyn_modinl": "-mllvm -enable-module-inliner",
+    "r3_ints_nomasks": "SPECIALIZE NO_MASKS",
     "r3_all_peel": "SPECIALIZE_ALL -DPTL_PEEL_FIRST_TRIP", "r3_ints_peel": "SPECIALIZE -DPTL_PEEL_FIRST_TRIP", "r3_dyn_peel": "-DPTL_PEEL_FIRST_TRIP",
     "r3_all_w4_zerofold": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -fno-signed-zeros -fno-honor-nans",
 }
@@ -160,7 +161,7 @@ def run_one(case, vname, flags):
     w, h, d, aa = int(w), int(h), int(d), int(aa)
     toks = flags.split()
     rflags = (pa.FLAG_SPECIALIZE_INTS if ("SPECIALIZE" in toks or "SPECIALIZE_ALL" in toks) else 0) | (pa.FLAG_SPECIALIZE_ALL if "SPECIALIZE_ALL" in toks else 0)
-    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0) | (pa.FLAG_NO_DEFERRED_UPDATES if "NO_DEFER" in toks else 0) | (pa.FLAG_NO_UNIFORM_HOIST if "NO_HOIST" in toks else 0) | (pa.FLAG_NO_FIRST_TRIP if "NO_FIRST_TRIP" in toks else 0) | (pa.FLAG_EXACT_CR if "EXACT_CR" in toks else 0) | (pa.FLAG_NO_UNROLL if "NO_UNROLL" in toks else 0) | (pa.FLAG_NO_FIRST_TRIP_PLANES if "NO_FTP" in toks else 0)
+    rflags |= (pa.FLAG_NO_DERIVED_UNIFORMS if "NO_DERIVED" in toks else 0) | (pa.FLAG_FAST_MATH if "FAST" in toks else 0) | (pa.FLAG_NO_DEFERRED_UPDATES if "NO_DEFER" in toks else 0) | (pa.FLAG_NO_UNIFORM_HOIST if "NO_HOIST" in toks else 0) | (pa.FLAG_NO_FIRST_TRIP if "NO_FIRST_TRIP" in toks else 0) | (pa.FLAG_EXACT_CR if "EXACT_CR" in toks else 0) | (pa.FLAG_NO_UNROLL if "NO_UNROLL" in toks else 0) | (pa.FLAG_NO_FIRST_TRIP_PLANES if "NO_FTP" in toks else 0) | (pa.FLAG_NO_ZERO_MASKS if "NO_MASKS" in toks else 0)
     # the VGPR allocator is an option the JIT always passes (kernel.cpp): select it through its own switch, not a second -mllvm
     ra = [t.split("=", 1)[1] for t in toks if t.startswith("-vgpr-regalloc=")]
     if "RA_DEFAULT" in toks:
