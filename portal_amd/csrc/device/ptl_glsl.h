@@ -772,6 +772,8 @@ template <unsigned MASK, int R> PTL_FN float ptl_row_m(const mat4& m, const vec4
 template <unsigned MASK> PTL_FN vec4 ptl_mul_m(const mat4& m, const vec4& v) {
     return vec4(ptl_row_m<MASK, 0>(m, v), ptl_row_m<MASK, 1>(m, v), ptl_row_m<MASK, 2>(m, v), ptl_row_m<MASK, 3>(m, v));
 }
+// (`X_mat * <anything else>` that the generator rewrote by its shape alone -- a matrix, a scalar: the ordinary product)
+template <unsigned MASK, class T> PTL_FN auto ptl_mul_m(const mat4& m, const T& x) -> decltype(m * x) { return m * x; }
 // the same product for a matrix that is a run-time value in every build (the camera): no zero tests (they would be executed)
 PTL_FN vec4 ptl_mul_runtime(const mat4& m, const vec4& v) {
     return vec4(ptl_term(m.c[3].x, v.w, ptl_term(m.c[2].x, v.z, ptl_term(m.c[1].x, v.y, ptl_term0(m.c[0].x, v.x)))),

@@ -477,6 +477,75 @@ static void apply_zero_masks(std::string& src, const std::vector<std::pair<std::
             src.replace(at, 9, repl);
             at += repl.size();
         }
+        // NAME * <operand>  ->  ptl_mul_m<PTL_MASK_NAME>(NAME, <operand>): a product written out in a snippet (`(b0_mat_inv * pos).z`).  NAME must
+        // be the whole left operand (nothing multiplicative before it); the right operand of `*` is one unary expression: a parenthesised
+        // group, or a name with its call / member / index suffixes.  ptl_mul_m falls back to the plain product for anything but a vec4.
+        for (size_t at = 0; (at = src.find(name, at)) != std::string::npos;) {
+            size_t e = at + name.size();
+            if ((at > 0 && (ident(src[at - 1]) || src[at - 1] == '.')) || (e < src.size() && ident(src[e]))) {
+                at = e;
+                continue;
+            }
+            size_t b = at;
+            while (b > 0 && src[b - 1] == ' ') --b;
+            if (b > 0 && (src[b - 1] == '*' || src[b - 1] == '/' || src[b - 1] == '%')) {
+                at = e;
+                continue;
+            }
+            if (b > 0 && (src[b - 1] == '-' || src[b - 1] == '+')) {  // a UNARY sign on the matrix binds tighter than the product: leave (-M) * v alone
+                size_t c = b - 1;
+                while (c > 0 && src[c - 1] == ' ') --c;
+                if (c == 0 || !(ident(src[c - 1]) || src[c - 1] == ')' || src[c - 1] == ']')) {
+                    at = e;
+                    continue;
+                }
+            }
+            size_t p = e;
+            while (p < src.size() && src[p] == ' ') ++p;
+            if (p + 1 >= src.size() || src[p] != '*' || src[p + 1] == '=') {
+                at = e;
+                continue;
+            }
+            size_t q = p + 1;
+            while (q < src.size() && src[q] == ' ') ++q;
+            auto skip_group = [&](size_t k, char open, char close) {  // k at `open`: one past the matching `close`, npos if unbalanced on this line
+                int depth = 0;
+                for (; k < src.size() && src[k] != '\n'; ++k) {
+                    if (src[k] == open) ++depth;
+                    else if (src[k] == close && --depth == 0) return k + 1;
+                }
+                return std::string::npos;
+            };
+            size_t end = std::string::npos;
+            if (q < src.size() && src[q] == '(') {
+                end = skip_group(q, '(', ')');
+            } else if (q < src.size() && (std::isalpha((unsigned char)src[q]) || src[q] == '_')) {
+                end = q;
+                while (end < src.size() && ident(src[end])) ++end;
+                for (;;) {  // suffixes
+                    if (end < src.size() && src[end] == '(') end = skip_group(end, '(', ')');
+                    else if (end < src.size() && src[end] == '[') end = skip_group(end, '[', ']');
+                    else if (end + 1 < src.size() && src[end] == '.' && (std::isalpha((unsigned char)src[end + 1]) || src[end + 1] == '_')) {
+                        size_t member = ++end;
+                        while (end < src.size() && ident(src[end])) ++end;
+                        std::string m = src.substr(member, end - member);
+                        if ((m == "sw" || m == "swr") && end < src.size() && src[end] == '<') end = skip_group(end, '<', '>');  // a translated swizzle: .sw<0,1,2>()
+                    } else if (end + 2 < src.size() && src[end] == '-' && src[end + 1] == '>' && (std::isalpha((unsigned char)src[end + 2]) || src[end + 2] == '_')) {
+                        end += 2;  // (the generated prologue: `X_mat_inv * out->ptl_dv_origin`)
+                        while (end < src.size() && ident(src[end])) ++end;
+                    } else break;
+                    if (end == std::string::npos) break;
+                }
+            }
+            if (end == std::string::npos) {
+                at = e;
+                continue;
+            }
+            std::string operand = src.substr(q, end - q);
+            std::string repl = "ptl_mul_m<PTL_MASK_" + name + ">(" + name + ", " + operand + ")";
+            src.replace(at, end - at, repl);
+            at += std::string("ptl_mul_m<PTL_MASK_").size() + name.size() + 2 + name.size();  // continue inside the operand: it may hold further products
+        }
         for (const char* fn : {"ptl_plane_cull_o", "ptl_plane_cull", "plane_intersect_derived_o", "plane_intersect_derived"}) {
             std::string from = std::string(fn) + "(r, " + name + ",", to = std::string(fn) + "<PTL_MASK_" + name + ">(r, " + name + ",";
             for (size_t at = 0; (at = src.find(from, at)) != std::string::npos;) {
@@ -559,10 +628,15 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             // A matrix that reads the formulas' `time` is identity-like exactly when a clip starts -- the moment a clip-constant kernel is
             // generated.  Its pattern is therefore taken over the whole clip: the union over probes of `time` in [0, 1] (a copy of the scene;
             // the pattern of an animation changes at its end points or nowhere, a probe that misses something costs one rebuild, not a pixel).
+            // The other per-frame input is the camera (Matrix::Camera): the last probe gives it a matrix without a single zero, so that
+            // nothing that follows the camera is ever masked (a renderer is even created before its camera is known).
             if (any_animated)
-                for (double t : {0.0, 0.0625, 0.271, 0.5, 0.729, 0.9375, 1.0}) {
+                for (double t : {0.0, 0.0625, 0.271, 0.5, 0.729, 0.9375, 1.0, -1.0}) {
                     Scene probe = scene;
-                    probe.time = t;
+                    if (t >= 0.0) probe.time = t;
+                    else
+                        probe.camera_matrix = DMat4::from_cols(DVec4(0.36, 0.48, -0.8, 0.013), DVec4(-0.8, 0.6, 0.017, 0.011), DVec4(0.48, 0.64, 0.6, 0.019),
+                                                               DVec4(0.37, -1.21, 2.53, 1.0));
                     for (auto& up : evaluate_scene_uniforms(probe, nullptr))
                         if (up.type == UniformType::Mat4 && up.animated)
                             for (auto& f : found)

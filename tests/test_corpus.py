@@ -30,14 +30,25 @@ def scene_files():
     return [f for f in sorted(glob.glob(os.path.join(CORPUS, "*.ron"))) if os.path.getsize(f) > 0 and os.path.basename(f)[:-4] not in OUT_OF_SCOPE]
 
 
-@pytest.mark.parametrize("path", scene_files(), ids=[os.path.basename(f)[:-4] for f in scene_files()])
-def test_corpus_scene_product_equals_oracle(pa, path):
+def masked_build_sample():
+    """Scenes that also go through the Bool / Int baked build (zero patterns of the run-time matrices compiled in, masked products): every
+    fifth file plus the ones whose snippets multiply by matrices in every way the corpus knows (written-out products, chains, Matrix::Camera)."""
+    named = {"portal_in_portal", "portal_in_portal_plus_ultra", "triple_portal", "mobius_monoportal", "monoportal", "matryoshka", "trefoil_knot_portal", "cone_portal"}
+    return [f for k, f in enumerate(scene_files()) if k % 5 == 0 or os.path.basename(f)[:-4] in named]
+
+
+def _parity_cases():
+    return [(f, "plain") for f in scene_files()] + [(f, "ints") for f in masked_build_sample()]
+
+
+@pytest.mark.parametrize("path,build", _parity_cases(), ids=[os.path.basename(f)[:-4] + ("" if b == "plain" else "-ints") for f, b in _parity_cases()])
+def test_corpus_scene_product_equals_oracle(pa, path, build):
     from oracle import host_build as hb
     from oracle.portal_oracle import Oracle
 
     w, h, depth = 24, 14, 12
     scene = pa.Scene.from_file(path)
-    source = scene.generate_source(0)
+    source = scene.generate_source(0 if build == "plain" else pa.FLAG_SPECIALIZE_INTS)
     layout, size = scene.uniform_layout()
     hk = hb.HostKernel(source, layout, size, opt="-O0")  # tiny frames: compile time dominates
     o = Oracle(path, asset_root="/root/reference")
@@ -92,6 +103,11 @@ def test_corpus_scene_compiles_for_gfx950(pa, path, tmp_path, monkeypatch):
     scene = pa.Scene.from_file(path)
     r = pa.SceneRenderer(scene, device=-1, asset_root="/root/reference", flags=pa.FLAG_SPECIALIZE_STATIC)
     assert r.code_object()[:4] == b"\x7fELF"
+    # ... and with only Bool / Int uniforms baked: every matrix stays a run-time value and the generator rewrites the products with the
+    # masked ones by their shape (`X_mat * <operand>`, `transform(X_mat, ..)`) -- whatever the scene's authors wrote has to survive that
+    if path in masked_build_sample():
+        r = pa.SceneRenderer(pa.Scene.from_file(path), device=-1, asset_root="/root/reference", flags=pa.FLAG_SPECIALIZE_INTS)
+        assert r.code_object()[:4] == b"\x7fELF"
 
 
 def animated_scene_files():

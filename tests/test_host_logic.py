@@ -920,6 +920,52 @@ def test_zero_patterns_of_runtime_matrices_shorten_their_products(pa):
     assert len(np.unique(frames["masked"].reshape(-1, 4), axis=0)) > 100
 
 
+_PRODUCT_SHAPES = """vec4 p = r.o;
+vec4 a = portal_a_mat_inv * p;
+vec4 b = portal_a_mat * (portal_b_mat_inv * vec4(p.xyz, 1.));
+vec4 c = portal_b_mat * p.xyzw;
+vec4 d = p.x * portal_a_mat * p;
+vec4 e = portal_a_mat * -p;
+mat4 m = portal_a_mat * portal_b_mat_inv;
+vec4 f = (portal_a_mat_inv * transform(portal_b_mat, r).o) * 2.;
+float s = dot(a + b + c + d + e + f, vec4(1.)) + (m * p).x;
+SceneIntersectionWithMaterial result = SceneIntersectionWithMaterial(scene_intersection_none, material_empty());
+if (s > 1e30) result.scene = SceneIntersection(CUSTOM_MATERIAL, SurfaceIntersection(true, 1., 0., 0., vec3(0., 0., 1.)), false);
+return result;"""
+
+
+def test_masked_product_rewrite_follows_the_shape_of_the_operand(pa):
+    """`X_mat * <operand>` of a snippet becomes `ptl_mul_m<PTL_MASK_X_mat>(X_mat, <operand>)` for the operand shapes GLSL has -- a name, a
+    parenthesised group, a constructor call, a swizzle (already `.sw<..>()` by then), a call with a member -- and stays as written where the
+    matrix is not the whole left operand (`p.x * M * p`), where the right operand starts with a sign, or where it is another matrix (the
+    overload set of ptl_mul_m takes that one); the source compiles for gfx950 and the host build draws the bits of the full products."""
+    from oracle import host_build as hb
+
+    ints = pa.FLAG_SPECIALIZE_INTS
+    text = open(pa.scene_path("basics")).read()
+    text = text.replace("intersection_materials: ([]),", 'intersection_materials: ([\n        (\n            name: "shapes",\n            data: ((("' + _PRODUCT_SHAPES + '"))),\n        ),\n    ]),')
+    src = pa.Scene.from_text(text).generate_source(ints | pa.FLAG_NO_FIRST_TRIP)
+    body = src[src.index("intersect_material_0(Ray r) {"):]
+    body = body[:body.index("return result;")]
+    for want in ("vec4 a = ptl_mul_m<PTL_MASK_portal_a_mat_inv>(portal_a_mat_inv, p);",
+                 "vec4 b = ptl_mul_m<PTL_MASK_portal_a_mat>(portal_a_mat, (ptl_mul_m<PTL_MASK_portal_b_mat_inv>(portal_b_mat_inv, vec4(p.sw<0,1,2>(), 1.f))));",
+                 "vec4 c = ptl_mul_m<PTL_MASK_portal_b_mat>(portal_b_mat, p.sw<0,1,2,3>());",
+                 "vec4 d = p.x * portal_a_mat * p;",
+                 "vec4 e = portal_a_mat * -p;",
+                 "mat4 m = PTL_U.ptl_hv0;",   # uniform-only: hoisted into the prologue, where the same rewrite meets it (below)
+                 "(ptl_mul_m<PTL_MASK_portal_a_mat_inv>(portal_a_mat_inv, ptl_transform_m<PTL_MASK_portal_b_mat>(portal_b_mat, r).o))"):
+        assert want in body, (want, body)
+    assert "ptl_mul_m<PTL_MASK_portal_a_mat>(portal_a_mat, portal_b_mat_inv)" in src  # matrix x matrix: the overload for "anything else"
+    frames = {}
+    for label, flags in (("masked", ints), ("full", ints | pa.FLAG_NO_ZERO_MASKS)):
+        sc = pa.Scene.from_text(text)
+        r = pa.SceneRenderer(sc, device=-1, flags=flags)  # hiprtc for gfx950
+        assert r.code_object()[:4] == b"\x7fELF"
+        r.set_option("render_depth", 6)
+        frames[label] = hb.host_kernel_for(r, sc, 48, 27, flags=flags).render(48, 27)["rgba32f"].copy()
+    assert np.array_equal(frames["masked"].view(np.uint32), frames["full"].view(np.uint32))
+
+
 def test_code_object_cache_rejects_foreign_files_and_names_the_toolchain(pa, tmp_path, monkeypatch):
     """The cache key covers source + options + the hiprtc library that compiled it; a truncated or non-ELF file under that name is
     ignored and replaced by a fresh build."""
