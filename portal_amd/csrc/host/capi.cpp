@@ -847,6 +847,9 @@ static bool zero_patterns_broken(ptl_renderer* r, const std::vector<UniformUploa
                 }
             break;
         }
+    // one broken pattern says the probes did not see this clip's motion: every mask goes, so that a clip costs at most ONE extra rebuild
+    if (broken)
+        for (auto& m : r->masked) r->keep_unmasked.insert(m.first);
     return broken;
 }
 

@@ -628,20 +628,37 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             // A matrix that reads the formulas' `time` is identity-like exactly when a clip starts -- the moment a clip-constant kernel is
             // generated.  Its pattern is therefore taken over the whole clip: the union over probes of `time` in [0, 1] (a copy of the scene;
             // the pattern of an animation changes at its end points or nowhere, a probe that misses something costs one rebuild, not a pixel).
-            // The other per-frame input is the camera (Matrix::Camera): the last probe gives it a matrix without a single zero, so that
-            // nothing that follows the camera is ever masked (a renderer is even created before its camera is known).
-            if (any_animated)
-                for (double t : {0.0, 0.0625, 0.271, 0.5, 0.729, 0.9375, 1.0, -1.0}) {
-                    Scene probe = scene;
-                    if (t >= 0.0) probe.time = t;
-                    else
-                        probe.camera_matrix = DMat4::from_cols(DVec4(0.36, 0.48, -0.8, 0.013), DVec4(-0.8, 0.6, 0.017, 0.011), DVec4(0.48, 0.64, 0.6, 0.019),
-                                                               DVec4(0.37, -1.21, 2.53, 1.0));
+            if (any_animated) {
+                auto take = [&](const Scene& probe) {
                     for (auto& up : evaluate_scene_uniforms(probe, nullptr))
                         if (up.type == UniformType::Mat4 && up.animated)
                             for (auto& f : found)
                                 if (f.first == up.name) f.second |= nonzero_bits(up);
+                };
+                Scene probe = scene;
+                const bool in_clip = !scene.run_animations && scene.current_stage.kind == StageRef::RealAnimation && scene.current_stage.index >= 0 &&
+                                     scene.current_stage.index < (int)scene.animations.size() && scene.animations[scene.current_stage.index].duration > 0.0;
+                if (in_clip) {
+                    // inside a clip: the video pipeline's own step (Scene::update) at 33 moments of the clip.  On the reference's corpus (471 clips,
+                    // patterns taken on a 240-point grid) 7 probes miss something in 16 clips, 16 in 10, 32 in none: elements like cos(pi/2)
+                    // flicker between 0 and 1e-17, and every miss is a rebuild in the middle of a clip
+                    const double duration = scene.animations[scene.current_stage.index].duration;
+                    for (int k = 0; k <= 32; ++k) {
+                        probe.update(duration * (k < 32 ? k / 32.0 : 0.999999));
+                        take(probe);
+                    }
+                } else {
+                    for (double t : {0.0, 0.0625, 0.271, 0.5, 0.729, 0.9375, 1.0}) {
+                        probe.time = t;
+                        take(probe);
+                    }
                 }
+                // The other per-frame input is the camera (Matrix::Camera): one probe gives it a matrix without a single zero, so that
+                // nothing that follows the camera is ever masked (a renderer is even created before its camera is known).
+                probe = scene;
+                probe.camera_matrix = DMat4::from_cols(DVec4(0.36, 0.48, -0.8, 0.013), DVec4(-0.8, 0.6, 0.017, 0.011), DVec4(0.48, 0.64, 0.6, 0.019), DVec4(0.37, -1.21, 2.53, 1.0));
+                take(probe);
+            }
             for (auto& f : found)
                 if (f.second != 0xffffu) gk.masked.push_back(f);
         }

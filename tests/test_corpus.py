@@ -146,6 +146,32 @@ def test_corpus_real_animations_product_equals_oracle(pa, path):
             hl._same_uniforms(ps.uniform_values(), osc.scene_uniform_values(), (clip, t))
 
 
+def test_zero_patterns_compiled_into_clip_kernels_hold_through_every_corpus_clip(pa):
+    """KernelOptions::mask_zero_elements in the clip-constant build: the zero pattern of an animated matrix is taken over 33 moments of the
+    clip (Scene::update on a copy of the scene).  A pattern that breaks in the middle of a clip is not a wrong pixel -- the renderer checks
+    every upload and rebuilds -- but it is a rebuild in the middle of a clip; so: every clip of every animated scene of the corpus (471 clips,
+    ~3 900 masked matrices), at 29 other moments, never leaves the patterns its kernel was generated with."""
+    import re
+
+    clips = masked = 0
+    for path in animated_scene_files():
+        ps = pa.Scene.from_file(path)
+        for clip, duration in ps.animations():
+            ps.init_animation(clip)
+            ps.update(0.0)
+            src = ps.generate_source(pa.FLAG_SPECIALIZE_STATIC)
+            masks = {n: int(v, 16) for n, v in re.findall(r"#define PTL_MASK_(\w+) (0x[0-9a-f]{4})u", src)}
+            clips += 1
+            masked += len(masks)
+            for k in range(29):
+                ps.update(duration * k / 29.0)
+                vals = ps.uniform_values()
+                for name, mask in masks.items():
+                    a = np.asarray(vals[name], np.float32).T.reshape(-1)  # column-major like the uniform block: bit 4 * column + row
+                    assert not any(a[e] != 0 and not (mask >> e) & 1 for e in range(16)), (os.path.basename(path), clip, name, k)
+    assert clips > 400 and masked > 3000
+
+
 @pytest.mark.parametrize("path", scene_files(), ids=[os.path.basename(f)[:-4] for f in scene_files()])
 def test_corpus_scene_writer_reproduces_the_file(pa, path):
     """All 82 scene files were written by the reference's RON writer: parse -> write must give each back byte for byte."""
