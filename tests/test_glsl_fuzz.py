@@ -183,8 +183,9 @@ def test_random_glsl_expressions_product_equals_oracle(pa, tmp_path, seed):
     assert len(np.unique(got.reshape(-1, 4), axis=0)) > N_EXPR       # the bands really show different values
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
-def test_random_glsl_expressions_over_uniforms_survive_the_hoister(pa, tmp_path, seed):
+@pytest.mark.parametrize("seed,flags", [(11, 0), (12, 0), (13, 0), (14, 0), (15, 0), (16, 0), (11, 1), (13, 1), (16, 1)],
+                         ids=["11", "12", "13", "14", "15", "16", "11-masked", "13-masked", "16-masked"])
+def test_random_glsl_expressions_over_uniforms_survive_the_hoister(pa, tmp_path, seed, flags):
     """The same differential test with uniform leaves, uniform locals and a tabulated loop-carried chain: the hoister moves a good part
     of every snippet into the prologue (the source must show it), and the host build -- which runs derive() -- still equals the oracle,
     which evaluates the snippet as written, bit for bit."""
@@ -196,9 +197,13 @@ def test_random_glsl_expressions_over_uniforms_survive_the_hoister(pa, tmp_path,
     path.write_text(text)
     w, h = 4 * N_EXPR, 12
     scene = pa.Scene.from_file(str(path))
-    source = scene.generate_source(0)
+    # flags 1 (Bool / Int baked): the zero patterns of tilt_mat / back_mat are compiled in and the random products over them are rewritten
+    # into their masked forms by shape (codegen.cpp::apply_zero_masks) -- in the snippet and in what the hoister moved to the prologue
+    source = scene.generate_source(flags)
     assert source.count("PTL_U.ptl_hv") >= 10 and "ptl_tab_ok_" in source and "for (int ptl_k = 0;" in source
-    r = pa.SceneRenderer(scene, device=-1)
+    if flags:
+        assert source.count("ptl_mul_m<PTL_MASK_") >= 3
+    r = pa.SceneRenderer(scene, device=-1, flags=flags)
     r.set_option("render_depth", 2)
     r.set_option("view_angle", 1.5)
     hk = hb.HostKernel(source, *scene.uniform_layout(), opt="-O0")
