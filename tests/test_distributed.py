@@ -84,6 +84,34 @@ def test_gatherer_single_rank_is_identity():
     assert torch.equal(g.gather(shard), shard[:20])
 
 
+def _one_rank_worker(rank, world, port):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from portal_amd import parallel
+
+        tr = parallel.GatherTransport(H, W, 0, 1, "cpu", depth=2, collective_at_one_rank=True)
+        assert tr.depth == 2 and tr.collective and tr.gatherer.slots[0][1] is not None  # the gather buffers exist although world == 1
+        for slot, value in ((0, 5), (1, 9)):
+            tr.shards[slot][:] = value
+        works = [tr.submit(0), tr.submit(1)]             # dist.gather(..., async_op=True) of one shard to oneself
+        for slot, value in ((0, 5), (1, 9)):
+            got = tr.download(tr.finish(works[slot], slot))
+            assert got.shape == (H, W, 4) and (got == value).all()
+        plain = parallel.GatherTransport(H, W, 0, 1, "cpu")
+        assert plain.depth == 1 and not plain.collective and plain.submit(0) is None  # the default at one rank: no collective at all
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_transport_can_run_its_collective_with_one_rank():
+    """`collective_at_one_rank` (how a one-GPU box takes the real RCCL gather, tests/test_gpu_round2.py): the same switch over gloo."""
+    mp.spawn(_one_rank_worker, args=(1, _free_port()), nprocs=1, join=True)
+
+
 def _transport_worker(rank, world, port):
     import sys
 
