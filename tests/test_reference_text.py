@@ -284,6 +284,33 @@ def test_live_reference_text_on_random_views_equals_the_oracle():
 
 
 @needs_text
+@pytest.mark.parametrize("mode", [0, 1])
+def test_live_reference_text_anaglyph_frames_equal_the_oracle(mode):
+    """frag.glsl:343-406,466-475 with the `!ANAGLYPH!` lines kept (the reference's `disable_anaglyph = false`, src/main.rs:939): two eyes
+    from teleport_eye_matrices, combined in linear light, both colour modes -- the reference's text against the restatement, whole frames."""
+    from oracle.portal_oracle import CameraRig, Oracle
+    from oracle.reference_shader import ReferenceShader
+
+    frames = []
+    for cls in (ReferenceShader, Oracle):
+        o = cls(os.path.join(T.ROOT, "scenes", "monoportal.ron"))
+        o.anaglyph_compiled_in = True
+        o.options.update(render_depth=20, aa_count=1)
+        o.overrides.update({"_draw_anaglyph": np.int32(1), "_anaglyph_mode": np.int32(mode)})
+        rig = CameraRig(o)
+        rig.stereo = True
+        rig.move((0.2, 0.1, -0.3), 0.9, 1.2, 2.2)
+        o.camera = rig.settings()
+        frames.append(o.render(64, 36)["rgba32f"])
+    assert T.bits_equal(*frames).all()
+    assert len(np.unique(frames[0].reshape(-1, 4), axis=0)) > 200
+    r, g, b = frames[0][..., 0], frames[0][..., 1], frames[0][..., 2]
+    assert (np.abs(r - g) > 1e-3).mean() > 0.05  # the eyes differ: red and cyan channels are not one grey picture
+    if mode == 0:
+        assert np.array_equal(g.view(np.uint32), b.view(np.uint32))  # luminance mode: one cyan value for green and blue
+
+
+@needs_text
 def test_live_teleport_query_function_and_framebuffer_route_agree_with_the_oracle():
     from oracle.portal_oracle import Oracle
     from oracle.reference_shader import ReferenceShader
