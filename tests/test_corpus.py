@@ -150,7 +150,7 @@ def test_zero_patterns_compiled_into_clip_kernels_hold_through_every_corpus_clip
     """KernelOptions::mask_zero_elements in the clip-constant build: the zero pattern of an animated matrix is taken over 33 moments of the
     clip (Scene::update on a copy of the scene).  A pattern that breaks in the middle of a clip is not a wrong pixel -- the renderer checks
     every upload and rebuilds -- but it is a rebuild in the middle of a clip; so: every clip of every animated scene of the corpus (471 clips,
-    ~3 900 masked matrices), at 29 other moments, never leaves the patterns its kernel was generated with."""
+    ~3 900 masked matrices), at 13 other moments, never leaves the patterns its kernel was generated with."""
     import re
 
     clips = masked = 0
@@ -163,8 +163,8 @@ def test_zero_patterns_compiled_into_clip_kernels_hold_through_every_corpus_clip
             masks = {n: int(v, 16) for n, v in re.findall(r"#define PTL_MASK_(\w+) (0x[0-9a-f]{4})u", src)}
             clips += 1
             masked += len(masks)
-            for k in range(29):
-                ps.update(duration * k / 29.0)
+            for k in range(13):
+                ps.update(duration * (k + 0.37) / 13.0)
                 vals = ps.uniform_values()
                 for name, mask in masks.items():
                     a = np.asarray(vals[name], np.float32).T.reshape(-1)  # column-major like the uniform block: bit 4 * column + row
