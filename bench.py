@@ -193,7 +193,7 @@ def cpu_baseline(args, pa):
     }
 
 
-def reference_text_baseline(args, pa, seconds=8.0):
+def reference_text_baseline(args, pa, seconds=8.0, keep=None):
     """A second CPU figure that does not move when the product's translator improves: the reference's OWN shader text
     (oracle/reference_shader.py: library.glsl + frag.glsl with the generated slots, executed by the numpy GLSL interpreter, one core) on a
     seeded pixel sample of the same frame.  `kind: reference` -- the nearest thing to the reference's path that runs on a CPU at all."""
@@ -214,12 +214,70 @@ def reference_text_baseline(args, pa, seconds=8.0):
     rng = np.random.default_rng(zlib.crc32(args.scene.encode()) + 7)
     n, done, t0 = 4096, 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        o.shade_pixels(args.width, args.height, rng.integers(0, args.width, n), rng.integers(0, args.height, n))
+        xs, ys = rng.integers(0, args.width, n), rng.integers(0, args.height, n)
+        shaded = o.shade_pixels(args.width, args.height, xs, ys)
+        if keep is not None:  # the colours are the reference text's answer for these pixels: reference_text_check compares them with the timed build's frame
+            keep.append((xs, ys, shaded["rgba32f"], shaded["rgba8"]))
         done += n
     dt = time.perf_counter() - t0
     return {"value": round(done * args.aa / dt / 1e6, 5), "unit": "Mray/s", "cores": 1, "kind": "reference",
             "sample": f"{done} seeded pixels of the {args.width}x{args.height} frame in {dt:.1f} s: /root/reference/src/library.glsl + frag.glsl (text digest {RS.text_digest()}) "
                       "with the slots of scene.rs:693-1075, interpreted by oracle/glsl_interp.py on numpy lanes, single thread"}
+
+
+def reference_text_check(args, pa, renderer, torch, dev, stream, kept):
+    """The parity chain closed directly: the frame the TIMED renderer draws against the colours the reference's own shader text
+    (/root/reference/src/frag.glsl:106-159,515-551 + library.glsl, executed by oracle/reference_shader.py) gave for the seeded pixels
+    reference_text_baseline shaded -- float bits and RGBA8.  No hand oracle in between."""
+    W, H = args.width, args.height
+    f32 = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+    u8 = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
+    renderer.draw_device(pa.Frame(W, H, 0, 1), out_rgba8=u8.data_ptr(), out_rgba32f=f32.data_ptr(), stream=stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    xs, ys = np.concatenate([k[0] for k in kept]), np.concatenate([k[1] for k in kept])
+    want32, want8 = np.concatenate([k[2] for k in kept]), np.concatenate([k[3] for k in kept])
+    sel = torch.as_tensor(ys * W + xs, device=dev)
+    got32 = f32.view(-1, 4)[sel].cpu().numpy()
+    got8 = u8.view(-1, 4)[sel].cpu().numpy()
+    same = ((got32.view(np.uint32) == want32.view(np.uint32)) | (np.isnan(got32) & np.isnan(want32))).all(axis=1)
+    ok8 = (got8 == want8).all(axis=1)
+    err = np.abs(got32[:, :3].astype(np.float64) - want32[:, :3].astype(np.float64))
+    return {"pixels": int(len(xs)), "float_bits_equal": int(same.sum()), "rgba8_equal": int(ok8.sum()), "bit_exact": bool(same.all() and ok8.all()),
+            "max_abs_error": float(np.nanmax(err)) if len(err) else 0.0,
+            "checker": "oracle/reference_shader.py: the reference's library.glsl + frag.glsl text, slots as scene.rs:693-1075 prints them, run by oracle/glsl_interp.py"}
+
+
+def contract_distance(args, pa, torch, dev, stream, local_rank, spec_flags, workloads):
+    """How far numerics contract 2 (the shipped default: 1/x and sqrt correctly rounded with the extremes flushed, a / b = a * (1/b)) sits
+    from the IEEE evaluation (contract 1, FLAG_EXACT_CR: correctly rounded / and sqrt on every input) on whole BASELINE frames: the north
+    star's bar is 1e-5 per channel against a CPU evaluation, so the cost of the contract is a number here, not an anecdote."""
+    out = {}
+    for key, w in workloads.items():
+        scene = pa.Scene.from_file(pa.scene_path(w["scene"]))
+        W, H = w["width"], w["height"]
+        f32 = torch.empty((2, H, W, 4), dtype=torch.float32, device=dev)
+        u8 = torch.empty((2, H, W, 4), dtype=torch.uint8, device=dev)
+        ms = []
+        for k, flags in enumerate((spec_flags, spec_flags | pa.FLAG_EXACT_CR)):
+            r = pa.SceneRenderer(scene, device=local_rank, flags=flags)
+            r.set_option("render_depth", w["depth"])
+            r.set_option("aa_count", w["aa"])
+            r.draw_device(pa.Frame(W, H, 0, 1), out_rgba8=u8[k].data_ptr(), out_rgba32f=f32[k].data_ptr(), stream=stream.cuda_stream)
+            ms.append(float(np.median([r.draw_device(pa.Frame(W, H, 0, 1), out_rgba8=u8[k].data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(5)])))
+            del r
+        torch.cuda.synchronize(dev)
+        err = (f32[0, :, :, :3] - f32[1, :, :, :3]).abs().amax(dim=2)
+        err = torch.nan_to_num(err, nan=0.0)
+        differ = (f32[0].view(torch.int32) != f32[1].view(torch.int32)).any(dim=2)
+        out[key] = {"workload": f"scenes/{w['scene']}.ron {W}x{H} aa={w['aa']} depth={w['depth']}", "pixels": W * H,
+                    "pixels_with_other_bits": int(differ.sum().item()), "pixels_beyond_1e-5": int((err > 1e-5).sum().item()),
+                    "rgba8_pixels_differing": int((u8[0] != u8[1]).any(dim=2).sum().item()),
+                    "max_abs_error": float(err.max().item()), "median_abs_error": float(err.median().item()),
+                    "kernel_ms_contract2": round(ms[0], 4), "kernel_ms_contract1": round(ms[1], 4)}
+        del f32, u8
+    out["note"] = ("contract 2 (timed) against contract 1 = IEEE correctly rounded / and sqrt on every input (FLAG_EXACT_CR, `--exact-cr`), same scene, same build "
+                   "otherwise; pixels beyond 1e-5 are pixels where a last-bit difference decides a path (object and portal edges)")
+    return out
 
 
 def oracle_check(args, pa, renderer, torch, dev, stream, n=2048):
@@ -829,10 +887,24 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, pa)
             except Exception as e:
                 out["cpu_baseline"] = {"error": str(e)[:300]}
+            kept = []
             try:
-                out["cpu_baseline_reference_text"] = reference_text_baseline(args, pa)
+                out["cpu_baseline_reference_text"] = reference_text_baseline(args, pa, keep=kept)
             except Exception as e:
                 out["cpu_baseline_reference_text"] = {"error": str(e)[:300]}
+            try:
+                if kept:
+                    out["reference_text_check_of_the_timed_build"] = reference_text_check(args, pa, renderer, torch, dev, stream, kept)
+            except Exception as e:
+                out["reference_text_check_of_the_timed_build"] = {"error": str(e)[:300]}
+            try:
+                which = {"headline": dict(scene=args.scene, width=W, height=H, depth=args.depth, aa=args.aa)} if not (args.scene_file or args.camera or args.panini >= 0) else {}
+                if workload_key(args) == "portal_in_portal_3840x2160_d40" and not args.no_second_workload:
+                    which["c5"] = WORKLOADS["c5"]
+                if which and args.specialize == 2:
+                    out["contract1_vs_contract2"] = contract_distance(args, pa, torch, dev, stream, local_rank, spec_flags, which)
+            except Exception as e:
+                out["contract1_vs_contract2"] = {"error": str(e)[:300]}
             try:
                 out["oracle_check_of_the_timed_build"] = oracle_check(args, pa, renderer, torch, dev, stream)
             except Exception as e:

@@ -219,7 +219,8 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * bit16 = NO first-trip form of the generated plane tests: by default, where the scene's matrices are run-time uniforms, a second copy of
  * scene_intersect serves the trip on which every ray of a wave still starts at the camera and takes `plane_inv * r.o` of every Flat
  * object from the prologue kernel (ptl_dvo_<object>_<side>) -- the same product of the same values, identical frames.
- * bit17 = ASYNC REJIT (ptl_renderer_create only): see ptl_renderer_rejit_pending.
+ * bit17 = ASYNC REJIT (read by ptl_renderer_create only; the "specialize_static" option may be switched on such a renderer: the pair
+ * of kernels is rebuilt synchronously, like at creation): see ptl_renderer_rejit_pending.
  * bit18 = QUICK JIT: compile at -O1 instead of the shipped -O3 without SLP: half the hiprtc time for a 5-20 % slower kernel, identical
  * frames -- for a build that is wanted now and used briefly (the CLI's render-frame; the kernel a clip starts on).  Implies bit15;
  * ignored together with bit3 (a clip-constant build is asked for because many frames follow).
@@ -233,6 +234,14 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * ptl_renderer_create additionally reads bits 8-11 as an occupancy hint n (0 = none):
  * the kernel is built with __launch_bounds__(256, n), i.e. at least n waves per SIMD. */
 int ptl_scene_generate_source(ptl_scene* s, unsigned flags, char** source);
+/* The preprocessor defines that belong to the source generated last (ptl_scene_generate_source / ptl_renderer_*), space separated: what
+ * ptl_kernel_compile has to be given with it ("PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS" -- absent when a matrix of the scene is infinite or
+ * NaN: shortened products are exact for finite vectors only, so such a scene keeps every full chain -- "PTL_COUNT_SEGMENTS" ...). */
+int ptl_scene_generated_defines(ptl_scene* s, char* out, size_t cap);
+/* Diagnostics: how often a generation with zero patterns (bit0 / bit2 / bit3 without bit19) probed the scene for them (copies of the scene
+ * stepped through the clip) and how often it reused the last result because the state the patterns depend on had not changed -- a renderer
+ * with baked Bool / Int uniforms regenerates on every camera move. */
+int ptl_scene_zero_mask_probes(ptl_scene* s, int* reused, int* probed);
 /* Scene::uniforms + layout: descs are owned by the scene handle and stay valid until the next
  * call of this function or ptl_scene_free. */
 int ptl_scene_uniform_layout(ptl_scene* s, const ptl_uniform_desc** descs, int* n, size_t* block_size);
@@ -252,11 +261,21 @@ void ptl_free(void* p);
  * ptl_renderer_uniform_* queries work. */
 int ptl_renderer_create(ptl_scene* s, int device, const char* asset_root, unsigned flags, ptl_renderer** out, char* log,
                         size_t log_cap);
+/* The same with renderer options (ptl_renderer_set_option names, "specialize_static" excluded) applied BEFORE the first build: a
+ * specialised renderer (flags bit0 / bit2 / bit3) compiles its mode switches in, so a caller that draws side by side, with Panini, a
+ * 360 camera ... gets the kernel it will draw with from the start -- and a compile-only handle (device = -1) warms the code-object cache
+ * with exactly that kernel (`portal-amd render --stereoimage` prefetches its clips' kernels this way).  An unknown name is
+ * PTL_ERR_INVALID. */
+int ptl_renderer_create_with_options(ptl_scene* s, int device, const char* asset_root, unsigned flags, const char* const* option_names,
+                                     const double* option_values, int n_options, ptl_renderer** out, char* log, size_t log_cap);
 /* CLI / GUI knobs of SceneRenderer, by the reference's field names: "render_depth", "aa_count",
  * "aa_start", "view_angle", "use_panini_projection", "panini_param", "use_360_camera",
  * "use_180_camera", "darken_by_distance", "gray_t_start", "gray_t_size", "draw_depth_map",
  * "depth_map_min", "depth_map_max", "angle_color_disable", "grid_disable",
  * "black_border_disable", "offset_after_material", "draw_side_by_side". */
+/* The translation unit the renderer's current kernel was compiled from (malloc'ed, free with ptl_free): ptl_scene_generate_source's text
+ * with the renderer's own mode switches compiled in where it is a specialised build -- what tools/isa_hist.py attributes instructions to. */
+int ptl_renderer_kernel_source(ptl_renderer* r, char** source);
 int ptl_renderer_set_option(ptl_renderer* r, const char* name, double value);
 /* Camera (RotateAroundCam): look_at xyz, alpha, beta, r. */
 int ptl_renderer_set_camera(ptl_renderer* r, const double look_at[3], double alpha, double beta, double radius);

@@ -119,8 +119,8 @@ def host_kernel_for(renderer, scene, width: int, height: int, flags: int = 0, co
 
     source = scene.generate_source(flags)
     layout, size = scene.uniform_layout()
-    defines = (("PTL_ANAGLYPH",) if flags & 16 else ()) + (("PTL_FIRST_TRIP",) if "_first(Ray r) {" in source else ()) + \
-        (("PTL_CONTRACT_V1",) if flags & 16384 else ()) + (("PTL_DROP_ZERO_TERMS",) if (flags & (4 | 8)) and not (flags & (16384 | 64)) else ())  # (what the generator asks the JIT for)
+    # (what the generator asks the JIT for with this source; PTL_COUNT_SEGMENTS comes through `count_segments`, the occupancy hint is the renderer's)
+    defines = tuple(d for d in scene.generated_defines() if d != "PTL_COUNT_SEGMENTS" and not d.startswith("PTL_WAVES_PER_EU") and d != "PTL_QUICK_JIT")
     hk = HostKernel(source, layout, size, count_segments, defines=defines)
     for name, typ, _ in layout:
         if typ == pa.PTL_SAMPLER:

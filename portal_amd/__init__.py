@@ -133,12 +133,16 @@ def _load() -> C.CDLL:
         "ptl_scene_cam": (ci, [vp, P(cd)]),
         "ptl_scene_texture": (ci, [vp, ci, cp, cs, cp, cs]),
         "ptl_scene_generate_source": (ci, [vp, C.c_uint, P(vp)]),
+        "ptl_scene_generated_defines": (ci, [vp, cp, cs]),
+        "ptl_scene_zero_mask_probes": (ci, [vp, P(ci), P(ci)]),
         "ptl_scene_uniform_layout": (ci, [vp, P(P(UniformDesc)), P(ci), P(cs)]),
         "ptl_scene_set_uniforms": (ci, [vp, vp]),
         "ptl_scene_visit_uniforms": (ci, [vp, vp, vp]),
         "ptl_scene_source_line_owner": (ci, [vp, ci, cp, cs, cp, cs, P(ci)]),
         "ptl_free": (None, [vp]),
         "ptl_renderer_create": (ci, [vp, ci, cp, C.c_uint, P(vp), cp, cs]),
+        "ptl_renderer_kernel_source": (ci, [vp, P(vp)]),
+        "ptl_renderer_create_with_options": (ci, [vp, ci, cp, C.c_uint, P(cp), P(cd), ci, P(vp), cp, cs]),
         "ptl_renderer_set_option": (ci, [vp, cp, cd]),
         "ptl_renderer_set_camera": (ci, [vp, P(cd), cd, cd, cd]),
         "ptl_renderer_use_camera": (ci, [vp, cp]),
@@ -375,6 +379,18 @@ class Scene:
         finally:
             lib().ptl_free(p)
 
+    def zero_mask_probes(self):
+        """(reused, probed): generations that reused the last zero patterns / that probed the scene for them."""
+        a, b = C.c_int(), C.c_int()
+        _check(lib().ptl_scene_zero_mask_probes(self._h, C.byref(a), C.byref(b)), "zero_mask_probes")
+        return a.value, b.value
+
+    def generated_defines(self):
+        """The preprocessor defines that go with the source generated last (``generate_source`` / a renderer's build)."""
+        buf = C.create_string_buffer(4096)
+        _check(lib().ptl_scene_generated_defines(self._h, buf, len(buf)), "generated_defines")
+        return tuple(buf.value.decode().split())
+
     def uniform_layout(self):
         """[(name, type, offset)], block_size -- Scene::uniforms plus the block layout."""
         descs, n, size = C.POINTER(UniformDesc)(), C.c_int(), C.c_size_t()
@@ -413,12 +429,19 @@ class SceneRenderer:
     queries); drawing then raises.
     """
 
-    def __init__(self, scene: Scene, device: int = 0, asset_root: Optional[str] = None, flags: int = 0):
+    def __init__(self, scene: Scene, device: int = 0, asset_root: Optional[str] = None, flags: int = 0, options: Optional[dict] = None):
+        """``options``: renderer options (``set_option`` names) applied before the first build -- a specialised renderer compiles its
+        mode switches in, so e.g. ``options={"draw_side_by_side": 1}`` gets the side-by-side kernel from the start."""
         self.scene = scene
         h = C.c_void_p()
         log = C.create_string_buffer(1 << 16)
         root = (asset_root if asset_root is not None else REPO_ROOT).encode()
-        rc = lib().ptl_renderer_create(scene._h, device, root, flags, C.byref(h), log, len(log))
+        if options:
+            names = (C.c_char_p * len(options))(*[k.encode() for k in options])
+            values = (C.c_double * len(options))(*[float(v) for v in options.values()])
+            rc = lib().ptl_renderer_create_with_options(scene._h, device, root, flags, names, values, len(options), C.byref(h), log, len(log))
+        else:
+            rc = lib().ptl_renderer_create(scene._h, device, root, flags, C.byref(h), log, len(log))
         self.compile_log = log.value.decode("utf-8", "replace")
         if rc != 0:
             raise PortalError(f"SceneRenderer::new failed ({rc}): {_err()}\n{self.compile_log}")
@@ -432,6 +455,15 @@ class SceneRenderer:
                 self._h = None
         except Exception:
             pass
+
+    def kernel_source(self) -> str:
+        """The translation unit the current kernel was compiled from (mode switches compiled in where the build is specialised)."""
+        p = C.c_void_p()
+        _check(lib().ptl_renderer_kernel_source(self._h, C.byref(p)), "kernel_source")
+        try:
+            return C.string_at(p).decode("utf-8")
+        finally:
+            lib().ptl_free(p)
 
     def set_option(self, name: str, value: float) -> None:
         rc = lib().ptl_renderer_set_option(self._h, name.encode(), float(value))

@@ -90,6 +90,7 @@ struct ptl_scene {
     GeneratedKernel last;  // most recent generate_kernel_source() result
     std::vector<ptl_uniform_desc> descs;
     std::vector<std::string> desc_names;
+    ZeroMaskCache mask_cache;  // zero patterns of the run-time matrices as probed last, and the scene state they belong to (codegen.h)
 };
 
 struct ptl_renderer {
@@ -120,6 +121,8 @@ struct ptl_renderer {
     std::map<std::string, int> kernel_switches;  // the mode switches the current specialised kernel has compiled in (KernelOptions::baked_options)
     std::vector<std::pair<std::string, unsigned>> masked;  // run-time matrices whose zero pattern the current kernel has compiled in (GeneratedKernel::masked)
     std::set<std::string> keep_unmasked;                   // ... and those whose pattern did not hold (clip-constant builds: demoted like keep_dynamic)
+    bool shortened = false;    // the current kernel skips zero terms of matrix products (PTL_DROP_ZERO_TERMS and / or masks): exact for finite vectors
+    bool full_chains = false;  // a run-time matrix turned non-finite under such a kernel: every later build of this stage keeps the full chains
     // SceneRenderer::update state (src/main.rs:1430-1538)
     Camera prev_cam;
     bool has_prev_cam = false;
@@ -449,8 +452,10 @@ static std::map<std::string, int> mode_switches(const ptl_renderer& r) {
 }
 
 static void refresh_generated(ptl_scene* s, unsigned flags, const std::set<std::string>* keep_dynamic = nullptr, const std::map<std::string, int>* switches = nullptr,
-                              const std::set<std::string>* keep_unmasked = nullptr) {
+                              const std::set<std::string>* keep_unmasked = nullptr, bool full_chains = false) {
     KernelOptions opts = options_from_flags(flags);
+    opts.full_chains = full_chains;
+    opts.mask_cache = &s->mask_cache;
     if (keep_dynamic) opts.keep_dynamic = *keep_dynamic;
     if (keep_unmasked) opts.keep_unmasked = *keep_unmasked;
     if (switches && (flags & 13u) != 0) opts.baked_options = *switches;
@@ -472,6 +477,20 @@ extern "C" int ptl_scene_generate_source(ptl_scene* s, unsigned flags, char** so
         std::memcpy(*source, s->last.source.c_str(), s->last.source.size() + 1);
         return PTL_OK;
     });
+}
+extern "C" int ptl_scene_zero_mask_probes(ptl_scene* s, int* reused, int* probed) {
+    if (!s) return PTL_ERR_INVALID;
+    if (reused) *reused = s->mask_cache.hits;
+    if (probed) *probed = s->mask_cache.misses;
+    return PTL_OK;
+}
+extern "C" int ptl_scene_generated_defines(ptl_scene* s, char* out, size_t cap) {
+    if (!s || !out || cap == 0) return PTL_ERR_INVALID;
+    std::string joined;
+    for (const std::string& d : s->last.defines) joined += (joined.empty() ? "" : " ") + d;
+    if (joined.size() + 1 > cap) return PTL_ERR_INVALID;
+    std::memcpy(out, joined.c_str(), joined.size() + 1);
+    return PTL_OK;
 }
 extern "C" int ptl_scene_uniform_layout(ptl_scene* s, const ptl_uniform_desc** descs, int* n, size_t* block_size) {
     if (!s) return PTL_ERR_INVALID;
@@ -642,10 +661,12 @@ static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     ptl_scene* s = r->owner;
     if (!(r->kernel_stage == r->scene->current_stage)) r->keep_dynamic.clear();  // another stage / clip: judge afresh what is constant
     if (!(r->kernel_stage == r->scene->current_stage)) r->keep_unmasked.clear();
+    if (!(r->kernel_stage == r->scene->current_stage)) r->full_chains = false;
     r->kernel_switches = mode_switches(*r);
-    refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches, &r->keep_unmasked);
+    refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches, &r->keep_unmasked, r->full_chains);
     r->baked = s->last.baked;
     r->masked = s->last.masked;
+    r->shortened = !s->last.full_chains && (s->last.masked.size() > 0 || std::find(s->last.defines.begin(), s->last.defines.end(), "PTL_DROP_ZERO_TERMS") != s->last.defines.end());
     r->kernel_stage = r->scene->current_stage;
     if (r->kernel && s->last.source == r->kernel_source) {  // nothing baked in changed
         r->kernel_scene_version = r->scene->version;
@@ -687,9 +708,37 @@ static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     return update_videos(r);
 }
 
-extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_root, unsigned flags, ptl_renderer** out, char* log,
-                                   size_t log_cap) {
-    if (!s || !out) return PTL_ERR_INVALID;
+// Background re-JIT bookkeeping around a synchronous build_kernel() (renderer creation; a switch of the specialisation bits):
+// `kernel` aliases `spec_kernel` or `dyn_kernel` in that mode, so the pair is dropped as a whole before the rebuild (the worker joined
+// first) and the freshly built specialised kernel seeds it again afterwards.
+static void drop_async_kernels(ptl_renderer* r) {
+    if (r->job) {
+        if (r->job->worker.joinable()) r->job->worker.join();
+        r->job.reset();
+    }
+    if (r->spec_kernel || r->dyn_kernel) {
+        ptl_kernel_destroy(r->spec_kernel);
+        ptl_kernel_destroy(r->dyn_kernel);
+        r->spec_kernel = r->dyn_kernel = r->kernel = nullptr;
+        r->kernel_source.clear();
+    }
+    r->spec_source.clear();
+    r->failed_source.clear();
+    r->want = ptl_renderer::Build{};
+}
+static void seed_async_kernels(ptl_renderer* r) {
+    if ((r->flags & kAsyncRejit) != 0 && (r->flags & 13u) != 0 && r->device >= 0) {  // the first kernel is the specialised one of this state
+        r->spec_kernel = r->kernel;
+        r->spec_source = r->kernel_source;
+        r->want = snapshot_build(r->owner, r->flags);
+    }
+}
+
+static int set_plain_option(ptl_renderer* r, const std::string& n, double v);
+
+extern "C" int ptl_renderer_create_with_options(ptl_scene* s, int device, const char* asset_root, unsigned flags, const char* const* option_names,
+                                                const double* option_values, int n_options, ptl_renderer** out, char* log, size_t log_cap) {
+    if (!s || !out || n_options < 0 || (n_options > 0 && (!option_names || !option_values))) return PTL_ERR_INVALID;
     if (log && log_cap) log[0] = '\0';
     return guarded([&] {
         auto r = std::make_unique<ptl_renderer>();
@@ -698,13 +747,19 @@ extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_r
         r->device = device;
         r->flags = flags;
         r->asset_root = asset_root ? asset_root : "";
+        // options first: a specialised build compiles the mode switches in (mode_switches), so the FIRST build is already the one the
+        // caller will draw with (`render --stereoimage`: draw_side_by_side) instead of a build nothing runs on plus a rebuild
+        for (int k = 0; k < n_options; ++k) {
+            if (!option_names[k]) return (int)PTL_ERR_INVALID;
+            int orc = set_plain_option(r.get(), option_names[k], option_values[k]);
+            if (orc != PTL_OK) {
+                set_last_error(std::string("ptl_renderer_create_with_options: unknown option `") + option_names[k] + "`");
+                return (int)PTL_ERR_INVALID;
+            }
+        }
         int rc = build_kernel(r.get(), log, log_cap);
         if (rc != PTL_OK) return rc;
-        if ((flags & kAsyncRejit) != 0 && (flags & 13u) != 0 && device >= 0) {  // background re-JIT: the first kernel is the specialised one of this state
-            r->spec_kernel = r->kernel;
-            r->spec_source = r->kernel_source;
-            r->want = snapshot_build(s, flags);
-        }
+        seed_async_kernels(r.get());
         // cam.set_cam(scene.cam); offset_after_material from the scene (main.rs:1057-1059)
         const CamSettings& c = s->scene->cam;
         r->cam.look_at = c.look_at;
@@ -718,10 +773,13 @@ extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_r
         return PTL_OK;
     });
 }
+extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_root, unsigned flags, ptl_renderer** out, char* log,
+                                   size_t log_cap) {
+    return ptl_renderer_create_with_options(s, device, asset_root, flags, nullptr, nullptr, 0, out, log, log_cap);
+}
 
-extern "C" int ptl_renderer_set_option(ptl_renderer* r, const char* name, double v) {
-    if (!r || !name) return PTL_ERR_INVALID;
-    std::string n = name;
+// every option that is a plain field (no rebuild): PTL_OK, or PTL_UNKNOWN_UNIFORM for a name that is not one
+static int set_plain_option(ptl_renderer* r, const std::string& n, double v) {
     bool b = v > 0.5;
     if (n == "render_depth") r->render_depth = (int)v;
     else if (n == "aa_count") r->aa_count = (int)v;
@@ -743,15 +801,7 @@ extern "C" int ptl_renderer_set_option(ptl_renderer* r, const char* name, double
     else if (n == "offset_after_material") r->offset_after_material = v;
     else if (n == "draw_side_by_side") r->draw_side_by_side = b;
     else if (n == "in_subspace") r->cam.in_subspace = b;
-    else if (n == "specialize_static") {  // switch clip-constant specialisation (flags bit3) on or off for what follows
-        unsigned want = b ? (r->flags | 8u) : (r->flags & ~8u);
-        if (want != r->flags) {
-            r->flags = want;
-            r->keep_dynamic.clear();
-            int rc = build_kernel(r, nullptr, 0);
-            if (rc != PTL_OK) return rc;
-        }
-    } else if (n == "draw_anaglyph") r->draw_anaglyph = b;
+    else if (n == "draw_anaglyph") r->draw_anaglyph = b;
     else if (n == "anaglyph_mode") r->anaglyph_mode = b;
     else if (n == "anaglyph_p") r->anaglyph_p = v;
     else if (n == "anaglyph_q") r->anaglyph_q = v;
@@ -762,6 +812,29 @@ extern "C" int ptl_renderer_set_option(ptl_renderer* r, const char* name, double
     else return PTL_UNKNOWN_UNIFORM;
     ++r->options_version;
     return PTL_OK;
+}
+
+extern "C" int ptl_renderer_set_option(ptl_renderer* r, const char* name, double v) {
+    if (!r || !name) return PTL_ERR_INVALID;
+    std::string n = name;
+    if (n == "specialize_static") {  // switch clip-constant specialisation (flags bit3) on or off for what follows
+        unsigned want = v > 0.5 ? (r->flags | 8u) : (r->flags & ~8u);
+        if (want == r->flags) return PTL_OK;
+        return guarded([&] {
+            // With PTL_FLAG_ASYNC_REJIT `kernel` is one of spec_kernel / dyn_kernel and a worker may be compiling for the old flags: the
+            // pair is dropped as a whole (build_kernel would free only the alias), rebuilt synchronously like at creation, and re-seeded.
+            const bool async = (r->flags & kAsyncRejit) != 0 && r->device >= 0;
+            if (async) drop_async_kernels(r);
+            r->flags = want;
+            r->keep_dynamic.clear();
+            int rc = build_kernel(r, nullptr, 0);
+            if (rc != PTL_OK) return rc;
+            if (async) seed_async_kernels(r);
+            ++r->options_version;
+            return (int)PTL_OK;
+        });
+    }
+    return set_plain_option(r, n, v);
 }
 
 extern "C" int ptl_renderer_set_camera(ptl_renderer* r, const double look_at[3], double alpha, double beta, double radius) {
@@ -836,6 +909,11 @@ extern "C" int ptl_renderer_uniform_value(ptl_renderer* r, int width, int height
 // the pattern says zero is demoted (keep_unmasked) and reported.
 static bool zero_patterns_broken(ptl_renderer* r, const std::vector<UniformUpload>& values) {
     bool broken = false;
+    // a kernel with shortened products is exact for finite vectors: a matrix that got infinite elements, or NaN beside numbers, since the kernel was generated
+    // (the generator checks the values it sees, codegen.cpp `full_chains`) asks for the full chains from here on
+    if (r->shortened && !r->full_chains)
+        for (const UniformUpload& v : values)
+            if (v.type == UniformType::Mat4 && matrix_breaks_short_chains(v.f)) r->full_chains = broken = true;
     for (auto& [name, mask] : r->masked)
         for (const UniformUpload& v : values) {
             if (v.name != name || v.type != UniformType::Mat4) continue;
@@ -872,6 +950,7 @@ static int async_select_kernel(ptl_renderer* r) {
         if (!(r->kernel_stage == r->scene->current_stage)) {
             r->keep_dynamic.clear();
             r->keep_unmasked.clear();
+            r->full_chains = false;
         }
         if ((r->flags & 8u) != 0 && (r->flags & 5u) == 0) {  // clip-constant specialisation: a compiled-in value that moved becomes a run-time uniform
             std::vector<UniformUpload> values = evaluate_scene_uniforms(*r->scene, nullptr);
@@ -884,8 +963,9 @@ static int async_select_kernel(ptl_renderer* r) {
             zero_patterns_broken(r, values);
         }
         r->kernel_switches = mode_switches(*r);
-        refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches, &r->keep_unmasked);  // the specialised source of the CURRENT state (generation is milliseconds)
+        refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches, &r->keep_unmasked, r->full_chains);  // the specialised source of the CURRENT state (generation is milliseconds)
         r->masked = s->last.masked;
+        r->shortened = !s->last.full_chains && (s->last.masked.size() > 0 || std::find(s->last.defines.begin(), s->last.defines.end(), "PTL_DROP_ZERO_TERMS") != s->last.defines.end());
         r->want = snapshot_build(s, r->flags);
         r->kernel_scene_version = r->scene->version;
         r->kernel_stage = r->scene->current_stage;
@@ -1285,6 +1365,13 @@ extern "C" ptl_kernel* ptl_renderer_kernel(ptl_renderer* r) {
         if (rc != PTL_OK) return nullptr;  // ptl_last_error() says why; the old kernel has other switches compiled in
     }
     return r->kernel;
+}
+extern "C" int ptl_renderer_kernel_source(ptl_renderer* r, char** source) {
+    if (!r || !source) return PTL_ERR_INVALID;
+    *source = (char*)std::malloc(r->kernel_source.size() + 1);
+    if (!*source) return PTL_ERR_INVALID;
+    std::memcpy(*source, r->kernel_source.c_str(), r->kernel_source.size() + 1);
+    return PTL_OK;
 }
 extern "C" int ptl_renderer_rejit_count(ptl_renderer* r) { return r ? r->rejit_count : -1; }
 extern "C" int ptl_renderer_rejit_pending(ptl_renderer* r) {

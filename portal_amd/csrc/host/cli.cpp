@@ -684,7 +684,7 @@ int encode_video(const Options& o, const std::string& scene_name, const std::str
 // is taken through the same history (every clip initialised so far, with its overrides), then compiled for gfx950 without a
 // device.  When the main thread gets to that clip it generates the same source and finds the binary on disk; if the histories
 // ever disagree it just compiles as before.
-void prefetch_clip_kernel(std::string path, std::vector<std::string> history, std::string asset_root, unsigned extra_flags) {
+void prefetch_clip_kernel(std::string path, std::vector<std::string> history, std::string asset_root, unsigned extra_flags, bool stereo) {
     ptl_scene* scene = nullptr;
     if (ptl_scene_load_file(path.c_str(), &scene) != PTL_OK) return;
     for (const std::string& clip : history) {
@@ -694,8 +694,12 @@ void prefetch_clip_kernel(std::string path, std::vector<std::string> history, st
         }
         apply_clip_overrides(scene, nullptr, clip, nullptr);
     }
+    // (the mode switches are compiled into a specialised kernel: the compile-only renderer must have the ones the clip is drawn with)
+    const char* names[] = {"draw_side_by_side"};
+    const double values[] = {stereo ? 1.0 : 0.0};
     ptl_renderer* r = nullptr;
-    if (ptl_renderer_create(scene, -1, asset_root.c_str(), kRenderFlags | 8u | extra_flags, &r, nullptr, 0) == PTL_OK) ptl_renderer_destroy(r);
+    if (ptl_renderer_create_with_options(scene, -1, asset_root.c_str(), kRenderFlags | 8u | extra_flags, names, values, 1, &r, nullptr, 0) == PTL_OK)
+        ptl_renderer_destroy(r);
     ptl_scene_free(scene);
 }
 
@@ -770,7 +774,10 @@ int render(const Options& o) {
             apply_clip_overrides(scene, nullptr, todo[0].first, nullptr);
         }
         unsigned start_flags = kRenderFlags | (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u) | (o.opt3 ? 0u : 262144u) | (start_baked ? 8u : 0u);
-        if (ptl_renderer_create(scene, o.device, o.asset_root.c_str(), start_flags, &r, log.data(), log.size()) != PTL_OK) {  // --fast: tolerance mode for the whole clip
+        const char* create_names[] = {"aa_count", "render_depth", "draw_side_by_side"};  // before the first build: a baked kernel has its mode switches compiled in
+        const double create_values[] = {(double)o.aa, (double)o.depth, o.stereo ? 1.0 : 0.0};
+        if (ptl_renderer_create_with_options(scene, o.device, o.asset_root.c_str(), start_flags, create_names, create_values, 3, &r, log.data(), log.size()) !=
+            PTL_OK) {  // --fast: tolerance mode for the whole clip
             std::fprintf(stderr, "renderer: %s\n%s\n", ptl_last_error(), log.data());
             return 1;
         }
@@ -788,7 +795,7 @@ int render(const Options& o) {
             int n_workers = (int)std::min<size_t>({(size_t)6, todo.size() - 1, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)});
             pf.next = 1;  // the first clip is compiled by the main thread right away
             for (int wk = 0; wk < n_workers; ++wk)
-                pf.workers.emplace_back([&pf, &todo, &specialise, path, asset_root = o.asset_root, extra_flags = (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u)] {
+                pf.workers.emplace_back([&pf, &todo, &specialise, path, asset_root = o.asset_root, extra_flags = (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u), stereo = o.stereo] {
                     for (;;) {
                         size_t k;
                         {
@@ -799,7 +806,7 @@ int render(const Options& o) {
                         if (specialise[k]) {
                             std::vector<std::string> history;
                             for (size_t c = 0; c <= k; ++c) history.push_back(todo[c].first);
-                            prefetch_clip_kernel(path, history, asset_root, extra_flags);
+                            prefetch_clip_kernel(path, history, asset_root, extra_flags, stereo);
                         }
                         {
                             std::unique_lock<std::mutex> lock(pf.mu);

@@ -560,6 +560,15 @@ static void apply_zero_masks(std::string& src, const std::vector<std::pair<std::
     }
 }
 
+bool matrix_breaks_short_chains(const float m[16]) {
+    int nan = 0, inf = 0;
+    for (int k = 0; k < 16; ++k) {
+        nan += std::isnan(m[k]) ? 1 : 0;
+        inf += std::isinf(m[k]) ? 1 : 0;
+    }
+    return inf > 0 || (nan > 0 && nan < 16);
+}
+
 GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& flags, const KernelOptions& opts) {
     GeneratedKernel gk;
     std::map<std::string, StringStorage> storages;
@@ -611,7 +620,19 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 gk.baked.push_back(up);
             }
         }
-        if (opts.mask_zero_elements && !opts.exact_cr && !opts.fast_math) {
+        // Shortened products are exact for finite vectors (device/ptl_glsl.h, "the deviation, stated"): a skipped `0 * x` would have been NaN
+        // for an infinite or NaN x.  Where such vectors come from is known at generation time -- a matrix with non-finite elements (the
+        // inverse of a zero scale, 1/0 in a formula) -- so it is decided here, for the whole kernel:
+        //   * a matrix that is NaN in EVERY element (glam's inverse of a matrix scaled to zero on all axes: how the reference's scenes switch
+        //     an object off, scenes/portal_in_portal.ron `c0`) turns every vector into all-NaN, and NaN times a retained non-zero element is
+        //     NaN in the short chain as in the full one: allowed;
+        //   * any other non-finite matrix (infinities, or NaN beside numbers) produces +-inf components, for which the two chains do differ
+        //     (inf * 1 against inf * 1 + 0 * inf = NaN): the kernel keeps every full chain (GeneratedKernel::full_chains).
+        gk.full_chains = opts.full_chains;
+        if (!gk.full_chains && (opts.mask_zero_elements || opts.specialize_all || opts.specialize_static))
+            for (auto& up : evaluate_scene_uniforms(scene, nullptr))
+                if (up.type == UniformType::Mat4 && matrix_breaks_short_chains(up.f)) gk.full_chains = true;
+        if (opts.mask_zero_elements && !opts.exact_cr && !opts.fast_math && !gk.full_chains) {
             auto nonzero_bits = [](const UniformUpload& up) {
                 unsigned mask = 0;
                 for (int k = 0; k < 16; ++k)
@@ -620,54 +641,92 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             };
             std::vector<std::pair<std::string, unsigned>> found;
             bool any_animated = false;
-            for (auto& up : evaluate_scene_uniforms(scene, nullptr)) {
-                if (up.type != UniformType::Mat4 || baked.count(up.name) || opts.keep_unmasked.count(up.name)) continue;
-                found.emplace_back(up.name, nonzero_bits(up));
-                any_animated = any_animated || up.animated;
+            const std::vector<UniformUpload> current = evaluate_scene_uniforms(scene, nullptr);
+            // the state the patterns depend on: stage / clip, every value that is not animated (the probes move the animated ones themselves)
+            std::string key;
+            if (opts.mask_cache) {
+                auto put = [&key](const void* p, size_t n) { key.append(static_cast<const char*>(p), n); };
+                const int stage[3] = {(int)scene.current_stage.kind, scene.current_stage.index, scene.run_animations ? 1 : 0};
+                put(stage, sizeof stage);
+                for (auto& up : current) {
+                    key += up.name;
+                    key += up.animated ? '~' : '=';
+                    if (!up.animated) {
+                        put(up.f, sizeof up.f);
+                        put(&up.i, sizeof up.i);
+                    }
+                    key += baked.count(up.name) ? 'b' : (opts.keep_unmasked.count(up.name) ? 'k' : 'r');
+                }
             }
-            // A matrix that reads the formulas' `time` is identity-like exactly when a clip starts -- the moment a clip-constant kernel is
-            // generated.  Its pattern is therefore taken over the whole clip: the union over probes of `time` in [0, 1] (a copy of the scene;
-            // the pattern of an animation changes at its end points or nowhere, a probe that misses something costs one rebuild, not a pixel).
-            if (any_animated) {
-                auto take = [&](const Scene& probe) {
-                    for (auto& up : evaluate_scene_uniforms(probe, nullptr))
-                        if (up.type == UniformType::Mat4 && up.animated)
-                            for (auto& f : found)
-                                if (f.first == up.name) f.second |= nonzero_bits(up);
-                };
-                Scene probe = scene;
-                const bool in_clip = !scene.run_animations && scene.current_stage.kind == StageRef::RealAnimation && scene.current_stage.index >= 0 &&
-                                     scene.current_stage.index < (int)scene.animations.size() && scene.animations[scene.current_stage.index].duration > 0.0;
-                if (in_clip) {
-                    // inside a clip: the video pipeline's own step (Scene::update) at 33 moments of the clip.  On the reference's corpus (471 clips,
-                    // patterns taken on a 240-point grid) 7 probes miss something in 16 clips, 16 in 10, 32 in none: elements like cos(pi/2)
-                    // flicker between 0 and 1e-17, and every miss is a rebuild in the middle of a clip
-                    const double duration = scene.animations[scene.current_stage.index].duration;
-                    try {
-                        for (int k = 0; k <= 32; ++k) {
-                            probe.update(duration * (k < 32 ? k / 32.0 : 0.999999));
-                            take(probe);
-                        }
-                    } catch (const std::exception&) {  // a clip whose cameras cannot be evaluated fails where it is played, not here: no pattern for what moves
-                        for (auto& up : evaluate_scene_uniforms(scene, nullptr))
+            // (a hit must still cover what the animated matrices hold NOW: their values are not part of the key, and a build with baked Bool /
+            // Int uniforms has nothing but this generation between a moved value and the draw)
+            bool hit = opts.mask_cache && !key.empty() && key == opts.mask_cache->key;
+            if (hit)
+                for (auto& up : current) {
+                    if (up.type != UniformType::Mat4 || !up.animated || baked.count(up.name) || opts.keep_unmasked.count(up.name)) continue;
+                    unsigned mask = 0xffffu;
+                    for (auto& m : opts.mask_cache->masked)
+                        if (m.first == up.name) mask = m.second;
+                    if (nonzero_bits(up) & ~mask) hit = false;
+                }
+            if (hit) {
+                ++opts.mask_cache->hits;
+                gk.masked = opts.mask_cache->masked;
+            } else {
+                for (auto& up : current) {
+                    if (up.type != UniformType::Mat4 || baked.count(up.name) || opts.keep_unmasked.count(up.name)) continue;
+                    found.emplace_back(up.name, nonzero_bits(up));
+                    any_animated = any_animated || up.animated;
+                }
+                // A matrix that reads the formulas' `time` is identity-like exactly when a clip starts -- the moment a clip-constant kernel is
+                // generated.  Its pattern is therefore taken over the whole clip: the union over probes of `time` in [0, 1] (a copy of the scene;
+                // the pattern of an animation changes at its end points or nowhere, a probe that misses something costs one rebuild, not a pixel).
+                if (any_animated) {
+                    auto take = [&](const Scene& probe) {
+                        for (auto& up : evaluate_scene_uniforms(probe, nullptr))
                             if (up.type == UniformType::Mat4 && up.animated)
                                 for (auto& f : found)
-                                    if (f.first == up.name) f.second = 0xffffu;
+                                    if (f.first == up.name) f.second |= nonzero_bits(up);
+                    };
+                    Scene probe = scene;
+                    const bool in_clip = !scene.run_animations && scene.current_stage.kind == StageRef::RealAnimation && scene.current_stage.index >= 0 &&
+                                         scene.current_stage.index < (int)scene.animations.size() && scene.animations[scene.current_stage.index].duration > 0.0;
+                    if (in_clip) {
+                        // inside a clip: the video pipeline's own step (Scene::update) at 33 moments of the clip.  On the reference's corpus (471 clips,
+                        // patterns taken on a 240-point grid) 7 probes miss something in 16 clips, 16 in 10, 32 in none: elements like cos(pi/2)
+                        // flicker between 0 and 1e-17, and every miss is a rebuild in the middle of a clip
+                        const double duration = scene.animations[scene.current_stage.index].duration;
+                        try {
+                            for (int k = 0; k <= 32; ++k) {
+                                probe.update(duration * (k < 32 ? k / 32.0 : 0.999999));
+                                take(probe);
+                            }
+                        } catch (const std::exception&) {  // a clip whose cameras cannot be evaluated fails where it is played, not here: no pattern for what moves
+                            for (auto& up : evaluate_scene_uniforms(scene, nullptr))
+                                if (up.type == UniformType::Mat4 && up.animated)
+                                    for (auto& f : found)
+                                        if (f.first == up.name) f.second = 0xffffu;
+                        }
+                    } else {
+                        for (double t : {0.0, 0.0625, 0.271, 0.5, 0.729, 0.9375, 1.0}) {
+                            probe.time = t;
+                            take(probe);
+                        }
                     }
-                } else {
-                    for (double t : {0.0, 0.0625, 0.271, 0.5, 0.729, 0.9375, 1.0}) {
-                        probe.time = t;
-                        take(probe);
-                    }
+                    // The other per-frame input is the camera (Matrix::Camera): one probe gives it a matrix without a single zero, so that
+                    // nothing that follows the camera is ever masked (a renderer is even created before its camera is known).
+                    probe = scene;
+                    probe.camera_matrix = DMat4::from_cols(DVec4(0.36, 0.48, -0.8, 0.013), DVec4(-0.8, 0.6, 0.017, 0.011), DVec4(0.48, 0.64, 0.6, 0.019), DVec4(0.37, -1.21, 2.53, 1.0));
+                    take(probe);
                 }
-                // The other per-frame input is the camera (Matrix::Camera): one probe gives it a matrix without a single zero, so that
-                // nothing that follows the camera is ever masked (a renderer is even created before its camera is known).
-                probe = scene;
-                probe.camera_matrix = DMat4::from_cols(DVec4(0.36, 0.48, -0.8, 0.013), DVec4(-0.8, 0.6, 0.017, 0.011), DVec4(0.48, 0.64, 0.6, 0.019), DVec4(0.37, -1.21, 2.53, 1.0));
-                take(probe);
+                for (auto& f : found)
+                    if (f.second != 0xffffu) gk.masked.push_back(f);
+                if (opts.mask_cache) {
+                    ++opts.mask_cache->misses;
+                    opts.mask_cache->key = key;
+                    opts.mask_cache->masked = gk.masked;
+                }
             }
-            for (auto& f : found)
-                if (f.second != 0xffffu) gk.masked.push_back(f);
         }
         if (opts.specialize_ints || opts.specialize_all || opts.specialize_static)
             for (auto& [name, value] : opts.baked_options)
@@ -1077,7 +1136,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     if (opts.exact_cr) gk.defines.push_back("PTL_CONTRACT_V1");
     if (opts.quick_jit) gk.defines.push_back("PTL_QUICK_JIT");
     // matrices baked into the source: a matrix product skips the terms whose matrix element is zero (device/ptl_glsl.h `ptl_mterm`)
-    if ((opts.specialize_all || opts.specialize_static) && !opts.exact_cr && !opts.fast_math) gk.defines.push_back("PTL_DROP_ZERO_TERMS");
+    if ((opts.specialize_all || opts.specialize_static) && !opts.exact_cr && !opts.fast_math && !gk.full_chains) gk.defines.push_back("PTL_DROP_ZERO_TERMS");
     if (gk.first_trip_variants) gk.defines.push_back("PTL_FIRST_TRIP");
     return gk;
 }

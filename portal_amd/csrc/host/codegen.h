@@ -71,6 +71,15 @@ struct UniformUpload {
     bool same_value(const UniformUpload& o) const;
 };
 
+// What the zero-pattern probing of generate_kernel_source found last time, and for which scene state (KernelOptions::mask_cache): a renderer
+// with baked Bool / Int uniforms regenerates its source on every scene-version bump -- every camera move -- and the probing (two scene
+// copies, up to 33 Scene::update + 34 evaluations) is by far the most expensive part of a generation that nearly always ends in "unchanged".
+struct ZeroMaskCache {
+    std::string key;  // stage, clip, and every uniform's name with its value (animated ones: the name only -- their patterns come from the probes)
+    std::vector<std::pair<std::string, unsigned>> masked;
+    int hits = 0, misses = 0;
+};
+
 struct KernelOptions {
     bool specialize_ints = false;  // bake current Bool/Int uniform values in as literals (recompile when they change)
     bool specialize_all = false;   // also bake Float / matrix scene uniforms (not the camera / builtins)
@@ -91,6 +100,11 @@ struct KernelOptions {
     // (non-finite vector components); the renderer rebuilds when a masked element stops being zero.  Off for contract 1 and the tolerance mode.
     bool mask_zero_elements = false;
     std::set<std::string> keep_unmasked;  // ... except these (a pattern that did not hold: demoted by the renderer)
+    ZeroMaskCache* mask_cache = nullptr;  // optional: reuse the probed patterns while the scene state they depend on is the same
+    // Shortened products (ptl_mterm / masks) equal the full chains for every FINITE vector.  A scene with a matrix that holds infinities, or
+    // NaN beside numbers (matrix_breaks_short_chains), sends +-inf components down its rays, so the generator keeps every full chain for it
+    // (GeneratedKernel::full_chains: no PTL_DROP_ZERO_TERMS, no masks); the renderer sets this when a run-time matrix turns so later.
+    bool full_chains = false;
     // Ray-independent work of the generated plane code (normalize(get_normal(X_mat)), both possible is_collinear verdicts) is
     // evaluated once per uniform upload by the module's prologue kernel `ptl_derive_kernel` and read back as extra uniforms,
     // instead of once per bounce-loop trip by every lane.  Same functions, same binary32 operations: identical frames.
@@ -132,6 +146,7 @@ struct GeneratedKernel {
     int hoisted_members = 0;            // ... plus this many members holding uniform-only work of the scene snippets (glsl_hoist.h)
     std::vector<DerivedPlane> derived;  // members appended to the block behind uniform_block_size, written on the device
     std::vector<std::pair<std::string, unsigned>> masked;  // run-time matrices whose zero pattern is compiled in: bit 4 * column + row set = may be non-zero
+    bool full_chains = false;           // a matrix of the scene is not finite (or KernelOptions::full_chains): no product was shortened
 };
 
 // Scene::uniforms (scene.rs:424-543): names and types, in the reference's order.
@@ -140,6 +155,9 @@ std::vector<UniformDesc> scene_uniform_list(const Scene& scene);
 std::vector<std::string> scene_texture_list(const Scene& scene);
 
 GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& flags, const KernelOptions& opts);
+// A matrix with infinite elements, or with NaN beside numbers: its products carry +-inf components, for which a product that skips zero
+// terms differs from the full chain (KernelOptions::full_chains).  An all-NaN matrix does not (all-NaN vectors stay NaN either way).
+bool matrix_breaks_short_chains(const float m[16]);
 
 // All scene-derived uniforms: X_mat, X_mat_inv, A_to_B_mat_teleport, user uniforms.
 // `errors` receives the reference's "matrix `x` can't be getted" style messages.

@@ -53,9 +53,27 @@ std::vector<Token> tokenize_glsl(const std::string& s) {
             i = j;
             continue;
         }
-        if (c == '#' && line_start) {  // preprocessor directive: keep the line verbatim
+        if (c == '#' && line_start) {  // preprocessor directive: keep the line verbatim ...
             size_t j = s.find('\n', i);
             if (j == std::string::npos) j = n;
+            // ... except the replacement text of a `#define`, which is GLSL like any other: its float literals need their suffix and its
+            // divisions are the contract's (rewrite_divisions), e.g. the reference's own `#define PI2 (acos(-1.) / 2.0)`.  The head
+            // (`#define NAME` or `#define NAME(params)`) stays one verbatim token, the rest of the line is tokenised as code.
+            size_t h = i + 1;
+            while (h < j && (s[h] == ' ' || s[h] == '\t')) ++h;
+            if (s.compare(h, 6, "define") == 0 && h + 6 < j && (s[h + 6] == ' ' || s[h + 6] == '\t') && s.find('\\', i) >= j) {
+                h += 6;
+                while (h < j && (s[h] == ' ' || s[h] == '\t')) ++h;
+                while (h < j && (std::isalnum((unsigned char)s[h]) || s[h] == '_')) ++h;
+                if (h < j && s[h] == '(') {  // function-like: the parameter list belongs to the head
+                    size_t close = s.find(')', h);
+                    h = (close == std::string::npos || close >= j) ? j : close + 1;
+                }
+                out.push_back({Token::Preproc, s.substr(i, h - i)});
+                i = h;
+                line_start = false;
+                continue;
+            }
             out.push_back({Token::Preproc, s.substr(i, j - i)});
             i = j;
             continue;

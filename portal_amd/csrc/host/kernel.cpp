@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <fstream>
 #include <iterator>
 #include <memory>
@@ -278,7 +279,10 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
         rc->hiprtcDestroyProgram(&prog);
         if (!cache_path.empty()) {
             ::mkdir(cdir.c_str(), 0755);
-            std::string tmp = cache_path + ".tmp" + std::to_string((long)getpid());
+            // one temp file per COMPILE, not per process: background re-JIT workers and the ranks of a frame group compile the same source on
+            // several threads of one process, and a shared temp path would let one of them rename a file another is still writing
+            static std::atomic<unsigned long> compile_serial{0};
+            std::string tmp = cache_path + ".tmp" + std::to_string((long)getpid()) + "." + std::to_string(compile_serial.fetch_add(1));
             std::ofstream f(tmp, std::ios::binary);
             f.write(k->code.data(), (std::streamsize)k->code.size());
             f.close();

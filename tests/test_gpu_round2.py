@@ -479,3 +479,43 @@ def test_background_rejit_does_not_stall_draws_and_changes_no_bit(gpu, tmp_path,
     count = r.rejit_count()
     assert np.array_equal(_bits(r.draw(w, h, rgba32f=True)["rgba32f"]), _bits(ref.draw(w, h, rgba32f=True)["rgba32f"]))
     assert r.rejit_count() == count and not r.rejit_pending()
+
+
+def test_specialize_static_can_be_switched_on_a_background_rejit_renderer(gpu):
+    """with FLAG_ASYNC_REJIT `kernel` aliases one of a pair (specialised / un-specialised); switching the clip-constant
+    specialisation rebuilds synchronously, and used to free only the alias.  Both orders -- created specialised and switched off and on
+    again while stale; created plain and switched on -- keep drawing the reference renderer's bits, adopt background builds afterwards,
+    and are destroyed cleanly."""
+    import time
+
+    pa = gpu
+    w, h = 160, 90
+    plain_scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+    ref = pa.SceneRenderer(plain_scene, device=0, flags=0)
+    ref.set_option("render_depth", 12)
+
+    def settle(r):
+        deadline = time.time() + 120
+        while r.rejit_pending() and time.time() < deadline:
+            time.sleep(0.05)
+            r.draw(w, h, rgba32f=True)
+        assert not r.rejit_pending()
+
+    def same(r):
+        return np.array_equal(_bits(r.draw(w, h, rgba32f=True)["rgba32f"]), _bits(ref.draw(w, h, rgba32f=True)["rgba32f"]))
+
+    for start_flags in (pa.FLAG_SPECIALIZE_STATIC | pa.FLAG_ASYNC_REJIT, pa.FLAG_ASYNC_REJIT):
+        scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+        r = pa.SceneRenderer(scene, device=0, flags=start_flags)
+        r.set_option("render_depth", 12)
+        assert same(r)
+        for k, value in enumerate((0.3, 0.7, 1.1)):
+            assert scene.set_uniform("portal_rotate_angle", value) and plain_scene.set_uniform("portal_rotate_angle", value)
+            assert same(r)                                   # stale: the un-specialised kernel draws, a worker compiles
+            r.set_option("specialize_static", k % 2)         # ... and the pair is rebuilt under it (off, on, off)
+            assert same(r)
+            r.set_option("specialize_static", 1)
+            assert same(r)
+            settle(r)
+            assert same(r)
+        del r

@@ -1331,3 +1331,114 @@ def test_first_trip_plane_tests_are_selfconsistent_and_change_no_bit_on_the_host
         assert np.array_equal(frames["first"][k].view(np.uint32), frames["general"][k].view(np.uint32))
         assert np.array_equal(frames["first_baked"][k].view(np.uint32), frames["general"][k].view(np.uint32))
     assert not np.array_equal(frames["general"][0].view(np.uint32), frames["general"][1].view(np.uint32))
+
+
+def _flat_wall_with_extra_matrix(extra):
+    from tests.synthetic import wall_scene
+
+    return wall_scene(extra_matrices=extra, extra_objects='(name: "flat2", data: Flat(kind: Simple(Some(Named("squash"))), is_inside: (("return wall_M;")), in_subspace: Normal)),')
+
+
+def test_a_matrix_with_infinities_keeps_every_full_chain(pa):
+    """Products that skip zero terms (PTL_DROP_ZERO_TERMS, PTL_MASK_*) equal the full chains for finite vectors and for all-NaN ones.  A scene
+    matrix with infinite elements -- the inverse of a matrix flattened along ONE axis -- sends +-inf components down the rays, for which the
+    two differ (inf * 1 against inf * 1 + 0 * inf = NaN); the generator sees the values and keeps every full chain for that kernel.  An
+    all-NaN inverse (scaled to zero on all axes: how the reference's scenes switch an object off) does not need that."""
+    exact = '(name: "squash", data: Exact(i: (x: Value(1.0), y: Value(0.0), z: Value(0.0)), j: (x: Value(0.0), y: Value(%s), z: Value(0.0)), k: (x: Value(0.0), y: Value(0.0), z: Value(1.0)), pos: (x: Value(0.3), y: Value(0.0), z: Value(-1.0)))),'
+    spec, ints = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL, pa.FLAG_SPECIALIZE_INTS
+    flat = pa.Scene.from_text(_flat_wall_with_extra_matrix(exact % "0.0"))
+    inv = np.asarray(flat.uniform_values()["squash_mat_inv"])
+    assert np.isinf(inv).any() or (np.isnan(inv).any() and not np.isnan(inv).all())
+    src = flat.generate_source(spec)
+    assert "PTL_DROP_ZERO_TERMS" not in flat.generated_defines()
+    assert "#define PTL_MASK_" not in flat.generate_source(ints)
+    assert "#define PTL_MASK_" not in flat.generate_source(pa.FLAG_SPECIALIZE_STATIC) and "PTL_DROP_ZERO_TERMS" not in flat.generated_defines()
+    regular = pa.Scene.from_text(_flat_wall_with_extra_matrix(exact % "1.5"))
+    regular.generate_source(spec)
+    assert "PTL_DROP_ZERO_TERMS" in regular.generated_defines()
+    assert "#define PTL_MASK_squash_mat_inv" in regular.generate_source(ints)
+    # the reference's idiom -- scale 0 on all axes -- gives an all-NaN inverse and keeps the short chains (the headline scene has two)
+    pip = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    assert np.isnan(np.asarray(pip.uniform_values()["c0_mat_inv"])).all()
+    pip.generate_source(spec)
+    assert "PTL_DROP_ZERO_TERMS" in pip.generated_defines()
+    assert src != regular.generate_source(spec)
+
+
+def test_generated_defines_go_with_the_generated_source(pa):
+    scene = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    spec = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
+    for flags, want in ((0, {"PTL_FIRST_TRIP"}), (spec, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS"}), (spec | pa.FLAG_EXACT_CR, {"PTL_FIRST_TRIP", "PTL_CONTRACT_V1"}),
+                        (spec | pa.FLAG_FAST_MATH, {"PTL_FIRST_TRIP", "PTL_FAST_MATH"}), (pa.FLAG_COUNT_SEGMENTS | pa.FLAG_ANAGLYPH, {"PTL_FIRST_TRIP", "PTL_COUNT_SEGMENTS", "PTL_ANAGLYPH"})):
+        scene.generate_source(flags)
+        assert set(scene.generated_defines()) == want, flags
+
+
+def test_renderer_options_given_at_creation_are_in_the_first_build(pa, tmp_path, monkeypatch):
+    """ptl_renderer_create_with_options: a specialised renderer compiles its mode switches in, so a caller that draws side by side (`portal-amd
+    render --stereoimage`, and its compile-only prefetch renderers) gets THAT kernel from the first build -- the same code object a renderer
+    reaches by switching the option afterwards, without the build nothing runs on."""
+    monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path))
+    flags = pa.FLAG_SPECIALIZE_STATIC | pa.FLAG_QUICK_JIT
+    seeded = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("basics")), device=-1, flags=flags, options={"draw_side_by_side": 1, "render_depth": 7})
+    assert seeded.rejit_count() == 0
+    assert seeded.uniform_value("_ray_tracing_depth", 8, 8) == 7
+    switched = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("basics")), device=-1, flags=flags)
+    flat = switched.code_object()
+    switched.set_option("draw_side_by_side", 1)
+    assert switched.code_object() == seeded.code_object() != flat and switched.rejit_count() == 1
+    with pytest.raises(pa.PortalError):
+        pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("basics")), device=-1, flags=flags, options={"no_such_option": 1})
+    with pytest.raises(pa.PortalError):  # a rebuild at creation time makes no sense: the flag bit says it
+        pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("basics")), device=-1, flags=flags, options={"specialize_static": 1})
+
+
+def test_divisions_inside_a_library_define_are_the_contracts(pa):
+    """A `#define` of a scene library is GLSL like any other text (the reference's own library has `#define PI2 (acos(-1.) / 2.0)`): its
+    divisions become ptl_div (numerics contract 2: a * (1/b)) and its float literals get their suffix -- the macro draws the same bits
+    as the same expression written as a function."""
+    from oracle import host_build as hb
+    from tests.synthetic import wall_scene
+
+    out = pa.translate_glsl("#define PI2 (acos(-1.) / 2.0)\n#define THIRD(x) ((x) / 3.)\n#define K 0.5\n#ifdef GL_ES\nfloat f(float a) { return a / PI2 + THIRD(a) * K; }\n#endif\n")
+    assert out.splitlines()[0].replace(" ", "") == "#definePI2(ptl_div(acos(-1.f),2.0f))"
+    assert out.splitlines()[1].replace(" ", "") == "#defineTHIRD(x)(ptl_div((x),3.f))"
+    assert out.splitlines()[2] == "#define K 0.5f" and out.splitlines()[3] == "#ifdef GL_ES"
+    frames = []
+    for lib in ('#define THIRD(x) ((x) / 3.)\\n#define K 0.37', 'float THIRD(float x) { return x / 3.; }\\nconst float K = 0.37;'):
+        text = wall_scene(size=0.9, grid=True, library='(name: "lib", data: (("%s")))' % lib).replace(
+            "if (abs(x) < size_u && abs(y) < size_u)", "if (abs(x) < THIRD(size_u * 2.5 + y) + K && abs(y) < THIRD(2. + x) / K * 0.4)")
+        scene = pa.Scene.from_text(text)
+        assert "ptl_div(" in scene.generate_source(0).split("namespace glsl {")[-1]
+        r = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_QUICK_JIT)
+        frames.append(hb.host_kernel_for(r, scene, 48, 32).render(48, 32)["rgba32f"].copy())
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    wall = (frames[0][..., :3] != np.float32(0.6)).any(axis=2).mean()  # the region the divisions bound: part of the frame, not all of it
+    assert 0.05 < wall < 0.95, wall
+
+
+def test_zero_pattern_probes_are_reused_while_the_state_they_depend_on_stands(pa):
+    """A renderer with baked Bool / Int uniforms regenerates its source on every scene-version bump, i.e. on every camera move; the zero
+    patterns of its run-time matrices (two scene copies, up to 33 Scene::update + 34 evaluations to find) are reused while every value
+    they depend on is the same, probed again when one moves, and the generated source is the same text either way."""
+    ints = pa.FLAG_SPECIALIZE_INTS
+    scene = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    first = scene.generate_source(ints)
+    assert scene.zero_mask_probes() == (0, 1)
+    scene.set_camera_matrix(np.eye(4) + 0.01)  # a camera move: nothing the patterns depend on
+    assert scene.generate_source(ints) == first and scene.zero_mask_probes() == (1, 1)
+    scene.set_uniform("portal_rotate_angle", 0.3) if "portal_rotate_angle" in scene.uniform_values() else scene.set_uniform("pass_offset", 0.4)
+    moved = scene.generate_source(ints)
+    assert scene.zero_mask_probes() == (1, 2)
+    fresh = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    fresh.set_camera_matrix(np.eye(4) + 0.01)
+    fresh.set_uniform("portal_rotate_angle", 0.3) if "portal_rotate_angle" in fresh.uniform_values() else fresh.set_uniform("pass_offset", 0.4)
+    assert fresh.generate_source(ints) == moved
+    # a scene whose matrices follow the camera (Matrix::Camera): the cached patterns must still cover what such a matrix holds now
+    cam = pa.Scene.from_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "corpus", "scenes", "portal_in_portal_plus_ultra.ron"))
+    a = cam.generate_source(ints)
+    cam.set_camera_matrix(np.array([[0.0, 0, 1, 0.3], [0, 1, 0, 0.2], [-1, 0, 0, 0.1], [0, 0, 0, 1]]))
+    b = cam.generate_source(ints)
+    fresh = pa.Scene.from_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "corpus", "scenes", "portal_in_portal_plus_ultra.ron"))
+    fresh.set_camera_matrix(np.array([[0.0, 0, 1, 0.3], [0, 1, 0, 0.2], [-1, 0, 0, 0.1], [0, 0, 0, 1]]))
+    assert fresh.generate_source(ints) == b and a.count("#define PTL_MASK_") == b.count("#define PTL_MASK_")
