@@ -149,12 +149,23 @@ PTL_FN float ptl_rcp(float x) { return 1.0f / x; }
 //   sqrt(x): g = v_sqrt_f32 (1 ulp), h = v_rsq_f32 / 2; d = x - g*g is exact above 2^-103 (a multiple of ulp(g)^2) and
 //            s = g + d*h rounds correctly (Markstein).  Inputs below 2^-100 are flushed to +0 first (a select on |x|, so negative
 //            numbers of ordinary size still give NaN); +0 and +inf make the correction NaN and keep the estimate (0, inf).
+//   The "not a number -> keep the estimate" step is ONE instruction: v_med3_f32(y, y0, y).  With a NaN among its operands v_med3 returns
+//   v_min3 of them, and v_min returns the operand that is a number -- y0 when y is NaN (NaN when both are); without a NaN the median
+//   of {y, y0, y} is y.  A compare + select pair costs 7.5 issue cycles on gfx950 against 2.3 (profiles/r01/valu_rates.jsonl), and
+//   these two guards were 37 % of the headline kernel's compares and 55 % of its selects (tools/isa_hist.py).  -DPTL_CMP_GUARD: the pair (A/B).
+PTL_FN float ptl_number_or(float y, float fallback) {  // y, or `fallback` where y is NaN
+#if defined(PTL_CMP_GUARD)
+    return y == y ? y : fallback;
+#else
+    return __builtin_amdgcn_fmed3f(y, fallback, y);
+#endif
+}
 PTL_FN float ptl_rcp(float x) {
     if (__builtin_constant_p(x)) return ptl_rcp_model(x);  // after JIT specialisation: the compiler folds the operator form
     const float y0 = __builtin_amdgcn_rcpf(x);
     const float e = __builtin_fmaf(-x, y0, 1.0f);
     const float y = __builtin_fmaf(y0, e, y0);
-    return y == y ? y : y0;
+    return ptl_number_or(y, y0);
 }
 PTL_FN float sqrt(float x) {
     if (__builtin_constant_p(x)) return ptl_sqrt_model(x);
@@ -163,7 +174,7 @@ PTL_FN float sqrt(float x) {
     const float h = 0.5f * __builtin_amdgcn_rsqf(xe);
     const float d = __builtin_fmaf(-g, g, xe);
     const float s = __builtin_fmaf(d, h, g);
-    return s == s ? s : g;
+    return ptl_number_or(s, g);
 }
 #else
 PTL_FN float ptl_rcp(float x) { return ptl_rcp_model(x); }

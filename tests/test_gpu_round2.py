@@ -490,10 +490,6 @@ def test_specialize_static_can_be_switched_on_a_background_rejit_renderer(gpu):
 
     pa = gpu
     w, h = 160, 90
-    plain_scene = pa.Scene.from_file(pa.scene_path("monoportal"))
-    ref = pa.SceneRenderer(plain_scene, device=0, flags=0)
-    ref.set_option("render_depth", 12)
-
     def settle(r):
         deadline = time.time() + 120
         while r.rejit_pending() and time.time() < deadline:
@@ -501,10 +497,14 @@ def test_specialize_static_can_be_switched_on_a_background_rejit_renderer(gpu):
             r.draw(w, h, rgba32f=True)
         assert not r.rejit_pending()
 
-    def same(r):
-        return np.array_equal(_bits(r.draw(w, h, rgba32f=True)["rgba32f"]), _bits(ref.draw(w, h, rgba32f=True)["rgba32f"]))
-
     for start_flags in (pa.FLAG_SPECIALIZE_STATIC | pa.FLAG_ASYNC_REJIT, pa.FLAG_ASYNC_REJIT):
+        plain_scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+        ref = pa.SceneRenderer(plain_scene, device=0, flags=0)
+        ref.set_option("render_depth", 12)
+
+        def same(r, ref=ref):
+            return np.array_equal(_bits(r.draw(w, h, rgba32f=True)["rgba32f"]), _bits(ref.draw(w, h, rgba32f=True)["rgba32f"]))
+
         scene = pa.Scene.from_file(pa.scene_path("monoportal"))
         r = pa.SceneRenderer(scene, device=0, flags=start_flags)
         r.set_option("render_depth", 12)
@@ -518,4 +518,4 @@ def test_specialize_static_can_be_switched_on_a_background_rejit_renderer(gpu):
             assert same(r)
             settle(r)
             assert same(r)
-        del r
+        del r, ref
