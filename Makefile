@@ -7,7 +7,7 @@ CXXFLAGS ?= -O2 -g -std=c++20 -fPIC -Wall -Wextra -Wno-unused-parameter
 HOST     := portal_amd/csrc/host
 DEVICE   := portal_amd/csrc/device
 OBJDIR   := build/obj
-SRCS     := ron.cpp formula.cpp scene.cpp glsl_translate.cpp glsl_hoist.cpp codegen.cpp embedded.cpp hip_api.cpp kernel.cpp postprocess.cpp png_io.cpp capi.cpp multigpu.cpp
+SRCS     := ron.cpp formula.cpp scene.cpp glsl_translate.cpp glsl_bound.cpp glsl_hoist.cpp codegen.cpp embedded.cpp hip_api.cpp kernel.cpp postprocess.cpp png_io.cpp capi.cpp multigpu.cpp
 OBJS     := $(SRCS:%.cpp=$(OBJDIR)/%.o)
 LIB      := portal_amd/libportal_amd.so
 CLI      := portal_amd/portal-amd

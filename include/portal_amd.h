@@ -228,6 +228,15 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * run-time value (only Bool / Int baked; animated within the clip -- its pattern then taken over probes of the clip's `time`; demoted):
  * `transform(X_mat, ..)` of the scene snippets and the generated plane tests skip the terms whose element is zero, as a baked matrix's do
  * (same results for finite operands); a renderer rebuilds when a masked element stops being zero.  This bit keeps the full products (A/B),
+ * bit20 = SPECIALIZE PATTERNS: no VALUE of the scene is compiled in, only what survives while the values move -- the zero patterns of the
+ * matrix uniforms (as with bit19 clear) and, in a renderer, its mode switches.  The kernel for scenes whose uniforms move every frame (the
+ * reference uploads them every frame and never recompiles, src/main.rs:1266-1359): a renderer rebuilds only when a matrix element stops
+ * being zero (then without masks, at most once per stage) or a switch flips; with bit17 the un-specialised kernel draws meanwhile.
+ * bit21 = BOUNDED SNIPPETS (opt-in): the bounce loop evaluates scene_intersect() first and hands its hit distance to the scene's
+ * intersection-material snippets; a snippet of the usual shape (an accumulator filled in `if (nearer(result.scene.hit, H)) { ... }` blocks)
+ * then skips the candidates beyond it, which could never be the nearest hit -- exact by construction (host/glsl_translate.h
+ * `bound_nearer_blocks` has the proof and the conditions), identical frames.  Off by default: on the headline scene it measures -2 ... +13 %
+ * kernel time over five views (profiles/r04/ab_bounded_snippets.jsonl),
  * bit15 = NO unrolling of baked loops: by default (with bit0) a counting loop of a scene snippet whose bound is a baked Int uniform
  * (<= 16 iterations) is unrolled -- the same operations in the same order, identical frames; every iteration then has its own
  * constants (scenes/portal_in_portal.ron's `size` drives an inner loop and a material index).
@@ -394,6 +403,16 @@ int ptl_frame_group_use_camera(ptl_frame_group* g, const char* camera);
 int ptl_frame_group_set_camera(ptl_frame_group* g, const double look_at[3], double alpha, double beta, double radius);
 int ptl_frame_group_update(ptl_frame_group* g, double seconds);
 int ptl_frame_group_draw(ptl_frame_group* g, int width, int height, void** device_rgba8, float* kernel_ms);
+/* The pipelined form for clips ("gather of frame n overlaps tracing of frame n+1 on a second stream"): _submit enqueues the
+ * trace of one frame on every rank's compute stream and its transfer to devices[0] behind it on the rank's second stream, and returns at
+ * once with a ticket; _wait blocks until THAT frame is assembled and hands out its buffer (valid until the frame after the next is
+ * submitted).  Two frames may be in flight -- shards, gather buffer and frame are double-buffered -- so while frame n travels over xGMI
+ * the compute streams already trace frame n + 1 (set the camera / options / update for it between the two calls: uniform uploads are
+ * stream-ordered behind the previous frame's kernel).  A third _submit before the oldest _wait is PTL_ERR_INVALID, and so is a _submit with
+ * another frame size while a frame is in flight (the buffers are re-allocated); ptl_frame_group_draw is _submit + _wait and finishes
+ * whatever is in flight first. */
+int ptl_frame_group_submit(ptl_frame_group* g, int width, int height, int* ticket);
+int ptl_frame_group_wait(ptl_frame_group* g, int ticket, void** device_rgba8, float* kernel_ms);
 int ptl_frame_group_download(ptl_frame_group* g, uint8_t* host_rgba8);
 void ptl_frame_group_destroy(ptl_frame_group* g);
 
@@ -438,6 +457,10 @@ const char* ptl_device_source(const char* which);
 
 /* GLSL snippet -> C++ (malloc'ed, ptl_free) and the formula evaluator, exposed for tests. */
 char* ptl_translate_glsl(const char* glsl);
+/* The distance-bound rewrite of an intersection-material snippet on its own (host/glsl_translate.h `bound_nearer_blocks`; tests): the GLSL
+ * body with `&& !(H.t > ptl_far)` added to the conditions it recognises (malloc'ed, ptl_free), *bounded = how many; `out_functions`:
+ * comma-separated names of scene functions with out / inout parameters.  Unchanged text and 0 when the snippet's shape does not allow it. */
+char* ptl_bound_glsl(const char* glsl_body, const char* out_functions, int* bounded);
 /* The uniform-work hoister on one snippet, exposed for tests (the code generator runs it on every scene snippet unless flags
  * bit12 / bit5 say otherwise).  `uniforms` lists the run-time uniforms as "type name;type name;..." (GLSL types), `out_functions`
  * the functions that write through an argument ("f;g"; "=f" marks a function the scene merely defines itself, which is then never

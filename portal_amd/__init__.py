@@ -57,6 +57,8 @@ FLAG_NO_FIRST_TRIP = 8192  # no first-trip copies of the intersection-material s
 FLAG_NO_UNIFORM_HOIST = 4096  # scene snippets evaluate their uniform-only expressions per ray (default: once per upload, in the prologue kernel)
 FLAG_NO_DEFERRED_UPDATES = 128  # translate scene snippets exactly as written (default: loop-carried ray transforms are applied lazily)
 FLAG_QUICK_JIT = 262144  # compile at -O1 instead of the shipped -O3: half the JIT time, a 5-20 % slower kernel (one-off frames)
+FLAG_SPECIALIZE_PATTERNS = 1048576  # compile in only what survives moving values: zero patterns of the matrices + the renderer's mode switches
+FLAG_BOUNDED_SNIPPETS = 2097152  # opt-in: scene_intersect first, its hit distance bounds the intersection-material snippets (exact; measured: no gain on the headline)
 FLAG_NO_ZERO_MASKS = 524288  # A/B: run-time matrices keep their full products although their zero pattern is known (KernelOptions::mask_zero_elements)
 FLAG_ASYNC_REJIT = 131072  # a specialised renderer never stalls on a rebuild: it draws with the un-specialised kernel until a worker thread has the new one
 FLAG_NO_FIRST_TRIP_PLANES = 65536  # no first-trip copy of the generated plane tests (default: on the first trip `plane_inv * camera origin` comes from the prologue kernel)
@@ -171,6 +173,8 @@ def _load() -> C.CDLL:
         "ptl_frame_group_set_camera": (ci, [vp, P(cd), cd, cd, cd]),
         "ptl_frame_group_update": (ci, [vp, cd]),
         "ptl_frame_group_draw": (ci, [vp, ci, ci, P(vp), P(C.c_float)]),
+        "ptl_frame_group_submit": (ci, [vp, ci, ci, P(ci)]),
+        "ptl_frame_group_wait": (ci, [vp, ci, P(vp), P(C.c_float)]),
         "ptl_frame_group_download": (ci, [vp, vp]),
         "ptl_frame_group_destroy": (None, [vp]),
         "ptl_host_alloc": (ci, [cs, P(vp)]),
@@ -190,6 +194,7 @@ def _load() -> C.CDLL:
         "ptl_strstore_get_identifier": (ci, [vp, ci, cp, cs, cp, cs, P(ci)]),
         "ptl_device_source": (cp, [cp]),
         "ptl_translate_glsl": (vp, [cp]),
+        "ptl_bound_glsl": (vp, [cp, cp, P(ci)]),
         "ptl_formula_eval": (ci, [cp, P(cp), P(cd), ci, cd, P(cd)]),
     }
     for name, (res, args) in sig.items():
@@ -593,6 +598,24 @@ class FrameGroup:
     def update(self, seconds: float) -> None:
         _check(lib().ptl_frame_group_update(self._h, float(seconds)), "ptl_frame_group_update")
 
+    def submit(self, width: int, height: int) -> int:
+        """Enqueue one frame (trace on every rank + its transfer to devices[0]) without waiting; returns the ticket for `wait`.
+        Two frames may be in flight: the transfer of frame n overlaps the trace of frame n + 1."""
+        ticket = C.c_int(-1)
+        _check(lib().ptl_frame_group_submit(self._h, width, height, C.byref(ticket)), "ptl_frame_group_submit")
+        self._size = (width, height)  # (one size for everything in flight: another one is refused while a frame is on its way)
+        return ticket.value
+
+    def wait(self, ticket: int) -> dict:
+        """The frame of `ticket`, assembled: dict(rgba8, kernel_ms per rank, device_ptr)."""
+        ptr = C.c_void_p()
+        ms = (C.c_float * len(self.devices))()
+        _check(lib().ptl_frame_group_wait(self._h, ticket, C.byref(ptr), ms), "ptl_frame_group_wait")
+        width, height = self._size
+        img = np.empty((height, width, 4), np.uint8)
+        _check(lib().ptl_frame_group_download(self._h, img.ctypes.data_as(C.c_void_p)), "ptl_frame_group_download")
+        return {"rgba8": img, "kernel_ms": [float(x) for x in ms], "device_ptr": ptr.value}
+
     def draw(self, width: int, height: int) -> dict:
         """Returns dict(rgba8 (H, W, 4) uint8, kernel_ms per rank, device_ptr of the frame on devices[0])."""
         ptr = C.c_void_p()
@@ -737,6 +760,16 @@ def ron_format(text: str) -> str:
         raise PortalError(_err())
     try:
         return C.string_at(p).decode("utf-8")
+    finally:
+        lib().ptl_free(p)
+
+
+def bound_glsl(body: str, out_functions=()):
+    """(text, n): an intersection-material snippet with the caller's distance bound in the `nearer` blocks it recognises (n of them)."""
+    n = C.c_int()
+    p = lib().ptl_bound_glsl(body.encode("utf-8"), ",".join(out_functions).encode(), C.byref(n))
+    try:
+        return C.string_at(p).decode("utf-8"), n.value
     finally:
         lib().ptl_free(p)
 

@@ -172,7 +172,10 @@ PTL_FN MaterialProcessing material_process(Ray r, const SceneIntersection& i) {
 }
 
 // Scene snippets that return hit and material in one go. (src/frag.glsl:52-59)
-PTL_FN SceneIntersectionWithMaterial scene_intersect_material_process(const Ray& r) {
+// `ptl_far`: a distance beyond which a hit cannot matter to the caller (PTL_BOUNDED_SNIPPETS: the bounce loop passes the hit distance of
+// scene_intersect(), which it then evaluates first; the snippets whose shape allows it skip candidates beyond it, glsl_translate.h).
+PTL_FN SceneIntersectionWithMaterial scene_intersect_material_process(const Ray& r, float ptl_far = __builtin_inff()) {
+    (void)ptl_far;
     SceneIntersectionWithMaterial result = SceneIntersectionWithMaterial{scene_intersection_none, material_empty()};
     SceneIntersectionWithMaterial hit = SceneIntersectionWithMaterial{scene_intersection_none, material_empty()};
     (void)hit;
@@ -188,7 +191,8 @@ PTL_FN SceneIntersectionWithMaterial scene_intersect_material_process(const Ray&
 // snippets do to the ray depends on uniforms alone.  The code generator emits a second copy of each snippet, `intersect_material_<N>_first`,
 // in which the hoister (host/glsl_hoist.h) knows that about `r`: origins of `transform(uniform matrix, ray)` chains come from the
 // prologue kernel's tables, the direction half stays per ray.  Same operations on the same values; later trips use the general copy.
-PTL_FN SceneIntersectionWithMaterial scene_intersect_material_process_first(const Ray& r) {
+PTL_FN SceneIntersectionWithMaterial scene_intersect_material_process_first(const Ray& r, float ptl_far = __builtin_inff()) {
+    (void)ptl_far;
     SceneIntersectionWithMaterial result = SceneIntersectionWithMaterial{scene_intersection_none, material_empty()};
     SceneIntersectionWithMaterial hit = SceneIntersectionWithMaterial{scene_intersection_none, material_empty()};
     (void)hit;
@@ -238,6 +242,22 @@ PTL_FN bool trace_segment(Ray& r, vec3& current_color, float& all_t, float camer
 #else
 PTL_FN bool trace_segment(Ray& r, vec3& current_color, float& all_t, float camera_scale, const vec3& not_found_color, RayTraceResult& out) {
 #endif
+#if defined(PTL_BOUNDED_SNIPPETS) && !defined(PTL_SNIPPETS_FIRST)
+    // Like the reference (frag.glsl:114-115): scene_intersect first.  Its hit distance then bounds the snippets: a candidate of theirs
+    // beyond it could never be the `nearer` one below, and the snippets the generator could prove it for skip such candidates
+    // (KernelOptions::bound_snippets) -- for the headline scene that is most of what its snippet does.  (-DPTL_SNIPPETS_FIRST: A/B.)
+#ifdef PTL_FIRST_TRIP_PLANES
+    SceneIntersection i = first_form ? scene_intersect_first(r) : scene_intersect(r);
+#else
+    SceneIntersection i = scene_intersect(r);
+#endif
+    const float ptl_bound = i.hit.hit ? i.hit.t : __builtin_inff();
+#ifdef PTL_FIRST_TRIP_SNIPPETS
+    SceneIntersectionWithMaterial i2 = first_form ? scene_intersect_material_process_first(r, ptl_bound) : scene_intersect_material_process(r, ptl_bound);
+#else
+    SceneIntersectionWithMaterial i2 = scene_intersect_material_process(r, ptl_bound);
+#endif
+#else
     // The reference evaluates scene_intersect first (frag.glsl:114-115); both are pure, and with the snippet's hit distance known the
     // plane tests beyond it can be culled: `i` then is the nearest object in front of the snippet's hit, or whatever else survived --
     // and whenever the two differ the snippet's hit is nearer than both and is what gets used below.
@@ -251,6 +271,7 @@ PTL_FN bool trace_segment(Ray& r, vec3& current_color, float& all_t, float camer
     SceneIntersection i = first_form ? scene_intersect_first(r, ptl_bound) : scene_intersect(r, ptl_bound);
 #else
     SceneIntersection i = scene_intersect(r, ptl_bound);
+#endif
 #endif
 #if defined(PTL_FIRST_TRIP) && !defined(PTL_FIRST_TRIP_SNIPPETS) && !defined(PTL_FIRST_TRIP_PLANES)
     (void)first_form;

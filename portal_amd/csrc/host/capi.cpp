@@ -434,7 +434,8 @@ static KernelOptions options_from_flags(unsigned flags) {
     o.quick_jit = (flags & 262144u) != 0 && !o.specialize_static;
     // zero patterns of the matrices that stay run-time values: with any specialisation (the un-specialised kernel has to be valid for every
     // state of the scene -- the background re-JIT draws with it meanwhile); PTL_FLAG_NO_ZERO_MASKS (bit 19) for A/B measurements and tests
-    o.mask_zero_elements = (flags & 13u) != 0 && (flags & 524288u) == 0;
+    o.mask_zero_elements = (flags & (13u | (1u << 20))) != 0 && (flags & 524288u) == 0;
+    o.bound_snippets = (flags & (1u << 21)) != 0;  // PTL_FLAG_BOUNDED_SNIPPETS: scene_intersect first, its distance bounds the intersection-material snippets (opt-in: measured, no gain)
     o.first_trip_planes = (flags & 65536u) == 0;   // PTL_FLAG_NO_FIRST_TRIP_PLANES: one scene_intersect for every trip (A/B measurements, tests)
     // PTL_FLAG_NO_UNROLL: keep snippet loops with baked bounds as loops (A/B measurements).  The quick build keeps them too: unrolling
     // is half of its hiprtc time for the headline scene (3.4 -> 1.8 s on this container's cores) and buys 0.05 ms of kernel
@@ -458,7 +459,7 @@ static void refresh_generated(ptl_scene* s, unsigned flags, const std::set<std::
     opts.mask_cache = &s->mask_cache;
     if (keep_dynamic) opts.keep_dynamic = *keep_dynamic;
     if (keep_unmasked) opts.keep_unmasked = *keep_unmasked;
-    if (switches && (flags & 13u) != 0) opts.baked_options = *switches;
+    if (switches && (flags & (13u | (1u << 20))) != 0) opts.baked_options = *switches;
     CodegenFlags cg;
     cg.defer_loop_updates = (flags & 128u) == 0;  // PTL_FLAG_NO_DEFERRED_UPDATES: the snippets exactly as written (A/B measurements, tests)
     s->last = generate_kernel_source(*s->scene, cg, opts);
@@ -612,6 +613,10 @@ int update_videos(ptl_renderer* r) {
 }  // namespace
 
 static constexpr unsigned kAsyncRejit = 1u << 17;  // PTL_FLAG_ASYNC_REJIT
+// PTL_FLAG_SPECIALIZE_PATTERNS (bit 20): no VALUE of the scene is compiled in, only what survives while values move -- the zero patterns of
+// the matrices and the renderer's mode switches.  kSpecialised = the builds that compile in something a later state can invalidate.
+static constexpr unsigned kPatterns = 1u << 20;
+static constexpr unsigned kSpecialised = 13u | kPatterns;
 
 // reload_textures (main.rs:1066-1083) into a freshly built kernel
 static int bind_textures(ptl_renderer* r, ptl_kernel* k) {
@@ -727,7 +732,7 @@ static void drop_async_kernels(ptl_renderer* r) {
     r->want = ptl_renderer::Build{};
 }
 static void seed_async_kernels(ptl_renderer* r) {
-    if ((r->flags & kAsyncRejit) != 0 && (r->flags & 13u) != 0 && r->device >= 0) {  // the first kernel is the specialised one of this state
+    if ((r->flags & kAsyncRejit) != 0 && (r->flags & kSpecialised) != 0 && r->device >= 0) {  // the first kernel is the specialised one of this state
         r->spec_kernel = r->kernel;
         r->spec_source = r->kernel_source;
         r->want = snapshot_build(r->owner, r->flags);
@@ -952,7 +957,7 @@ static int async_select_kernel(ptl_renderer* r) {
             r->keep_unmasked.clear();
             r->full_chains = false;
         }
-        if ((r->flags & 8u) != 0 && (r->flags & 5u) == 0) {  // clip-constant specialisation: a compiled-in value that moved becomes a run-time uniform
+        if ((r->flags & (8u | kPatterns)) != 0 && (r->flags & 5u) == 0) {  // clip-constant specialisation: a compiled-in value that moved becomes a run-time uniform
             std::vector<UniformUpload> values = evaluate_scene_uniforms(*r->scene, nullptr);
             size_t at = 0;
             for (const UniformUpload& b : r->want.baked) {
@@ -1017,7 +1022,7 @@ static int async_select_kernel(ptl_renderer* r) {
         r->job = job;
     }
     if (!r->dyn_kernel) {  // first need: built here, once (a cached code object makes it a module load)
-        refresh_generated(s, r->flags & ~13u);
+        refresh_generated(s, r->flags & ~kSpecialised);
         ptl_renderer::Build dyn = snapshot_build(s, r->flags);
         ptl_kernel* k = nullptr;
         int rc = compile_build(dyn, r->device, nullptr, &k, nullptr, 0);
@@ -1030,12 +1035,12 @@ static int async_select_kernel(ptl_renderer* r) {
 
 static int prepare_draw(ptl_renderer* r, const ptl_frame* frame) {
     send_camera_matrix(r);
-    const bool async = (r->flags & kAsyncRejit) != 0 && (r->flags & 13u) != 0 && r->device >= 0;
+    const bool async = (r->flags & kAsyncRejit) != 0 && (r->flags & kSpecialised) != 0 && r->device >= 0;
     if (async) {
         int rc = async_select_kernel(r);
         if (rc != PTL_OK) return rc;
     }
-    if (!async && (r->flags & 13u) != 0 && mode_switches(*r) != r->kernel_switches) {
+    if (!async && (r->flags & kSpecialised) != 0 && mode_switches(*r) != r->kernel_switches) {
         // a camera model / output mode was switched: the specialised kernel has the old one compiled in (and the new one compiled out)
         int rc = build_kernel(r, nullptr, 0);
         if (rc != PTL_OK) return rc;
@@ -1049,7 +1054,7 @@ static int prepare_draw(ptl_renderer* r, const ptl_frame* frame) {
     if (r->uploaded_scene != r->scene->version) {
         std::vector<std::string> errors;
         std::vector<UniformUpload> values = evaluate_scene_uniforms(*r->scene, &errors);  // scene.set_uniforms
-        if (!async && (r->flags & 8u) != 0 && (r->flags & 5u) == 0) {
+        if (!async && (r->flags & (8u | kPatterns)) != 0 && (r->flags & 5u) == 0) {
             // clip-constant specialisation: the kernel stays valid as long as every compiled-in value still holds; a value
             // that moved after all is demoted to a run-time uniform and the kernel is built again (cached by source hash)
             bool stale = !(r->kernel_stage == r->scene->current_stage);
@@ -1356,7 +1361,7 @@ extern "C" int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16],
 extern "C" ptl_kernel* ptl_renderer_kernel(ptl_renderer* r) {
     if (!r) return nullptr;
     // the kernel the next draw would use: a specialised build follows the mode switches (also on a handle without a device, which never draws)
-    if ((r->flags & 13u) != 0 && !((r->flags & kAsyncRejit) != 0 && r->device >= 0) && mode_switches(*r) != r->kernel_switches) {
+    if ((r->flags & kSpecialised) != 0 && !((r->flags & kAsyncRejit) != 0 && r->device >= 0) && mode_switches(*r) != r->kernel_switches) {
         int rc = guarded([&] {
             int rc2 = build_kernel(r, nullptr, 0);
             if (rc2 == PTL_OK) ++r->rejit_count;
@@ -1458,6 +1463,25 @@ extern "C" char* ptl_translate_glsl(const char* glsl) {
         set_last_error(e.what());
         return nullptr;
     }
+    char* p = (char*)std::malloc(out.size() + 1);
+    std::memcpy(p, out.c_str(), out.size() + 1);
+    return p;
+}
+
+extern "C" char* ptl_bound_glsl(const char* glsl_body, const char* out_functions, int* bounded) {
+    if (!glsl_body) return nullptr;
+    std::set<std::string> with_out;
+    std::string cur;
+    for (const char* c = out_functions ? out_functions : ""; ; ++c) {
+        if (*c == ',' || *c == '\0') {
+            if (!cur.empty()) with_out.insert(cur);
+            cur.clear();
+            if (*c == '\0') break;
+        } else {
+            cur += *c;
+        }
+    }
+    std::string out = bound_nearer_blocks(glsl_body, with_out, bounded);
     char* p = (char*)std::malloc(out.size() + 1);
     std::memcpy(p, out.c_str(), out.size() + 1);
     return p;

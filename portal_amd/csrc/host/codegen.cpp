@@ -1,6 +1,7 @@
 // codegen.cpp -- see codegen.h.
 #include "codegen.h"
 #include "glsl_hoist.h"
+#include "glsl_tokens.h"
 
 #include <cstring>
 
@@ -340,6 +341,13 @@ struct SnippetTranslator {
     // (profiles/r03/stub_profile.jsonl `pip_unrolled`, variants5_unroll.jsonl): 0.409 -> 0.350 ms, same frame hash.
     std::map<std::string, int> unroll_bounds;
     static constexpr int kUnrollLimit = 16;
+    // intersection-material snippets that take the caller's distance bound (KernelOptions::bound_snippets): their filtered GLSL with the
+    // bounded conditions, by the address of the scene's text
+    std::map<const std::string*, std::string> bounded_src;
+    std::string filtered(const std::string& code) const {
+        auto it = bounded_src.find(&code);
+        return it != bounded_src.end() ? it->second : filter_tagged_lines(code, flags);
+    }
 
     std::string unrolled(std::string cxx) const {
         if (unroll_bounds.empty()) return cxx;
@@ -362,7 +370,7 @@ struct SnippetTranslator {
         HoistParams hp = base;
         hp.body_only = body_only;
         hp.body_params = std::move(params);
-        HoistResult r = hoist_uniform_work(filter_tagged_lines(code, flags), hp, next_member);
+        HoistResult r = hoist_uniform_work(filtered(code), hp, next_member);
         if (r.members.empty()) return;
         hoisted[&code] = r.glsl;
         members.insert(members.end(), r.members.begin(), r.members.end());
@@ -372,10 +380,10 @@ struct SnippetTranslator {
     void prepare_first(const std::string& code, const HoistParams& base) {
         HoistParams hp = base;
         hp.body_only = true;
-        hp.body_params = {"r"};
+        hp.body_params = {"r", "ptl_far"};
         hp.origin_uniform_rays = {"r"};
         hp.origin_expr = "PTL_DV_OUT.ptl_dv_origin";
-        HoistResult r = hoist_uniform_work(filter_tagged_lines(code, flags), hp, next_member);
+        HoistResult r = hoist_uniform_work(filtered(code), hp, next_member);
         if (r.members.empty()) return;
         hoisted_first[&code] = r.glsl;
         members.insert(members.end(), r.members.begin(), r.members.end());
@@ -385,7 +393,7 @@ struct SnippetTranslator {
     std::string first(const std::string& code) const { return unrolled(translate_glsl(hoisted_first.at(&code), flags.defer_loop_updates)); }
     std::string operator()(const std::string& code) const {
         auto it = hoisted.find(&code);
-        return unrolled(translate_glsl(it != hoisted.end() ? it->second : filter_tagged_lines(code, flags), flags.defer_loop_updates));
+        return unrolled(translate_glsl(it != hoisted.end() ? it->second : filtered(code), flags.defer_loop_updates));
     }
 };
 
@@ -572,7 +580,7 @@ bool matrix_breaks_short_chains(const float m[16]) {
 GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& flags, const KernelOptions& opts) {
     GeneratedKernel gk;
     std::map<std::string, StringStorage> storages;
-    SnippetTranslator snippet{flags, {}, {}, {}, {}, 0, {}};
+    SnippetTranslator snippet{flags, {}, {}, {}, {}, 0, {}, {}};
 
     // --- uniform block --------------------------------------------------------------------
     {
@@ -728,8 +736,8 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 }
             }
         }
-        if (opts.specialize_ints || opts.specialize_all || opts.specialize_static)
-            for (auto& [name, value] : opts.baked_options)
+        // (KernelOptions::baked_options is only filled in for builds that may compile the switches in: any specialisation, patterns-only included)
+        for (auto& [name, value] : opts.baked_options)
                 for (auto& u : list)
                     if (u.name == name && u.type == UniformType::Int1) baked[name] = std::to_string(value);
         // first-trip plane tests (KernelOptions::first_trip_planes): only where some Flat object's matrix is a run-time value
@@ -776,6 +784,32 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             for (const NamedCode& im : scene.intersection_materials) bodies.push_back(filter_tagged_lines(im.code, flags));
             check_out_argument_aliasing(file_scope, bodies);
         }
+        // --- the caller's distance bound inside the intersection-material snippets (KernelOptions::bound_snippets) ----------------
+        if (opts.bound_snippets && !scene.intersection_materials.empty()) {
+            // process_portal_intersection never resets SceneIntersection::in_subspace (library.glsl:571-589): with subspace portals a skipped
+            // candidate could leave that flag behind, so a scene whose GLSL names them keeps its snippets as written
+            bool subspace = false;
+            auto names_subspace = [&](const std::string& code) {
+                for (const Token& t : tokenize_glsl(code))
+                    if (t.kind == Token::Ident && (t.text == "TELEPORT_SUBSPACE" || t.text == "in_subspace")) subspace = true;
+            };
+            std::set<std::string> with_out;
+            for (const NamedCode& lib : scene.library) names_subspace(lib.code), functions_with_out_params(lib.code, with_out);
+            for (const Material& m : scene.materials)
+                if (m.kind == Material::Complex) names_subspace(m.code);
+            for (const Object& o : scene.objects)
+                if (o.kind == Object::Flat || o.kind == Object::Complex) names_subspace(o.code);
+            for (const NamedCode& im : scene.intersection_materials) names_subspace(im.code);
+            if (!subspace)
+                for (const NamedCode& im : scene.intersection_materials) {
+                    int n = 0;
+                    std::string bounded = bound_nearer_blocks(filter_tagged_lines(im.code, flags), with_out, &n);
+                    if (n > 0) {
+                        snippet.bounded_src[&im.code] = bounded;
+                        gk.bounded_snippet_blocks += n;
+                    }
+                }
+        }
         // --- uniform-only work of the scene snippets: members behind the derived planes, filled by the same prologue kernel -----
         if (opts.derived_uniforms && opts.hoist_uniform_work) {
             HoistParams hp;
@@ -793,7 +827,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 if (o.kind == Object::Flat) snippet.prepare(o.code, hp, true, o.portal ? std::vector<std::string>{"pos", "x", "y", "back", "first"} : std::vector<std::string>{"pos", "x", "y", "back"});
                 else if (o.kind == Object::Complex) snippet.prepare(o.code, hp, true, o.portal ? std::vector<std::string>{"r", "first"} : std::vector<std::string>{"r"});
             }
-            for (const NamedCode& im : scene.intersection_materials) snippet.prepare(im.code, hp, true, {"r"});
+            for (const NamedCode& im : scene.intersection_materials) snippet.prepare(im.code, hp, true, {"r", "ptl_far"});
             if (opts.first_trip)
                 for (const NamedCode& im : scene.intersection_materials) snippet.prepare_first(im.code, hp);
         }
@@ -1060,19 +1094,19 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         for (size_t pos = 0; pos < scene.intersection_materials.size(); ++pos) any_first = any_first || snippet.has_first(scene.intersection_materials[pos].code);
         for (size_t pos = 0; pos < scene.intersection_materials.size(); ++pos) {
             const NamedCode& im = scene.intersection_materials[pos];
-            fns.add_string("PTL_FN SceneIntersectionWithMaterial intersect_material_" + std::to_string(pos) + "(Ray r) {\n");
+            fns.add_string("PTL_FN SceneIntersectionWithMaterial intersect_material_" + std::to_string(pos) + "(Ray r, float ptl_far) {\n(void)ptl_far; ");
             fns.add_identifier_string({"intersection_material", im.name}, snippet(im.code));
             fns.add_string("\n}\n");
-            calls.add_string("hit = intersect_material_" + std::to_string(pos) + "(r);\n");
+            calls.add_string("hit = intersect_material_" + std::to_string(pos) + "(r, ptl_far);\n");
             calls.add_string("if (nearer(result.scene.hit, hit.scene.hit)) { result = hit; }\n\n");
             if (!any_first) continue;
             const bool own = snippet.has_first(im.code);  // (a snippet without ray chains: its general form serves the first trip too)
             if (own) {
-                fns.add_string("PTL_FN SceneIntersectionWithMaterial intersect_material_" + std::to_string(pos) + "_first(Ray r) {\n");
+                fns.add_string("PTL_FN SceneIntersectionWithMaterial intersect_material_" + std::to_string(pos) + "_first(Ray r, float ptl_far) {\n(void)ptl_far; ");
                 fns.add_string(snippet.first(im.code));
                 fns.add_string("\n}\n");
             }
-            calls_first.add_string("hit = intersect_material_" + std::to_string(pos) + (own ? "_first" : "") + "(r);\n");
+            calls_first.add_string("hit = intersect_material_" + std::to_string(pos) + (own ? "_first" : "") + "(r, ptl_far);\n");
             calls_first.add_string("if (nearer(result.scene.hit, hit.scene.hit)) { result = hit; }\n\n");
         }
         gk.first_trip_variants = any_first;
@@ -1138,6 +1172,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     // matrices baked into the source: a matrix product skips the terms whose matrix element is zero (device/ptl_glsl.h `ptl_mterm`)
     if ((opts.specialize_all || opts.specialize_static) && !opts.exact_cr && !opts.fast_math && !gk.full_chains) gk.defines.push_back("PTL_DROP_ZERO_TERMS");
     if (gk.first_trip_variants) gk.defines.push_back("PTL_FIRST_TRIP");
+    if (gk.bounded_snippet_blocks > 0) gk.defines.push_back("PTL_BOUNDED_SNIPPETS");
     return gk;
 }
 

@@ -122,6 +122,13 @@ struct KernelOptions {
     // wave still starts at the camera takes `plane_inv * r.o` of every Flat object from the prologue kernel (a vec4 per plane behind the
     // derived uniforms) -- the same product of the same values, computed once per upload instead of per lane.  Needs derived_uniforms.
     bool first_trip_planes = true;
+    // The caller's distance bound inside the intersection-material snippets (glsl_translate.h `bound_nearer_blocks`): the bounce loop evaluates
+    // scene_intersect() first and hands its hit distance to the snippets, whose `if (nearer(result.scene.hit, H))` blocks then skip candidates
+    // that could never be the nearest hit.  Exact by construction (identical frames); applied per snippet where its shape allows.
+    // OFF by default: measured on the headline scene from five views (profiles/r04/ab_bounded_snippets.jsonl) it gains nothing -- the blocks it
+    // skips are entered by few lanes anyway, and keeping scene_intersect's hit alive across the snippet costs what the skipped work saves
+    // (-2 ... +13 % kernel time).  Kept as an option for scenes whose snippets are dominated by their inside tests.
+    bool bound_snippets = false;
     bool quick_jit = false;  // PTL_QUICK_JIT: compile at -O1 instead of the shipped -O3 (half the JIT time, a 5-20 % slower kernel)
     bool fast_math = false;  // PTL_FAST_MATH: hardware rcp / sqrt / rsq (1 ulp), a/b = a * rcp(b), FMA contraction: tolerance mode, not bit-exact
 };
@@ -146,6 +153,7 @@ struct GeneratedKernel {
     int hoisted_members = 0;            // ... plus this many members holding uniform-only work of the scene snippets (glsl_hoist.h)
     std::vector<DerivedPlane> derived;  // members appended to the block behind uniform_block_size, written on the device
     std::vector<std::pair<std::string, unsigned>> masked;  // run-time matrices whose zero pattern is compiled in: bit 4 * column + row set = may be non-zero
+    int bounded_snippet_blocks = 0;     // `nearer` blocks of intersection-material snippets that take the caller's distance bound (define PTL_BOUNDED_SNIPPETS)
     bool full_chains = false;           // a matrix of the scene is not finite (or KernelOptions::full_chains): no product was shortened
 };
 

@@ -12,6 +12,7 @@
 //   * identifiers that are C++ keywords are renamed
 //   * the tagged-line filter of src/gui/scene.rs:1065-1107 (!FOR_NUMBER! etc.)
 #pragma once
+#include <set>
 #include <string>
 #include <vector>
 
@@ -50,5 +51,26 @@ std::string translate_glsl(const std::string& glsl, bool defer_loop_updates = tr
 // copy out: a mutable global handed to a function that also names it, or one variable handed to two out parameters of a call.
 // `sources`: file-scope GLSL (the scene's library); `bodies`: statement lists that call into it (material / object / intersection snippets).
 void check_out_argument_aliasing(const std::vector<std::string>& sources, const std::vector<std::string>& bodies);
+
+// The caller's distance bound inside an intersection-material snippet (KernelOptions::bound_snippets).  The bounce loop takes the nearest
+// of scene_intersect() and the scene's snippets (src/frag.glsl:114-125); a snippet candidate farther than the hit scene_intersect() has
+// already found can never be that nearest hit, yet the snippets of the reference's scenes spend most of their time deciding whether such
+// candidates lie inside a portal (scenes/portal_in_portal.ron:1133-1191: ten nested copies of two portals, each with an O(copy) walk).
+// For a snippet of the shape
+//     SceneIntersectionWithMaterial R = SceneIntersectionWithMaterial(scene_intersection_none, material_empty());
+//     ... if (nearer(R.scene.hit, H)) { ... R.scene = process_portal_intersection(R.scene, H, ...); ... R.material = ...; } ...
+//     return R;
+// every such condition becomes `nearer(R.scene.hit, H) && !(H.t > ptl_far)` (`ptl_far`: a new parameter of the snippet function).
+// Exact by construction: with S_k the accumulator of the snippet as written after block k and T_k the bounded one's, T_k = S_k whenever
+// S_k.t <= ptl_far and "no hit" otherwise (induction over the blocks: a candidate within the bound meets the same `nearer` verdict in
+// both, one beyond it is accepted as written only when the accumulator holds no nearer hit -- and a hit beyond the bound loses against
+// scene_intersect()'s in the caller either way).  Applied only when the token stream shows that nothing else can carry a skipped block's
+// effect out of it: R appears only in the declaration, the conditions, `R.scene = process_{portal,plane}_intersection(R.scene, H, ..)`,
+// `R.scene.material ==/!=`, `R.material =` and the final `return R;`; a block assigns only R and its own locals, calls no function with
+// out / inout parameters, and stores R.material itself whenever it may leave CUSTOM_MATERIAL behind (the one case in which the caller reads
+// it).  The caller additionally requires that no GLSL of the scene names TELEPORT_SUBSPACE / in_subspace: process_portal_intersection never
+// resets SceneIntersection::in_subspace, so with subspace portals a skipped candidate could leave that flag behind.  Returns the text
+// unchanged (and *bounded = 0) when any of this fails.
+std::string bound_nearer_blocks(const std::string& glsl_body, const std::set<std::string>& functions_with_out_params, int* bounded);
 
 }  // namespace ptl

@@ -40,16 +40,28 @@ using namespace ptl;
 struct ptl_frame_group {
     std::vector<int> devices;
     std::vector<ptl_renderer*> renderers;
-    std::vector<hip::hipStream_t> streams;
-    std::vector<hip::hipEvent_t> begin, end;
-    std::vector<void*> shards;  // PTL_GROUP_COPY_GATHER / RCCL_GATHER: packed rows of rank g in devices[g]'s memory
+    std::vector<hip::hipStream_t> streams;       // per rank: the trace kernels
+    std::vector<hip::hipStream_t> comm_streams;  // per rank: what moves its rows to devices[0] (peer copy, RCCL send / receive, de-interleave)
+    // Two frames may be in flight (ptl_frame_group_submit / _wait): the transfer of frame n runs on the comm streams behind its kernels
+    // while the compute streams already trace frame n + 1 into the other slot's buffers ("gather of frame n overlaps tracing
+    // of frame n+1 on a second stream").
+    struct Slot {
+        std::vector<hip::hipEvent_t> begin, end;  // around rank g's trace kernel (compute stream)
+        std::vector<hip::hipEvent_t> sent;        // rank g's rows have left its shard (comm stream; peer stores: = end)
+        hip::hipEvent_t assembled = nullptr;      // RCCL gather: the de-interleave copies on devices[0] have finished
+        std::vector<void*> shards;                // PTL_GROUP_COPY_GATHER / RCCL_GATHER: packed rows of rank g in devices[g]'s memory
+        void* frame = nullptr;                    // the assembled RGBA8 frame, devices[0]
+        void* gathered = nullptr;                 // RCCL gather: the G packed shards side by side on devices[0], before the de-interleave copies
+        bool in_flight = false, used = false;
+        int ticket = -1;
+    } slots[2];
     size_t shard_bytes = 0;
-    void* frame = nullptr;      // the assembled RGBA8 frame, devices[0]
+    void* frame = nullptr;      // the frame handed out last (one of the slots'), for ptl_frame_group_download
     size_t frame_bytes = 0;
     int width = 0, height = 0;
     int transport = PTL_GROUP_PEER_STORES;
+    int next_ticket = 0;
     std::vector<hip::ncclComm_t> comms;  // PTL_GROUP_RCCL_GATHER: one communicator per rank (ncclCommInitAll)
-    void* gathered = nullptr;            //   the G packed shards side by side on devices[0], before the de-interleave copies
 };
 
 namespace {
@@ -62,23 +74,37 @@ int hip_fail(const hip::Runtime* rt, int e, const char* what) {
 }
 
 void release_buffers(ptl_frame_group* g, const hip::Runtime* rt) {
-    if (g->frame) {
-        rt->hipSetDevice(g->devices[0]);
-        rt->hipFree(g->frame);
-        g->frame = nullptr;
-    }
-    for (size_t k = 0; k < g->shards.size(); ++k)
-        if (g->shards[k]) {
-            rt->hipSetDevice(g->devices[k]);
-            rt->hipFree(g->shards[k]);
-            g->shards[k] = nullptr;
+    for (auto& slot : g->slots) {
+        if (slot.frame) {
+            rt->hipSetDevice(g->devices[0]);
+            rt->hipFree(slot.frame);
+            slot.frame = nullptr;
         }
-    if (g->gathered) {
-        rt->hipSetDevice(g->devices[0]);
-        rt->hipFree(g->gathered);
-        g->gathered = nullptr;
+        for (size_t k = 0; k < slot.shards.size(); ++k)
+            if (slot.shards[k]) {
+                rt->hipSetDevice(g->devices[k]);
+                rt->hipFree(slot.shards[k]);
+                slot.shards[k] = nullptr;
+            }
+        if (slot.gathered) {
+            rt->hipSetDevice(g->devices[0]);
+            rt->hipFree(slot.gathered);
+            slot.gathered = nullptr;
+        }
+        slot.used = false;
     }
+    g->frame = nullptr;
     g->frame_bytes = g->shard_bytes = 0;
+}
+
+// everything that has been enqueued for every rank has finished (before buffers are freed or re-sized, and on errors)
+void drain_all(ptl_frame_group* g, const hip::Runtime* rt) {
+    for (size_t k = 0; k < g->streams.size(); ++k) {
+        rt->hipSetDevice(g->devices[k]);
+        if (g->streams[k]) rt->hipStreamSynchronize(g->streams[k]);
+        if (k < g->comm_streams.size() && g->comm_streams[k]) rt->hipStreamSynchronize(g->comm_streams[k]);
+    }
+    for (auto& slot : g->slots) slot.in_flight = false;
 }
 
 int nccl_fail(const hip::Rccl* nc, int e, const char* what) {
@@ -128,17 +154,28 @@ extern "C" int ptl_frame_group_create(ptl_scene* scene, const int* devices, int 
         rc = ptl_renderer_create(scene, devices[k], asset_root, flags, &r, log, log_cap);  // the code-object cache makes ranks 1.. a module load
         if (rc != PTL_OK) break;
         g->renderers.push_back(r);
-        hip::hipStream_t s = nullptr;
-        hip::hipEvent_t b = nullptr, e = nullptr;
+        hip::hipStream_t s = nullptr, c = nullptr;
         rc = hip_fail(rt, rt->hipSetDevice(devices[k]), "hipSetDevice");
         if (rc == PTL_OK) rc = hip_fail(rt, rt->hipStreamCreateWithFlags(&s, hip::kStreamNonBlocking), "hipStreamCreateWithFlags");
-        if (rc == PTL_OK) rc = hip_fail(rt, rt->hipEventCreate(&b), "hipEventCreate");
-        if (rc == PTL_OK) rc = hip_fail(rt, rt->hipEventCreate(&e), "hipEventCreate");
+        if (rc == PTL_OK) rc = hip_fail(rt, rt->hipStreamCreateWithFlags(&c, hip::kStreamNonBlocking), "hipStreamCreateWithFlags");
         g->streams.push_back(s);
-        g->begin.push_back(b);
-        g->end.push_back(e);
+        g->comm_streams.push_back(c);
+        for (auto& slot : g->slots) {
+            hip::hipEvent_t b = nullptr, e = nullptr, t = nullptr;
+            if (rc == PTL_OK) rc = hip_fail(rt, rt->hipEventCreate(&b), "hipEventCreate");
+            if (rc == PTL_OK) rc = hip_fail(rt, rt->hipEventCreate(&e), "hipEventCreate");
+            if (rc == PTL_OK) rc = hip_fail(rt, rt->hipEventCreateWithFlags(&t, hip::kEventDisableTiming), "hipEventCreateWithFlags");
+            slot.begin.push_back(b);
+            slot.end.push_back(e);
+            slot.sent.push_back(t);
+        }
     }
-    g->shards.assign(n_devices, nullptr);
+    for (auto& slot : g->slots) slot.shards.assign(n_devices, nullptr);
+    if (rc == PTL_OK) {
+        rc = hip_fail(rt, rt->hipSetDevice(devices[0]), "hipSetDevice");
+        for (auto& slot : g->slots)
+            if (rc == PTL_OK) rc = hip_fail(rt, rt->hipEventCreateWithFlags(&slot.assembled, hip::kEventDisableTiming), "hipEventCreateWithFlags");
+    }
     if (rc == PTL_OK && transport == PTL_GROUP_RCCL_GATHER) {
         const hip::Rccl* nc = hip::rccl(&err);
         if (!nc) {
@@ -199,8 +236,8 @@ extern "C" int ptl_frame_group_update(ptl_frame_group* g, double seconds) {
     return PTL_OK;
 }
 
-extern "C" int ptl_frame_group_draw(ptl_frame_group* g, int width, int height, void** device_rgba8, float* kernel_ms) {
-    if (!g || width <= 0 || height <= 0) return PTL_ERR_INVALID;
+extern "C" int ptl_frame_group_submit(ptl_frame_group* g, int width, int height, int* ticket) {
+    if (!g || width <= 0 || height <= 0 || !ticket) return PTL_ERR_INVALID;
     const hip::Runtime* rt = hip::runtime(nullptr);
     if (!rt) return PTL_ERR_NO_DEVICE;
     const int n = (int)g->renderers.size();
@@ -209,14 +246,28 @@ extern "C" int ptl_frame_group_draw(ptl_frame_group* g, int width, int height, v
     const size_t frame_bytes = (size_t)blocks * 8 * pitch;  // whole blocks: the strided copy of a ragged last block stays inside
     const size_t shard_bytes = (size_t)((blocks + n - 1) / n) * 8 * pitch;
     const bool packed = g->transport != PTL_GROUP_PEER_STORES;  // ranks render packed shards in their own memory
+    ptl_frame_group::Slot& slot = g->slots[g->next_ticket & 1];
+    if (slot.in_flight) {
+        set_last_error("ptl_frame_group_submit: two frames are in flight already; ptl_frame_group_wait for ticket " + std::to_string(slot.ticket) + " first");
+        return PTL_ERR_INVALID;
+    }
     if (frame_bytes != g->frame_bytes || (packed && shard_bytes != g->shard_bytes)) {
+        for (auto& sl : g->slots)
+            if (sl.in_flight) {  // its buffers are about to be re-allocated
+                set_last_error("ptl_frame_group_submit: another frame size while ticket " + std::to_string(sl.ticket) + " is in flight; ptl_frame_group_wait for it first");
+                return PTL_ERR_INVALID;
+            }
+        drain_all(g, rt);
         release_buffers(g, rt);
-        int rc = hip_fail(rt, rt->hipSetDevice(g->devices[0]), "hipSetDevice");
-        if (rc == PTL_OK) rc = hip_fail(rt, rt->hipMalloc(&g->frame, frame_bytes), "hipMalloc(frame)");
-        if (rc == PTL_OK && g->transport == PTL_GROUP_RCCL_GATHER) rc = hip_fail(rt, rt->hipMalloc(&g->gathered, shard_bytes * (size_t)n), "hipMalloc(gathered shards)");
-        for (int k = 0; k < n && rc == PTL_OK && packed; ++k) {
-            rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice");
-            if (rc == PTL_OK) rc = hip_fail(rt, rt->hipMalloc(&g->shards[k], shard_bytes), "hipMalloc(shard)");
+        int rc = PTL_OK;
+        for (auto& sl : g->slots) {
+            if (rc == PTL_OK) rc = hip_fail(rt, rt->hipSetDevice(g->devices[0]), "hipSetDevice");
+            if (rc == PTL_OK) rc = hip_fail(rt, rt->hipMalloc(&sl.frame, frame_bytes), "hipMalloc(frame)");
+            if (rc == PTL_OK && g->transport == PTL_GROUP_RCCL_GATHER) rc = hip_fail(rt, rt->hipMalloc(&sl.gathered, shard_bytes * (size_t)n), "hipMalloc(gathered shards)");
+            for (int k = 0; k < n && rc == PTL_OK && packed; ++k) {
+                rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice");
+                if (rc == PTL_OK) rc = hip_fail(rt, rt->hipMalloc(&sl.shards[k], shard_bytes), "hipMalloc(shard)");
+            }
         }
         if (rc != PTL_OK) {
             release_buffers(g, rt);
@@ -227,69 +278,110 @@ extern "C" int ptl_frame_group_draw(ptl_frame_group* g, int width, int height, v
     }
     g->width = width;
     g->height = height;
-    // A failure on rank k must not leave the launches of ranks 0..k-1 in flight into g->frame / g->shards: the next draw may free them
-    // (release_buffers on a size change).  Every early return below first drains what has been started.
-    auto drain = [&](int started, int rc) {
-        for (int j = 0; j < started; ++j) {
-            rt->hipSetDevice(g->devices[j]);
-            rt->hipStreamSynchronize(g->streams[j]);
-        }
+    // A failure on rank k must not leave launches in flight into buffers the next call may free: every early return drains first.
+    auto fail = [&](int rc) {
+        drain_all(g, rt);
         return rc;
     };
     for (int k = 0; k < n; ++k) {
-        if (int rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice"); rc != PTL_OK) return drain(k, rc);
-        rt->hipEventRecord(g->begin[k], g->streams[k]);
+        if (int rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice"); rc != PTL_OK) return fail(rc);
+        // this slot's shard of two frames ago must have left before the kernel overwrites it (a no-op wait in the steady state)
+        if (slot.used && packed)
+            if (int rc = hip_fail(rt, rt->hipStreamWaitEvent(g->streams[k], slot.sent[k], 0), "hipStreamWaitEvent(shard sent)"); rc != PTL_OK) return fail(rc);
+        rt->hipEventRecord(slot.begin[k], g->streams[k]);
         if (g->transport == PTL_GROUP_PEER_STORES) {
             ptl_frame f{width, height, k, n, 1};
-            if (int rc = ptl_renderer_draw(g->renderers[k], &f, g->frame, nullptr, nullptr, g->streams[k], nullptr); rc != PTL_OK) return drain(k + 1, rc);
-            rt->hipEventRecord(g->end[k], g->streams[k]);
+            if (int rc = ptl_renderer_draw(g->renderers[k], &f, slot.frame, nullptr, nullptr, g->streams[k], nullptr); rc != PTL_OK) return fail(rc);
+            rt->hipEventRecord(slot.end[k], g->streams[k]);
+            rt->hipEventRecord(slot.sent[k], g->streams[k]);  // the stores ARE the transfer
         } else {
             ptl_frame f{width, height, k, n, 0};
-            if (int rc = ptl_renderer_draw(g->renderers[k], &f, g->shards[k], nullptr, nullptr, g->streams[k], nullptr); rc != PTL_OK) return drain(k + 1, rc);
-            rt->hipEventRecord(g->end[k], g->streams[k]);  // kernel time; the copy below is behind it on the same stream
+            if (int rc = ptl_renderer_draw(g->renderers[k], &f, slot.shards[k], nullptr, nullptr, g->streams[k], nullptr); rc != PTL_OK) return fail(rc);
+            rt->hipEventRecord(slot.end[k], g->streams[k]);
+            // the transfer runs on the rank's comm stream, behind this kernel -- the compute stream is free for the next frame's trace
+            if (int rc = hip_fail(rt, rt->hipStreamWaitEvent(g->comm_streams[k], slot.end[k], 0), "hipStreamWaitEvent(trace done)"); rc != PTL_OK) return fail(rc);
             const int my_blocks = blocks > k ? (blocks - k + n - 1) / n : 0;
             if (my_blocks > 0 && g->transport == PTL_GROUP_COPY_GATHER) {
                 // shard block j -> frame block j * n + k: source pitch one block, destination pitch n blocks, `my_blocks` rows of 8 * pitch bytes
-                char* dst = static_cast<char*>(g->frame) + (size_t)k * 8 * pitch;
-                if (int rc = hip_fail(rt, rt->hipMemcpy2DAsync(dst, (size_t)n * 8 * pitch, g->shards[k], 8 * pitch, 8 * pitch, (size_t)my_blocks,
-                                                               hip::kMemcpyDefault, g->streams[k]),
+                char* dst = static_cast<char*>(slot.frame) + (size_t)k * 8 * pitch;
+                if (int rc = hip_fail(rt, rt->hipMemcpy2DAsync(dst, (size_t)n * 8 * pitch, slot.shards[k], 8 * pitch, 8 * pitch, (size_t)my_blocks,
+                                                               hip::kMemcpyDefault, g->comm_streams[k]),
                                       "hipMemcpy2DAsync(shard -> frame)");
                     rc != PTL_OK)
-                    return drain(k + 1, rc);
+                    return fail(rc);
             }
+            if (g->transport == PTL_GROUP_COPY_GATHER) rt->hipEventRecord(slot.sent[k], g->comm_streams[k]);
         }
     }
     if (g->transport == PTL_GROUP_RCCL_GATHER) {
-        // ONE collective: every rank sends its packed shard to rank 0 (behind its kernel, on its stream), rank 0 receives them side by
+        // ONE collective: every rank sends its packed shard to rank 0 (behind its kernel, on its comm stream), rank 0 receives them side by
         // side -- a gather as RCCL composes it from point-to-point calls in a group; over xGMI that is G - 1 direct transfers into rank 0.
         const hip::Rccl* nc = hip::rccl(nullptr);
         int rc = nccl_fail(nc, nc->ncclGroupStart(), "ncclGroupStart");
-        for (int k = 0; k < n && rc == PTL_OK; ++k) rc = nccl_fail(nc, nc->ncclSend(g->shards[k], shard_bytes, hip::kNcclUint8, 0, g->comms[k], g->streams[k]), "ncclSend(shard)");
+        for (int k = 0; k < n && rc == PTL_OK; ++k) rc = nccl_fail(nc, nc->ncclSend(slot.shards[k], shard_bytes, hip::kNcclUint8, 0, g->comms[k], g->comm_streams[k]), "ncclSend(shard)");
         for (int k = 0; k < n && rc == PTL_OK; ++k)
-            rc = nccl_fail(nc, nc->ncclRecv(static_cast<char*>(g->gathered) + (size_t)k * shard_bytes, shard_bytes, hip::kNcclUint8, k, g->comms[0], g->streams[0]), "ncclRecv(shard)");
+            rc = nccl_fail(nc, nc->ncclRecv(static_cast<char*>(slot.gathered) + (size_t)k * shard_bytes, shard_bytes, hip::kNcclUint8, k, g->comms[0], g->comm_streams[0]), "ncclRecv(shard)");
         int end = nc->ncclGroupEnd();  // always closed, also after a failed call inside the group
         if (rc == PTL_OK) rc = nccl_fail(nc, end, "ncclGroupEnd");
-        if (rc != PTL_OK) return drain(n, rc);
-        // de-interleave on rank 0, behind the receives on its stream: shard k's block j -> frame block j * n + k
-        if (int rc2 = hip_fail(rt, rt->hipSetDevice(g->devices[0]), "hipSetDevice"); rc2 != PTL_OK) return drain(n, rc2);
+        if (rc != PTL_OK) return fail(rc);
+        for (int k = 0; k < n; ++k) {
+            rt->hipSetDevice(g->devices[k]);
+            rt->hipEventRecord(slot.sent[k], g->comm_streams[k]);
+        }
+        // de-interleave on rank 0, behind the receives on its comm stream: shard k's block j -> frame block j * n + k
+        if (int rc2 = hip_fail(rt, rt->hipSetDevice(g->devices[0]), "hipSetDevice"); rc2 != PTL_OK) return fail(rc2);
         for (int k = 0; k < n; ++k) {
             const int my_blocks = blocks > k ? (blocks - k + n - 1) / n : 0;
             if (my_blocks == 0) continue;
-            char* dst = static_cast<char*>(g->frame) + (size_t)k * 8 * pitch;
-            const char* src = static_cast<const char*>(g->gathered) + (size_t)k * shard_bytes;
-            if (int rc2 = hip_fail(rt, rt->hipMemcpy2DAsync(dst, (size_t)n * 8 * pitch, src, 8 * pitch, 8 * pitch, (size_t)my_blocks, hip::kMemcpyDefault, g->streams[0]),
+            char* dst = static_cast<char*>(slot.frame) + (size_t)k * 8 * pitch;
+            const char* src = static_cast<const char*>(slot.gathered) + (size_t)k * shard_bytes;
+            if (int rc2 = hip_fail(rt, rt->hipMemcpy2DAsync(dst, (size_t)n * 8 * pitch, src, 8 * pitch, 8 * pitch, (size_t)my_blocks, hip::kMemcpyDefault, g->comm_streams[0]),
                                    "hipMemcpy2DAsync(gathered shard -> frame)");
                 rc2 != PTL_OK)
-                return drain(n, rc2);
+                return fail(rc2);
         }
+        rt->hipEventRecord(slot.assembled, g->comm_streams[0]);
     }
-    for (int k = 0; k < n; ++k) {
-        if (int rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice"); rc != PTL_OK) return drain(n, rc);
-        if (int rc = hip_fail(rt, rt->hipStreamSynchronize(g->streams[k]), "hipStreamSynchronize(rank)"); rc != PTL_OK) return drain(n, rc);
-        if (kernel_ms) rt->hipEventElapsedTime(&kernel_ms[k], g->begin[k], g->end[k]);
-    }
-    if (device_rgba8) *device_rgba8 = g->frame;
+    slot.in_flight = slot.used = true;
+    slot.ticket = g->next_ticket++;
+    *ticket = slot.ticket;
     return PTL_OK;
+}
+
+extern "C" int ptl_frame_group_wait(ptl_frame_group* g, int ticket, void** device_rgba8, float* kernel_ms) {
+    if (!g || ticket < 0) return PTL_ERR_INVALID;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!rt) return PTL_ERR_NO_DEVICE;
+    ptl_frame_group::Slot& slot = g->slots[ticket & 1];
+    if (!slot.in_flight || slot.ticket != ticket) {
+        set_last_error("ptl_frame_group_wait: no frame with ticket " + std::to_string(ticket) + " is in flight");
+        return PTL_ERR_INVALID;
+    }
+    const int n = (int)g->renderers.size();
+    for (int k = 0; k < n; ++k) {
+        if (int rc = hip_fail(rt, rt->hipSetDevice(g->devices[k]), "hipSetDevice"); rc != PTL_OK) return rc;
+        if (int rc = hip_fail(rt, rt->hipEventSynchronize(slot.sent[k]), "hipEventSynchronize(rank)"); rc != PTL_OK) return rc;
+        if (kernel_ms) rt->hipEventElapsedTime(&kernel_ms[k], slot.begin[k], slot.end[k]);
+    }
+    if (g->transport == PTL_GROUP_RCCL_GATHER) {
+        rt->hipSetDevice(g->devices[0]);
+        if (int rc = hip_fail(rt, rt->hipEventSynchronize(slot.assembled), "hipEventSynchronize(assembled)"); rc != PTL_OK) return rc;
+    }
+    slot.in_flight = false;
+    g->frame = slot.frame;
+    if (device_rgba8) *device_rgba8 = slot.frame;
+    return PTL_OK;
+}
+
+extern "C" int ptl_frame_group_draw(ptl_frame_group* g, int width, int height, void** device_rgba8, float* kernel_ms) {
+    if (!g) return PTL_ERR_INVALID;
+    // (a caller that mixes the two forms gets the frames in order: whatever is in flight is finished first)
+    for (int older = g->next_ticket - 2; older < g->next_ticket; ++older)
+        if (older >= 0 && g->slots[older & 1].in_flight && g->slots[older & 1].ticket == older)
+            if (int rc = ptl_frame_group_wait(g, older, nullptr, nullptr); rc != PTL_OK) return rc;
+    int ticket = -1;
+    if (int rc = ptl_frame_group_submit(g, width, height, &ticket); rc != PTL_OK) return rc;
+    return ptl_frame_group_wait(g, ticket, device_rgba8, kernel_ms);
 }
 
 extern "C" int ptl_frame_group_download(ptl_frame_group* g, uint8_t* host_rgba8) {
@@ -302,13 +394,10 @@ extern "C" int ptl_frame_group_download(ptl_frame_group* g, uint8_t* host_rgba8)
 extern "C" void ptl_frame_group_destroy(ptl_frame_group* g) {
     if (!g) return;
     const hip::Runtime* rt = hip::runtime(nullptr);
-    for (ptl_renderer* r : g->renderers) ptl_renderer_destroy(r);  // first: a kernel handle waits for its last launch's stream
+    if (rt) drain_all(g, rt);  // before the renderers go: frames may still be in flight
+    for (ptl_renderer* r : g->renderers) ptl_renderer_destroy(r);  // a kernel handle waits for its last launch's stream
     g->renderers.clear();
     if (rt && !g->comms.empty()) {  // before the streams the collectives ran on
-        for (size_t k = 0; k < g->streams.size(); ++k) {
-            rt->hipSetDevice(g->devices[k]);
-            if (g->streams[k]) rt->hipStreamSynchronize(g->streams[k]);
-        }
         if (const hip::Rccl* nc = hip::rccl(nullptr))
             for (hip::ncclComm_t c : g->comms)
                 if (c) nc->ncclCommDestroy(c);
@@ -317,13 +406,16 @@ extern "C" void ptl_frame_group_destroy(ptl_frame_group* g) {
     if (rt) {
         for (size_t k = 0; k < g->streams.size(); ++k) {
             rt->hipSetDevice(g->devices[k]);
-            if (g->streams[k]) {
-                rt->hipStreamSynchronize(g->streams[k]);
-                rt->hipStreamDestroy(g->streams[k]);
+            if (g->streams[k]) rt->hipStreamDestroy(g->streams[k]);
+            if (k < g->comm_streams.size() && g->comm_streams[k]) rt->hipStreamDestroy(g->comm_streams[k]);
+            for (auto& slot : g->slots) {
+                if (k < slot.begin.size() && slot.begin[k]) rt->hipEventDestroy(slot.begin[k]);
+                if (k < slot.end.size() && slot.end[k]) rt->hipEventDestroy(slot.end[k]);
+                if (k < slot.sent.size() && slot.sent[k]) rt->hipEventDestroy(slot.sent[k]);
             }
-            if (k < g->begin.size() && g->begin[k]) rt->hipEventDestroy(g->begin[k]);
-            if (k < g->end.size() && g->end[k]) rt->hipEventDestroy(g->end[k]);
         }
+        for (auto& slot : g->slots)
+            if (slot.assembled) rt->hipEventDestroy(slot.assembled);
         release_buffers(g, rt);
     }
     delete g;

@@ -110,7 +110,7 @@ def test_first_trip_snippet_variants_change_no_bit(gpu, scene_file, spec):
     frames = {}
     for label, flags in (("first", spec), ("general", spec | pa.FLAG_NO_FIRST_TRIP)):
         scene = pa.Scene.from_file(path)
-        assert ("_first(Ray r) {" in scene.generate_source(flags)) == (label == "first")
+        assert ("_first(Ray r, float ptl_far) {" in scene.generate_source(flags)) == (label == "first")
         r = pa.SceneRenderer(scene, device=0, flags=flags, **extra)
         r.set_option("render_depth", 20)
         got = [r.draw(w, h, rgba32f=True)["rgba32f"].copy()]
@@ -180,6 +180,56 @@ def test_frame_group_rccl_gather_on_the_devices_of_this_box(gpu):
     del g
     with pytest.raises(pa.PortalError, match="listed twice"):
         pa.FrameGroup(pa.Scene.from_file(pa.scene_path("monoportal")), [0, 0], transport=pa.GROUP_RCCL_GATHER)
+
+
+@pytest.mark.parametrize("transport", ["stores", "copy", "rccl"])
+def test_frame_group_pipelines_two_frames_in_flight(gpu, transport):
+    """ptl_frame_group_submit / _wait (the gather of frame n overlaps the trace of frame n + 1): seven frames of a moving camera
+    with two in flight at any time -- each rank's transfer on its second stream, shards / gather buffer / frame double-buffered -- must be
+    the frames a single renderer draws one by one, byte for byte; a third submit before the oldest wait is refused, a wait for a ticket
+    that is not in flight too, a size change in the middle drains and re-allocates, and ptl_frame_group_draw finishes what is in flight."""
+    pa = gpu
+    if transport == "rccl":
+        devices, kind = list(range(pa.device_count())), pa.GROUP_RCCL_GATHER
+    else:
+        devices, kind = [0, 0, 0], (pa.GROUP_PEER_STORES if transport == "stores" else pa.GROUP_COPY_GATHER)
+    single = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("monoportal")), device=0)
+    single.set_option("render_depth", 20)
+    g = pa.FrameGroup(pa.Scene.from_file(pa.scene_path("monoportal")), devices, transport=kind)
+    g.set_option("render_depth", 20)
+    cams = [((0.05 * k, 0.1, -0.3 + 0.02 * k), 0.9 + 0.1 * k, 1.2, 3.1 - 0.1 * k) for k in range(7)]
+    sizes = [(640, 360)] * 4 + [(200, 100)] * 3  # the size changes while a frame is in flight
+    want = []
+    for cam, (w, h) in zip(cams, sizes):
+        single.set_camera(*cam)
+        want.append(single.draw(w, h)["rgba8"].copy())
+    tickets, got = [], []
+    for k, (cam, (w, h)) in enumerate(zip(cams, sizes)):
+        g.set_camera(*cam)
+        if k == 4:  # another size: refused while the frame of the old size is in flight; its wait comes first
+            with pytest.raises(pa.PortalError, match="another frame size"):
+                g.submit(w, h)
+            got.append(g.wait(tickets.pop(0))["rgba8"].copy())
+        tickets.append(g.submit(w, h))
+        if len(tickets) == 2:
+            if k == 1:
+                with pytest.raises(pa.PortalError, match="two frames are in flight"):
+                    g.submit(w, h)
+            out = g.wait(tickets.pop(0))
+            assert len(out["kernel_ms"]) == len(devices) and all(ms > 0 for ms in out["kernel_ms"])
+            got.append(out["rgba8"].copy())
+    while tickets:
+        got.append(g.wait(tickets.pop(0))["rgba8"].copy())
+    assert len(got) == len(want)
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert a.shape == b.shape and np.array_equal(a, b), k
+    with pytest.raises(pa.PortalError, match="no frame with ticket"):
+        g.wait(3)
+    t = g.submit(640, 360)  # (the last camera) ... and the synchronous form behind a frame in flight
+    single_last = single.draw(640, 360)["rgba8"]
+    assert np.array_equal(g.draw(640, 360)["rgba8"], single_last)
+    with pytest.raises(pa.PortalError, match="no frame with ticket"):
+        g.wait(t)  # draw() has finished it
 
 
 def test_flipped_mode_switch_with_background_rejit_draws_the_same_bits_meanwhile(gpu, tmp_path, monkeypatch):

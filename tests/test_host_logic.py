@@ -1442,3 +1442,87 @@ def test_zero_pattern_probes_are_reused_while_the_state_they_depend_on_stands(pa
     fresh = pa.Scene.from_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "corpus", "scenes", "portal_in_portal_plus_ultra.ron"))
     fresh.set_camera_matrix(np.array([[0.0, 0, 1, 0.3], [0, 1, 0, 0.2], [-1, 0, 0, 0.1], [0, 0, 0, 1]]))
     assert fresh.generate_source(ints) == b and a.count("#define PTL_MASK_") == b.count("#define PTL_MASK_")
+
+
+_BOUND_OK = """vec3 normal_a = -get_normal(a_mat);
+SurfaceIntersection hit_a = plane_intersect(r, a_mat_inv, normal_a);
+SceneIntersectionWithMaterial result = SceneIntersectionWithMaterial(scene_intersection_none, material_empty());
+for (int size = 0; size < 4; size++) {
+  if (nearer(result.scene.hit, hit_a)) {
+    int is_inside = inside_a(r.o + r.d * hit_a.t, hit_a.u, hit_a.v, size);
+    if (is_inside != NOT_INSIDE) {
+      result.scene = process_portal_intersection(result.scene, hit_a, is_inside, CUSTOM_MATERIAL);
+      if (result.scene.material == CUSTOM_MATERIAL) {
+        result.material = material_teleport_transformed(offset_ray(r, hit_a.t), vec3(1.));
+      }
+    }
+  }
+}
+return result;"""
+
+
+def test_distance_bound_is_added_only_to_snippets_whose_shape_allows_it(pa):
+    """glsl_translate.h `bound_nearer_blocks`: the accumulator pattern of the reference's intersection-material snippets gets the caller's
+    bound; anything through which a skipped candidate could still be seen -- the accumulator read outside its blocks, an else branch, a store
+    of something other than the tested hit, an outer local assigned in a block, a function with out parameters, a material the block does not
+    store itself, the previous candidate's id read in front of the store, another initial value -- leaves the text exactly as written."""
+    text, n = pa.bound_glsl(_BOUND_OK)
+    assert n == 1 and "if (nearer(result.scene.hit, hit_a) && !(hit_a.t > ptl_far)) {" in text
+    assert text.replace(" && !(hit_a.t > ptl_far)", "") == _BOUND_OK
+    refused = {
+        "read outside": _BOUND_OK.replace("return result;", "if (result.scene.hit.hit) { result.material = material_empty(); }\nreturn result;"),
+        "else branch": _BOUND_OK.replace("  }\n}\nreturn", "  } else { size += 1; }\n}\nreturn"),
+        "stores another hit": _BOUND_OK.replace("process_portal_intersection(result.scene, hit_a,", "process_portal_intersection(result.scene, other_hit,"),
+        "outer local assigned": _BOUND_OK.replace("int is_inside = inside_a(", "normal_a = vec3(0.); int is_inside = inside_a("),
+        "outer local incremented": _BOUND_OK.replace("int is_inside = inside_a(", "size++; int is_inside = inside_a("),
+        "material not stored": _BOUND_OK.replace("        result.material = material_teleport_transformed(offset_ray(r, hit_a.t), vec3(1.));\n", ""),
+        "id read before the store": _BOUND_OK.replace("    int is_inside = inside_a(", "    if (result.scene.material == CUSTOM_MATERIAL) { int k = 1; }\n    int is_inside = inside_a("),
+        "other initial value": _BOUND_OK.replace("SceneIntersectionWithMaterial(scene_intersection_none, material_empty());", "first_guess(r);"),
+        "whole accumulator assigned": _BOUND_OK.replace("      result.scene = process_portal_intersection(", "      result = other(r); result.scene = process_portal_intersection("),
+        "not the last statement": _BOUND_OK.replace("return result;", "return result;\nreturn other(r);"),
+        "nearer of another shape": _BOUND_OK.replace("nearer(result.scene.hit, hit_a)", "nearer(result.scene.hit, hits[size])"),
+    }
+    for why, body in refused.items():
+        assert body != _BOUND_OK, why
+        assert pa.bound_glsl(body) == (body, 0), why
+    assert pa.bound_glsl(_BOUND_OK, out_functions=["inside_a"]) == (_BOUND_OK, 0)
+    assert pa.bound_glsl(_BOUND_OK, out_functions=["something_else"])[1] == 1
+    # scene level: the headline scene's snippet qualifies (both copies: general and first-trip); a scene that names subspace portals does not
+    # (opt-in, FLAG_BOUNDED_SNIPPETS: on the headline scene it measures no gain, profiles/r04/ab_bounded_snippets.jsonl)
+    pip = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    src = pip.generate_source(pa.FLAG_BOUNDED_SNIPPETS)
+    assert src.count("&& !(hit_a.t > ptl_far)") == 2 and src.count("&& !(hit_b.t > ptl_far)") == 2 and "PTL_BOUNDED_SNIPPETS" in pip.generated_defines()
+    src = pip.generate_source(0)
+    assert "> ptl_far)" not in src and "PTL_BOUNDED_SNIPPETS" not in pip.generated_defines()
+    ultra = pa.Scene.from_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "corpus", "scenes", "portal_in_portal_plus_ultra.ron"))
+    assert "> ptl_far)" not in ultra.generate_source(pa.FLAG_BOUNDED_SNIPPETS) and "PTL_BOUNDED_SNIPPETS" not in ultra.generated_defines()
+
+
+@pytest.mark.parametrize("flags_name", ["dynamic", "baked"])
+def test_bounded_snippets_draw_the_frames_of_the_snippets_as_written(pa, flags_name):
+    """The bounce loop with the bound (FLAG_BOUNDED_SNIPPETS: scene_intersect first, its hit distance handed to the snippet) against the snippet as written,
+    evaluated first: the same bits, from the scene's own camera and from four views that look into, along and out of the nested portals
+    (where the snippet's candidates ARE the nearest hits) -- and the numpy oracle, which knows nothing of either order, agrees."""
+    from oracle import host_build as hb
+    from oracle.portal_oracle import Oracle
+
+    flags = 0 if flags_name == "dynamic" else (pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
+    views = [None, ((0.0, 0.0, 0.0), 0.2, 1.5, 1.6), ((0.3, -0.1, 0.2), 2.8, 1.0, 2.4), ((0.1, 0.3, -0.2), 1.2, 1.4, 3.0), ((0.0, 0.1, 0.0), 4.0, 1.7, 0.8)]
+    w, h = 96, 54
+    for view in views:
+        frames = []
+        for extra in (pa.FLAG_BOUNDED_SNIPPETS, 0):
+            sc = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+            r = pa.SceneRenderer(sc, device=-1, flags=0)
+            r.set_option("render_depth", 30)
+            if view:
+                r.set_camera(*view)
+            frames.append(hb.host_kernel_for(r, sc, w, h, flags=flags | extra).render(w, h)["rgba32f"].copy())
+        assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)), view
+        if flags_name == "dynamic":
+            o = Oracle(pa.scene_path("portal_in_portal"))
+            o.options["render_depth"] = 30
+            if view:
+                o.camera = dict(look_at=view[0], alpha=view[1], beta=view[2], r=view[3])
+            want = o.render(w, h)
+            assert np.array_equal(frames[0].view(np.uint32), want["rgba32f"].view(np.uint32)), view

@@ -104,7 +104,7 @@ if __name__ == "__main__":
         if src is None:
             continue
         # the defines the generator asks the JIT for (codegen.cpp: first-trip copies, zero terms of baked matrices)
-        defines = (["PTL_FIRST_TRIP"] if "_first(Ray r) {" in src else []) + (["PTL_DROP_ZERO_TERMS"] if flags & 4 else [])
+        defines = (["PTL_FIRST_TRIP"] if "_first(Ray r, float ptl_far) {" in src else []) + (["PTL_DROP_ZERO_TERMS"] if flags & 4 else [])
         k = pa.Kernel(src, layout, size, device=device, defines=defines)
         if device < 0:
             continue

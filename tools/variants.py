@@ -143,6 +143,9 @@ VARIANTS = {
     "r3_ints_nomasks": "SPECIALIZE NO_MASKS",
     "r3_all_peel": "SPECIALIZE_ALL -DPTL_PEEL_FIRST_TRIP", "r3_ints_peel": "SPECIALIZE -DPTL_PEEL_FIRST_TRIP", "r3_dyn_peel": "-DPTL_PEEL_FIRST_TRIP",
     "r3_all_w4_zerofold": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -fno-signed-zeros -fno-honor-nans",
+    # round 4: the NaN guard of 1/x and sqrt as one v_med3_f32 (default) against the compare + select pair of round 3
+    "r4_all": "SPECIALIZE_ALL", "r4_all_w4": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4", "r4_all_cmpguard": "SPECIALIZE_ALL -DPTL_CMP_GUARD", "r4_all_w4_cmpguard": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -DPTL_CMP_GUARD",
+    "r4_ints": "SPECIALIZE", "r4_ints_cmpguard": "SPECIALIZE -DPTL_CMP_GUARD", "r4_dyn": "", "r4_dyn_cmpguard": "-DPTL_CMP_GUARD",
 }
 CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
 
