@@ -674,10 +674,12 @@ def main():
     # (Skipped together with the CPU baseline, i.e. in the profiling runs: their per-kernel statistics are about the timed launches.)
     # ... and with only the Bool / Int scene uniforms baked (FLAG_SPECIALIZE_INTS): what an animation whose float uniforms and matrices
     # move every frame runs on without a rebuild per frame.
-    dynamic_ms = ints_ms = dynamic_build = ints_build = None
+    # ... and with NO value baked but the zero patterns of the matrices and the renderer's mode switches compiled in (FLAG_SPECIALIZE_PATTERNS):
+    # valid while the patterns hold, i.e. for every frame of a clip whose portals move without leaving their planes' axes.
+    dynamic_ms = ints_ms = patterns_ms = dynamic_build = ints_build = patterns_build = None
     if world == 1 and args.specialize != 0 and not args.no_cpu_baseline:
         try:
-            for base_flags in (0, pa.FLAG_SPECIALIZE_INTS):
+            for base_flags in (0, pa.FLAG_SPECIALIZE_INTS, pa.FLAG_SPECIALIZE_PATTERNS):
                 timings = []
                 # the two register budgets that matter for this kernel, at the JIT's optimisation level (-O3 without SLP) and at rounds 1-2's
                 # -O1: the un-specialised headline kernel is the one measured case where -O1 is faster (kernel.cpp `opt_level`)
@@ -701,8 +703,10 @@ def main():
                     del plain
                 if base_flags == 0:
                     dynamic_ms, dynamic_build = min(timings)[1:]  # a spill-free build first, then the faster
-                else:
+                elif base_flags == pa.FLAG_SPECIALIZE_INTS:
                     ints_ms, ints_build = min(timings)[1:]
+                else:
+                    patterns_ms, patterns_build = min(timings)[1:]
         except Exception as e:
             print(f"[bench] dynamic-uniform timing unavailable: {e}", file=sys.stderr)
 
@@ -800,6 +804,9 @@ def main():
         if ints_ms is not None:
             out["kernel_ms_with_only_int_uniforms_baked"] = round(ints_ms, 4)
             out["kernel_ms_with_only_int_uniforms_baked_build"] = ints_build
+        if patterns_ms is not None:
+            out["kernel_ms_with_only_zero_patterns_and_mode_switches"] = round(patterns_ms, 4)  # no scene VALUE compiled in (FLAG_SPECIALIZE_PATTERNS)
+            out["kernel_ms_with_only_zero_patterns_and_mode_switches_build"] = patterns_build
         pmc = stored_pmc(args, best)
         hbm = {
             "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),

@@ -103,7 +103,7 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
 
 // The camera-teleport query of src/main.rs:1361-1409: one thread instead of the reference's 2x3-pixel
 // draw with float-in-RGBA8 packing.  (A hand-written kernel without a scene can opt out.)
-#ifndef PTL_NO_TELEPORT_ENTRY
+#if !defined(PTL_NO_TELEPORT_ENTRY) && !defined(PTL_RENDER_MODULE)
 extern "C" __global__ void __launch_bounds__(64) ptl_teleport_kernel(float* __restrict__ out6) {
 #ifdef PTL_UNIFORMS_IN_LDS
     {

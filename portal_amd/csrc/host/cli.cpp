@@ -175,6 +175,10 @@ private:
 // spill (128 VGPRs + 240 B scratch: 2.19 ms against 1.52 ms at 4K, profiles/r02/variants1_prologue_waveloop_fast.jsonl); the
 // other scenes do not care.  (Round 1, greedy allocator: the hint was a 18 % gain on that kernel.)
 constexpr unsigned kRenderFlags = 0u;
+// `render` (clips): the kernel a clip runs on when it gets no clip-constant build of its own still has the zero patterns of the scene's
+// matrices and the mode switches compiled in (PTL_FLAG_SPECIALIZE_PATTERNS, bit 20: no value baked, so nothing moves under it but a
+// pattern -- one rebuild per stage at most): 0.58 against 0.83 ms on the headline frame (profiles/r04/ab_bounded_snippets.jsonl `patterns`)
+constexpr unsigned kClipFlags = kRenderFlags | (1u << 20);
 // frames of a clip are intermediates (ffmpeg reads them, then anim/ is removed): fast deflate, 2.3x the encode rate of level 6
 constexpr int kFrameDeflateLevel = 3;
 
@@ -477,7 +481,7 @@ int precompile(const Options& o) {
     if (!o.stage.empty() && ptl_scene_init_stage(scene, o.stage.c_str(), stage_cam, sizeof stage_cam) != PTL_OK) return fail("stage");
     std::vector<char> log(1 << 16);
     std::vector<unsigned> variants = {frame_flags(o)};
-    if (o.specialize != 0) variants.push_back(kRenderFlags | (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u) | (o.opt3 ? 0u : 262144u));  // + the dynamic-uniform kernel `render` starts clips with
+    if (o.specialize != 0) variants.push_back(kClipFlags | (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u) | (o.opt3 ? 0u : 262144u));  // + the dynamic-uniform kernel `render` starts clips with
     for (unsigned flags : variants) {
         auto t1 = std::chrono::steady_clock::now();
         ptl_renderer* r = nullptr;
@@ -698,7 +702,7 @@ void prefetch_clip_kernel(std::string path, std::vector<std::string> history, st
     const char* names[] = {"draw_side_by_side"};
     const double values[] = {stereo ? 1.0 : 0.0};
     ptl_renderer* r = nullptr;
-    if (ptl_renderer_create_with_options(scene, -1, asset_root.c_str(), kRenderFlags | 8u | extra_flags, names, values, 1, &r, nullptr, 0) == PTL_OK)
+    if (ptl_renderer_create_with_options(scene, -1, asset_root.c_str(), kClipFlags | 8u | extra_flags, names, values, 1, &r, nullptr, 0) == PTL_OK)
         ptl_renderer_destroy(r);
     ptl_scene_free(scene);
 }
@@ -773,7 +777,7 @@ int render(const Options& o) {
             if (ptl_scene_init_animation(scene, todo[0].first.c_str()) != PTL_OK) return fail("init_animation");
             apply_clip_overrides(scene, nullptr, todo[0].first, nullptr);
         }
-        unsigned start_flags = kRenderFlags | (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u) | (o.opt3 ? 0u : 262144u) | (start_baked ? 8u : 0u);
+        unsigned start_flags = kClipFlags | (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u) | (o.opt3 ? 0u : 262144u) | (start_baked ? 8u : 0u);
         const char* create_names[] = {"aa_count", "render_depth", "draw_side_by_side"};  // before the first build: a baked kernel has its mode switches compiled in
         const double create_values[] = {(double)o.aa, (double)o.depth, o.stereo ? 1.0 : 0.0};
         if (ptl_renderer_create_with_options(scene, o.device, o.asset_root.c_str(), start_flags, create_names, create_values, 3, &r, log.data(), log.size()) !=

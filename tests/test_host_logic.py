@@ -945,7 +945,7 @@ def test_masked_product_rewrite_follows_the_shape_of_the_operand(pa):
     text = open(pa.scene_path("basics")).read()
     text = text.replace("intersection_materials: ([]),", 'intersection_materials: ([\n        (\n            name: "shapes",\n            data: ((("' + _PRODUCT_SHAPES + '"))),\n        ),\n    ]),')
     src = pa.Scene.from_text(text).generate_source(ints | pa.FLAG_NO_FIRST_TRIP)
-    body = src[src.index("intersect_material_0(Ray r) {"):]
+    body = src[src.index("intersect_material_0(Ray r, float ptl_far) {"):]
     body = body[:body.index("return result;")]
     for want in ("vec4 a = ptl_mul_m<PTL_MASK_portal_a_mat_inv>(portal_a_mat_inv, p);",
                  "vec4 b = ptl_mul_m<PTL_MASK_portal_a_mat>(portal_a_mat, (ptl_mul_m<PTL_MASK_portal_b_mat_inv>(portal_b_mat_inv, vec4(p.sw<0,1,2>(), 1.f))));",
@@ -1157,7 +1157,7 @@ def test_hoisted_scene_source_is_selfconsistent(pa):
     src = scene.generate_source(baked)
     block = src[src.index("struct ptl_uniform_block {"):src.index("};", src.index("struct ptl_uniform_block {"))]
     assert re.findall(r"(\w+) ptl_hv\d+(\[\d+\])?;", block) == [("vec4", "[66]"), ("vec4", "[66]")]
-    assert src.count("ptl_ray_o(") == 3 and "intersect_material_0_first(Ray r) {" in src
+    assert src.count("ptl_ray_o(") == 3 and "intersect_material_0_first(Ray r, float ptl_far) {" in src
     # (the generator says in the source itself which first-trip forms the kernel has; with the matrices baked: the snippets', not the planes')
     assert "#define PTL_FIRST_TRIP_SNIPPETS 1" in src and "#define PTL_FIRST_TRIP_PLANES" not in src
 
@@ -1235,7 +1235,7 @@ def test_first_trip_copy_declares_the_rays_a_plain_uniform_expression_reads(pa):
         scene = pa.Scene.from_text(text)
         src = scene.generate_source(flags)
         if label == "first":
-            assert "intersect_material_0_first(Ray r) {" in src
+            assert "intersect_material_0_first(Ray r, float ptl_far) {" in src
             derive = src[src.index("PTL_FN void derive(ptl_uniform_block* out)"):src.index("// Material id -> what happens to the path.")]
             assert "Ray r = Ray(PTL_DV_OUT.ptl_dv_origin" in derive  # the dummy parameter the hoisted `r.o...` expression names
         r = pa.SceneRenderer(scene, device=-1, flags=flags)  # hiprtc for gfx950: used to fail with "use of undeclared identifier 'r'"

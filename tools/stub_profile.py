@@ -41,7 +41,16 @@ PATCHES = {
     # planes never hit: what do the Flat objects cost (transform, early-out, sqrt, divisions, is_inside)?
     "no_planes": [("    r = transform(plane_inv, r);\n    float len = length(r.d);", "    return intersection_none;\n    r = transform(plane_inv, r);\n    float len = length(r.d);")],
     # the snippet of the scene (intersection material) never hits
-    "no_snippet": [("hit = intersect_material_0(r);", "hit = SceneIntersectionWithMaterial{scene_intersection_none, material_empty()};")],
+    "no_snippet": [("hit = intersect_material_0(r, ptl_far);", "hit = SceneIntersectionWithMaterial{scene_intersection_none, material_empty()};"),
+                   ("hit = intersect_material_0_first(r, ptl_far);", "hit = SceneIntersectionWithMaterial{scene_intersection_none, material_empty()};")],
+    # round 4: the chain of early returns that tells which ring of a portal a point is in (scenes/portal_in_portal.ron library `is_inside_portal`)
+    "pip_no_is_inside_portal": [("  int material = material_second;\n  if (first) { material = material_first; }\n", "  return NOT_INSIDE;\n  int material = material_second;\n  if (first) { material = material_first; }\n")],
+    # ... everything behind the bounding test of is_inside_portal_advanced (the walk through the nested copies + the rings)
+    "pip_no_advanced_tail": [("if (definitely_not_in_portal(x, y)) return NOT_INSIDE;\n", "if (definitely_not_in_portal(x, y)) return NOT_INSIDE;\nif (x > -1e30f) return NOT_INSIDE;\n")],
+    # ... the three boxes' own hit code (intersect_box) replaced by a miss: transform + normalisation stay
+    "pip_no_box_body": [("vec3 rad = vec3(4.f, 4.f, 4.f);\n", "if (r.d.x > -2.f) return scene_intersection_none;\nvec3 rad = vec3(4.f, 4.f, 4.f);\n")],
+    # colour of a hit wall: grid + normal shading of material_simple2
+    "no_grid": [("#define _grid_disable (PTL_U._grid_disable)", "#define _grid_disable (1)")],
     # the scene snippet of portal_in_portal, piece by piece (scenes/portal_in_portal.ron:1127-1185): the nested copies of portal a ...
     "pip_no_a_part": [("\tif (nearer(result.scene.hit, hit_a)) {", "\tif (false) {")],
     # ... the nested copies of portal b: their inside test and material (the plane test and the ray chain stay)
@@ -87,7 +96,8 @@ if __name__ == "__main__":
     flags = int(os.environ.get("STUB_FLAGS", str(pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)))  # 0: the un-specialised kernel
     r = pa.SceneRenderer(scene, device=device, flags=flags)
     r.set_option("render_depth", depth)
-    source = scene.generate_source(flags)
+    source = r.kernel_source()  # the shipped text: the renderer's mode switches compiled in
+    defines_of_build = list(scene.generated_defines()) + ([os.environ["STUB_DEFINE"]] if os.environ.get("STUB_DEFINE") else [])
     layout, size = scene.uniform_layout()
     import ctypes as C
 
@@ -104,8 +114,7 @@ if __name__ == "__main__":
         if src is None:
             continue
         # the defines the generator asks the JIT for (codegen.cpp: first-trip copies, zero terms of baked matrices)
-        defines = (["PTL_FIRST_TRIP"] if "_first(Ray r, float ptl_far) {" in src else []) + (["PTL_DROP_ZERO_TERMS"] if flags & 4 else [])
-        k = pa.Kernel(src, layout, size, device=device, defines=defines)
+        k = pa.Kernel(src, layout, size, device=device, defines=defines_of_build)
         if device < 0:
             continue
         for uname, typ, _ in layout:
