@@ -170,6 +170,7 @@ CORPUS_BUILDS = {  # the builds a corpus scene goes through on the GPU
     "dynamic": 0,      # every scene uniform a run-time value
     "baked": 1 | 4,    # the CLI's default (cli.cpp `frame_flags`): the scene state compiled in -- zero terms dropped, loops unrolled, switches compiled in
     "ints": 1,         # Bool / Int baked, zero PATTERNS of the run-time matrices compiled in (masked products)
+    "patterns": 1 << 20,  # no value baked: only the zero patterns and the renderer's mode switches (what `portal-amd render` starts clips on)
 }
 
 
@@ -212,8 +213,8 @@ def _corpus_oracle_frame(path, w, h, depth):
 @pytest.mark.parametrize("build", list(CORPUS_BUILDS))
 @pytest.mark.parametrize("path", corpus_files(), ids=[os.path.basename(f)[:-4] for f in corpus_files()])
 def test_corpus_scene_on_gpu_matches_numpy_oracle(gpu, corpus_cache, path, build):
-    """Every scene file of the reference (82 non-empty ones; generator src/gui/scene.rs:885-1009 for every object kind) through the three
-    builds -- un-specialised, everything baked (what `portal-amd render-frame` ships by default), Bool / Int baked with zero patterns:
+    """Every scene file of the reference (82 non-empty ones; generator src/gui/scene.rs:885-1009 for every object kind) through the four
+    builds -- un-specialised, everything baked (what `portal-amd render-frame` ships by default), Bool / Int baked with zero patterns, patterns only:
     load -> generate -> hiprtc -> render 64x36 at depth 12 on the MI355X -> bit-equal to the numpy oracle's frame.  Oracle throughout
     (no host-build stand-in).  The baked builds skip matrix terms whose element is zero; where that is not exact (a scene matrix with
     infinite elements) the generator keeps the full chains (tests/test_host_logic.py::test_a_matrix_with_infinities_keeps_every_full_chain),
@@ -229,13 +230,13 @@ def test_corpus_scene_on_gpu_matches_numpy_oracle(gpu, corpus_cache, path, build
     assert np.array_equal(out["rgba8"], want["rgba8"])
 
 
-HUNT_BUILDS = (0, 8, 1, 1 | 4)  # un-specialised, clip-constant, Bool / Int baked (masked products), everything baked
+HUNT_BUILDS = (0, 8, 1, 1 | 4, 1 << 20)  # un-specialised, clip-constant, Bool / Int baked (masked products), everything baked, patterns only
 
 
-@pytest.mark.parametrize("seed", range(300, 348))
-def test_random_scenes_through_the_four_builds_match_numpy_oracle(gpu, seed, tmp_path):
-    """A bounded slice of tests/gpu_fuzz_hunt.py inside the suite: 48 random scenes (tests/test_scene_fuzz.py::random_scene: random portal
-    graphs, matrices, materials, subspaces, cameras) cycling through the four builds, 40x24 at depth 10, GPU == numpy oracle bit for bit."""
+@pytest.mark.parametrize("seed", range(300, 350))
+def test_random_scenes_through_the_builds_match_numpy_oracle(gpu, seed, tmp_path):
+    """A bounded slice of tests/gpu_fuzz_hunt.py inside the suite: 50 random scenes (tests/test_scene_fuzz.py::random_scene: random portal
+    graphs, matrices, materials, subspaces, cameras) cycling through the five builds, 40x24 at depth 10, GPU == numpy oracle bit for bit."""
     from oracle.portal_oracle import Oracle
     from tests.test_scene_fuzz import random_scene
 
@@ -244,7 +245,7 @@ def test_random_scenes_through_the_four_builds_match_numpy_oracle(gpu, seed, tmp
     path = str(tmp_path / "r.ron")
     with open(path, "w") as f:
         f.write(text)
-    r = pa.SceneRenderer(pa.Scene.from_file(path), device=0, flags=HUNT_BUILDS[seed % 4])
+    r = pa.SceneRenderer(pa.Scene.from_file(path), device=0, flags=HUNT_BUILDS[seed % 5])
     r.set_option("render_depth", 10)
     r.set_option("in_subspace", 1 if sub else 0)
     r.set_camera(cam["look_at"], cam["alpha"], cam["beta"], cam["r"])
@@ -253,7 +254,7 @@ def test_random_scenes_through_the_four_builds_match_numpy_oracle(gpu, seed, tmp
     o.options["render_depth"] = 10
     o.camera = dict(cam, in_subspace=sub)
     want = o.render(40, 24)["rgba32f"]
-    assert _bits_equal(got, want).all(), f"seed {seed}, build flags {HUNT_BUILDS[seed % 4]}"
+    assert _bits_equal(got, want).all(), f"seed {seed}, build flags {HUNT_BUILDS[seed % 5]}"
 
 
 @pytest.mark.parametrize("seed", range(400, 424))

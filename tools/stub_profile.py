@@ -49,6 +49,11 @@ PATCHES = {
     "pip_no_advanced_tail": [("if (definitely_not_in_portal(x, y)) return NOT_INSIDE;\n", "if (definitely_not_in_portal(x, y)) return NOT_INSIDE;\nif (x > -1e30f) return NOT_INSIDE;\n")],
     # ... the three boxes' own hit code (intersect_box) replaced by a miss: transform + normalisation stay
     "pip_no_box_body": [("vec3 rad = vec3(4.f, 4.f, 4.f);\n", "if (r.d.x > -2.f) return scene_intersection_none;\nvec3 rad = vec3(4.f, 4.f, 4.f);\n")],
+    # WHAT IF (wrong picture where a portal's back is seen): the `back` argument of the snippet's inside tests cost nothing.  GLSL evaluates
+    # is_collinear(hit.n, normal) -- two square roots and a division -- at every call, the callee looks at it on one path in ten
+    "pip_b_back_free": [("is_collinear(hit_b.n, normal_b.sw<0,1,2>())", "false")],
+    "pip_ab_back_free": [("is_collinear(hit_b.n, normal_b.sw<0,1,2>())", "false"), ("is_collinear(hit_a.n, normal_a)", "false")],
+    "planes_back_free": [("is_collinear(hit.n, normal)", "false")],
     # colour of a hit wall: grid + normal shading of material_simple2
     "no_grid": [("#define _grid_disable (PTL_U._grid_disable)", "#define _grid_disable (1)")],
     # the scene snippet of portal_in_portal, piece by piece (scenes/portal_in_portal.ron:1127-1185): the nested copies of portal a ...
