@@ -74,6 +74,13 @@ int ptl_kernel_compile(int device, const char* hip_source, const ptl_uniform_des
                        size_t uniform_block_size, const char* const* defines, int n_defines, ptl_kernel** out, char* log,
                        size_t log_cap);
 
+/* A second instance of a compiled kernel on the same device: the code object loaded once more, so it has a uniform block of its own and
+ * can be in flight on another stream with other uniform values (one module's block is a single global: consecutive launches of ONE handle
+ * with different uniforms serialise on the upload).  Nothing is compiled.  ptl_kernel_copy_uniforms hands the original's current values
+ * (sampler records included: the clone reads the original's texel buffers, so the original must outlive it) to the clone.  What
+ * ptl_renderer_set_option("concurrent_draws", K) is built on. */
+int ptl_kernel_clone(ptl_kernel* src, ptl_kernel** out);
+int ptl_kernel_copy_uniforms(ptl_kernel* dst, const ptl_kernel* src);
 /* The compiled gfx950 code object (valid until ptl_kernel_destroy). */
 int ptl_kernel_code_object(ptl_kernel* k, const void** data, size_t* size);
 
@@ -286,6 +293,13 @@ int ptl_renderer_create_with_options(ptl_scene* s, int device, const char* asset
  * with the renderer's own mode switches compiled in where it is a specialised build -- what tools/isa_hist.py attributes instructions to. */
 int ptl_renderer_kernel_source(ptl_renderer* r, char** source);
 int ptl_renderer_set_option(ptl_renderer* r, const char* name, double value);
+/* "concurrent_draws" K (1 = off, up to 8; round 4): draws issued with stream = NULL / the caller's stream and without a request for the
+ * kernel time go round-robin to K internal streams, each with its own instance of the kernel (ptl_kernel_clone), so consecutive draws with
+ * DIFFERENT uniforms -- the motion-blur sub-frames of a clip frame (src/main.rs:1798) -- overlap on the GPU instead of serialising on the one
+ * uniform block a module has.  Each launch waits for what the caller's stream had queued when it was issued; nothing waits for the launches
+ * until ptl_renderer_join(r, stream), which puts `stream` (NULL = the default stream) behind all of them -- call it before the frames are
+ * consumed (averaged, downloaded).  Timed draws, counting draws, draws to host memory and the teleport query join by themselves. */
+int ptl_renderer_join(ptl_renderer* r, void* stream);
 /* Camera (RotateAroundCam): look_at xyz, alpha, beta, r. */
 int ptl_renderer_set_camera(ptl_renderer* r, const double look_at[3], double alpha, double beta, double radius);
 /* `render-frame --camera NAME` (src/main.rs:2918-2926, 1442-1478): take look_at / alpha / beta / r /

@@ -144,6 +144,9 @@ def _load() -> C.CDLL:
         "ptl_free": (None, [vp]),
         "ptl_renderer_create": (ci, [vp, ci, cp, C.c_uint, P(vp), cp, cs]),
         "ptl_renderer_kernel_source": (ci, [vp, P(vp)]),
+        "ptl_renderer_join": (ci, [vp, vp]),
+        "ptl_kernel_clone": (ci, [vp, P(vp)]),
+        "ptl_kernel_copy_uniforms": (ci, [vp, vp]),
         "ptl_renderer_create_with_options": (ci, [vp, ci, cp, C.c_uint, P(cp), P(cd), ci, P(vp), cp, cs]),
         "ptl_renderer_set_option": (ci, [vp, cp, cd]),
         "ptl_renderer_set_camera": (ci, [vp, P(cd), cd, cd, cd]),
@@ -460,6 +463,10 @@ class SceneRenderer:
                 self._h = None
         except Exception:
             pass
+
+    def join(self, stream: int = 0) -> None:
+        """With ``set_option("concurrent_draws", K)``: put `stream` (0 = the default stream) behind every draw issued so far."""
+        _check(lib().ptl_renderer_join(self._h, C.c_void_p(stream or None)), "ptl_renderer_join")
 
     def kernel_source(self) -> str:
         """The translation unit the current kernel was compiled from (mode switches compiled in where the build is specialised)."""

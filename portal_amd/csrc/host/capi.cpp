@@ -155,6 +155,21 @@ struct ptl_renderer {
     std::string spec_source, failed_source;
     Build want;                 // the specialised build of the scene state seen by the last draw
     std::shared_ptr<Job> job;
+    // "concurrent_draws" K > 1: draws on the caller's default stream go round-robin to K internal streams, each with its OWN instance of the
+    // kernel (ptl_kernel_clone: the same code object, another uniform block), so that consecutive draws with different uniforms -- the blur
+    // sub-frames of a clip frame -- overlap on the GPU (tail of one under the ramp of the next) instead of serialising on the one uniform
+    // block a module has.  Lane 0 draws with `kernel` itself.  ptl_renderer_join orders a stream behind everything issued so far.
+    struct Lane {
+        ptl_kernel* clone = nullptr;
+        void* stream = nullptr;
+        void* done = nullptr;
+        bool busy = false;
+    };
+    int concurrent = 1;
+    std::vector<Lane> lanes;
+    ptl_kernel* lanes_of = nullptr;  // the kernel the clones were made from
+    unsigned next_lane = 0;
+    void* fence = nullptr;
     // VideoRuntime (src/main.rs:771-925): per video, the sorted frame files and the frame currently bound
     struct VideoState {
         bool scanned = false;
@@ -662,6 +677,31 @@ static int compile_build(const ptl_renderer::Build& b, int device, const std::ve
     return ptl_kernel_compile(device, b.source.c_str(), descs.data(), (int)descs.size(), b.block_size, defines.data(), (int)defines.size(), out, log, log_cap);
 }
 
+// ---- concurrent draws (ptl_renderer::Lane) ----
+static void wait_for_lanes(ptl_renderer* r) {  // host-side: everything issued on the lanes has finished
+    for (auto& l : r->lanes)
+        if (l.busy && l.done) {
+            ptl_event_synchronize(l.done);
+            l.busy = false;
+        }
+}
+static void drop_lane_clones(ptl_renderer* r) {  // before the kernel they were cloned from goes away (they read its texel buffers)
+    wait_for_lanes(r);
+    for (auto& l : r->lanes) {
+        ptl_kernel_destroy(l.clone);
+        l.clone = nullptr;
+    }
+    r->lanes_of = nullptr;
+}
+static int join_lanes(ptl_renderer* r, void* stream) {  // GPU-side: `stream` continues behind every draw issued so far
+    for (auto& l : r->lanes)
+        if (l.busy && l.done) {
+            if (int rc = ptl_stream_wait_event(stream, l.done); rc != PTL_OK) return rc;
+            l.busy = false;
+        }
+    return PTL_OK;
+}
+
 static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     ptl_scene* s = r->owner;
     if (!(r->kernel_stage == r->scene->current_stage)) r->keep_dynamic.clear();  // another stage / clip: judge afresh what is constant
@@ -703,6 +743,8 @@ static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
             }
         }
     }
+    if (r->lanes_of == r->kernel) drop_lane_clones(r);
+    wait_for_lanes(r);
     ptl_kernel_destroy(r->kernel);
     r->kernel = k;
     r->kernel_source = s->last.source;
@@ -722,6 +764,7 @@ static void drop_async_kernels(ptl_renderer* r) {
         r->job.reset();
     }
     if (r->spec_kernel || r->dyn_kernel) {
+        drop_lane_clones(r);
         ptl_kernel_destroy(r->spec_kernel);
         ptl_kernel_destroy(r->dyn_kernel);
         r->spec_kernel = r->dyn_kernel = r->kernel = nullptr;
@@ -814,6 +857,15 @@ static int set_plain_option(ptl_renderer* r, const std::string& n, double v) {
     else if (n == "swap_eyes") r->swap_eyes = b;
     else if (n == "allow_teleport") r->cam.allow_teleport = b;    // RotateAroundCam toggles, src/main.rs:136-137
     else if (n == "stop_at_objects") r->cam.stop_at_objects = b;
+    else if (n == "concurrent_draws") {  // 1 = off (the default); K <= 8 kernel instances on K internal streams (ptl_renderer::Lane)
+        int k = (int)v;
+        if (k < 1 || k > 8) return PTL_ERR_INVALID;
+        if (k != r->concurrent) {
+            drop_lane_clones(r);
+            r->concurrent = k;
+        }
+        return PTL_OK;
+    }
     else return PTL_UNKNOWN_UNIFORM;
     ++r->options_version;
     return PTL_OK;
@@ -995,6 +1047,7 @@ static int async_select_kernel(ptl_renderer* r) {
                 r->baked = job->build.baked;
                 ++r->rejit_count;
                 rc = activate_kernel(r, k);
+                if (r->lanes_of == old) drop_lane_clones(r);
                 ptl_kernel_destroy(old);  // (never the active one: `k` has just been activated)
                 return rc;
             }
@@ -1091,12 +1144,59 @@ static int prepare_draw(ptl_renderer* r, const ptl_frame* frame) {
     return PTL_OK;
 }
 
+// One draw of a renderer with "concurrent_draws" K > 1, issued on the caller's stream `stream` without a request for its time: it goes to
+// the next of K lanes.  prepare_draw leaves the complete current state in the primary kernel's host copy of the uniform block; a clone
+// takes that copy over and uploads it behind its own previous launch, on its own stream.  The launch waits (GPU-side) for what the
+// caller's stream has queued so far -- the consumer of this target buffer from the previous round -- and nothing waits for the launch
+// until ptl_renderer_join.
+static int draw_on_a_lane(ptl_renderer* r, const ptl_frame* frame, void* out_rgba8, void* out_rgba32f, void* stream) {
+    if ((int)r->lanes.size() != r->concurrent) {
+        drop_lane_clones(r);
+        for (auto& l : r->lanes) {
+            if (l.stream) ptl_stream_destroy(l.stream);
+            if (l.done) ptl_event_destroy(l.done);
+        }
+        r->lanes.assign((size_t)r->concurrent, ptl_renderer::Lane{});
+        for (auto& l : r->lanes) {
+            if (int rc = ptl_stream_create(r->device, &l.stream); rc != PTL_OK) return rc;
+            if (int rc = ptl_event_create(r->device, &l.done); rc != PTL_OK) return rc;
+        }
+        if (!r->fence)
+            if (int rc = ptl_event_create(r->device, &r->fence); rc != PTL_OK) return rc;
+    }
+    if (r->lanes_of != r->kernel) {  // first use, or the kernel was rebuilt / switched: instances of THIS code object
+        drop_lane_clones(r);
+        for (size_t i = 1; i < r->lanes.size(); ++i)
+            if (int rc = ptl_kernel_clone(r->kernel, &r->lanes[i].clone); rc != PTL_OK) return rc;
+        r->lanes_of = r->kernel;
+    }
+    const size_t idx = r->next_lane++ % r->lanes.size();
+    ptl_renderer::Lane& lane = r->lanes[idx];
+    ptl_kernel* k = idx == 0 ? r->kernel : lane.clone;
+    if (idx != 0)
+        if (int rc = ptl_kernel_copy_uniforms(k, r->kernel); rc != PTL_OK) return rc;
+    if (int rc = ptl_event_record(r->fence, stream); rc != PTL_OK) return rc;
+    if (int rc = ptl_stream_wait_event(lane.stream, r->fence); rc != PTL_OK) return rc;
+    if (int rc = ptl_kernel_render(k, frame, out_rgba8, out_rgba32f, nullptr, lane.stream, nullptr); rc != PTL_OK) return rc;
+    if (int rc = ptl_event_record(lane.done, lane.stream); rc != PTL_OK) return rc;
+    lane.busy = true;
+    return PTL_OK;
+}
+
+extern "C" int ptl_renderer_join(ptl_renderer* r, void* stream) {
+    if (!r) return PTL_ERR_INVALID;
+    return guarded([&] { return join_lanes(r, stream); });
+}
+
 extern "C" int ptl_renderer_draw(ptl_renderer* r, const ptl_frame* frame, void* out_rgba8, void* out_rgba32f, void* segments, void* stream,
                                  float* elapsed_ms) {
     if (!r || !frame) return PTL_ERR_INVALID;
     return guarded([&] {
         int rc = prepare_draw(r, frame);
         if (rc < 0) return rc;
+        if (r->concurrent > 1 && r->device >= 0 && !elapsed_ms && !segments) return draw_on_a_lane(r, frame, out_rgba8, out_rgba32f, stream);
+        // (a timed or counting draw, and every draw of a renderer without lanes: on the caller's stream, behind what the lanes still hold)
+        if (int jrc = join_lanes(r, stream); jrc != PTL_OK) return jrc;
         return ptl_kernel_render(r->kernel, frame, out_rgba8, out_rgba32f, segments, stream, elapsed_ms);
     });
 }
@@ -1106,6 +1206,7 @@ extern "C" int ptl_renderer_draw_to_host(ptl_renderer* r, const ptl_frame* frame
     return guarded([&] {
         int rc = prepare_draw(r, frame);
         if (rc < 0) return rc;
+        wait_for_lanes(r);
         return ptl_kernel_render_to_host(r->kernel, frame, host_rgba8, host_rgba32f, host_segments, elapsed_ms);
     });
 }
@@ -1116,6 +1217,7 @@ extern "C" int ptl_renderer_teleport_ray(ptl_renderer* r, const double a[3], con
         ptl_frame zero{0, 0, 0, 1, 0};  // the reference calls self.set_uniforms(0., 0.) here
         int rc = prepare_draw(r, &zero);
         if (rc < 0) return rc;
+        wait_for_lanes(r);  // (the query runs on the primary kernel's block, on the default stream)
         int one = 1;
         ptl_kernel_set_uniform(r->kernel, "teleport_light_u", PTL_I32, &one);  // src/main.rs:1367 (a scene without it: no-op)
         float fa[3] = {(float)a[0], (float)a[1], (float)a[2]}, fb[3] = {(float)b[0], (float)b[1], (float)b[2]}, pos[3] = {0, 0, 0};
@@ -1386,6 +1488,12 @@ extern "C" int ptl_renderer_rejit_pending(ptl_renderer* r) {
 extern "C" void ptl_renderer_destroy(ptl_renderer* r) {
     if (!r) return;
     if (r->job && r->job->worker.joinable()) r->job->worker.join();  // (the worker owns nothing of ours, but a thread must be joined)
+    drop_lane_clones(r);
+    for (auto& l : r->lanes) {
+        if (l.stream) ptl_stream_destroy(l.stream);
+        if (l.done) ptl_event_destroy(l.done);
+    }
+    if (r->fence) ptl_event_destroy(r->fence);
     if (r->spec_kernel || r->dyn_kernel) {  // background re-JIT: `kernel` is one of these two
         ptl_kernel_destroy(r->spec_kernel);
         ptl_kernel_destroy(r->dyn_kernel);

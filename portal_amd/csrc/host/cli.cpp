@@ -185,6 +185,7 @@ constexpr int kFrameDeflateLevel = 3;
 struct Options {
     std::string scene, clips, output = "frame.png", asset_root = ".", stage, animation, camera, scenes_dir = "scenes", out_dir = ".", starts_with;
     bool have_camera = false, stereo = false, skip_existing = true;
+    int concurrent = -1;  // render: kernel instances in flight for a frame's blur sub-frames (-1: min(blur, 4); --timing times draws one by one: 1)
     std::vector<std::pair<std::string, double>> sets;  // --set name=value
     bool timing = false;  // --timing: wait for every kernel and report GPU milliseconds (serialises host and GPU)
     int specialize = -1;  // -1 auto: clip-constant specialisation when the clip has enough sub-frames to repay the extra JIT
@@ -575,6 +576,7 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
             ++traced;
             bool first = i == 0 && j == 0, final_one = i == count - 1 && j == o.blur - 1;
             if (first || final_one) {  // the clip's .start.png / .end.png stills: same pool, same pinned buffers
+                if (ptl_renderer_join(r, nullptr) != PTL_OK) return fail("join");  // (the download below is on the default stream)
                 for (int which = 0; which < 2; ++which) {
                     if (!(which == 0 ? first : final_one)) continue;
                     uint8_t* still = pinned.take();
@@ -587,6 +589,7 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
                 }
             }
         }
+        if (ptl_renderer_join(r, nullptr) != PTL_OK) return fail("join");  // the default stream goes on behind every sub-frame of this frame
         if (o.blur > 1) {
             float ms = 0.0f;
             if (ptl_average_images(o.device, subframes.data(), o.blur, pipe.results[slot], width, height, nullptr, o.timing ? &ms : nullptr) != PTL_OK)
@@ -788,6 +791,11 @@ int render(const Options& o) {
         ptl_renderer_set_option(r, "aa_count", o.aa);
         ptl_renderer_set_option(r, "render_depth", o.depth);
         ptl_renderer_set_option(r, "draw_side_by_side", o.stereo ? 1 : 0);
+        // The blur sub-frames of one output frame differ in their uniforms only: with several kernel instances in flight (each has a uniform
+        // block of its own) the tail of one sub-frame runs under the ramp of the next instead of waiting for the block (the reference re-draws
+        // with `_aa_start` windows one after the other, src/main.rs:1798).  --timing wants every draw's own time: one by one.
+        const int lanes = o.concurrent >= 1 ? std::min(8, o.concurrent) : (o.timing ? 1 : std::max(1, std::min(4, o.blur)));
+        if (ptl_renderer_set_option(r, "concurrent_draws", lanes) != PTL_OK) return fail("concurrent_draws");
         std::vector<void*> subframes(std::max(1, o.blur), nullptr);
         size_t bytes = (size_t)width * o.height * 4;
         for (void*& p : subframes)
@@ -997,6 +1005,7 @@ int main(int argc, char** argv) {
         else if (a == "--fps") o.fps = std::atoi(next());
         else if (a == "--motion-blur-frames") o.blur = std::atoi(next());
         else if (a == "--stereoimage" || a == "--stereo-image") o.stereo = true;
+        else if (a == "--concurrent-draws") o.concurrent = std::atoi(next());
         else if (a == "--no-skip-existing") o.skip_existing = false;
         else if (a == "--filter-starts-with" || a == "--starts-with") o.starts_with = next();
         else if (a == "--scenes-dir") o.scenes_dir = next();

@@ -339,6 +339,57 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
     return PTL_OK;
 }
 
+// A second instance of a compiled kernel on the same device: the same code object loaded once more, hence a uniform block (and a
+// prologue) of its OWN -- two instances can be in flight on two streams with two different sets of uniform values, which one module
+// cannot (its block is one global).  Nothing is compiled.  The clone shares the original's textures: sampler records travel with
+// ptl_kernel_copy_uniforms and the texel buffers stay owned by the original, which must outlive its clones.
+extern "C" int ptl_kernel_clone(ptl_kernel* src, ptl_kernel** out) {
+    if (!src || !out) return PTL_ERR_INVALID;
+    if (src->device < 0 || !src->fn) return PTL_ERR_NO_DEVICE;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!rt) return PTL_ERR_NO_DEVICE;
+    auto k = std::make_unique<ptl_kernel>();
+    k->device = src->device;
+    k->code = src->code;
+    k->slots = src->slots;
+    k->shadow = src->shadow;
+    k->block_waves = src->block_waves;
+    if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;
+    if (!hip_ok(rt, rt->hipModuleLoadData(&k->module, k->code.data()), "hipModuleLoadData(clone)")) return PTL_ERR_HIP;
+    auto fail = [&](int rc) {
+        rt->hipModuleUnload(k->module);
+        k->module = nullptr;
+        return rc;
+    };
+    if (!hip_ok(rt, rt->hipModuleGetFunction(&k->fn, k->module, "ptl_render_kernel"), "hipModuleGetFunction(ptl_render_kernel)")) return fail(PTL_ERR_HIP);
+    if (rt->hipModuleGetFunction(&k->teleport_fn, k->module, "ptl_teleport_kernel") != 0) {
+        k->teleport_fn = nullptr;
+        rt->hipGetLastError();
+    }
+    if (rt->hipModuleGetFunction(&k->derive_fn, k->module, "ptl_derive_kernel") != 0) {
+        k->derive_fn = nullptr;
+        rt->hipGetLastError();
+    }
+    if (!hip_ok(rt, rt->hipModuleGetGlobal(&k->dev_block, &k->dev_block_size, k->module, "_ZN4glsl5ptl_uE"), "hipModuleGetGlobal(ptl_u)")) return fail(PTL_ERR_HIP);
+    rt->hipEventCreate(&k->ev0);
+    rt->hipEventCreate(&k->ev1);
+    rt->hipEventCreateWithFlags(&k->ev_done, hip::kEventDisableTiming);
+    k->dirty = true;
+    *out = k.release();
+    return PTL_OK;
+}
+
+// The host copy of `src`'s uniform block -- every value set so far, sampler records included -- becomes `dst`'s; uploaded behind dst's next
+// launch like any other change.  Both must come from the same source (ptl_kernel_clone).
+extern "C" int ptl_kernel_copy_uniforms(ptl_kernel* dst, const ptl_kernel* src) {
+    if (!dst || !src || dst->shadow.size() != src->shadow.size()) return PTL_ERR_INVALID;
+    if (std::memcmp(dst->shadow.data(), src->shadow.data(), src->shadow.size()) != 0) {
+        dst->shadow = src->shadow;
+        dst->dirty = true;
+    }
+    return PTL_OK;
+}
+
 extern "C" int ptl_kernel_code_object(ptl_kernel* k, const void** data, size_t* size) {
     if (!k) return PTL_ERR_INVALID;
     if (data) *data = k->code.data();

@@ -569,3 +569,63 @@ def test_specialize_static_can_be_switched_on_a_background_rejit_renderer(gpu):
             settle(r)
             assert same(r)
         del r, ref
+
+
+@pytest.mark.parametrize("flags_name", ["dynamic", "static"])
+def test_concurrent_draws_give_the_frames_of_draws_one_by_one(gpu, flags_name):
+    """ptl_renderer_set_option("concurrent_draws", K): the sub-frames of a motion-blurred clip frame -- same kernel, other uniforms, other
+    `_aa_start` window -- go round-robin to K instances of the kernel on K streams (each instance has a uniform block of its own) and overlap
+    on the GPU; the frames must be the ones a renderer draws one by one, byte for byte, also when a target buffer is reused right away
+    (the next round's draw has to wait for the consumer of the previous one), after a rebuild in the middle, and when a timed draw, a
+    draw to host memory or a teleport query comes in between (they join by themselves)."""
+    import torch
+
+    pa = gpu
+    w, h, n, rounds = 640, 360, 4, 3
+    flags = 0 if flags_name == "dynamic" else pa.FLAG_SPECIALIZE_STATIC
+    dev = torch.device("cuda:0")
+
+    def values(k):  # what moves between sub-frames
+        return 0.05 * k, ((0.02 * k, 0.1, -0.3), 0.9 + 0.03 * k, 1.2, 3.1)
+
+    def run(concurrent):
+        scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+        r = pa.SceneRenderer(scene, device=0, flags=flags)
+        r.set_option("render_depth", 20)
+        r.set_option("aa_count", 2)
+        r.set_option("concurrent_draws", concurrent)
+        targets = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+        total = torch.zeros((h, w, 4), dtype=torch.int32, device=dev)
+        sums = []
+        torch.cuda.synchronize(dev)
+        for rnd in range(rounds):
+            for j in range(n):
+                k = rnd * n + j
+                angle, cam = values(k)
+                assert scene.set_uniform("portal_rotate_angle", angle)
+                r.set_camera(*cam)
+                r.set_option("aa_start", j)
+                r.draw_device(pa.Frame(w, h, 0, 1), out_rgba8=targets[j].data_ptr())  # stream 0 = the default stream, like the consumer below
+            r.join()
+            # the consumer, on the default (legacy) stream like the CLI's averaging kernel: torch's current stream IS that stream here
+            total = total + targets.to(torch.int32).sum(dim=0)
+            sums.append(total.clone())
+            if rnd == 0:  # in between: a timed draw, a draw to host memory, a teleport query -- each joins by itself
+                ms = r.draw_device(pa.Frame(w, h, 0, 1), out_rgba8=targets[0].data_ptr(), timed=True)
+                assert ms > 0
+                host = r.draw(w, h)["rgba8"]
+                assert np.array_equal(host, targets[0].cpu().numpy())
+                r.teleport_external_ray((0.0, 0.0, 2.0), (0.0, 0.0, -2.0))
+            if rnd == 1 and flags_name == "static":  # a moved compiled-in value: the kernel is rebuilt, the clones with it
+                assert scene.set_uniform("portal_rotate_angle", 1.0)
+        torch.cuda.synchronize(dev)
+        return [s.cpu().numpy() for s in sums], targets.cpu().numpy(), r.rejit_count()
+
+    one_by_one, last1, _ = run(1)
+    together, last4, rejits = run(4)
+    for a, b in zip(one_by_one, together):
+        assert np.array_equal(a, b)
+    assert np.array_equal(last1, last4)
+    assert len(np.unique(last1.reshape(-1, 4), axis=0)) > 100 and not np.array_equal(last1[0], last1[1])
+    if flags_name == "static":
+        assert rejits >= 1
