@@ -356,6 +356,9 @@ def valu_roofline(fl, pmc, segments, world, kernel_ms, traffic, specialize):
     roof = {
         "bound": "valu", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5),
         "traffic": traffic,
+        # rounds 1-3 also claimed the oracle's comparisons as operations (a v_cmp is not a floating-point operation of this peak; with them the
+        # count sat above the hardware's instruction ceiling): the same launch by that accounting, for comparison across rounds only
+        "frac_with_comparisons_as_in_round_3": round(segments / world * fl.get("with_compares", fl["flops"]) / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5),
         "flops_per_segment": round(fl["flops"], 1), "flops_counted": fl["which"], "flops_sample_pixels": fl["sampled_pixels"],
         # the reference algorithm's arithmetic (as the oracle evaluates the GLSL) per second against the same peak: what the frame "is worth";
         # `frac` above counts only what this kernel still executes of it

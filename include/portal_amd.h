@@ -298,7 +298,10 @@ int ptl_renderer_set_option(ptl_renderer* r, const char* name, double value);
  * DIFFERENT uniforms -- the motion-blur sub-frames of a clip frame (src/main.rs:1798) -- overlap on the GPU instead of serialising on the one
  * uniform block a module has.  Each launch waits for what the caller's stream had queued when it was issued; nothing waits for the launches
  * until ptl_renderer_join(r, stream), which puts `stream` (NULL = the default stream) behind all of them -- call it before the frames are
- * consumed (averaged, downloaded).  Timed draws, counting draws, draws to host memory and the teleport query join by themselves. */
+ * consumed (averaged, downloaded).  Timed draws, counting draws, draws to host memory and the teleport query join by themselves.
+ * Identical frames (tests/test_gpu_round2.py); measured on one MI355X it buys nothing (profiles/r04/concurrent_draws.jsonl: 1080p
+ * 0.0519 ms per sub-frame with one instance, 0.0522 with two, 0.0559 with four) -- the cross-stream waits cost what the overlap saves --
+ * so nothing switches it on by default. */
 int ptl_renderer_join(ptl_renderer* r, void* stream);
 /* Camera (RotateAroundCam): look_at xyz, alpha, beta, r. */
 int ptl_renderer_set_camera(ptl_renderer* r, const double look_at[3], double alpha, double beta, double radius);

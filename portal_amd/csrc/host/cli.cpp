@@ -185,7 +185,7 @@ constexpr int kFrameDeflateLevel = 3;
 struct Options {
     std::string scene, clips, output = "frame.png", asset_root = ".", stage, animation, camera, scenes_dir = "scenes", out_dir = ".", starts_with;
     bool have_camera = false, stereo = false, skip_existing = true;
-    int concurrent = -1;  // render: kernel instances in flight for a frame's blur sub-frames (-1: min(blur, 4); --timing times draws one by one: 1)
+    int concurrent = -1;  // render --concurrent-draws K: kernel instances in flight for a frame's blur sub-frames (default 1: measured, no gain)
     std::vector<std::pair<std::string, double>> sets;  // --set name=value
     bool timing = false;  // --timing: wait for every kernel and report GPU milliseconds (serialises host and GPU)
     int specialize = -1;  // -1 auto: clip-constant specialisation when the clip has enough sub-frames to repay the extra JIT
@@ -791,10 +791,12 @@ int render(const Options& o) {
         ptl_renderer_set_option(r, "aa_count", o.aa);
         ptl_renderer_set_option(r, "render_depth", o.depth);
         ptl_renderer_set_option(r, "draw_side_by_side", o.stereo ? 1 : 0);
-        // The blur sub-frames of one output frame differ in their uniforms only: with several kernel instances in flight (each has a uniform
-        // block of its own) the tail of one sub-frame runs under the ramp of the next instead of waiting for the block (the reference re-draws
-        // with `_aa_start` windows one after the other, src/main.rs:1798).  --timing wants every draw's own time: one by one.
-        const int lanes = o.concurrent >= 1 ? std::min(8, o.concurrent) : (o.timing ? 1 : std::max(1, std::min(4, o.blur)));
+        // The blur sub-frames of one output frame differ in their uniforms only; with several kernel instances in flight (each has a uniform
+        // block of its own, "concurrent_draws") consecutive sub-frames need not wait for the one block of a module (the reference re-draws with
+        // `_aa_start` windows one after the other, src/main.rs:1798).  Measured (tools/concurrent_draws.py, profiles/r04/concurrent_draws.jsonl):
+        // identical frames and NO gain -- 1080p monoportal 0.0519 ms per sub-frame with one instance, 0.0522 with two, 0.0559 with four; 720p 0.031
+        // -> 0.039; 4K aa 4 0.884 -> 0.885 / 0.908: the cross-stream event waits cost what the overlapped tails save.  So: off unless asked for.
+        const int lanes = o.concurrent >= 1 ? std::min(8, o.concurrent) : 1;
         if (ptl_renderer_set_option(r, "concurrent_draws", lanes) != PTL_OK) return fail("concurrent_draws");
         std::vector<void*> subframes(std::max(1, o.blur), nullptr);
         size_t bytes = (size_t)width * o.height * 4;
