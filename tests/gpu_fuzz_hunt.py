@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tests/gpu_fuzz_hunt.py -- a larger one-off run of the tests' differential fuzzers on the GPU (60 random scenes through the four builds in turn, and 30 x 48 random GLSL expressions): gfx950 against the numpy oracle, bit for bit.  Development aid.
+"""tests/gpu_fuzz_hunt.py -- a larger one-off run of the tests' differential fuzzers on the GPU (60 random scenes through the five builds in turn; a bounded slice of it runs inside the suite: tests/test_gpu_oracle_fullsize.py, and 30 x 48 random GLSL expressions): gfx950 against the numpy oracle, bit for bit.  Development aid.
 usage: gpu_fuzz_hunt.py [SEED_BASE [N_SCENES [N_GLSL]]] -- e.g. `1000 240 120` was run after the sqrt / reciprocal change: no mismatch
 in 240 scenes and 5 760 expressions."""
 import sys, os, tempfile, numpy as np
@@ -15,8 +15,8 @@ N_SCENES=int(sys.argv[2]) if len(sys.argv)>2 else 60
 N_GLSL=int(sys.argv[3]) if len(sys.argv)>3 else 30
 for seed in range(300+BASE,300+BASE+N_SCENES):
     text,cam,sub=random_scene(seed); d=tempfile.mkdtemp(); path=os.path.join(d,'r.ron'); open(path,'w').write(text)
-    # the builds in turn: un-specialised, clip-constant, Bool / Int baked (zero patterns of the run-time matrices compiled in), everything baked
-    flags=(0, pa.FLAG_SPECIALIZE_STATIC, pa.FLAG_SPECIALIZE_INTS, pa.FLAG_SPECIALIZE_INTS|pa.FLAG_SPECIALIZE_ALL)[seed%4]
+    # the builds in turn: un-specialised, clip-constant, Bool / Int baked (zero patterns of the run-time matrices compiled in), everything baked, patterns only
+    flags=(0, pa.FLAG_SPECIALIZE_STATIC, pa.FLAG_SPECIALIZE_INTS, pa.FLAG_SPECIALIZE_INTS|pa.FLAG_SPECIALIZE_ALL, pa.FLAG_SPECIALIZE_PATTERNS)[seed%5]
     r=pa.SceneRenderer(pa.Scene.from_file(path),device=0,flags=flags); r.set_option("render_depth",10); r.set_option("in_subspace",1 if sub else 0)
     r.set_camera(cam["look_at"],cam["alpha"],cam["beta"],cam["r"])
     got=r.draw(40,24,rgba32f=True)["rgba32f"]

@@ -1,0 +1,70 @@
+"""The committed measurement records of the current round are self-consistent: no roofline object under profiles/r04/ claims
+more than its own hardware ceiling, every workload whose roofline bench.py prints has stored PMC class counters, and the checks the bench line
+carries about the build it timed are green in the record."""
+import glob
+import json
+import os
+
+import pytest
+
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R04 = os.path.join(HERE, "profiles", "r04")
+
+
+def _lines(path):
+    with open(path) as f:
+        return [json.loads(l) for l in f if l.startswith("{")]
+
+
+def _rooflines():
+    out = []
+    for path in [os.path.join(R04, "bench_pip4k_1gpu.json"), os.path.join(R04, "bench_other_configs_1gpu.jsonl")]:
+        for d in _lines(path):
+            out.append((os.path.basename(path) + ": " + d["config"]["workload"], d["roofline"]))
+            if "second_workload" in d and "roofline" in d["second_workload"]:
+                out.append((os.path.basename(path) + ": second workload " + d["second_workload"]["workload"], d["second_workload"]["roofline"]))
+    return out
+
+
+def test_no_printed_roofline_exceeds_its_own_instruction_ceiling():
+    found = _rooflines()
+    assert len(found) >= 6  # headline + its second workload, C2, Panini, C3, C5
+    for what, r in found:
+        assert r["bound"] == "valu" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-4, what
+        assert "pmc_source" in r and "frac_ceiling_valu_plus_fma" in r, f"{what}: no stored PMC class counters"
+        assert r["frac"] <= r["frac_ceiling_valu_plus_fma"] + 1e-9, what
+        assert r["hw_flops_frac"] <= r["frac_ceiling_valu_plus_fma"], what
+        assert 0.9 < r["lane_utilisation"] <= 1.0, what
+
+
+def test_pmc_files_cover_every_bench_workload_with_all_counter_classes():
+    names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(R04, "pmc_*.json")))
+    for key in ("portal_in_portal_3840x2160_d40_spec", "monoportal_1920x1080_d20_spec", "triple_portal_3840x2160_d40_spec", "mobius_monoportal_7680x4320_d64_aa4_spec",
+                "portal_in_portal_3840x2160_d40_panini_spec"):
+        mine = [n for n in names if n.startswith("pmc_" + key + "_")]
+        assert mine, key
+        c = json.load(open(os.path.join(R04, mine[0])))["counters"]
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "GRBM_GUI_ACTIVE",
+                  "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+            assert c[k]["mean_per_launch"] > 0, (key, k)
+
+
+def test_the_headline_record_carries_green_checks_of_the_timed_build():
+    d = _lines(os.path.join(R04, "bench_pip4k_1gpu.json"))[-1]
+    assert d["unit"] == "Mray/s" and d["dtype"] == "f32" and d["n_gpus"] == 1 and d["config"]["workload"].startswith("scenes/portal_in_portal.ron 3840x2160")
+    assert d["kernel_ms"] <= d["ms_per_step"] and abs(d["value"] - 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    assert d["config"]["candidate_frames_identical"]
+    for key in ("oracle_check_of_the_timed_build", "reference_text_check_of_the_timed_build"):
+        c = d[key]
+        assert c["bit_exact"] and c["float_bits_equal"] == c["pixels"] == c["rgba8_equal"], key
+    assert d["reference_text_check_of_the_timed_build"]["pixels"] >= 100_000
+    dist = d["contract1_vs_contract2"]
+    assert dist["headline"]["pixels"] == 3840 * 2160 and dist["headline"]["pixels_beyond_1e-5"] < 100
+    assert dist["c5"]["pixels"] == 7680 * 4320 and dist["c5"]["pixels_beyond_1e-5"] / dist["c5"]["pixels"] < 0.01
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    # the rocprofv3 kernel trace of the same command agrees with the HIP-event kernel time (within 3 %)
+    import csv
+
+    rows = list(csv.DictReader(open(os.path.join(R04, "kernel_stats_pip4k_bench.csv"))))
+    render = [r for r in rows if r["Name"] == "ptl_render_kernel"][0]
+    assert abs(float(render["AverageNs"]) * 1e-6 - d["kernel_ms"]) / d["kernel_ms"] < 0.03
