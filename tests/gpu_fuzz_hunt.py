@@ -23,7 +23,8 @@ for seed in range(300+BASE,300+BASE+N_SCENES):
     o=Oracle(path); o.options["render_depth"]=10; o.camera=dict(cam,in_subspace=sub)
     if not same(got,o.render(40,24)["rgba32f"]): bad+=1; print("scene seed",seed,"DIFF")
 for seed in range(100000+BASE,100000+BASE+N_GLSL) if BASE else range(400,430):
-    text,_=(fuzz_scene_with_uniforms if seed%2 else fuzz_scene)(seed); d=tempfile.mkdtemp()  # every other one with uniform leaves (glsl_hoist); path=os.path.join(d,'f.ron'); open(path,'w').write(text)
+    # every other one with uniform leaves (glsl_hoist)
+    text,_=(fuzz_scene_with_uniforms if seed%2 else fuzz_scene)(seed); d=tempfile.mkdtemp(); path=os.path.join(d,'f.ron'); open(path,'w').write(text)
     w,h=4*N_EXPR,12
     r=pa.SceneRenderer(pa.Scene.from_file(path),device=0,flags=pa.FLAG_SPECIALIZE_INTS if seed%4==1 else 0); r.set_option("render_depth",2); r.set_option("view_angle",1.5)  # (masked products every fourth)
     got=r.draw(w,h,rgba32f=True)["rgba32f"]
