@@ -121,6 +121,25 @@ int ptl_kernel_render(ptl_kernel* k, const ptl_frame* frame, void* out_rgba8, vo
 /* Convenience: render the shard and copy it to HOST buffers (either may be NULL). */
 int ptl_kernel_render_to_host(ptl_kernel* k, const ptl_frame* frame, uint8_t* host_rgba8, float* host_rgba32f,
                               uint64_t* host_segments, float* elapsed_ms);
+/* Slices: ONE launch for several frames that differ in their uniforms only (the motion-blur sub-frames of a clip frame, src/main.rs:1798).
+ * A source generated with flag bit 22 (PTL_FLAG_SLICES) has the render entry `ptl_render_slices_kernel`, which reads the uniform block of
+ * slice blockIdx.z from a device buffer of blocks instead of the module's one global -- through the same scalar loads -- and writes slice z's
+ * frame behind slice z - 1's.  ptl_kernel_stage_slice(k, j) makes the values set so far (ptl_kernel_set_uniform ...) slice j of the next
+ * batch; ptl_kernel_render_slices uploads slices 0 .. n-1 with one copy, runs the prologue of every slice and launches once with
+ * grid.z = n: slice z lands at out_rgba8 + z * slice_pixels pixels (out_rgba32f + 4 * z * slice_pixels floats; either may be NULL).  The
+ * ramp and tail of a small frame (~10 us of a 50 us 1080p launch) overlap with its neighbours' instead of adding up.  A single
+ * ptl_kernel_render of such a module is a batch of one; the camera-teleport query keeps using the module's own block.
+ * ptl_kernel_max_slices: 16 for such a module, 0 otherwise. */
+int ptl_kernel_max_slices(ptl_kernel* k);
+int ptl_kernel_stage_slice(ptl_kernel* k, int index);
+/* ... or a block saved earlier (ptl_kernel_snapshot_uniforms: the host copy of the uniform block, ptl_kernel_uniform_block_size bytes), also one
+ * saved from ANOTHER kernel of the same scene -- every build of a scene has the same block layout, so a renderer that had to rebuild its
+ * kernel between staging and launching re-stages its snapshots into the new kernel.  Sampler records are taken from `k` itself. */
+int ptl_kernel_stage_slice_from(ptl_kernel* k, int index, const void* block, size_t size);
+size_t ptl_kernel_uniform_block_size(ptl_kernel* k);
+int ptl_kernel_snapshot_uniforms(ptl_kernel* k, void* dst, size_t cap);
+int ptl_kernel_render_slices(ptl_kernel* k, const ptl_frame* frame, int n, void* out_rgba8, void* out_rgba32f, unsigned long long slice_pixels,
+                             void* stream, float* elapsed_ms);
 
 /* SceneRenderer::teleport_external_ray (src/main.rs:1361-1409): where does point b end up when the
  * segment a -> b is carried through the scene's portals (at most 10)?  One-thread launch of the
@@ -244,6 +263,9 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * then skips the candidates beyond it, which could never be the nearest hit -- exact by construction (host/glsl_translate.h
  * `bound_nearer_blocks` has the proof and the conditions), identical frames.  Off by default: on the headline scene it measures -2 ... +13 %
  * kernel time over five views (profiles/r04/ab_bounded_snippets.jsonl),
+ * bit22 = SLICES: the render entry takes its uniform block from a buffer of blocks, one per blockIdx.z (ptl_kernel_render_slices /
+ * ptl_renderer_draw_slices: one launch for the blur sub-frames of a clip frame).  Same arithmetic, same scalar loads, identical frames; a
+ * single draw is a batch of one,
  * bit15 = NO unrolling of baked loops: by default (with bit0) a counting loop of a scene snippet whose bound is a baked Int uniform
  * (<= 16 iterations) is unrolled -- the same operations in the same order, identical frames; every iteration then has its own
  * constants (scenes/portal_in_portal.ron's `size` drives an inner loop and a material index).
@@ -303,6 +325,15 @@ int ptl_renderer_set_option(ptl_renderer* r, const char* name, double value);
  * 0.0519 ms per sub-frame with one instance, 0.0522 with two, 0.0559 with four) -- the cross-stream waits cost what the overlap saves --
  * so nothing switches it on by default. */
 int ptl_renderer_join(ptl_renderer* r, void* stream);
+/* One launch for several draws of a renderer created with flag bit 22 (PTL_FLAG_SLICES): ptl_renderer_stage_slice does everything a draw
+ * does short of launching -- camera, rebuild checks, uniform evaluation for `frame` -- and keeps the resulting uniform block as slice `index`;
+ * ptl_renderer_draw_slices launches slices 0 .. n-1 at once (ptl_kernel_render_slices).  Between two stage calls: ptl_renderer_update,
+ * ptl_renderer_set_option("aa_start", j), camera moves ... as between two draws.  The slices are kept as snapshots of the uniform block, so a
+ * kernel rebuilt between two stage calls (a clip-constant build whose value moved) does not lose them.  draw_slices without slices
+ * 0 .. n-1 staged since the last launch is PTL_ERR_INVALID. */
+int ptl_renderer_stage_slice(ptl_renderer* r, const ptl_frame* frame, int index);
+int ptl_renderer_draw_slices(ptl_renderer* r, const ptl_frame* frame, int n, void* out_rgba8, void* out_rgba32f, unsigned long long slice_pixels,
+                             void* stream, float* elapsed_ms);
 /* Camera (RotateAroundCam): look_at xyz, alpha, beta, r. */
 int ptl_renderer_set_camera(ptl_renderer* r, const double look_at[3], double alpha, double beta, double radius);
 /* `render-frame --camera NAME` (src/main.rs:2918-2926, 1442-1478): take look_at / alpha / beta / r /

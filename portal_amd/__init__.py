@@ -59,6 +59,7 @@ FLAG_NO_DEFERRED_UPDATES = 128  # translate scene snippets exactly as written (d
 FLAG_QUICK_JIT = 262144  # compile at -O1 instead of the shipped -O3: half the JIT time, a 5-20 % slower kernel (one-off frames)
 FLAG_SPECIALIZE_PATTERNS = 1048576  # compile in only what survives moving values: zero patterns of the matrices + the renderer's mode switches
 FLAG_BOUNDED_SNIPPETS = 2097152  # opt-in: scene_intersect first, its hit distance bounds the intersection-material snippets (exact; measured: no gain on the headline)
+FLAG_SLICES = 4194304  # the render entry reads its uniform block from a buffer of blocks (one per blockIdx.z): stage_slice / draw_slices, one launch for several draws
 FLAG_NO_ZERO_MASKS = 524288  # A/B: run-time matrices keep their full products although their zero pattern is known (KernelOptions::mask_zero_elements)
 FLAG_ASYNC_REJIT = 131072  # a specialised renderer never stalls on a rebuild: it draws with the un-specialised kernel until a worker thread has the new one
 FLAG_NO_FIRST_TRIP_PLANES = 65536  # no first-trip copy of the generated plane tests (default: on the first trip `plane_inv * camera origin` comes from the prologue kernel)
@@ -145,6 +146,11 @@ def _load() -> C.CDLL:
         "ptl_renderer_create": (ci, [vp, ci, cp, C.c_uint, P(vp), cp, cs]),
         "ptl_renderer_kernel_source": (ci, [vp, P(vp)]),
         "ptl_renderer_join": (ci, [vp, vp]),
+        "ptl_renderer_stage_slice": (ci, [vp, P(Frame), ci]),
+        "ptl_renderer_draw_slices": (ci, [vp, P(Frame), ci, vp, vp, C.c_ulonglong, vp, P(C.c_float)]),
+        "ptl_kernel_max_slices": (ci, [vp]),
+        "ptl_kernel_stage_slice": (ci, [vp, ci]),
+        "ptl_kernel_render_slices": (ci, [vp, P(Frame), ci, vp, vp, C.c_ulonglong, vp, P(C.c_float)]),
         "ptl_kernel_clone": (ci, [vp, P(vp)]),
         "ptl_kernel_copy_uniforms": (ci, [vp, vp]),
         "ptl_renderer_create_with_options": (ci, [vp, ci, cp, C.c_uint, P(cp), P(cd), ci, P(vp), cp, cs]),
@@ -463,6 +469,17 @@ class SceneRenderer:
                 self._h = None
         except Exception:
             pass
+
+    def stage_slice(self, frame: Frame, index: int) -> None:
+        """Everything a draw of `frame` does short of launching; the uniform block it arrives at becomes slice `index` (FLAG_SLICES renderers)."""
+        _check(lib().ptl_renderer_stage_slice(self._h, C.byref(frame), index), "ptl_renderer_stage_slice")
+
+    def draw_slices(self, frame: Frame, n: int, out_rgba8: int = 0, out_rgba32f: int = 0, slice_pixels: int = 0, stream: int = 0, timed: bool = False):
+        """ONE launch for the staged slices 0 .. n-1: slice z at out_rgba8 + 4 * z * slice_pixels bytes (device addresses)."""
+        ms = C.c_float()
+        _check(lib().ptl_renderer_draw_slices(self._h, C.byref(frame), n, C.c_void_p(out_rgba8 or None), C.c_void_p(out_rgba32f or None), slice_pixels,
+                                              C.c_void_p(stream or None), C.byref(ms) if timed else None), "ptl_renderer_draw_slices")
+        return ms.value if timed else None
 
     def join(self, stream: int = 0) -> None:
         """With ``set_option("concurrent_draws", K)``: put `stream` (0 = the default stream) behind every draw issued so far."""

@@ -165,6 +165,8 @@ struct ptl_renderer {
         void* done = nullptr;
         bool busy = false;
     };
+    std::vector<std::vector<unsigned char>> staged_blocks;  // ptl_renderer_stage_slice: snapshots of the uniform block, one per slice ...
+    unsigned staged_mask = 0;                               // ... and which of them are staged since the last launch
     int concurrent = 1;
     std::vector<Lane> lanes;
     ptl_kernel* lanes_of = nullptr;  // the kernel the clones were made from
@@ -450,6 +452,7 @@ static KernelOptions options_from_flags(unsigned flags) {
     // zero patterns of the matrices that stay run-time values: with any specialisation (the un-specialised kernel has to be valid for every
     // state of the scene -- the background re-JIT draws with it meanwhile); PTL_FLAG_NO_ZERO_MASKS (bit 19) for A/B measurements and tests
     o.mask_zero_elements = (flags & (13u | (1u << 20))) != 0 && (flags & 524288u) == 0;
+    o.slices_entry = (flags & (1u << 22)) != 0;  // PTL_FLAG_SLICES: the render entry reads its uniform block from a buffer of blocks, one per blockIdx.z
     o.bound_snippets = (flags & (1u << 21)) != 0;  // PTL_FLAG_BOUNDED_SNIPPETS: scene_intersect first, its distance bounds the intersection-material snippets (opt-in: measured, no gain)
     o.first_trip_planes = (flags & 65536u) == 0;   // PTL_FLAG_NO_FIRST_TRIP_PLANES: one scene_intersect for every trip (A/B measurements, tests)
     // PTL_FLAG_NO_UNROLL: keep snippet loops with baked bounds as loops (A/B measurements).  The quick build keeps them too: unrolling
@@ -1181,6 +1184,39 @@ static int draw_on_a_lane(ptl_renderer* r, const ptl_frame* frame, void* out_rgb
     if (int rc = ptl_event_record(lane.done, lane.stream); rc != PTL_OK) return rc;
     lane.busy = true;
     return PTL_OK;
+}
+
+extern "C" int ptl_renderer_stage_slice(ptl_renderer* r, const ptl_frame* frame, int index) {
+    if (!r || !frame || index < 0 || index >= 16) return PTL_ERR_INVALID;
+    return guarded([&] {
+        int rc = prepare_draw(r, frame);
+        if (rc < 0) return rc;
+        // kept as a snapshot of the kernel's host copy of the uniform block: the block layout is the scene's, not the build's, so the
+        // snapshot outlives a rebuild of the kernel between two stage calls (a clip-constant build whose compiled-in value moved)
+        if (r->staged_blocks.size() < 16) r->staged_blocks.resize(16);
+        std::vector<unsigned char>& b = r->staged_blocks[index];
+        b.resize(ptl_kernel_uniform_block_size(r->kernel));
+        rc = ptl_kernel_snapshot_uniforms(r->kernel, b.data(), b.size());
+        if (rc == PTL_OK) r->staged_mask |= 1u << index;
+        return rc;
+    });
+}
+extern "C" int ptl_renderer_draw_slices(ptl_renderer* r, const ptl_frame* frame, int n, void* out_rgba8, void* out_rgba32f, unsigned long long slice_pixels,
+                                        void* stream, float* elapsed_ms) {
+    if (!r || !frame || n < 1 || n > 16) return PTL_ERR_INVALID;
+    return guarded([&] {
+        const unsigned want = (1u << n) - 1u;
+        if ((r->staged_mask & want) != want) {
+            set_last_error("ptl_renderer_draw_slices: slices 0 .. n-1 are not all staged (ptl_renderer_stage_slice) since the last launch");
+            return (int)PTL_ERR_INVALID;
+        }
+        for (int j = 0; j < n; ++j)
+            if (int rc = ptl_kernel_stage_slice_from(r->kernel, j, r->staged_blocks[j].data(), r->staged_blocks[j].size()); rc != PTL_OK) return rc;
+        if (int jrc = join_lanes(r, stream); jrc != PTL_OK) return jrc;
+        int rc = ptl_kernel_render_slices(r->kernel, frame, n, out_rgba8, out_rgba32f, slice_pixels, stream, elapsed_ms);
+        r->staged_mask = 0;
+        return rc;
+    });
 }
 
 extern "C" int ptl_renderer_join(ptl_renderer* r, void* stream) {

@@ -458,6 +458,64 @@ struct PortalMaterialNames {
 //   transform(NAME, ...)                                  -> ptl_transform_m<PTL_MASK_NAME>(NAME, ...)        (scene snippets, Complex objects)
 //   ptl_plane_cull[_o] / plane_intersect_derived[_o](r, NAME, ...) -> ...<PTL_MASK_NAME>(r, NAME, ...)     (generated plane tests)
 // Every other use of the matrix (a product written out in a snippet, a copy into a local) keeps the full chain: correct, just not shortened.
+// KernelOptions::slices_entry: the render entry takes its uniform block from a buffer of blocks (one per slice of the launch, blockIdx.z).
+// Done on the finished text, so that every other build stays exactly what it was; each anchor must be there (the template is ours).
+static void apply_slices_entry(std::string& src) {
+    auto replace_all = [&](const std::string& from, const std::string& to, int at_least) {
+        int n = 0;
+        for (size_t pos = 0; (pos = src.find(from, pos)) != std::string::npos; pos += to.size()) {
+            src.replace(pos, from.size(), to);
+            ++n;
+        }
+        if (n < at_least) throw SceneError("slices entry: the kernel template no longer has `" + from.substr(0, 60) + "`");
+    };
+    // The prelude (device/ptl_library.h) sits in front of the tracer struct as free functions, and three of them read renderer uniforms
+    // (`_grid_disable`, `_angle_color_disable`, `_offset_after_material`) -- through the module's global block, which a slice does not use.
+    // It moves INTO the struct, in front of the scene snippets: as member functions they read the block the tracer points at, like
+    // everything else.  Same text, same line count behind it (the scene's own lines keep their numbers for diagnostics).
+    {
+        const std::string tail = "}  // namespace glsl\n";
+        const std::string anchor = "// Scene snippets are plain GLSL functions without HIP attributes: let clang treat every\n";
+        const size_t begin = src.find("// ptl_library.h -- the fixed prelude every generated portal kernel starts with.");
+        const size_t ns_open = begin == std::string::npos ? std::string::npos : src.find("namespace glsl {\n", begin);
+        // the prelude's own closing line is the one in front of the `namespace glsl {` the generator re-opens behind it
+        const size_t reopen = begin == std::string::npos ? std::string::npos : src.find("\n" + tail + "\nnamespace glsl {\n", begin);
+        const size_t into = src.find(anchor);
+        if (begin == std::string::npos || ns_open == std::string::npos || reopen == std::string::npos || into == std::string::npos || into < reopen)
+            throw SceneError("slices entry: the prelude is not where the kernel template used to put it");
+        const size_t lib_end = reopen + 1 + tail.size();  // one past the prelude's closing line
+        std::string lib = src.substr(begin, lib_end - begin);
+        lib.replace(lib.size() - tail.size(), tail.size() - 1, "");                   // a class body has no namespaces: the wrapper's two
+        lib.replace(ns_open - begin, std::string("namespace glsl {").size(), "");     // lines stay as empty lines
+        src.erase(begin, lib_end - begin);
+        src.insert(src.find(anchor), lib);  // cut N lines above, paste N lines above: every line from here on keeps its number
+    }
+    // the tracer remembers where the block of THIS launch lives; the once-per-trip re-laundering starts from there
+    replace_all("    const ptl_uniform_block* ptl_ubp;\n", "    const ptl_uniform_block* ptl_ubp; const ptl_uniform_block* ptl_home;\n", 1);  // (same line: the snippets keep their line numbers)
+    replace_all("reinterpret_cast<const char*>(&ptl_u) + ptl_zero", "reinterpret_cast<const char*>(ptl_home) + ptl_zero", 1);
+    replace_all("ptl_tracer t{&ptl_u};", "ptl_tracer t{&ptl_u, &ptl_u};", 3);
+    replace_all("PTL_FN void derive_uniforms(ptl_uniform_block* block) {\n    ptl_tracer t{&ptl_u, &ptl_u};\n    t.derive(block);\n}\n",
+                "PTL_FN void derive_uniforms(ptl_uniform_block* block) {\n    ptl_tracer t{&ptl_u, &ptl_u};\n    t.derive(block);\n}\n"
+                "// (slices entry: the block of a slice is read where it lies in the launch's buffer, and its derived members are written there)\n"
+                "PTL_FN vec4 shade_pixel_in(vec2 position, const ptl_uniform_block* home) {\n    ptl_tracer t{home, home};\n    return t.shade_pixel(position);\n}\n"
+                "PTL_FN void derive_uniforms_in(ptl_uniform_block* block) {\n    ptl_tracer t{block, block};\n    t.derive(block);\n}\n",
+                1);
+    // the entry: another name (layer 1 tells the two kinds of module apart by it), two more arguments, one slice per blockIdx.z
+    replace_all("ptl_render_kernel(unsigned int* __restrict__ out_rgba8,", "ptl_render_slices_kernel(const glsl::ptl_uniform_block* __restrict__ ptl_slices, unsigned long long ptl_slice_pixels, unsigned int* __restrict__ out_rgba8,", 1);
+    replace_all("    const int t = (int)threadIdx.x;\n    const int wave = t >> 6, lane = t & 63;\n",
+                "    const int t = (int)threadIdx.x;\n    const int wave = t >> 6, lane = t & 63;\n"
+                "    if (out_rgba8 != nullptr) out_rgba8 += (unsigned long long)blockIdx.z * ptl_slice_pixels;      // slice z of the launch: its own frame ...\n"
+                "    if (out_rgba32f != nullptr) out_rgba32f += 4ull * blockIdx.z * ptl_slice_pixels;\n"
+                "    const glsl::ptl_uniform_block* const ptl_slice_block = ptl_slices + blockIdx.z;                // ... and its own uniforms\n", 1);
+    replace_all("    if (live) c = glsl::shade_pixel(glsl::vec2((float)px + 0.5f, (float)py + 0.5f));\n\n    const int out_block",
+                "    if (live) c = glsl::shade_pixel_in(glsl::vec2((float)px + 0.5f, (float)py + 0.5f), ptl_slice_block);\n\n    const int out_block", 1);
+    // the prologue of a batch: one workgroup per slice fills the derived members of that slice's block
+    replace_all("#else  // host build of the same source (oracle/host_build): rows [row_begin, row_end) of the frame\n",
+                "extern \"C\" __global__ void __launch_bounds__(64) ptl_derive_slices_kernel(glsl::ptl_uniform_block* blocks) {\n"
+                "    if (threadIdx.x == 0) glsl::derive_uniforms_in(blocks + blockIdx.x);\n}\n\n"
+                "#else  // host build of the same source (oracle/host_build): rows [row_begin, row_end) of the frame\n", 1);
+}
+
 static void apply_zero_masks(std::string& src, const std::vector<std::pair<std::string, unsigned>>& masked) {
     auto ident = [](char c) { return std::isalnum((unsigned char)c) || c == '_'; };
     for (auto& [name, mask] : masked) {
@@ -1164,6 +1222,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     gk.source = std::move(body.storage);
     gk.line_numbers = std::move(body.line_numbers);
     apply_zero_masks(gk.source, gk.masked);
+    if (opts.slices_entry) apply_slices_entry(gk.source);
     if (opts.count_segments) gk.defines.push_back("PTL_COUNT_SEGMENTS");
     if (opts.anaglyph) gk.defines.push_back("PTL_ANAGLYPH");
     if (opts.fast_math) gk.defines.push_back("PTL_FAST_MATH");

@@ -129,6 +129,11 @@ struct KernelOptions {
     // skips are entered by few lanes anyway, and keeping scene_intersect's hit alive across the snippet costs what the skipped work saves
     // (-2 ... +13 % kernel time).  Kept as an option for scenes whose snippets are dominated by their inside tests.
     bool bound_snippets = false;
+    // The render entry reads its uniform block from a device BUFFER of blocks instead of the module's one global, indexed by blockIdx.z
+    // (`ptl_render_slices_kernel`): ONE launch then traces several frames that differ in their uniforms -- the motion-blur sub-frames of a clip
+    // frame (src/main.rs:1798 re-draws with `_aa_start` windows one after the other) -- so that their ramps and tails overlap.  Applied to the
+    // generated text by substitution (codegen.cpp `apply_slices_entry`): kernels built without it are byte for byte what they were.
+    bool slices_entry = false;
     bool quick_jit = false;  // PTL_QUICK_JIT: compile at -O1 instead of the shipped -O3 (half the JIT time, a 5-20 % slower kernel)
     bool fast_math = false;  // PTL_FAST_MATH: hardware rcp / sqrt / rsq (1 ulp), a/b = a * rcp(b), FMA contraction: tolerance mode, not bit-exact
 };

@@ -139,6 +139,14 @@ struct ptl_kernel {
     hip::hipEvent_t ev_done = nullptr;  // recorded behind every render launch: what destroy / a teleport query wait for.  Owned here, so it
                                         // stays valid when the caller has already destroyed the stream it launched on (a torch stream, a
                                         // user stream freed before the renderer: Python __del__ order is unspecified).
+    // A module generated with the slices entry (codegen.cpp `apply_slices_entry`): its render entry `ptl_render_slices_kernel` reads the uniform
+    // block of slice blockIdx.z from a device buffer of blocks, so one launch can trace several frames with different uniforms.  The module's
+    // own global block stays what the camera-teleport query uses.
+    bool sliced = false;
+    hip::hipFunction_t derive_slices_fn = nullptr;
+    void* dev_slices = nullptr;           // kMaxSlices blocks of dev_block_size bytes
+    std::vector<unsigned char> staged;    // host side of it: slice j at j * dev_block_size (ptl_kernel_stage_slice)
+    bool slice0_dirty = true;             // slice 0 of the buffer no longer holds `shadow` (a single draw uses slice 0)
     unsigned block_waves = 4;       // PTL_BLOCK_WAVES (experiments with narrower workgroups), read once at compile time
     void* last_stream = nullptr;    // the stream of the most recent render launch ...
     bool launched = false;          // ... which may still be reading the uniform block
@@ -167,6 +175,8 @@ extern "C" int ptl_device_count(void) {
     if (rt->hipGetDeviceCount(&n) != 0) return 0;
     return n;
 }
+
+static constexpr int kMaxSlices = 16;
 
 static size_t type_size(ptl_type t) {
     switch (t) {
@@ -314,8 +324,15 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
         }
         return PTL_ERR_HIP;
     }
-    if (!hip_ok(rt, rt->hipModuleGetFunction(&k->fn, k->module, "ptl_render_kernel"), "hipModuleGetFunction(ptl_render_kernel)"))
-        return PTL_ERR_HIP;
+    if (rt->hipModuleGetFunction(&k->fn, k->module, "ptl_render_kernel") != 0) {
+        rt->hipGetLastError();
+        // a module with the slices entry instead (codegen.cpp `apply_slices_entry`)
+        if (!hip_ok(rt, rt->hipModuleGetFunction(&k->fn, k->module, "ptl_render_slices_kernel"), "hipModuleGetFunction(ptl_render_kernel / ptl_render_slices_kernel)"))
+            return PTL_ERR_HIP;
+        if (!hip_ok(rt, rt->hipModuleGetFunction(&k->derive_slices_fn, k->module, "ptl_derive_slices_kernel"), "hipModuleGetFunction(ptl_derive_slices_kernel)"))
+            return PTL_ERR_HIP;
+        k->sliced = true;
+    }
     if (rt->hipModuleGetFunction(&k->teleport_fn, k->module, "ptl_teleport_kernel") != 0) {
         k->teleport_fn = nullptr;   // hand-written layer-1 kernels need not have the second entry point
         rt->hipGetLastError();      // ... and the expected hipErrorNotFound must not stay behind as the thread's sticky
@@ -361,7 +378,12 @@ extern "C" int ptl_kernel_clone(ptl_kernel* src, ptl_kernel** out) {
         k->module = nullptr;
         return rc;
     };
-    if (!hip_ok(rt, rt->hipModuleGetFunction(&k->fn, k->module, "ptl_render_kernel"), "hipModuleGetFunction(ptl_render_kernel)")) return fail(PTL_ERR_HIP);
+    if (rt->hipModuleGetFunction(&k->fn, k->module, src->sliced ? "ptl_render_slices_kernel" : "ptl_render_kernel") != 0 ||
+        (src->sliced && rt->hipModuleGetFunction(&k->derive_slices_fn, k->module, "ptl_derive_slices_kernel") != 0)) {
+        hip_ok(rt, 1, "hipModuleGetFunction(clone)");
+        return fail(PTL_ERR_HIP);
+    }
+    k->sliced = src->sliced;
     if (rt->hipModuleGetFunction(&k->teleport_fn, k->module, "ptl_teleport_kernel") != 0) {
         k->teleport_fn = nullptr;
         rt->hipGetLastError();
@@ -386,6 +408,7 @@ extern "C" int ptl_kernel_copy_uniforms(ptl_kernel* dst, const ptl_kernel* src) 
     if (std::memcmp(dst->shadow.data(), src->shadow.data(), src->shadow.size()) != 0) {
         dst->shadow = src->shadow;
         dst->dirty = true;
+        dst->slice0_dirty = true;
     }
     return PTL_OK;
 }
@@ -417,6 +440,7 @@ extern "C" int ptl_kernel_set_uniform(ptl_kernel* k, const char* name, ptl_type 
     if (std::memcmp(k->shadow.data() + it->second.offset, value, n) != 0) {
         std::memcpy(k->shadow.data() + it->second.offset, value, n);
         k->dirty = true;
+        k->slice0_dirty = true;
     }
     return PTL_OK;
 }
@@ -444,6 +468,7 @@ extern "C" int ptl_kernel_set_texture(ptl_kernel* k, const char* sampler, const 
     static_assert(sizeof s == 16, "sampler2D layout");
     std::memcpy(k->shadow.data() + it->second.offset, &s, sizeof s);
     k->dirty = true;
+    k->slice0_dirty = true;
     return PTL_OK;
 }
 
@@ -477,12 +502,118 @@ static int upload_uniforms(ptl_kernel* k, const hip::Runtime* rt, void* stream) 
     return PTL_OK;
 }
 
+// ---- modules with the slices entry -------------------------------------------------------------------------------------------
+// Stream-ordered upload of `n` staged blocks (or, for a single draw, of the host copy as slice 0) into the module's buffer of blocks,
+// followed by the prologue of every slice.
+static int upload_slices(ptl_kernel* k, const hip::Runtime* rt, void* stream, int n, bool single) {
+    const size_t stride = k->dev_block_size;
+    if (!k->dev_slices && !hip_ok(rt, rt->hipMalloc(&k->dev_slices, stride * kMaxSlices), "hipMalloc(uniform block slices)")) return PTL_ERR_HIP;
+    if (single) {
+        if (!k->slice0_dirty) return PTL_OK;
+        if (!hip_ok(rt, rt->hipMemcpyAsync(k->dev_slices, k->shadow.data(), k->shadow.size(), hip::kMemcpyHostToDevice, stream), "hipMemcpyAsync(uniform block -> slice 0)"))
+            return PTL_ERR_HIP;
+    } else {
+        if (!hip_ok(rt, rt->hipMemcpyAsync(k->dev_slices, k->staged.data(), stride * (size_t)n, hip::kMemcpyHostToDevice, stream), "hipMemcpyAsync(uniform block slices)"))
+            return PTL_ERR_HIP;
+    }
+    void* blocks = k->dev_slices;
+    void* args[] = {&blocks};
+    if (!hip_ok(rt, rt->hipModuleLaunchKernel(k->derive_slices_fn, (unsigned)n, 1, 1, 64, 1, 1, 0, stream, args, nullptr), "hipModuleLaunchKernel(ptl_derive_slices_kernel)"))
+        return PTL_ERR_HIP;
+    k->slice0_dirty = !single;  // (a batch leaves its own slice 0 behind)
+    return PTL_OK;
+}
+
+static int launch_slices(ptl_kernel* k, const hip::Runtime* rt, const ptl_frame* frame, int n, void* out_rgba8, void* out_rgba32f, unsigned long long slice_pixels,
+                         void* segments, void* stream, float* elapsed_ms) {
+    int nby = shard_blocks(frame);
+    if (nby == 0) {
+        if (elapsed_ms) *elapsed_ms = 0.0f;
+        return PTL_OK;
+    }
+    int width = frame->width, height = frame->height, phase = frame->rb_phase, stride = frame->rb_stride;
+    int in_place = frame->in_place ? 1 : 0;
+    void* blocks = k->dev_slices;
+    void* args[] = {&blocks, &slice_pixels, &out_rgba8, &out_rgba32f, &width, &height, &phase, &stride, &segments, &in_place};
+    const unsigned waves = k->block_waves;
+    unsigned gx = (unsigned)((width + 8 * waves - 1) / (8 * waves)), gy = (unsigned)nby;
+    if (elapsed_ms) rt->hipEventRecord(k->ev0, stream);
+    if (!hip_ok(rt, rt->hipModuleLaunchKernel(k->fn, gx, gy, (unsigned)n, 64 * waves, 1, 1, 0, stream, args, nullptr), "hipModuleLaunchKernel(ptl_render_slices_kernel)")) return PTL_ERR_HIP;
+    k->last_stream = stream;
+    k->launched = true;
+    if (k->ev_done) rt->hipEventRecord(k->ev_done, stream);
+    if (elapsed_ms) {
+        rt->hipEventRecord(k->ev1, stream);
+        if (!hip_ok(rt, rt->hipEventSynchronize(k->ev1), "hipEventSynchronize")) return PTL_ERR_HIP;
+        rt->hipEventElapsedTime(elapsed_ms, k->ev0, k->ev1);
+    }
+    return PTL_OK;
+}
+
+extern "C" int ptl_kernel_max_slices(ptl_kernel* k) { return (k && k->sliced) ? kMaxSlices : 0; }
+
+// The current uniform values (everything set with ptl_kernel_set_uniform / _set_texture so far) become slice `index` of the next batch.
+extern "C" int ptl_kernel_stage_slice(ptl_kernel* k, int index) {
+    if (!k) return PTL_ERR_INVALID;
+    return ptl_kernel_stage_slice_from(k, index, k->shadow.data(), k->shadow.size());
+}
+
+// ... or a block saved earlier with ptl_kernel_snapshot_uniforms -- possibly from ANOTHER kernel of the same scene (every build of a scene has
+// the same block layout; a renderer that had to rebuild its kernel between staging and launching re-stages its snapshots into the new one).
+// Sampler records are taken from THIS kernel: they point at texel buffers each kernel owns.
+extern "C" int ptl_kernel_stage_slice_from(ptl_kernel* k, int index, const void* block, size_t size) {
+    if (!k || !block || index < 0 || index >= kMaxSlices) return PTL_ERR_INVALID;
+    if (!k->sliced) {
+        set_last_error("ptl_kernel_stage_slice: the kernel was not generated with the slices entry (PTL_FLAG_SLICES)");
+        return PTL_ERR_INVALID;
+    }
+    if (k->device < 0) return PTL_ERR_NO_DEVICE;
+    if (size != k->shadow.size()) {
+        set_last_error("ptl_kernel_stage_slice_from: the block has another size than this kernel's uniform block (another scene?)");
+        return PTL_ERR_INVALID;
+    }
+    const size_t stride = k->dev_block_size;
+    if (k->staged.size() < stride * kMaxSlices) k->staged.assign(stride * kMaxSlices, 0);
+    unsigned char* dst = k->staged.data() + stride * (size_t)index;
+    std::memcpy(dst, block, size);
+    for (auto& [name, slot] : k->slots)
+        if (slot.type == PTL_SAMPLER) std::memcpy(dst + slot.offset, k->shadow.data() + slot.offset, 16);
+    return PTL_OK;
+}
+
+extern "C" size_t ptl_kernel_uniform_block_size(ptl_kernel* k) { return k ? k->shadow.size() : 0; }
+extern "C" int ptl_kernel_snapshot_uniforms(ptl_kernel* k, void* dst, size_t cap) {
+    if (!k || !dst || cap < k->shadow.size()) return PTL_ERR_INVALID;
+    std::memcpy(dst, k->shadow.data(), k->shadow.size());
+    return PTL_OK;
+}
+
+// ONE launch for the staged slices 0 .. n-1: slice z renders `frame` with its own uniforms into out_rgba8 + z * slice_pixels pixels
+// (and out_rgba32f + 4 * z * slice_pixels floats).
+extern "C" int ptl_kernel_render_slices(ptl_kernel* k, const ptl_frame* frame, int n, void* out_rgba8, void* out_rgba32f, unsigned long long slice_pixels,
+                                        void* stream, float* elapsed_ms) {
+    if (!k || !frame || ptl_frame_shard_rows(frame) < 0 || n < 1 || n > kMaxSlices) return PTL_ERR_INVALID;
+    if (!k->sliced || k->staged.empty()) {
+        set_last_error("ptl_kernel_render_slices: no staged slices (PTL_FLAG_SLICES build + ptl_kernel_stage_slice)");
+        return PTL_ERR_INVALID;
+    }
+    if (k->device < 0 || !k->fn) return PTL_ERR_NO_DEVICE;
+    const hip::Runtime* rt = hip::runtime(nullptr);
+    if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;
+    if (int rc = upload_slices(k, rt, stream, n, false); rc != PTL_OK) return rc;
+    return launch_slices(k, rt, frame, n, out_rgba8, out_rgba32f, slice_pixels, nullptr, stream, elapsed_ms);
+}
+
 extern "C" int ptl_kernel_render(ptl_kernel* k, const ptl_frame* frame, void* out_rgba8, void* out_rgba32f, void* segments,
                                  void* stream, float* elapsed_ms) {
     if (!k || !frame || ptl_frame_shard_rows(frame) < 0) return PTL_ERR_INVALID;
     if (k->device < 0 || !k->fn) return PTL_ERR_NO_DEVICE;
     const hip::Runtime* rt = hip::runtime(nullptr);
     if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;
+    if (k->sliced) {  // a single draw of a module with the slices entry: slice 0 of its buffer, one slice
+        if (int rc = upload_slices(k, rt, stream, 1, true); rc != PTL_OK) return rc;
+        return launch_slices(k, rt, frame, 1, out_rgba8, out_rgba32f, 0, segments, stream, elapsed_ms);
+    }
     if (int rc = upload_uniforms(k, rt, stream); rc != PTL_OK) return rc;
     int nby = shard_blocks(frame);
     if (nby == 0) {
@@ -585,6 +716,7 @@ extern "C" void ptl_kernel_destroy(ptl_kernel* k) {
         if (k->ev_done) rt->hipEventDestroy(k->ev_done);
         for (auto& t : k->textures)
             if (t.second) rt->hipFree(t.second);
+        if (k->dev_slices) rt->hipFree(k->dev_slices);
         if (k->ev0) rt->hipEventDestroy(k->ev0);
         if (k->ev1) rt->hipEventDestroy(k->ev1);
         if (k->module) rt->hipModuleUnload(k->module);

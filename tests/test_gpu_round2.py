@@ -269,7 +269,7 @@ def test_flipped_mode_switch_with_background_rejit_draws_the_same_bits_meanwhile
     assert np.array_equal(_bits(got), _bits(pinhole))
 
 
-@pytest.mark.parametrize("flavour", ["ints", "static", "static+async"])
+@pytest.mark.parametrize("flavour", ["ints", "static", "static+async", "patterns", "patterns+async"])
 def test_zero_patterns_of_runtime_matrices_follow_the_values(gpu, flavour):
     """KernelOptions::mask_zero_elements: a specialised build shortens the products of matrices that stay run-time values by their ZERO
     PATTERN.  `progress` of portal_in_portal turns a portal (rotation 0 at progress 0: zeros in the rotation block, none once it moves): the
@@ -279,7 +279,8 @@ def test_zero_patterns_of_runtime_matrices_follow_the_values(gpu, flavour):
 
     pa = gpu
     path = pa.scene_path("portal_in_portal")
-    flags = {"ints": pa.FLAG_SPECIALIZE_INTS, "static": pa.FLAG_SPECIALIZE_STATIC, "static+async": pa.FLAG_SPECIALIZE_STATIC | pa.FLAG_ASYNC_REJIT}[flavour]
+    flags = {"ints": pa.FLAG_SPECIALIZE_INTS, "static": pa.FLAG_SPECIALIZE_STATIC, "static+async": pa.FLAG_SPECIALIZE_STATIC | pa.FLAG_ASYNC_REJIT,
+             "patterns": pa.FLAG_SPECIALIZE_PATTERNS, "patterns+async": pa.FLAG_SPECIALIZE_PATTERNS | pa.FLAG_ASYNC_REJIT}[flavour]
     sa, sb = pa.Scene.from_file(path), pa.Scene.from_file(path)
     ra, rb = pa.SceneRenderer(sa, device=0), pa.SceneRenderer(sb, device=0, flags=flags)
     for r in (ra, rb):
@@ -299,6 +300,8 @@ def test_zero_patterns_of_runtime_matrices_follow_the_values(gpu, flavour):
         assert np.array_equal(_bits(a), _bits(b)), (flavour, value, "adopted")
         seen.append(a.copy())
     assert not np.array_equal(_bits(seen[0]), _bits(seen[1])) and np.array_equal(_bits(seen[0]), _bits(seen[2]))  # the portal really moved, and came back
+    if flavour == "patterns":  # no value is compiled in: the ONE rebuild is the broken pattern's (all masks dropped), later moves cost nothing
+        assert rb.rejit_count() == 1
     # the masks are there to be followed: the Bool / Int build of the start state knows the zero rotation of the portal, the later one does not
     if flavour == "ints":
         start, moved = pa.Scene.from_file(path), pa.Scene.from_file(path)
@@ -629,3 +632,74 @@ def test_concurrent_draws_give_the_frames_of_draws_one_by_one(gpu, flags_name):
     assert len(np.unique(last1.reshape(-1, 4), axis=0)) > 100 and not np.array_equal(last1[0], last1[1])
     if flags_name == "static":
         assert rejits >= 1
+
+
+@pytest.mark.parametrize("flags_name", ["dynamic", "baked", "static"])
+def test_one_launch_for_several_draws_gives_the_frames_of_draws_one_by_one(gpu, flags_name):
+    """PTL_FLAG_SLICES: the render entry reads the uniform block of slice blockIdx.z from a buffer of blocks (same scalar loads, same
+    arithmetic), so ONE launch traces the motion-blur sub-frames of a clip frame -- other camera, other uniform values, other `_aa_start`
+    window each.  The frames must be the ones a renderer without the flag draws one by one, byte for byte (RGBA8) and bit for bit (float),
+    for a ragged frame size too; a single draw of such a renderer is a batch of one; the camera-teleport query still answers; slices staged
+    before a rebuild of the kernel (a clip-constant build whose value moves) are launched with the rebuilt kernel."""
+    import torch
+
+    pa = gpu
+    dev = torch.device("cuda:0")
+    base = {"dynamic": 0, "baked": pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL, "static": pa.FLAG_SPECIALIZE_STATIC}[flags_name]
+    w, h, n = 328, 186, 5
+    frame = pa.Frame(w, h, 0, 1)
+
+    def state(k):
+        return 0.04 * k, ((0.02 * k, 0.1 - 0.01 * k, -0.3), 0.9 + 0.05 * k, 1.2, 3.1 - 0.1 * k)
+
+    def make(extra):
+        scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+        r = pa.SceneRenderer(scene, device=0, flags=base | extra)
+        r.set_option("render_depth", 20)
+        r.set_option("aa_count", 2)
+        return scene, r
+
+    # the frames one by one, classic renderer (the moving uniform is animated per frame: a baked build would re-JIT per value -- keep it to the camera there)
+    moving_uniform = flags_name != "baked"
+    scene_a, ra = make(0)
+    want8, want32 = [], []
+    for k in range(n):
+        angle, cam = state(k)
+        if moving_uniform:
+            assert scene_a.set_uniform("portal_rotate_angle", angle)
+        ra.set_camera(*cam)
+        ra.set_option("aa_start", k)
+        out = ra.draw(w, h, rgba8=True, rgba32f=True)
+        want8.append(out["rgba8"].copy())
+        want32.append(out["rgba32f"].copy())
+    assert not np.array_equal(want8[0], want8[1])
+
+    scene_b, rb = make(pa.FLAG_SLICES)
+    assert "ptl_render_slices_kernel" in rb.kernel_source() and "ptl_render_slices_kernel" not in ra.kernel_source()
+    out8 = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
+    out32 = torch.zeros((n, h, w, 4), dtype=torch.float32, device=dev)
+    for k in range(n):
+        angle, cam = state(k)
+        if moving_uniform:
+            assert scene_b.set_uniform("portal_rotate_angle", angle)
+        rb.set_camera(*cam)
+        rb.set_option("aa_start", k)
+        rb.stage_slice(frame, k)
+    ms = rb.draw_slices(frame, n, out_rgba8=out8.data_ptr(), out_rgba32f=out32.data_ptr(), slice_pixels=w * h, timed=True)
+    assert ms > 0
+    got8, got32 = out8.cpu().numpy(), out32.cpu().numpy()
+    for k in range(n):
+        assert np.array_equal(got8[k], want8[k]), k
+        assert np.array_equal(_bits(got32[k]), _bits(want32[k])), k
+    # launching again without staging: refused; a single draw of the sliced renderer: a batch of one, the last state
+    with pytest.raises(pa.PortalError, match="not all staged"):
+        rb.draw_slices(frame, n, out_rgba8=out8.data_ptr(), slice_pixels=w * h)
+    single = rb.draw(w, h, rgba8=True, rgba32f=True)
+    assert np.array_equal(single["rgba8"], want8[-1]) and np.array_equal(_bits(single["rgba32f"]), _bits(want32[-1]))
+    # the camera-teleport query runs on the module's own block: same answer as the classic renderer's
+    qa = ra.teleport_external_ray((0.0, 0.0, 2.0), (0.0, 0.0, -2.0))
+    qb = rb.teleport_external_ray((0.0, 0.0, 2.0), (0.0, 0.0, -2.0))
+    assert str(qa) == str(qb)
+    assert np.array_equal(rb.draw(w, h)["rgba8"], ra.draw(w, h)["rgba8"])  # ... and leaves the next draws alone
+    if flags_name == "static":  # (the moving uniform was compiled in: the kernel was rebuilt between two stage calls, and the slices staged before it survived)
+        assert rb.rejit_count() >= 1

@@ -4,7 +4,8 @@
     python tools/concurrent_draws.py [--precompile]
 
 For each (scene, size): ROUNDS x 4 sub-frames whose uniforms move from one to the next (what `portal-amd render --motion-blur-frames 4` issues),
-with "concurrent_draws" 1 (one kernel instance: every launch waits for the previous one's uniform block), 2 and 4; wall time from the first
+with "concurrent_draws" 1 (one kernel instance: every launch waits for the previous one's uniform block), 2 and 4, and as ONE launch
+with grid.z = 4 (FLAG_SLICES: one uniform block per slice in a device buffer); wall time from the first
 launch to a device synchronize, per sub-frame, and a hash over all frames that must not depend on K."""
 import hashlib, json, os, sys, time
 import numpy as np
@@ -18,11 +19,40 @@ ROUNDS, N = 24, 4
 if __name__ == "__main__":
     pre = "--precompile" in sys.argv
     for name, w, h, depth, aa in CASES:
-        for lanes in (1, 2, 4):
+        for lanes in (1, 2, 4, "one launch"):
             scene = pa.Scene.from_file(pa.scene_path(name))
-            r = pa.SceneRenderer(scene, device=-1 if pre else 0, flags=pa.FLAG_SPECIALIZE_STATIC)
+            sliced = lanes == "one launch"
+            r = pa.SceneRenderer(scene, device=-1 if pre else 0, flags=pa.FLAG_SPECIALIZE_STATIC | (pa.FLAG_SLICES if sliced else 0))
             if pre:
-                break
+                if sliced:
+                    break
+                continue
+            if sliced:
+                r.set_option("render_depth", depth)
+                r.set_option("aa_count", aa)
+                big = pa.device_alloc(N * w * h * 4, 0)
+                frame = pa.Frame(w, h, 0, 1)
+                digest = hashlib.sha1()
+
+                def batch(k0):
+                    for j in range(N):
+                        k = k0 + j
+                        r.set_camera((0.01 * (k % 7), 0.1, -0.3), 0.9 + 0.01 * (k % 11), 1.2, 3.1)
+                        r.set_option("aa_start", j)
+                        r.stage_slice(frame, j)
+                    r.draw_slices(frame, N, out_rgba8=big, slice_pixels=w * h)
+
+                batch(0)
+                digest.update(pa.device_download(big, N * w * h * 4).tobytes())
+                t0 = time.perf_counter()
+                for rnd in range(ROUNDS):
+                    batch(rnd * N)
+                pa.device_download(big, 16)
+                dt = time.perf_counter() - t0
+                print(json.dumps({"scene": name, "size": f"{w}x{h}", "aa": aa, "concurrent_draws": "one launch, grid.z = 4", "ms_per_subframe": round(dt / (ROUNDS * N) * 1e3, 4),
+                                  "sha": digest.hexdigest()[:10]}), flush=True)
+                pa.device_free(big)
+                continue
             r.set_option("render_depth", depth)
             r.set_option("aa_count", aa)
             r.set_option("concurrent_draws", lanes)
