@@ -37,7 +37,7 @@ void usage() {
                  "                  [--specialize 0] do NOT bake the scene state into the kernel   [--fast] tolerance mode   [--exact-cr] numerics contract 1   [--opt3] JIT at -O3 like the library default (render-frame: -O1)   [--timing] where the wall time went\n"
                  "       portal-amd precompile <scene.ron> [--stage NAME] [--specialize 0]      fill the code-object cache (no GPU needed)\n"
                  "       portal-amd render <scene[,scene..]> [clip[,clip..]] [--width 3840] [--height 2160] [--fps 60] [--motion-blur-frames 1]\n"
-                 "                  [--stereoimage] [--no-skip-existing] [--filter-starts-with P] [--aa-count 4] [--render-depth 150]\n"
+                 "                  [--stereoimage] [--batch-subframes 0|1] [--no-skip-existing] [--filter-starts-with P] [--aa-count 4] [--render-depth 150]\n"
                  "                  [--scenes-dir DIR] [--out-dir DIR] [--device I] [--shard K/N] [--max-frames N] [--asset-root DIR]\n"
                  "                  [--specialize 0|1]   bake what is constant within a clip into the kernel (default: when it pays)\n"
                  "                  [--fast]             tolerance mode for the whole clip (hardware rcp / sqrt, FMA contraction)\n"
@@ -179,12 +179,18 @@ constexpr unsigned kRenderFlags = 0u;
 // matrices and the mode switches compiled in (PTL_FLAG_SPECIALIZE_PATTERNS, bit 20: no value baked, so nothing moves under it but a
 // pattern -- one rebuild per stage at most): 0.58 against 0.83 ms on the headline frame (profiles/r04/ab_bounded_snippets.jsonl `patterns`)
 constexpr unsigned kClipFlags = kRenderFlags | (1u << 20);
+// ... and, for a clip with motion blur, the slices entry (bit 22): the blur sub-frames of an output frame differ in their uniforms only and are
+// traced by ONE launch (grid.z = sub-frame, a uniform block per slice), so the ramp and tail of a small frame overlap with its neighbours' instead
+// of adding up: 1080p monoportal 0.0526 -> 0.0415 ms per sub-frame, 720p 0.0319 -> 0.0213, 4K aa 4 0.885 -> 0.861 (profiles/r04/concurrent_draws.jsonl)
+constexpr unsigned kSlicesFlag = 1u << 22;
+inline bool batch_subframes(int blur, int batch_option) { return batch_option != 0 && blur >= 2 && blur <= 16; }
 // frames of a clip are intermediates (ffmpeg reads them, then anim/ is removed): fast deflate, 2.3x the encode rate of level 6
 constexpr int kFrameDeflateLevel = 3;
 
 struct Options {
     std::string scene, clips, output = "frame.png", asset_root = ".", stage, animation, camera, scenes_dir = "scenes", out_dir = ".", starts_with;
     bool have_camera = false, stereo = false, skip_existing = true;
+    int batch = -1;       // render --batch-subframes 0|1: one launch for a frame's blur sub-frames (default: on where 2 <= blur <= 16)
     int concurrent = -1;  // render --concurrent-draws K: kernel instances in flight for a frame's blur sub-frames (default 1: measured, no gain)
     std::vector<std::pair<std::string, double>> sets;  // --set name=value
     bool timing = false;  // --timing: wait for every kernel and report GPU milliseconds (serialises host and GPU)
@@ -482,7 +488,7 @@ int precompile(const Options& o) {
     if (!o.stage.empty() && ptl_scene_init_stage(scene, o.stage.c_str(), stage_cam, sizeof stage_cam) != PTL_OK) return fail("stage");
     std::vector<char> log(1 << 16);
     std::vector<unsigned> variants = {frame_flags(o)};
-    if (o.specialize != 0) variants.push_back(kClipFlags | (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u) | (o.opt3 ? 0u : 262144u));  // + the dynamic-uniform kernel `render` starts clips with
+    if (o.specialize != 0) variants.push_back(kClipFlags | (batch_subframes(o.blur, o.batch) ? kSlicesFlag : 0u) | (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u) | (o.opt3 ? 0u : 262144u));  // + the dynamic-uniform kernel `render` starts clips with
     for (unsigned flags : variants) {
         auto t1 = std::chrono::steady_clock::now();
         ptl_renderer* r = nullptr;
@@ -564,23 +570,32 @@ int render_clip(const Options& o, ptl_scene* scene, ptl_renderer* r, const std::
         }
         int slot = (int)(drawn_frames++ % FramePipeline::kRing);
         if (pipe.copy_pending[slot] && ptl_stream_wait_event(nullptr, pipe.copied[slot]) != PTL_OK) return fail("wait");  // GPU-side: slot is free
+        const bool batched = batch_subframes(o.blur, o.batch);
         for (int j = 0; j < o.blur; ++j) {
             double t = ((double)i / count) + (double)j / o.blur / count * exposure;
             ptl_renderer_set_option(r, "aa_start", j);
             if (ptl_renderer_update(r, t * (double)(float)duration, nullptr, nullptr) != PTL_OK) return fail("update");
             void* target = o.blur > 1 ? subframes[j] : pipe.results[slot];  // one image: average_images hands it back untouched
             float ms = 0.0f;
-            // without --timing the launch is not waited for: the host evaluates the next sub-frame's uniforms while this one traces
-            if (ptl_renderer_draw(r, &frame, target, nullptr, nullptr, nullptr, o.timing ? &ms : nullptr) != PTL_OK) return fail("render");
+            if (batched) {
+                // everything a draw does short of launching; the launch follows behind the last sub-frame, once for all of them
+                if (ptl_renderer_stage_slice(r, &frame, j) != PTL_OK) return fail("stage");
+                if (j == o.blur - 1 && ptl_renderer_draw_slices(r, &frame, o.blur, subframes[0], nullptr, (unsigned long long)width * height, nullptr, o.timing ? &ms : nullptr) != PTL_OK)
+                    return fail("render");
+            } else if (ptl_renderer_draw(r, &frame, target, nullptr, nullptr, nullptr, o.timing ? &ms : nullptr) != PTL_OK) {
+                // (without --timing the launch is not waited for: the host evaluates the next sub-frame's uniforms while this one traces)
+                return fail("render");
+            }
             gpu_ms += ms;
             ++traced;
             bool first = i == 0 && j == 0, final_one = i == count - 1 && j == o.blur - 1;
+            if (batched) first = i == 0 && j == o.blur - 1;  // (the stills are read behind the launch: sub-frame 0 of the first frame, the last of the last)
             if (first || final_one) {  // the clip's .start.png / .end.png stills: same pool, same pinned buffers
                 if (ptl_renderer_join(r, nullptr) != PTL_OK) return fail("join");  // (the download below is on the default stream)
                 for (int which = 0; which < 2; ++which) {
                     if (!(which == 0 ? first : final_one)) continue;
                     uint8_t* still = pinned.take();
-                    if (ptl_device_download(still, target, frame_bytes, nullptr) != PTL_OK) return fail("download");
+                    if (ptl_device_download(still, (batched && which == 0) ? subframes[0] : target, frame_bytes, nullptr) != PTL_OK) return fail("download");
                     std::string still_name = video_base + (which == 0 ? ".start.png" : ".end.png");
                     pool.submit([still, still_name, width, height, &pinned] {
                         if (ptl_png_write(still_name.c_str(), still, width, height) != PTL_OK) std::fprintf(stderr, "\n%s\n", ptl_last_error());
@@ -691,7 +706,7 @@ int encode_video(const Options& o, const std::string& scene_name, const std::str
 // is taken through the same history (every clip initialised so far, with its overrides), then compiled for gfx950 without a
 // device.  When the main thread gets to that clip it generates the same source and finds the binary on disk; if the histories
 // ever disagree it just compiles as before.
-void prefetch_clip_kernel(std::string path, std::vector<std::string> history, std::string asset_root, unsigned extra_flags, bool stereo) {
+void prefetch_clip_kernel(std::string path, std::vector<std::string> history, std::string asset_root, unsigned extra_flags, bool stereo) {  // extra_flags: --fast / --exact-cr / slices
     ptl_scene* scene = nullptr;
     if (ptl_scene_load_file(path.c_str(), &scene) != PTL_OK) return;
     for (const std::string& clip : history) {
@@ -780,7 +795,7 @@ int render(const Options& o) {
             if (ptl_scene_init_animation(scene, todo[0].first.c_str()) != PTL_OK) return fail("init_animation");
             apply_clip_overrides(scene, nullptr, todo[0].first, nullptr);
         }
-        unsigned start_flags = kClipFlags | (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u) | (o.opt3 ? 0u : 262144u) | (start_baked ? 8u : 0u);
+        unsigned start_flags = kClipFlags | (batch_subframes(o.blur, o.batch) ? kSlicesFlag : 0u) | (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u) | (o.opt3 ? 0u : 262144u) | (start_baked ? 8u : 0u);
         const char* create_names[] = {"aa_count", "render_depth", "draw_side_by_side"};  // before the first build: a baked kernel has its mode switches compiled in
         const double create_values[] = {(double)o.aa, (double)o.depth, o.stereo ? 1.0 : 0.0};
         if (ptl_renderer_create_with_options(scene, o.device, o.asset_root.c_str(), start_flags, create_names, create_values, 3, &r, log.data(), log.size()) !=
@@ -800,8 +815,10 @@ int render(const Options& o) {
         if (ptl_renderer_set_option(r, "concurrent_draws", lanes) != PTL_OK) return fail("concurrent_draws");
         std::vector<void*> subframes(std::max(1, o.blur), nullptr);
         size_t bytes = (size_t)width * o.height * 4;
-        for (void*& p : subframes)
-            if (ptl_device_alloc(o.device, bytes, &p) != PTL_OK) return fail("alloc");
+        // ONE allocation, sub-frame j at j * bytes: what the one-launch form writes (slice z behind slice z - 1)
+        void* subframe_block = nullptr;
+        if (ptl_device_alloc(o.device, bytes * subframes.size(), &subframe_block) != PTL_OK) return fail("alloc");
+        for (size_t j = 0; j < subframes.size(); ++j) subframes[j] = static_cast<char*>(subframe_block) + j * bytes;
         FramePipeline pipe;
         if (!pipe.create(o.device, bytes)) return fail("pipeline");
 
@@ -809,7 +826,7 @@ int render(const Options& o) {
             int n_workers = (int)std::min<size_t>({(size_t)6, todo.size() - 1, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)});
             pf.next = 1;  // the first clip is compiled by the main thread right away
             for (int wk = 0; wk < n_workers; ++wk)
-                pf.workers.emplace_back([&pf, &todo, &specialise, path, asset_root = o.asset_root, extra_flags = (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u), stereo = o.stereo] {
+                pf.workers.emplace_back([&pf, &todo, &specialise, path, asset_root = o.asset_root, extra_flags = (o.fast ? 64u : 0u) | (o.exact_cr ? 16384u : 0u) | (batch_subframes(o.blur, o.batch) ? kSlicesFlag : 0u), stereo = o.stereo] {
                     for (;;) {
                         size_t k;
                         {
@@ -858,7 +875,7 @@ int render(const Options& o) {
             }
             if (o.shards == 1 && o.max_frames < 0) encode_video(o, scene_name, clip, fps);
         }
-        for (void* p : subframes) ptl_device_free(p);
+        ptl_device_free(subframe_block);
         ptl_renderer_destroy(r);
         ptl_scene_free(scene);
     }
@@ -1008,6 +1025,7 @@ int main(int argc, char** argv) {
         else if (a == "--motion-blur-frames") o.blur = std::atoi(next());
         else if (a == "--stereoimage" || a == "--stereo-image") o.stereo = true;
         else if (a == "--concurrent-draws") o.concurrent = std::atoi(next());
+        else if (a == "--batch-subframes") o.batch = std::atoi(next());
         else if (a == "--no-skip-existing") o.skip_existing = false;
         else if (a == "--filter-starts-with" || a == "--starts-with") o.starts_with = next();
         else if (a == "--scenes-dir") o.scenes_dir = next();
