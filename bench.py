@@ -829,6 +829,36 @@ def main():
         except Exception as e:
             print(f"[bench] dynamic-uniform timing unavailable: {e}", file=sys.stderr)
 
+    # untimed, N = 1 only: several frames per LAUNCH (FLAG_SLICES: grid.z = frame, one uniform block per slice in a device buffer -- what
+    # `portal-amd render` does with the blur sub-frames of a clip frame).  The ramp and tail of one launch are shared by the frames in it,
+    # which is what a small frame (C2: 50 us) loses most of its time to.  Same build otherwise, same frames (compared below).
+    batched = None
+    if world == 1 and not args.no_cpu_baseline and args.specialize == 2:
+        try:
+            nsl = 8 if W * H <= 1920 * 1080 else 4
+            sl_r = pa.SceneRenderer(scene, device=local_rank, flags=spec_flags | pa.FLAG_SLICES, **scene_kw)
+            configure(sl_r, args)
+            big = torch.empty((nsl, H, W, 4), dtype=torch.uint8, device=dev)
+
+            def one_batch(timed=False):
+                for j in range(nsl):
+                    sl_r.stage_slice(frame, j)
+                return sl_r.draw_slices(frame, nsl, out_rgba8=big.data_ptr(), slice_pixels=W * H, stream=stream.cuda_stream, timed=timed)
+
+            for _ in range(4):
+                one_batch()
+            ms_b = float(np.median([one_batch(True) for _ in range(12)])) / nsl
+            one = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
+            renderer.draw_device(frame, out_rgba8=one.data_ptr(), stream=stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            same = bool(all(torch.equal(big[j], one) for j in range(nsl)))
+            batched = {"frames_per_launch": nsl, "kernel_ms_per_frame": round(ms_b, 4), "value": round(W * H * args.aa / (ms_b * 1e-3) / 1e6, 3), "unit": "Mray/s",
+                       "frames_identical_to_the_timed_build": same,
+                       "note": "one launch, grid.z = frame, a uniform block per slice (FLAG_SLICES); kernel time only, NOT the measured value above"}
+            del sl_r, big, one
+        except Exception as e:
+            print(f"[bench] batched-launch timing unavailable: {e}", file=sys.stderr)
+
     # untimed, N = 1 only: the tolerance mode (FLAG_FAST_MATH) on the same frame: kernel time and how far its picture is from the exact one
     fast = None
     if world == 1 and not args.no_cpu_baseline:
@@ -915,6 +945,8 @@ def main():
             out["second_workload"] = second
         if jit_seconds is not None:
             out["jit_seconds"] = jit_seconds  # cold compile of the timed build (hiprtc, -O1); cached on disk by source + options + toolchain hash afterwards
+        if batched is not None:
+            out["several_frames_per_launch"] = batched
         if fast is not None:
             out["fast_math_mode"] = fast
         if dynamic_ms is not None:
@@ -941,6 +973,11 @@ def main():
             roof = valu_roofline(fl, pmc, segments, world, kernel_ms, hbm["traffic"], args.specialize)
             out["roofline"] = roof
             out["roofline_hbm"] = hbm
+            if batched is not None:  # the same instructions in less time: fraction and ceiling scale alike
+                ratio = kernel_ms / batched["kernel_ms_per_frame"]
+                batched["frac"] = round(roof["frac"] * ratio, 5)
+                if "frac_ceiling_valu_plus_fma" in roof:
+                    batched["frac_ceiling_valu_plus_fma"] = round(roof["frac_ceiling_valu_plus_fma"] * ratio, 4)
         else:
             out["roofline"] = hbm
         if world == 1 and not args.no_cpu_baseline:
