@@ -833,7 +833,7 @@ def main():
     # `portal-amd render` does with the blur sub-frames of a clip frame).  The ramp and tail of one launch are shared by the frames in it,
     # which is what a small frame (C2: 50 us) loses most of its time to.  Same build otherwise, same frames (compared below).
     batched = None
-    if world == 1 and not args.no_cpu_baseline and args.specialize == 2:
+    if world == 1 and not args.no_segments and args.specialize == 2:  # (--no-segments: the profiling passes, whose statistics are about the timed launches)
         try:
             nsl = 8 if W * H <= 1920 * 1080 else 4
             sl_r = pa.SceneRenderer(scene, device=local_rank, flags=spec_flags | pa.FLAG_SLICES, **scene_kw)
