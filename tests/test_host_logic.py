@@ -1526,3 +1526,43 @@ def test_bounded_snippets_draw_the_frames_of_the_snippets_as_written(pa, flags_n
                 o.camera = dict(look_at=view[0], alpha=view[1], beta=view[2], r=view[3])
             want = o.render(w, h)
             assert np.array_equal(frames[0].view(np.uint32), want["rgba32f"].view(np.uint32)), view
+
+
+def test_slices_entry_is_a_substitution_that_keeps_the_scene_lines_and_the_pictures(pa):
+    """PTL_FLAG_SLICES (codegen.cpp `apply_slices_entry`): the render entry `ptl_render_slices_kernel` reads the uniform block of slice blockIdx.z
+    from a buffer of blocks.  Without the flag the source is byte for byte what it was; with it the scene's own lines keep their numbers (compiler
+    diagnostics map back to scene elements by line), the prelude sits inside the tracer struct (its uniform-reading functions see the slice), the
+    classic entry is gone, a per-slice prologue entry is there -- and the host build of that source still draws the oracle's bits."""
+    from oracle import host_build as hb
+    from oracle.portal_oracle import Oracle
+
+    for name in ("basics", "portal_in_portal"):
+        scene = pa.Scene.from_file(pa.scene_path(name))
+        plain, sliced = scene.generate_source(0), scene.generate_source(pa.FLAG_SLICES)
+        assert plain == pa.Scene.from_file(pa.scene_path(name)).generate_source(0) and "ptl_slices" not in plain and "ptl_home" not in plain
+        assert "ptl_render_slices_kernel(const glsl::ptl_uniform_block* __restrict__ ptl_slices" in sliced and "\nptl_render_kernel(" not in sliced
+        assert "ptl_derive_slices_kernel(glsl::ptl_uniform_block* blocks)" in sliced and "ptl_teleport_kernel" in sliced
+        line_of = lambda text, key: text[:text.index(key)].count("\n")
+        for key in ("PTL_FN int is_inside_0(", "PTL_FN SceneIntersection scene_intersect(const Ray& r"):
+            assert line_of(plain, key) == line_of(sliced, key), key
+        # the prelude: in front of the tracer struct in the plain source, inside it in the sliced one
+        assert line_of(plain, "PTL_FN float color_normal(") < line_of(plain, "struct ptl_tracer {")
+        assert line_of(sliced, "struct ptl_tracer {") < line_of(sliced, "PTL_FN float color_normal(") < line_of(sliced, "};  // struct ptl_tracer")
+        w, h = 48, 27
+        r = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_QUICK_JIT)
+        r.set_option("render_depth", 10)
+        o = Oracle(pa.scene_path(name))
+        o.options["render_depth"] = 10
+        want = o.render(w, h)
+        for flags in (pa.FLAG_SLICES, pa.FLAG_SLICES | pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL):
+            sc = pa.Scene.from_file(pa.scene_path(name))
+            got = hb.host_kernel_for(r, sc, w, h, flags=flags).render(w, h)
+            assert np.array_equal(got["rgba32f"].view(np.uint32), want["rgba32f"].view(np.uint32)), (name, flags)
+    # the sliced source compiles for gfx950 without a GPU; staging is host work (a snapshot of the uniform block), launching needs the device
+    r = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("basics")), device=-1, flags=pa.FLAG_SLICES | pa.FLAG_QUICK_JIT)
+    assert r.code_object()[:4] == b"\x7fELF"
+    r.stage_slice(pa.Frame(64, 64, 0, 1), 0)
+    with pytest.raises(pa.PortalError):
+        r.draw_slices(pa.Frame(64, 64, 0, 1), 1)
+    with pytest.raises(pa.PortalError, match="not all staged"):
+        r.draw_slices(pa.Frame(64, 64, 0, 1), 2)
