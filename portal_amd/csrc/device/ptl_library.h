@@ -151,16 +151,23 @@ PTL_FN SurfaceIntersection plane_intersect(Ray r, const mat4& plane_inv, vec3 no
 #endif
 
 // Wave-level exact cull of a plane test.  A plane only matters to scene_intersect if its hit is NEARER than the best one so far
-// (nearer(): hit, t > 0, t < best).  Two things that follow from the z row of plane_inv * ray alone -- 8 FMAs that the full test
-// evaluates anyway -- settle that without the square root and the three correctly rounded divisions of plane_intersect:
-//   behind   o'.z and d'.z have the same sign: the quotient -o'.z / d'.z is negative (or rounds to -0), so t < 0 or t is not > 0;
-//   farther  a lower bound of t, -o'.z * rcp(d'.z) * (1 - 2^-16), is already above `best_t`.  (The exact chain and this estimate
-//            differ by less than a dozen rounding errors, < 2^-20 relative; NaN and infinity compare false / consistently.  Only
-//            for |d'.z| >= 2^-100: below, the reciprocal estimate may overflow where the exact quotient of two tiny numbers is
-//            an ordinary distance.)
+// (nearer(): hit, t > 0, t < best).  The z row of plane_inv * ray alone -- 8 FMAs that the full test evaluates anyway -- settles that
+// without the square root and the three reciprocals of plane_intersect: in the plane's frame the ray is at height o'.z and moves with
+// d'.z per unit of t, so it crosses the plane at t = -o'.z / d'.z; it cannot be nearer than `best_t` exactly when it has not crossed yet
+// at t = best_t, i.e. when o'.z + best_t * d'.z still has the sign of o'.z.  ONE test for both cases:
+//   behind   o'.z and d'.z have the same sign (the ray moves away: it never crosses for t > 0; with best_t = +inf the sum is
+//            +-inf with the sign of d'.z);
+//   farther  the crossing lies beyond best_t.
+// The height is taken a little farther out, at best_t * (1 + 2^-16): the exact chain's t (six roundings, < 2^-20 relative) and the
+// rounding of this one FMA cannot bridge that margin, so a culled test's hit distance really is above best_t.  Zero, NaN (0 * inf,
+// a NaN ray) and underflowing products compare false: not culled, tested in full -- conservative.  (Round 3 made the two decisions
+// separately -- four sign compares, a reciprocal estimate, two more compares: 39 issue cycles per plane against 11.)
 // A cull decides nothing about the picture -- the culled test could never have been selected -- so frames stay bit-identical;
 // what it saves is the work.  It is taken per WAVE (ballot): the 64 rays of an 8x8 tile nearly always agree about which walls are
 // behind them or beyond the surface they have already found, and a uniform branch costs a scalar compare.
+PTL_FN bool ptl_cannot_be_nearer(float oz, float dz, float best_t) {
+    return oz * __builtin_fmaf(best_t * (1.0f + 0x1p-16f), dz, oz) > 0.0f;
+}
 template <unsigned MASK = 0xffffu> PTL_FN bool ptl_plane_cull(const Ray& r, const mat4& plane_inv, float best_t) {
 #if defined(PTL_NO_PLANE_CULL)
     (void)r; (void)plane_inv; (void)best_t;
@@ -168,18 +175,15 @@ template <unsigned MASK = 0xffffu> PTL_FN bool ptl_plane_cull(const Ray& r, cons
 #else
     const float oz = ptl_row_m<MASK, 2>(plane_inv, r.o);
     const float dz = ptl_row_m<MASK, 2>(plane_inv, r.d);
-    const bool behind = (oz > 0.0f && dz > 0.0f) || (oz < 0.0f && dz < 0.0f);
 #if PTL_DEVICE_BUILD
-    const float t_low = (-oz * __builtin_amdgcn_rcpf(dz)) * (1.0f - 0x1p-16f);
-    return __builtin_amdgcn_ballot_w64(!(behind || (t_low > best_t && abs(dz) >= 0x1p-100f))) == 0ull;
+    return __builtin_amdgcn_ballot_w64(!ptl_cannot_be_nearer(oz, dz, best_t)) == 0ull;
 #else
-    const float t_low = (-oz * (1.0f / dz)) * (1.0f - 0x1p-16f);
-    return behind || (t_low > best_t && abs(dz) >= 0x1p-100f);
+    return ptl_cannot_be_nearer(oz, dz, best_t);
 #endif
 #endif
 }
 // The cull for a ray whose origin in the plane's frame is already known (first-trip plane tests: `o_in_plane` = plane_inv * r.o from
-// the prologue kernel): the same two decisions from the same two numbers, half the products.
+// the prologue kernel): the same decision from the same two numbers, half the products.
 template <unsigned MASK = 0xffffu> PTL_FN bool ptl_plane_cull_o(const Ray& r, const mat4& plane_inv, const vec4& o_in_plane, float best_t) {
 #if defined(PTL_NO_PLANE_CULL)
     (void)r; (void)plane_inv; (void)o_in_plane; (void)best_t;
@@ -187,13 +191,10 @@ template <unsigned MASK = 0xffffu> PTL_FN bool ptl_plane_cull_o(const Ray& r, co
 #else
     const float oz = o_in_plane.z;
     const float dz = ptl_row_m<MASK, 2>(plane_inv, r.d);
-    const bool behind = (oz > 0.0f && dz > 0.0f) || (oz < 0.0f && dz < 0.0f);
 #if PTL_DEVICE_BUILD
-    const float t_low = (-oz * __builtin_amdgcn_rcpf(dz)) * (1.0f - 0x1p-16f);
-    return __builtin_amdgcn_ballot_w64(!(behind || (t_low > best_t && abs(dz) >= 0x1p-100f))) == 0ull;
+    return __builtin_amdgcn_ballot_w64(!ptl_cannot_be_nearer(oz, dz, best_t)) == 0ull;
 #else
-    const float t_low = (-oz * (1.0f / dz)) * (1.0f - 0x1p-16f);
-    return behind || (t_low > best_t && abs(dz) >= 0x1p-100f);
+    return ptl_cannot_be_nearer(oz, dz, best_t);
 #endif
 #endif
 }
