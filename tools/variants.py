@@ -145,6 +145,17 @@ VARIANTS = {
     "r3_all_w4_zerofold": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -fno-signed-zeros -fno-honor-nans",
     # round 4: the NaN guard of 1/x and sqrt as one v_med3_f32 (default) against the compare + select pair of round 3
     "r4_all": "SPECIALIZE_ALL", "r4_all_w4": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4", "r4_all_cmpguard": "SPECIALIZE_ALL -DPTL_CMP_GUARD", "r4_all_w4_cmpguard": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -DPTL_CMP_GUARD",
+    # round 4, after the one-sign-test cull: IR-level if-conversion / sinking knobs of the same source
+    "r5_base": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4",
+    "r5_phi8": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -phi-node-folding-threshold=8",
+    "r5_phi32": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -phi-node-folding-threshold=32",
+    "r5_two16": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -two-entry-phi-node-folding-threshold=16",
+    "r5_two64": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -two-entry-phi-node-folding-threshold=64",
+    "r5_phi8_two16": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -phi-node-folding-threshold=8 -mllvm -two-entry-phi-node-folding-threshold=16",
+    "r5_gvnsink": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -enable-gvn-sink=true",
+    "r5_gvnhoist": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -enable-gvn-hoist=true",
+    "r5_nojt": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -jump-threading-threshold=0",
+    "r5_nocull": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -DPTL_NO_PLANE_CULL",
     "r4_ints": "SPECIALIZE", "r4_ints_cmpguard": "SPECIALIZE -DPTL_CMP_GUARD", "r4_dyn": "", "r4_dyn_cmpguard": "-DPTL_CMP_GUARD",
 }
 CASES = ["monoportal:1920:1080:20:1", "triple_portal:3840:2160:40:1", "portal_in_portal:3840:2160:40:1", "mobius_monoportal:3840:2160:64:1", "mobius_monoportal:3840:2160:64:4"]
