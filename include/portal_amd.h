@@ -147,6 +147,13 @@ int ptl_kernel_render_slices(ptl_kernel* k, const ptl_frame* frame, int n, void*
  * reference's `None`), out_pos is then (0,0,0).  Uses whatever uniforms are currently set. */
 int ptl_kernel_teleport_ray(ptl_kernel* k, const float a[3], const float b[3], float out_pos[3], int* hit_object,
                             int* changed_subspace, int* teleported);
+/* Split builds.  A source compiled with the define PTL_RENDER_MODULE has no teleport entry: that entry is a second copy of the whole
+ * tracer, a fifth of every hiprtc build, and a camera that stands still never asks for it.  ptl_kernel_teleport_ray on such a kernel
+ * compiles the other half on demand -- the same source with PTL_TELEPORT_MODULE: teleport entry + prologue, no render entry; its code
+ * object is cached like any other -- and runs the query there with this kernel's uniform values.  ptl_kernel_prebuild_teleport does the
+ * compile ahead of time (on a compile-only handle, device -1: fills the code-object cache).  Kernels compiled without either define
+ * have every entry in one module, as before.  ptl_renderer_* builds split (environment PTL_ONE_MODULE=1: one module). */
+int ptl_kernel_prebuild_teleport(ptl_kernel* k);
 
 void ptl_kernel_destroy(ptl_kernel* k);
 
@@ -352,6 +359,8 @@ int ptl_renderer_draw_to_host(ptl_renderer* r, const ptl_frame* frame, uint8_t* 
  * (set_uniforms(0,0), teleport_light_u = 1), then ptl_kernel_teleport_ray. */
 int ptl_renderer_teleport_ray(ptl_renderer* r, const double a[3], const double b[3], double out_pos[3], int* hit_object,
                               int* changed_subspace, int* teleported);
+/* Build (or load from the cache) the teleport half of the renderer's current kernel now instead of at the first query. */
+int ptl_renderer_prebuild_teleport(ptl_renderer* r);
 /* Move the camera the way the interactive reference does every frame: set the new orbit parameters, then
  * SceneRenderer::teleport_camera (src/main.rs:1217-1264): if the straight segment from the previous camera
  * position to the new one crosses a portal, the camera's teleport matrix becomes the portal map's
@@ -505,6 +514,8 @@ const char* ptl_device_source(const char* which);
 
 /* GLSL snippet -> C++ (malloc'ed, ptl_free) and the formula evaluator, exposed for tests. */
 char* ptl_translate_glsl(const char* glsl);
+/* The same for a file-scope library text (scene.rs:1037-1044): every function DEFINITION gets the kernel's force-inline attribute PTL_FN. */
+char* ptl_translate_library_glsl(const char* glsl);
 /* The distance-bound rewrite of an intersection-material snippet on its own (host/glsl_translate.h `bound_nearer_blocks`; tests): the GLSL
  * body with `&& !(H.t > ptl_far)` added to the conditions it recognises (malloc'ed, ptl_free), *bounded = how many; `out_functions`:
  * comma-separated names of scene functions with out / inout parameters.  Unchanged text and 0 when the snippet's shape does not allow it. */

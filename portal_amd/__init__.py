@@ -161,6 +161,8 @@ def _load() -> C.CDLL:
         "ptl_renderer_draw": (ci, [vp, P(Frame), vp, vp, vp, vp, P(C.c_float)]),
         "ptl_renderer_draw_to_host": (ci, [vp, P(Frame), vp, vp, P(C.c_uint64), P(C.c_float)]),
         "ptl_renderer_teleport_ray": (ci, [vp, P(cd), P(cd), P(cd), P(ci), P(ci), P(ci)]),
+        "ptl_renderer_prebuild_teleport": (ci, [vp]),
+        "ptl_kernel_prebuild_teleport": (ci, [vp]),
         "ptl_renderer_move_camera": (ci, [vp, P(cd), cd, cd, cd, P(ci), P(ci)]),
         "ptl_renderer_camera_state": (ci, [vp, P(cd), P(ci), P(cd)]),
         "ptl_renderer_kernel": (vp, [vp]),
@@ -203,6 +205,7 @@ def _load() -> C.CDLL:
         "ptl_strstore_get_identifier": (ci, [vp, ci, cp, cs, cp, cs, P(ci)]),
         "ptl_device_source": (cp, [cp]),
         "ptl_translate_glsl": (vp, [cp]),
+        "ptl_translate_library_glsl": (vp, [cp]),
         "ptl_bound_glsl": (vp, [cp, cp, P(ci)]),
         "ptl_formula_eval": (ci, [cp, P(cp), P(cd), ci, cd, P(cd)]),
     }
@@ -524,6 +527,10 @@ class SceneRenderer:
         _check(lib().ptl_renderer_teleport_ray(self._h, pa_, pb_, out, C.byref(hit), C.byref(sub), C.byref(tel)), "teleport_external_ray")
         return (tuple(out) if tel.value else None), bool(hit.value), bool(sub.value)
 
+    def prebuild_teleport(self) -> None:
+        """Compile (or load from the cache) the camera-teleport half of the current kernel now instead of at the first query."""
+        _check(lib().ptl_renderer_prebuild_teleport(self._h), "prebuild_teleport")
+
     def resources(self) -> dict:
         """Per-lane registers / scratch bytes / LDS bytes of the loaded kernel."""
         regs, scratch, lds = C.c_int(), C.c_int(), C.c_int()
@@ -800,6 +807,16 @@ def bound_glsl(body: str, out_functions=()):
 
 def translate_glsl(code: str) -> str:
     p = lib().ptl_translate_glsl(code.encode("utf-8"))
+    if not p:
+        raise PortalError(_err())
+    try:
+        return C.string_at(p).decode("utf-8")
+    finally:
+        lib().ptl_free(p)
+
+
+def translate_library_glsl(code: str) -> str:
+    p = lib().ptl_translate_library_glsl(code.encode("utf-8"))
     if not p:
         raise PortalError(_err())
     try:

@@ -22,6 +22,9 @@
 #define PTL_LAUNCH_BOUNDS __launch_bounds__(256)
 #endif
 
+// A build can be split in two modules (host/kernel.cpp `ptl_kernel::split`): -DPTL_RENDER_MODULE leaves the camera-teleport entry out,
+// -DPTL_TELEPORT_MODULE the render entry; the prologue entry is in both.  Without either define the module has all three.
+#if !defined(PTL_TELEPORT_MODULE)
 extern "C" __global__ void PTL_LAUNCH_BOUNDS
 ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this shard, or null
                   float* __restrict__ out_rgba32f,        // same, 4 floats per pixel, or null
@@ -100,6 +103,7 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
     }
 #endif
 }
+#endif  // !PTL_TELEPORT_MODULE
 
 // The camera-teleport query of src/main.rs:1361-1409: one thread instead of the reference's 2x3-pixel
 // draw with float-in-RGBA8 packing.  (A hand-written kernel without a scene can opt out.)

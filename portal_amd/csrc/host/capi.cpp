@@ -654,12 +654,20 @@ static int bind_textures(ptl_renderer* r, ptl_kernel* k) {
 // the kernel the draws use from now on: a different one starts from a blank uniform block and blank samplers
 static int activate_kernel(ptl_renderer* r, ptl_kernel* k);
 
+// The renderer's kernels are built in two halves (kernel.cpp `ptl_kernel::split`): the render module now, the camera-teleport module when a
+// query first asks for it -- a fifth of every build that a still camera never needs.  PTL_ONE_MODULE=1: one module with every entry (A/B).
+static bool split_builds() {
+    const char* e = std::getenv("PTL_ONE_MODULE");
+    return !(e && e[0] == '1');
+}
+
 static ptl_renderer::Build snapshot_build(ptl_scene* s, unsigned flags) {
     ptl_renderer::Build b;
     b.source = s->last.source;
     b.defines = s->last.defines;
     unsigned waves = (flags >> 8) & 0xFu;
     if (waves) b.defines.push_back("PTL_WAVES_PER_EU=" + std::to_string(waves));
+    if (split_builds()) b.defines.push_back("PTL_RENDER_MODULE");
     b.desc_names = s->desc_names;
     b.descs = s->descs;
     for (size_t k = 0; k < b.descs.size(); ++k) b.descs[k].name = b.desc_names[k].c_str();
@@ -724,6 +732,7 @@ static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     if (waves) s->last.defines.push_back("PTL_WAVES_PER_EU=" + std::to_string(waves));
     std::vector<const char*> defines;
     for (auto& d : s->last.defines) defines.push_back(d.c_str());
+    if (split_builds()) defines.push_back("PTL_RENDER_MODULE");  // (not into s->last.defines: ptl_scene_generated_defines describes the source, not this build)
     ptl_kernel* k = nullptr;
     int rc = ptl_kernel_compile(r->device, s->last.source.c_str(), s->descs.data(), (int)s->descs.size(), s->last.uniform_block_size, defines.data(),
                                 (int)defines.size(), &k, log, log_cap);
@@ -1246,6 +1255,10 @@ extern "C" int ptl_renderer_draw_to_host(ptl_renderer* r, const ptl_frame* frame
         return ptl_kernel_render_to_host(r->kernel, frame, host_rgba8, host_rgba32f, host_segments, elapsed_ms);
     });
 }
+extern "C" int ptl_renderer_prebuild_teleport(ptl_renderer* r) {
+    if (!r || !r->kernel) return PTL_ERR_INVALID;
+    return guarded([&] { return ptl_kernel_prebuild_teleport(r->kernel); });
+}
 extern "C" int ptl_renderer_teleport_ray(ptl_renderer* r, const double a[3], const double b[3], double out_pos[3], int* hit_object,
                                          int* changed_subspace, int* teleported) {
     if (!r || !a || !b) return PTL_ERR_INVALID;
@@ -1604,6 +1617,20 @@ extern "C" char* ptl_translate_glsl(const char* glsl) {
     try {
         out = translate_glsl(glsl);
     } catch (const std::exception& e) {  // e.g. a struct field that spells a swizzle: NULL + ptl_last_error()
+        set_last_error(e.what());
+        return nullptr;
+    }
+    char* p = (char*)std::malloc(out.size() + 1);
+    std::memcpy(p, out.c_str(), out.size() + 1);
+    return p;
+}
+
+extern "C" char* ptl_translate_library_glsl(const char* glsl) {  // a file-scope library text: function definitions get PTL_FN
+    if (!glsl) return nullptr;
+    std::string out;
+    try {
+        out = translate_glsl(glsl, true, true);
+    } catch (const std::exception& e) {
         set_last_error(e.what());
         return nullptr;
     }

@@ -720,8 +720,10 @@ void prefetch_clip_kernel(std::string path, std::vector<std::string> history, st
     const char* names[] = {"draw_side_by_side"};
     const double values[] = {stereo ? 1.0 : 0.0};
     ptl_renderer* r = nullptr;
-    if (ptl_renderer_create_with_options(scene, -1, asset_root.c_str(), kClipFlags | 8u | extra_flags, names, values, 1, &r, nullptr, 0) == PTL_OK)
+    if (ptl_renderer_create_with_options(scene, -1, asset_root.c_str(), kClipFlags | 8u | extra_flags, names, values, 1, &r, nullptr, 0) == PTL_OK) {
+        ptl_renderer_prebuild_teleport(r);  // the camera of a clip moves: its teleport queries need the other half of the build as well
         ptl_renderer_destroy(r);
+    }
     ptl_scene_free(scene);
 }
 

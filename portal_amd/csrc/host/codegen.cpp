@@ -395,6 +395,11 @@ struct SnippetTranslator {
         auto it = hoisted.find(&code);
         return unrolled(translate_glsl(it != hoisted.end() ? it->second : filtered(code), flags.defer_loop_updates));
     }
+    // a file-scope library text: its function definitions become PTL_FN (force-inlined) like the rest of the kernel
+    std::string library(const std::string& code) const {
+        auto it = hoisted.find(&code);
+        return unrolled(translate_glsl(it != hoisted.end() ? it->second : filtered(code), flags.defer_loop_updates, true));
+    }
 };
 
 // names of the functions a GLSL text defines (`type name(...) {` at brace depth 0)
@@ -1168,6 +1173,14 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             calls_first.add_string("if (nearer(result.scene.hit, hit.scene.hit)) { result = hit; }\n\n");
         }
         gk.first_trip_variants = any_first;
+        // A loop in an intersection-material snippet (portal_in_portal's ten nested copies) puts the deepest call chain of the kernel inside a
+        // loop nest, unrolled when its bound is baked: the kernels whose hiprtc time the bottom-up inliner pipeline dominates (kernel.cpp
+        // compile_options; tools/jit_inliner_survey.py).  The JIT switches to the module inliner for them.
+        for (const NamedCode& im : scene.intersection_materials) {
+            const std::vector<Token> toks = tokenize_glsl(filter_tagged_lines(im.code, flags));
+            for (const Token& t : toks)
+                if (t.kind == Token::Ident && (t.text == "for" || t.text == "while")) gk.looped_snippets = true;
+        }
         storages["intersection_material_functions"] = std::move(fns);
         storages["intersection_material_processing"] = std::move(calls);
         storages["intersection_material_processing_first"] = std::move(calls_first);
@@ -1177,9 +1190,8 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     {
         StringStorage s;
         for (const NamedCode& lib : scene.library) {
-            // scene functions are plain GLSL functions: give them the device attribute by defining
-            // them inside a PTL_FN-aware region (see ptl_scene_fn below)
-            s.add_identifier_string({"library", lib.name}, snippet(lib.code));
+            // scene functions are plain GLSL functions: the translation puts PTL_FN in front of every definition
+            s.add_identifier_string({"library", lib.name}, snippet.library(lib.code));
         }
         storages["library"] = std::move(s);
     }
@@ -1231,6 +1243,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     // matrices baked into the source: a matrix product skips the terms whose matrix element is zero (device/ptl_glsl.h `ptl_mterm`)
     if ((opts.specialize_all || opts.specialize_static) && !opts.exact_cr && !opts.fast_math && !gk.full_chains) gk.defines.push_back("PTL_DROP_ZERO_TERMS");
     if (gk.first_trip_variants) gk.defines.push_back("PTL_FIRST_TRIP");
+    if (gk.looped_snippets) gk.defines.push_back("PTL_JIT_MODULE_INLINER");
     if (gk.bounded_snippet_blocks > 0) gk.defines.push_back("PTL_BOUNDED_SNIPPETS");
     return gk;
 }

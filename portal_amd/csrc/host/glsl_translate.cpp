@@ -745,10 +745,45 @@ void check_out_argument_aliasing(const std::vector<std::string>& sources, const 
     }
 }
 
-std::string translate_glsl(const std::string& glsl, bool defer_loop_updates) {
+// Token indices of the return types of the function DEFINITIONS of a file-scope GLSL text: `type name ( ... ) {` at brace depth 0.
+// (Prototypes, struct heads, globals with initialisers and whatever follows a #define are not definitions.)
+static std::set<size_t> definition_heads(const std::vector<Token>& toks) {
+    std::set<size_t> heads;
+    auto sig = [&](size_t k) {  // the next token that is neither space nor comment, or toks.size()
+        while (k < toks.size() && (toks[k].kind == Token::Space || toks[k].kind == Token::Comment)) ++k;
+        return k;
+    };
+    int brace = 0;
+    bool in_define = false;
+    for (size_t k = 0; k < toks.size(); ++k) {
+        const Token& t = toks[k];
+        if (t.kind == Token::Preproc) in_define = true;
+        if (t.kind == Token::Space && t.text.find('\n') != std::string::npos) in_define = false;
+        if (t.kind == Token::Punct && t.text == "{") ++brace;
+        if (t.kind == Token::Punct && t.text == "}") --brace;
+        if (in_define || brace != 0 || t.kind != Token::Ident) continue;
+        const size_t name = sig(k + 1);
+        if (name >= toks.size() || toks[name].kind != Token::Ident) continue;
+        size_t open = sig(name + 1);
+        if (open >= toks.size() || toks[open].kind != Token::Punct || toks[open].text != "(") continue;
+        int depth = 0;
+        size_t close = open;
+        for (; close < toks.size(); ++close) {
+            if (toks[close].kind != Token::Punct) continue;
+            if (toks[close].text == "(") ++depth;
+            if (toks[close].text == ")" && --depth == 0) break;
+        }
+        const size_t body = sig(close + 1);
+        if (body < toks.size() && toks[body].kind == Token::Punct && toks[body].text == "{") heads.insert(k);
+    }
+    return heads;
+}
+
+std::string translate_glsl(const std::string& glsl, bool defer_loop_updates, bool force_inline_definitions) {
     std::vector<Token> toks = tokenize(glsl);
     if (defer_loop_updates) defer_loop_carried_updates(toks);
     rewrite_divisions(toks);
+    const std::set<size_t> heads = force_inline_definitions ? definition_heads(toks) : std::set<size_t>();
     std::string out;
     out.reserve(glsl.size() + glsl.size() / 8);
 
@@ -820,6 +855,7 @@ std::string translate_glsl(const std::string& glsl, bool defer_loop_updates) {
                 out += t.text;
                 break;
             case Token::Ident: {
+                if (heads.count(k)) out += "PTL_FN ";  // on the line of the definition: the scene's line numbers stay what they are
                 const Token* p = prev_sig(k);
                 const Token* nx = next_sig(k);
                 bool after_dot = p && p->kind == Token::Punct && p->text == ".";

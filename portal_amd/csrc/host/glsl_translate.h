@@ -45,7 +45,10 @@ std::string filter_tagged_lines(const std::string& text, const CodegenFlags& fla
 //     snippet never assigns or declares;
 //   * every other occurrence of X in the loop body sits in a nested block, is not an assignment target, and X does not appear in
 //     the loop header.
-std::string translate_glsl(const std::string& glsl, bool defer_loop_updates = true);
+// `force_inline_definitions`: the text is a file-scope library (scene.rs:1037-1044) -- its function definitions get PTL_FN like every other function
+// of the kernel.  Without it they are plain inline members that LLVM's bottom-up inliner happens to inline and its module inliner does not
+// (a call with `this` then keeps the tracer object in scratch).
+std::string translate_glsl(const std::string& glsl, bool defer_loop_updates = true, bool force_inline_definitions = false);
 
 // Refuses (std::runtime_error) a scene in which passing `out` / `inout` arguments by reference could differ from GLSL's copy in /
 // copy out: a mutable global handed to a function that also names it, or one variable handed to two out parameters of a call.

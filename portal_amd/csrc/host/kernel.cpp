@@ -91,6 +91,23 @@ std::vector<std::string> compile_options(const char* const* defines, int n_defin
             o.push_back(std::string("-vgpr-regalloc=") + (ra ? ra : "basic"));
         }
     }
+    {
+        // LLVM's module inliner instead of its bottom-up (call-graph SCC) one, for the kernels that need it.  Every function of the generated
+        // kernel is force-inlined into ONE body, eight call levels deep (kernel -> shade_pixel -> get_color -> get_color2 -> ray_tracing ->
+        // trace_segment -> snippets -> library); the bottom-up pipeline re-runs its whole function simplification on that body at each level
+        // on the way up (opt --time-trace of the headline: 0.25 s per level of a 5 s build).  The module inliner inlines first and simplifies
+        // once: -28 ... -43 % hiprtc time where an intersection-material snippet loops (portal_in_portal: 10 nested portal copies per trip;
+        // codegen.cpp sets PTL_JIT_MODULE_INLINER), the same kernel time there; elsewhere it saves 0-25 % of a 1-2 s build and the kernel
+        // is 1.5-3 % slower (monoportal, triple_portal: profiles/r04/variants_module_inliner.jsonl), so those keep the toolchain's default.
+        // Same source, same arithmetic, other instruction schedule: bit-identical frames.  PTL_MODULE_INLINER=0 / 1 forces the choice.
+        const char* mi = std::getenv("PTL_MODULE_INLINER");
+        bool wanted = quick;  // a quick build wants its kernel NOW
+        for (int k = 0; k < n_defines; ++k) wanted = wanted || std::string(defines[k]) == "PTL_JIT_MODULE_INLINER";
+        if (mi ? (mi[0] != '0') : wanted) {
+            o.push_back("-mllvm");
+            o.push_back("-enable-module-inliner");
+        }
+    }
     if (fast && !std::getenv("PTL_FAST_KEEP_ZEROS")) {
         // Tolerance mode only: a product with a literal zero is zero.  With the scene state baked in, the portal matrices of most scenes are
         // translations and axis rotations -- 41 % of the multiplications in the headline snippet's loop have a literal +-0 operand, and
@@ -147,6 +164,14 @@ struct ptl_kernel {
     void* dev_slices = nullptr;           // kMaxSlices blocks of dev_block_size bytes
     std::vector<unsigned char> staged;    // host side of it: slice j at j * dev_block_size (ptl_kernel_stage_slice)
     bool slice0_dirty = true;             // slice 0 of the buffer no longer holds `shadow` (a single draw uses slice 0)
+    // A module compiled with -DPTL_RENDER_MODULE has no camera-teleport entry (ptl_entry.h): that entry is a second copy of the whole tracer
+    // and a fifth of every build, and only a camera that moves asks for it.  Such a kernel keeps what its build was made from and compiles
+    // the other half -- the same source with -DPTL_TELEPORT_MODULE: the teleport entry and the prologue, no render entry -- at the first query
+    // (ptl_kernel_teleport_ray / ptl_kernel_prebuild_teleport).  The companion has a uniform block of its own; a query copies this kernel's.
+    bool split = false;
+    std::string source;
+    std::vector<std::string> defines;
+    ptl_kernel* companion = nullptr;
     unsigned block_waves = 4;       // PTL_BLOCK_WAVES (experiments with narrower workgroups), read once at compile time
     void* last_stream = nullptr;    // the stream of the most recent render launch ...
     bool launched = false;          // ... which may still be reading the uniform block
@@ -225,6 +250,15 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
     }
     k->shadow.assign(uniform_block_size, 0);
 
+    bool teleport_only = false;
+    for (int i = 0; i < n_defines; ++i) {
+        if (std::string(defines[i]) == "PTL_RENDER_MODULE") k->split = true;
+        if (std::string(defines[i]) == "PTL_TELEPORT_MODULE") teleport_only = true;
+    }
+    if (k->split) {
+        k->source = hip_source;
+        for (int i = 0; i < n_defines; ++i) k->defines.push_back(defines[i]);
+    }
     std::vector<std::string> opts = compile_options(defines, n_defines);
     // ---- code-object cache: same source + options -> same gfx950 binary -----------------------
     std::string cdir = cache_dir();
@@ -324,7 +358,9 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
         }
         return PTL_ERR_HIP;
     }
-    if (rt->hipModuleGetFunction(&k->fn, k->module, "ptl_render_kernel") != 0) {
+    if (teleport_only) {
+        k->fn = nullptr;  // the teleport half of a split build: no render entry by construction
+    } else if (rt->hipModuleGetFunction(&k->fn, k->module, "ptl_render_kernel") != 0) {
         rt->hipGetLastError();
         // a module with the slices entry instead (codegen.cpp `apply_slices_entry`)
         if (!hip_ok(rt, rt->hipModuleGetFunction(&k->fn, k->module, "ptl_render_slices_kernel"), "hipModuleGetFunction(ptl_render_kernel / ptl_render_slices_kernel)"))
@@ -371,6 +407,9 @@ extern "C" int ptl_kernel_clone(ptl_kernel* src, ptl_kernel** out) {
     k->slots = src->slots;
     k->shadow = src->shadow;
     k->block_waves = src->block_waves;
+    k->split = src->split;
+    k->source = src->source;
+    k->defines = src->defines;
     if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;
     if (!hip_ok(rt, rt->hipModuleLoadData(&k->module, k->code.data()), "hipModuleLoadData(clone)")) return PTL_ERR_HIP;
     auto fail = [&](int rc) {
@@ -674,10 +713,47 @@ extern "C" int ptl_kernel_render_to_host(ptl_kernel* k, const ptl_frame* frame, 
     return rc;
 }
 
+// The teleport half of a split build (see ptl_kernel::split): compiled -- or found in the code-object cache -- once per kernel, on the
+// kernel's device (a compile-only handle gets a compile-only companion: that fills the cache).
+extern "C" int ptl_kernel_prebuild_teleport(ptl_kernel* k) {
+    if (!k) return PTL_ERR_INVALID;
+    if (!k->split || k->companion) return PTL_OK;
+    std::vector<std::string> defs;
+    for (auto& d : k->defines)
+        if (d != "PTL_RENDER_MODULE") defs.push_back(d);
+    defs.push_back("PTL_TELEPORT_MODULE");
+    std::vector<const char*> cdefs;
+    for (auto& d : defs) cdefs.push_back(d.c_str());
+    std::vector<ptl_uniform_desc> descs;
+    for (auto& sl : k->slots) descs.push_back(ptl_uniform_desc{sl.first.c_str(), sl.second.type, sl.second.offset});
+    ptl_kernel* c = nullptr;
+    int rc = ptl_kernel_compile(k->device, k->source.c_str(), descs.data(), (int)descs.size(), k->shadow.size(), cdefs.data(), (int)cdefs.size(), &c, nullptr, 0);
+    if (rc != PTL_OK) return rc;
+    if (k->device >= 0 && !c->teleport_fn) {
+        ptl_kernel_destroy(c);
+        set_last_error("the teleport half of the build has no ptl_teleport_kernel entry");
+        return PTL_ERR_INVALID;
+    }
+    k->companion = c;
+    return PTL_OK;
+}
+
 extern "C" int ptl_kernel_teleport_ray(ptl_kernel* k, const float a[3], const float b[3], float out_pos[3], int* hit_object,
                                        int* changed_subspace, int* teleported) {
     if (!k || !a || !b) return PTL_ERR_INVALID;
-    if (k->device < 0 || !k->fn) return PTL_ERR_NO_DEVICE;
+    if (k->device < 0 || (!k->fn && !k->teleport_fn)) return PTL_ERR_NO_DEVICE;
+    if (!k->teleport_fn && k->split) {  // the query runs on the other half of the build, with this kernel's uniform values
+        if (int rc = ptl_kernel_prebuild_teleport(k); rc != PTL_OK) return rc;
+        ptl_kernel* c = k->companion;
+        if (c->shadow.size() != k->shadow.size()) return PTL_ERR_INVALID;
+        if (std::memcmp(c->shadow.data(), k->shadow.data(), k->shadow.size()) != 0) {
+            c->shadow = k->shadow;
+            c->dirty = true;
+        }
+        int rc = ptl_kernel_teleport_ray(c, a, b, out_pos, hit_object, changed_subspace, teleported);
+        // (the segment end points the query wrote into the companion's block stay there; this kernel's block never sees them)
+        return rc;
+    }
     if (!k->teleport_fn) {
         set_last_error("the loaded code object has no ptl_teleport_kernel entry");
         return PTL_ERR_INVALID;
@@ -709,6 +785,7 @@ extern "C" int ptl_kernel_teleport_ray(ptl_kernel* k, const float a[3], const fl
 
 extern "C" void ptl_kernel_destroy(ptl_kernel* k) {
     if (!k) return;
+    if (k->companion) ptl_kernel_destroy(k->companion);
     const hip::Runtime* rt = k->device >= 0 ? hip::runtime(nullptr) : nullptr;
     if (rt) {
         rt->hipSetDevice(k->device);

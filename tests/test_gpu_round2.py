@@ -703,3 +703,47 @@ def test_one_launch_for_several_draws_gives_the_frames_of_draws_one_by_one(gpu, 
     assert np.array_equal(rb.draw(w, h)["rgba8"], ra.draw(w, h)["rgba8"])  # ... and leaves the next draws alone
     if flags_name == "static":  # (the moving uniform was compiled in: the kernel was rebuilt between two stage calls, and the slices staged before it survived)
         assert rb.rejit_count() >= 1
+
+
+# ---- split builds: the teleport entry as a module of its own ------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name, flags_name", [("basics", "dyn"), ("triple_portal", "baked"), ("portal_in_portal", "baked")])
+def test_teleport_queries_of_a_split_build_equal_the_one_module_build(gpu, monkeypatch, scene_name, flags_name):
+    """The renderer's kernels have no teleport entry (-DPTL_RENDER_MODULE); a query compiles the other half of the build on demand and runs
+    there with the render kernel's uniform values (kernel.cpp `ptl_kernel::split`).  Same answers as the classic one-module build
+    (PTL_ONE_MODULE=1) for ray queries and whole camera walks, frames untouched by the queries in between, and the query does not wait for --
+    or disturb -- a uniform change made for the next frame."""
+    pa = gpu
+    flags = 0 if flags_name == "dyn" else pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
+    path = pa.scene_path(scene_name)
+
+    def walk(r, scene):
+        seen = []
+        vals = scene.uniform_values()
+        rng = np.random.default_rng(3)
+        for tname in sorted(k for k in vals if k.endswith("_mat_teleport"))[:3]:
+            A = np.asarray(vals[tname[: -len("_mat_teleport")].split("_to_")[0] + "_mat"], np.float64)
+            for _ in range(3):
+                uv = rng.uniform(-0.6, 0.6, 2)
+                a = (A @ np.array([uv[0], uv[1], 0.4, 1.0]))[:3]
+                b = (A @ np.array([uv[0] + 0.1, uv[1], -0.4, 1.0]))[:3]
+                seen.append(str(r.teleport_external_ray(a, b)))
+            seen.append(r.draw(48, 32)["rgba8"].tobytes())
+        look = np.zeros(3)
+        for step in range(12):
+            look = look + np.array([0.35, 0.1, -0.3]) * (1 if step < 8 else -1)
+            seen.append(str(r.move_camera(tuple(look), 0.3 + 0.2 * step, 0.2, 2.5)))
+            seen.append(r.draw(48, 32)["rgba8"].tobytes())
+        return seen
+
+    scene_a = pa.Scene.from_file(path)
+    ra = pa.SceneRenderer(scene_a, device=0, flags=flags)
+    assert b"ptl_teleport_kernel" not in ra.code_object()
+    split = walk(ra, scene_a)
+    monkeypatch.setenv("PTL_ONE_MODULE", "1")
+    scene_b = pa.Scene.from_file(path)
+    rb = pa.SceneRenderer(scene_b, device=0, flags=flags)
+    assert b"ptl_teleport_kernel" in rb.code_object()
+    whole = walk(rb, scene_b)
+    assert split == whole
+    assert sum(1 for s in split if isinstance(s, str) and s.startswith("((")) >= 2  # some rays did go through a portal

@@ -1371,7 +1371,11 @@ def test_generated_defines_go_with_the_generated_source(pa):
     for flags, want in ((0, {"PTL_FIRST_TRIP"}), (spec, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS"}), (spec | pa.FLAG_EXACT_CR, {"PTL_FIRST_TRIP", "PTL_CONTRACT_V1"}),
                         (spec | pa.FLAG_FAST_MATH, {"PTL_FIRST_TRIP", "PTL_FAST_MATH"}), (pa.FLAG_COUNT_SEGMENTS | pa.FLAG_ANAGLYPH, {"PTL_FIRST_TRIP", "PTL_COUNT_SEGMENTS", "PTL_ANAGLYPH"})):
         scene.generate_source(flags)
-        assert set(scene.generated_defines()) == want, flags
+        # (PTL_JIT_MODULE_INLINER: this scene's intersection-material snippet loops -- the JIT picks LLVM's module inliner for it, kernel.cpp)
+        assert set(scene.generated_defines()) == want | {"PTL_JIT_MODULE_INLINER"}, flags
+    mono = pa.Scene.from_file(pa.scene_path("monoportal"))
+    mono.generate_source(spec)
+    assert set(mono.generated_defines()) == {"PTL_DROP_ZERO_TERMS"}  # no looping snippet: the toolchain's default inliner
 
 
 def test_renderer_options_given_at_creation_are_in_the_first_build(pa, tmp_path, monkeypatch):
@@ -1566,3 +1570,99 @@ def test_slices_entry_is_a_substitution_that_keeps_the_scene_lines_and_the_pictu
         r.draw_slices(pa.Frame(64, 64, 0, 1), 1)
     with pytest.raises(pa.PortalError, match="not all staged"):
         r.draw_slices(pa.Frame(64, 64, 0, 1), 2)
+
+
+def test_library_functions_of_a_scene_are_force_inlined(pa):
+    """Scene libraries (scene.rs:1037-1044) are pasted into the kernel as translated GLSL: every function DEFINITION among them gets PTL_FN on
+    its own line -- prototypes, struct heads, globals and #define lines do not -- so that LLVM's module inliner (which does not inline plain
+    `inline` members by itself) leaves no call behind: a call passes `this`, and the tracer object would live in scratch."""
+    import re
+
+    text = """
+#define TWICE(x) float twice_macro(x)
+struct Pair { float a; float b; };
+const vec3 tint = vec3(1., 0.5, 0.25);
+float helper(float x);
+float helper(float x) {
+  return x * 2.;
+}
+vec3 shade(vec3 c, in float k, out float used) { used = k; if (k > 0.) { return c * helper(k); } return c; }
+int
+count_up(int n)
+{
+  int s = 0;
+  for (int i = 0; i < 4; i++) { s += i; }
+  return s;
+}
+"""
+    out = pa.translate_library_glsl(text)
+    assert out.count("PTL_FN") == 3
+    assert "PTL_FN float helper(float x) {" in out and "PTL_FN vec3 shade(" in out and re.search(r"PTL_FN int\s+count_up\(int n\)\s*\{", out)
+    assert "float helper(float x);" in out and "PTL_FN float helper(float x);" not in out
+    assert "struct Pair {" in out and "const vec3 tint" in out and "#define TWICE(x) float twice_macro(x)" in out
+    assert out.count("\n") == text.count("\n")  # line numbers of the scene text survive
+    # every library function of the reference's scenes
+    for name in ("portal_in_portal", "monoportal", "triple_portal", "mobius_monoportal", "basics"):
+        src = pa.Scene.from_file(pa.scene_path(name)).generate_source(0)
+        lib = src[src.index("// --- scene library snippets"):src.index("// --- is_inside_N / intersect_N wrappers")]
+        depth, bare = 0, []
+        for line in lib.splitlines():
+            m = re.match(r"\}?\s*(PTL_FN\s+)?(int|float|bool|void|vec[234]|mat[234]|Ray|SceneIntersection|SurfaceIntersection|MaterialProcessing)\s+\w+\s*\([^;]*$", line)
+            if depth == 0 or line.startswith("}"):
+                if m and not m.group(1) and "(" in line and not line.rstrip().endswith(";"):
+                    bare.append(line)
+            depth += line.count("{") - line.count("}")
+        assert not bare, (name, bare[:3])
+
+
+def test_renderer_builds_are_split_in_a_render_and_a_teleport_module(pa, tmp_path, monkeypatch):
+    """The camera-teleport entry is a second copy of the tracer and a fifth of every hiprtc build: the renderer compiles its kernels without it
+    (-DPTL_RENDER_MODULE) and the other half (-DPTL_TELEPORT_MODULE: teleport entry + prologue) when a query first needs it, or ahead of time
+    through prebuild_teleport -- a cached code object of its own.  PTL_ONE_MODULE=1: everything in one module, as layer 1 compiles a plain source."""
+    import glob
+
+    monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path))
+    scene = pa.Scene.from_file(pa.scene_path("basics"))
+    r = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_QUICK_JIT)
+    code = r.code_object()
+    assert b"ptl_render_kernel" in code and b"ptl_derive_kernel" in code and b"ptl_teleport_kernel" not in code
+    assert len(glob.glob(str(tmp_path / "*.hsaco"))) == 1
+    r.prebuild_teleport()
+    files = glob.glob(str(tmp_path / "*.hsaco"))
+    assert len(files) == 2
+    other = next(open(f, "rb").read() for f in files if open(f, "rb").read() != code)
+    assert b"ptl_teleport_kernel" in other and b"ptl_derive_kernel" in other and b"ptl_render_kernel" not in other
+    r.prebuild_teleport()  # once per kernel
+    assert len(glob.glob(str(tmp_path / "*.hsaco"))) == 2
+    monkeypatch.setenv("PTL_ONE_MODULE", "1")
+    whole = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_QUICK_JIT).code_object()
+    assert b"ptl_render_kernel" in whole and b"ptl_teleport_kernel" in whole and len(whole) > len(code)
+    # layer 1: a generated source compiled without either define has every entry
+    k = pa.compile_source(scene.generate_source(0), scene, defines=list(scene.generated_defines()) + ["PTL_QUICK_JIT"]) if hasattr(pa, "compile_source") else None
+    if k is not None:
+        assert b"ptl_teleport_kernel" in k
+
+
+def test_the_jit_picks_the_module_inliner_where_a_snippet_loops(pa, tmp_path, monkeypatch):
+    """kernel.cpp compile_options: LLVM's module inliner for kernels whose intersection-material snippet has a loop (define
+    PTL_JIT_MODULE_INLINER from codegen.cpp) and for quick builds; the toolchain's bottom-up inliner otherwise.  Observable through the code-object
+    cache: forcing the same choice with PTL_MODULE_INLINER gives the same file, forcing the other one a second file."""
+    import glob
+
+    monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path))
+    n = lambda: len(glob.glob(str(tmp_path / "*.hsaco")))
+    mono = pa.Scene.from_file(pa.scene_path("monoportal"))
+    pa.SceneRenderer(mono, device=-1, flags=0)
+    assert n() == 1
+    monkeypatch.setenv("PTL_MODULE_INLINER", "0")
+    pa.SceneRenderer(mono, device=-1, flags=0)
+    assert n() == 1  # the default for a scene without looping snippets IS the bottom-up inliner
+    monkeypatch.setenv("PTL_MODULE_INLINER", "1")
+    pa.SceneRenderer(mono, device=-1, flags=0)
+    assert n() == 2
+    monkeypatch.delenv("PTL_MODULE_INLINER")
+    pa.SceneRenderer(mono, device=-1, flags=pa.FLAG_QUICK_JIT)  # quick: -O1 and the module inliner
+    assert n() == 3
+    monkeypatch.setenv("PTL_MODULE_INLINER", "1")
+    pa.SceneRenderer(mono, device=-1, flags=pa.FLAG_QUICK_JIT)
+    assert n() == 3
