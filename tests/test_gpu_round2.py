@@ -746,4 +746,5 @@ def test_teleport_queries_of_a_split_build_equal_the_one_module_build(gpu, monke
     assert b"ptl_teleport_kernel" in rb.code_object()
     whole = walk(rb, scene_b)
     assert split == whole
-    assert sum(1 for s in split if isinstance(s, str) and s.startswith("((")) >= 2  # some rays did go through a portal
+    if scene_name != "portal_in_portal":  # (its portals live in an intersection-material snippet: no *_mat_teleport uniform to aim the rays with)
+        assert sum(1 for s in split if isinstance(s, str) and s.startswith("((")) >= 2  # some rays did go through a portal
