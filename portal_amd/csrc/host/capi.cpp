@@ -661,13 +661,21 @@ static bool split_builds() {
     return !(e && e[0] == '1');
 }
 
+// What a renderer's build adds to the defines that belong to the generated source: the occupancy hint of the flags (bits 8-11:
+// __launch_bounds__(256, waves)) and the split.
+static std::vector<std::string> build_defines(const GeneratedKernel&, unsigned flags) {
+    std::vector<std::string> d;
+    unsigned waves = (flags >> 8) & 0xFu;
+    if (waves) d.push_back("PTL_WAVES_PER_EU=" + std::to_string(waves));
+    if (split_builds()) d.push_back("PTL_RENDER_MODULE");
+    return d;
+}
+
 static ptl_renderer::Build snapshot_build(ptl_scene* s, unsigned flags) {
     ptl_renderer::Build b;
     b.source = s->last.source;
     b.defines = s->last.defines;
-    unsigned waves = (flags >> 8) & 0xFu;
-    if (waves) b.defines.push_back("PTL_WAVES_PER_EU=" + std::to_string(waves));
-    if (split_builds()) b.defines.push_back("PTL_RENDER_MODULE");
+    for (auto& d : build_defines(s->last, flags)) b.defines.push_back(d);
     b.desc_names = s->desc_names;
     b.descs = s->descs;
     for (size_t k = 0; k < b.descs.size(); ++k) b.descs[k].name = b.desc_names[k].c_str();
@@ -728,11 +736,10 @@ static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
         r->kernel_scene_version = r->scene->version;
         return PTL_OK;
     }
-    unsigned waves = (r->flags >> 8) & 0xFu;  // occupancy hint: __launch_bounds__(256, waves)
-    if (waves) s->last.defines.push_back("PTL_WAVES_PER_EU=" + std::to_string(waves));
+    const std::vector<std::string> extra = build_defines(s->last, r->flags);  // (not into s->last.defines: ptl_scene_generated_defines describes the source, not this build)
     std::vector<const char*> defines;
     for (auto& d : s->last.defines) defines.push_back(d.c_str());
-    if (split_builds()) defines.push_back("PTL_RENDER_MODULE");  // (not into s->last.defines: ptl_scene_generated_defines describes the source, not this build)
+    for (auto& d : extra) defines.push_back(d.c_str());
     ptl_kernel* k = nullptr;
     int rc = ptl_kernel_compile(r->device, s->last.source.c_str(), s->descs.data(), (int)s->descs.size(), s->last.uniform_block_size, defines.data(),
                                 (int)defines.size(), &k, log, log_cap);

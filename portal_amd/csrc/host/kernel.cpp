@@ -55,6 +55,26 @@ std::string opt_level(bool quick) {
     return quick ? "-O1" : "-O3";
 }
 
+// The largest value a key of the code object's kernel metadata (msgpack in the AMDGPU note: ".vgpr_count", ".vgpr_spill_count",
+// ".private_segment_fixed_size" ...) takes over the kernels of the module; -1 when the key does not occur.  A scan for the key's bytes
+// followed by a msgpack unsigned integer -- enough for a decision about an occupancy hint, no msgpack reader.
+int code_object_note_max(const std::vector<char>& code, const char* key) {
+    const size_t n = std::strlen(key);
+    int best = -1;
+    for (size_t i = 0; i + n + 1 < code.size(); ++i) {
+        if (std::memcmp(code.data() + i, key, n) != 0) continue;
+        const unsigned char* p = reinterpret_cast<const unsigned char*>(code.data()) + i + n;
+        const size_t left = code.size() - (i + n);
+        long v = -1;
+        if (p[0] <= 0x7f) v = p[0];
+        else if (p[0] == 0xcc && left >= 2) v = p[1];
+        else if (p[0] == 0xcd && left >= 3) v = (p[1] << 8) | p[2];
+        else if (p[0] == 0xce && left >= 5) v = ((long)p[1] << 24) | (p[2] << 16) | (p[3] << 8) | p[4];
+        if (v > best) best = (int)v;
+    }
+    return best;
+}
+
 std::vector<std::string> compile_options(const char* const* defines, int n_defines) {
     const char* arch = std::getenv("PTL_OFFLOAD_ARCH");
     bool fast = false;  // the tolerance mode (device/ptl_glsl.h, PTL_FAST_MATH): contraction and approximate / and sqrt allowed
@@ -291,36 +311,56 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
             set_last_error(err);
             return PTL_ERR_COMPILE;
         }
-        hip::hiprtcProgram prog = nullptr;
-        int r = rc->hiprtcCreateProgram(&prog, hip_source, "portal_scene.hip", 0, nullptr, nullptr);
-        if (r != 0) {
-            set_last_error(std::string("hiprtcCreateProgram: ") + rc->hiprtcGetErrorString(r));
-            return PTL_ERR_COMPILE;
-        }
-        std::vector<const char*> copts;
-        for (auto& o : opts) copts.push_back(o.c_str());
-        r = rc->hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
-        size_t log_size = 0;
-        rc->hiprtcGetProgramLogSize(prog, &log_size);
-        if (log_size > 1) {
-            std::vector<char> buf(log_size + 1, 0);
-            rc->hiprtcGetProgramLog(prog, buf.data());
-            if (log && log_cap) {
-                std::strncpy(log, buf.data(), log_cap - 1);
-                log[log_cap - 1] = '\0';
+        auto run_hiprtc = [&](const std::vector<std::string>& options, std::vector<char>& code, bool report) -> int {
+            hip::hiprtcProgram prog = nullptr;
+            int r = rc->hiprtcCreateProgram(&prog, hip_source, "portal_scene.hip", 0, nullptr, nullptr);
+            if (r != 0) {
+                if (report) set_last_error(std::string("hiprtcCreateProgram: ") + rc->hiprtcGetErrorString(r));
+                return PTL_ERR_COMPILE;
             }
-            if (r != 0) set_last_error(std::string("hiprtc: ") + buf.data());
-        }
-        if (r != 0) {
-            if (log_size <= 1) set_last_error(std::string("hiprtcCompileProgram: ") + rc->hiprtcGetErrorString(r));
+            std::vector<const char*> copts;
+            for (auto& o : options) copts.push_back(o.c_str());
+            r = rc->hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
+            size_t log_size = 0;
+            rc->hiprtcGetProgramLogSize(prog, &log_size);
+            if (log_size > 1 && report) {
+                std::vector<char> buf(log_size + 1, 0);
+                rc->hiprtcGetProgramLog(prog, buf.data());
+                if (log && log_cap) {
+                    std::strncpy(log, buf.data(), log_cap - 1);
+                    log[log_cap - 1] = '\0';
+                }
+                if (r != 0) set_last_error(std::string("hiprtc: ") + buf.data());
+            }
+            if (r != 0) {
+                if (log_size <= 1 && report) set_last_error(std::string("hiprtcCompileProgram: ") + rc->hiprtcGetErrorString(r));
+                rc->hiprtcDestroyProgram(&prog);
+                return PTL_ERR_COMPILE;
+            }
+            size_t code_size = 0;
+            rc->hiprtcGetCodeSize(prog, &code_size);
+            code.resize(code_size);
+            rc->hiprtcGetCode(prog, code.data());
             rc->hiprtcDestroyProgram(&prog);
-            return PTL_ERR_COMPILE;
+            return PTL_OK;
+        };
+        if (int rc1 = run_hiprtc(opts, k->code, true); rc1 != PTL_OK) return rc1;
+        // 128 VGPRs is where the fourth wave per SIMD goes.  A kernel that lands a few registers above it without having been told an
+        // occupancy (no PTL_WAVES_PER_EU: the module inliner's builds of portal_in_portal with the Panini switch and the slices entry, 130
+        // VGPRs, 0.262 -> 0.314 ms per frame) is compiled once more with __launch_bounds__(256, 4); that build is kept if the allocator got
+        // there without spilling (the same source under a register cap: same arithmetic, same frames).  One more hiprtc run, for the rare
+        // kernel in that band, stored under the key of the options the caller asked for.
+        bool hinted = false;
+        for (int i = 0; i < n_defines; ++i) hinted = hinted || std::strncmp(defines[i], "PTL_WAVES_PER_EU", 16) == 0;
+        const int vgprs = code_object_note_max(k->code, ".vgpr_count");
+        if (!hinted && !teleport_only && vgprs > 128 && vgprs <= 168 && !std::getenv("PTL_NO_OCCUPANCY_RETRY")) {
+            std::vector<std::string> capped = opts;
+            capped.push_back("-DPTL_WAVES_PER_EU=4");
+            std::vector<char> second;
+            if (run_hiprtc(capped, second, false) == PTL_OK && code_object_note_max(second, ".vgpr_spill_count") == 0 &&
+                code_object_note_max(second, ".private_segment_fixed_size") <= code_object_note_max(k->code, ".private_segment_fixed_size"))
+                k->code.swap(second);
         }
-        size_t code_size = 0;
-        rc->hiprtcGetCodeSize(prog, &code_size);
-        k->code.resize(code_size);
-        rc->hiprtcGetCode(prog, k->code.data());
-        rc->hiprtcDestroyProgram(&prog);
         if (!cache_path.empty()) {
             ::mkdir(cdir.c_str(), 0755);
             // one temp file per COMPILE, not per process: background re-JIT workers and the ranks of a frame group compile the same source on
