@@ -1174,12 +1174,15 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         }
         gk.first_trip_variants = any_first;
         // A loop in an intersection-material snippet (portal_in_portal's ten nested copies) puts the deepest call chain of the kernel inside a
-        // loop nest, unrolled when its bound is baked: the kernels whose hiprtc time the bottom-up inliner pipeline dominates (kernel.cpp
-        // compile_options; tools/jit_inliner_survey.py).  The JIT switches to the module inliner for them.
+        // loop nest; unrolled -- its bound a baked Int (`unrolled()` above) -- it multiplies the body that LLVM's bottom-up inliner pipeline
+        // re-simplifies at every call level: the kernels whose hiprtc time that pipeline dominates (kernel.cpp compile_options;
+        // tools/jit_inliner_survey.py).  The JIT switches to the module inliner for them.  Only for them: it needs ~10 more VGPRs, which the
+        // baked builds have (115 -> 125 of 128) and the others do not (patterns build with the slices entry: 120 -> 139, a wave per SIMD lost).
         for (const NamedCode& im : scene.intersection_materials) {
-            const std::vector<Token> toks = tokenize_glsl(filter_tagged_lines(im.code, flags));
-            for (const Token& t : toks)
-                if (t.kind == Token::Ident && (t.text == "for" || t.text == "while")) gk.looped_snippets = true;
+            bool loops = false;
+            for (const Token& t : tokenize_glsl(filter_tagged_lines(im.code, flags)))
+                if (t.kind == Token::Ident && (t.text == "for" || t.text == "while")) loops = true;
+            if (loops && snippet(im.code).find("_Pragma(\"unroll\")") != std::string::npos) gk.looped_snippets = true;
         }
         storages["intersection_material_functions"] = std::move(fns);
         storages["intersection_material_processing"] = std::move(calls);

@@ -155,7 +155,7 @@ struct GeneratedKernel {
     std::vector<UniformUpload> baked;   // the values compiled in as literals (specialised builds)
     int first_trip_plane_tests = 0;     // generated plane tests that have a first-trip form (ptl_dvo_<object>_<side> members)
     bool first_trip_variants = false;   // the kernel has first-trip copies of its intersection-material snippets (define PTL_FIRST_TRIP)
-    bool looped_snippets = false;       // an intersection-material snippet has a loop (define PTL_JIT_MODULE_INLINER: kernel.cpp compiles it with the module inliner)
+    bool looped_snippets = false;       // an intersection-material snippet has a force-unrolled loop (define PTL_JIT_MODULE_INLINER: kernel.cpp compiles it with the module inliner)
     int hoisted_members = 0;            // ... plus this many members holding uniform-only work of the scene snippets (glsl_hoist.h)
     std::vector<DerivedPlane> derived;  // members appended to the block behind uniform_block_size, written on the device
     std::vector<std::pair<std::string, unsigned>> masked;  // run-time matrices whose zero pattern is compiled in: bit 4 * column + row set = may be non-zero

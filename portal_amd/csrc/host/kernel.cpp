@@ -116,12 +116,14 @@ std::vector<std::string> compile_options(const char* const* defines, int n_defin
         // kernel is force-inlined into ONE body, eight call levels deep (kernel -> shade_pixel -> get_color -> get_color2 -> ray_tracing ->
         // trace_segment -> snippets -> library); the bottom-up pipeline re-runs its whole function simplification on that body at each level
         // on the way up (opt --time-trace of the headline: 0.25 s per level of a 5 s build).  The module inliner inlines first and simplifies
-        // once: -28 ... -43 % hiprtc time where an intersection-material snippet loops (portal_in_portal: 10 nested portal copies per trip;
-        // codegen.cpp sets PTL_JIT_MODULE_INLINER), the same kernel time there; elsewhere it saves 0-25 % of a 1-2 s build and the kernel
-        // is 1.5-3 % slower (monoportal, triple_portal: profiles/r04/variants_module_inliner.jsonl), so those keep the toolchain's default.
-        // Same source, same arithmetic, other instruction schedule: bit-identical frames.  PTL_MODULE_INLINER=0 / 1 forces the choice.
+        // once: -28 ... -43 % hiprtc time where an intersection-material snippet has a force-unrolled loop (portal_in_portal with its Ints
+        // baked: 10 nested portal copies per trip; codegen.cpp sets PTL_JIT_MODULE_INLINER), the same kernel time there.  Elsewhere it saves
+        // 0-25 % of a 1-2 s build for a kernel that is 1.5-3 % slower (monoportal, triple_portal: profiles/r04/variants_module_inliner.jsonl)
+        // or, with ~10 more VGPRs, a wave per SIMD poorer (portal_in_portal's un-baked builds with the slices entry: 120 -> 139 registers), so
+        // those keep the toolchain's default.  Same source, same arithmetic, other instruction schedule: bit-identical frames.
+        // PTL_MODULE_INLINER=0 / 1 forces the choice.
         const char* mi = std::getenv("PTL_MODULE_INLINER");
-        bool wanted = quick;  // a quick build wants its kernel NOW
+        bool wanted = false;
         for (int k = 0; k < n_defines; ++k) wanted = wanted || std::string(defines[k]) == "PTL_JIT_MODULE_INLINER";
         if (mi ? (mi[0] != '0') : wanted) {
             o.push_back("-mllvm");

@@ -1371,8 +1371,9 @@ def test_generated_defines_go_with_the_generated_source(pa):
     for flags, want in ((0, {"PTL_FIRST_TRIP"}), (spec, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS"}), (spec | pa.FLAG_EXACT_CR, {"PTL_FIRST_TRIP", "PTL_CONTRACT_V1"}),
                         (spec | pa.FLAG_FAST_MATH, {"PTL_FIRST_TRIP", "PTL_FAST_MATH"}), (pa.FLAG_COUNT_SEGMENTS | pa.FLAG_ANAGLYPH, {"PTL_FIRST_TRIP", "PTL_COUNT_SEGMENTS", "PTL_ANAGLYPH"})):
         scene.generate_source(flags)
-        # (PTL_JIT_MODULE_INLINER: this scene's intersection-material snippet loops -- the JIT picks LLVM's module inliner for it, kernel.cpp)
-        assert set(scene.generated_defines()) == want | {"PTL_JIT_MODULE_INLINER"}, flags
+        # (PTL_JIT_MODULE_INLINER: this scene's intersection-material snippet loops, and with the Ints baked the loop is force-unrolled -- the
+        # JIT picks LLVM's module inliner for those builds, kernel.cpp)
+        assert set(scene.generated_defines()) == want | ({"PTL_JIT_MODULE_INLINER"} if flags & pa.FLAG_SPECIALIZE_INTS else set()), flags
     mono = pa.Scene.from_file(pa.scene_path("monoportal"))
     mono.generate_source(spec)
     assert set(mono.generated_defines()) == {"PTL_DROP_ZERO_TERMS"}  # no looping snippet: the toolchain's default inliner
@@ -1643,29 +1644,34 @@ def test_renderer_builds_are_split_in_a_render_and_a_teleport_module(pa, tmp_pat
         assert b"ptl_teleport_kernel" in k
 
 
-def test_the_jit_picks_the_module_inliner_where_a_snippet_loops(pa, tmp_path, monkeypatch):
-    """kernel.cpp compile_options: LLVM's module inliner for kernels whose intersection-material snippet has a loop (define
-    PTL_JIT_MODULE_INLINER from codegen.cpp) and for quick builds; the toolchain's bottom-up inliner otherwise.  Observable through the code-object
-    cache: forcing the same choice with PTL_MODULE_INLINER gives the same file, forcing the other one a second file."""
+def test_the_jit_picks_the_module_inliner_where_a_snippet_loop_is_unrolled(pa, tmp_path, monkeypatch):
+    """kernel.cpp compile_options: LLVM's module inliner for kernels whose intersection-material snippet has a force-unrolled loop (define
+    PTL_JIT_MODULE_INLINER from codegen.cpp: portal_in_portal with its Ints baked); the toolchain's bottom-up inliner otherwise.  Observable through
+    the code-object cache: forcing the same choice with PTL_MODULE_INLINER gives the same file, forcing the other one a second file."""
     import glob
 
     monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path))
     n = lambda: len(glob.glob(str(tmp_path / "*.hsaco")))
     mono = pa.Scene.from_file(pa.scene_path("monoportal"))
-    pa.SceneRenderer(mono, device=-1, flags=0)
+    pa.SceneRenderer(mono, device=-1, flags=pa.FLAG_QUICK_JIT)
     assert n() == 1
     monkeypatch.setenv("PTL_MODULE_INLINER", "0")
-    pa.SceneRenderer(mono, device=-1, flags=0)
+    pa.SceneRenderer(mono, device=-1, flags=pa.FLAG_QUICK_JIT)
     assert n() == 1  # the default for a scene without looping snippets IS the bottom-up inliner
     monkeypatch.setenv("PTL_MODULE_INLINER", "1")
-    pa.SceneRenderer(mono, device=-1, flags=0)
+    pa.SceneRenderer(mono, device=-1, flags=pa.FLAG_QUICK_JIT)
     assert n() == 2
     monkeypatch.delenv("PTL_MODULE_INLINER")
-    pa.SceneRenderer(mono, device=-1, flags=pa.FLAG_QUICK_JIT)  # quick: -O1 and the module inliner
+    pip = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    baked = pa.FLAG_SPECIALIZE_INTS  # (not a quick build: those leave the loop rolled)
+    pa.SceneRenderer(pip, device=-1, flags=baked)
     assert n() == 3
     monkeypatch.setenv("PTL_MODULE_INLINER", "1")
-    pa.SceneRenderer(mono, device=-1, flags=pa.FLAG_QUICK_JIT)
-    assert n() == 3
+    pa.SceneRenderer(pip, device=-1, flags=baked)
+    assert n() == 3  # ... and for the unrolled nested-portal loop the module inliner
+    monkeypatch.setenv("PTL_MODULE_INLINER", "0")
+    pa.SceneRenderer(pip, device=-1, flags=baked)
+    assert n() == 4
 
 
 def _note_max(code: bytes, key: bytes) -> int:
