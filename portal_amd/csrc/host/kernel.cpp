@@ -353,7 +353,7 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
         // there without spilling (the same source under a register cap: same arithmetic, same frames).  One more hiprtc run, for the rare
         // kernel in that band, stored under the key of the options the caller asked for.
         bool hinted = false;
-        for (int i = 0; i < n_defines; ++i) hinted = hinted || std::strncmp(defines[i], "PTL_WAVES_PER_EU", 16) == 0;
+        for (auto& o : opts) hinted = hinted || o.find("PTL_WAVES_PER_EU") != std::string::npos;  // (a define of the caller's, or PTL_HIPRTC_FLAGS of an experiment)
         const int vgprs = code_object_note_max(k->code, ".vgpr_count");
         if (!hinted && !teleport_only && vgprs > 128 && vgprs <= 168 && !std::getenv("PTL_NO_OCCUPANCY_RETRY")) {
             std::vector<std::string> capped = opts;
