@@ -158,6 +158,7 @@ VARIANTS = {
     # LLVM's module inliner (kernel.cpp compile_options): same arithmetic, half the hiprtc time -- what does the kernel cost?
     "r5_mi": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -mllvm -enable-module-inliner", "r5_base_w0": "SPECIALIZE_ALL", "r5_mi_w0": "SPECIALIZE_ALL -mllvm -enable-module-inliner",
     "r5_ints": "SPECIALIZE", "r5_ints_mi": "SPECIALIZE -mllvm -enable-module-inliner", "r5_dyn": "", "r5_dyn_mi": "-mllvm -enable-module-inliner",
+    "r5_bw4": "SPECIALIZE_ALL", "r5_bw2": "SPECIALIZE_ALL BLOCK_WAVES=2", "r5_bw1": "SPECIALIZE_ALL BLOCK_WAVES=1",
     "r5_nocull": "SPECIALIZE_ALL -DPTL_WAVES_PER_EU=4 -DPTL_NO_PLANE_CULL",
     "r4_ints": "SPECIALIZE", "r4_ints_cmpguard": "SPECIALIZE -DPTL_CMP_GUARD", "r4_dyn": "", "r4_dyn_cmpguard": "-DPTL_CMP_GUARD",
 }
