@@ -89,6 +89,28 @@ PATCHES = {
                   "    bool alive = true;\n    if (r.d.x > 2.0f) return RayTraceResult{vec3(r.d.x, r.d.y, r.d.z), 0.0f, false};\n    for (int j = 0; j < 0; j++) {")],
 }
 
+def _select_form_is_inside_portal(src):
+    """EXPERIMENT (must draw the intact picture): the ring classification of scenes/portal_in_portal.ron's library as straight-line selects instead of
+    the author's chain of early returns -- what a select-form rewrite of pure early-return functions in the translator would buy."""
+    a = src.index("  int material = material_second;\n  if (first) { material = material_first; }\n")
+    b = src.index("PTL_FN int ellipse_portal(")
+    body = """  int material = first ? material_first : material_second;
+  int inner = back ? material : (teleport_light_u == 1 ? TELEPORT : (first ? grid_material_first : grid_material_second));
+  int black_material = (_black_border_disable == 1) ? material : solid_black_M;
+  int result = NOT_INSIDE;
+  result = (distance < size + black_border + border + black_border) ? black_material : result;
+  result = (distance < size + black_border + border) ? material : result;
+  result = (distance < size + black_border && !back) ? black_material : result;
+  result = (distance < size) ? inner : result;
+  return result;
+}
+
+"""
+    return src[:a] + body + src[b:]
+
+
+PATCHES["pip_select_is_inside_portal"] = _select_form_is_inside_portal
+
 if __name__ == "__main__":
     only = [a[2:] for a in sys.argv[1:] if a.startswith("--")]
     sys.argv = [a for a in sys.argv if not a.startswith("--")]
@@ -110,6 +132,8 @@ if __name__ == "__main__":
         src = source
         if variant.startswith("pip_") and name != "portal_in_portal":
             continue
+        if callable(subs):
+            src, subs = subs(src), []
         for old, new in subs:
             if old not in src:
                 print(json.dumps({"scene": name, "variant": variant, "skipped": "pattern not in this build's source"}), flush=True)
