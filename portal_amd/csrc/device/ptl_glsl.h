@@ -768,23 +768,35 @@ template <int R> PTL_FN float ptl_comp(const vec4& v) {
     else if constexpr (R == 2) return v.z;
     else return v.w;
 }
-template <unsigned MASK, int R> PTL_FN float ptl_row_m(const mat4& m, const vec4& v) {
+// Round 4: the pattern also says which elements are exactly +1 or -1 (bits 16-31 and 32-47 of MASK, same element order; PTL_UNIT_BITS):
+// the portal and wall matrices of the reference's scenes are translations and quarter turns, and a fully baked build gets `x + acc` /
+// `acc - x` for such terms from constant folding (a chain of identity-diagonal products then collapses: (x + 0) + 0 is x + 0).  With the
+// element's value known the term is the SAME operation on the same numbers -- fma(1, x, acc) -- so this part of the pattern changes no
+// bit at all; the host rebuilds the kernel when such an element moves, as for the zeros (capi.cpp `zero_patterns_broken`).
+typedef unsigned long long ptl_mask_t;
+#define PTL_UNIT_BITS(ones, negs) ((ptl_mask_t)(ones) << 16 | (ptl_mask_t)(negs) << 32)
+template <ptl_mask_t MASK, int K> PTL_FN float ptl_element(float loaded) {  // element K = 4 * column + row of a matrix with pattern MASK
+    if constexpr ((MASK >> (16 + K)) & 1u) return 1.0f;
+    else if constexpr ((MASK >> (32 + K)) & 1u) return -1.0f;
+    else return loaded;
+}
+template <ptl_mask_t MASK, int R> PTL_FN float ptl_row_m(const mat4& m, const vec4& v) {
     if constexpr (MASK == 0xffffu) {  // nothing known: the ordinary chain of this build
         return ptl_mterm(ptl_comp<R>(m.c[3]), v.w, ptl_mterm(ptl_comp<R>(m.c[2]), v.z, ptl_mterm(ptl_comp<R>(m.c[1]), v.y, ptl_mterm0(ptl_comp<R>(m.c[0]), v.x))));
     } else {
         float acc = 0.0f;
-        if constexpr ((MASK >> (0 + R)) & 1u) acc = __builtin_fmaf(ptl_comp<R>(m.c[0]), v.x, acc);
-        if constexpr ((MASK >> (4 + R)) & 1u) acc = __builtin_fmaf(ptl_comp<R>(m.c[1]), v.y, acc);
-        if constexpr ((MASK >> (8 + R)) & 1u) acc = __builtin_fmaf(ptl_comp<R>(m.c[2]), v.z, acc);
-        if constexpr ((MASK >> (12 + R)) & 1u) acc = __builtin_fmaf(ptl_comp<R>(m.c[3]), v.w, acc);
+        if constexpr ((MASK >> (0 + R)) & 1u) acc = __builtin_fmaf(ptl_element<MASK, 0 + R>(ptl_comp<R>(m.c[0])), v.x, acc);
+        if constexpr ((MASK >> (4 + R)) & 1u) acc = __builtin_fmaf(ptl_element<MASK, 4 + R>(ptl_comp<R>(m.c[1])), v.y, acc);
+        if constexpr ((MASK >> (8 + R)) & 1u) acc = __builtin_fmaf(ptl_element<MASK, 8 + R>(ptl_comp<R>(m.c[2])), v.z, acc);
+        if constexpr ((MASK >> (12 + R)) & 1u) acc = __builtin_fmaf(ptl_element<MASK, 12 + R>(ptl_comp<R>(m.c[3])), v.w, acc);
         return acc;
     }
 }
-template <unsigned MASK> PTL_FN vec4 ptl_mul_m(const mat4& m, const vec4& v) {
+template <ptl_mask_t MASK> PTL_FN vec4 ptl_mul_m(const mat4& m, const vec4& v) {
     return vec4(ptl_row_m<MASK, 0>(m, v), ptl_row_m<MASK, 1>(m, v), ptl_row_m<MASK, 2>(m, v), ptl_row_m<MASK, 3>(m, v));
 }
 // (`X_mat * <anything else>` that the generator rewrote by its shape alone -- a matrix, a scalar: the ordinary product)
-template <unsigned MASK, class T> PTL_FN auto ptl_mul_m(const mat4& m, const T& x) -> decltype(m * x) { return m * x; }
+template <ptl_mask_t MASK, class T> PTL_FN auto ptl_mul_m(const mat4& m, const T& x) -> decltype(m * x) { return m * x; }
 // the same product for a matrix that is a run-time value in every build (the camera): no zero tests (they would be executed)
 PTL_FN vec4 ptl_mul_runtime(const mat4& m, const vec4& v) {
     return vec4(ptl_term(m.c[3].x, v.w, ptl_term(m.c[2].x, v.z, ptl_term(m.c[1].x, v.y, ptl_term0(m.c[0].x, v.x)))),

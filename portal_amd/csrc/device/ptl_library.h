@@ -89,7 +89,7 @@ PTL_FN Ray transform(const mat4& matrix, const Ray& r) {
 #endif
 // transform() for a matrix with a known zero pattern (ptl_mul_m, device/ptl_glsl.h): what the generator writes for `transform(X_mat, ..)`
 // when X_mat is a run-time uniform whose pattern it knows (PTL_MASK_X_mat)
-template <unsigned MASK> PTL_FN Ray ptl_transform_m(const mat4& matrix, const Ray& r) {
+template <ptl_mask_t MASK> PTL_FN Ray ptl_transform_m(const mat4& matrix, const Ray& r) {
     if constexpr (MASK == 0xffffu) return transform(matrix, r);
     else return Ray{ptl_mul_m<MASK>(matrix, r.o), ptl_mul_m<MASK>(matrix, r.d), r.tmul, r.in_subspace};
 }
@@ -168,7 +168,7 @@ PTL_FN SurfaceIntersection plane_intersect(Ray r, const mat4& plane_inv, vec3 no
 PTL_FN bool ptl_cannot_be_nearer(float oz, float dz, float best_t) {
     return oz * __builtin_fmaf(best_t * (1.0f + 0x1p-16f), dz, oz) > 0.0f;
 }
-template <unsigned MASK = 0xffffu> PTL_FN bool ptl_plane_cull(const Ray& r, const mat4& plane_inv, float best_t) {
+template <ptl_mask_t MASK = 0xffffu> PTL_FN bool ptl_plane_cull(const Ray& r, const mat4& plane_inv, float best_t) {
 #if defined(PTL_NO_PLANE_CULL)
     (void)r; (void)plane_inv; (void)best_t;
     return false;
@@ -184,7 +184,7 @@ template <unsigned MASK = 0xffffu> PTL_FN bool ptl_plane_cull(const Ray& r, cons
 }
 // The cull for a ray whose origin in the plane's frame is already known (first-trip plane tests: `o_in_plane` = plane_inv * r.o from
 // the prologue kernel): the same decision from the same two numbers, half the products.
-template <unsigned MASK = 0xffffu> PTL_FN bool ptl_plane_cull_o(const Ray& r, const mat4& plane_inv, const vec4& o_in_plane, float best_t) {
+template <ptl_mask_t MASK = 0xffffu> PTL_FN bool ptl_plane_cull_o(const Ray& r, const mat4& plane_inv, const vec4& o_in_plane, float best_t) {
 #if defined(PTL_NO_PLANE_CULL)
     (void)r; (void)plane_inv; (void)o_in_plane; (void)best_t;
     return false;
@@ -202,7 +202,7 @@ template <unsigned MASK = 0xffffu> PTL_FN bool ptl_plane_cull_o(const Ray& r, co
 
 // plane_intersect with the ray-independent half done beforehand: `unit_normal` = normalize(normal) comes from the
 // prologue kernel (ptl_tracer::derive); `flipped` tells the caller which of the two precomputed is_collinear verdicts applies.
-template <unsigned MASK = 0xffffu> PTL_FN SurfaceIntersection plane_intersect_derived(Ray r, const mat4& plane_inv, vec3 unit_normal, bool& flipped) {
+template <ptl_mask_t MASK = 0xffffu> PTL_FN SurfaceIntersection plane_intersect_derived(Ray r, const mat4& plane_inv, vec3 unit_normal, bool& flipped) {
     flipped = dot(unit_normal, r.d.sw<0, 1, 2>()) > 0.0f;
     if (flipped) unit_normal *= -1.0f;
 #if PTL_DEVICE_BUILD && defined(PTL_FAST_MATH)
@@ -237,7 +237,7 @@ PTL_FN SurfaceIntersection plane_intersect_o(Ray r, const mat4& plane_inv, vec3 
     }
     return result;
 }
-template <unsigned MASK = 0xffffu> PTL_FN SurfaceIntersection plane_intersect_derived_o(Ray r, const mat4& plane_inv, vec3 unit_normal, bool& flipped, const vec4& o_in_plane) {
+template <ptl_mask_t MASK = 0xffffu> PTL_FN SurfaceIntersection plane_intersect_derived_o(Ray r, const mat4& plane_inv, vec3 unit_normal, bool& flipped, const vec4& o_in_plane) {
 #if PTL_DEVICE_BUILD && defined(PTL_FAST_MATH)
     (void)o_in_plane;
     return plane_intersect_derived(r, plane_inv, unit_normal, flipped);

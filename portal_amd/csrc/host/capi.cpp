@@ -119,7 +119,7 @@ struct ptl_renderer {
     unsigned long long kernel_scene_version = 0;
     std::string kernel_source;
     std::map<std::string, int> kernel_switches;  // the mode switches the current specialised kernel has compiled in (KernelOptions::baked_options)
-    std::vector<std::pair<std::string, unsigned>> masked;  // run-time matrices whose zero pattern the current kernel has compiled in (GeneratedKernel::masked)
+    std::vector<std::pair<std::string, MatrixPattern>> masked;  // run-time matrices whose pattern (zeros, +-1) the current kernel has compiled in (GeneratedKernel::masked)
     std::set<std::string> keep_unmasked;                   // ... and those whose pattern did not hold (clip-constant builds: demoted like keep_dynamic)
     bool shortened = false;    // the current kernel skips zero terms of matrix products (PTL_DROP_ZERO_TERMS and / or masks): exact for finite vectors
     bool full_chains = false;  // a run-time matrix turned non-finite under such a kernel: every later build of this stage keeps the full chains
@@ -993,12 +993,10 @@ static bool zero_patterns_broken(ptl_renderer* r, const std::vector<UniformUploa
     for (auto& [name, mask] : r->masked)
         for (const UniformUpload& v : values) {
             if (v.name != name || v.type != UniformType::Mat4) continue;
-            for (int k = 0; k < 16; ++k)
-                if (v.f[k] != 0.0f && !((mask >> k) & 1u)) {
-                    r->keep_unmasked.insert(name);
-                    broken = true;
-                    break;
-                }
+            if (!pattern_holds(mask, v.f)) {  // a non-zero where the kernel skips a term, or a +-1 the kernel has as a literal and the matrix no longer holds
+                r->keep_unmasked.insert(name);
+                broken = true;
+            }
             break;
         }
     // one broken pattern says the probes did not see this clip's motion: every mask goes, so that a clip costs at most ONE extra rebuild

@@ -521,7 +521,7 @@ static void apply_slices_entry(std::string& src) {
                 "#else  // host build of the same source (oracle/host_build): rows [row_begin, row_end) of the frame\n", 1);
 }
 
-static void apply_zero_masks(std::string& src, const std::vector<std::pair<std::string, unsigned>>& masked) {
+static void apply_zero_masks(std::string& src, const std::vector<std::pair<std::string, MatrixPattern>>& masked) {
     auto ident = [](char c) { return std::isalnum((unsigned char)c) || c == '_'; };
     for (auto& [name, mask] : masked) {
         (void)mask;
@@ -631,6 +631,16 @@ static void apply_zero_masks(std::string& src, const std::vector<std::pair<std::
     }
 }
 
+MatrixPattern matrix_pattern(const float e[16]) {
+    MatrixPattern p = 0;
+    for (int k = 0; k < 16; ++k) {
+        if (e[k] != 0.0f) p |= 1ull << k;  // (column-major: k = 4 * column + row; a NaN element counts as non-zero)
+        if (e[k] == 1.0f) p |= 1ull << (16 + k);
+        if (e[k] == -1.0f) p |= 1ull << (32 + k);
+    }
+    return p;
+}
+
 bool matrix_breaks_short_chains(const float m[16]) {
     int nan = 0, inf = 0;
     for (int k = 0; k < 16; ++k) {
@@ -704,13 +714,8 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             for (auto& up : evaluate_scene_uniforms(scene, nullptr))
                 if (up.type == UniformType::Mat4 && matrix_breaks_short_chains(up.f)) gk.full_chains = true;
         if (opts.mask_zero_elements && !opts.exact_cr && !opts.fast_math && !gk.full_chains) {
-            auto nonzero_bits = [](const UniformUpload& up) {
-                unsigned mask = 0;
-                for (int k = 0; k < 16; ++k)
-                    if (up.f[k] != 0.0f) mask |= 1u << k;  // (column-major: k = 4 * column + row; a NaN element counts as non-zero)
-                return mask;
-            };
-            std::vector<std::pair<std::string, unsigned>> found;
+            auto pattern_of = [](const UniformUpload& up) { return matrix_pattern(up.f); };
+            std::vector<std::pair<std::string, MatrixPattern>> found;
             bool any_animated = false;
             const std::vector<UniformUpload> current = evaluate_scene_uniforms(scene, nullptr);
             // the state the patterns depend on: stage / clip, every value that is not animated (the probes move the animated ones themselves)
@@ -735,10 +740,10 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             if (hit)
                 for (auto& up : current) {
                     if (up.type != UniformType::Mat4 || !up.animated || baked.count(up.name) || opts.keep_unmasked.count(up.name)) continue;
-                    unsigned mask = 0xffffu;
+                    MatrixPattern mask = 0xffffu;
                     for (auto& m : opts.mask_cache->masked)
                         if (m.first == up.name) mask = m.second;
-                    if (nonzero_bits(up) & ~mask) hit = false;
+                    if (!pattern_holds(mask, up.f)) hit = false;
                 }
             if (hit) {
                 ++opts.mask_cache->hits;
@@ -746,7 +751,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             } else {
                 for (auto& up : current) {
                     if (up.type != UniformType::Mat4 || baked.count(up.name) || opts.keep_unmasked.count(up.name)) continue;
-                    found.emplace_back(up.name, nonzero_bits(up));
+                    found.emplace_back(up.name, pattern_of(up));
                     any_animated = any_animated || up.animated;
                 }
                 // A matrix that reads the formulas' `time` is identity-like exactly when a clip starts -- the moment a clip-constant kernel is
@@ -757,7 +762,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                         for (auto& up : evaluate_scene_uniforms(probe, nullptr))
                             if (up.type == UniformType::Mat4 && up.animated)
                                 for (auto& f : found)
-                                    if (f.first == up.name) f.second |= nonzero_bits(up);
+                                    if (f.first == up.name) f.second = combine_patterns(f.second, pattern_of(up));
                     };
                     Scene probe = scene;
                     const bool in_clip = !scene.run_animations && scene.current_stage.kind == StageRef::RealAnimation && scene.current_stage.index >= 0 &&
@@ -941,8 +946,10 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             else s.add_string("#define " + u.name + " (PTL_U." + u.name + ")\n");
         }
         for (auto& [name, mask] : gk.masked) {
-            char hex[16];
-            std::snprintf(hex, sizeof hex, "0x%04xu", mask);
+            char hex[96];
+            const unsigned ones = (unsigned)((mask >> 16) & 0xffffu), negs = (unsigned)((mask >> 32) & 0xffffu);
+            if (ones | negs) std::snprintf(hex, sizeof hex, "0x%04xu | PTL_UNIT_BITS(0x%04x, 0x%04x)", (unsigned)(mask & 0xffffu), ones, negs);
+            else std::snprintf(hex, sizeof hex, "0x%04xu", (unsigned)(mask & 0xffffu));
             s.add_string("#define PTL_MASK_" + name + " " + hex + "\n");
         }
         storages["uniforms"] = std::move(s);

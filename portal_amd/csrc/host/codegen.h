@@ -71,12 +71,25 @@ struct UniformUpload {
     bool same_value(const UniformUpload& o) const;
 };
 
+// What a kernel may assume about a matrix uniform that stays a run-time value (KernelOptions::mask_zero_elements), element k = 4 * column + row:
+//   bit k        the element may be non-zero (clear: it is zero -- its term is skipped, device/ptl_glsl.h `ptl_row_m`);
+//   bit 16 + k   it is exactly +1;   bit 32 + k   it is exactly -1   (the term is `x + acc` / `acc - x`: the same operation, the value known).
+// 0xffff = nothing known.  Patterns of several states of a matrix (probes over a clip) combine: may-be-non-zero bits by OR, unit bits by AND.
+typedef unsigned long long MatrixPattern;
+MatrixPattern matrix_pattern(const float elements[16]);
+inline MatrixPattern combine_patterns(MatrixPattern a, MatrixPattern b) { return ((a | b) & 0xffffull) | (a & b & ~0xffffull); }
+// does a matrix with these elements have (at least) what `assumed` says?
+inline bool pattern_holds(MatrixPattern assumed, const float elements[16]) {
+    const MatrixPattern now = matrix_pattern(elements);
+    return ((now & 0xffffull) & ~assumed) == 0 && ((assumed & ~0xffffull) & ~now) == 0;
+}
+
 // What the zero-pattern probing of generate_kernel_source found last time, and for which scene state (KernelOptions::mask_cache): a renderer
 // with baked Bool / Int uniforms regenerates its source on every scene-version bump -- every camera move -- and the probing (two scene
 // copies, up to 33 Scene::update + 34 evaluations) is by far the most expensive part of a generation that nearly always ends in "unchanged".
 struct ZeroMaskCache {
     std::string key;  // stage, clip, and every uniform's name with its value (animated ones: the name only -- their patterns come from the probes)
-    std::vector<std::pair<std::string, unsigned>> masked;
+    std::vector<std::pair<std::string, MatrixPattern>> masked;
     int hits = 0, misses = 0;
 };
 
@@ -158,7 +171,7 @@ struct GeneratedKernel {
     bool looped_snippets = false;       // an intersection-material snippet has a force-unrolled loop (define PTL_JIT_MODULE_INLINER: kernel.cpp compiles it with the module inliner)
     int hoisted_members = 0;            // ... plus this many members holding uniform-only work of the scene snippets (glsl_hoist.h)
     std::vector<DerivedPlane> derived;  // members appended to the block behind uniform_block_size, written on the device
-    std::vector<std::pair<std::string, unsigned>> masked;  // run-time matrices whose zero pattern is compiled in: bit 4 * column + row set = may be non-zero
+    std::vector<std::pair<std::string, MatrixPattern>> masked;  // run-time matrices whose pattern is compiled in (MatrixPattern)
     int bounded_snippet_blocks = 0;     // `nearer` blocks of intersection-material snippets that take the caller's distance bound (define PTL_BOUNDED_SNIPPETS)
     bool full_chains = false;           // a matrix of the scene is not finite (or KernelOptions::full_chains): no product was shortened
 };

@@ -153,7 +153,7 @@ def test_zero_patterns_compiled_into_clip_kernels_hold_through_every_corpus_clip
     ~3 900 masked matrices), at 13 other moments, never leaves the patterns its kernel was generated with."""
     import re
 
-    clips = masked = 0
+    clips = masked = units = 0
     for path in animated_scene_files():
         ps = pa.Scene.from_file(path)
         for clip, duration in ps.animations():
@@ -161,15 +161,20 @@ def test_zero_patterns_compiled_into_clip_kernels_hold_through_every_corpus_clip
             ps.update(0.0)
             src = ps.generate_source(pa.FLAG_SPECIALIZE_STATIC)
             masks = {n: int(v, 16) for n, v in re.findall(r"#define PTL_MASK_(\w+) (0x[0-9a-f]{4})u", src)}
+            # ... and the elements compiled in as +1 / -1 (round 4: PTL_UNIT_BITS(ones, negs) behind the zero pattern)
+            unit = {n: (int(a, 16), int(b, 16)) for n, a, b in re.findall(r"#define PTL_MASK_(\w+) 0x[0-9a-f]{4}u \| PTL_UNIT_BITS\((0x[0-9a-f]{4}), (0x[0-9a-f]{4})\)", src)}
             clips += 1
             masked += len(masks)
+            units += sum(bin(a).count("1") + bin(b).count("1") for a, b in unit.values())
             for k in range(13):
                 ps.update(duration * (k + 0.37) / 13.0)
                 vals = ps.uniform_values()
                 for name, mask in masks.items():
                     a = np.asarray(vals[name], np.float32).T.reshape(-1)  # column-major like the uniform block: bit 4 * column + row
                     assert not any(a[e] != 0 and not (mask >> e) & 1 for e in range(16)), (os.path.basename(path), clip, name, k)
-    assert clips > 400 and masked > 3000
+                    ones, negs = unit.get(name, (0, 0))
+                    assert not any(((ones >> e) & 1 and a[e] != 1) or ((negs >> e) & 1 and a[e] != -1) for e in range(16)), (os.path.basename(path), clip, name, k)
+    assert clips > 400 and masked > 3000 and units > 3000
 
 
 @pytest.mark.parametrize("path", scene_files(), ids=[os.path.basename(f)[:-4] for f in scene_files()])

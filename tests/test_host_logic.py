@@ -1705,3 +1705,35 @@ def test_a_kernel_just_above_128_registers_is_rebuilt_under_the_four_wave_cap(pa
     # a kernel far above the cap keeps its registers: the capped build would spill (the un-specialised kernel of the same scene)
     big = pa.SceneRenderer(scene, device=-1, flags=0).code_object()
     assert _note_max(big, b".vgpr_spill_count") == 0 and _note_max(big, b".private_segment_fixed_size") == 0
+
+
+def test_unit_elements_of_runtime_matrices_are_part_of_the_compiled_pattern(pa):
+    """Round 4: the pattern of a matrix that stays a run-time value also names its elements that are exactly +1 or -1 (PTL_UNIT_BITS behind the
+    zero mask): the term of such an element is `x + acc` / `acc - x` -- the same operation with the value known, what a fully baked build gets
+    from constant folding.  The portal matrices of the headline scene are pure translations: every diagonal element is a known 1."""
+    import re
+
+    scene = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    src = scene.generate_source(pa.FLAG_SPECIALIZE_INTS)
+    vals = scene.uniform_values()
+    found = re.findall(r"#define PTL_MASK_(\w+) (0x[0-9a-f]{4})u(?: \| PTL_UNIT_BITS\((0x[0-9a-f]{4}), (0x[0-9a-f]{4})\))?", src)
+    assert len(found) > 40
+    with_units = 0
+    for name, zero, ones, negs in found:
+        a = np.asarray(vals[name], np.float32).T.reshape(-1)  # column-major: element 4 * column + row
+        zero, ones, negs = int(zero, 16), int(ones or "0", 16), int(negs or "0", 16)
+        for e in range(16):
+            assert (a[e] != 0) <= bool((zero >> e) & 1), (name, e)
+            assert bool((ones >> e) & 1) == (a[e] == 1.0) and bool((negs >> e) & 1) == (a[e] == -1.0), (name, e, a[e])  # (nothing animates here: the pattern IS the current state)
+        with_units += bool(ones | negs)
+    assert with_units > 40
+    masks = {n: (int(o or "0", 16), int(g or "0", 16)) for n, _, o, g in found}
+    assert masks["a_mat"] == (0x8421, 0x4000) and masks["b0_mat"] == (0xC421, 0x0000)  # translations by -1 and +1 along z
+    # a scene state in which the portal is turned: the rotation block is no longer made of ones and zeros
+    moved = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    assert moved.set_uniform("progress", 0.3)
+    later = dict((n, (z, o, g)) for n, z, o, g in re.findall(r"#define PTL_MASK_(\w+) (0x[0-9a-f]{4})u(?: \| PTL_UNIT_BITS\((0x[0-9a-f]{4}), (0x[0-9a-f]{4})\))?", moved.generate_source(pa.FLAG_SPECIALIZE_INTS)))
+    assert any(later.get(n, ("0xffff", "", ""))[1:] != (o, g) for n, _, o, g in found)
+    # contract 1 and the tolerance mode never get patterns
+    for flags in (pa.FLAG_SPECIALIZE_INTS | pa.FLAG_EXACT_CR, pa.FLAG_SPECIALIZE_INTS | pa.FLAG_FAST_MATH):
+        assert "PTL_UNIT_BITS(0x" not in scene.generate_source(flags)
