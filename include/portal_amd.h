@@ -260,7 +260,9 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * bit19 = NO ZERO MASKS: by default a build with bit0, bit2 or bit3 compiles in the ZERO PATTERN of every matrix uniform that stays a
  * run-time value (only Bool / Int baked; animated within the clip -- its pattern then taken over probes of the clip's `time`; demoted):
  * `transform(X_mat, ..)` of the scene snippets and the generated plane tests skip the terms whose element is zero, as a baked matrix's do
- * (same results for finite operands); a renderer rebuilds when a masked element stops being zero.  This bit keeps the full products (A/B),
+ * (same results for finite operands); a renderer rebuilds when a masked element stops being zero.  Since round 4 the pattern also names the
+ * elements that are exactly +1 or -1 (their terms become `x + acc` / `acc - x`: the same operation, no bit moves), with the same rebuild rule.
+ * This bit keeps the full products (A/B),
  * bit20 = SPECIALIZE PATTERNS: no VALUE of the scene is compiled in, only what survives while the values move -- the zero patterns of the
  * matrix uniforms (as with bit19 clear) and, in a renderer, its mode switches.  The kernel for scenes whose uniforms move every frame (the
  * reference uploads them every frame and never recompiles, src/main.rs:1266-1359): a renderer rebuilds only when a matrix element stops
