@@ -83,3 +83,39 @@ def test_random_scenes_product_equals_oracle(pa, tmp_path, seed):
     same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
     assert same.all(), f"seed {seed}: {int((~same).any(axis=2).sum())} of {w * h} pixels differ"
     assert got["segments"] == int(want["segments"].sum())
+
+
+@pytest.mark.parametrize("seed", range(100, 112))
+@pytest.mark.parametrize("build", ["ints", "patterns", "baked"])
+def test_random_scenes_through_the_specialised_builds_equal_the_oracle(pa, tmp_path, seed, build):
+    """The same fuzz through the builds that shorten matrix products: Bool / Int baked and patterns-only (zero pattern and +-1 elements of the
+    run-time matrices compiled in: device/ptl_glsl.h `ptl_row_m`, PTL_UNIT_BITS) and everything baked (literal matrices: `ptl_mterm`).  Random
+    Simple matrices with mirrors and quarter-ish turns give every kind of pattern; the numpy oracle evaluates the full chains."""
+    from oracle import host_build as hb
+    from oracle.portal_oracle import Oracle
+
+    flags = {"ints": pa.FLAG_SPECIALIZE_INTS, "patterns": pa.FLAG_SPECIALIZE_PATTERNS, "baked": pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL}[build]
+    text, cam, in_subspace = random_scene(seed)
+    if seed % 3 == 0:  # axis-aligned copies of the scene's matrices: zeros and units everywhere
+        import re
+
+        text = re.sub(r"rotate: \(-?[0-9.]+, -?[0-9.]+, -?[0-9.]+\)", lambda m: "rotate: (%s, %s, %s)" % tuple(random.Random(seed + m.start()).choice(["0.", "1.5707963267948966", "3.141592653589793"]) for _ in range(3)), text)
+        text = re.sub(r"scale: [0-9]+\.[0-9]+", "scale: 1.", text)
+    path = tmp_path / "random.ron"
+    path.write_text(text)
+    w, h = 32, 20
+    scene = pa.Scene.from_file(str(path))
+    r = pa.SceneRenderer(scene, device=-1, flags=flags)
+    r.set_option("render_depth", 8)
+    r.set_option("in_subspace", 1 if in_subspace else 0)
+    r.set_camera(cam["look_at"], cam["alpha"], cam["beta"], cam["r"])
+    r.uniform_value("_ray_tracing_depth", w, h)  # (evaluates the state the kernel source belongs to)
+    hk = hb.host_kernel_for(r, scene, w, h, flags=flags)
+    got = hk.render(w, h)
+    o = Oracle(str(path))
+    o.options["render_depth"] = 8
+    o.camera = dict(cam, in_subspace=in_subspace)
+    want = o.render(w, h)
+    a, b = got["rgba32f"], want["rgba32f"]
+    same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), f"seed {seed} {build}: {int((~same).any(axis=2).sum())} of {w * h} pixels differ"
