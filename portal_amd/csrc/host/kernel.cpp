@@ -359,9 +359,32 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
             std::vector<std::string> capped = opts;
             capped.push_back("-DPTL_WAVES_PER_EU=4");
             std::vector<char> second;
+            bool settled = false;
             if (run_hiprtc(capped, second, false) == PTL_OK && code_object_note_max(second, ".vgpr_spill_count") == 0 &&
-                code_object_note_max(second, ".private_segment_fixed_size") <= code_object_note_max(k->code, ".private_segment_fixed_size"))
+                code_object_note_max(second, ".private_segment_fixed_size") <= code_object_note_max(k->code, ".private_segment_fixed_size")) {
                 k->code.swap(second);
+                settled = true;
+            }
+            // ... and if the cap only produces spills while this build came from the module inliner -- whose schedule needs ~10 registers
+            // more than the bottom-up pipeline's (portal_in_portal_plus_ultra with its Ints baked: 139 against 128) -- the toolchain's own
+            // pipeline gets a try under the same cap: kept when it fits four waves without spilling.  Three hiprtc runs for such a kernel, once (the code
+            // object is cached under the key of the options the caller asked for).
+            if (!settled) {
+                std::vector<std::string> bottom_up;
+                for (size_t i = 0; i < opts.size(); ++i) {
+                    if (opts[i] == "-mllvm" && i + 1 < opts.size() && opts[i + 1] == "-enable-module-inliner") {
+                        ++i;
+                        continue;
+                    }
+                    bottom_up.push_back(opts[i]);
+                }
+                bottom_up.push_back("-DPTL_WAVES_PER_EU=4");
+                std::vector<char> third;
+                if (bottom_up.size() < opts.size() && run_hiprtc(bottom_up, third, false) == PTL_OK && code_object_note_max(third, ".vgpr_count") <= 128 &&
+                    code_object_note_max(third, ".vgpr_spill_count") == 0 &&
+                    code_object_note_max(third, ".private_segment_fixed_size") <= code_object_note_max(k->code, ".private_segment_fixed_size"))
+                    k->code.swap(third);
+            }
         }
         if (!cache_path.empty()) {
             ::mkdir(cdir.c_str(), 0755);

@@ -1737,3 +1737,23 @@ def test_unit_elements_of_runtime_matrices_are_part_of_the_compiled_pattern(pa):
     # contract 1 and the tolerance mode never get patterns
     for flags in (pa.FLAG_SPECIALIZE_INTS | pa.FLAG_EXACT_CR, pa.FLAG_SPECIALIZE_INTS | pa.FLAG_FAST_MATH):
         assert "PTL_UNIT_BITS(0x" not in scene.generate_source(flags)
+
+
+def test_a_module_inliner_build_that_cannot_be_capped_falls_back_to_the_bottom_up_pipeline(pa, tmp_path, monkeypatch):
+    """The module inliner's schedule needs ~10 VGPRs more than the bottom-up pipeline's.  Where that costs the fourth wave per SIMD and the cap
+    alone only produces spills (portal_in_portal_plus_ultra with its Ints baked: 139 registers, 128 under the toolchain's own pipeline), the JIT
+    builds the kernel the old way under the same cap and keeps that (kernel.cpp)."""
+    import os
+
+    path = os.path.join(os.path.dirname(__file__), "corpus", "scenes", "portal_in_portal_plus_ultra.ron")
+    scene = pa.Scene.from_file(path)
+    monkeypatch.setenv("PTL_JIT_OPT", "-O3")
+    monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path / "a"))
+    monkeypatch.setenv("PTL_NO_OCCUPANCY_RETRY", "1")
+    first = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_SPECIALIZE_INTS, asset_root=os.path.join(os.path.dirname(__file__), "corpus")).code_object()
+    if not 128 < _note_max(first, b".vgpr_count") <= 168:
+        pytest.skip("this toolchain builds the case outside the band the retry looks at")
+    monkeypatch.delenv("PTL_NO_OCCUPANCY_RETRY")
+    monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path / "b"))
+    kept = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_SPECIALIZE_INTS, asset_root=os.path.join(os.path.dirname(__file__), "corpus")).code_object()
+    assert _note_max(kept, b".vgpr_count") <= 128 and _note_max(kept, b".vgpr_spill_count") == 0 and _note_max(kept, b".private_segment_fixed_size") == 0
