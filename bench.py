@@ -441,16 +441,38 @@ def main():
 
     import portal_amd as pa
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the render path has no CPU fallback)")
     # PTL_BENCH_BACKEND=gloo is a rehearsal hook: the multi-rank control flow on a box with ONE GPU (all ranks share it, the
     # gather is staged through host memory).  The driver's runs use the default: one rank per GPU, RCCL.
     backend = os.environ.get("PTL_BENCH_BACKEND", "nccl")
+    if args.gpus < 1:
+        raise SystemExit(f"--gpus {args.gpus}: at least one GPU")
+    launched = "RANK" in os.environ or "WORLD_SIZE" in os.environ
+    if backend == "nccl" and not launched and args.gpus > (torch.cuda.device_count() if torch.cuda.is_available() else 0):
+        # one rank per GPU over RCCL: never a line that says n_gpus: N for fewer devices, never a silent n_gpus: 1
+        raise SystemExit(f"--gpus {args.gpus} but this node shows {torch.cuda.device_count() if torch.cuda.is_available() else 0} GPU(s) "
+                         "(PTL_BENCH_BACKEND=gloo rehearses N ranks on fewer devices)")
+    if args.gpus > 1 and not launched:
+        # started as plain `python bench.py --gpus N`: launch the N ranks ourselves, exactly as the driver's torch.distributed.run line would
+        import socket
+        import subprocess
+
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks under torch.distributed.run (port {port})", file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the render path has no CPU fallback)")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the run")
+    narrowed = any(os.environ.get(k) for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))  # a launcher that shows each rank its own GPU
+    if backend == "nccl" and world > torch.cuda.device_count() and not narrowed:
+        raise SystemExit(f"--gpus {world} over RCCL needs one GPU per rank; this node shows {torch.cuda.device_count()}")
     # one rank per GPU: LOCAL_RANK is the device index when every rank sees the whole node (torchrun's default); when the launcher
     # narrows visibility to one GPU per process, or the gloo rehearsal shares one GPU, the modulo picks what is there
     local_rank = local_rank % torch.cuda.device_count()

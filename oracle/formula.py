@@ -156,6 +156,14 @@ def _fdiv(a, b):
         return math.copysign(math.inf, a) * math.copysign(1.0, b)
 
 
+def _fmod(a, b):
+    """C fmod() / Rust's f64 `%`: NaN for an infinite dividend or a zero divisor, where Python raises."""
+    try:
+        return math.fmod(a, b)
+    except ValueError:
+        return float("nan")
+
+
 def _ln(x, fn=math.log):
     if x != x or x < 0:
         return float("nan")
@@ -292,7 +300,7 @@ def _compile_slice(first, pairs):
     if op_txt == "%":
         acc = nodes[0]
         for n in nodes[1:]:
-            acc = ("const", math.fmod(acc[1], n[1])) if _is_const(acc) and _is_const(n) and n[1] != 0 else ("mod", acc, n)
+            acc = ("const", _fmod(acc[1], n[1])) if _is_const(acc) and _is_const(n) and n[1] != 0 else ("mod", acc, n)
         return acc
     acc = nodes[-1]  # ^ : right to left
     for n in reversed(nodes[:-1]):
@@ -346,7 +354,7 @@ def evaluate(node, ns):
         if k == "mul":
             return a * b
         if k == "mod":
-            return math.fmod(a, b) if b != 0 and math.isfinite(a) else float("nan")
+            return _fmod(a, b)
         return _pow(a, b)
     if k == "cmp":
         a, b = evaluate(node[2], ns), evaluate(node[3], ns)

@@ -155,3 +155,33 @@ def _transport_worker(rank, world, port):
 @pytest.mark.skipif(torch.cuda.is_available(), reason="the no-device failure path")
 def test_transports_on_cpu_ranks_fail_together_and_gather():
     mp.spawn(_transport_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_bench_gpus_n_launches_its_own_ranks_and_never_degrades_to_one():
+    """`python bench.py --gpus N` started WITHOUT torch.distributed.run (how the driver starts `--gpus 1`): bench.py starts the N ranks itself.
+    Here (no GPU) every rank must then refuse loudly; what may never happen is a silent one-rank run that prints n_gpus: 1.
+    Over RCCL (the default backend) N > visible GPUs is refused before anything starts."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, env=dict(env, PTL_BENCH_BACKEND="gloo"))
+    import torch
+
+    if not torch.cuda.is_available():
+        assert run.returncode != 0
+        assert "starting 3 ranks under torch.distributed.run" in run.stderr
+        assert run.stderr.count("bench.py needs a GPU") >= 1 and '"n_gpus"' not in run.stdout
+    else:  # on a GPU box the same command line is the rehearsal itself
+        import json
+
+        assert run.returncode == 0, run.stderr[-2000:]
+        assert json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 3
+    many = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300, env=dict(env, PTL_BENCH_BACKEND="nccl"))
+    assert many.returncode != 0 and "--gpus 64 but this node shows" in many.stderr and '"n_gpus"' not in many.stdout
+    # a launcher whose WORLD_SIZE disagrees with --gpus (including WORLD_SIZE=1 for --gpus 8) is refused too
+    odd = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300,
+                         env=dict(env, PTL_BENCH_BACKEND="gloo", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert odd.returncode != 0 and '"n_gpus"' not in odd.stdout

@@ -871,9 +871,15 @@ def test_bench_multi_rank_rehearsal_of_the_headline_line(gpu, tmp_path):
 
     pa = gpu
     env = dict(os.environ, PTL_BENCH_BACKEND="gloo")
-    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", "29519",
-                          os.path.join(pa.REPO_ROOT, "bench.py"), "--gpus", "3", "--steps", "6", "--warmup", "2"], capture_output=True, text=True, timeout=1200, env=env)
+    # started the way the driver starts `--gpus 1`: plain python, no launcher -- bench.py starts its three ranks itself
+    env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    run = subprocess.run([sys.executable, os.path.join(pa.REPO_ROOT, "bench.py"), "--gpus", "3", "--steps", "6", "--warmup", "2"], capture_output=True, text=True, timeout=1200, env=env)
     assert run.returncode == 0, run.stderr[-2000:]
+    assert "starting 3 ranks under torch.distributed.run" in run.stderr
+    # ... and over RCCL, more ranks than this box has GPUs is refused loudly: never a line with the wrong n_gpus
+    refused = subprocess.run([sys.executable, os.path.join(pa.REPO_ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300,
+                             env={k: v for k, v in env.items() if k != "PTL_BENCH_BACKEND"})
+    assert refused.returncode != 0 and "--gpus 64 but this node shows" in refused.stderr and '"n_gpus"' not in refused.stdout
     line = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
     cfg = line["config"]
     assert line["n_gpus"] == 3 and line["value"] > 0 and "portal_in_portal.ron 3840x2160" in cfg["workload"]

@@ -3,6 +3,7 @@ and raw strings, comments, arbitrary whitespace) are read by the product's reade
 (portal_amd/csrc/host/ron.cpp through ptl_ron_format); the result must mean the same to the oracle's independent reader
 (oracle/ron.py), and writing must be idempotent."""
 import math
+import os
 
 import pytest
 
@@ -53,7 +54,8 @@ def same(a, b):
     return a == b
 
 
-@settings(max_examples=800, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much])
+@settings(max_examples=800, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much],
+          derandomize=not os.environ.get("PTL_FUZZ_RANDOM"), database=None)  # deterministic in the suite; PTL_FUZZ_RANDOM=1 hunts
 @given(text=documents())
 def test_product_ron_writer_preserves_what_the_oracle_reads(pa, text):
     from oracle import ron
