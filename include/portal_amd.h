@@ -84,6 +84,11 @@ int ptl_kernel_copy_uniforms(ptl_kernel* dst, const ptl_kernel* src);
 /* The compiled gfx950 code object (valid until ptl_kernel_destroy). */
 int ptl_kernel_code_object(ptl_kernel* k, const void** data, size_t* size);
 
+/* Kernel metadata of a gfx950 code object (ptl_kernel_code_object, or a file of the code-object cache) without a device: the largest value of
+ * `key` (".vgpr_count", ".vgpr_spill_count", ".private_segment_fixed_size", ".sgpr_count") over the kernels whose name starts with
+ * `kernel_prefix` (NULL or "": every kernel of the module); -1 when the key does not occur.  The JIT's occupancy retry decides on the render
+ * entries alone ("ptl_render"): the one-wave teleport and prologue entries of a one-module build say nothing about the render kernel. */
+int ptl_code_object_note(const void* code, size_t size, const char* key, const char* kernel_prefix);
 /* Per-lane resources of the loaded render kernel (hipFuncGetAttribute): vector registers, scratch
  * (private segment) bytes -- non-zero means register spills that travel through the memory hierarchy --
  * and static LDS bytes per workgroup.  -1 where the runtime cannot tell. */
@@ -133,9 +138,17 @@ int ptl_kernel_render_to_host(ptl_kernel* k, const ptl_frame* frame, uint8_t* ho
 int ptl_kernel_max_slices(ptl_kernel* k);
 int ptl_kernel_stage_slice(ptl_kernel* k, int index);
 /* ... or a block saved earlier (ptl_kernel_snapshot_uniforms: the host copy of the uniform block, ptl_kernel_uniform_block_size bytes), also one
- * saved from ANOTHER kernel of the same scene -- every build of a scene has the same block layout, so a renderer that had to rebuild its
- * kernel between staging and launching re-stages its snapshots into the new kernel.  Sampler records are taken from `k` itself. */
+ * saved from ANOTHER kernel of the same scene -- every build of a scene has the same block layout.  A sampler record that names a texel buffer
+ * of `k` itself (bound now, or bound when the block was taken) is kept; any other record is replaced by `k`'s current one.
+ * Textures and slices: a staged slice names the texel buffers that were bound when it was staged.  Re-binding a sampler
+ * (ptl_kernel_set_texture: a video texture stepping to its next frame) between two stage calls does NOT free the buffer the earlier slice
+ * reads: it is retired and freed behind the launch.  A caller that keeps snapshots instead of staging at once brackets them with
+ * ptl_kernel_hold_textures(k, 1) ... (k, 0) for the same guarantee.
+ * A block is only meaningful for a kernel whose compiled-in values agree with it: a value-baked build (flag bits 0 / 2 / 3 / 20) that had to
+ * be rebuilt between two stage calls must not trace the earlier blocks -- layer 2 (ptl_renderer_stage_slice / _draw_slices) launches each
+ * slice on the kernel it was staged with; a layer-1 caller that rebuilds has to do the same. */
 int ptl_kernel_stage_slice_from(ptl_kernel* k, int index, const void* block, size_t size);
+int ptl_kernel_hold_textures(ptl_kernel* k, int hold);
 size_t ptl_kernel_uniform_block_size(ptl_kernel* k);
 int ptl_kernel_snapshot_uniforms(ptl_kernel* k, void* dst, size_t cap);
 int ptl_kernel_render_slices(ptl_kernel* k, const ptl_frame* frame, int n, void* out_rgba8, void* out_rgba32f, unsigned long long slice_pixels,
@@ -337,9 +350,11 @@ int ptl_renderer_join(ptl_renderer* r, void* stream);
 /* One launch for several draws of a renderer created with flag bit 22 (PTL_FLAG_SLICES): ptl_renderer_stage_slice does everything a draw
  * does short of launching -- camera, rebuild checks, uniform evaluation for `frame` -- and keeps the resulting uniform block as slice `index`;
  * ptl_renderer_draw_slices launches slices 0 .. n-1 at once (ptl_kernel_render_slices).  Between two stage calls: ptl_renderer_update,
- * ptl_renderer_set_option("aa_start", j), camera moves ... as between two draws.  The slices are kept as snapshots of the uniform block, so a
- * kernel rebuilt between two stage calls (a clip-constant build whose value moved) does not lose them.  draw_slices without slices
- * 0 .. n-1 staged since the last launch is PTL_ERR_INVALID. */
+ * ptl_renderer_set_option("aa_start", j), camera moves ... as between two draws.  A slice is a snapshot of the uniform block TOGETHER WITH the
+ * kernel it was staged with: when the kernel is rebuilt between two stage calls (a value-baked build whose value moved, a mode switch, an
+ * adopted background build) the earlier slices are still traced by the earlier kernel -- draw_slices then issues one launch per run of
+ * slices that share a kernel, same frames as draws one by one -- and the texel buffers a slice names (a video texture that steps between
+ * two sub-frames) live until its launch.  draw_slices without slices 0 .. n-1 staged since the last launch is PTL_ERR_INVALID. */
 int ptl_renderer_stage_slice(ptl_renderer* r, const ptl_frame* frame, int index);
 int ptl_renderer_draw_slices(ptl_renderer* r, const ptl_frame* frame, int n, void* out_rgba8, void* out_rgba32f, unsigned long long slice_pixels,
                              void* stream, float* elapsed_ms);

@@ -150,6 +150,8 @@ def _load() -> C.CDLL:
         "ptl_renderer_draw_slices": (ci, [vp, P(Frame), ci, vp, vp, C.c_ulonglong, vp, P(C.c_float)]),
         "ptl_kernel_max_slices": (ci, [vp]),
         "ptl_kernel_stage_slice": (ci, [vp, ci]),
+        "ptl_kernel_hold_textures": (ci, [vp, ci]),
+        "ptl_code_object_note": (ci, [vp, cs, cp, cp]),
         "ptl_kernel_render_slices": (ci, [vp, P(Frame), ci, vp, vp, C.c_ulonglong, vp, P(C.c_float)]),
         "ptl_kernel_clone": (ci, [vp, P(vp)]),
         "ptl_kernel_copy_uniforms": (ci, [vp, vp]),
@@ -567,6 +569,18 @@ class SceneRenderer:
         _check(lib().ptl_kernel_code_object(k, C.byref(data), C.byref(size)), "code_object")
         return C.string_at(data, size.value)
 
+    def code_object_sha256(self) -> str:
+        """sha256 of the loaded gfx950 code object: what ties a bench line to the PMC passes of the same binary."""
+        import hashlib
+
+        return hashlib.sha256(self.code_object()).hexdigest()
+
+    def code_object_note(self, key: str, kernel_prefix: str = "ptl_render") -> int:
+        """Kernel metadata of the loaded code object (".vgpr_count", ".vgpr_spill_count", ".private_segment_fixed_size", ".sgpr_count"):
+        the largest value over the kernels whose name starts with ``kernel_prefix`` ("" = all)."""
+        code = self.code_object()
+        return lib().ptl_code_object_note(code, len(code), key.encode(), kernel_prefix.encode())
+
     # -- drawing ---------------------------------------------------------------------------
     def draw_device(self, frame: Frame, out_rgba8: int = 0, out_rgba32f: int = 0, segments: int = 0, stream: int = 0, timed: bool = False):
         """draw_texture into DEVICE buffers given as integer addresses (e.g. torch data_ptr()).
@@ -799,6 +813,8 @@ def bound_glsl(body: str, out_functions=()):
     """(text, n): an intersection-material snippet with the caller's distance bound in the `nearer` blocks it recognises (n of them)."""
     n = C.c_int()
     p = lib().ptl_bound_glsl(body.encode("utf-8"), ",".join(out_functions).encode(), C.byref(n))
+    if not p:
+        raise PortalError(lib().ptl_last_error().decode())
     try:
         return C.string_at(p).decode("utf-8"), n.value
     finally:

@@ -167,6 +167,11 @@ struct ptl_renderer {
     };
     std::vector<std::vector<unsigned char>> staged_blocks;  // ptl_renderer_stage_slice: snapshots of the uniform block, one per slice ...
     unsigned staged_mask = 0;                               // ... and which of them are staged since the last launch
+    // A slice is traced by the kernel it was staged with: a rebuild between two stage calls (a value-baked build whose value moved, a mode
+    // switch, an adopted background build) compiles ANOTHER state in, and the earlier blocks are only right for the earlier kernel.
+    // A kernel that is replaced while staged slices name it is parked here (with its texel buffers) until those slices are launched.
+    std::vector<ptl_kernel*> staged_kernels;
+    std::vector<ptl_kernel*> parked_kernels;
     int concurrent = 1;
     std::vector<Lane> lanes;
     ptl_kernel* lanes_of = nullptr;  // the kernel the clones were made from
@@ -721,6 +726,27 @@ static int join_lanes(ptl_renderer* r, void* stream) {  // GPU-side: `stream` co
     return PTL_OK;
 }
 
+// The renderer lets go of kernel `k` (replaced by a rebuild): destroyed, unless a staged slice still has to be traced by it.
+static void retire_kernel(ptl_renderer* r, ptl_kernel* k) {
+    if (!k) return;
+    bool named = false;
+    for (size_t j = 0; j < r->staged_kernels.size(); ++j) named = named || ((r->staged_mask >> j & 1u) && r->staged_kernels[j] == k);
+    if (named)
+        r->parked_kernels.push_back(k);
+    else
+        ptl_kernel_destroy(k);
+}
+static void drop_staged_slices(ptl_renderer* r) {  // forget what was staged (after the launch; when the builds are torn down)
+    for (size_t j = 0; j < r->staged_kernels.size(); ++j)
+        if ((r->staged_mask >> j & 1u) && r->staged_kernels[j]) {
+            bool parked = std::find(r->parked_kernels.begin(), r->parked_kernels.end(), r->staged_kernels[j]) != r->parked_kernels.end();
+            if (!parked) ptl_kernel_hold_textures(r->staged_kernels[j], 0);
+        }
+    r->staged_mask = 0;
+    for (ptl_kernel* k : r->parked_kernels) ptl_kernel_destroy(k);
+    r->parked_kernels.clear();
+}
+
 static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     ptl_scene* s = r->owner;
     if (!(r->kernel_stage == r->scene->current_stage)) r->keep_dynamic.clear();  // another stage / clip: judge afresh what is constant
@@ -764,7 +790,7 @@ static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     }
     if (r->lanes_of == r->kernel) drop_lane_clones(r);
     wait_for_lanes(r);
-    ptl_kernel_destroy(r->kernel);
+    retire_kernel(r, r->kernel);
     r->kernel = k;
     r->kernel_source = s->last.source;
     r->kernel_scene_version = r->scene->version;
@@ -784,6 +810,7 @@ static void drop_async_kernels(ptl_renderer* r) {
     }
     if (r->spec_kernel || r->dyn_kernel) {
         drop_lane_clones(r);
+        drop_staged_slices(r);  // (a switch of the specialisation bits between stage calls: what was staged is gone with its kernels)
         ptl_kernel_destroy(r->spec_kernel);
         ptl_kernel_destroy(r->dyn_kernel);
         r->spec_kernel = r->dyn_kernel = r->kernel = nullptr;
@@ -1065,7 +1092,7 @@ static int async_select_kernel(ptl_renderer* r) {
                 ++r->rejit_count;
                 rc = activate_kernel(r, k);
                 if (r->lanes_of == old) drop_lane_clones(r);
-                ptl_kernel_destroy(old);  // (never the active one: `k` has just been activated)
+                retire_kernel(r, old);  // (never the active one: `k` has just been activated; parked while a staged slice names it)
                 return rc;
             }
             r->failed_source = job->build.source;
@@ -1208,11 +1235,20 @@ extern "C" int ptl_renderer_stage_slice(ptl_renderer* r, const ptl_frame* frame,
         // kept as a snapshot of the kernel's host copy of the uniform block: the block layout is the scene's, not the build's, so the
         // snapshot outlives a rebuild of the kernel between two stage calls (a clip-constant build whose compiled-in value moved)
         if (r->staged_blocks.size() < 16) r->staged_blocks.resize(16);
+        if (r->staged_kernels.size() < 16) r->staged_kernels.resize(16, nullptr);
         std::vector<unsigned char>& b = r->staged_blocks[index];
         b.resize(ptl_kernel_uniform_block_size(r->kernel));
         rc = ptl_kernel_snapshot_uniforms(r->kernel, b.data(), b.size());
-        if (rc == PTL_OK) r->staged_mask |= 1u << index;
-        return rc;
+        if (rc != PTL_OK) return rc;
+        if ((r->staged_mask >> index & 1u) && r->staged_kernels[index]) {  // staged twice: the earlier one is dropped
+            bool parked = std::find(r->parked_kernels.begin(), r->parked_kernels.end(), r->staged_kernels[index]) != r->parked_kernels.end();
+            if (!parked) ptl_kernel_hold_textures(r->staged_kernels[index], 0);
+        }
+        // the block names the texel buffers bound NOW (a video texture may step before the next stage call): they stay until the launch
+        ptl_kernel_hold_textures(r->kernel, 1);
+        r->staged_kernels[index] = r->kernel;
+        r->staged_mask |= 1u << index;
+        return (int)PTL_OK;
     });
 }
 extern "C" int ptl_renderer_draw_slices(ptl_renderer* r, const ptl_frame* frame, int n, void* out_rgba8, void* out_rgba32f, unsigned long long slice_pixels,
@@ -1224,11 +1260,25 @@ extern "C" int ptl_renderer_draw_slices(ptl_renderer* r, const ptl_frame* frame,
             set_last_error("ptl_renderer_draw_slices: slices 0 .. n-1 are not all staged (ptl_renderer_stage_slice) since the last launch");
             return (int)PTL_ERR_INVALID;
         }
-        for (int j = 0; j < n; ++j)
-            if (int rc = ptl_kernel_stage_slice_from(r->kernel, j, r->staged_blocks[j].data(), r->staged_blocks[j].size()); rc != PTL_OK) return rc;
         if (int jrc = join_lanes(r, stream); jrc != PTL_OK) return jrc;
-        int rc = ptl_kernel_render_slices(r->kernel, frame, n, out_rgba8, out_rgba32f, slice_pixels, stream, elapsed_ms);
-        r->staged_mask = 0;
+        // runs of consecutive slices staged with the same kernel go out as one launch each, on the kernel they were staged with -- one launch
+        // for all n unless a rebuild fell between two stage calls (then the earlier slices keep the state THEIR kernel has compiled in)
+        int rc = PTL_OK;
+        float total_ms = 0.0f;
+        for (int j0 = 0; j0 < n && rc == PTL_OK;) {
+            ptl_kernel* k = r->staged_kernels[j0];
+            int j1 = j0 + 1;
+            while (j1 < n && r->staged_kernels[j1] == k) ++j1;
+            for (int j = j0; j < j1 && rc == PTL_OK; ++j) rc = ptl_kernel_stage_slice_from(k, j - j0, r->staged_blocks[j].data(), r->staged_blocks[j].size());
+            float ms = 0.0f;
+            void* out8 = out_rgba8 ? static_cast<unsigned char*>(out_rgba8) + (size_t)j0 * slice_pixels * 4 : nullptr;
+            void* out32 = out_rgba32f ? static_cast<float*>(out_rgba32f) + (size_t)j0 * slice_pixels * 4 : nullptr;
+            if (rc == PTL_OK) rc = ptl_kernel_render_slices(k, frame, j1 - j0, out8, out32, slice_pixels, stream, elapsed_ms ? &ms : nullptr);
+            total_ms += ms;
+            j0 = j1;
+        }
+        if (elapsed_ms) *elapsed_ms = total_ms;
+        drop_staged_slices(r);
         return rc;
     });
 }
@@ -1543,6 +1593,7 @@ extern "C" void ptl_renderer_destroy(ptl_renderer* r) {
     if (!r) return;
     if (r->job && r->job->worker.joinable()) r->job->worker.join();  // (the worker owns nothing of ours, but a thread must be joined)
     drop_lane_clones(r);
+    drop_staged_slices(r);
     for (auto& l : r->lanes) {
         if (l.stream) ptl_stream_destroy(l.stream);
         if (l.done) ptl_event_destroy(l.done);
@@ -1657,10 +1708,19 @@ extern "C" char* ptl_bound_glsl(const char* glsl_body, const char* out_functions
             cur += *c;
         }
     }
-    std::string out = bound_nearer_blocks(glsl_body, with_out, bounded);
-    char* p = (char*)std::malloc(out.size() + 1);
-    std::memcpy(p, out.c_str(), out.size() + 1);
-    return p;
+    try {
+        std::string out = bound_nearer_blocks(glsl_body, with_out, bounded);
+        char* p = (char*)std::malloc(out.size() + 1);
+        if (!p) {
+            set_last_error("ptl_bound_glsl: out of memory");
+            return nullptr;
+        }
+        std::memcpy(p, out.c_str(), out.size() + 1);
+        return p;
+    } catch (const std::exception& e) {  // malformed input (the tokenizer throws): an error, never an exception across the C boundary
+        set_last_error(std::string("ptl_bound_glsl: ") + e.what());
+        return nullptr;
+    }
 }
 
 extern "C" char* ptl_hoist_glsl(const char* glsl, const char* uniforms, const char* out_functions, int body_only, const char* params, char** prologue) {

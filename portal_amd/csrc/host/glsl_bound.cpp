@@ -167,6 +167,10 @@ std::string bound_nearer_blocks(const std::string& glsl_body, const std::set<std
         // ... nor through an `out` / `inout` argument: no function that has such parameters is called in a block
         for (size_t i = b.open + 1; i + 1 < b.close; ++i)
             if (s.any_ident(i) && s.is(i + 1, "(") && functions_with_out_params.count(s[i].text)) return glsl_body;
+        // ... nor through control flow: a block that leaves a loop or the function (`break`, `continue`, `return`, `discard`) changes which LATER
+        // candidates are reached at all, so skipping it could let a candidate through that the code as written never saw
+        for (size_t i = b.open + 1; i < b.close; ++i)
+            if (s.ident(i, "break") || s.ident(i, "continue") || s.ident(i, "return") || s.ident(i, "discard")) return glsl_body;
     }
 
     // (5) who reads R.material: the caller, and only when R.scene.material == CUSTOM_MATERIAL (src/frag.glsl:118-122).  A block that may leave

@@ -58,11 +58,34 @@ std::string opt_level(bool quick) {
 // The largest value a key of the code object's kernel metadata (msgpack in the AMDGPU note: ".vgpr_count", ".vgpr_spill_count",
 // ".private_segment_fixed_size" ...) takes over the kernels of the module; -1 when the key does not occur.  A scan for the key's bytes
 // followed by a msgpack unsigned integer -- enough for a decision about an occupancy hint, no msgpack reader.
-int code_object_note_max(const std::vector<char>& code, const char* key) {
+// `kernel_prefix`: only the kernels whose name starts with it (the render entries "ptl_render": a one-module build also holds the one-wave
+// teleport and prologue entries, whose registers say nothing about the render kernel's occupancy); when no kernel of the module has such a
+// name -- a hand-written layer-1 source -- every kernel counts.  A kernel's map lists its keys in alphabetical order, so the most recent
+// ".name" string in front of ".private_segment_fixed_size" / ".vgpr_count" / ".vgpr_spill_count" is the kernel's own (its arguments' names
+// sit inside ".args", ahead of it).
+int code_object_note_max(const std::vector<char>& code, const char* key, const char* kernel_prefix = nullptr) {
     const size_t n = std::strlen(key);
+    if (kernel_prefix && *kernel_prefix) {
+        const std::string prefix = kernel_prefix;
+        bool any = false;
+        for (size_t i = 0; i + 6 + prefix.size() < code.size() && !any; ++i)
+            if (std::memcmp(code.data() + i, "\xa5.name", 6) == 0) {
+                const unsigned char h = (unsigned char)code[i + 6];
+                const size_t at = (h & 0xe0) == 0xa0 ? i + 7 : (h == 0xd9 ? i + 8 : 0);
+                any = at != 0 && at + prefix.size() <= code.size() && std::memcmp(code.data() + at, prefix.data(), prefix.size()) == 0;
+            }
+        if (!any) kernel_prefix = nullptr;
+    }
     int best = -1;
+    bool wanted = !kernel_prefix;
     for (size_t i = 0; i + n + 1 < code.size(); ++i) {
-        if (std::memcmp(code.data() + i, key, n) != 0) continue;
+        if (kernel_prefix && i + 8 < code.size() && std::memcmp(code.data() + i, "\xa5.name", 6) == 0) {
+            const unsigned char h = (unsigned char)code[i + 6];
+            const size_t at = (h & 0xe0) == 0xa0 ? i + 7 : (h == 0xd9 ? i + 8 : 0);
+            const size_t len = std::strlen(kernel_prefix);
+            wanted = at != 0 && at + len <= code.size() && std::memcmp(code.data() + at, kernel_prefix, len) == 0;
+        }
+        if (!wanted || std::memcmp(code.data() + i, key, n) != 0) continue;
         const unsigned char* p = reinterpret_cast<const unsigned char*>(code.data()) + i + n;
         const size_t left = code.size() - (i + n);
         long v = -1;
@@ -174,6 +197,11 @@ struct ptl_kernel {
     };
     std::map<std::string, Slot> slots;
     std::map<std::string, void*> textures;  // sampler -> device texel buffer
+    // Staged slices carry sampler records: a texel buffer that a staged slice may still name is not freed by a re-bind of its sampler (a video
+    // texture that steps to its next frame between two sub-frames of one launch) but retired, and freed behind the next launch.
+    std::vector<void*> retired_textures;
+    bool staged_since_launch = false;  // ptl_kernel_stage_slice* since the last launch: its sampler records are live
+    int texture_holds = 0;             // ptl_kernel_hold_textures: a caller keeps snapshots of the block that name texel buffers
     hip::hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hip::hipEvent_t ev_done = nullptr;  // recorded behind every render launch: what destroy / a teleport query wait for.  Owned here, so it
                                         // stays valid when the caller has already destroyed the stream it launched on (a torch stream, a
@@ -354,14 +382,14 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
         // kernel in that band, stored under the key of the options the caller asked for.
         bool hinted = false;
         for (auto& o : opts) hinted = hinted || o.find("PTL_WAVES_PER_EU") != std::string::npos;  // (a define of the caller's, or PTL_HIPRTC_FLAGS of an experiment)
-        const int vgprs = code_object_note_max(k->code, ".vgpr_count");
+        const int vgprs = code_object_note_max(k->code, ".vgpr_count", "ptl_render");  // the render entries only
         if (!hinted && !teleport_only && vgprs > 128 && vgprs <= 168 && !std::getenv("PTL_NO_OCCUPANCY_RETRY")) {
             std::vector<std::string> capped = opts;
             capped.push_back("-DPTL_WAVES_PER_EU=4");
             std::vector<char> second;
             bool settled = false;
-            if (run_hiprtc(capped, second, false) == PTL_OK && code_object_note_max(second, ".vgpr_spill_count") == 0 &&
-                code_object_note_max(second, ".private_segment_fixed_size") <= code_object_note_max(k->code, ".private_segment_fixed_size")) {
+            if (run_hiprtc(capped, second, false) == PTL_OK && code_object_note_max(second, ".vgpr_spill_count", "ptl_render") == 0 &&
+                code_object_note_max(second, ".private_segment_fixed_size", "ptl_render") <= code_object_note_max(k->code, ".private_segment_fixed_size", "ptl_render")) {
                 k->code.swap(second);
                 settled = true;
             }
@@ -380,9 +408,9 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
                 }
                 bottom_up.push_back("-DPTL_WAVES_PER_EU=4");
                 std::vector<char> third;
-                if (bottom_up.size() < opts.size() && run_hiprtc(bottom_up, third, false) == PTL_OK && code_object_note_max(third, ".vgpr_count") <= 128 &&
-                    code_object_note_max(third, ".vgpr_spill_count") == 0 &&
-                    code_object_note_max(third, ".private_segment_fixed_size") <= code_object_note_max(k->code, ".private_segment_fixed_size"))
+                if (bottom_up.size() < opts.size() && run_hiprtc(bottom_up, third, false) == PTL_OK && code_object_note_max(third, ".vgpr_count", "ptl_render") <= 128 &&
+                    code_object_note_max(third, ".vgpr_spill_count", "ptl_render") == 0 &&
+                    code_object_note_max(third, ".private_segment_fixed_size", "ptl_render") <= code_object_note_max(k->code, ".private_segment_fixed_size", "ptl_render"))
                     k->code.swap(third);
             }
         }
@@ -524,6 +552,15 @@ extern "C" int ptl_kernel_code_object(ptl_kernel* k, const void** data, size_t* 
     return PTL_OK;
 }
 
+// The kernel metadata of a code object (the one ptl_kernel_code_object hands out, or a file of the cache): the largest value of `key`
+// (".vgpr_count", ".vgpr_spill_count", ".private_segment_fixed_size", ".sgpr_count" ...) over the kernels whose name starts with
+// `kernel_prefix` (NULL / "": all kernels); -1 when the key does not occur.  What the JIT's occupancy retry decides on; no device needed.
+extern "C" int ptl_code_object_note(const void* code, size_t size, const char* key, const char* kernel_prefix) {
+    if (!code || !key) return -1;
+    std::vector<char> bytes(static_cast<const char*>(code), static_cast<const char*>(code) + size);
+    return code_object_note_max(bytes, key, kernel_prefix);
+}
+
 extern "C" int ptl_kernel_resources(ptl_kernel* k, int* registers, int* scratch_bytes, int* lds_bytes) {
     if (!k) return PTL_ERR_INVALID;
     if (k->device < 0 || !k->fn) return PTL_ERR_NO_DEVICE;
@@ -549,6 +586,27 @@ extern "C" int ptl_kernel_set_uniform(ptl_kernel* k, const char* name, ptl_type 
     return PTL_OK;
 }
 
+static void free_retired_textures(ptl_kernel* k, const hip::Runtime* rt) {
+    for (void* t : k->retired_textures) rt->hipFree(t);  // waits for the device: the launch that read them has finished
+    k->retired_textures.clear();
+}
+
+// While held (counted), re-binding a sampler keeps the previous texel buffer alive: the caller holds copies of the uniform block
+// (ptl_kernel_snapshot_uniforms) that it will stage later.  Releasing the last hold frees what was retired meanwhile.
+extern "C" int ptl_kernel_hold_textures(ptl_kernel* k, int hold) {
+    if (!k) return PTL_ERR_INVALID;
+    if (hold) {
+        ++k->texture_holds;
+        return PTL_OK;
+    }
+    if (k->texture_holds > 0) --k->texture_holds;
+    if (k->texture_holds == 0 && !k->staged_since_launch && !k->retired_textures.empty() && k->device >= 0) {
+        const hip::Runtime* rt = hip::runtime(nullptr);
+        if (rt && rt->hipSetDevice(k->device) == 0) free_retired_textures(k, rt);
+    }
+    return PTL_OK;
+}
+
 extern "C" int ptl_kernel_set_texture(ptl_kernel* k, const char* sampler, const uint8_t* rgba8, int width, int height) {
     if (!k || !sampler || !rgba8 || width <= 0 || height <= 0) return PTL_ERR_INVALID;
     auto it = k->slots.find(sampler);
@@ -558,10 +616,15 @@ extern "C" int ptl_kernel_set_texture(ptl_kernel* k, const char* sampler, const 
     const hip::Runtime* rt = hip::runtime(nullptr);
     if (!hip_ok(rt, rt->hipSetDevice(k->device), "hipSetDevice")) return PTL_ERR_HIP;
     void*& dev = k->textures[sampler];
+    const bool held = k->staged_since_launch || k->texture_holds > 0;
     if (dev) {
-        rt->hipFree(dev);
+        if (held)
+            k->retired_textures.push_back(dev);  // a staged slice / a caller's snapshot may name it: it lives until the launch that reads it is behind us
+        else
+            rt->hipFree(dev);  // (hipFree waits for the device: a launch still reading it has finished)
         dev = nullptr;
     }
+    if (!held) free_retired_textures(k, rt);
     size_t bytes = (size_t)width * height * 4;
     if (!hip_ok(rt, rt->hipMalloc(&dev, bytes), "hipMalloc(texture)")) return PTL_ERR_HIP;
     if (!hip_ok(rt, rt->hipMemcpy(dev, rgba8, bytes, hip::kMemcpyHostToDevice), "hipMemcpy(texture)")) return PTL_ERR_HIP;
@@ -643,6 +706,7 @@ static int launch_slices(ptl_kernel* k, const hip::Runtime* rt, const ptl_frame*
     unsigned gx = (unsigned)((width + 8 * waves - 1) / (8 * waves)), gy = (unsigned)nby;
     if (elapsed_ms) rt->hipEventRecord(k->ev0, stream);
     if (!hip_ok(rt, rt->hipModuleLaunchKernel(k->fn, gx, gy, (unsigned)n, 64 * waves, 1, 1, 0, stream, args, nullptr), "hipModuleLaunchKernel(ptl_render_slices_kernel)")) return PTL_ERR_HIP;
+    k->staged_since_launch = false;  // what was staged is launched: retired texel buffers go with the next re-bind (hipFree waits for this launch)
     k->last_stream = stream;
     k->launched = true;
     if (k->ev_done) rt->hipEventRecord(k->ev_done, stream);
@@ -681,7 +745,17 @@ extern "C" int ptl_kernel_stage_slice_from(ptl_kernel* k, int index, const void*
     unsigned char* dst = k->staged.data() + stride * (size_t)index;
     std::memcpy(dst, block, size);
     for (auto& [name, slot] : k->slots)
-        if (slot.type == PTL_SAMPLER) std::memcpy(dst + slot.offset, k->shadow.data() + slot.offset, 16);
+        if (slot.type == PTL_SAMPLER) {
+            // a record that names a texel buffer of THIS kernel (bound now, or bound when the block was taken and retired since) stays: a video
+            // texture that stepped between two sub-frames is read by each slice as it was.  Anything else came from another kernel of the scene.
+            void* texels = nullptr;
+            std::memcpy(&texels, dst + slot.offset, sizeof texels);
+            bool own = false;
+            for (auto& t : k->textures) own = own || (texels && t.second == texels);
+            for (void* t : k->retired_textures) own = own || (texels && t == texels);
+            if (!own) std::memcpy(dst + slot.offset, k->shadow.data() + slot.offset, 16);
+        }
+    k->staged_since_launch = true;
     return PTL_OK;
 }
 
@@ -858,6 +932,7 @@ extern "C" void ptl_kernel_destroy(ptl_kernel* k) {
         if (k->ev_done) rt->hipEventDestroy(k->ev_done);
         for (auto& t : k->textures)
             if (t.second) rt->hipFree(t.second);
+        free_retired_textures(k, rt);
         if (k->dev_slices) rt->hipFree(k->dev_slices);
         if (k->ev0) rt->hipEventDestroy(k->ev0);
         if (k->ev1) rt->hipEventDestroy(k->ev1);

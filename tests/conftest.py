@@ -8,6 +8,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """`pytest -m gpu` (the driver's round-end command, single process, 1 200 s limit) spreads itself over four worker processes: the GPU
+    suite is ~650 independent frames + kernel builds and most of its wall time is host work (hiprtc, the numpy oracle), 131 s with four
+    workers against 498 s with one (profiles/r04).  `-n ...` on the command line or PTL_GPU_SUITE_WORKERS=0 keeps the caller's choice."""
+    marker = config.getoption("-m", default="") or ""
+    if marker.strip() != "gpu" or not config.pluginmanager.hasplugin("xdist"):
+        return None
+    if getattr(config.option, "numprocesses", None) is not None or getattr(config.option, "tx", None) or os.environ.get("PYTEST_XDIST_WORKER"):
+        return None
+    workers = int(os.environ.get("PTL_GPU_SUITE_WORKERS", "4"))
+    if workers > 1:
+        config.option.numprocesses = workers
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # The CPU suite only checks that the generated kernels COMPILE for gfx950 (hiprtc, no device); it builds a few hundred of them, and the

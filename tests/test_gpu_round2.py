@@ -659,8 +659,9 @@ def test_one_launch_for_several_draws_gives_the_frames_of_draws_one_by_one(gpu, 
         r.set_option("aa_count", 2)
         return scene, r
 
-    # the frames one by one, classic renderer (the moving uniform is animated per frame: a baked build would re-JIT per value -- keep it to the camera there)
-    moving_uniform = flags_name != "baked"
+    # the frames one by one, classic renderer.  The moving uniform is animated per frame; a value-baked build re-JITs per value BETWEEN two stage
+    # calls (round 5): every slice is then traced by the kernel it was staged with, the earlier kernels parked until the launch
+    moving_uniform = True
     scene_a, ra = make(0)
     want8, want32 = [], []
     for k in range(n):
@@ -703,6 +704,49 @@ def test_one_launch_for_several_draws_gives_the_frames_of_draws_one_by_one(gpu, 
     assert np.array_equal(rb.draw(w, h)["rgba8"], ra.draw(w, h)["rgba8"])  # ... and leaves the next draws alone
     if flags_name == "static":  # (the moving uniform was compiled in: the kernel was rebuilt between two stage calls, and the slices staged before it survived)
         assert rb.rejit_count() >= 1
+
+
+@pytest.mark.gpu
+def test_slices_read_the_video_frame_that_was_bound_when_they_were_staged(gpu, tmp_path):
+    """A video texture that steps to its next frame BETWEEN two sub-frames of one launch (motion blur across a video frame boundary):
+    each slice reads the texel buffer that was bound when it was staged -- the earlier buffer is retired, not freed, until the launch -- so the
+    batched frames are the frames of draws one by one."""
+    import torch
+    from tests import synthetic
+
+    pa = gpu
+    colours = [(255, 0, 0), (0, 255, 0), (0, 0, 255)]
+    frames_dir = tmp_path / "video_png" / "clip"
+    frames_dir.mkdir(parents=True)
+    for k, c in enumerate(colours):
+        img = np.zeros((4, 4, 4), np.uint8)
+        img[..., :3] = c
+        img[..., 3] = 255
+        pa.png_write(str(frames_dir / f"frame_{k:03d}.png"), img)
+    mat = '(name: "screen", data: Complex(code: (("MaterialProcessing result = material_simple(hit, r, vec3(1.0, 1.0, 1.0), 0.0, false, 1.0, 0.0);\\nresult.mul_to_color *= texture(vid_tex, vec2(0.5, 0.5)).rgb;\\nreturn result;")))),'
+    text = synthetic.wall_scene(extra_materials=mat).replace("return wall_M; }", "return screen_M; }")
+    text = text.replace('uniforms: ([', 'uniforms: ([ (name: "pos", data: Formula(("time"))),')
+    text = text.replace("    textures: ([]),", '    textures: ([]),\n    videos: ([ (name: "vid", data: (path: "somewhere/clip.mov", uniform: Some(Named("pos")))) ]),')
+    times = (0.1, 0.2, 0.3, 0.7, 0.8, 1.0)   # frames 0 0 1 1 2 2: two boundaries inside one batch
+    w, h = 16, 16
+    frame = pa.Frame(w, h, 0, 1)
+    for flags in (0, pa.FLAG_SPECIALIZE_STATIC):
+        one = pa.SceneRenderer(pa.Scene.from_text(text), device=0, asset_root=str(tmp_path), flags=flags)
+        want = []
+        for t in times:
+            one.update(t)
+            want.append(one.draw(w, h)["rgba8"].copy())
+        assert [tuple(int(x) for x in f[8, 8][:3]) for f in want] == [colours[k] for k in (0, 0, 1, 1, 2, 2)]
+        r = pa.SceneRenderer(pa.Scene.from_text(text), device=0, asset_root=str(tmp_path), flags=flags | pa.FLAG_SLICES)
+        out = torch.zeros((len(times), h, w, 4), dtype=torch.uint8, device="cuda:0")
+        for rounds in range(2):  # (the second batch: retired buffers of the first are released, the last frame of the first batch is bound)
+            for j, t in enumerate(times):
+                r.update(t)
+                r.stage_slice(frame, j)
+            r.draw_slices(frame, len(times), out_rgba8=out.data_ptr(), slice_pixels=w * h)
+            got = out.cpu().numpy()
+            for j in range(len(times)):
+                assert np.array_equal(got[j], want[j]), (flags, rounds, j)
 
 
 # ---- split builds: the teleport entry as a module of its own ------------------------------------------------------------------------

@@ -1486,6 +1486,11 @@ def test_distance_bound_is_added_only_to_snippets_whose_shape_allows_it(pa):
         "whole accumulator assigned": _BOUND_OK.replace("      result.scene = process_portal_intersection(", "      result = other(r); result.scene = process_portal_intersection("),
         "not the last statement": _BOUND_OK.replace("return result;", "return result;\nreturn other(r);"),
         "nearer of another shape": _BOUND_OK.replace("nearer(result.scene.hit, hit_a)", "nearer(result.scene.hit, hits[size])"),
+        # control flow out of a block: skipping a far candidate that ends in `break` would let the loop reach candidates it never saw
+        "break in a block": _BOUND_OK.replace("        result.material = material_teleport_transformed(offset_ray(r, hit_a.t), vec3(1.));\n      }\n    }\n",
+                                              "        result.material = material_teleport_transformed(offset_ray(r, hit_a.t), vec3(1.));\n      }\n    }\n    break;\n"),
+        "continue in a block": _BOUND_OK.replace("    if (is_inside != NOT_INSIDE) {", "    if (is_inside == NOT_INSIDE) { continue; }\n    if (is_inside != NOT_INSIDE) {"),
+        "return in a block": _BOUND_OK.replace("    if (is_inside != NOT_INSIDE) {", "    if (size == 3) { return result; }\n    if (is_inside != NOT_INSIDE) {"),
     }
     for why, body in refused.items():
         assert body != _BOUND_OK, why
@@ -1757,3 +1762,50 @@ def test_a_module_inliner_build_that_cannot_be_capped_falls_back_to_the_bottom_u
     monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path / "b"))
     kept = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_SPECIALIZE_INTS, asset_root=os.path.join(os.path.dirname(__file__), "corpus")).code_object()
     assert _note_max(kept, b".vgpr_count") <= 128 and _note_max(kept, b".vgpr_spill_count") == 0 and _note_max(kept, b".private_segment_fixed_size") == 0
+
+
+def test_bound_glsl_reports_malformed_input_instead_of_throwing_across_the_c_boundary(pa):
+    """ptl_bound_glsl: whatever the tokenizer makes of broken text, the call returns -- text unchanged or NULL + ptl_last_error --
+    and the process lives."""
+    for body in ["/* never closed", "if (nearer(result.scene.hit, hit_a)) {", "}}}}", "\x01\x02 \"unterminated", ""]:
+        try:
+            text, n = pa.bound_glsl(body)
+            assert n == 0 and text == body
+        except pa.PortalError as e:
+            assert "ptl_bound_glsl" in str(e)
+
+
+def test_code_object_metadata_is_read_per_kernel(pa, monkeypatch):
+    """ptl_code_object_note: the JIT's occupancy retry looks at the RENDER entries of a module only -- a one-module build also holds
+    the one-wave teleport and prologue entries.  Checked against the ELF notes as llvm-readelf prints them."""
+    import re
+    import subprocess
+
+    monkeypatch.setenv("PTL_ONE_MODULE", "1")
+    r = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("monoportal")), device=-1, flags=pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
+    code = r.code_object()
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    per_kernel = {}
+    if os.path.exists(readelf):
+        import tempfile
+
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(code)
+            f.flush()
+            notes = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+        name = None
+        for line in notes.splitlines():
+            m = re.match(r"\s+\.name:\s+(ptl_\w+_kernel)\s*$", line)
+            if m:
+                name = m.group(1)
+            m = re.match(r"\s+(\.vgpr_count|\.sgpr_count|\.private_segment_fixed_size|\.vgpr_spill_count):\s+(\d+)", line)
+            if m and name:
+                per_kernel.setdefault(name, {})[m.group(1)] = int(m.group(2))
+        assert {"ptl_render_kernel", "ptl_teleport_kernel", "ptl_derive_kernel"} <= set(per_kernel)
+        for key in (".vgpr_count", ".sgpr_count", ".private_segment_fixed_size", ".vgpr_spill_count"):
+            assert r.code_object_note(key, "ptl_render") == per_kernel["ptl_render_kernel"][key]
+            assert r.code_object_note(key, "ptl_teleport") == per_kernel["ptl_teleport_kernel"][key]
+            assert r.code_object_note(key, "") == max(v[key] for v in per_kernel.values())
+    assert r.code_object_note(".vgpr_count") > r.code_object_note(".vgpr_count", "ptl_derive") > 0
+    assert r.code_object_note(".vgpr_count", "no_such_kernel") == r.code_object_note(".vgpr_count", "")   # no kernel of that name: every kernel counts
+    assert r.code_object_note(".no_such_key") == -1 and len(r.code_object_sha256()) == 64
