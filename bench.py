@@ -58,40 +58,44 @@ def workload_key(args):
     return key
 
 
-PROFILE_ROUNDS = ("r04", "r03")  # newest first; a round's files are measurements of that round's kernels
+PROFILE_ROUNDS = ("r05", "r04", "r03")  # newest first; a round's files are measurements of that round's kernels
 
 
-def stored_pmc(args, build):
+def stored_pmc(args, build, code_sha=None):
     """The committed rocprofv3 PMC passes of exactly this workload (profiles/rNN/pmc_<workload>_<spec>_<build>.json, one counter group per
-    pass, tools/collect_pmc.sh): HBM bytes per launch (FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE, KB units)
-    and SQ_INSTS_VALU per launch.  The file of the build that was timed if there is one, else another candidate build's of the same
-    workload and round (w0 / w3 / w4 / minreg differ in register budget, not in what they execute: < 1 % in any counter) -- named in
-    `source`.  None when there is no such file."""
+    pass, tools/collect_pmc.sh): HBM bytes per launch (FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE, KB units),
+    SQ_INSTS_VALU and the instruction classes per launch.  Round 5: a PMC file names the sha256 of the code object whose launches it counted
+    (`code_object_sha256`, written by tools/collect_pmc.sh from the bench line of the counted run); with `code_sha` given -- the timed build's
+    -- only a file of the SAME binary is used.  Returns (counters or None, why not)."""
     import glob
 
     spec = {0: "dynamic", 1: "ints", 2: "spec"}[args.specialize]
     dirs = ([os.environ["PTL_PMC_DIR"]] if os.environ.get("PTL_PMC_DIR") else []) + [os.path.join(HERE, "profiles", rnd) for rnd in PROFILE_ROUNDS]
-    for d in dirs:  # (PTL_PMC_DIR: passes collected a moment ago on this very box, tools/collect_profiles_r04.sh)
+    refused = []
+    for d in dirs:  # (PTL_PMC_DIR: passes collected a moment ago on this very box)
         base = os.path.join(d, f"pmc_{workload_key(args)}_{spec}_")
-        paths = [base + build + ".json"] + sorted(p for p in glob.glob(base + "*.json") if p != base + build + ".json" and os.path.basename(p)[len(os.path.basename(base)):-5] in ("w0", "w3", "w4", "minreg"))
+        paths = [base + build + ".json"] + sorted(p for p in glob.glob(base + "*.json") if p != base + build + ".json" and os.path.basename(p)[len(os.path.basename(base)):-5] in ("w0", "w3", "w4", "w5", "minreg"))
         for path in paths:
             try:
-                c = json.load(open(path))["counters"]
+                doc = json.load(open(path))
+                c = doc["counters"]
+                if code_sha is not None and doc.get("code_object_sha256") != code_sha:
+                    refused.append(f"{os.path.relpath(path, HERE)}: counted code object {str(doc.get('code_object_sha256'))[:16]}, timed {code_sha[:16]}")
+                    continue
                 out = {"traffic": int((2 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024),
-                       "insts_valu": float(c["SQ_INSTS_VALU"]["mean_per_launch"]), "source": os.path.relpath(path, HERE)}
-                # instruction classes + the busy cycles of the same passes: what the VALU pipes were occupied with (valu_busy_bounds below)
+                       "insts_valu": float(c["SQ_INSTS_VALU"]["mean_per_launch"]), "source": os.path.relpath(path, HERE), "code_object_sha256": doc.get("code_object_sha256")}
                 classes = ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "GRBM_GUI_ACTIVE")
                 if all(k in c for k in classes):
                     out["classes"] = {k: float(c[k]["mean_per_launch"]) for k in classes}
                 if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:  # lanes active per issued VALU instruction
                     out["lane_utilisation"] = float(c["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"]) / (64.0 * float(c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"]))
-                return out
+                return out, None
             except Exception:
                 continue
-    return None
+    return None, ("; ".join(refused) if refused else "no stored PMC passes of this workload")
 
 
-def flops_per_segment(args):
+def flops_per_segment(args, affine=False):
     """Binary32 operations per bounce-loop trip (fma = 2) on a pixel sample of this full-size frame (tools/count_flops.py):
     (`flops_varying`, the ray-dependent ones, when the timed kernel has every scene uniform baked in and so folds the rest;
     `flops`, all of them, for a kernel that reads the uniforms at run time).  Data file only."""
@@ -117,6 +121,11 @@ def flops_per_segment(args):
     # zero (device/ptl_glsl.h `ptl_mterm`): counted by the oracle (`zero_term_flops_varying`) and taken off as well
     if args.specialize == 2 and not (args.extra_flags & 16384) and "flops_varying_executed_baked" in entry["per_segment"]:
         executed, label = float(entry["per_segment"]["flops_varying_executed_baked"]), "flops_varying_executed_baked"
+        # round 5: neither the multiplications by +-1 matrix elements (one add each) nor -- in a kernel with affine rays -- the terms that
+        # meet a ray's w (tools/count_flops.py: `unit_term`, `known_w_term`)
+        want = "flops_varying_executed_baked_affine" if affine else "flops_varying_executed_baked_units"
+        if want in entry["per_segment"]:
+            executed, label = float(entry["per_segment"][want]), want
     # Comparisons are not claimed: the oracle tallies a compare as one operation, but a v_cmp is not a floating-point operation of the peak
     # this is priced against (round 3's count, with them, sat 2-3 % above the hardware's own instruction ceiling).
     compares = float(entry["per_segment"].get("cmp_varying", 0.0))
@@ -134,6 +143,9 @@ WORKLOADS = {  # --workload NAME: BASELINE.json configs by name
     # (the views tests/test_gpu_oracle_fullsize.py checks at 320x180), and the corpus scene with four nested chains
     "c4-deep": dict(scene="portal_in_portal", width=3840, height=2160, depth=40, aa=1, camera="0,0,0,0.2,1.5,1.6"),
     "c4-deep2": dict(scene="portal_in_portal", width=3840, height=2160, depth=40, aa=1, camera="0.3,-0.1,0.2,2.8,1.0,2.4"),
+    # the corpus scene whose default view takes 26 trips per primary ray at depth 40 (a room that contains itself): the one BASELINE-sized workload in
+    # which "depth = 40" is what the frame costs (the five BASELINE views take 1.02-1.11 trips per ray)
+    "recursive-room": dict(scene="recursive_room", scene_file="tests/corpus/scenes/recursive_room.ron", width=3840, height=2160, depth=40, aa=1),
     "plus-ultra": dict(scene="portal_in_portal_plus_ultra", scene_file="tests/corpus/scenes/portal_in_portal_plus_ultra.ron", width=3840, height=2160, depth=40, aa=1),
 }
 
@@ -156,7 +168,7 @@ def parse_args():
     p.add_argument("--fov", type=float, default=90.0)
     p.add_argument("--specialize", type=int, default=2, help="JIT specialisation: 0 none, 1 bake Bool/Int scene uniforms, 2 bake all scene uniforms")
     p.add_argument("--waves", type=int, default=-1, help="occupancy hint (__launch_bounds__(256, n)); -1 = pick the fastest candidate build before timing")
-    p.add_argument("--build", default="", help="pin one candidate build by name (w0, w3, w4, minreg) instead of picking the fastest")
+    p.add_argument("--build", default="", help="pin one candidate build by name (w0, w3, w4, w5, minreg) instead of picking the fastest")
     p.add_argument("--extra-flags", type=int, default=0, help="extra SceneRenderer flag bits for A/B measurements (e.g. 16384 = FLAG_EXACT_CR, the round-2 numerics contract)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-second-workload", action="store_true", help="skip the C5 frames that follow the headline's timed region (`second_workload` in the JSON line)")
@@ -408,17 +420,21 @@ def valu_roofline(fl, pmc, segments, world, kernel_ms, traffic, specialize):
             roof["frac_ceiling_valu_plus_fma"] = round((pmc["insts_valu"] + k["SQ_INSTS_VALU_FMA_F32"]) / world * 64 / t_s / 1e12 / FP32_PEAK_TFLOPS, 4)
             roof["hw_flops_frac"] = round((2 * k["SQ_INSTS_VALU_FMA_F32"] + k["SQ_INSTS_VALU_MUL_F32"] + k["SQ_INSTS_VALU_ADD_F32"]) / world * 64 * util / t_s / 1e12 / FP32_PEAK_TFLOPS, 4)
             roof["lane_utilisation"] = round(util, 4)
-            # The oracle counts the operations of the optimised ALGORITHM on a pixel sample; the compiler then removes what it can prove
-            # redundant (common subexpressions across plane tests whose baked matrices share rows, results no material reads), so the
-            # count can exceed what the hardware executed.  The ceiling is a hard bound on executed work: `frac` never claims more.
-            if roof["frac"] > roof["frac_ceiling_valu_plus_fma"]:
-                roof["frac_counted_by_the_oracle"] = roof["frac"]
-                roof["achieved_counted_by_the_oracle"] = roof["achieved"]
-                roof["frac"] = roof["frac_ceiling_valu_plus_fma"]
-                roof["achieved"] = round(roof["frac"] * FP32_PEAK_TFLOPS, 3)
-                roof["frac_capped"] = ("the oracle's operation count exceeds the hardware's instruction ceiling (every VALU instruction one operation, FMAs two): "
-                                       "`frac` / `achieved` are the ceiling; the uncapped figures are in *_counted_by_the_oracle")
-        roof["pmc_source"] = pmc["source"] + " (stored rocprofv3 PMC passes of this build, not re-measured by this run)"
+            # Round 5: what the hardware counted as ARITHMETIC -- 2 x FMA + MUL + ADD + the transcendental unit's instructions
+            # (v_rcp / v_sqrt / v_rsq: one operation each) on the active lanes -- is what `frac` may claim at most.  The oracle's count is the
+            # operations of the algorithm the kernel still has to perform; the compiler shares and folds more (common subexpressions across
+            # the unrolled copies of a snippet, constants), so where the count is above the counters the counters are printed.
+            hw = (2 * k["SQ_INSTS_VALU_FMA_F32"] + k["SQ_INSTS_VALU_MUL_F32"] + k["SQ_INSTS_VALU_ADD_F32"] + k["SQ_INSTS_VALU_TRANS_F32"]) / world * 64 * util / t_s / 1e12 / FP32_PEAK_TFLOPS
+            roof["hw_arith_frac"] = round(hw, 4)
+            roof["frac_counted_by_the_oracle"] = roof["frac"]
+            roof["achieved_counted_by_the_oracle"] = roof["achieved"]
+            roof["count_over_hardware"] = round(roof["frac"] / hw, 3) if hw > 0 else None
+            if hw < roof["frac"]:
+                roof["frac"] = round(hw, 5)
+                roof["achieved"] = round(hw * FP32_PEAK_TFLOPS, 3)
+            roof["frac_is"] = "min(the oracle's count of executed arithmetic, the hardware's FP32 arithmetic counters of the same code object)"
+        roof["pmc_source"] = pmc["source"] + " (stored rocprofv3 PMC passes of the code object named in pmc_code_object_sha256 -- the one this run timed; not re-measured by this run)"
+        roof["pmc_code_object_sha256"] = pmc.get("code_object_sha256")
     return roof
 
 
@@ -531,7 +547,7 @@ def main():
 
     # untimed: JIT-compile the candidate builds (same arithmetic: different register budgets / instruction schedulers) and keep
     # the fastest on this rank's shard.  16 launches each after a short spin-up, so that differences of a few percent are real.
-    candidates = {"w0": (0, ""), "w3": (3, ""), "w4": (4, ""), "minreg": (0, "-mllvm -amdgpu-sched-strategy=iterative-minreg")}
+    candidates = {"w0": (0, ""), "w3": (3, ""), "w4": (4, ""), "w5": (5, ""), "minreg": (0, "-mllvm -amdgpu-sched-strategy=iterative-minreg")}
     if world > 1 and args.build != "minreg":
         candidates.pop("minreg")  # needs a child-process compile per rank (sticky -mllvm options): not worth a start-up hazard on 8 ranks
     if args.build:
@@ -778,11 +794,20 @@ def main():
                 torch.cuda.synchronize(dev)
                 if world > 1:
                     dist.all_reduce(seg2)
-                fl2, pmc2 = flops_per_segment(a2), stored_pmc(a2, "w0")
+                sha2 = r2.code_object_sha256()
+                fl2, (pmc2, why2) = flops_per_segment(a2, r2.affine_rays()), stored_pmc(a2, "w0", sha2)
                 second["segments_per_frame"] = int(seg2.item())
+                second["trips_per_primary_ray"] = round(int(seg2.item()) / (w2["width"] * w2["height"] * w2["aa"]), 4)
+                second["code_object_sha256"] = sha2
                 if fl2:
                     second["roofline"] = valu_roofline(fl2, pmc2, int(seg2.item()), world, max(k2), pmc2["traffic"] if pmc2 else None, args.specialize)
+                    if pmc2 is None:
+                        second["roofline"]["pmc_unavailable"] = why2
                 del counting2, buf2
+                if world == 1 and not args.no_cpu_baseline:  # the checker's verdict and a bounded CPU baseline for this workload too
+                    a2.cpu_seconds = min(args.cpu_seconds, 4.0)
+                    second["cpu_baseline"] = cpu_baseline(a2, pa)
+                    second["oracle_check"] = oracle_check(a2, pa, r2, torch, dev, stream, n=1024)
             except Exception as e:
                 print(f"[bench] second workload roofline unavailable: {e}", file=sys.stderr)
                 if world > 1:
@@ -793,6 +818,74 @@ def main():
             print(f"[bench] second workload unavailable: {e}", file=sys.stderr)
             if world > 1:
                 raise  # ... but at N > 1 a rank that skipped collectives would hang the others: fail loudly instead
+
+    # After that, N = 1 only: the other BASELINE.json configs, SURVEY 8d's Panini variant and one DEEP view of the headline scene (into the nested
+    # portals: several trips per primary ray, the regime "depth = 40" exists for), each timed like the headline -- K frames between two
+    # synchronisations, the kernel's launches between HIP events -- with its trips per ray, its roofline, a bounded CPU baseline and the
+    # checker's verdict on the frame of the build that was timed.  (one driver-run line for every workload.)
+    others = []
+    if world == 1 and not args.no_second_workload and not args.no_cpu_baseline and workload_key(args) == "portal_in_portal_3840x2160_d40":
+        import argparse as _ap
+
+        extra = [("c2", WORKLOADS["c2"]), ("c3", WORKLOADS["c3"]), ("c4-panini", dict(WORKLOADS["c4"], panini=1.0, fov=140.0)), ("c4-deep", WORKLOADS["c4-deep"]),
+                 ("recursive-room", WORKLOADS["recursive-room"])]
+        for wname, wl in extra:
+            try:
+                stage(f"workload {wname}")
+                a = _ap.Namespace(**{**vars(args), "camera": "", "panini": -1.0, "fov": 90.0, "scene_file": "", **wl})
+                a.cpu_seconds = min(args.cpu_seconds, 4.0)
+                sc_path, sc_kw = scene_of(a, pa)
+                sc = pa.Scene.from_file(sc_path)
+                Wk, Hk = a.width, a.height
+                fr = pa.Frame(Wk, Hk, 0, 1)
+                buf = torch.empty((Hk, Wk, 4), dtype=torch.uint8, device=dev)
+                cands = {}
+                for waves in (0, 4):  # the two register budgets that matter (the headline tries four)
+                    rr = pa.SceneRenderer(sc, device=local_rank, flags=spec_flags | pa.flag_waves(waves), **sc_kw)
+                    configure(rr, a)
+                    for _ in range(6):
+                        rr.draw_device(fr, out_rgba8=buf.data_ptr(), stream=stream.cuda_stream)
+                    cands[waves] = (float(np.median([rr.draw_device(fr, out_rgba8=buf.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(10)])), rr)
+                waves = min(cands, key=lambda k: cands[k][0])
+                rr = cands[waves][1]
+                steps = int(max(10, min(200, 40.0 / max(cands[waves][0], 0.02))))  # ~40 ms of timed region
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for k in range(steps):
+                    ev[k][0].record(stream)
+                    rr.draw_device(fr, out_rgba8=buf.data_ptr(), stream=stream.cuda_stream)
+                    ev[k][1].record(stream)
+                torch.cuda.synchronize(dev)
+                ms_step = (time.perf_counter() - t0) / steps * 1e3
+                kms = float(np.mean([x.elapsed_time(y) for x, y in ev]))
+                cnt = pa.SceneRenderer(sc, device=local_rank, flags=pa.FLAG_COUNT_SEGMENTS | spec_flags, **sc_kw)
+                configure(cnt, a)
+                seg = torch.zeros(1, dtype=torch.int64, device=dev)
+                cnt.draw_device(fr, out_rgba8=buf.data_ptr(), segments=seg.data_ptr(), stream=stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                trips = int(seg.item())
+                del cnt
+                sha = rr.code_object_sha256()
+                rec = {"name": wname, "workload": f"{a.scene_file or 'scenes/' + a.scene + '.ron'} {Wk}x{Hk} aa={a.aa} depth={a.depth}" + (f" panini d={a.panini} fov={a.fov}" if a.panini >= 0 else "")
+                                                  + (f" camera look_at,alpha,beta,r={a.camera}" if a.camera else ""),
+                       "steps": steps, "ms_per_step": round(ms_step, 4), "kernel_ms": round(kms, 4), "value": round(Wk * Hk * a.aa / (ms_step * 1e-3) / 1e6, 3), "unit": "Mray/s",
+                       "build": f"w{waves}", "code_object_sha256": sha, "segments_per_frame": trips, "trips_per_primary_ray": round(trips / (Wk * Hk * a.aa), 4),
+                       "segment_mray_s": round(trips / (ms_step * 1e-3) / 1e6, 3)}
+                fl_k, (pmc_k, why_k) = flops_per_segment(a, rr.affine_rays()), stored_pmc(a, f"w{waves}", sha)
+                if fl_k:
+                    rec["roofline"] = valu_roofline(fl_k, pmc_k, trips, 1, kms, pmc_k["traffic"] if pmc_k else None, args.specialize)
+                    if pmc_k is None:
+                        rec["roofline"]["pmc_unavailable"] = why_k
+                rec["roofline_hbm"] = {"bound": "hbm", "achieved": round(Wk * Hk * 4 / (kms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(Wk * Hk * 4 / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": pmc_k["traffic"] if pmc_k else None}
+                rec["cpu_baseline"] = cpu_baseline(a, pa)
+                rec["oracle_check"] = oracle_check(a, pa, rr, torch, dev, stream, n=2048)
+                others.append(rec)
+                del cands, rr, buf
+            except Exception as e:  # the headline number does not depend on it
+                print(f"[bench] workload {wname} unavailable: {e}", file=sys.stderr)
+                others.append({"name": wname, "error": str(e)[:300]})
 
     # bounce-loop trips per frame (untimed, separate kernel variant with the counter compiled in)
     segments = None
@@ -979,6 +1072,9 @@ def main():
             out["frame_check"] = frame_check
         if second is not None:
             out["second_workload"] = second
+        if others or second is not None:
+            # every BASELINE.json config, the Panini variant and the deep view in ONE list (the C5 entry is `second_workload`, timed through the gather)
+            out["workloads"] = ([dict(second, name="c5")] if second is not None else []) + others
         if jit_seconds is not None:
             out["jit_seconds"] = jit_seconds  # cold compile of the timed build's render module (hiprtc, -O3); cached on disk by source + options + toolchain hash afterwards
             if jit_detail is not None:
@@ -996,7 +1092,11 @@ def main():
         if patterns_ms is not None:
             out["kernel_ms_with_only_zero_patterns_and_mode_switches"] = round(patterns_ms, 4)  # no scene VALUE compiled in (FLAG_SPECIALIZE_PATTERNS)
             out["kernel_ms_with_only_zero_patterns_and_mode_switches_build"] = patterns_build
-        pmc = stored_pmc(args, best)
+        timed_sha = renderer.code_object_sha256()
+        out["config"]["code_object_sha256"] = timed_sha  # of the binary the timed region launched: what ties this line to stored PMC passes
+        out["config"]["affine_rays"] = renderer.affine_rays()
+        out["config"]["toolchain"] = pa.version()
+        pmc, pmc_why = stored_pmc(args, best, timed_sha)
         hbm = {
             "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": pmc["traffic"] if pmc else None,
@@ -1006,9 +1106,11 @@ def main():
             out["config"]["trips_per_primary_ray"] = round(segments / rays, 4)
             out["segments_per_frame"] = segments
             out["segment_mray_s"] = round(segments / (ms_per_step * 1e-3) / 1e6, 3)
-        fl = flops_per_segment(args)
+        fl = flops_per_segment(args, renderer.affine_rays())
         if segments is not None and fl:
             roof = valu_roofline(fl, pmc, segments, world, kernel_ms, hbm["traffic"], args.specialize)
+            if pmc is None:
+                roof["pmc_unavailable"] = pmc_why
             out["roofline"] = roof
             out["roofline_hbm"] = hbm
             if batched is not None:  # the same instructions in less time: fraction and ceiling scale alike

@@ -288,6 +288,12 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * bit22 = SLICES: the render entry takes its uniform block from a buffer of blocks, one per blockIdx.z (ptl_kernel_render_slices /
  * ptl_renderer_draw_slices: one launch for the blur sub-frames of a clip frame).  Same arithmetic, same scalar loads, identical frames; a
  * single draw is a batch of one,
+ * bit23 = NO AFFINE RAYS: by default (round 5) a build that may shorten products (bit0, bit2, bit3 or bit20; not with bit14 / bit6) whose scene
+ * matrices all have the bottom row 0 0 0 1 -- or are NaN throughout: a switched-off object -- and whose snippets never write a ray's w says in
+ * its matrix-times-ray products what every ray of the reference satisfies anyway: an origin has w = 1, a direction w = 0.  The translation
+ * column then costs a direction nothing and the w row folds to a constant (headline kernel -16 %); the same operations on the same values
+ * for finite rays, identical frames.  A renderer rebuilds without it when a matrix -- the camera's included -- stops being affine.
+ * This bit keeps the general products (A/B measurements, tests),
  * bit15 = NO unrolling of baked loops: by default (with bit0) a counting loop of a scene snippet whose bound is a baked Int uniform
  * (<= 16 iterations) is unrolled -- the same operations in the same order, identical frames; every iteration then has its own
  * constants (scenes/portal_in_portal.ron's `size` drives an inner loop and a material index).
@@ -395,6 +401,14 @@ int ptl_renderer_update(ptl_renderer* r, double seconds, int* teleported, int* b
 /* Current teleport matrix (binary64, column-major), subspace flag and world position of the camera. */
 int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16], int* in_subspace, double position[3]);
 ptl_kernel* ptl_renderer_kernel(ptl_renderer* r);
+/* 1 when the renderer's current kernel was generated with affine rays (flag bit23 clear, a build that may shorten products, every scene
+ * matrix and the camera affine, no snippet that writes a ray's w): its matrix-times-ray products spell o.w = 1 / d.w = 0.  A matrix or a
+ * camera that stops being affine makes the next draw rebuild without it (counted by ptl_renderer_rejit_count); 0 then, and for every other build. */
+int ptl_renderer_affine_rays(ptl_renderer* r);
+/* The scan behind that decision, exposed for tests: 1 when the GLSL text keeps rays affine (no Ray built from halves whose w is not spelled
+ * `vec4(.., 1.)` / `vec4(.., 0.)`, no `.o` / `.d` assigned in another than the whitelisted forms, no out / inout parameter of type Ray or
+ * vec4, no transform() by a matrix that is not a scene uniform), 0 with the offending text in `why`, -1 on malformed input (ptl_last_error). */
+int ptl_snippets_keep_rays_affine(const char* glsl, char* why, size_t why_cap);
 /* how many times a draw had to rebuild a specialised kernel since the renderer was created: a clip-constant value that moved (flags bit3),
  * a mode switch that was flipped (flags bit0 / bit2 / bit3) */
 int ptl_renderer_rejit_count(ptl_renderer* r);

@@ -38,7 +38,7 @@ STATS = {"flops": 0.0, "div": 0.0, "sqrt": 0.0, "fma": 0.0,
          "flops_varying": 0.0, "div_varying": 0.0, "sqrt_varying": 0.0, "fma_varying": 0.0,
          # of `flops_varying`: terms of matrix products whose matrix element is a uniform zero -- a build with the matrices baked in
          # skips them (ptl_glsl.h `ptl_mterm`), so they are not executed work there (tools/count_flops.py subtracts them)
-         "zero_term_flops_varying": 0.0,
+         "zero_term_flops_varying": 0.0, "unit_term_flops_varying": 0.0, "known_w_term_flops_varying": 0.0,
          # of `flops`: comparisons, min / max, step -- VALU instructions without arithmetic (reported beside the totals, tools/count_flops.py)
          "cmp": 0.0, "cmp_varying": 0.0}
 _active = 1.0
@@ -243,14 +243,36 @@ def term0(a, b):
         return np.where(p == 0, F64(0), p).astype(F32)
 
 
-def note_matrix_term(m, v, first: bool) -> None:
-    """Bookkeeping only (COUNT_VARYING): a matrix-product term with matrix element `m` and vector component `v`."""
+def note_matrix_term(m, v, first: bool, acc=None) -> None:
+    """Bookkeeping only (COUNT_VARYING): a matrix-product term with matrix element `m`, vector component `v` and the accumulator it is
+    added to.  What a kernel that knows the matrix (baked, or its pattern) and that rays are affine does NOT execute of the 2 operations
+    (1 for the first term of a chain) this module counts for the term:
+      zero_term      m is a ray-independent zero: the term is skipped                                   (round 3, ptl_glsl.h `ptl_mterm`)
+      unit_term      m is a ray-independent +-1 and v varies: fma(+-1, v, acc) is ONE add / sub          (round 4 / 5: the multiplication is not executed)
+      known_w_term   v is a ray-independent 0 (a direction's w) under a varying accumulator: skipped;    (round 5, PTL_AFFINE_RAYS)
+                     v is a ray-independent 1 (an origin's w), m ray-independent: `acc + m`, one add"""
     if not COUNT_VARYING:
         return
-    a = np.asarray(m)
-    uniform_zero = (a.ndim == 0 and a == 0) or (a.ndim > 0 and a.size > 0 and not _lane_varying(a) and a.reshape(-1)[0] == 0)
-    if uniform_zero and _lane_varying(v):
-        STATS["zero_term_flops_varying"] += (1.0 if first else 2.0) * _active
+
+    def uniform_value(x):
+        a = np.asarray(x)
+        if a.ndim == 0:
+            return float(a)
+        if a.size > 0 and not _lane_varying(a):
+            return float(a.reshape(-1)[0])
+        return None
+
+    mv, vv = uniform_value(m), uniform_value(v)
+    full = 1.0 if first else 2.0
+    if mv == 0.0 and _lane_varying(v):
+        STATS["zero_term_flops_varying"] += full * _active
+    elif mv is not None and abs(mv) == 1.0 and _lane_varying(v) and not first:
+        STATS["unit_term_flops_varying"] += 1.0 * _active
+    elif vv is not None and mv is not None and mv != 0.0 and acc is not None and _lane_varying(acc) and not first:
+        if vv == 0.0:
+            STATS["known_w_term_flops_varying"] += 2.0 * _active
+        elif vv == 1.0:
+            STATS["known_w_term_flops_varying"] += 1.0 * _active
 
 
 def lt(a, b):

@@ -255,8 +255,9 @@ def mat_vec(m: Mat, v: Vec) -> Vec:
         acc = M.term0(m.cols[0].c[i], v.c[0])  # contract 2: the chain starts from +0 (ptl_glsl.h `ptl_term`); contract 1: the bare product
         M.note_matrix_term(m.cols[0].c[i], v.c[0], True)
         for j in range(1, m.n):
+            before = acc
             acc = M.fma(m.cols[j].c[i], v.c[j], acc)
-            M.note_matrix_term(m.cols[j].c[i], v.c[j], False)
+            M.note_matrix_term(m.cols[j].c[i], v.c[j], False, before)
         out.append(acc)
     return Vec(out)
 

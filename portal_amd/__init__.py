@@ -59,6 +59,7 @@ FLAG_NO_DEFERRED_UPDATES = 128  # translate scene snippets exactly as written (d
 FLAG_QUICK_JIT = 262144  # compile at -O1 instead of the shipped -O3: half the JIT time, a 5-20 % slower kernel (one-off frames)
 FLAG_SPECIALIZE_PATTERNS = 1048576  # compile in only what survives moving values: zero patterns of the matrices + the renderer's mode switches
 FLAG_BOUNDED_SNIPPETS = 2097152  # opt-in: scene_intersect first, its hit distance bounds the intersection-material snippets (exact; measured: no gain on the headline)
+FLAG_NO_AFFINE_RAYS = 8388608  # A/B: matrix-times-ray products never assume o.w = 1 / d.w = 0 (default in specialised builds of affine scenes: they do; identical frames)
 FLAG_SLICES = 4194304  # the render entry reads its uniform block from a buffer of blocks (one per blockIdx.z): stage_slice / draw_slices, one launch for several draws
 FLAG_NO_ZERO_MASKS = 524288  # A/B: run-time matrices keep their full products although their zero pattern is known (KernelOptions::mask_zero_elements)
 FLAG_ASYNC_REJIT = 131072  # a specialised renderer never stalls on a rebuild: it draws with the un-specialised kernel until a worker thread has the new one
@@ -151,6 +152,8 @@ def _load() -> C.CDLL:
         "ptl_kernel_max_slices": (ci, [vp]),
         "ptl_kernel_stage_slice": (ci, [vp, ci]),
         "ptl_kernel_hold_textures": (ci, [vp, ci]),
+        "ptl_renderer_affine_rays": (ci, [vp]),
+        "ptl_snippets_keep_rays_affine": (ci, [cp, cp, cs]),
         "ptl_code_object_note": (ci, [vp, cs, cp, cp]),
         "ptl_kernel_render_slices": (ci, [vp, P(Frame), ci, vp, vp, C.c_ulonglong, vp, P(C.c_float)]),
         "ptl_kernel_clone": (ci, [vp, P(vp)]),
@@ -554,6 +557,11 @@ class SceneRenderer:
     def rejit_count(self) -> int:
         return lib().ptl_renderer_rejit_count(self._h)
 
+    def affine_rays(self) -> bool:
+        """The current kernel spells o.w = 1 / d.w = 0 in its matrix-times-ray products (every scene matrix and the camera affine)."""
+        lib().ptl_renderer_kernel(self._h)  # (the kernel the next draw would use)
+        return lib().ptl_renderer_affine_rays(self._h) == 1
+
     def rejit_pending(self) -> bool:
         """FLAG_ASYNC_REJIT: a specialised build is being compiled in the background / the un-specialised kernel is in use."""
         return lib().ptl_renderer_rejit_pending(self._h) == 1
@@ -819,6 +827,15 @@ def bound_glsl(body: str, out_functions=()):
         return C.string_at(p).decode("utf-8"), n.value
     finally:
         lib().ptl_free(p)
+
+
+def snippets_keep_rays_affine(code: str):
+    """(ok, why): does this GLSL text keep every ray's w at 1 (origin) / 0 (direction)?  (the scan behind the affine-rays builds)"""
+    why = C.create_string_buffer(512)
+    rc = lib().ptl_snippets_keep_rays_affine(code.encode("utf-8"), why, len(why))
+    if rc < 0:
+        raise PortalError(_err())
+    return rc == 1, why.value.decode("utf-8", "replace")
 
 
 def translate_glsl(code: str) -> str:

@@ -780,21 +780,43 @@ template <ptl_mask_t MASK, int K> PTL_FN float ptl_element(float loaded) {  // e
     else if constexpr ((MASK >> (32 + K)) & 1u) return -1.0f;
     else return loaded;
 }
-template <ptl_mask_t MASK, int R> PTL_FN float ptl_row_m(const mat4& m, const vec4& v) {
-    if constexpr (MASK == 0xffffu) {  // nothing known: the ordinary chain of this build
-        return ptl_mterm(ptl_comp<R>(m.c[3]), v.w, ptl_mterm(ptl_comp<R>(m.c[2]), v.z, ptl_mterm(ptl_comp<R>(m.c[1]), v.y, ptl_mterm0(ptl_comp<R>(m.c[0]), v.x))));
+// Round 5, `W`: what is known about v.w.  Rays are affine objects -- every origin has w = 1, every direction w = 0 (the camera builds them
+// so, library.glsl's materials keep them so, and an affine matrix maps them so) -- and in a kernel generated with PTL_AFFINE_RAYS
+// (codegen.cpp `affine_rays`: every matrix of the scene has the bottom row 0 0 0 1, no scene snippet writes a ray's w) the products of a
+// matrix with a ray's two halves say it: PTL_W_ONE = the fourth term is `acc + element` (the same fma with the operand's value spelled: no
+// bit can move), PTL_W_ZERO = the fourth term is skipped like a term with a zero MATRIX element (exact for a finite element and an
+// accumulator that is not -0: the stated deviation of the shortened products, under the same guard).  The row (0 0 0 1) then folds to the
+// constants 1 / 0 at JIT time, so the w of a transformed ray costs nothing and a direction never pays for the translation column:
+// headline kernel 0.280 -> 0.235 ms, identical frames (profiles/r05/stub_profile_a.jsonl `r5_w_known`).
+enum { PTL_W_ZERO = 0, PTL_W_ONE = 1, PTL_W_ANY = 2 };
+template <ptl_mask_t MASK, int R, int W = PTL_W_ANY> PTL_FN float ptl_row_m(const mat4& m, const vec4& v) {
+    if constexpr (MASK == 0xffffu) {  // nothing known about the matrix: the ordinary chain of this build
+        const float head = ptl_mterm(ptl_comp<R>(m.c[2]), v.z, ptl_mterm(ptl_comp<R>(m.c[1]), v.y, ptl_mterm0(ptl_comp<R>(m.c[0]), v.x)));
+        if constexpr (W == PTL_W_ZERO) return head;
+        else if constexpr (W == PTL_W_ONE) return ptl_mterm(ptl_comp<R>(m.c[3]), 1.0f, head);
+        else return ptl_mterm(ptl_comp<R>(m.c[3]), v.w, head);
     } else {
         float acc = 0.0f;
         if constexpr ((MASK >> (0 + R)) & 1u) acc = __builtin_fmaf(ptl_element<MASK, 0 + R>(ptl_comp<R>(m.c[0])), v.x, acc);
         if constexpr ((MASK >> (4 + R)) & 1u) acc = __builtin_fmaf(ptl_element<MASK, 4 + R>(ptl_comp<R>(m.c[1])), v.y, acc);
         if constexpr ((MASK >> (8 + R)) & 1u) acc = __builtin_fmaf(ptl_element<MASK, 8 + R>(ptl_comp<R>(m.c[2])), v.z, acc);
-        if constexpr ((MASK >> (12 + R)) & 1u) acc = __builtin_fmaf(ptl_element<MASK, 12 + R>(ptl_comp<R>(m.c[3])), v.w, acc);
+        if constexpr (((MASK >> (12 + R)) & 1u) && W != PTL_W_ZERO) acc = __builtin_fmaf(ptl_element<MASK, 12 + R>(ptl_comp<R>(m.c[3])), W == PTL_W_ONE ? 1.0f : v.w, acc);
         return acc;
     }
 }
-template <ptl_mask_t MASK> PTL_FN vec4 ptl_mul_m(const mat4& m, const vec4& v) {
-    return vec4(ptl_row_m<MASK, 0>(m, v), ptl_row_m<MASK, 1>(m, v), ptl_row_m<MASK, 2>(m, v), ptl_row_m<MASK, 3>(m, v));
+template <ptl_mask_t MASK, int W = PTL_W_ANY> PTL_FN vec4 ptl_mul_m(const mat4& m, const vec4& v) {
+    return vec4(ptl_row_m<MASK, 0, W>(m, v), ptl_row_m<MASK, 1, W>(m, v), ptl_row_m<MASK, 2, W>(m, v), ptl_row_m<MASK, 3, W>(m, v));
 }
+// matrix * (a ray's origin) and matrix * (a ray's direction): the plain products unless the kernel was generated with PTL_AFFINE_RAYS
+#ifdef PTL_AFFINE_RAYS
+#define PTL_W_OF_ORIGIN PTL_W_ONE
+#define PTL_W_OF_DIRECTION PTL_W_ZERO
+#else
+#define PTL_W_OF_ORIGIN PTL_W_ANY
+#define PTL_W_OF_DIRECTION PTL_W_ANY
+#endif
+template <ptl_mask_t MASK = 0xffffu> PTL_FN vec4 ptl_mul_origin(const mat4& m, const vec4& o) { return ptl_mul_m<MASK, PTL_W_OF_ORIGIN>(m, o); }
+template <ptl_mask_t MASK = 0xffffu> PTL_FN vec4 ptl_mul_direction(const mat4& m, const vec4& d) { return ptl_mul_m<MASK, PTL_W_OF_DIRECTION>(m, d); }
 // (`X_mat * <anything else>` that the generator rewrote by its shape alone -- a matrix, a scalar: the ordinary product)
 template <ptl_mask_t MASK, class T> PTL_FN auto ptl_mul_m(const mat4& m, const T& x) -> decltype(m * x) { return m * x; }
 // the same product for a matrix that is a run-time value in every build (the camera): no zero tests (they would be executed)
@@ -803,6 +825,12 @@ PTL_FN vec4 ptl_mul_runtime(const mat4& m, const vec4& v) {
                 ptl_term(m.c[3].y, v.w, ptl_term(m.c[2].y, v.z, ptl_term(m.c[1].y, v.y, ptl_term0(m.c[0].y, v.x)))),
                 ptl_term(m.c[3].z, v.w, ptl_term(m.c[2].z, v.z, ptl_term(m.c[1].z, v.y, ptl_term0(m.c[0].z, v.x)))),
                 ptl_term(m.c[3].w, v.w, ptl_term(m.c[2].w, v.z, ptl_term(m.c[1].w, v.y, ptl_term0(m.c[0].w, v.x)))));
+}
+// ... times a DIRECTION, in a kernel with affine rays: the three terms of the upper-left 3 x 3 block, w = 0 (the matrix is affine: capi.cpp `camera_is_affine`)
+PTL_FN vec4 ptl_mul_runtime_direction(const mat4& m, const vec4& v) {
+    return vec4(ptl_term(m.c[2].x, v.z, ptl_term(m.c[1].x, v.y, ptl_term0(m.c[0].x, v.x))),
+                ptl_term(m.c[2].y, v.z, ptl_term(m.c[1].y, v.y, ptl_term0(m.c[0].y, v.x))),
+                ptl_term(m.c[2].z, v.z, ptl_term(m.c[1].z, v.y, ptl_term0(m.c[0].z, v.x))), 0.0f);
 }
 // row vector times matrix: component i is dot(v, column i)
 PTL_FN vec2 operator*(const vec2& v, const mat2& m) { return vec2(dot(v, m.c[0]), dot(v, m.c[1])); }

@@ -84,14 +84,26 @@ PTL_FN Ray transform(const mat4& m, const Ray& r) {
 }
 #else
 PTL_FN Ray transform(const mat4& matrix, const Ray& r) {
+#ifdef PTL_AFFINE_RAYS
+    return Ray{ptl_mul_origin(matrix, r.o), ptl_mul_direction(matrix, r.d), r.tmul, r.in_subspace};  // o.w = 1, d.w = 0 (ptl_glsl.h `ptl_row_m`)
+#else
     return Ray{matrix * r.o, matrix * r.d, r.tmul, r.in_subspace};
+#endif
 }
 #endif
+// PTL_AFFINE_RAYS: the ray with its two w components spelled (they hold these very values): whatever reads them afterwards folds
+PTL_FN Ray ptl_affine(const Ray& r) {
+#ifdef PTL_AFFINE_RAYS
+    return Ray{vec4(r.o.x, r.o.y, r.o.z, 1.0f), vec4(r.d.x, r.d.y, r.d.z, 0.0f), r.tmul, r.in_subspace};
+#else
+    return r;
+#endif
+}
 // transform() for a matrix with a known zero pattern (ptl_mul_m, device/ptl_glsl.h): what the generator writes for `transform(X_mat, ..)`
 // when X_mat is a run-time uniform whose pattern it knows (PTL_MASK_X_mat)
 template <ptl_mask_t MASK> PTL_FN Ray ptl_transform_m(const mat4& matrix, const Ray& r) {
     if constexpr (MASK == 0xffffu) return transform(matrix, r);
-    else return Ray{ptl_mul_m<MASK>(matrix, r.o), ptl_mul_m<MASK>(matrix, r.d), r.tmul, r.in_subspace};
+    else return Ray{ptl_mul_origin<MASK>(matrix, r.o), ptl_mul_direction<MASK>(matrix, r.d), r.tmul, r.in_subspace};
 }
 PTL_FN vec3 get_normal(const mat4& matrix) { return (matrix * vec4(0.0f, 0.0f, 1.0f, 0.0f)).sw<0, 1, 2>(); }
 PTL_FN Ray normalize_ray(Ray r) {
@@ -173,8 +185,8 @@ template <ptl_mask_t MASK = 0xffffu> PTL_FN bool ptl_plane_cull(const Ray& r, co
     (void)r; (void)plane_inv; (void)best_t;
     return false;
 #else
-    const float oz = ptl_row_m<MASK, 2>(plane_inv, r.o);
-    const float dz = ptl_row_m<MASK, 2>(plane_inv, r.d);
+    const float oz = ptl_row_m<MASK, 2, PTL_W_OF_ORIGIN>(plane_inv, r.o);
+    const float dz = ptl_row_m<MASK, 2, PTL_W_OF_DIRECTION>(plane_inv, r.d);
 #if PTL_DEVICE_BUILD
     return __builtin_amdgcn_ballot_w64(!ptl_cannot_be_nearer(oz, dz, best_t)) == 0ull;
 #else
@@ -190,7 +202,7 @@ template <ptl_mask_t MASK = 0xffffu> PTL_FN bool ptl_plane_cull_o(const Ray& r, 
     return false;
 #else
     const float oz = o_in_plane.z;
-    const float dz = ptl_row_m<MASK, 2>(plane_inv, r.d);
+    const float dz = ptl_row_m<MASK, 2, PTL_W_OF_DIRECTION>(plane_inv, r.d);
 #if PTL_DEVICE_BUILD
     return __builtin_amdgcn_ballot_w64(!ptl_cannot_be_nearer(oz, dz, best_t)) == 0ull;
 #else
@@ -227,7 +239,7 @@ PTL_FN SurfaceIntersection plane_intersect_o(Ray r, const mat4& plane_inv, vec3 
     return plane_intersect(r, plane_inv, normal);  // the tolerance mode has its own plane test (same source as the exact build: FLAG_FAST_MATH only adds a define)
 #endif
     normal = normalize_normal(normal, r.d.sw<0, 1, 2>());
-    r = Ray{o_in_plane, plane_inv * r.d, r.tmul, r.in_subspace};
+    r = Ray{o_in_plane, ptl_mul_direction(plane_inv, r.d), r.tmul, r.in_subspace};
     float len = length(r.d);
     r.d = normalize(r.d);
     SurfaceIntersection result = plane_intersect_normalized(r);
@@ -244,7 +256,7 @@ template <ptl_mask_t MASK = 0xffffu> PTL_FN SurfaceIntersection plane_intersect_
 #endif
     flipped = dot(unit_normal, r.d.sw<0, 1, 2>()) > 0.0f;
     if (flipped) unit_normal *= -1.0f;
-    r = Ray{o_in_plane, ptl_mul_m<MASK>(plane_inv, r.d), r.tmul, r.in_subspace};
+    r = Ray{o_in_plane, ptl_mul_direction<MASK>(plane_inv, r.d), r.tmul, r.in_subspace};
     float len = length(r.d);
     r.d = normalize(r.d);
     SurfaceIntersection result = plane_intersect_normalized(r);

@@ -242,6 +242,7 @@ PTL_FN bool trace_segment(Ray& r, vec3& current_color, float& all_t, float camer
 #else
 PTL_FN bool trace_segment(Ray& r, vec3& current_color, float& all_t, float camera_scale, const vec3& not_found_color, RayTraceResult& out) {
 #endif
+    r = ptl_affine(r);  // PTL_AFFINE_RAYS: o.w = 1 and d.w = 0 spelled once per trip (ptl_library.h); otherwise nothing
 #if defined(PTL_BOUNDED_SNIPPETS) && !defined(PTL_SNIPPETS_FIRST)
     // Like the reference (frag.glsl:114-115): scene_intersect first.  Its hit distance then bounds the snippets: a candidate of theirs
     // beyond it could never be the `nearer` one below, and the snippets the generator could prove it for skip such candidates
@@ -487,7 +488,8 @@ PTL_FN vec3 PaniniProjection(vec2 tc, float fov, float d) {
 // of a wave; as a per-lane POINTER the matrix would be read with 16 vector loads at the start of every pixel.  Instead the wave works
 // through the eyes its lanes ask for one at a time (nearly always one): the choice is then uniform and the matrix comes through
 // scalar loads.
-PTL_FN vec4 camera_times(const mat4& camera_matrix, int which_eye, vec4 v) {
+// (`direction`: v is a ray direction, w = 0 -- every call but the one that makes the origin where the prologue kernel does not)
+PTL_FN vec4 camera_times(const mat4& camera_matrix, int which_eye, vec4 v, bool direction = true) {
 #if PTL_DEVICE_BUILD
     (void)camera_matrix;
     vec4 product = vec4(0.0f);
@@ -495,14 +497,26 @@ PTL_FN vec4 camera_times(const mat4& camera_matrix, int which_eye, vec4 v) {
         const int eye = __builtin_amdgcn_readfirstlane(which_eye);
         if (which_eye == eye) {
             const mat4& m = eye == 0 ? _camera : (eye == 1 ? _camera_left_eye : _camera_right_eye);
+#ifdef PTL_AFFINE_RAYS
+            // every caller hands over a DIRECTION (w = 0), and the renderer keeps this kernel only while the camera matrices are affine: the
+            // translation column meets a zero, the w row gives that zero back (ptl_glsl.h `ptl_row_m`, PTL_W_ZERO)
+            product = direction ? ptl_mul_runtime_direction(m, v) : ptl_mul_runtime(m, v);
+#else
             product = ptl_mul_runtime(m, v);  // a run-time matrix in every build: the full chain, no zero tests (ptl_glsl.h `ptl_mterm`)
+#endif
             done = true;
         }
     }
+    (void)direction;
     return product;
 #else
     (void)which_eye;
+    (void)direction;
+#ifdef PTL_AFFINE_RAYS
+    return direction ? ptl_mul_runtime_direction(camera_matrix, v) : ptl_mul_runtime(camera_matrix, v);
+#else
     return ptl_mul_runtime(camera_matrix, v);
+#endif
 #endif
 }
 
@@ -534,7 +548,7 @@ PTL_FN vec3 get_color2(vec2 image_position, const mat4& camera_matrix, bool in_s
 #ifdef PTL_DERIVED_BUILTINS
     vec4 o = camera_origin(which_eye);
 #else
-    vec4 o = camera_times(camera_matrix, which_eye, vec4(0.0f, 0.0f, 0.0f, 1.0f));
+    vec4 o = camera_times(camera_matrix, which_eye, vec4(0.0f, 0.0f, 0.0f, 1.0f), false);
 #endif
     vec4 d;
     if (_use_panini_projection == 1) {

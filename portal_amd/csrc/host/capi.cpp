@@ -123,6 +123,11 @@ struct ptl_renderer {
     std::set<std::string> keep_unmasked;                   // ... and those whose pattern did not hold (clip-constant builds: demoted like keep_dynamic)
     bool shortened = false;    // the current kernel skips zero terms of matrix products (PTL_DROP_ZERO_TERMS and / or masks): exact for finite vectors
     bool full_chains = false;  // a run-time matrix turned non-finite under such a kernel: every later build of this stage keeps the full chains
+    // Affine rays (codegen.h KernelOptions::affine_rays): the current kernel assumes o.w = 1 / d.w = 0, which holds while every matrix that
+    // meets a ray -- the scene's (checked where the zero patterns are, and by the generator) and the CAMERA's (a run-time value in every
+    // build: checked before every draw) -- has the bottom row 0 0 0 1.  One that does not switches the assumption off for this stage.
+    bool affine_rays = false;  // the current kernel was generated with PTL_AFFINE_RAYS
+    bool no_affine = false;    // ... and must not be any more
     // SceneRenderer::update state (src/main.rs:1430-1538)
     Camera prev_cam;
     bool has_prev_cam = false;
@@ -201,6 +206,21 @@ int guarded(const std::function<int()>& fn) {
         set_last_error(std::string("internal error: ") + e.what());
         return PTL_ERR_INVALID;
     }
+}
+
+// The three camera matrices as the kernel gets them (binary32): bottom row 0 0 0 1?  (RotateAroundCam::get_matrix builds an affine basis,
+// src/main.rs:278-304; the accumulated portal matrix in front of it is affine while the portals are.)
+bool camera_is_affine(const ptl_renderer& r) {
+    float f[16];
+    r.cam.matrix().to_f32(f);
+    if (!matrix_is_affine(f)) return false;
+    if (r.draw_side_by_side || r.draw_anaglyph) {
+        r.cam.left_eye_matrix.to_f32(f);
+        if (!matrix_is_affine(f)) return false;
+        r.cam.right_eye_matrix.to_f32(f);
+        if (!matrix_is_affine(f)) return false;
+    }
+    return true;
 }
 
 std::vector<UniformUpload> builtin_uniforms(const ptl_renderer& r, int width, int height) {
@@ -463,6 +483,7 @@ static KernelOptions options_from_flags(unsigned flags) {
     // PTL_FLAG_NO_UNROLL: keep snippet loops with baked bounds as loops (A/B measurements).  The quick build keeps them too: unrolling
     // is half of its hiprtc time for the headline scene (3.4 -> 1.8 s on this container's cores) and buys 0.05 ms of kernel
     o.unroll_baked_loops = (flags & 32768u) == 0 && !o.quick_jit;
+    o.affine_rays = (flags & (1u << 23)) == 0;    // PTL_FLAG_NO_AFFINE_RAYS: matrix-times-ray products never assume o.w = 1 / d.w = 0 (A/B measurements, tests)
     o.first_trip = (flags & 8192u) == 0;          // PTL_FLAG_NO_FIRST_TRIP: no first-trip copies of the intersection-material snippets
     o.hoist_uniform_work = (flags & 4096u) == 0;  // PTL_FLAG_NO_UNIFORM_HOIST: snippets evaluate their uniform-only expressions per ray
     return o;
@@ -476,9 +497,10 @@ static std::map<std::string, int> mode_switches(const ptl_renderer& r) {
 }
 
 static void refresh_generated(ptl_scene* s, unsigned flags, const std::set<std::string>* keep_dynamic = nullptr, const std::map<std::string, int>* switches = nullptr,
-                              const std::set<std::string>* keep_unmasked = nullptr, bool full_chains = false) {
+                              const std::set<std::string>* keep_unmasked = nullptr, bool full_chains = false, bool no_affine = false) {
     KernelOptions opts = options_from_flags(flags);
     opts.full_chains = full_chains;
+    if (no_affine) opts.affine_rays = false;
     opts.mask_cache = &s->mask_cache;
     if (keep_dynamic) opts.keep_dynamic = *keep_dynamic;
     if (keep_unmasked) opts.keep_unmasked = *keep_unmasked;
@@ -752,10 +774,12 @@ static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     if (!(r->kernel_stage == r->scene->current_stage)) r->keep_dynamic.clear();  // another stage / clip: judge afresh what is constant
     if (!(r->kernel_stage == r->scene->current_stage)) r->keep_unmasked.clear();
     if (!(r->kernel_stage == r->scene->current_stage)) r->full_chains = false;
+    if (!(r->kernel_stage == r->scene->current_stage)) r->no_affine = !camera_is_affine(*r);
     r->kernel_switches = mode_switches(*r);
-    refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches, &r->keep_unmasked, r->full_chains);
+    refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches, &r->keep_unmasked, r->full_chains, r->no_affine);
     r->baked = s->last.baked;
     r->masked = s->last.masked;
+    r->affine_rays = s->last.affine_rays;
     r->shortened = !s->last.full_chains && (s->last.masked.size() > 0 || std::find(s->last.defines.begin(), s->last.defines.end(), "PTL_DROP_ZERO_TERMS") != s->last.defines.end());
     r->kernel_stage = r->scene->current_stage;
     if (r->kernel && s->last.source == r->kernel_source) {  // nothing baked in changed
@@ -1017,6 +1041,14 @@ static bool zero_patterns_broken(ptl_renderer* r, const std::vector<UniformUploa
     if (r->shortened && !r->full_chains)
         for (const UniformUpload& v : values)
             if (v.type == UniformType::Mat4 && matrix_breaks_short_chains(v.f)) r->full_chains = broken = true;
+    // ... and a kernel with affine rays is exact while every scene matrix maps w = 1 to 1 and w = 0 to 0 (or is NaN throughout: a switched-off object)
+    if (r->affine_rays && !r->no_affine)
+        for (const UniformUpload& v : values) {
+            if (v.type != UniformType::Mat4 || matrix_is_affine(v.f)) continue;
+            bool all_nan = true;
+            for (int k = 0; k < 16; ++k) all_nan = all_nan && std::isnan(v.f[k]);
+            if (!all_nan) r->no_affine = broken = true;
+        }
     for (auto& [name, mask] : r->masked)
         for (const UniformUpload& v : values) {
             if (v.name != name || v.type != UniformType::Mat4) continue;
@@ -1027,7 +1059,7 @@ static bool zero_patterns_broken(ptl_renderer* r, const std::vector<UniformUploa
             break;
         }
     // one broken pattern says the probes did not see this clip's motion: every mask goes, so that a clip costs at most ONE extra rebuild
-    if (broken)
+    if (!r->keep_unmasked.empty())
         for (auto& m : r->masked) r->keep_unmasked.insert(m.first);
     return broken;
 }
@@ -1045,14 +1077,17 @@ static int activate_kernel(ptl_renderer* r, ptl_kernel* k) {
 // PTL_FLAG_ASYNC_REJIT: pick the kernel for this draw without ever waiting for a compile of the specialised source (see ptl_renderer::Job).
 static int async_select_kernel(ptl_renderer* r) {
     ptl_scene* s = r->owner;
-    const bool changed = r->kernel_scene_version != r->scene->version || !(r->kernel_stage == r->scene->current_stage) || mode_switches(*r) != r->kernel_switches;
+    const bool changed = r->kernel_scene_version != r->scene->version || !(r->kernel_stage == r->scene->current_stage) || mode_switches(*r) != r->kernel_switches ||
+                         (r->affine_rays && !r->no_affine && !camera_is_affine(*r));  // (a camera that stopped being affine: the affine-rays kernel is no longer valid)
     if (!changed && !r->job && r->kernel == r->spec_kernel) return PTL_OK;
     if (changed) {
         if (!(r->kernel_stage == r->scene->current_stage)) {
             r->keep_dynamic.clear();
             r->keep_unmasked.clear();
             r->full_chains = false;
+            r->no_affine = false;
         }
+        if (!camera_is_affine(*r)) r->no_affine = true;
         if ((r->flags & (8u | kPatterns)) != 0 && (r->flags & 5u) == 0) {  // clip-constant specialisation: a compiled-in value that moved becomes a run-time uniform
             std::vector<UniformUpload> values = evaluate_scene_uniforms(*r->scene, nullptr);
             size_t at = 0;
@@ -1064,8 +1099,9 @@ static int async_select_kernel(ptl_renderer* r) {
             zero_patterns_broken(r, values);
         }
         r->kernel_switches = mode_switches(*r);
-        refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches, &r->keep_unmasked, r->full_chains);  // the specialised source of the CURRENT state (generation is milliseconds)
+        refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches, &r->keep_unmasked, r->full_chains, r->no_affine);  // the specialised source of the CURRENT state (generation is milliseconds)
         r->masked = s->last.masked;
+        r->affine_rays = s->last.affine_rays;
         r->shortened = !s->last.full_chains && (s->last.masked.size() > 0 || std::find(s->last.defines.begin(), s->last.defines.end(), "PTL_DROP_ZERO_TERMS") != s->last.defines.end());
         r->want = snapshot_build(s, r->flags);
         r->kernel_scene_version = r->scene->version;
@@ -1139,6 +1175,13 @@ static int prepare_draw(ptl_renderer* r, const ptl_frame* frame) {
     }
     if (!async && (r->flags & kSpecialised) != 0 && mode_switches(*r) != r->kernel_switches) {
         // a camera model / output mode was switched: the specialised kernel has the old one compiled in (and the new one compiled out)
+        int rc = build_kernel(r, nullptr, 0);
+        if (rc != PTL_OK) return rc;
+        ++r->rejit_count;
+    }
+    if (!async && r->affine_rays && !r->no_affine && !camera_is_affine(*r)) {
+        // the camera went through something that is not an affine map: the kernel's w = 1 / w = 0 no longer holds for primary rays
+        r->no_affine = true;
         int rc = build_kernel(r, nullptr, 0);
         if (rc != PTL_OK) return rc;
         ++r->rejit_count;
@@ -1567,7 +1610,9 @@ extern "C" int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16],
 extern "C" ptl_kernel* ptl_renderer_kernel(ptl_renderer* r) {
     if (!r) return nullptr;
     // the kernel the next draw would use: a specialised build follows the mode switches (also on a handle without a device, which never draws)
-    if ((r->flags & kSpecialised) != 0 && !((r->flags & kAsyncRejit) != 0 && r->device >= 0) && mode_switches(*r) != r->kernel_switches) {
+    const bool camera_left_the_affine_maps = r->affine_rays && !r->no_affine && !camera_is_affine(*r);
+    if (camera_left_the_affine_maps && !((r->flags & kAsyncRejit) != 0 && r->device >= 0)) r->no_affine = true;
+    if ((r->flags & kSpecialised) != 0 && !((r->flags & kAsyncRejit) != 0 && r->device >= 0) && (mode_switches(*r) != r->kernel_switches || camera_left_the_affine_maps)) {
         int rc = guarded([&] {
             int rc2 = build_kernel(r, nullptr, 0);
             if (rc2 == PTL_OK) ++r->rejit_count;
@@ -1585,6 +1630,21 @@ extern "C" int ptl_renderer_kernel_source(ptl_renderer* r, char** source) {
     return PTL_OK;
 }
 extern "C" int ptl_renderer_rejit_count(ptl_renderer* r) { return r ? r->rejit_count : -1; }
+extern "C" int ptl_renderer_affine_rays(ptl_renderer* r) { return r ? (r->affine_rays ? 1 : 0) : -1; }
+extern "C" int ptl_snippets_keep_rays_affine(const char* glsl, char* why, size_t why_cap) {
+    if (!glsl) return -1;
+    try {
+        std::string reason;
+        const bool ok = snippets_keep_rays_affine({glsl}, &reason);
+        if (why && why_cap) {
+            std::snprintf(why, why_cap, "%s", ok ? "" : reason.c_str());
+        }
+        return ok ? 1 : 0;
+    } catch (const std::exception& e) {
+        set_last_error(std::string("ptl_snippets_keep_rays_affine: ") + e.what());
+        return -1;
+    }
+}
 extern "C" int ptl_renderer_rejit_pending(ptl_renderer* r) {
     if (!r) return -1;
     return (r->job || (r->spec_kernel != nullptr && r->kernel != r->spec_kernel)) ? 1 : 0;

@@ -650,6 +650,159 @@ bool matrix_breaks_short_chains(const float m[16]) {
     return inf > 0 || (nan > 0 && nan < 16);
 }
 
+bool matrix_is_affine(const float m[16]) { return m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f && m[15] == 1.0f; }
+
+namespace {
+// the significant tokens of a snippet (no spaces, no comments, no preprocessor lines)
+std::vector<Token> significant_tokens(const std::string& code) {
+    std::vector<Token> out;
+    for (Token& t : tokenize_glsl(code))
+        if (t.kind == Token::Ident || t.kind == Token::Number || t.kind == Token::Punct) out.push_back(std::move(t));
+    return out;
+}
+size_t closing_paren(const std::vector<Token>& t, size_t open) {  // index of the `)` that closes t[open] == "(", or t.size()
+    int depth = 0;
+    for (size_t i = open; i < t.size(); ++i) {
+        if (t[i].text == "(" || t[i].text == "[" || t[i].text == "{") ++depth;
+        else if (t[i].text == ")" || t[i].text == "]" || t[i].text == "}") {
+            if (--depth == 0) return i;
+        }
+    }
+    return t.size();
+}
+// t[from, to) split at its top-level commas
+std::vector<std::pair<size_t, size_t>> top_level_parts(const std::vector<Token>& t, size_t from, size_t to) {
+    std::vector<std::pair<size_t, size_t>> parts;
+    int depth = 0;
+    size_t start = from;
+    for (size_t i = from; i < to; ++i) {
+        if (t[i].text == "(" || t[i].text == "[" || t[i].text == "{") ++depth;
+        else if (t[i].text == ")" || t[i].text == "]" || t[i].text == "}") --depth;
+        else if (t[i].text == "," && depth == 0) {
+            parts.emplace_back(start, i);
+            start = i + 1;
+        }
+    }
+    parts.emplace_back(start, to);
+    return parts;
+}
+// t[from, to) is `vec4(<three components in one or three arguments>, <the literal w>)`
+bool is_vec4_with_w(const std::vector<Token>& t, size_t from, size_t to, double w) {
+    if (to < from + 4 || t[from].text != "vec4" || t[from + 1].text != "(" || closing_paren(t, from + 1) != to - 1) return false;
+    auto parts = top_level_parts(t, from + 2, to - 1);
+    if (parts.size() != 2 && parts.size() != 4) return false;
+    auto [a, b] = parts.back();
+    if (b != a + 1 || t[a].kind != Token::Number) return false;
+    char* end = nullptr;
+    const double v = std::strtod(t[a].text.c_str(), &end);
+    return end != t[a].text.c_str() && (*end == '\0' || *end == 'f' || *end == 'F') && v == w;
+}
+}  // namespace
+
+bool snippets_keep_rays_affine(const std::vector<std::string>& codes, std::string* why) {
+    auto refuse = [&](const std::vector<Token>& t, size_t at, const char* what) {
+        if (why) {
+            *why = std::string(what) + ":";
+            for (size_t i = at; i < t.size() && i < at + 12; ++i) *why += " " + t[i].text;
+        }
+        return false;
+    };
+    for (const std::string& code : codes) {
+        const std::vector<Token> t = significant_tokens(code);
+        for (size_t i = 0; i < t.size(); ++i) {
+            // out / inout parameters through which a caller's ray halves could be rewritten
+            if (t[i].kind == Token::Ident && (t[i].text == "out" || t[i].text == "inout") && i + 1 < t.size() && (t[i + 1].text == "Ray" || t[i + 1].text == "vec4"))
+                return refuse(t, i, "an out parameter that can carry a ray half");
+            // Ray( origin, direction, ... ): both halves spelled with their w
+            if (t[i].kind == Token::Ident && t[i].text == "Ray" && i + 1 < t.size() && t[i + 1].text == "(") {
+                const size_t close = closing_paren(t, i + 1);
+                if (close == t.size()) return refuse(t, i, "an unbalanced Ray constructor");
+                auto parts = top_level_parts(t, i + 2, close);
+                if (parts.size() < 2 || !is_vec4_with_w(t, parts[0].first, parts[0].second, 1.0) || !is_vec4_with_w(t, parts[1].first, parts[1].second, 0.0))
+                    return refuse(t, i, "a Ray built from halves whose w is not spelled");
+                continue;
+            }
+            // transform(<matrix>, ray): the matrix must be one the affinity checks see -- a scene uniform by name, not a matrix the snippet computed
+            if (t[i].kind == Token::Ident && t[i].text == "transform" && i + 1 < t.size() && t[i + 1].text == "(" && !(i > 0 && t[i - 1].kind == Token::Ident)) {
+                const size_t close = closing_paren(t, i + 1);
+                if (close == t.size()) return refuse(t, i, "an unbalanced transform call");
+                auto parts = top_level_parts(t, i + 2, close);
+                auto ends_with = [](const std::string& x, const char* tail) { const size_t n = std::strlen(tail); return x.size() > n && x.compare(x.size() - n, n, tail) == 0; };
+                const bool uniform_matrix = parts.size() == 2 && parts[0].second == parts[0].first + 1 && t[parts[0].first].kind == Token::Ident &&
+                                            (ends_with(t[parts[0].first].text, "_mat") || ends_with(t[parts[0].first].text, "_mat_inv") || ends_with(t[parts[0].first].text, "_mat_teleport"));
+                if (!uniform_matrix) return refuse(t, i, "transform() by a matrix that is not a scene uniform");
+                continue;
+            }
+            // <something>.o / .d [.swizzle] <assignment operator>
+            if (t[i].text == "." && i + 2 < t.size() && t[i + 1].kind == Token::Ident && (t[i + 1].text == "o" || t[i + 1].text == "d")) {
+                const bool origin = t[i + 1].text == "o";
+                size_t j = i + 2;
+                bool swizzle = false, touches_w = false;
+                if (t[j].text == "." && j + 1 < t.size() && t[j + 1].kind == Token::Ident) {
+                    swizzle = true;
+                    for (char c : t[j + 1].text) touches_w = touches_w || c == 'w' || c == 'a' || c == 'q';
+                    j += 2;
+                }
+                if (j >= t.size()) break;
+                const std::string& op = t[j].text;
+                const bool assigns = op == "=" || op == "+=" || op == "-=" || op == "*=" || op == "/=" || op == "++" || op == "--";
+                if (!assigns) continue;
+                if (swizzle) {
+                    if (touches_w) return refuse(t, i, "a write to the w of a ray half");
+                    continue;  // x / y / z only
+                }
+                size_t end = j + 1;  // the statement's right-hand side: up to the `;` at this nesting level
+                int depth = 0;
+                while (end < t.size() && !(depth == 0 && t[end].text == ";")) {
+                    if (t[end].text == "(" || t[end].text == "[") ++depth;
+                    else if (t[end].text == ")" || t[end].text == "]") --depth;
+                    ++end;
+                }
+                // the owner of the member, as written: the tokens of `a.b[c]` in front of `.o`
+                size_t own = i;
+                while (own > 0 && (t[own - 1].kind == Token::Ident || t[own - 1].text == ".")) --own;
+                std::string owner;
+                for (size_t k = own; k < i; ++k) owner += t[k].text;
+                auto spells = [&](size_t from, const std::vector<std::string>& words) {
+                    for (size_t k = 0; k < words.size(); ++k)
+                        if (from + k >= end || t[from + k].text != words[k]) return false;
+                    return true;
+                };
+                std::vector<std::string> own_tokens;
+                for (size_t k = own; k < i; ++k) own_tokens.push_back(t[k].text);
+                auto member = [&](const char* half) {
+                    std::vector<std::string> w = own_tokens;
+                    w.push_back(".");
+                    w.push_back(half);
+                    return w;
+                };
+                if (origin && op == "+=") {  // X.o += X.d * <scalar expression>: w moves by 0 * s
+                    std::vector<std::string> lead = member("d");
+                    lead.push_back("*");
+                    if (spells(j + 1, lead)) continue;
+                }
+                if (op == "=") {
+                    if (is_vec4_with_w(t, j + 1, end, origin ? 1.0 : 0.0)) continue;  // X.o = vec4(.., 1.) / X.d = vec4(.., 0.)
+                    if (!origin) {  // X.d = normalize(X.d)
+                        std::vector<std::string> call = {"normalize", "("};
+                        for (auto& w : member("d")) call.push_back(w);
+                        call.push_back(")");
+                        if (spells(j + 1, call) && j + 1 + call.size() == end) continue;
+                    } else {  // X.o = X.o + X.d * <scalar expression>
+                        std::vector<std::string> lead = member("o");
+                        lead.push_back("+");
+                        for (auto& w : member("d")) lead.push_back(w);
+                        lead.push_back("*");
+                        if (spells(j + 1, lead)) continue;
+                    }
+                }
+                return refuse(t, own, "a ray half assigned in a form that is not known to keep its w");
+            }
+        }
+    }
+    return true;
+}
+
 GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& flags, const KernelOptions& opts) {
     GeneratedKernel gk;
     std::map<std::string, StringStorage> storages;
@@ -803,6 +956,31 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                     opts.mask_cache->masked = gk.masked;
                 }
             }
+        }
+        // --- affine rays (KernelOptions::affine_rays): every matrix of the scene maps w = 1 to 1 and w = 0 to 0 (bottom row 0 0 0 1) -- or is NaN in
+        // every element (a switched-off object: its products are NaN whatever the w) -- and no scene snippet writes a ray's w.  Only in builds
+        // that may shorten products at all (the same deviation for non-finite rays, the same guard), i.e. never in the un-specialised build.
+        if (opts.affine_rays && !opts.exact_cr && !opts.fast_math && !gk.full_chains && (opts.mask_zero_elements || opts.specialize_all || opts.specialize_static)) {
+            bool affine = true;
+            // (a matrix that stays a run-time value: what holds now is checked again by the renderer before every upload that could change it
+            // -- capi.cpp `zero_patterns_broken` for the builds that keep their kernel across scene states; the others come back here)
+            for (auto& up : evaluate_scene_uniforms(scene, nullptr)) {
+                if (up.type != UniformType::Mat4) continue;
+                bool all_nan = true;
+                for (int k = 0; k < 16; ++k) all_nan = all_nan && std::isnan(up.f[k]);
+                affine = affine && (all_nan || matrix_is_affine(up.f));
+            }
+            if (affine) {
+                std::vector<std::string> codes;
+                for (const NamedCode& lib : scene.library) codes.push_back(filter_tagged_lines(lib.code, flags));
+                for (const Material& m : scene.materials)
+                    if (m.kind == Material::Complex) codes.push_back(filter_tagged_lines(m.code, flags));
+                for (const Object& o : scene.objects)
+                    if (o.kind == Object::Flat || o.kind == Object::Complex) codes.push_back(filter_tagged_lines(o.code, flags));
+                for (const NamedCode& im : scene.intersection_materials) codes.push_back(filter_tagged_lines(im.code, flags));
+                affine = snippets_keep_rays_affine(codes, nullptr);
+            }
+            gk.affine_rays = affine;
         }
         // (KernelOptions::baked_options is only filled in for builds that may compile the switches in: any specialisation, patterns-only included)
         for (auto& [name, value] : opts.baked_options)
@@ -992,10 +1170,12 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             std::string m1 = "teleport_" + std::to_string(pos) + "_1_M", m2 = "teleport_" + std::to_string(pos) + "_2_M";
             defines.add_string("#define " + m1 + " (USER_MATERIAL_OFFSET + " + std::to_string(counter++) + ")\n");
             defines.add_string("#define " + m2 + " (USER_MATERIAL_OFFSET + " + std::to_string(counter++) + ")\n");
+            // material_teleport(hit, r, M) (library.glsl:366-379) spelled as its body: behind the function parameter the product with M is out of
+            // reach of the zero / unit patterns (apply_zero_masks rewrites `transform(<uniform>, ..)` by name) -- the same two calls, same values
             processing.add_string("} else if (i.material == " + m1 + ") {\n");
-            processing.add_string("return material_teleport(hit, r, " + teleport_name(a, b) + ");");
+            processing.add_string("return material_teleport_transformed(transform(" + teleport_name(a, b) + ", r), hit.n);");
             processing.add_string("} else if (i.material == " + m2 + ") {\n");
-            processing.add_string("return material_teleport(hit, r, " + teleport_name(b, a) + ");");
+            processing.add_string("return material_teleport_transformed(transform(" + teleport_name(b, a) + ", r), hit.n);");
         }
         storages["material_processing"] = std::move(processing);
         storages["materials_defines"] = std::move(defines);
@@ -1252,6 +1432,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     if (opts.quick_jit) gk.defines.push_back("PTL_QUICK_JIT");
     // matrices baked into the source: a matrix product skips the terms whose matrix element is zero (device/ptl_glsl.h `ptl_mterm`)
     if ((opts.specialize_all || opts.specialize_static) && !opts.exact_cr && !opts.fast_math && !gk.full_chains) gk.defines.push_back("PTL_DROP_ZERO_TERMS");
+    if (gk.affine_rays) gk.defines.push_back("PTL_AFFINE_RAYS");
     if (gk.first_trip_variants) gk.defines.push_back("PTL_FIRST_TRIP");
     if (gk.looped_snippets) gk.defines.push_back("PTL_JIT_MODULE_INLINER");
     if (gk.bounded_snippet_blocks > 0) gk.defines.push_back("PTL_BOUNDED_SNIPPETS");

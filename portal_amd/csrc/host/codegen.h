@@ -147,6 +147,12 @@ struct KernelOptions {
     // frame (src/main.rs:1798 re-draws with `_aa_start` windows one after the other) -- so that their ramps and tails overlap.  Applied to the
     // generated text by substitution (codegen.cpp `apply_slices_entry`): kernels built without it are byte for byte what they were.
     bool slices_entry = false;
+    // Affine rays (round 5): in a kernel whose every scene matrix is KNOWN to have the bottom row 0 0 0 1 (baked, or through its pattern) and
+    // whose scene snippets never write a ray's w, every origin has w = 1 and every direction w = 0, and the products of a matrix with a ray
+    // say so (device/ptl_glsl.h PTL_AFFINE_RAYS): the translation column costs a direction nothing, the w row folds to a constant.  Exact for
+    // finite rays -- the guard and the stated deviation of the shortened products (full_chains).  The renderer switches it off, and rebuilds,
+    // when a CAMERA matrix (a run-time value in every build) is not affine (GeneratedKernel::affine_rays says whether the kernel has it).
+    bool affine_rays = true;
     bool quick_jit = false;  // PTL_QUICK_JIT: compile at -O1 instead of the shipped -O3 (half the JIT time, a 5-20 % slower kernel)
     bool fast_math = false;  // PTL_FAST_MATH: hardware rcp / sqrt / rsq (1 ulp), a/b = a * rcp(b), FMA contraction: tolerance mode, not bit-exact
 };
@@ -174,6 +180,7 @@ struct GeneratedKernel {
     std::vector<std::pair<std::string, MatrixPattern>> masked;  // run-time matrices whose pattern is compiled in (MatrixPattern)
     int bounded_snippet_blocks = 0;     // `nearer` blocks of intersection-material snippets that take the caller's distance bound (define PTL_BOUNDED_SNIPPETS)
     bool full_chains = false;           // a matrix of the scene is not finite (or KernelOptions::full_chains): no product was shortened
+    bool affine_rays = false;           // generated with PTL_AFFINE_RAYS: valid while the camera matrices have the bottom row 0 0 0 1
 };
 
 // Scene::uniforms (scene.rs:424-543): names and types, in the reference's order.
@@ -185,6 +192,14 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
 // A matrix with infinite elements, or with NaN beside numbers: its products carry +-inf components, for which a product that skips zero
 // terms differs from the full chain (KernelOptions::full_chains).  An all-NaN matrix does not (all-NaN vectors stay NaN either way).
 bool matrix_breaks_short_chains(const float m[16]);
+// Bottom row exactly 0 0 0 1 (column-major elements 3, 7, 11, 15): an affine map -- it keeps the w of a point at 1 and of a direction at 0.
+bool matrix_is_affine(const float m[16]);
+inline bool pattern_is_affine(MatrixPattern p) { return (p & ((1ull << 3) | (1ull << 7) | (1ull << 11))) == 0 && ((p >> (16 + 15)) & 1ull) != 0; }
+// Do the scene's GLSL snippets keep rays affine?  True unless one of them builds a Ray from parts that are not spelled `vec4(.., 1.)` /
+// `vec4(.., 0.)`, assigns a ray's `.o` / `.d` in another than a whitelisted form, calls transform() with a matrix that is not a scene uniform
+// (`X_mat`, `X_mat_inv`, `A_to_B_mat_teleport`: the ones whose values are checked), or has an out / inout parameter of type Ray or vec4
+// (KernelOptions::affine_rays; conservative: a refusal only costs the optimisation).  `why` receives the offending text.
+bool snippets_keep_rays_affine(const std::vector<std::string>& codes, std::string* why);
 
 // All scene-derived uniforms: X_mat, X_mat_inv, A_to_B_mat_teleport, user uniforms.
 // `errors` receives the reference's "matrix `x` can't be getted" style messages.

@@ -792,3 +792,69 @@ def test_teleport_queries_of_a_split_build_equal_the_one_module_build(gpu, monke
     assert split == whole
     if scene_name != "portal_in_portal":  # (its portals live in an intersection-material snippet: no *_mat_teleport uniform to aim the rays with)
         assert sum(1 for s in split if isinstance(s, str) and s.startswith("((")) >= 2  # some rays did go through a portal
+
+
+# ---- affine rays (round 5): o.w = 1 / d.w = 0 spelled in the matrix-times-ray products ---------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name,w,h,depth,moves", [
+    ("monoportal", 640, 360, 20, ("portal_rotate_angle", 0.37)),
+    ("triple_portal", 640, 360, 40, ("room_size_x", 7.3)),
+    ("portal_in_portal", 640, 360, 40, ("progress", 0.37)),
+    ("basics", 256, 256, 4, ("room_size_y", 5.1)),
+    ("mobius_monoportal", 320, 180, 64, ("mobius_rotate_local_oy", 0.5))])
+def test_affine_rays_change_no_bit(gpu, scene_name, w, h, depth, moves):
+    """Builds that may shorten products spell what every ray of the reference satisfies -- an origin has w = 1, a direction w = 0 -- in their
+    matrix-times-ray products (PTL_AFFINE_RAYS; headline kernel -16 %).  The same operations on the same values: float frames identical to
+    the general products (FLAG_NO_AFFINE_RAYS), for the Int-baked, the patterns-only and the fully baked build, before and after a scene
+    uniform moved, through Panini and from another camera position."""
+    pa = gpu
+    for label, flags in (("ints", pa.FLAG_SPECIALIZE_INTS), ("patterns", pa.FLAG_SPECIALIZE_PATTERNS), ("baked", pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)):
+        frames = {}
+        for name, extra in (("affine", 0), ("general", pa.FLAG_NO_AFFINE_RAYS)):
+            scene = pa.Scene.from_file(pa.scene_path(scene_name))
+            r = pa.SceneRenderer(scene, device=0, flags=flags | extra)
+            assert r.affine_rays() == (extra == 0), (scene_name, label)
+            r.set_option("render_depth", depth)
+            first = r.draw(w, h, rgba32f=True, rgba8=True)
+            assert scene.set_uniform(*moves)
+            moved = r.draw(w, h, rgba32f=True)["rgba32f"].copy()
+            r.set_option("use_panini_projection", 1)
+            r.set_option("view_angle", 2.2)
+            r.move_camera((0.1, -0.2, 0.3), 1.9, 1.3, 2.7)
+            panini = r.draw(w, h, rgba32f=True)["rgba32f"].copy()
+            frames[name] = (first["rgba32f"].copy(), first["rgba8"].copy(), moved, panini)
+        for k in range(4):
+            a, b = frames["affine"][k], frames["general"][k]
+            assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), (scene_name, label, k)
+        assert not np.array_equal(_bits(frames["general"][0]), _bits(frames["general"][2]))
+
+
+@pytest.mark.gpu
+def test_a_camera_that_is_not_affine_switches_affine_rays_off(gpu):
+    """The camera matrices are run-time values in every build.  A camera whose accumulated portal matrix has a bottom row of its own (here: a
+    named camera of the scene file) makes the next draw rebuild without affine rays; the frame is the one the general kernel draws."""
+    pa = gpu
+    text = open(pa.scene_path("basics")).read()
+    cam_text = text.replace("matrix: (1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0),", "matrix: (1.0, 0.0, 0.0, 0.125, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0),", 1)
+    assert cam_text != text
+    spec = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
+    frames = {}
+    for name, flags in (("default", spec), ("general", spec | pa.FLAG_NO_AFFINE_RAYS), ("patterns", pa.FLAG_SPECIALIZE_PATTERNS), ("async", spec | pa.FLAG_ASYNC_REJIT)):
+        r = pa.SceneRenderer(pa.Scene.from_text(cam_text), device=0, flags=flags)
+        r.set_option("render_depth", 8)
+        before = r.draw(160, 90, rgba32f=True)["rgba32f"].copy()
+        r.use_camera("doorway")
+        after = r.draw(160, 90, rgba32f=True)["rgba32f"].copy()
+        if name == "async":
+            import time
+
+            deadline = time.time() + 120
+            while r.rejit_pending() and time.time() < deadline:
+                time.sleep(0.05)
+                after = r.draw(160, 90, rgba32f=True)["rgba32f"].copy()
+        assert not r.affine_rays()
+        frames[name] = (before, after)
+    for name in ("default", "patterns", "async"):
+        assert np.array_equal(_bits(frames[name][0]), _bits(frames["general"][0])), name
+        assert np.array_equal(_bits(frames[name][1]), _bits(frames["general"][1])), name
+    assert not np.array_equal(_bits(frames["general"][0]), _bits(frames["general"][1]))

@@ -1368,7 +1368,8 @@ def test_a_matrix_with_infinities_keeps_every_full_chain(pa):
 def test_generated_defines_go_with_the_generated_source(pa):
     scene = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
     spec = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
-    for flags, want in ((0, {"PTL_FIRST_TRIP"}), (spec, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS"}), (spec | pa.FLAG_EXACT_CR, {"PTL_FIRST_TRIP", "PTL_CONTRACT_V1"}),
+    for flags, want in ((0, {"PTL_FIRST_TRIP"}), (spec, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}), (spec | pa.FLAG_NO_AFFINE_RAYS, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS"}),
+                        (pa.FLAG_SPECIALIZE_PATTERNS, {"PTL_FIRST_TRIP", "PTL_AFFINE_RAYS"}), (spec | pa.FLAG_EXACT_CR, {"PTL_FIRST_TRIP", "PTL_CONTRACT_V1"}),
                         (spec | pa.FLAG_FAST_MATH, {"PTL_FIRST_TRIP", "PTL_FAST_MATH"}), (pa.FLAG_COUNT_SEGMENTS | pa.FLAG_ANAGLYPH, {"PTL_FIRST_TRIP", "PTL_COUNT_SEGMENTS", "PTL_ANAGLYPH"})):
         scene.generate_source(flags)
         # (PTL_JIT_MODULE_INLINER: this scene's intersection-material snippet loops, and with the Ints baked the loop is force-unrolled -- the
@@ -1376,7 +1377,7 @@ def test_generated_defines_go_with_the_generated_source(pa):
         assert set(scene.generated_defines()) == want | ({"PTL_JIT_MODULE_INLINER"} if flags & pa.FLAG_SPECIALIZE_INTS else set()), flags
     mono = pa.Scene.from_file(pa.scene_path("monoportal"))
     mono.generate_source(spec)
-    assert set(mono.generated_defines()) == {"PTL_DROP_ZERO_TERMS"}  # no looping snippet: the toolchain's default inliner
+    assert set(mono.generated_defines()) == {"PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}  # no looping snippet: the toolchain's default inliner
 
 
 def test_renderer_options_given_at_creation_are_in_the_first_build(pa, tmp_path, monkeypatch):
@@ -1809,3 +1810,84 @@ def test_code_object_metadata_is_read_per_kernel(pa, monkeypatch):
     assert r.code_object_note(".vgpr_count") > r.code_object_note(".vgpr_count", "ptl_derive") > 0
     assert r.code_object_note(".vgpr_count", "no_such_kernel") == r.code_object_note(".vgpr_count", "")   # no kernel of that name: every kernel counts
     assert r.code_object_note(".no_such_key") == -1 and len(r.code_object_sha256()) == 64
+
+
+# ---- affine rays (round 5) -----------------------------------------------------------------------------------------------------------
+def test_affine_rays_scan_of_the_scene_snippets(pa):
+    """codegen.cpp `snippets_keep_rays_affine`: what a snippet may do to a ray while every origin keeps w = 1 and every direction w = 0 --
+    library transforms by scene matrices, offsets along the direction, halves spelled with their w -- and what switches the optimisation off."""
+    keeps = ["Ray r3 = transform(b0_mat_inv, r_b); r3 = normalize_ray(r3);", "r.o += r.d * _offset_after_material;", "r.o = r.o + r.d * (_offset_after_material + hit.t);",
+             "r.d = vec4(m * (inverse(n) * r.d.xyz), 0.);", "r.o = vec4(f(i.u, i.v), 1.0);", "return Ray(vec4(mobius_o(u), 1.), vec4(mobius_d(u), 0.), 1.0, false);",
+             "r_mob.d = normalize(r_mob.d);", "r.o.xyz -= offset_box; r.o.x += a - b;", "if (r.o == r.d) { float w = r.o.w + r.d.w; }",
+             "Ray q = transform(a_mat, transform(b0_mat_inv, r_b)); q = transform(a_to_b_mat_teleport, q);", "vec4 p = b0_mat * (a_mat_inv * pos);", "// r.d = -r.d;\nfloat x = 1.;"]
+    refused = {"Ray q = Ray(ray_o, ray_d, 1.0, false);": "Ray built from halves", "r.o -= center;": "not known to keep its w", "r.d = -r.d;": "not known to keep its w",
+               "r.o.w = 2.;": "write to the w", "r.d.xw += vec2(1.);": "write to the w", "void f(inout Ray r) { }": "out parameter", "void g(out vec4 p) { p = vec4(0.); }": "out parameter",
+               "r.d = get_mat(int(hit.v)) * r.d;": "not known to keep its w", "r.o = vec4(p, 0.);": "not known to keep its w", "r.d = normalize(q.d);": "not known to keep its w",
+               "x.d /= 2.;": "not known to keep its w", "r3 = transform(mat_transform_inv, r);": "not a scene uniform", "Ray q = transform(inverse(a_mat), r);": "not a scene uniform",
+               "Ray q = Ray(vec4(o, 1.), vec4(d, 1.), 1., false);": "Ray built from halves", "Ray q = Ray(vec4(o.x, o.y, 1.), vec4(d, 0.), 1., false);": "Ray built from halves"}
+    for code in keeps:
+        assert pa.snippets_keep_rays_affine(code) == (True, ""), code
+    for code, why in refused.items():
+        ok, said = pa.snippets_keep_rays_affine(code)
+        assert not ok and why in said, (code, said)
+
+
+def test_affine_rays_are_generated_only_where_they_hold(pa, tmp_path):
+    """Which builds get PTL_AFFINE_RAYS: a build that may shorten products, of a scene whose matrices all have the bottom row 0 0 0 1 (or are NaN
+    throughout) and whose snippets pass the scan -- never the un-specialised build, contract 1, the tolerance mode or a kernel that keeps its
+    full chains; a renderer whose camera leaves the affine maps rebuilds without it."""
+    spec = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
+
+    def has(scene, flags):
+        scene.generate_source(flags)
+        return "PTL_AFFINE_RAYS" in scene.generated_defines()
+
+    for name in ("basics", "monoportal", "triple_portal", "portal_in_portal", "mobius_monoportal"):
+        scene = pa.Scene.from_file(pa.scene_path(name))
+        assert [has(scene, f) for f in (0, pa.FLAG_SPECIALIZE_INTS, pa.FLAG_SPECIALIZE_PATTERNS, pa.FLAG_SPECIALIZE_STATIC, spec)] == [False, True, True, True, True], name
+        assert not has(scene, spec | pa.FLAG_NO_AFFINE_RAYS) and not has(scene, spec | pa.FLAG_EXACT_CR) and not has(scene, spec | pa.FLAG_FAST_MATH)
+    corpus = os.path.join(os.path.dirname(os.path.abspath(__file__)), "corpus", "scenes")
+    # a Ray from unknown halves / a matrix the snippet computes itself: refused by the scan
+    for name in ("half_spheres", "portal_in_portal_plus_ultra", "trefoil", "cylinder"):
+        assert not has(pa.Scene.from_file(os.path.join(corpus, name + ".ron")), spec), name
+    # a projective matrix among the scene's uniforms (bottom row 0.25 0 0 1): no affine rays, in any build
+    text = open(pa.scene_path("basics")).read()
+    exact_full = ('data: ExactFull(c0: (x: Value(1.0), y: Value(0.0), z: Value(0.0), w: Value(0.25)), c1: (x: Value(0.0), y: Value(1.0), z: Value(0.0), w: Value(0.0)), '
+                  'c2: (x: Value(0.0), y: Value(0.0), z: Value(1.0), w: Value(0.0)), c3: (x: Value(0.5), y: Value(0.0), z: Value(0.0), w: Value(1.0)))')
+    import re
+
+    m = re.search(r'name: "room_red",\s*data: \w+\((?:[^()]|\([^()]*\))*\)', text)
+    assert m, "basics.ron: the matrix `room_red`"
+    projective = pa.Scene.from_text(text[:m.start()] + 'name: "room_red", ' + exact_full + text[m.end():])
+    assert not has(projective, spec) and not has(projective, pa.FLAG_SPECIALIZE_INTS)
+    # the camera is a run-time value in every build: one that is not affine (a named camera whose teleport matrix has a bottom row of its own)
+    cam_text = text.replace("matrix: (1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0),", "matrix: (1.0, 0.0, 0.0, 0.125, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0),", 1)
+    assert cam_text != text
+    for flags in (spec, pa.FLAG_SPECIALIZE_PATTERNS):
+        r = pa.SceneRenderer(pa.Scene.from_text(cam_text), device=-1, flags=flags | pa.FLAG_QUICK_JIT)
+        assert r.affine_rays() and r.rejit_count() == 0
+        r.use_camera("doorway")
+        assert not r.affine_rays() and r.rejit_count() == 1
+        r.use_camera("red")   # back among the affine maps: the assumption stays off for this stage (one rebuild, not one per camera move)
+        assert not r.affine_rays() and r.rejit_count() == 1
+
+
+@pytest.mark.parametrize("name, depth", [("basics", 6), ("monoportal", 10), ("triple_portal", 10), ("portal_in_portal", 8), ("mobius_monoportal", 12)])
+def test_affine_rays_draw_the_bits_of_the_general_products(pa, name, depth):
+    """PTL_AFFINE_RAYS spells o.w = 1 / d.w = 0 in the matrix-times-ray products: the same operations on the same values.  The host build of
+    the generated source draws the same bits with and without it -- Int-baked (masked matrices), patterns-only, everything baked -- and (through
+    tests/test_corpus.py, whose builds have it on) the bits of the numpy oracle, which knows nothing of it."""
+    from oracle import host_build as hb
+
+    w, h = 64, 36
+    for label, flags in (("ints", pa.FLAG_SPECIALIZE_INTS), ("patterns", pa.FLAG_SPECIALIZE_PATTERNS), ("baked", pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)):
+        frames = []
+        for extra in (0, pa.FLAG_NO_AFFINE_RAYS):
+            sc = pa.Scene.from_file(pa.scene_path(name))
+            r = pa.SceneRenderer(sc, device=-1, flags=flags | extra | pa.FLAG_QUICK_JIT)
+            r.set_option("render_depth", depth)
+            src = sc.generate_source(flags | extra)
+            assert ("PTL_AFFINE_RAYS" in sc.generated_defines()) == (extra == 0), (name, label)
+            frames.append(hb.host_kernel_for(r, sc, w, h, flags=flags | extra).render(w, h)["rgba32f"].copy())
+        assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)), (name, label)
+        assert len(np.unique(frames[0].reshape(-1, 4), axis=0)) > 50

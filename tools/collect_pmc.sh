@@ -19,4 +19,4 @@ for group in "${GROUPS_[@]}"; do
     i=$((i + 1))
     rocprofv3 --pmc $group --output-format csv -d /tmp/pmc_$NAME/p$i -o p -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-segments --no-second-workload --build $BUILD ${BENCH_ARGS:-} > /tmp/pmc_$NAME.log 2>&1 || tail -3 /tmp/pmc_$NAME.log
 done
-python $R/tools/pmc_summary.py $O/$NAME.json "${WORKLOAD:-portal_in_portal 3840x2160 depth 40, all scene uniforms baked, build $BUILD, flags '${PTL_HIPRTC_FLAGS:-}', 1 GPU; the 5 timed launches of each pass; FETCH_SIZE / WRITE_SIZE in KB}" 5 /tmp/pmc_$NAME/p*
+PMC_BENCH_LOG=/tmp/pmc_$NAME.log python $R/tools/pmc_summary.py $O/$NAME.json "${WORKLOAD:-portal_in_portal 3840x2160 depth 40, all scene uniforms baked, build $BUILD, flags '${PTL_HIPRTC_FLAGS:-}', 1 GPU; the 5 timed launches of each pass; FETCH_SIZE / WRITE_SIZE in KB}" 5 /tmp/pmc_$NAME/p*

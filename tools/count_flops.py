@@ -47,7 +47,16 @@ CONFIGS = {  # name: (scene, width, height, depth, aa, sample fraction of the fr
 }
 
 
-def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None):
+def _scene_path(pa, scene):
+    """`scene`: a name under scenes/, or a repo-relative .ron path (the reference's corpus under tests/corpus/scenes)"""
+    return os.path.join(HERE, scene) if scene.endswith(".ron") else pa.scene_path(scene)
+
+
+def _scene_kw(scene):
+    return {"asset_root": os.path.dirname(os.path.dirname(os.path.join(HERE, scene)))} if scene.endswith(".ron") else {}
+
+
+def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None, camera=None):
     import portal_amd as pa
     from oracle import glsl_math as M
     from oracle.portal_oracle import Oracle
@@ -56,10 +65,12 @@ def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None
     _vary_the_camera_between_lanes()
     _meter_the_generated_plane_tests()
     PLANE_METER.update(flops=0.0, flops_varying=0.0, lane_tests=0.0)
-    o = Oracle(pa.scene_path(scene))
+    o = Oracle(_scene_path(pa, scene), **_scene_kw(scene))
     o.options.update(render_depth=depth, aa_count=aa)
     if options:
         o.options.update(options)
+    if camera:
+        o.camera = dict(look_at=tuple(camera[:3]), alpha=camera[3], beta=camera[4], r=camera[5])
     rng = np.random.default_rng(seed)
     n = int(round(w * h * frac))
     flat = rng.choice(w * h, size=n, replace=False)
@@ -72,12 +83,12 @@ def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None
             total[k] = total.get(k, 0.0) + float(v)
     seg = total.pop("segments")
     per_segment = {k: v / seg for k, v in total.items()}
-    deferred = deferred_update_counts(scene, w, h, depth, aa, options)
+    deferred = deferred_update_counts(scene, w, h, depth, aa, options, camera=camera)
     if deferred:
         skipped = deferred["flops_per_update"] * (deferred["scheduled_per_segment"] - deferred["applied_per_segment"])
         per_segment["flops_executed"] = per_segment["flops"] - skipped
         per_segment["flops_varying_executed"] = per_segment["flops_varying"] - skipped
-    culls = plane_cull_counts(scene, w, h, depth, aa, options)
+    culls = plane_cull_counts(scene, w, h, depth, aa, options, camera=camera)
     if culls and PLANE_METER["lane_tests"]:
         per_test = {k: PLANE_METER[k] / PLANE_METER["lane_tests"] for k in ("flops", "flops_varying")}
         culls["oracle_flops_per_plane_test"] = per_test
@@ -102,6 +113,13 @@ def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None
         base = per_segment.get("flops_varying_executed", per_segment["flops_varying"])
         per_segment["zero_term_flops_varying"] = zero_terms
         per_segment["flops_varying_executed_baked"] = base - zero_terms * min(1.0, base / per_segment["flops_varying"]) if share < 1 else base
+        # round 5: +-1 matrix elements (the multiplication of fma(+-1, x, acc) is not executed: one add) and, in a kernel with affine rays,
+        # the terms that meet a ray's w (a direction's 0: skipped; an origin's 1: `acc + element`) -- scaled like the zero terms
+        scale = min(1.0, base / per_segment["flops_varying"]) if share < 1 else 0.0
+        unit = per_segment.get("unit_term_flops_varying", 0.0)
+        known_w = per_segment.get("known_w_term_flops_varying", 0.0)
+        per_segment["flops_varying_executed_baked_units"] = per_segment["flops_varying_executed_baked"] - unit * scale
+        per_segment["flops_varying_executed_baked_affine"] = per_segment["flops_varying_executed_baked_units"] - known_w * scale
     return {
         "first_trip_origin_arithmetic": first,
         "scene": scene, "width": w, "height": h, "depth": depth, "aa": aa,
@@ -182,7 +200,7 @@ def _meter_the_generated_plane_tests():
     Natives.plane_intersect = plane_intersect
 
 
-def plane_cull_counts(scene_name, w, h, depth, aa, options=None, row_step=61):
+def plane_cull_counts(scene_name, w, h, depth, aa, options=None, row_step=61, camera=None):
     """Generated plane tests and how many of them ptl_plane_cull skips, per bounce-loop trip, counted per ray on the host build of the
     baked source (rows row_step/2, +row_step, ... of the full-size frame).  None when the source has no culled test."""
     import ctypes as C
@@ -190,19 +208,21 @@ def plane_cull_counts(scene_name, w, h, depth, aa, options=None, row_step=61):
     import portal_amd as pa
     from oracle import host_build as hb
 
-    scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    scene = pa.Scene.from_file(_scene_path(pa, scene_name))
     source = scene.generate_source(pa.FLAG_COUNT_SEGMENTS)
-    needle = "    return behind || (t_low > best_t && abs(dz) >= 0x1p-100f);"
-    if needle not in source or "ptl_plane_cull(r," not in source:
+    needle = "    return ptl_cannot_be_nearer(oz, dz, best_t);\n"  # the host form of ptl_plane_cull / ptl_plane_cull_o (one sign test since round 4)
+    if needle not in source or "ptl_plane_cull" not in source:
         return None
     source = source.replace("namespace glsl {\n", "namespace glsl {\nstatic long ptl_cull_stats[2] = {0, 0};\n", 1)
-    source = source.replace(needle, "    { const bool ptl_c = behind || (t_low > best_t && abs(dz) >= 0x1p-100f); __atomic_fetch_add(&ptl_cull_stats[ptl_c ? 1 : 0], 1, __ATOMIC_RELAXED); return ptl_c; }")
+    source = source.replace(needle, "    { const bool ptl_c = ptl_cannot_be_nearer(oz, dz, best_t); __atomic_fetch_add(&ptl_cull_stats[ptl_c ? 1 : 0], 1, __ATOMIC_RELAXED); return ptl_c; }\n")
     source += '\nextern "C" long* ptl_cull_stats_ptr() { return glsl::ptl_cull_stats; }\n'
-    renderer = pa.SceneRenderer(scene, device=-1)
+    renderer = pa.SceneRenderer(scene, device=-1, **_scene_kw(scene_name))
     renderer.set_option("render_depth", depth)
     renderer.set_option("aa_count", aa)
     for k, v in (options or {}).items():
         renderer.set_option({"use_panini": "use_panini_projection"}.get(k, k), float(v))
+    if camera:
+        renderer.set_camera(camera[:3], camera[3], camera[4], camera[5])
     layout, size = scene.uniform_layout()
     hk = hb.HostKernel(source, layout, size, True)
     for name, typ, _ in layout:
@@ -236,10 +256,10 @@ def first_trip_origin_flops(scene_name, w, h, options=None):
 
     import portal_amd as pa
 
-    scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    scene = pa.Scene.from_file(_scene_path(pa, scene_name))
     source = scene.generate_source(pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
     total, sites = 0, []
-    for m in re.finditer(r"PTL_FN SceneIntersectionWithMaterial intersect_material_\d+_first\(Ray r\) \{", source):
+    for m in re.finditer(r"PTL_FN SceneIntersectionWithMaterial intersect_material_\d+_first\(Ray r(?:, float ptl_far)?\) \{", source):
         body = source[m.end():source.index("\n}\n", m.end())]
         bound = re.search(r"const bool ptl_tab_ok_\d+ = \((\w+)\) <= \d+;", body)
         if not bound:
@@ -263,7 +283,7 @@ def first_trip_origin_flops(scene_name, w, h, options=None):
     return {"flops_per_first_trip": total, "sites": sites, "iterations": iterations, "note": "28 binary32 operations per mat4 x vec4 (4 x (1 mul + 3 fma))"}
 
 
-def deferred_update_counts(scene_name, w, h, depth, aa, options=None, row_step=61):
+def deferred_update_counts(scene_name, w, h, depth, aa, options=None, row_step=61, camera=None):
     """Deferred loop-carried updates of the generated source: scheduled vs applied per bounce-loop trip, counted on the host build
     (rows row_step/2, +row_step, ... of the full-size frame).  None when the scene has no such update."""
     import re
@@ -271,7 +291,7 @@ def deferred_update_counts(scene_name, w, h, depth, aa, options=None, row_step=6
     import portal_amd as pa
     from oracle import host_build as hb
 
-    scene = pa.Scene.from_file(pa.scene_path(scene_name))
+    scene = pa.Scene.from_file(_scene_path(pa, scene_name))
     source = scene.generate_source(pa.FLAG_COUNT_SEGMENTS)
     updates = re.findall(r"for \(; (ptl_pend_\d+) > 0; --\1\) ([^;]*;)", source)
     if not updates:
@@ -283,12 +303,14 @@ def deferred_update_counts(scene_name, w, h, depth, aa, options=None, row_step=6
     source = re.sub(r"\+\+(ptl_pend_\d+);", r"++\1; __atomic_fetch_add(&ptl_deferred_stats[0], 1, __ATOMIC_RELAXED);", source)
     source = re.sub(r"for \(; (ptl_pend_\d+) > 0; --\1\) ", r"for (; \1 > 0; --\1, __atomic_fetch_add(&ptl_deferred_stats[1], 1, __ATOMIC_RELAXED)) ", source)
     source += '\nextern "C" long* ptl_deferred_stats_ptr() { return glsl::ptl_deferred_stats; }\n'
-    renderer = pa.SceneRenderer(scene, device=-1)
+    renderer = pa.SceneRenderer(scene, device=-1, **_scene_kw(scene_name))
     renderer.set_option("render_depth", depth)
     renderer.set_option("aa_count", aa)
     for k, v in (options or {}).items():
         name = {"use_panini": "use_panini_projection"}.get(k, k)
         renderer.set_option(name, float(v))
+    if camera:
+        renderer.set_camera(camera[:3], camera[3], camera[4], camera[5])
     layout, size = scene.uniform_layout()
     hk = hb.HostKernel(source, layout, size, True)
     for name, typ, _ in layout:
@@ -311,7 +333,7 @@ def deferred_update_counts(scene_name, w, h, depth, aa, options=None, row_step=6
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(HERE, "profiles", "r03", "flops_per_segment.json"))
+    ap.add_argument("--out", default=os.path.join(HERE, "profiles", "r05", "flops_per_segment.json"))
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     out = {}
@@ -326,6 +348,12 @@ def main():
     if not args.only or args.only == "portal_in_portal_3840x2160_d40_panini":
         out["portal_in_portal_3840x2160_d40_panini"] = count("portal_in_portal", 3840, 2160, 40, 1, 0.0125,
                                                              options=dict(use_panini=True, panini_param=1.0, view_angle=float(np.radians(140.0))))
+    # round 5: the headline scene seen INTO the nested portals (bench.py --workload c4-deep: the regime with several trips per primary ray)
+    if not args.only or args.only == "portal_in_portal_3840x2160_d40_cam0_0_0_0.2_1.5_1.6":
+        out["portal_in_portal_3840x2160_d40_cam0_0_0_0.2_1.5_1.6"] = count("portal_in_portal", 3840, 2160, 40, 1, 0.005, camera=(0.0, 0.0, 0.0, 0.2, 1.5, 1.6))
+    # ... and the corpus scene whose default view bounces 26 times per primary ray (bench.py --workload recursive-room): "depth = 40" exercised
+    if not args.only or args.only == "recursive_room_3840x2160_d40":
+        out["recursive_room_3840x2160_d40"] = count("tests/corpus/scenes/recursive_room.ron", 3840, 2160, 40, 1, 0.002)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

@@ -89,6 +89,31 @@ PATCHES = {
                   "    bool alive = true;\n    if (r.d.x > 2.0f) return RayTraceResult{vec3(r.d.x, r.d.y, r.d.z), 0.0f, false};\n    for (int j = 0; j < 0; j++) {")],
 }
 
+# ---- round 5 experiments on the headline snippet (each must draw the intact picture) ----------------------------------------------------
+_WALK_OLD = ("    for (int i = 0; i < size; i++) { // !FOR_VARIABLE!\n\t\tif (pos2.z > 0.f) return NOT_INSIDE;\n\t\tif (first) {\n\t\t\tpos2 = a_mat_inv * (b0_mat * pos2);\n"
+             "\t\t} else {\n\t\t\tpos2 = b0_mat_inv * (a_mat * pos2);\n\t\t}\n\t}\n")
+_WALK_FLAGS = ("    bool ptl_left = false;\n    for (int i = 0; i < size; i++) { // !FOR_VARIABLE!\n\t\tptl_left = ptl_left || (pos2.z > 0.f);\n\t\tif (first) {\n\t\t\tpos2 = a_mat_inv * (b0_mat * pos2);\n"
+               "\t\t} else {\n\t\t\tpos2 = b0_mat_inv * (a_mat * pos2);\n\t\t}\n\t}\n\tif (ptl_left) return NOT_INSIDE;\n")
+# the walk through the nested copies with its early return turned into a flag: straight-line code after unrolling (and the a-side walk, whose
+# start point pos_a is the same for every copy, becomes a common subexpression of the ten unrolled copies)
+PATCHES["r5_walk_flags"] = [(_WALK_OLD, _WALK_FLAGS)]
+# rays are affine objects: o.w = 1, d.w = 0 (every matrix of this scene has the bottom row 0 0 0 1): transform() with the constants spelled
+_W_OLD1 = "    return Ray{matrix * r.o, matrix * r.d, r.tmul, r.in_subspace};"
+_W_NEW1 = "    return Ray{matrix * vec4(r.o.x, r.o.y, r.o.z, 1.0f), matrix * vec4(r.d.x, r.d.y, r.d.z, 0.0f), r.tmul, r.in_subspace};"
+_W_OLD2 = "    else return Ray{ptl_mul_m<MASK>(matrix, r.o), ptl_mul_m<MASK>(matrix, r.d), r.tmul, r.in_subspace};"
+_W_NEW2 = "    else return Ray{ptl_mul_m<MASK>(matrix, vec4(r.o.x, r.o.y, r.o.z, 1.0f)), ptl_mul_m<MASK>(matrix, vec4(r.d.x, r.d.y, r.d.z, 0.0f)), r.tmul, r.in_subspace};"
+PATCHES["r5_w_known"] = [(_W_OLD1, _W_NEW1), (_W_OLD2, _W_NEW2)]
+PATCHES["r5_walk_flags_w_known"] = PATCHES["r5_walk_flags"] + PATCHES["r5_w_known"]
+# the wave-level cull (one sign test since round 4) around the hand-inlined plane test of every copy of portal b, general and first-trip copy
+_BCULL = []
+for _ray in ("transform(b0_mat_inv, r_b)", "(ptl_tab_ok_0 ? ptl_ray_o(transform(b0_mat_inv, r_b), PTL_U.ptl_hv1[size]) : (transform(b0_mat_inv, r_b)))"):
+    _BCULL.append(("\tRay r3 = " + _ray + ";\n\tfloat len = length(r3.d);\n\tr3 = normalize_ray(r3);\n\n\tSurfaceIntersection hit_b = plane_intersect_normalized(r3);\n\tif (hit_b.hit) {\n\t    ptl_div_assign(hit_b.t , len);\n\t    hit_b.n = normal3;\n\t}\n",
+                   "\tSurfaceIntersection hit_b = intersection_none;\n\tif (!ptl_plane_cull(r_b, b0_mat_inv, (result.scene.hit.hit ? result.scene.hit.t : __builtin_inff()))) {\n\tRay r3 = " + _ray +
+                   ";\n\tfloat len = length(r3.d);\n\tr3 = normalize_ray(r3);\n\thit_b = plane_intersect_normalized(r3);\n\tif (hit_b.hit) {\n\t    ptl_div_assign(hit_b.t , len);\n\t    hit_b.n = normal3;\n\t}\n\t}\n"))
+PATCHES["r5_b_cull"] = _BCULL
+PATCHES["r5_all"] = PATCHES["r5_walk_flags_w_known"] + _BCULL
+
+
 def _select_form_is_inside_portal(src):
     """EXPERIMENT (must draw the intact picture): the ring classification of scenes/portal_in_portal.ron's library as straight-line selects instead of
     the author's chain of early returns -- what a select-form rewrite of pure early-return functions in the translator would buy."""
