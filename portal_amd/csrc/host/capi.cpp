@@ -468,6 +468,7 @@ static KernelOptions options_from_flags(unsigned flags) {
     o.specialize_all = (flags & 4u) != 0;
     o.anaglyph = (flags & 16u) != 0;
     o.specialize_static = (flags & 8u) != 0;
+    o.specialize_static_ints = (flags & (1u << 20)) != 0;  // PTL_FLAG_SPECIALIZE_PATTERNS: + the scene's own switches (Bool / Int uniforms that read no per-frame input)
     o.derived_uniforms = (flags & 32u) == 0;  // PTL_FLAG_NO_DERIVED_UNIFORMS: the plain plane tests (A/B measurements, tests)
     o.fast_math = (flags & 64u) != 0;         // PTL_FLAG_FAST_MATH: tolerance mode
     o.exact_cr = (flags & 16384u) != 0;       // PTL_FLAG_EXACT_CR: numerics contract 1 (IEEE / and sqrt on every input), `--exact-cr`

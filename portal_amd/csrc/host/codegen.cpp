@@ -826,7 +826,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         // JIT-time specialisation: current values baked in as literals (same arithmetic, the
         // compiler folds branches on mode switches / ray-independent subexpressions)
         std::map<std::string, std::string> baked;
-        if (opts.specialize_ints || opts.specialize_all || opts.specialize_static) {
+        if (opts.specialize_ints || opts.specialize_all || opts.specialize_static || opts.specialize_static_ints) {
             auto hexf = [](float v) -> std::string {
                 if (std::isnan(v)) return "__builtin_nanf(\"\")";
                 if (std::isinf(v)) return v > 0 ? "__builtin_inff()" : "(-__builtin_inff())";
@@ -838,6 +838,8 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 if (up.name == "teleport_light_u") continue;  // forced to 1 by the camera-teleport query (src/main.rs:1367)
                 if (opts.keep_dynamic.count(up.name)) continue;
                 if (opts.specialize_static && up.animated) continue;  // changes every frame: stays a run-time uniform
+                const bool switches_only = opts.specialize_static_ints && !(opts.specialize_ints || opts.specialize_all || opts.specialize_static);
+                if (switches_only && (up.animated || up.type != UniformType::Int1)) continue;  // the patterns build: only the Bool / Int uniforms that hold still
                 bool all = opts.specialize_all || opts.specialize_static;
                 if (up.type == UniformType::Int1) {
                     baked[up.name] = std::to_string(up.i);
@@ -1077,6 +1079,9 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             if (opts.first_trip)
                 for (const NamedCode& im : scene.intersection_materials) snippet.prepare_first(im.code, hp);
         }
+        // (in the TEXT as well as among the defines: a renderer tells "nothing compiled in changed" by comparing sources, and a kernel with and
+        // one without affine rays differ in nothing else)
+        if (gk.affine_rays) s.add_string("#define PTL_AFFINE_RAYS 1\n");
         if (opts.derived_uniforms) s.add_string("#define PTL_DERIVED_BUILTINS 1\n");
         {
             if (first_trip_planes_wanted())

@@ -98,6 +98,12 @@ struct KernelOptions {
     bool specialize_all = false;   // also bake Float / matrix scene uniforms (not the camera / builtins)
     bool count_segments = false;   // compile with PTL_COUNT_SEGMENTS
     bool anaglyph = false;         // compile the !ANAGLYPH! code in (the reference's `disable_anaglyph = false`)
+    // The scene's own SWITCHES: Bool / Int uniforms whose evaluation reads no per-frame input (time, the camera) are GUI toggles and
+    // counters -- `filter_teleported`, `shape`, `show_teleported` -- that stay put while Float / Angle / matrix values animate.  The patterns build
+    // (PTL_FLAG_SPECIALIZE_PATTERNS) compiles them in like the renderer's mode switches (round 5: the headline's patterns kernel 0.50 -> 0.30 ms --
+    // dead branches, constant loop bounds, unrolled snippet loops); the renderer checks them before every draw like a clip-constant value,
+    // demotes the one that moved and rebuilds.
+    bool specialize_static_ints = false;
     bool specialize_static = false;  // bake every scene uniform whose evaluation does not read a per-frame input ...
     std::set<std::string> keep_dynamic;  // ... except these (values that changed after all: demoted by the renderer)
     // The renderer's own mode switches (`_use_panini_projection`, `_use_360_camera`, `_use_180_camera`, `_draw_depth_map`, `_draw_anaglyph`,

@@ -858,3 +858,53 @@ def test_a_camera_that_is_not_affine_switches_affine_rays_off(gpu):
         assert np.array_equal(_bits(frames[name][0]), _bits(frames["general"][0])), name
         assert np.array_equal(_bits(frames[name][1]), _bits(frames["general"][1])), name
     assert not np.array_equal(_bits(frames["general"][0]), _bits(frames["general"][1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flavour", ["patterns", "patterns+async"])
+def test_patterns_build_compiles_the_scenes_switches_in_and_follows_them(gpu, flavour):
+    """Round 5: the patterns build also has the scene's own switches as literals -- the Bool / Int uniforms whose evaluation reads no per-frame
+    input (`filter_teleported`, `shape`, the loop bound `show_teleported` ...): 0.50 -> 0.30 ms on the headline.  Frames are the un-specialised
+    kernel's bit for bit before a switch is flipped, after (the one that moved is demoted to a run-time uniform, ONE rebuild), and while the
+    floats of the scene move (no rebuild at all)."""
+    import time
+
+    pa = gpu
+    path = pa.scene_path("portal_in_portal")
+    flags = pa.FLAG_SPECIALIZE_PATTERNS | (pa.FLAG_ASYNC_REJIT if flavour.endswith("async") else 0)
+    sa, sb = pa.Scene.from_file(path), pa.Scene.from_file(path)
+    ra, rb = pa.SceneRenderer(sa, device=0), pa.SceneRenderer(sb, device=0, flags=flags)
+    src = rb.kernel_source()
+    assert "#define filter_teleported_u (1)" in src and "#define show_teleported_u (10)" in src and "#define progress_u (PTL_U.progress_u)" in src
+    for r in (ra, rb):
+        r.set_option("render_depth", 12)
+    w, h = 160, 90
+
+    def same(tag):
+        a = ra.draw(w, h, rgba32f=True)["rgba32f"]
+        b = rb.draw(w, h, rgba32f=True)["rgba32f"]
+        assert np.array_equal(_bits(a), _bits(b)), (flavour, tag)
+        deadline = time.time() + 120
+        while rb.rejit_pending() and time.time() < deadline:
+            time.sleep(0.05)
+            b = rb.draw(w, h, rgba32f=True)["rgba32f"]
+        assert np.array_equal(_bits(a), _bits(b)), (flavour, tag, "adopted")
+
+    same("start")
+    for s_ in (sa, sb):
+        assert s_.set_uniform("pass_offset", 0.3) and s_.set_uniform("portal_scale", 1.25)   # floats move: no rebuild
+    same("floats moved")
+    assert rb.rejit_count() == 0
+    for s_ in (sa, sb):
+        assert s_.set_uniform("show_teleported", 4)   # a compiled-in switch moves: demoted, one rebuild
+    same("loop bound 4")
+    rebuilt = rb.rejit_count()
+    assert rebuilt >= 1 and "#define show_teleported_u (PTL_U.show_teleported_u)" in rb.kernel_source()
+    for value in (7, 12):
+        for s_ in (sa, sb):
+            assert s_.set_uniform("show_teleported", value)   # ... and moves again: a run-time uniform now
+        same(f"loop bound {value}")
+    assert rb.rejit_count() == rebuilt
+    for s_ in (sa, sb):
+        assert s_.set_uniform("filter_teleported", 0)
+    same("another switch")

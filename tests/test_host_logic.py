@@ -1374,7 +1374,8 @@ def test_generated_defines_go_with_the_generated_source(pa):
         scene.generate_source(flags)
         # (PTL_JIT_MODULE_INLINER: this scene's intersection-material snippet loops, and with the Ints baked the loop is force-unrolled -- the
         # JIT picks LLVM's module inliner for those builds, kernel.cpp)
-        assert set(scene.generated_defines()) == want | ({"PTL_JIT_MODULE_INLINER"} if flags & pa.FLAG_SPECIALIZE_INTS else set()), flags
+        # (... and so do the patterns builds since round 5: the loop bound `show_teleported` is one of the scene's switches they compile in)
+        assert set(scene.generated_defines()) == want | ({"PTL_JIT_MODULE_INLINER"} if flags & (pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_PATTERNS) else set()), flags
     mono = pa.Scene.from_file(pa.scene_path("monoportal"))
     mono.generate_source(spec)
     assert set(mono.generated_defines()) == {"PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}  # no looping snippet: the toolchain's default inliner
@@ -1866,8 +1867,10 @@ def test_affine_rays_are_generated_only_where_they_hold(pa, tmp_path):
     for flags in (spec, pa.FLAG_SPECIALIZE_PATTERNS):
         r = pa.SceneRenderer(pa.Scene.from_text(cam_text), device=-1, flags=flags | pa.FLAG_QUICK_JIT)
         assert r.affine_rays() and r.rejit_count() == 0
+        affine_binary = r.code_object()
         r.use_camera("doorway")
         assert not r.affine_rays() and r.rejit_count() == 1
+        assert r.code_object() != affine_binary and "#define PTL_AFFINE_RAYS" not in r.kernel_source()   # really another kernel (the flag is part of the source text)
         r.use_camera("red")   # back among the affine maps: the assumption stays off for this stage (one rebuild, not one per camera move)
         assert not r.affine_rays() and r.rejit_count() == 1
 

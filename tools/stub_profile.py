@@ -114,6 +114,15 @@ PATCHES["r5_b_cull"] = _BCULL
 PATCHES["r5_all"] = PATCHES["r5_walk_flags_w_known"] + _BCULL
 
 
+# round 5, STUB_FLAGS=1048576 (the patterns build): which of the Int / Bool uniforms that the Int-baked build has as literals make it 0.27 ms against 0.44?
+_PIP_INTS = {"show_teleported_u": 10, "filter_teleported_u": 1, "teleport_light_u": 1, "shape_u": 0, "double_sided_u": 0, "show_arrow_u": 0, "show_object_u": 0,
+             "pass_use_teleported_matrix_u": 0, "pass_not_disable_orange_portal_u": 0, "gray_room_u": 0, "show_cube_u": 0}
+PATCHES["r5_bake_loop_bound"] = [("#define show_teleported_u (PTL_U.show_teleported_u)", "#define show_teleported_u (10)")]
+PATCHES["r5_bake_flags_not_the_bound"] = [("#define %s (PTL_U.%s)" % (n, n), "#define %s (%d)" % (n, v)) for n, v in _PIP_INTS.items() if n != "show_teleported_u"]
+PATCHES["r5_bake_all_ints"] = [("#define %s (PTL_U.%s)" % (n, n), "#define %s (%d)" % (n, v)) for n, v in _PIP_INTS.items()]
+PATCHES["r5_bake_bound_and_unroll"] = PATCHES["r5_bake_loop_bound"] + [("for (int size = 0; size < show_teleported_u; size++) {", "_Pragma(\"unroll\") for (int size = 0; size < show_teleported_u; size++) {")]
+
+
 def _select_form_is_inside_portal(src):
     """EXPERIMENT (must draw the intact picture): the ring classification of scenes/portal_in_portal.ron's library as straight-line selects instead of
     the author's chain of early returns -- what a select-form rewrite of pure early-return functions in the translator would buy."""
