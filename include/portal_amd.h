@@ -404,6 +404,11 @@ int ptl_renderer_update(ptl_renderer* r, double seconds, int* teleported, int* b
 /* Current teleport matrix (binary64, column-major), subspace flag and world position of the camera. */
 int ptl_renderer_camera_state(ptl_renderer* r, double teleport16[16], int* in_subspace, double position[3]);
 ptl_kernel* ptl_renderer_kernel(ptl_renderer* r);
+/* The binary64 primitives behind the scene's constants, exposed one by one for tests (tests/test_matrix_exact.py compares each with exact
+ * arithmetic): op = "inverse" (a), "mul" (a * b), "teleport" (b * a^-1: `A_to_B_mat_teleport`, src/gui/scene.rs:624-632), "srt" (a = scale
+ * xyz, b = rotate xyz, c = offset xyz: Matrix::Simple / Parametrized, src/gui/matrix.rs:555-569), "camera" (a = look_at xyz, alpha, beta, r;
+ * b = the teleport matrix: RotateAroundCam::get_matrix, src/main.rs:278-304).  Matrices are 16 doubles, column-major. */
+int ptl_dmath(const char* op, const double* a, const double* b, const double* c, double* out);
 /* 1 when the renderer's current kernel was generated with affine rays (flag bit23 clear, a build that may shorten products, every scene
  * matrix and the camera affine, no snippet that writes a ray's w): its matrix-times-ray products spell o.w = 1 / d.w = 0.  A matrix or a
  * camera that stops being affine makes the next draw rebuild without it (counted by ptl_renderer_rejit_count); 0 then, and for every other build. */

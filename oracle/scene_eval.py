@@ -670,6 +670,8 @@ class OracleScene:
             a = self.eval_matrix(node[1])  # this is the exact principal root (Denman-Beavers), the point that minimisation heads for
             if a is None:
                 return None
+            if getattr(self, "override_sqrt", None) is not None:  # tools/mat_sqrt_bfgs.py: what a minimiser like the reference's reaches, put in the root's place
+                return self.override_sqrt
             y, z = a, IDENT
             half = lambda p, q: [[(p[c][r] + q[c][r]) * 0.5 for r in range(4)] for c in range(4)]
             for _ in range(64):

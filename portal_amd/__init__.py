@@ -153,6 +153,7 @@ def _load() -> C.CDLL:
         "ptl_kernel_stage_slice": (ci, [vp, ci]),
         "ptl_kernel_hold_textures": (ci, [vp, ci]),
         "ptl_renderer_affine_rays": (ci, [vp]),
+        "ptl_dmath": (ci, [cp, P(cd), P(cd), P(cd), P(cd)]),
         "ptl_snippets_keep_rays_affine": (ci, [cp, cp, cs]),
         "ptl_code_object_note": (ci, [vp, cs, cp, cp]),
         "ptl_kernel_render_slices": (ci, [vp, P(Frame), ci, vp, vp, C.c_ulonglong, vp, P(C.c_float)]),
@@ -827,6 +828,14 @@ def bound_glsl(body: str, out_functions=()):
         return C.string_at(p).decode("utf-8"), n.value
     finally:
         lib().ptl_free(p)
+
+
+def dmath(op: str, a, b=None, c=None) -> np.ndarray:
+    """One binary64 primitive of the host's matrix arithmetic (ptl_dmath): 16 doubles, column-major, as a flat array."""
+    arr = lambda v: (C.c_double * len(v))(*[float(x) for x in v]) if v is not None else None
+    out = (C.c_double * 16)()
+    _check(lib().ptl_dmath(op.encode(), arr(a), arr(b), arr(c), out), "ptl_dmath")
+    return np.array(out, np.float64)
 
 
 def snippets_keep_rays_affine(code: str):

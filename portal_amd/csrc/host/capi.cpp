@@ -1630,6 +1630,41 @@ extern "C" int ptl_renderer_kernel_source(ptl_renderer* r, char** source) {
     std::memcpy(*source, r->kernel_source.c_str(), r->kernel_source.size() + 1);
     return PTL_OK;
 }
+// ---- the binary64 primitives behind the scene's constants, one by one (test hooks: tests/test_matrix_exact.py checks each against exact
+// arithmetic).  Matrices are 16 doubles, column-major like glam's to_cols_array.
+extern "C" int ptl_dmath(const char* op, const double* a, const double* b, const double* c, double* out) {
+    if (!op || !a || !out) return PTL_ERR_INVALID;
+    auto load = [](const double* v) {
+        return DMat4::from_cols({v[0], v[1], v[2], v[3]}, {v[4], v[5], v[6], v[7]}, {v[8], v[9], v[10], v[11]}, {v[12], v[13], v[14], v[15]});
+    };
+    auto store = [&](const DMat4& m) {
+        for (int k = 0; k < 4; ++k) {
+            out[4 * k + 0] = m.c[k].x;
+            out[4 * k + 1] = m.c[k].y;
+            out[4 * k + 2] = m.c[k].z;
+            out[4 * k + 3] = m.c[k].w;
+        }
+        return (int)PTL_OK;
+    };
+    const std::string what = op;
+    if (what == "inverse") return store(load(a).inverse());  // glam DMat4::inverse (src/gui/scene.rs:587-588, matrix.rs:537-547)
+    if (what == "mul" && b) return store(load(a) * load(b));
+    if (what == "teleport" && b) return store(load(b) * load(a).inverse());  // a_to_b = B * A^-1 (src/gui/scene.rs:624-632)
+    if (what == "srt" && b && c)  // Simple / Parametrized: T * (Rx * Ry * Rz) * S (src/gui/matrix.rs:555-569); a = scale xyz, b = rotate xyz, c = offset xyz
+        return store(DMat4::from_scale_rotation_translation(DVec3(a[0], a[1], a[2]), DQuat::rotation_x(b[0]) * DQuat::rotation_y(b[1]) * DQuat::rotation_z(b[2]), DVec3(c[0], c[1], c[2])));
+    if (what == "camera" && b) {  // RotateAroundCam::get_matrix (src/main.rs:278-304): a = look_at xyz, alpha, beta, r; b = the teleport matrix
+        Camera cam;
+        cam.look_at = DVec3(a[0], a[1], a[2]);
+        cam.alpha = a[3];
+        cam.beta = a[4];
+        cam.r = a[5];
+        cam.teleport_matrix = load(b);
+        return store(cam.matrix());
+    }
+    set_last_error(std::string("ptl_dmath: unknown operation `") + what + "`");
+    return PTL_ERR_INVALID;
+}
+
 extern "C" int ptl_renderer_rejit_count(ptl_renderer* r) { return r ? r->rejit_count : -1; }
 extern "C" int ptl_renderer_affine_rays(ptl_renderer* r) { return r ? (r->affine_rays ? 1 : 0) : -1; }
 extern "C" int ptl_snippets_keep_rays_affine(const char* glsl, char* why, size_t why_cap) {
