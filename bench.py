@@ -599,6 +599,15 @@ def main():
     clean = {k: v for k, v in tried.items() if v[2]["scratch_bytes"] == 0 and v[0] <= fastest * 1.06}
     pool = clean if clean else tried
     best = min(pool, key=lambda k: pool[k][0])
+    # The candidates differ by a per cent or so and the pick would flip with the noise of 16 launches.  Among the builds within 1.5 % of the
+    # fastest, one whose stored PMC passes counted THIS binary (same code-object sha256) is taken: the line's roofline then comes with the
+    # hardware's own counters instead of without.
+    if rank == 0 and not args.build and args.waves < 0:
+        near = [k for k in pool if pool[k][0] <= pool[best][0] * 1.015]
+        for k in sorted(near, key=lambda k: pool[k][0]):
+            if stored_pmc(args, k, pool[k][1].code_object_sha256())[0] is not None:
+                best = k
+                break
     if world > 1:  # all ranks must run the same build: take rank 0's choice
         names = list(tried)
         choice = torch.tensor([names.index(best)], device=dev)
@@ -839,16 +848,13 @@ def main():
                 Wk, Hk = a.width, a.height
                 fr = pa.Frame(Wk, Hk, 0, 1)
                 buf = torch.empty((Hk, Wk, 4), dtype=torch.uint8, device=dev)
-                cands = {}
-                for waves in (0, 4):  # the two register budgets that matter (the headline tries four)
-                    rr = pa.SceneRenderer(sc, device=local_rank, flags=spec_flags | pa.flag_waves(waves), **sc_kw)
-                    configure(rr, a)
-                    for _ in range(6):
-                        rr.draw_device(fr, out_rgba8=buf.data_ptr(), stream=stream.cuda_stream)
-                    cands[waves] = (float(np.median([rr.draw_device(fr, out_rgba8=buf.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(10)])), rr)
-                waves = min(cands, key=lambda k: cands[k][0])
-                rr = cands[waves][1]
-                steps = int(max(10, min(200, 40.0 / max(cands[waves][0], 0.02))))  # ~40 ms of timed region
+                waves = 0  # ONE build per workload (no occupancy hint): the binary whose PMC passes are stored under profiles/
+                rr = pa.SceneRenderer(sc, device=local_rank, flags=spec_flags | pa.flag_waves(waves), **sc_kw)
+                configure(rr, a)
+                for _ in range(6):
+                    rr.draw_device(fr, out_rgba8=buf.data_ptr(), stream=stream.cuda_stream)
+                probe_ms = float(np.median([rr.draw_device(fr, out_rgba8=buf.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(10)]))
+                steps = int(max(10, min(200, 40.0 / max(probe_ms, 0.02))))  # ~40 ms of timed region
                 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
@@ -882,7 +888,7 @@ def main():
                 rec["cpu_baseline"] = cpu_baseline(a, pa)
                 rec["oracle_check"] = oracle_check(a, pa, rr, torch, dev, stream, n=2048)
                 others.append(rec)
-                del cands, rr, buf
+                del rr, buf
             except Exception as e:  # the headline number does not depend on it
                 print(f"[bench] workload {wname} unavailable: {e}", file=sys.stderr)
                 others.append({"name": wname, "error": str(e)[:300]})
