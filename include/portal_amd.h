@@ -297,6 +297,10 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * column then costs a direction nothing and the w row folds to a constant (headline kernel -16 %); the same operations on the same values
  * for finite rays, identical frames.  A renderer rebuilds without it when a matrix -- the camera's included -- stops being affine.
  * This bit keeps the general products (A/B measurements, tests),
+ * bit24 = KEEP TRANSFORM DODGES (A/B): a kernel with affine rays (bit23 clear and everything affine) is generated WITHOUT the deferred loop updates
+ * (bit7) and the first-trip snippet copies (bit13) -- both dodge `transform(uniform matrix, ray)`, which is a handful of additions there and
+ * cheaper than the bookkeeping around it (headline baked 0.2305 -> 0.2046 ms, Int-baked 0.272 -> 0.239, patterns 0.274 -> 0.239; identical
+ * frames).  This bit keeps both, as round 4 had them.  Kernels without affine rays (the un-specialised one above all: 0.70 against 0.89 ms) keep both anyway,
  * bit15 = NO unrolling of baked loops: by default (with bit0) a counting loop of a scene snippet whose bound is a baked Int uniform
  * (<= 16 iterations) is unrolled -- the same operations in the same order, identical frames; every iteration then has its own
  * constants (scenes/portal_in_portal.ron's `size` drives an inner loop and a material index).

@@ -59,6 +59,7 @@ FLAG_NO_DEFERRED_UPDATES = 128  # translate scene snippets exactly as written (d
 FLAG_QUICK_JIT = 262144  # compile at -O1 instead of the shipped -O3: half the JIT time, a 5-20 % slower kernel (one-off frames)
 FLAG_SPECIALIZE_PATTERNS = 1048576  # compile in only what survives moving values: zero patterns of the matrices + the renderer's mode switches
 FLAG_BOUNDED_SNIPPETS = 2097152  # opt-in: scene_intersect first, its hit distance bounds the intersection-material snippets (exact; measured: no gain on the headline)
+FLAG_KEEP_TRANSFORM_DODGES = 16777216  # A/B: deferred loop updates + first-trip snippet copies also in a kernel with affine rays (default there: neither; identical frames)
 FLAG_NO_AFFINE_RAYS = 8388608  # A/B: matrix-times-ray products never assume o.w = 1 / d.w = 0 (default in specialised builds of affine scenes: they do; identical frames)
 FLAG_SLICES = 4194304  # the render entry reads its uniform block from a buffer of blocks (one per blockIdx.z): stage_slice / draw_slices, one launch for several draws
 FLAG_NO_ZERO_MASKS = 524288  # A/B: run-time matrices keep their full products although their zero pattern is known (KernelOptions::mask_zero_elements)

@@ -484,6 +484,7 @@ static KernelOptions options_from_flags(unsigned flags) {
     // PTL_FLAG_NO_UNROLL: keep snippet loops with baked bounds as loops (A/B measurements).  The quick build keeps them too: unrolling
     // is half of its hiprtc time for the headline scene (3.4 -> 1.8 s on this container's cores) and buys 0.05 ms of kernel
     o.unroll_baked_loops = (flags & 32768u) == 0 && !o.quick_jit;
+    o.keep_transform_dodges = (flags & (1u << 24)) != 0;  // PTL_FLAG_KEEP_TRANSFORM_DODGES: deferred updates + first-trip snippet copies also with affine rays (A/B)
     o.affine_rays = (flags & (1u << 23)) == 0;    // PTL_FLAG_NO_AFFINE_RAYS: matrix-times-ray products never assume o.w = 1 / d.w = 0 (A/B measurements, tests)
     o.first_trip = (flags & 8192u) == 0;          // PTL_FLAG_NO_FIRST_TRIP: no first-trip copies of the intersection-material snippets
     o.hoist_uniform_work = (flags & 4096u) == 0;  // PTL_FLAG_NO_UNIFORM_HOIST: snippets evaluate their uniform-only expressions per ray

@@ -803,7 +803,8 @@ bool snippets_keep_rays_affine(const std::vector<std::string>& codes, std::strin
     return true;
 }
 
-GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& flags, const KernelOptions& opts) {
+GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& flags_in, const KernelOptions& opts) {
+    CodegenFlags flags = flags_in;  // (a copy: a kernel with affine rays drops the deferred loop updates, below)
     GeneratedKernel gk;
     std::map<std::string, StringStorage> storages;
     SnippetTranslator snippet{flags, {}, {}, {}, {}, 0, {}, {}};
@@ -984,6 +985,15 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             }
             gk.affine_rays = affine;
         }
+        // Deferred loop updates (glsl_translate.h) and the first-trip copies of the intersection-material snippets (ptl_trace.tpl PTL_FIRST_TRIP)
+        // both exist to dodge `transform(uniform matrix, ray)` -- 32 FMAs in the un-specialised kernel.  In a kernel with affine rays the matrices
+        // are literals or carry their patterns, a transform of the reference's portal matrices is a handful of additions, and the bookkeeping
+        // around it (pending counters and their flush loops; a second copy of every snippet and a wave-level choice between the two) costs more
+        // than it saves: measured on the headline, same frames, baked 0.2305 -> 0.2046 ms, Int-baked 0.272 -> 0.239, patterns 0.274 -> 0.239
+        // (profiles/r05/ab_flags2.jsonl; the un-specialised kernel: 0.70 -> 0.89 without the deferral, so it keeps both).
+        const bool cheap_transforms = gk.affine_rays && !opts.keep_transform_dodges;
+        if (cheap_transforms) flags.defer_loop_updates = false;
+        const bool first_trip_snippets = opts.first_trip && !cheap_transforms;
         // (KernelOptions::baked_options is only filled in for builds that may compile the switches in: any specialisation, patterns-only included)
         for (auto& [name, value] : opts.baked_options)
                 for (auto& u : list)
@@ -1076,7 +1086,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 else if (o.kind == Object::Complex) snippet.prepare(o.code, hp, true, o.portal ? std::vector<std::string>{"r", "first"} : std::vector<std::string>{"r"});
             }
             for (const NamedCode& im : scene.intersection_materials) snippet.prepare(im.code, hp, true, {"r", "ptl_far"});
-            if (opts.first_trip)
+            if (first_trip_snippets)
                 for (const NamedCode& im : scene.intersection_materials) snippet.prepare_first(im.code, hp);
         }
         // (in the TEXT as well as among the defines: a renderer tells "nothing compiled in changed" by comparing sources, and a kernel with and

@@ -159,6 +159,9 @@ struct KernelOptions {
     // finite rays -- the guard and the stated deviation of the shortened products (full_chains).  The renderer switches it off, and rebuilds,
     // when a CAMERA matrix (a run-time value in every build) is not affine (GeneratedKernel::affine_rays says whether the kernel has it).
     bool affine_rays = true;
+    // A/B switch (PTL_FLAG_KEEP_TRANSFORM_DODGES): a kernel with affine rays still gets the deferred loop updates and the first-trip snippet copies
+    // -- round 4's shape, for measurements; by default it gets neither (codegen.cpp: a transform is then a few additions, cheaper than its dodge)
+    bool keep_transform_dodges = false;
     bool quick_jit = false;  // PTL_QUICK_JIT: compile at -O1 instead of the shipped -O3 (half the JIT time, a 5-20 % slower kernel)
     bool fast_math = false;  // PTL_FAST_MATH: hardware rcp / sqrt / rsq (1 ulp), a/b = a * rcp(b), FMA contraction: tolerance mode, not bit-exact
 };

@@ -108,7 +108,9 @@ def test_first_trip_snippet_variants_change_no_bit(gpu, scene_file, spec):
     extra = {"asset_root": os.path.join(ROOT, "tests", "corpus")} if "corpus" in scene_file else {}
     w, h = 320, 180
     frames = {}
-    for label, flags in (("first", spec), ("general", spec | pa.FLAG_NO_FIRST_TRIP)):
+    # (round 5: a specialised build of a scene with affine rays has no first-trip copies by default; FLAG_KEEP_TRANSFORM_DODGES keeps them)
+    keep = pa.FLAG_KEEP_TRANSFORM_DODGES if spec else 0
+    for label, flags in (("first", spec | keep), ("general", spec | keep | pa.FLAG_NO_FIRST_TRIP)):
         scene = pa.Scene.from_file(path)
         assert ("_first(Ray r, float ptl_far) {" in scene.generate_source(flags)) == (label == "first")
         r = pa.SceneRenderer(scene, device=0, flags=flags, **extra)
@@ -810,10 +812,11 @@ def test_affine_rays_change_no_bit(gpu, scene_name, w, h, depth, moves):
     pa = gpu
     for label, flags in (("ints", pa.FLAG_SPECIALIZE_INTS), ("patterns", pa.FLAG_SPECIALIZE_PATTERNS), ("baked", pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)):
         frames = {}
-        for name, extra in (("affine", 0), ("general", pa.FLAG_NO_AFFINE_RAYS)):
+        # ("dodges": affine rays WITH the deferred loop updates and first-trip snippet copies that such a kernel drops by default -- round 4's shape)
+        for name, extra in (("affine", 0), ("general", pa.FLAG_NO_AFFINE_RAYS), ("dodges", pa.FLAG_KEEP_TRANSFORM_DODGES)):
             scene = pa.Scene.from_file(pa.scene_path(scene_name))
             r = pa.SceneRenderer(scene, device=0, flags=flags | extra)
-            assert r.affine_rays() == (extra == 0), (scene_name, label)
+            assert r.affine_rays() == (extra != pa.FLAG_NO_AFFINE_RAYS), (scene_name, label)
             r.set_option("render_depth", depth)
             first = r.draw(w, h, rgba32f=True, rgba8=True)
             assert scene.set_uniform(*moves)
@@ -824,8 +827,9 @@ def test_affine_rays_change_no_bit(gpu, scene_name, w, h, depth, moves):
             panini = r.draw(w, h, rgba32f=True)["rgba32f"].copy()
             frames[name] = (first["rgba32f"].copy(), first["rgba8"].copy(), moved, panini)
         for k in range(4):
-            a, b = frames["affine"][k], frames["general"][k]
-            assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), (scene_name, label, k)
+            for other in ("affine", "dodges"):
+                a, b = frames[other][k], frames["general"][k]
+                assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), (scene_name, label, other, k)
         assert not np.array_equal(_bits(frames["general"][0]), _bits(frames["general"][2]))
 
 

@@ -1153,8 +1153,13 @@ def test_hoisted_scene_source_is_selfconsistent(pa):
     baked = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
     for flags in (pa.FLAG_NO_UNIFORM_HOIST, pa.FLAG_NO_DERIVED_UNIFORMS, baked | pa.FLAG_NO_FIRST_TRIP):
         assert "ptl_hv" not in scene.generate_source(flags)
-    # with everything baked only the camera is left: the first-trip copy of the snippet reads two tables of ray origins, nothing else
+    # round 5: a baked build of this scene has affine rays, its transforms are a few additions, and it gets no first-trip copy at all
     src = scene.generate_source(baked)
+    assert "ptl_hv" not in src and "intersect_material_0_first(" not in src and "#define PTL_FIRST_TRIP_SNIPPETS" not in src and "ptl_pend_" not in src
+    # with everything baked only the camera is left: the first-trip copy of the snippet (round 4's shape: FLAG_KEEP_TRANSFORM_DODGES; also
+    # what a scene without affine rays gets) reads two tables of ray origins, nothing else
+    src = scene.generate_source(baked | pa.FLAG_KEEP_TRANSFORM_DODGES)
+    assert src.count("ptl_pend_") > 4
     block = src[src.index("struct ptl_uniform_block {"):src.index("};", src.index("struct ptl_uniform_block {"))]
     assert re.findall(r"(\w+) ptl_hv\d+(\[\d+\])?;", block) == [("vec4", "[66]"), ("vec4", "[66]")]
     assert src.count("ptl_ray_o(") == 3 and "intersect_material_0_first(Ray r, float ptl_far) {" in src
@@ -1368,8 +1373,10 @@ def test_a_matrix_with_infinities_keeps_every_full_chain(pa):
 def test_generated_defines_go_with_the_generated_source(pa):
     scene = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
     spec = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
-    for flags, want in ((0, {"PTL_FIRST_TRIP"}), (spec, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}), (spec | pa.FLAG_NO_AFFINE_RAYS, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS"}),
-                        (pa.FLAG_SPECIALIZE_PATTERNS, {"PTL_FIRST_TRIP", "PTL_AFFINE_RAYS"}), (spec | pa.FLAG_EXACT_CR, {"PTL_FIRST_TRIP", "PTL_CONTRACT_V1"}),
+    # (PTL_FIRST_TRIP: the kernel has first-trip copies of its snippets -- not with affine rays, where a transform is cheaper than its dodge)
+    for flags, want in ((0, {"PTL_FIRST_TRIP"}), (spec, {"PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}), (spec | pa.FLAG_NO_AFFINE_RAYS, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS"}),
+                        (spec | pa.FLAG_KEEP_TRANSFORM_DODGES, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}),
+                        (pa.FLAG_SPECIALIZE_PATTERNS, {"PTL_AFFINE_RAYS"}), (spec | pa.FLAG_EXACT_CR, {"PTL_FIRST_TRIP", "PTL_CONTRACT_V1"}),
                         (spec | pa.FLAG_FAST_MATH, {"PTL_FIRST_TRIP", "PTL_FAST_MATH"}), (pa.FLAG_COUNT_SEGMENTS | pa.FLAG_ANAGLYPH, {"PTL_FIRST_TRIP", "PTL_COUNT_SEGMENTS", "PTL_ANAGLYPH"})):
         scene.generate_source(flags)
         # (PTL_JIT_MODULE_INLINER: this scene's intersection-material snippet loops, and with the Ints baked the loop is force-unrolled -- the

@@ -119,7 +119,12 @@ def count(scene, w, h, depth, aa, frac, seed=20260925, chunk=16384, options=None
         unit = per_segment.get("unit_term_flops_varying", 0.0)
         known_w = per_segment.get("known_w_term_flops_varying", 0.0)
         per_segment["flops_varying_executed_baked_units"] = per_segment["flops_varying_executed_baked"] - unit * scale
-        per_segment["flops_varying_executed_baked_affine"] = per_segment["flops_varying_executed_baked_units"] - known_w * scale
+        # A kernel with affine rays is generated WITHOUT the deferred loop updates and without first-trip snippet copies (codegen.cpp: its
+        # transforms are a few additions): it executes every transform the snippet writes, shortened term by term.  So: the oracle's count,
+        # minus the culled plane tests, minus zero / unit / known-w terms -- nothing taken off for deferral or first-trip origins.
+        affine_base = per_segment["flops_varying"] - (culls["culled_per_segment"] * culls["oracle_flops_per_plane_test"]["flops_varying"] if culls and PLANE_METER["lane_tests"] else 0.0)
+        affine_scale = affine_base / per_segment["flops_varying"]
+        per_segment["flops_varying_executed_baked_affine"] = affine_base - (zero_terms + unit + known_w) * affine_scale
     return {
         "first_trip_origin_arithmetic": first,
         "scene": scene, "width": w, "height": h, "depth": depth, "aa": aa,

@@ -123,6 +123,10 @@ PATCHES["r5_bake_all_ints"] = [("#define %s (PTL_U.%s)" % (n, n), "#define %s (%
 PATCHES["r5_bake_bound_and_unroll"] = PATCHES["r5_bake_loop_bound"] + [("for (int size = 0; size < show_teleported_u; size++) {", "_Pragma(\"unroll\") for (int size = 0; size < show_teleported_u; size++) {")]
 
 
+# WHAT IF (this scene has no subspace: same picture): the `if (r.in_subspace == false) {` guard around every generated object test gone
+PATCHES["r5_no_subspace_guards"] = [("if (r.in_subspace == false) {", "{")]
+
+
 def _select_form_is_inside_portal(src):
     """EXPERIMENT (must draw the intact picture): the ring classification of scenes/portal_in_portal.ron's library as straight-line selects instead of
     the author's chain of early returns -- what a select-form rewrite of pure early-return functions in the translator would buy."""
