@@ -834,7 +834,14 @@ def test_bench_multi_rank_rehearsal_assembles_the_same_frame(gpu, tmp_path, tran
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common, "--save-png", str(one_png)], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-800:]
     env = dict(os.environ, PTL_BENCH_BACKEND="gloo", PTL_BENCH_TRANSPORT=transport)
-    many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", "29517",
+    # (a free port per run: the four transports of this test run side by side under xdist, and a fixed --master-port collided -- round 5)
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", str(port),
                            os.path.join(root, "bench.py"), "--gpus", "3", *common, "--save-png", str(tmp_path / "three.png")],
                           capture_output=True, text=True, timeout=900, env=env)
     assert many.returncode == 0, many.stderr[-1500:]
