@@ -139,7 +139,7 @@ PTL_FN SurfaceIntersection plane_intersect_normalized(const Ray& r) {
 // Tolerance mode: t = -o'.z / d'.z directly in the plane's frame.  The exact form normalises d' first and divides t by |d'| again
 // -- a square root, a reciprocal and two divisions that cancel algebraically.
 PTL_FN SurfaceIntersection ptl_plane_hit_fast(const Ray& r, const mat4& plane_inv, vec3 unit_normal) {
-    const vec4 o = plane_inv * r.o, d = plane_inv * r.d;
+    const vec4 o = ptl_mul_origin(plane_inv, r.o), d = ptl_mul_direction(plane_inv, r.d);  // (the plain products unless the kernel has affine rays)
     const float t = -o.z * __builtin_amdgcn_rcpf(d.z);
     if (t < 0.0f) return intersection_none;
     return SurfaceIntersection{true, t, fma(d.x, t, o.x), fma(d.y, t, o.y), unit_normal};

@@ -1377,7 +1377,7 @@ def test_generated_defines_go_with_the_generated_source(pa):
     for flags, want in ((0, {"PTL_FIRST_TRIP"}), (spec, {"PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}), (spec | pa.FLAG_NO_AFFINE_RAYS, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS"}),
                         (spec | pa.FLAG_KEEP_TRANSFORM_DODGES, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}),
                         (pa.FLAG_SPECIALIZE_PATTERNS, {"PTL_AFFINE_RAYS"}), (spec | pa.FLAG_EXACT_CR, {"PTL_FIRST_TRIP", "PTL_CONTRACT_V1"}),
-                        (spec | pa.FLAG_FAST_MATH, {"PTL_FIRST_TRIP", "PTL_FAST_MATH"}), (pa.FLAG_COUNT_SEGMENTS | pa.FLAG_ANAGLYPH, {"PTL_FIRST_TRIP", "PTL_COUNT_SEGMENTS", "PTL_ANAGLYPH"})):
+                        (spec | pa.FLAG_FAST_MATH, {"PTL_AFFINE_RAYS", "PTL_FAST_MATH"}), (pa.FLAG_COUNT_SEGMENTS | pa.FLAG_ANAGLYPH, {"PTL_FIRST_TRIP", "PTL_COUNT_SEGMENTS", "PTL_ANAGLYPH"})):
         scene.generate_source(flags)
         # (PTL_JIT_MODULE_INLINER: this scene's intersection-material snippet loops, and with the Ints baked the loop is force-unrolled -- the
         # JIT picks LLVM's module inliner for those builds, kernel.cpp)
@@ -1842,7 +1842,7 @@ def test_affine_rays_scan_of_the_scene_snippets(pa):
 
 def test_affine_rays_are_generated_only_where_they_hold(pa, tmp_path):
     """Which builds get PTL_AFFINE_RAYS: a build that may shorten products, of a scene whose matrices all have the bottom row 0 0 0 1 (or are NaN
-    throughout) and whose snippets pass the scan -- never the un-specialised build, contract 1, the tolerance mode or a kernel that keeps its
+    throughout) and whose snippets pass the scan -- never the un-specialised build, contract 1 or a kernel that keeps its
     full chains; a renderer whose camera leaves the affine maps rebuilds without it."""
     spec = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
 
@@ -1853,7 +1853,7 @@ def test_affine_rays_are_generated_only_where_they_hold(pa, tmp_path):
     for name in ("basics", "monoportal", "triple_portal", "portal_in_portal", "mobius_monoportal"):
         scene = pa.Scene.from_file(pa.scene_path(name))
         assert [has(scene, f) for f in (0, pa.FLAG_SPECIALIZE_INTS, pa.FLAG_SPECIALIZE_PATTERNS, pa.FLAG_SPECIALIZE_STATIC, spec)] == [False, True, True, True, True], name
-        assert not has(scene, spec | pa.FLAG_NO_AFFINE_RAYS) and not has(scene, spec | pa.FLAG_EXACT_CR) and not has(scene, spec | pa.FLAG_FAST_MATH)
+        assert not has(scene, spec | pa.FLAG_NO_AFFINE_RAYS) and not has(scene, spec | pa.FLAG_EXACT_CR) and has(scene, spec | pa.FLAG_FAST_MATH)  # (the tolerance mode has them too)
     corpus = os.path.join(os.path.dirname(os.path.abspath(__file__)), "corpus", "scenes")
     # a Ray from unknown halves / a matrix the snippet computes itself: refused by the scan
     for name in ("half_spheres", "portal_in_portal_plus_ultra", "trefoil", "cylinder"):
