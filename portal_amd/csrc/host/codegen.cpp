@@ -723,7 +723,8 @@ bool snippets_keep_rays_affine(const std::vector<std::string>& codes, std::strin
                 continue;
             }
             // transform(<matrix>, ray): the matrix must be one the affinity checks see -- a scene uniform by name, not a matrix the snippet computed
-            if (t[i].kind == Token::Ident && t[i].text == "transform" && i + 1 < t.size() && t[i + 1].text == "(" && !(i > 0 && t[i - 1].kind == Token::Ident)) {
+            // (`Ray transform(mat4 m, Ray r) {`: a definition, not a call -- anything else in front of the name, `return` included, is a call)
+            if (t[i].kind == Token::Ident && t[i].text == "transform" && i + 1 < t.size() && t[i + 1].text == "(" && !(i > 0 && t[i - 1].text == "Ray")) {
                 const size_t close = closing_paren(t, i + 1);
                 if (close == t.size()) return refuse(t, i, "an unbalanced transform call");
                 auto parts = top_level_parts(t, i + 2, close);
@@ -731,6 +732,17 @@ bool snippets_keep_rays_affine(const std::vector<std::string>& codes, std::strin
                 const bool uniform_matrix = parts.size() == 2 && parts[0].second == parts[0].first + 1 && t[parts[0].first].kind == Token::Ident &&
                                             (ends_with(t[parts[0].first].text, "_mat") || ends_with(t[parts[0].first].text, "_mat_inv") || ends_with(t[parts[0].first].text, "_mat_teleport"));
                 if (!uniform_matrix) return refuse(t, i, "transform() by a matrix that is not a scene uniform");
+                continue;
+            }
+            // material_teleport(hit, r, <matrix>) (library.glsl:376-379: it transforms r by the matrix and hands the result back to be traced): the same rule
+            if (t[i].kind == Token::Ident && t[i].text == "material_teleport" && i + 1 < t.size() && t[i + 1].text == "(" && !(i > 0 && t[i - 1].text == "MaterialProcessing")) {
+                const size_t close = closing_paren(t, i + 1);
+                if (close == t.size()) return refuse(t, i, "an unbalanced material_teleport call");
+                auto parts = top_level_parts(t, i + 2, close);
+                auto ends_with = [](const std::string& x, const char* tail) { const size_t n = std::strlen(tail); return x.size() > n && x.compare(x.size() - n, n, tail) == 0; };
+                const bool uniform_matrix = parts.size() == 3 && parts[2].second == parts[2].first + 1 && t[parts[2].first].kind == Token::Ident &&
+                                            (ends_with(t[parts[2].first].text, "_mat") || ends_with(t[parts[2].first].text, "_mat_inv") || ends_with(t[parts[2].first].text, "_mat_teleport"));
+                if (!uniform_matrix) return refuse(t, i, "material_teleport() by a matrix that is not a scene uniform");
                 continue;
             }
             // <something>.o / .d [.swizzle] <assignment operator>

@@ -1827,11 +1827,12 @@ def test_affine_rays_scan_of_the_scene_snippets(pa):
     keeps = ["Ray r3 = transform(b0_mat_inv, r_b); r3 = normalize_ray(r3);", "r.o += r.d * _offset_after_material;", "r.o = r.o + r.d * (_offset_after_material + hit.t);",
              "r.d = vec4(m * (inverse(n) * r.d.xyz), 0.);", "r.o = vec4(f(i.u, i.v), 1.0);", "return Ray(vec4(mobius_o(u), 1.), vec4(mobius_d(u), 0.), 1.0, false);",
              "r_mob.d = normalize(r_mob.d);", "r.o.xyz -= offset_box; r.o.x += a - b;", "if (r.o == r.d) { float w = r.o.w + r.d.w; }",
-             "Ray q = transform(a_mat, transform(b0_mat_inv, r_b)); q = transform(a_to_b_mat_teleport, q);", "vec4 p = b0_mat * (a_mat_inv * pos);", "// r.d = -r.d;\nfloat x = 1.;"]
+             "Ray q = transform(a_mat, transform(b0_mat_inv, r_b)); q = transform(a_to_b_mat_teleport, q);", "vec4 p = b0_mat * (a_mat_inv * pos);", "// r.d = -r.d;\nfloat x = 1.;", "return transform(a_mat_inv, r);", "Ray transform(mat4 m, Ray r) { return r; }", "return material_teleport(hit, r, a_to_b_mat_teleport);"]
     refused = {"Ray q = Ray(ray_o, ray_d, 1.0, false);": "Ray built from halves", "r.o -= center;": "not known to keep its w", "r.d = -r.d;": "not known to keep its w",
                "r.o.w = 2.;": "write to the w", "r.d.xw += vec2(1.);": "write to the w", "void f(inout Ray r) { }": "out parameter", "void g(out vec4 p) { p = vec4(0.); }": "out parameter",
                "r.d = get_mat(int(hit.v)) * r.d;": "not known to keep its w", "r.o = vec4(p, 0.);": "not known to keep its w", "r.d = normalize(q.d);": "not known to keep its w",
                "x.d /= 2.;": "not known to keep its w", "r3 = transform(mat_transform_inv, r);": "not a scene uniform", "Ray q = transform(inverse(a_mat), r);": "not a scene uniform",
+               "return material_teleport(hit, r, inverse(a_mat));": "not a scene uniform", "return transform(m, r);": "not a scene uniform", "return offset_ray(transform(get_mat(k), r), 0.1);": "not a scene uniform",
                "Ray q = Ray(vec4(o, 1.), vec4(d, 1.), 1., false);": "Ray built from halves", "Ray q = Ray(vec4(o.x, o.y, 1.), vec4(d, 0.), 1., false);": "Ray built from halves"}
     for code in keeps:
         assert pa.snippets_keep_rays_affine(code) == (True, ""), code
