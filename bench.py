@@ -11,15 +11,18 @@ by the kernels storing straight into rank 0's frame over xGMI (whichever is fast
 region; the frame stays in HBM (no host copy inside the timed region).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (ptl_render_kernel).  The kernel is FP32-VALU-bound
-(~10^3 flop per framebuffer byte), so `roofline.bound` is "valu": achieved = algorithmic binary32 operations
-per bounce-loop trip -- counted by the numpy oracle on a >= 1 % pixel sample of THIS full-size frame, restricted to operations
-with a ray-dependent operand when the timed kernel has the scene uniforms baked in (tools/count_flops.py ->
-profiles/r03/flops_per_segment.json) -- x the trips of this launch (counted on the GPU) / the kernel's mean launch time
-(HIP events on the launch stream).  `roofline.valu_issue_frac` is the share of the SIMDs' VALU issue cycles the kernel uses
-(SQ_INSTS_VALU from the committed rocprofv3 PMC pass of the same build) and `roofline.traffic` the HBM bytes per launch from the
-FETCH_SIZE / WRITE_SIZE passes: STORED figures, named in `roofline.pmc_source`, not re-measured by this run.  `roofline_hbm` is
-the framebuffer store (4 B/pixel) against HBM peak: tiny by construction.  `cpu_baseline` times the same generated source
-compiled for the host (oracle/host_build.py, "port") on a bounded sample.
+(~10^3 flop per framebuffer byte), so `roofline.bound` is "valu".  Round 5: `frac` = min(count, hw_arith_frac).
+  count          the oracle's ray-dependent binary32 operations per bounce-loop trip that the timed build still performs (tools/count_flops.py ->
+                 profiles/r05/flops_per_segment.json: a >= 1 % pixel sample of THIS full-size frame; minus culled plane tests, zero / unit matrix
+                 terms and, with affine rays, the terms that meet a ray's w) x the trips of this launch (counted on the GPU) / the kernel's mean
+                 launch time (HIP events on the launch stream);
+  hw_arith_frac  (2 x FMA + MUL + ADD + transcendental wave-instructions) x 64 x lane utilisation / time / peak from the committed rocprofv3 PMC
+                 passes OF THE CODE OBJECT THAT WAS TIMED: the line carries the sha256 of that binary (`config.code_object_sha256`), every
+                 profiles/r05/pmc_*.json the sha256 of the binary it counted, and a file of another binary is refused (`pmc_unavailable`).
+`roofline.traffic` = HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes of the same file.  `roofline_hbm` is the framebuffer store (4 B/pixel)
+against HBM peak: tiny by construction.  `cpu_baseline` times the same generated source compiled for the host (oracle/host_build.py, "port") on a
+bounded sample.  `workloads`: every other BASELINE.json config, the Panini variant and two deep views, each timed and checked the same way (N = 1).
+`python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run, 127.0.0.1).
 """
 from __future__ import annotations
 
