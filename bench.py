@@ -669,12 +669,22 @@ def main():
             while len(in_flight) >= tr.depth:  # a buffer is reused only after its frame has been assembled
                 s0, work = in_flight.pop(0)
                 last = tr.finish(work, s0)
-            pair = events.get(k) if isinstance(events, dict) else (events[k] if events is not None else None)
-            if pair is not None:
-                pair[0].record(stream)
-            r.draw_device(tr.frame, out_rgba8=tr.out_ptr(slot), stream=stream.cuda_stream)
-            if pair is not None:
-                pair[1].record(stream)
+            # `events`: a list of (start, end) pairs, one per step -- or a dict {first step of a group: (start, end, launches)}: ONE pair around a
+            # group of consecutive launches (what the timed region of the headline uses: see there)
+            if isinstance(events, dict):
+                if k in events:
+                    events[k][0].record(stream)
+                r.draw_device(tr.frame, out_rgba8=tr.out_ptr(slot), stream=stream.cuda_stream)
+                g0 = k - k % events["group"]
+                if k == min(g0 + events["group"], n) - 1:
+                    events[g0][1].record(stream)
+            else:
+                pair = events[k] if events is not None else None
+                if pair is not None:
+                    pair[0].record(stream)
+                r.draw_device(tr.frame, out_rgba8=tr.out_ptr(slot), stream=stream.cuda_stream)
+                if pair is not None:
+                    pair[1].record(stream)
             in_flight.append((slot, tr.submit(slot)))
         for s0, work in in_flight:
             last = tr.finish(work, s0)
@@ -737,15 +747,19 @@ def main():
 
     stage(f"timed region through {transport.name}")
     run_steps(transport, args.warmup)
-    # The kernel's launch duration is SAMPLED: an event pair around every 8th launch of the timed region (every launch when the region is short).
-    # An event record is a packet of its own in the queue, and two of them around every launch held consecutive frames 8 us apart -- 4 % of a
-    # headline step, 11 % of a 1080p step -- that a renderer which just queues its frames does not pay (tools/small_frames.py: 0.1873 ms per
-    # frame back to back against 0.1957 per step with the markers; profiles/r05/small_frames.jsonl).
+    # The kernel's launch duration is measured over GROUPS: one event pair around every eight consecutive launches of the timed region (around
+    # every launch when the region is short), the elapsed time divided by the launches in the group.  An event record is a packet of its own in
+    # the queue, and two of them around EVERY launch held consecutive frames 8 us apart -- 4 % of a headline step, 17 % of a 1080p step -- that a
+    # renderer which just queues its frames does not pay (tools/small_frames.py: 0.1873 ms per frame back to back against 0.1957 per step
+    # with the markers; profiles/r05/small_frames.jsonl); and a pair around ONE launch in eight measures that launch WITH its markers (0.1924
+    # against 0.1884 ms per step).  Per group, the figure is what rocprofv3's per-dispatch duration + the dispatch gap add up to.
     every = 8 if args.steps >= 64 else 1
-    events = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, args.steps, every)}
+    events = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), min(every, args.steps - k)) for k in range(0, args.steps, every)}
+    events["group"] = every
     elapsed, last = timed_steps(transport, args.steps, events)
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()]))
-    kernel_ms_sampled_launches = len(events)
+    groups = [v for k, v in events.items() if k != "group"]
+    kernel_ms = float(sum(a.elapsed_time(b) for a, b, _ in groups) / sum(c for _, _, c in groups))
+    kernel_ms_sampled_launches = len(groups)
     per_rank_ms = [kernel_ms]
     if world > 1:  # every rank's own kernel time: load balance of the interleave, and the slowest sets the frame
         gathered = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
@@ -865,20 +879,20 @@ def main():
                     rr.draw_device(fr, out_rgba8=buf.data_ptr(), stream=stream.cuda_stream)
                 probe_ms = float(np.median([rr.draw_device(fr, out_rgba8=buf.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(10)]))
                 steps = int(max(10, min(200, 40.0 / max(probe_ms, 0.02))))  # ~40 ms of timed region
-                ev_every = 8 if steps >= 64 else 1  # (sampled like the headline's: an event pair around every 8th launch)
-                ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, steps, ev_every)}
+                ev_every = 8 if steps >= 64 else 1  # (like the headline's: one event pair around every eight consecutive launches)
+                ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), min(ev_every, steps - k)) for k in range(0, steps, ev_every)}
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
                 for k in range(steps):
-                    pair = ev.get(k)
-                    if pair is not None:
-                        pair[0].record(stream)
+                    if k in ev:
+                        ev[k][0].record(stream)
                     rr.draw_device(fr, out_rgba8=buf.data_ptr(), stream=stream.cuda_stream)
-                    if pair is not None:
-                        pair[1].record(stream)
+                    g0 = k - k % ev_every
+                    if k == min(g0 + ev_every, steps) - 1:
+                        ev[g0][1].record(stream)
                 torch.cuda.synchronize(dev)
                 ms_step = (time.perf_counter() - t0) / steps * 1e3
-                kms = float(np.mean([x.elapsed_time(y) for x, y in ev.values()]))
+                kms = float(sum(x.elapsed_time(y) for x, y, _ in ev.values()) / sum(c for _, _, c in ev.values()))
                 cnt = pa.SceneRenderer(sc, device=local_rank, flags=pa.FLAG_COUNT_SEGMENTS | spec_flags, **sc_kw)
                 configure(cnt, a)
                 seg = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -1083,7 +1097,7 @@ def main():
                 **({"transport": transport.name, "transport_ms_per_frame": transport_ms, "transport_notes": transport_notes} if world > 1 else {}),
             },
             "kernel_ms": round(kernel_ms, 4),
-            "kernel_ms_from": f"HIP events around {kernel_ms_sampled_launches} of the {args.steps} timed launches (every {every}th)",
+            "kernel_ms_from": f"HIP events around {kernel_ms_sampled_launches} groups of {every} consecutive launches of the {args.steps} timed ones: elapsed / launches",
             # per rank: the interleave's load balance; ms_per_step - max(kernel_ms_per_rank) = what assembling the frame costs on top of tracing
             "kernel_ms_per_rank": [round(x, 4) for x in per_rank_ms],
             "kernel_ms_min_max": [round(min(per_rank_ms), 4), round(max(per_rank_ms), 4)],
