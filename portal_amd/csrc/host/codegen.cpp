@@ -788,10 +788,20 @@ bool snippets_keep_rays_affine(const std::vector<std::string>& codes, std::strin
                     w.push_back(half);
                     return w;
                 };
+                // (`X.d * <matrix>` is GLSL too -- a row vector times a matrix, with whatever w comes out: an offset "along the direction" may not name one)
+                auto names_a_matrix = [&](size_t from) {
+                    for (size_t k = from; k < end; ++k)
+                        if (t[k].kind == Token::Ident) {
+                            const std::string& x = t[k].text;
+                            auto tail = [&](const char* e) { const size_t n = std::strlen(e); return x.size() >= n && x.compare(x.size() - n, n, e) == 0; };
+                            if (x == "mat4" || x == "mat3" || x == "inverse" || x == "transpose" || tail("_mat") || tail("_mat_inv") || tail("_mat_teleport")) return true;
+                        }
+                    return false;
+                };
                 if (origin && op == "+=") {  // X.o += X.d * <scalar expression>: w moves by 0 * s
                     std::vector<std::string> lead = member("d");
                     lead.push_back("*");
-                    if (spells(j + 1, lead)) continue;
+                    if (spells(j + 1, lead) && !names_a_matrix(j + 1 + lead.size())) continue;
                 }
                 if (op == "=") {
                     if (is_vec4_with_w(t, j + 1, end, origin ? 1.0 : 0.0)) continue;  // X.o = vec4(.., 1.) / X.d = vec4(.., 0.)
@@ -805,7 +815,7 @@ bool snippets_keep_rays_affine(const std::vector<std::string>& codes, std::strin
                         lead.push_back("+");
                         for (auto& w : member("d")) lead.push_back(w);
                         lead.push_back("*");
-                        if (spells(j + 1, lead)) continue;
+                        if (spells(j + 1, lead) && !names_a_matrix(j + 1 + lead.size())) continue;
                     }
                 }
                 return refuse(t, own, "a ray half assigned in a form that is not known to keep its w");

@@ -1832,7 +1832,8 @@ def test_affine_rays_scan_of_the_scene_snippets(pa):
                "r.o.w = 2.;": "write to the w", "r.d.xw += vec2(1.);": "write to the w", "void f(inout Ray r) { }": "out parameter", "void g(out vec4 p) { p = vec4(0.); }": "out parameter",
                "r.d = get_mat(int(hit.v)) * r.d;": "not known to keep its w", "r.o = vec4(p, 0.);": "not known to keep its w", "r.d = normalize(q.d);": "not known to keep its w",
                "x.d /= 2.;": "not known to keep its w", "r3 = transform(mat_transform_inv, r);": "not a scene uniform", "Ray q = transform(inverse(a_mat), r);": "not a scene uniform",
-               "return material_teleport(hit, r, inverse(a_mat));": "not a scene uniform", "return transform(m, r);": "not a scene uniform", "return offset_ray(transform(get_mat(k), r), 0.1);": "not a scene uniform",
+               "return material_teleport(hit, r, inverse(a_mat));": "not a scene uniform", "r.o += r.d * a_mat;": "not known to keep its w",
+               "r.o = r.o + r.d * mat4(2.);": "not known to keep its w", "return transform(m, r);": "not a scene uniform", "return offset_ray(transform(get_mat(k), r), 0.1);": "not a scene uniform",
                "Ray q = Ray(vec4(o, 1.), vec4(d, 1.), 1., false);": "Ray built from halves", "Ray q = Ray(vec4(o.x, o.y, 1.), vec4(d, 0.), 1., false);": "Ray built from halves"}
     for code in keeps:
         assert pa.snippets_keep_rays_affine(code) == (True, ""), code
