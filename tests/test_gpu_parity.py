@@ -833,7 +833,7 @@ def test_bench_multi_rank_rehearsal_assembles_the_same_frame(gpu, tmp_path, tran
     one_png = tmp_path / "one.png"
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common, "--save-png", str(one_png)], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-800:]
-    env = dict(os.environ, PTL_BENCH_BACKEND="gloo", PTL_BENCH_TRANSPORT=transport)
+    env = dict(os.environ, PTL_BENCH_BACKEND="gloo", PTL_BENCH_TRANSPORT=transport, PTL_BENCH_DETAIL=str(tmp_path / "detail.json"))
     # (a free port per run: the four transports of this test run side by side under xdist, and a fixed --master-port collided -- round 5)
     import socket
 
@@ -845,8 +845,12 @@ def test_bench_multi_rank_rehearsal_assembles_the_same_frame(gpu, tmp_path, tran
                            os.path.join(root, "bench.py"), "--gpus", "3", *common, "--save-png", str(tmp_path / "three.png")],
                           capture_output=True, text=True, timeout=900, env=env)
     assert many.returncode == 0, many.stderr[-1500:]
-    line = json.loads([l for l in many.stdout.splitlines() if l.startswith("{")][-1])
+    last = many.stdout.strip().splitlines()[-1]
+    assert len(last) <= 4096, len(last)   # round 6: the stdout line is the compact one (round 5's 32 KB line came back unparsed from the driver)
+    line = json.loads(last)
     assert line["n_gpus"] == 3 and line["steps"] == 4 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["transport"] in ("rccl-gather", "p2p-stores", "p2p-copy") and len(line["kernel_ms_per_rank"]) == 3
+    line = json.load(open(tmp_path / "detail.json"))   # the detail record: everything the compact line leaves out
     cfg = line["config"]
     print(transport, cfg["transport"], cfg["transport_ms_per_frame"], cfg["transport_notes"])
     if transport == "gather":
@@ -863,7 +867,8 @@ def test_bench_multi_rank_rehearsal_assembles_the_same_frame(gpu, tmp_path, tran
     assert len(line["kernel_ms_per_rank"]) == 3 and all(ms > 0 for ms in line["kernel_ms_per_rank"])
     assert line["kernel_ms_min_max"] == [min(line["kernel_ms_per_rank"]), max(line["kernel_ms_per_rank"])] and line["transport_ms"] >= 0
     assert line["frame_check"] == {"last_timed_frame_equals_the_frame_rendered_by_rank0_alone": True}
-    single = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    single = json.loads(one.stdout.strip().splitlines()[-1])
+    assert len(one.stdout.strip().splitlines()[-1]) <= 4096
     assert len(single["kernel_ms_per_rank"]) == 1 and "frame_check" not in single and single["roofline"]["bound"] in ("valu", "hbm")
 
 
@@ -877,7 +882,7 @@ def test_bench_multi_rank_rehearsal_of_the_headline_line(gpu, tmp_path):
     import sys
 
     pa = gpu
-    env = dict(os.environ, PTL_BENCH_BACKEND="gloo")
+    env = dict(os.environ, PTL_BENCH_BACKEND="gloo", PTL_BENCH_DETAIL=str(tmp_path / "detail.json"))
     # started the way the driver starts `--gpus 1`: plain python, no launcher -- bench.py starts its three ranks itself
     env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     run = subprocess.run([sys.executable, os.path.join(pa.REPO_ROOT, "bench.py"), "--gpus", "3", "--steps", "6", "--warmup", "2"], capture_output=True, text=True, timeout=1200, env=env)
@@ -887,7 +892,14 @@ def test_bench_multi_rank_rehearsal_of_the_headline_line(gpu, tmp_path):
     refused = subprocess.run([sys.executable, os.path.join(pa.REPO_ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300,
                              env={k: v for k, v in env.items() if k != "PTL_BENCH_BACKEND"})
     assert refused.returncode != 0 and "--gpus 64 but this node shows" in refused.stderr and '"n_gpus"' not in refused.stdout
-    line = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    last = run.stdout.strip().splitlines()[-1]
+    assert len(last) <= 4096, len(last)   # the line the driver has to parse
+    compact = json.loads(last)
+    assert compact["n_gpus"] == 3 and compact["value"] > 0 and "portal_in_portal.ron 3840x2160" in compact["config"]["workload"]
+    assert compact["roofline"]["bound"] == "valu" and "frac" in compact["roofline"] and "traffic" in compact["roofline"]
+    assert compact["frame_check"] == {"last_timed_frame_equals_the_frame_rendered_by_rank0_alone": True}
+    assert len(compact["kernel_ms_per_rank"]) == 3 and [w["id"] for w in compact["workloads"]] == ["c5"] and len(compact["workloads"][0]["kernel_ms_per_rank"]) == 3
+    line = json.load(open(tmp_path / "detail.json"))
     cfg = line["config"]
     assert line["n_gpus"] == 3 and line["value"] > 0 and "portal_in_portal.ron 3840x2160" in cfg["workload"]
     assert cfg["candidate_frames_identical"] is True and len(cfg["candidate_frame_sha256_16"]) == 16 and "candidates_excluded" not in cfg

@@ -126,3 +126,37 @@ def test_round5_gpu_suite_and_clip_records():
 
     per_subframe = [float(x) for x in re.findall(r"\((\d+\.\d+) ms each\)", video)]
     assert len(per_subframe) == 2 and per_subframe[0] < 0.7 and per_subframe[1] <= 1.4   # clip-specialised; the patterns kernel
+
+
+# ---- round 6 -----------------------------------------------------------------------------------------------------------------------------
+def test_the_stdout_line_stays_small_enough_for_the_driver():
+    """round 5's line had grown to 32 KB and came back `parsed: null`.  bench.py now prints `compact_line(detail)`; fed round 5's
+    own 32 KB record -- and the same record dressed up as an 8-rank run -- it stays under 4 KB and keeps every key of the contract."""
+    import sys
+
+    sys.path.insert(0, HERE)
+    import bench
+
+    d = _lines(os.path.join(R05, "bench_pip4k_1gpu.json"))[-1]
+    assert len(json.dumps(d)) > 30_000
+    eight = json.loads(json.dumps(d))
+    eight.update(n_gpus=8, kernel_ms_per_rank=[0.0301 + 0.0001 * k for k in range(8)], frame_check={"last_timed_frame_equals_the_frame_rendered_by_rank0_alone": True})
+    eight["config"].update(transport="rccl-gather", parallelism="row-block interleave x8 + one RCCL gather to rank 0 + de-interleave copy, double-buffered (gather n overlaps trace n+1)")
+    eight["workloads"][0]["kernel_ms_per_rank"] = [1.6123 + 0.001 * k for k in range(8)]
+    for rec in (d, eight):
+        text = bench.compact_line(rec)
+        assert len(text) <= bench.COMPACT_LINE_LIMIT and "\n" not in text
+        line = json.loads(text)
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert key in line, key
+        assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and line["roofline"]["pmc_code_object_sha256"] == line["config"]["code_object_sha256"]
+        assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and "workload" in line["config"] and "model" not in line["config"]
+        assert line["parity"]["timed_build_vs_reference_text"] == {"pixels": 106496, "bit_exact": True, "max_abs_error": 0.0}
+        assert [w["id"] for w in line["workloads"]] == ["c5", "c2", "c3", "c4-panini", "c4-deep", "recursive-room"] and all(w["bit_exact"] for w in line["workloads"])
+        assert "dropped_for_size" not in line
+    assert json.loads(bench.compact_line(eight))["kernel_ms_per_rank"] == eight["kernel_ms_per_rank"]
+    # ... and a record that outgrows the limit anyway loses its extras, never its parseability
+    fat = json.loads(json.dumps(d))
+    fat["workloads"] = fat["workloads"] * 12
+    text = bench.compact_line(fat)
+    assert len(text) <= bench.COMPACT_LINE_LIMIT and "workloads" in json.loads(text)["dropped_for_size"] and "roofline" in json.loads(text)
