@@ -297,6 +297,9 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * column then costs a direction nothing and the w row folds to a constant (headline kernel -16 %); the same operations on the same values
  * for finite rays, identical frames.  A renderer rebuilds without it when a matrix -- the camera's included -- stops being affine.
  * This bit keeps the general products (A/B measurements, tests),
+ * bit25 = CHECK AFFINE (round 6, diagnostics): never affine rays; the kernel is generated with PTL_CHECK_AFFINE and its `segments` counter (bit1 is
+ * implied) counts, instead of bounce-loop trips, the ray halves that reach a matrix-times-ray product or the bounce loop with a w that is
+ * not 1 (origin) / 0 (direction) -- what a kernel with affine rays would have assumed wrongly.  Same frames as bit23.  See ptl_renderer_check_affine.
  * bit24 = KEEP TRANSFORM DODGES (A/B): a kernel with affine rays (bit23 clear and everything affine) is generated WITHOUT the deferred loop updates
  * (bit7) and the first-trip snippet copies (bit13) -- both dodge `transform(uniform matrix, ray)`, which is a handful of additions there and
  * cheaper than the bookkeeping around it (headline baked 0.2305 -> 0.2046 ms, Int-baked 0.272 -> 0.239, patterns 0.274 -> 0.239; identical
@@ -417,9 +420,19 @@ int ptl_dmath(const char* op, const double* a, const double* b, const double* c,
  * matrix and the camera affine, no snippet that writes a ray's w): its matrix-times-ray products spell o.w = 1 / d.w = 0.  A matrix or a
  * camera that stops being affine makes the next draw rebuild without it (counted by ptl_renderer_rejit_count); 0 then, and for every other build. */
 int ptl_renderer_affine_rays(ptl_renderer* r);
+/* Round 6 -- the dynamic belt behind that decision (the reference has nothing to check: `transform` multiplies all four components,
+ * /root/reference/src/library.glsl:95-120).  Builds the checking kernel of the renderer's CURRENT state (flag bit25: general products, every
+ * place an affine-rays kernel assumes a w counts the ray halves that arrive with another one), draws width x height with the renderer's camera
+ * and options, and reports the count.  A count above zero on a renderer whose kernel has affine rays switches them off for the stage and
+ * rebuilds (ptl_renderer_rejit_count goes up, ptl_last_error says why); its frames were and stay those of the general products only from then on.
+ * Needs a device.  The renderer option "check_affine" = 1 (or PTL_CHECK_AFFINE=1 in the environment) runs this at 64 x 36 before the first
+ * draw with every new affine-rays source; `portal-amd check` runs it when a GPU is present. */
+int ptl_renderer_check_affine(ptl_renderer* r, int width, int height, unsigned long long* violations);
 /* The scan behind that decision, exposed for tests: 1 when the GLSL text keeps rays affine (no Ray built from halves whose w is not spelled
  * `vec4(.., 1.)` / `vec4(.., 0.)`, no `.o` / `.d` assigned in another than the whitelisted forms, no out / inout parameter of type Ray or
- * vec4, no transform() by a matrix that is not a scene uniform), 0 with the offending text in `why`, -1 on malformed input (ptl_last_error). */
+ * vec4, no transform() by a matrix that is not a scene uniform), 0 with the offending text in `why`, -1 on malformed input (ptl_last_error).
+ * Round 6: a whitelist over EVERY write to a ray half (x / y / z alone, or the whole half in five spelled forms), no preprocessor directive, no
+ * out / inout parameter of any type, no modf / frexp, no `ray_none` (codegen.cpp; hunted by tests/test_affine_guard_fuzz.py). */
 int ptl_snippets_keep_rays_affine(const char* glsl, char* why, size_t why_cap);
 /* how many times a draw had to rebuild a specialised kernel since the renderer was created: a clip-constant value that moved (flags bit3),
  * a mode switch that was flipped (flags bit0 / bit2 / bit3) */

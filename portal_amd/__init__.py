@@ -60,6 +60,7 @@ FLAG_QUICK_JIT = 262144  # compile at -O1 instead of the shipped -O3: half the J
 FLAG_SPECIALIZE_PATTERNS = 1048576  # compile in only what survives moving values: zero patterns of the matrices + the renderer's mode switches
 FLAG_BOUNDED_SNIPPETS = 2097152  # opt-in: scene_intersect first, its hit distance bounds the intersection-material snippets (exact; measured: no gain on the headline)
 FLAG_KEEP_TRANSFORM_DODGES = 16777216  # A/B: deferred loop updates + first-trip snippet copies also in a kernel with affine rays (default there: neither; identical frames)
+FLAG_CHECK_AFFINE = 1 << 25  # diagnostics: general products, and `segments` counts the ray halves that meet a product / the bounce loop with a w that is not 1 / 0
 FLAG_NO_AFFINE_RAYS = 8388608  # A/B: matrix-times-ray products never assume o.w = 1 / d.w = 0 (default in specialised builds of affine scenes: they do; identical frames)
 FLAG_SLICES = 4194304  # the render entry reads its uniform block from a buffer of blocks (one per blockIdx.z): stage_slice / draw_slices, one launch for several draws
 FLAG_NO_ZERO_MASKS = 524288  # A/B: run-time matrices keep their full products although their zero pattern is known (KernelOptions::mask_zero_elements)
@@ -154,6 +155,7 @@ def _load() -> C.CDLL:
         "ptl_kernel_stage_slice": (ci, [vp, ci]),
         "ptl_kernel_hold_textures": (ci, [vp, ci]),
         "ptl_renderer_affine_rays": (ci, [vp]),
+        "ptl_renderer_check_affine": (ci, [vp, ci, ci, P(C.c_ulonglong)]),
         "ptl_dmath": (ci, [cp, P(cd), P(cd), P(cd), P(cd)]),
         "ptl_snippets_keep_rays_affine": (ci, [cp, cp, cs]),
         "ptl_code_object_note": (ci, [vp, cs, cp, cp]),
@@ -235,6 +237,11 @@ def lib() -> C.CDLL:
 
 def _err() -> str:
     return lib().ptl_last_error().decode("utf-8", "replace")
+
+
+def last_error() -> str:
+    """ptl_last_error(): the message of the most recent failure -- or note, e.g. why a renderer switched affine rays off -- on this thread."""
+    return _err()
 
 
 def _check(rc: int, what: str) -> int:
@@ -563,6 +570,13 @@ class SceneRenderer:
         """The current kernel spells o.w = 1 / d.w = 0 in its matrix-times-ray products (every scene matrix and the camera affine)."""
         lib().ptl_renderer_kernel(self._h)  # (the kernel the next draw would use)
         return lib().ptl_renderer_affine_rays(self._h) == 1
+
+    def check_affine(self, width: int = 64, height: int = 36) -> int:
+        """The dynamic belt behind the snippet scan: draws the current state with the checking build (FLAG_CHECK_AFFINE) and returns how many ray
+        halves met a place where an affine-rays kernel assumes a w with another one; above zero the renderer switches affine rays off and rebuilds."""
+        n = C.c_ulonglong(0)
+        _check(lib().ptl_renderer_check_affine(self._h, width, height, C.byref(n)), "ptl_renderer_check_affine")
+        return int(n.value)
 
     def rejit_pending(self) -> bool:
         """FLAG_ASYNC_REJIT: a specialised build is being compiled in the background / the un-specialised kernel is in use."""

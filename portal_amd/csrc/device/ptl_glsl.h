@@ -24,6 +24,32 @@
 #define PTL_DEVICE_BUILD 0
 #endif
 
+// Counters, compiled in only on request (the kernel's `segments` argument receives the sum): bounce-loop trips (PTL_COUNT_SEGMENTS: segment
+// Mray/s) or -- round 6, PTL_CHECK_AFFINE, the dynamic belt behind codegen.cpp `snippets_keep_rays_affine` -- the number of times a
+// ray half reached a place where a kernel with affine rays ASSUMES its w (the matrix-times-ray products, the bounce loop's `ptl_affine`) with
+// another w than 1 (origin) / 0 (direction).  Such a build has the general products, so its frame is right either way; a non-zero count says
+// that an affine-rays kernel of this scene state would not be (ptl_renderer_check_affine).
+#if defined(PTL_CHECK_AFFINE) && !defined(PTL_COUNT_SEGMENTS)
+#define PTL_COUNT_SEGMENTS 1
+#endif
+#ifdef PTL_COUNT_SEGMENTS
+#if PTL_DEVICE_BUILD
+__shared__ unsigned int ptl_segments_lds[256];
+#define PTL_COUNTER_BUMP() (ptl_segments_lds[threadIdx.x] += 1u)
+#else
+thread_local unsigned long long ptl_segments_tls = 0;
+#define PTL_COUNTER_BUMP() (ptl_segments_tls += 1ull)
+#endif
+#endif
+#if defined(PTL_CHECK_AFFINE)
+#define PTL_COUNT_SEGMENT() ((void)0)
+#define PTL_NOTE_NOT_AFFINE() PTL_COUNTER_BUMP()
+#elif defined(PTL_COUNT_SEGMENTS)
+#define PTL_COUNT_SEGMENT() PTL_COUNTER_BUMP()
+#else
+#define PTL_COUNT_SEGMENT() ((void)0)
+#endif
+
 namespace glsl {
 
 // ---------------------------------------------------------------------------------------
@@ -815,8 +841,23 @@ template <ptl_mask_t MASK, int W = PTL_W_ANY> PTL_FN vec4 ptl_mul_m(const mat4& 
 #define PTL_W_OF_ORIGIN PTL_W_ANY
 #define PTL_W_OF_DIRECTION PTL_W_ANY
 #endif
-template <ptl_mask_t MASK = 0xffffu> PTL_FN vec4 ptl_mul_origin(const mat4& m, const vec4& o) { return ptl_mul_m<MASK, PTL_W_OF_ORIGIN>(m, o); }
-template <ptl_mask_t MASK = 0xffffu> PTL_FN vec4 ptl_mul_direction(const mat4& m, const vec4& d) { return ptl_mul_m<MASK, PTL_W_OF_DIRECTION>(m, d); }
+// PTL_CHECK_AFFINE: a half that arrives with another w (a vector that is NaN throughout -- behind a switched-off object's all-NaN matrix -- gives NaN
+// products whatever its w is taken for, and is not counted)
+#ifdef PTL_CHECK_AFFINE
+PTL_FN void ptl_check_w(const vec4& v, float w) {
+    if (!(v.w == w) && (v.x == v.x || v.y == v.y || v.z == v.z || v.w == v.w)) PTL_NOTE_NOT_AFFINE();
+}
+#else
+PTL_FN void ptl_check_w(const vec4&, float) {}
+#endif
+template <ptl_mask_t MASK = 0xffffu> PTL_FN vec4 ptl_mul_origin(const mat4& m, const vec4& o) {
+    ptl_check_w(o, 1.0f);
+    return ptl_mul_m<MASK, PTL_W_OF_ORIGIN>(m, o);
+}
+template <ptl_mask_t MASK = 0xffffu> PTL_FN vec4 ptl_mul_direction(const mat4& m, const vec4& d) {
+    ptl_check_w(d, 0.0f);
+    return ptl_mul_m<MASK, PTL_W_OF_DIRECTION>(m, d);
+}
 // (`X_mat * <anything else>` that the generator rewrote by its shape alone -- a matrix, a scalar: the ordinary product)
 template <ptl_mask_t MASK, class T> PTL_FN auto ptl_mul_m(const mat4& m, const T& x) -> decltype(m * x) { return m * x; }
 // the same product for a matrix that is a run-time value in every build (the camera): no zero tests (they would be executed)

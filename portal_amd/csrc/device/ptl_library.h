@@ -84,8 +84,8 @@ PTL_FN Ray transform(const mat4& m, const Ray& r) {
 }
 #else
 PTL_FN Ray transform(const mat4& matrix, const Ray& r) {
-#ifdef PTL_AFFINE_RAYS
-    return Ray{ptl_mul_origin(matrix, r.o), ptl_mul_direction(matrix, r.d), r.tmul, r.in_subspace};  // o.w = 1, d.w = 0 (ptl_glsl.h `ptl_row_m`)
+#if defined(PTL_AFFINE_RAYS) || defined(PTL_CHECK_AFFINE)
+    return Ray{ptl_mul_origin(matrix, r.o), ptl_mul_direction(matrix, r.d), r.tmul, r.in_subspace};  // o.w = 1, d.w = 0 (ptl_glsl.h `ptl_row_m`; the checking build: the plain products, w looked at)
 #else
     return Ray{matrix * r.o, matrix * r.d, r.tmul, r.in_subspace};
 #endif
@@ -96,6 +96,8 @@ PTL_FN Ray ptl_affine(const Ray& r) {
 #ifdef PTL_AFFINE_RAYS
     return Ray{vec4(r.o.x, r.o.y, r.o.z, 1.0f), vec4(r.d.x, r.d.y, r.d.z, 0.0f), r.tmul, r.in_subspace};
 #else
+    ptl_check_w(r.o, 1.0f);  // (PTL_CHECK_AFFINE: the ray the bounce loop is about to trace; otherwise nothing)
+    ptl_check_w(r.d, 0.0f);
     return r;
 #endif
 }

@@ -9,18 +9,7 @@
 // LDS so that every wave stores two full 128-byte rows.
 //%predefined_library//%
 
-// bounce-loop trip counter (segment Mray/s, SURVEY.md 8d); compiled in only on request
-#ifdef PTL_COUNT_SEGMENTS
-#if PTL_DEVICE_BUILD
-__shared__ unsigned int ptl_segments_lds[256];
-#define PTL_COUNT_SEGMENT() (ptl_segments_lds[threadIdx.x] += 1u)
-#else
-thread_local unsigned long long ptl_segments_tls = 0;
-#define PTL_COUNT_SEGMENT() (ptl_segments_tls += 1ull)
-#endif
-#else
-#define PTL_COUNT_SEGMENT() ((void)0)
-#endif
+// (the bounce-loop trip counter PTL_COUNT_SEGMENT() -- and the checking build's PTL_NOTE_NOT_AFFINE() -- are declared at the top of ptl_glsl.h)
 
 namespace glsl {
 

@@ -128,6 +128,11 @@ struct ptl_renderer {
     // build: checked before every draw) -- has the bottom row 0 0 0 1.  One that does not switches the assumption off for this stage.
     bool affine_rays = false;  // the current kernel was generated with PTL_AFFINE_RAYS
     bool no_affine = false;    // ... and must not be any more
+    // Round 6: option "check_affine" (or PTL_CHECK_AFFINE=1 in the environment): the first draw with every NEW affine-rays source first runs the
+    // checking build of the same state at 64 x 36 (ptl_renderer_check_affine); a ray that met a product with another w switches the assumption off.
+    bool check_affine_on_new_source = false;
+    std::string checked_source;
+    unsigned long long affine_violations_seen = 0;
     // SceneRenderer::update state (src/main.rs:1430-1538)
     Camera prev_cam;
     bool has_prev_cam = false;
@@ -485,6 +490,7 @@ static KernelOptions options_from_flags(unsigned flags) {
     // is half of its hiprtc time for the headline scene (3.4 -> 1.8 s on this container's cores) and buys 0.05 ms of kernel
     o.unroll_baked_loops = (flags & 32768u) == 0 && !o.quick_jit;
     o.keep_transform_dodges = (flags & (1u << 24)) != 0;  // PTL_FLAG_KEEP_TRANSFORM_DODGES: deferred updates + first-trip snippet copies also with affine rays (A/B)
+    o.check_affine = (flags & (1u << 25)) != 0;   // PTL_FLAG_CHECK_AFFINE: general products, and `segments` counts the ray halves whose w is not 1 / 0
     o.affine_rays = (flags & (1u << 23)) == 0;    // PTL_FLAG_NO_AFFINE_RAYS: matrix-times-ray products never assume o.w = 1 / d.w = 0 (A/B measurements, tests)
     o.first_trip = (flags & 8192u) == 0;          // PTL_FLAG_NO_FIRST_TRIP: no first-trip copies of the intersection-material snippets
     o.hoist_uniform_work = (flags & 4096u) == 0;  // PTL_FLAG_NO_UNIFORM_HOIST: snippets evaluate their uniform-only expressions per ray
@@ -867,6 +873,7 @@ extern "C" int ptl_renderer_create_with_options(ptl_scene* s, int device, const 
         r->device = device;
         r->flags = flags;
         r->asset_root = asset_root ? asset_root : "";
+        if (const char* e = std::getenv("PTL_CHECK_AFFINE"); e && e[0] == '1') r->check_affine_on_new_source = true;
         // options first: a specialised build compiles the mode switches in (mode_switches), so the FIRST build is already the one the
         // caller will draw with (`render --stereoimage`: draw_side_by_side) instead of a build nothing runs on plus a rebuild
         for (int k = 0; k < n_options; ++k) {
@@ -901,6 +908,10 @@ extern "C" int ptl_renderer_create(ptl_scene* s, int device, const char* asset_r
 // every option that is a plain field (no rebuild): PTL_OK, or PTL_UNKNOWN_UNIFORM for a name that is not one
 static int set_plain_option(ptl_renderer* r, const std::string& n, double v) {
     bool b = v > 0.5;
+    if (n == "check_affine") {
+        r->check_affine_on_new_source = b;
+        return PTL_OK;
+    }
     if (n == "render_depth") r->render_depth = (int)v;
     else if (n == "aa_count") r->aa_count = (int)v;
     else if (n == "aa_start") r->aa_start = (int)v;
@@ -1333,12 +1344,92 @@ extern "C" int ptl_renderer_join(ptl_renderer* r, void* stream) {
     return guarded([&] { return join_lanes(r, stream); });
 }
 
+// The dynamic belt behind `snippets_keep_rays_affine` (VERDICT r5 #2c).  A sibling renderer of the same scene handle and the same specialisation is
+// built with PTL_FLAG_CHECK_AFFINE (general products; the assumption sites count what arrives with another w), gets this renderer's camera and
+// options, and draws the current state once at width x height.  A count above zero means: a kernel that ASSUMES w = 1 / 0 would have computed with
+// other values for this very state -- the renderer then switches affine rays off for its stage and rebuilds (one re-JIT, the frames stay right).
+static int check_affine_now(ptl_renderer* r, int width, int height, unsigned long long* violations) {
+    if (r->device < 0) return PTL_ERR_NO_DEVICE;
+    const unsigned flags = (r->flags & ~(kAsyncRejit | (1u << 22) | (1u << 23))) | (1u << 25) | 2u | 262144u;  // not async, no slices entry; checking + counting, quick JIT
+    std::vector<char> log(1 << 16);
+    ptl_renderer* sib = nullptr;
+    int rc = ptl_renderer_create(r->owner, r->device, r->asset_root.c_str(), flags, &sib, log.data(), log.size());
+    if (rc != PTL_OK) return rc;
+    sib->cam = r->cam;
+    sib->offset_after_material = r->offset_after_material;
+    sib->gray_t_start = r->gray_t_start;
+    sib->gray_t_size = r->gray_t_size;
+    sib->render_depth = r->render_depth;
+    sib->aa_count = r->aa_count;
+    sib->aa_start = r->aa_start;
+    sib->draw_side_by_side = r->draw_side_by_side;
+    sib->draw_depth_map = r->draw_depth_map;
+    sib->angle_color_disable = r->angle_color_disable;
+    sib->grid_disable = r->grid_disable;
+    sib->black_border_disable = r->black_border_disable;
+    sib->darken_by_distance = r->darken_by_distance;
+    sib->depth_map_min = r->depth_map_min;
+    sib->depth_map_max = r->depth_map_max;
+    sib->anaglyph_p = r->anaglyph_p;
+    sib->anaglyph_q = r->anaglyph_q;
+    sib->draw_anaglyph = r->draw_anaglyph;
+    sib->anaglyph_mode = r->anaglyph_mode;
+    sib->eye_distance = r->eye_distance;
+    sib->swap_eyes = r->swap_eyes;
+    sib->check_affine_on_new_source = false;
+    ++sib->options_version;
+    ptl_frame f{};
+    f.width = width;
+    f.height = height;
+    f.rb_phase = 0;
+    f.rb_stride = 1;
+    std::vector<uint8_t> pixels((size_t)width * height * 4);
+    uint64_t count = 0;
+    rc = ptl_renderer_draw_to_host(sib, &f, pixels.data(), nullptr, &count, nullptr);
+    ptl_renderer_destroy(sib);
+    if (rc != PTL_OK) return rc;
+    if (violations) *violations = count;
+    r->affine_violations_seen = count;
+    r->checked_source = r->kernel_source;
+    if (count > 0 && r->affine_rays && !r->no_affine) {
+        r->no_affine = true;
+        drop_async_kernels(r);
+        rc = build_kernel(r, nullptr, 0);
+        if (rc != PTL_OK) return rc;
+        seed_async_kernels(r);
+        ++r->rejit_count;
+        r->checked_source = r->kernel_source;
+        set_last_error("check_affine: " + std::to_string(count) + " ray halves met a product with a w that is not 1 / 0: affine rays switched off for this stage");
+    }
+    return PTL_OK;
+}
+extern "C" int ptl_renderer_check_affine(ptl_renderer* r, int width, int height, unsigned long long* violations) {
+    if (!r || width < 1 || height < 1) return PTL_ERR_INVALID;
+    return guarded([&] {
+        ptl_frame f{};
+        f.width = width;
+        f.height = height;
+        f.rb_stride = 1;
+        int rc = prepare_draw(r, &f);  // (the state a draw would see: pending rebuilds done, so that `kernel_source` is what would be launched)
+        if (rc < 0) return rc;
+        return check_affine_now(r, width, height, violations);
+    });
+}
+// (before a draw: option "check_affine" / PTL_CHECK_AFFINE=1 -- once per new source that has affine rays)
+static int check_affine_if_asked(ptl_renderer* r, const ptl_frame* frame) {
+    if (!r->check_affine_on_new_source || !r->affine_rays || r->no_affine || r->device < 0 || r->checked_source == r->kernel_source) return PTL_OK;
+    int rc = check_affine_now(r, 64, 36, nullptr);
+    if (rc != PTL_OK) return rc;
+    return prepare_draw(r, frame);  // (the rebuilt kernel, if any, wants its uniforms)
+}
+
 extern "C" int ptl_renderer_draw(ptl_renderer* r, const ptl_frame* frame, void* out_rgba8, void* out_rgba32f, void* segments, void* stream,
                                  float* elapsed_ms) {
     if (!r || !frame) return PTL_ERR_INVALID;
     return guarded([&] {
         int rc = prepare_draw(r, frame);
         if (rc < 0) return rc;
+        if (rc = check_affine_if_asked(r, frame); rc < 0) return rc;
         if (r->concurrent > 1 && r->device >= 0 && !elapsed_ms && !segments) return draw_on_a_lane(r, frame, out_rgba8, out_rgba32f, stream);
         // (a timed or counting draw, and every draw of a renderer without lanes: on the caller's stream, behind what the lanes still hold)
         if (int jrc = join_lanes(r, stream); jrc != PTL_OK) return jrc;
@@ -1351,6 +1442,7 @@ extern "C" int ptl_renderer_draw_to_host(ptl_renderer* r, const ptl_frame* frame
     return guarded([&] {
         int rc = prepare_draw(r, frame);
         if (rc < 0) return rc;
+        if (rc = check_affine_if_asked(r, frame); rc < 0) return rc;
         wait_for_lanes(r);
         return ptl_kernel_render_to_host(r->kernel, frame, host_rgba8, host_rgba32f, host_segments, elapsed_ms);
     });

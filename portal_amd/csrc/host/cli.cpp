@@ -909,6 +909,26 @@ int check(const Options& o) {
         ptl_scene_uniform_layout(scene, &descs, &n, &block);
         std::printf("%s: ok (%d uniforms, %zu-byte block)\n", o.scene.c_str(), n, block);
         ptl_renderer_destroy(r);
+        r = nullptr;
+        // with a GPU: the build `render-frame` draws with (everything baked), and -- where it has affine rays -- the checking build of the same state
+        // at 64 x 36: does any ray reach a product with a w the kernel assumes otherwise? (ptl_renderer_check_affine)
+        if (ptl_device_count() > 0 && ptl_renderer_create(scene, o.device, o.asset_root.c_str(), 5u | 262144u, &r, log.data(), log.size()) == PTL_OK) {
+            if (ptl_renderer_affine_rays(r) == 1) {
+                unsigned long long bad = 0;
+                if (ptl_renderer_check_affine(r, 64, 36, &bad) == PTL_OK)
+                    std::printf("  affine rays: %s\n", bad == 0 ? "hold on every ray of a 64x36 frame (checking build)" : "BROKEN by this scene's snippets -- switched off (please report: the snippet scan let it through)");
+                else
+                    std::printf("  affine rays: not checked (%s)\n", ptl_last_error());
+                if (bad != 0) {
+                    ptl_renderer_destroy(r);
+                    ptl_scene_free(scene);
+                    return 3;
+                }
+            } else {
+                std::printf("  affine rays: off for this scene (general products)\n");
+            }
+            ptl_renderer_destroy(r);
+        }
         ptl_scene_free(scene);
         return 0;
     }

@@ -3,6 +3,7 @@
 #include "glsl_hoist.h"
 #include "glsl_tokens.h"
 
+#include <cstdlib>
 #include <cstring>
 
 #include <algorithm>
@@ -699,6 +700,20 @@ bool is_vec4_with_w(const std::vector<Token>& t, size_t from, size_t to, double 
 }
 }  // namespace
 
+// Round 6: a WHITELIST over every occurrence of a ray half, not a list of known offenders (VERDICT r5 / ADVICE r5: `r.o[3] = 2.;`, `r.o += r.d * t +
+// vec4(0., 0., 0., 5.);`, `mat4 m = mat4(2.); r.o += r.d * m;`, a macro and a builtin's out parameter all passed the round-5 scan).  The invariant to keep:
+// every Ray value has o.w == 1 and d.w == 0.  A Ray value comes from (1) the camera and the library (checked once, by hand and by the A/B tests), (2) the
+// constructor `Ray(...)`, (3) a write to `.o` / `.d` of an existing one, (4) `transform` / `material_teleport` by some matrix.  So:
+//   * nothing a token scan cannot see through: no preprocessor directive, no `out` / `inout` parameter of any type, no builtin with an out parameter
+//     (modf, frexp), no use of the library's one non-affine ray constant (`ray_none`);
+//   * (2) both halves spelled as `vec4(.., 1.)` / `vec4(.., 0.)`;
+//   * (3) EVERY `.o` / `.d` followed (after its member / index chain) by an assignment operator or `++` / `--`, or preceded by a prefix `++` / `--`, is a
+//     write: allowed to x / y / z alone (a swizzle out of xyz / rgb / stp, a literal index 0..2), or to the whole half in five spelled forms
+//     (`= vec4(.., w)`, `d = normalize(same.d)`, `o += same.d * S`, `o = same.o + same.d * S` with S a product of factors none of which names a matrix);
+//     anything else -- `.w`, `[i]`, `[3]`, a deeper chain, another right-hand side -- switches the optimisation off;
+//   * (4) the matrix is a scene uniform by name (those the generator and the renderer check for the bottom row 0 0 0 1).
+// What the scan cannot prove it refuses; what it accepts is hunted by tests/test_affine_guard_fuzz.py (random legal ray writes, frames with and without
+// affine rays) and, on the device, checked by the PTL_CHECK_AFFINE build (ptl_renderer_check_affine).
 bool snippets_keep_rays_affine(const std::vector<std::string>& codes, std::string* why) {
     auto refuse = [&](const std::vector<Token>& t, size_t at, const char* what) {
         if (why) {
@@ -707,12 +722,44 @@ bool snippets_keep_rays_affine(const std::vector<std::string>& codes, std::strin
         }
         return false;
     };
+    auto ends_with = [](const std::string& x, const char* tail) { const size_t n = std::strlen(tail); return x.size() > n && x.compare(x.size() - n, n, tail) == 0; };
+    auto matrix_type = [](const std::string& x) { return x.size() >= 4 && x.compare(0, 3, "mat") == 0 && std::isdigit((unsigned char)x[3]); };
+    auto uniform_matrix_name = [&](const std::string& x) { return ends_with(x, "_mat") || ends_with(x, "_mat_inv") || ends_with(x, "_mat_teleport"); };
+    // every name some snippet declares with a matrix type: locals, parameters, functions that return a matrix (too many names only refuse more)
+    std::set<std::string> matrix_names;
     for (const std::string& code : codes) {
         const std::vector<Token> t = significant_tokens(code);
+        for (size_t i = 0; i + 1 < t.size(); ++i) {
+            if (t[i].kind != Token::Ident || !matrix_type(t[i].text) || t[i + 1].kind != Token::Ident) continue;
+            matrix_names.insert(t[i + 1].text);
+            int depth = 0;  // `mat4 a = .., b = ..;`
+            for (size_t k = i + 2; k < t.size() && depth >= 0 && t[k].text != ";" && t[k].text != "{"; ++k) {
+                if (t[k].text == "(" || t[k].text == "[") ++depth;
+                else if (t[k].text == ")" || t[k].text == "]") --depth;
+                else if (depth == 0 && t[k].text == "," && k + 2 < t.size() && t[k + 1].kind == Token::Ident && t[k + 2].kind != Token::Ident) matrix_names.insert(t[k + 1].text);
+            }
+        }
+    }
+    auto names_a_matrix = [&](const std::string& x) {
+        return matrix_type(x) || x == "inverse" || x == "transpose" || x == "outerProduct" || x == "matrixCompMult" || uniform_matrix_name(x) || matrix_names.count(x) != 0;
+    };
+    auto assignment = [](const std::string& op) {
+        return op == "=" || op == "+=" || op == "-=" || op == "*=" || op == "/=" || op == "%=" || op == "<<=" || op == ">>=" || op == "&=" || op == "|=" || op == "^=" || op == "++" || op == "--";
+    };
+    for (const std::string& code : codes) {
+        for (const Token& raw : tokenize_glsl(code))
+            if (raw.kind == Token::Preproc || raw.kind == Token::Raw) {
+                if (why) *why = "a preprocessor directive (a macro hides what it expands to from the scan): " + raw.text.substr(0, 60);
+                return false;
+            }
+        const std::vector<Token> t = significant_tokens(code);
         for (size_t i = 0; i < t.size(); ++i) {
-            // out / inout parameters through which a caller's ray halves could be rewritten
-            if (t[i].kind == Token::Ident && (t[i].text == "out" || t[i].text == "inout") && i + 1 < t.size() && (t[i + 1].text == "Ray" || t[i + 1].text == "vec4"))
-                return refuse(t, i, "an out parameter that can carry a ray half");
+            if (t[i].kind == Token::Punct && t[i].text == "#") return refuse(t, i, "a preprocessor directive (a macro hides what it expands to from the scan)");
+            if (t[i].kind != Token::Ident && t[i].text != ".") continue;
+            // out / inout parameters (of any type: `f(r.o.w)` into an `out float`), and the builtins that have one
+            if (t[i].kind == Token::Ident && (t[i].text == "out" || t[i].text == "inout")) return refuse(t, i, "an out parameter (it could carry a ray half)");
+            if (t[i].kind == Token::Ident && (t[i].text == "modf" || t[i].text == "frexp") && !(i > 0 && t[i - 1].text == ".")) return refuse(t, i, "a builtin with an out parameter");
+            if (t[i].kind == Token::Ident && t[i].text == "ray_none" && !(i > 0 && t[i - 1].text == ".")) return refuse(t, i, "the library's ray constant whose origin has w = 0");
             // Ray( origin, direction, ... ): both halves spelled with their w
             if (t[i].kind == Token::Ident && t[i].text == "Ray" && i + 1 < t.size() && t[i + 1].text == "(") {
                 const size_t close = closing_paren(t, i + 1);
@@ -728,9 +775,8 @@ bool snippets_keep_rays_affine(const std::vector<std::string>& codes, std::strin
                 const size_t close = closing_paren(t, i + 1);
                 if (close == t.size()) return refuse(t, i, "an unbalanced transform call");
                 auto parts = top_level_parts(t, i + 2, close);
-                auto ends_with = [](const std::string& x, const char* tail) { const size_t n = std::strlen(tail); return x.size() > n && x.compare(x.size() - n, n, tail) == 0; };
                 const bool uniform_matrix = parts.size() == 2 && parts[0].second == parts[0].first + 1 && t[parts[0].first].kind == Token::Ident &&
-                                            (ends_with(t[parts[0].first].text, "_mat") || ends_with(t[parts[0].first].text, "_mat_inv") || ends_with(t[parts[0].first].text, "_mat_teleport"));
+                                            uniform_matrix_name(t[parts[0].first].text) && matrix_names.count(t[parts[0].first].text) == 0;
                 if (!uniform_matrix) return refuse(t, i, "transform() by a matrix that is not a scene uniform");
                 continue;
             }
@@ -739,87 +785,124 @@ bool snippets_keep_rays_affine(const std::vector<std::string>& codes, std::strin
                 const size_t close = closing_paren(t, i + 1);
                 if (close == t.size()) return refuse(t, i, "an unbalanced material_teleport call");
                 auto parts = top_level_parts(t, i + 2, close);
-                auto ends_with = [](const std::string& x, const char* tail) { const size_t n = std::strlen(tail); return x.size() > n && x.compare(x.size() - n, n, tail) == 0; };
                 const bool uniform_matrix = parts.size() == 3 && parts[2].second == parts[2].first + 1 && t[parts[2].first].kind == Token::Ident &&
-                                            (ends_with(t[parts[2].first].text, "_mat") || ends_with(t[parts[2].first].text, "_mat_inv") || ends_with(t[parts[2].first].text, "_mat_teleport"));
+                                            uniform_matrix_name(t[parts[2].first].text) && matrix_names.count(t[parts[2].first].text) == 0;
                 if (!uniform_matrix) return refuse(t, i, "material_teleport() by a matrix that is not a scene uniform");
                 continue;
             }
-            // <something>.o / .d [.swizzle] <assignment operator>
-            if (t[i].text == "." && i + 2 < t.size() && t[i + 1].kind == Token::Ident && (t[i + 1].text == "o" || t[i + 1].text == "d")) {
-                const bool origin = t[i + 1].text == "o";
-                size_t j = i + 2;
-                bool swizzle = false, touches_w = false;
+            // every occurrence of <owner>.o / <owner>.d
+            if (!(t[i].text == "." && i + 1 < t.size() && t[i + 1].kind == Token::Ident && (t[i + 1].text == "o" || t[i + 1].text == "d"))) continue;
+            const bool origin = t[i + 1].text == "o";
+            // what follows the half: a chain of `.member` and `[index]`
+            size_t j = i + 2;
+            int links = 0;
+            bool xyz_only = false;
+            while (j < t.size()) {
                 if (t[j].text == "." && j + 1 < t.size() && t[j + 1].kind == Token::Ident) {
-                    swizzle = true;
-                    for (char c : t[j + 1].text) touches_w = touches_w || c == 'w' || c == 'a' || c == 'q';
+                    bool inside = !t[j + 1].text.empty() && t[j + 1].text.size() <= 4;
+                    for (char c : t[j + 1].text) inside = inside && std::strchr("xyzrgbstp", c) != nullptr;  // (no w / a / q; anything that is no swizzle at all counts as unknown)
+                    xyz_only = inside;
+                    ++links;
                     j += 2;
-                }
-                if (j >= t.size()) break;
-                const std::string& op = t[j].text;
-                const bool assigns = op == "=" || op == "+=" || op == "-=" || op == "*=" || op == "/=" || op == "++" || op == "--";
-                if (!assigns) continue;
-                if (swizzle) {
-                    if (touches_w) return refuse(t, i, "a write to the w of a ray half");
-                    continue;  // x / y / z only
-                }
-                size_t end = j + 1;  // the statement's right-hand side: up to the `;` at this nesting level
-                int depth = 0;
-                while (end < t.size() && !(depth == 0 && t[end].text == ";")) {
-                    if (t[end].text == "(" || t[end].text == "[") ++depth;
-                    else if (t[end].text == ")" || t[end].text == "]") --depth;
-                    ++end;
-                }
-                // the owner of the member, as written: the tokens of `a.b[c]` in front of `.o`
-                size_t own = i;
-                while (own > 0 && (t[own - 1].kind == Token::Ident || t[own - 1].text == ".")) --own;
-                std::string owner;
-                for (size_t k = own; k < i; ++k) owner += t[k].text;
-                auto spells = [&](size_t from, const std::vector<std::string>& words) {
-                    for (size_t k = 0; k < words.size(); ++k)
-                        if (from + k >= end || t[from + k].text != words[k]) return false;
-                    return true;
-                };
-                std::vector<std::string> own_tokens;
-                for (size_t k = own; k < i; ++k) own_tokens.push_back(t[k].text);
-                auto member = [&](const char* half) {
-                    std::vector<std::string> w = own_tokens;
-                    w.push_back(".");
-                    w.push_back(half);
-                    return w;
-                };
-                // (`X.d * <matrix>` is GLSL too -- a row vector times a matrix, with whatever w comes out: an offset "along the direction" may not name one)
-                auto names_a_matrix = [&](size_t from) {
-                    for (size_t k = from; k < end; ++k)
-                        if (t[k].kind == Token::Ident) {
-                            const std::string& x = t[k].text;
-                            auto tail = [&](const char* e) { const size_t n = std::strlen(e); return x.size() >= n && x.compare(x.size() - n, n, e) == 0; };
-                            if (x == "mat4" || x == "mat3" || x == "inverse" || x == "transpose" || tail("_mat") || tail("_mat_inv") || tail("_mat_teleport")) return true;
+                } else if (t[j].text == "[") {
+                    const size_t close = closing_paren(t, j);
+                    if (close == t.size()) return refuse(t, i, "an unbalanced index");
+                    xyz_only = close == j + 2 && t[j + 1].kind == Token::Number && (t[j + 1].text == "0" || t[j + 1].text == "1" || t[j + 1].text == "2");
+                    ++links;
+                    j = close + 1;
+                } else break;
+            }
+            // the owner of the member, as written: `a.b[c]` in front of `.o`
+            size_t own = i;
+            while (own > 0) {
+                if (t[own - 1].kind == Token::Ident || t[own - 1].text == ".") --own;
+                else if (t[own - 1].text == "]") {
+                    int depth = 0;
+                    size_t k = own;
+                    while (k > 0) {
+                        --k;
+                        if (t[k].text == "]" || t[k].text == ")") ++depth;
+                        else if (t[k].text == "[" || t[k].text == "(") {
+                            if (--depth == 0) break;
                         }
-                    return false;
-                };
-                if (origin && op == "+=") {  // X.o += X.d * <scalar expression>: w moves by 0 * s
-                    std::vector<std::string> lead = member("d");
-                    lead.push_back("*");
-                    if (spells(j + 1, lead) && !names_a_matrix(j + 1 + lead.size())) continue;
+                    }
+                    if (depth != 0) return refuse(t, i, "an unbalanced index");
+                    own = k;
+                } else break;
+            }
+            const bool prefix_write = own > 0 && (t[own - 1].text == "++" || t[own - 1].text == "--");
+            // (the lexer knows `+= -= *= /= ++ --`; the integer forms reach here as two tokens: `% =`, `<< =`, `& =` ... -- not legal on a float vector, refused all the same)
+            const bool two_token_assignment = j + 1 < t.size() && t[j + 1].text == "=" && (t[j].text == "%" || t[j].text == "<<" || t[j].text == ">>" || t[j].text == "&" || t[j].text == "|" || t[j].text == "^");
+            if (two_token_assignment) return refuse(t, own, "a ray half assigned in a form that is not known to keep its w");
+            const bool postfix_write = j < t.size() && assignment(t[j].text);
+            if (!prefix_write && !postfix_write) continue;  // a read (there are no out parameters it could be bound to)
+            if (links > 0) {
+                if (links == 1 && xyz_only) continue;  // x / y / z alone
+                return refuse(t, own, "a write that may reach the w of a ray half");
+            }
+            if (prefix_write || j >= t.size()) return refuse(t, own, "a ray half assigned in a form that is not known to keep its w");
+            const std::string& op = t[j].text;
+            size_t end = j + 1;  // the statement's right-hand side: up to the `;` at this nesting level
+            int depth = 0;
+            while (end < t.size() && !(depth == 0 && t[end].text == ";")) {
+                if (t[end].text == "(" || t[end].text == "[") ++depth;
+                else if (t[end].text == ")" || t[end].text == "]") {
+                    if (--depth < 0) break;  // (`for (..; ..; r.o += r.d * s)`, an argument: the expression ends with the group it stands in)
                 }
-                if (op == "=") {
-                    if (is_vec4_with_w(t, j + 1, end, origin ? 1.0 : 0.0)) continue;  // X.o = vec4(.., 1.) / X.d = vec4(.., 0.)
-                    if (!origin) {  // X.d = normalize(X.d)
-                        std::vector<std::string> call = {"normalize", "("};
-                        for (auto& w : member("d")) call.push_back(w);
-                        call.push_back(")");
-                        if (spells(j + 1, call) && j + 1 + call.size() == end) continue;
-                    } else {  // X.o = X.o + X.d * <scalar expression>
-                        std::vector<std::string> lead = member("o");
-                        lead.push_back("+");
-                        for (auto& w : member("d")) lead.push_back(w);
-                        lead.push_back("*");
-                        if (spells(j + 1, lead) && !names_a_matrix(j + 1 + lead.size())) continue;
+                ++end;
+            }
+            std::vector<std::string> own_tokens;
+            for (size_t k = own; k < i; ++k) own_tokens.push_back(t[k].text);
+            auto spells = [&](size_t from, const std::vector<std::string>& words) {
+                for (size_t k = 0; k < words.size(); ++k)
+                    if (from + k >= end || t[from + k].text != words[k]) return false;
+                return true;
+            };
+            auto member = [&](const char* half) {
+                std::vector<std::string> w = own_tokens;
+                w.push_back(".");
+                w.push_back(half);
+                return w;
+            };
+            // t[from, end) is a product of factors -- names, numbers, member chains, calls, parenthesised groups, joined by `*` and `/`, one leading `-` --
+            // with nothing else at the top level (no `+`, no `,`, no `?`), and no factor names a matrix (`X.d * <matrix>` is GLSL too: a row vector times
+            // a matrix, with whatever w comes out).  Then `X.d * S` has the w `0 * S.w`-or-`0 * S`: 0.
+            auto scalar_factors = [&](size_t from) {
+                if (from >= end) return false;
+                int depth = 0;
+                for (size_t k = from; k < end; ++k) {
+                    const std::string& x = t[k].text;
+                    if (t[k].kind == Token::Ident && names_a_matrix(x)) return false;
+                    if (x == "(" || x == "[") ++depth;
+                    else if (x == ")" || x == "]") --depth;
+                    else if (depth == 0) {
+                        const bool fine = t[k].kind == Token::Ident || t[k].kind == Token::Number || x == "*" || x == "/" || x == "." || (x == "-" && k == from);
+                        if (!fine) return false;
                     }
                 }
-                return refuse(t, own, "a ray half assigned in a form that is not known to keep its w");
+                return depth == 0;
+            };
+            if (origin && op == "+=") {  // X.o += X.d * S
+                std::vector<std::string> lead = member("d");
+                lead.push_back("*");
+                if (spells(j + 1, lead) && scalar_factors(j + 1 + lead.size())) continue;
             }
+            if (op == "=") {
+                if (is_vec4_with_w(t, j + 1, end, origin ? 1.0 : 0.0)) continue;  // X.o = vec4(.., 1.) / X.d = vec4(.., 0.)
+                if (!origin) {  // X.d = normalize(X.d)
+                    std::vector<std::string> call = {"normalize", "("};
+                    for (auto& w : member("d")) call.push_back(w);
+                    call.push_back(")");
+                    if (spells(j + 1, call) && j + 1 + call.size() == end) continue;
+                } else {  // X.o = X.o + X.d * S
+                    std::vector<std::string> lead = member("o");
+                    lead.push_back("+");
+                    for (auto& w : member("d")) lead.push_back(w);
+                    lead.push_back("*");
+                    if (spells(j + 1, lead) && scalar_factors(j + 1 + lead.size())) continue;
+                }
+            }
+            return refuse(t, own, "a ray half assigned in a form that is not known to keep its w");
         }
     }
     return true;
@@ -986,7 +1069,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         // every element (a switched-off object: its products are NaN whatever the w) -- and no scene snippet writes a ray's w.  Only in builds
         // that may shorten products at all (the same deviation for non-finite rays, the same guard), i.e. never in the un-specialised build.
         // (the tolerance mode gets them too: it is not bit-exact anyway, and without them it was SLOWER than the exact kernel -- 0.217 against 0.191 ms)
-        if (opts.affine_rays && !opts.exact_cr && !gk.full_chains && (opts.mask_zero_elements || opts.specialize_all || opts.specialize_static)) {
+        if (opts.affine_rays && !opts.check_affine && !opts.exact_cr && !gk.full_chains && (opts.mask_zero_elements || opts.specialize_all || opts.specialize_static)) {
             bool affine = true;
             // (a matrix that stays a run-time value: what holds now is checked again by the renderer before every upload that could change it
             // -- capi.cpp `zero_patterns_broken` for the builds that keep their kernel across scene states; the others come back here)
@@ -1004,7 +1087,9 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 for (const Object& o : scene.objects)
                     if (o.kind == Object::Flat || o.kind == Object::Complex) codes.push_back(filter_tagged_lines(o.code, flags));
                 for (const NamedCode& im : scene.intersection_materials) codes.push_back(filter_tagged_lines(im.code, flags));
-                affine = snippets_keep_rays_affine(codes, nullptr);
+                // (PTL_AFFINE_RAYS_SKIP_SCAN=1: a TEST hook -- tests/test_affine_guard_fuzz.py shows what a snippet the scan refuses would draw with the assumption)
+                const char* skip = std::getenv("PTL_AFFINE_RAYS_SKIP_SCAN");
+                affine = (skip && skip[0] == '1') || snippets_keep_rays_affine(codes, &gk.affine_rays_refused_because);
             }
             gk.affine_rays = affine;
         }
@@ -1115,6 +1200,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         // (in the TEXT as well as among the defines: a renderer tells "nothing compiled in changed" by comparing sources, and a kernel with and
         // one without affine rays differ in nothing else)
         if (gk.affine_rays) s.add_string("#define PTL_AFFINE_RAYS 1\n");
+        if (opts.check_affine) s.add_string("#define PTL_CHECK_AFFINE 1\n");  // (implies PTL_COUNT_SEGMENTS: the counter counts rays whose w is not 1 / 0)
         if (opts.derived_uniforms) s.add_string("#define PTL_DERIVED_BUILTINS 1\n");
         {
             if (first_trip_planes_wanted())
@@ -1463,7 +1549,8 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     gk.line_numbers = std::move(body.line_numbers);
     apply_zero_masks(gk.source, gk.masked);
     if (opts.slices_entry) apply_slices_entry(gk.source);
-    if (opts.count_segments) gk.defines.push_back("PTL_COUNT_SEGMENTS");
+    if (opts.count_segments || opts.check_affine) gk.defines.push_back("PTL_COUNT_SEGMENTS");
+    if (opts.check_affine) gk.defines.push_back("PTL_CHECK_AFFINE");
     if (opts.anaglyph) gk.defines.push_back("PTL_ANAGLYPH");
     if (opts.fast_math) gk.defines.push_back("PTL_FAST_MATH");
     if (opts.exact_cr) gk.defines.push_back("PTL_CONTRACT_V1");

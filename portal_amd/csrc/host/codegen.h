@@ -159,6 +159,10 @@ struct KernelOptions {
     // finite rays -- the guard and the stated deviation of the shortened products (full_chains).  The renderer switches it off, and rebuilds,
     // when a CAMERA matrix (a run-time value in every build) is not affine (GeneratedKernel::affine_rays says whether the kernel has it).
     bool affine_rays = true;
+    // Round 6, the dynamic belt behind the scan of the snippets: the same build WITHOUT affine rays (the general products) whose assumption sites --
+    // the matrix-times-ray products, the bounce loop -- count the ray halves that arrive with another w than 1 / 0 into the `segments` counter
+    // (device/ptl_glsl.h PTL_CHECK_AFFINE).  Its frame is right either way; a non-zero count says an affine-rays kernel's would not be.
+    bool check_affine = false;
     // A/B switch (PTL_FLAG_KEEP_TRANSFORM_DODGES): a kernel with affine rays still gets the deferred loop updates and the first-trip snippet copies
     // -- round 4's shape, for measurements; by default it gets neither (codegen.cpp: a transform is then a few additions, cheaper than its dodge)
     bool keep_transform_dodges = false;
@@ -189,6 +193,7 @@ struct GeneratedKernel {
     std::vector<std::pair<std::string, MatrixPattern>> masked;  // run-time matrices whose pattern is compiled in (MatrixPattern)
     int bounded_snippet_blocks = 0;     // `nearer` blocks of intersection-material snippets that take the caller's distance bound (define PTL_BOUNDED_SNIPPETS)
     bool full_chains = false;           // a matrix of the scene is not finite (or KernelOptions::full_chains): no product was shortened
+    std::string affine_rays_refused_because;  // what `snippets_keep_rays_affine` said when it switched the assumption off ("" otherwise)
     bool affine_rays = false;           // generated with PTL_AFFINE_RAYS: valid while the camera matrices have the bottom row 0 0 0 1
 };
 

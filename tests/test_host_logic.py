@@ -1829,12 +1829,32 @@ def test_affine_rays_scan_of_the_scene_snippets(pa):
              "r_mob.d = normalize(r_mob.d);", "r.o.xyz -= offset_box; r.o.x += a - b;", "if (r.o == r.d) { float w = r.o.w + r.d.w; }",
              "Ray q = transform(a_mat, transform(b0_mat_inv, r_b)); q = transform(a_to_b_mat_teleport, q);", "vec4 p = b0_mat * (a_mat_inv * pos);", "// r.d = -r.d;\nfloat x = 1.;", "return transform(a_mat_inv, r);", "Ray transform(mat4 m, Ray r) { return r; }", "return material_teleport(hit, r, a_to_b_mat_teleport);"]
     refused = {"Ray q = Ray(ray_o, ray_d, 1.0, false);": "Ray built from halves", "r.o -= center;": "not known to keep its w", "r.d = -r.d;": "not known to keep its w",
-               "r.o.w = 2.;": "write to the w", "r.d.xw += vec2(1.);": "write to the w", "void f(inout Ray r) { }": "out parameter", "void g(out vec4 p) { p = vec4(0.); }": "out parameter",
+               "r.o.w = 2.;": "may reach the w", "r.d.xw += vec2(1.);": "may reach the w", "void f(inout Ray r) { }": "out parameter", "void g(out vec4 p) { p = vec4(0.); }": "out parameter",
                "r.d = get_mat(int(hit.v)) * r.d;": "not known to keep its w", "r.o = vec4(p, 0.);": "not known to keep its w", "r.d = normalize(q.d);": "not known to keep its w",
                "x.d /= 2.;": "not known to keep its w", "r3 = transform(mat_transform_inv, r);": "not a scene uniform", "Ray q = transform(inverse(a_mat), r);": "not a scene uniform",
                "return material_teleport(hit, r, inverse(a_mat));": "not a scene uniform", "r.o += r.d * a_mat;": "not known to keep its w",
                "r.o = r.o + r.d * mat4(2.);": "not known to keep its w", "return transform(m, r);": "not a scene uniform", "return offset_ray(transform(get_mat(k), r), 0.1);": "not a scene uniform",
                "Ray q = Ray(vec4(o, 1.), vec4(d, 1.), 1., false);": "Ray built from halves", "Ray q = Ray(vec4(o.x, o.y, 1.), vec4(d, 0.), 1., false);": "Ray built from halves"}
+    # round 6: the scan is a whitelist over EVERY write to a ray half -- each of these passed round 5's
+    keeps += ["r.o[0] = 2.; r.d[2] -= 1.; q.r.o[1] *= 3.;", "r.o.xy = r.o.yx; r.d.stp = vec3(0.); r.o.rgb += c;", "float w = r.o[3] + r.d.w + rs[k].o.w;",
+              "r.o += r.d * -t;", "r.o += r.d * (a + b) * f(x, y) / q.z;", "rs[k].o.x = 1.; rs[k].o += rs[k].d * t;", "for (int k = 0; k < 3; k++) { r.o.x++; ++r.d.y; }",
+              "for (int k = 0; k < 3; r.o += r.d * s) { k++; }", "mat3 m = mat3(1.); vec3 p = m * r.o.xyz; r.o.xyz = p;", "float d = hit.d; s.d = 2.;" if False else "float e = r.d.x;"]
+    refused.update({
+        "r.o[3] = 2.0;": "may reach the w", "r.d[3] += 1.0;": "may reach the w", "q.r.o[3] = 0.5;": "may reach the w", "r.o[k] = 1.;": "may reach the w", "r.o[1 + 2] = 1.;": "may reach the w",
+        "r.o.xyz.x = 1.; r.o.wzyx.x = 2.;": "may reach the w", "r.d.a = 1.;": "may reach the w", "r.d.q++;": "may reach the w", "--r.o.w;": "may reach the w", "++r.o;": "not known to keep its w",
+        "r.o.W = 2.;": "may reach the w", "r.o.xyzw.xyz = p;": "may reach the w",
+        "r.o += r.d * t + vec4(0., 0., 0., 5.);": "not known to keep its w", "r.o = r.o + r.d * t + vec4(0., 0., 0., 5.);": "not known to keep its w",
+        "r.o += r.d * t - v;": "not known to keep its w", "r.o += r.d * t, q.o = v;": "not known to keep its w", "r.o += r.d * c ? a : b;": "not known to keep its w",
+        "mat4 m = mat4(2.); r.o += r.d * m;": "not known to keep its w", "mat4 a = mat4(1.), m2 = a; r.o += r.d * t * m2;": "not known to keep its w",
+        "mat4 spin(float a) { return mat4(1.); }\nvoid f(Ray r) { r.o += r.d * spin(1.); }": "not known to keep its w", "void f(mat4 k, Ray r) { r.o = r.o + r.d * k; }": "not known to keep its w",
+        "r.o += r.d * outerProduct(a, b);": "not known to keep its w", "r.o *= 2.;": "not known to keep its w", "r.o %= 2.;": "not known to keep its w",
+        "#define SET_W(r) r.o.w = 2.\nvoid f(Ray r) { SET_W(r); }": "preprocessor", "#define HALF o\nvoid f(Ray r) { r.HALF.w = 2.; }": "preprocessor", "#define M \\\n mat4(2.)\nfloat x;": "preprocessor",
+        "#if 1\nfloat x;\n#endif": "preprocessor",
+        "float i; float f = modf(x, r.o.w);": "builtin with an out parameter", "int e; float m = frexp(x, e);": "builtin with an out parameter",
+        "void g(out float w) { w = 2.; }\nvoid f(Ray r) { g(r.o.w); }": "out parameter", "void g(inout vec3 v) { }": "out parameter",
+        "Ray q = ray_none; q = transform(a_mat, q);": "ray constant", "return MaterialProcessing(false, c, ray_none);": "ray constant",
+        "void f(mat4 a_mat, Ray r) { r = transform(a_mat, r); }": "not a scene uniform", "mat4 b_mat_inv = mat4(2.); return material_teleport(hit, r, b_mat_inv);": "not a scene uniform",
+    })
     for code in keeps:
         assert pa.snippets_keep_rays_affine(code) == (True, ""), code
     for code, why in refused.items():
