@@ -86,7 +86,9 @@ int ptl_kernel_code_object(ptl_kernel* k, const void** data, size_t* size);
 
 /* Kernel metadata of a gfx950 code object (ptl_kernel_code_object, or a file of the code-object cache) without a device: the largest value of
  * `key` (".vgpr_count", ".vgpr_spill_count", ".private_segment_fixed_size", ".sgpr_count") over the kernels whose name starts with
- * `kernel_prefix` (NULL or "": every kernel of the module); -1 when the key does not occur.  The JIT's occupancy retry decides on the render
+ * `kernel_prefix` (NULL or "": every kernel of the module); -1 when the key does not occur -- and, with a prefix, for a key that sorts before
+ * ".name" (".kernarg_segment_size", ".group_segment_fixed_size" ...: the per-kernel attribution reads the metadata map in its alphabetical key
+ * order and is only right behind ".name").  The JIT's occupancy retry decides on the render
  * entries alone ("ptl_render"): the one-wave teleport and prologue entries of a one-module build say nothing about the render kernel. */
 int ptl_code_object_note(const void* code, size_t size, const char* key, const char* kernel_prefix);
 /* Per-lane resources of the loaded render kernel (hipFuncGetAttribute): vector registers, scratch
@@ -370,7 +372,10 @@ int ptl_renderer_join(ptl_renderer* r, void* stream);
  * kernel it was staged with: when the kernel is rebuilt between two stage calls (a value-baked build whose value moved, a mode switch, an
  * adopted background build) the earlier slices are still traced by the earlier kernel -- draw_slices then issues one launch per run of
  * slices that share a kernel, same frames as draws one by one -- and the texel buffers a slice names (a video texture that steps between
- * two sub-frames) live until its launch.  draw_slices without slices 0 .. n-1 staged since the last launch is PTL_ERR_INVALID. */
+ * two sub-frames) live until its launch.  draw_slices without slices 0 .. n-1 staged since the last launch is PTL_ERR_INVALID.
+ * draw_slices is asynchronous like a draw EXCEPT when a kernel was rebuilt or a video texture stepped between two stage calls: it then releases
+ * the parked kernels and retired texel buffers behind its launches, which waits for those launches (hipFree / the kernels' completion events);
+ * on an error return `elapsed_ms` covers only the runs launched so far. */
 int ptl_renderer_stage_slice(ptl_renderer* r, const ptl_frame* frame, int index);
 int ptl_renderer_draw_slices(ptl_renderer* r, const ptl_frame* frame, int n, void* out_rgba8, void* out_rgba32f, unsigned long long slice_pixels,
                              void* stream, float* elapsed_ms);

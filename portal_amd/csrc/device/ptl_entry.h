@@ -64,6 +64,12 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
 #ifdef PTL_COUNT_SEGMENTS
     ptl_segments_lds[t] = 0u;
 #endif
+#ifdef PTL_MATERIAL_TABLE
+    {  // stage the Simple materials' constants in LDS once per workgroup (codegen.cpp, materials): two ds_read_b128 per lane fetch a material's nine values
+        for (int k = (int)threadIdx.x; k < PTL_MATERIAL_TABLE_WORDS; k += (int)blockDim.x) glsl::ptl_material_table[k] = glsl::ptl_material_table_init[k];
+        __syncthreads();
+    }
+#endif
 #ifdef PTL_UNIFORMS_IN_LDS
     {  // stage the scene constants (portal matrices, uniforms) in LDS once per workgroup
         const unsigned int* src = reinterpret_cast<const unsigned int*>(&glsl::ptl_u);
@@ -119,6 +125,12 @@ extern "C" __global__ void __launch_bounds__(64) ptl_teleport_kernel(float* __re
 #endif
 #ifdef PTL_COUNT_SEGMENTS
     ptl_segments_lds[threadIdx.x] = 0u;
+#endif
+#ifdef PTL_MATERIAL_TABLE
+    {  // stage the Simple materials' constants in LDS once per workgroup (codegen.cpp, materials): two ds_read_b128 per lane fetch a material's nine values
+        for (int k = (int)threadIdx.x; k < PTL_MATERIAL_TABLE_WORDS; k += (int)blockDim.x) glsl::ptl_material_table[k] = glsl::ptl_material_table_init[k];
+        __syncthreads();
+    }
 #endif
     if (threadIdx.x == 0 && blockIdx.x == 0) glsl::teleport_external_ray_entry(out6);
 }

@@ -147,12 +147,22 @@ PTL_FN MaterialProcessing material_process(Ray r, const SceneIntersection& i) {
     SurfaceIntersection hit = i.hit;
     if (i.in_subspace) r.in_subspace = !r.in_subspace;
     if (i.material == 0) {
+#ifdef PTL_MATERIAL_TABLE
+    // every Simple material of the scene and the three DEBUG_* ones: their nine literals from the LDS table, ONE copy of the body (codegen.cpp, materials)
+    } else if (ptl_material_in_table(i.material)) {
+        struct alignas(16) ptl_words4 { unsigned int x, y, z, w; };
+        const ptl_words4 a = *reinterpret_cast<const ptl_words4*>(&ptl_material_table[8 * i.material]);
+        const ptl_words4 b = *reinterpret_cast<const ptl_words4*>(&ptl_material_table[8 * i.material + 4]);
+        return material_simple2(hit, r, vec3(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, a.y), __builtin_bit_cast(float, a.z)), __builtin_bit_cast(float, a.w),
+                                (b.z & 1u) != 0, __builtin_bit_cast(float, b.x), __builtin_bit_cast(float, b.y), (b.z & 2u) != 0, (b.z & 4u) != 0);
+#else
     } else if (i.material == DEBUG_RED) {
         return material_simple2(hit, r, color(0.9f, 0.2f, 0.2f), 0.5f, false, 1.0f, 0.0f, false, false);
     } else if (i.material == DEBUG_GREEN) {
         return material_simple2(hit, r, color(0.2f, 0.9f, 0.2f), 0.5f, false, 1.0f, 0.0f, false, false);
     } else if (i.material == DEBUG_BLUE) {
         return material_simple2(hit, r, color(0.2f, 0.2f, 0.9f), 0.5f, false, 1.0f, 0.0f, false, false);
+#endif
 
 //%material_processing//%
 

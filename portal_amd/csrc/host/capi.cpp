@@ -130,6 +130,8 @@ struct ptl_renderer {
     bool no_affine = false;    // ... and must not be any more
     // Round 6: option "check_affine" (or PTL_CHECK_AFFINE=1 in the environment): the first draw with every NEW affine-rays source first runs the
     // checking build of the same state at 64 x 36 (ptl_renderer_check_affine); a ray that met a product with another w switches the assumption off.
+    int affine_returns = 0;           // returns to affine rays in this stage (at most one: build_kernel)
+    bool no_affine_just_set = false;  // the rebuild in progress is the one that switches them off
     bool check_affine_on_new_source = false;
     std::string checked_source;
     unsigned long long affine_violations_seen = 0;
@@ -490,6 +492,7 @@ static KernelOptions options_from_flags(unsigned flags) {
     // is half of its hiprtc time for the headline scene (3.4 -> 1.8 s on this container's cores) and buys 0.05 ms of kernel
     o.unroll_baked_loops = (flags & 32768u) == 0 && !o.quick_jit;
     o.keep_transform_dodges = (flags & (1u << 24)) != 0;  // PTL_FLAG_KEEP_TRANSFORM_DODGES: deferred updates + first-trip snippet copies also with affine rays (A/B)
+    o.material_table = (flags & (1u << 26)) == 0;  // PTL_FLAG_NO_MATERIAL_TABLE: one inlined material_simple2 per Simple material, as the reference prints them (A/B)
     o.check_affine = (flags & (1u << 25)) != 0;   // PTL_FLAG_CHECK_AFFINE: general products, and `segments` counts the ray halves whose w is not 1 / 0
     o.affine_rays = (flags & (1u << 23)) == 0;    // PTL_FLAG_NO_AFFINE_RAYS: matrix-times-ray products never assume o.w = 1 / d.w = 0 (A/B measurements, tests)
     o.first_trip = (flags & 8192u) == 0;          // PTL_FLAG_NO_FIRST_TRIP: no first-trip copies of the intersection-material snippets
@@ -782,7 +785,17 @@ static int build_kernel(ptl_renderer* r, char* log, size_t log_cap) {
     if (!(r->kernel_stage == r->scene->current_stage)) r->keep_dynamic.clear();  // another stage / clip: judge afresh what is constant
     if (!(r->kernel_stage == r->scene->current_stage)) r->keep_unmasked.clear();
     if (!(r->kernel_stage == r->scene->current_stage)) r->full_chains = false;
-    if (!(r->kernel_stage == r->scene->current_stage)) r->no_affine = !camera_is_affine(*r);
+    if (!(r->kernel_stage == r->scene->current_stage)) {
+        r->no_affine = !camera_is_affine(*r) || r->affine_violations_seen > 0;
+        r->affine_returns = 0;
+    } else if (r->no_affine && r->affine_violations_seen == 0 && r->affine_returns < 1 && camera_is_affine(*r) && !r->no_affine_just_set) {
+        // one transient non-affine camera or matrix state cost the rest of the stage ~16 % of kernel time.  A rebuild that happens for another
+        // reason may return to affine rays ONCE per stage when the camera is affine again (the generator re-checks the scene's matrices itself); a second
+        // break keeps them off, so a state that flickers cannot rebuild per frame.  A violation the checking build counted stays off for good.
+        r->no_affine = false;
+        ++r->affine_returns;
+    }
+    r->no_affine_just_set = false;
     r->kernel_switches = mode_switches(*r);
     refresh_generated(s, r->flags, &r->keep_dynamic, &r->kernel_switches, &r->keep_unmasked, r->full_chains, r->no_affine);
     r->baked = s->last.baked;
@@ -1060,7 +1073,7 @@ static bool zero_patterns_broken(ptl_renderer* r, const std::vector<UniformUploa
             if (v.type != UniformType::Mat4 || matrix_is_affine(v.f)) continue;
             bool all_nan = true;
             for (int k = 0; k < 16; ++k) all_nan = all_nan && std::isnan(v.f[k]);
-            if (!all_nan) r->no_affine = broken = true;
+            if (!all_nan) r->no_affine = r->no_affine_just_set = broken = true;
         }
     for (auto& [name, mask] : r->masked)
         for (const UniformUpload& v : values) {
@@ -1194,7 +1207,7 @@ static int prepare_draw(ptl_renderer* r, const ptl_frame* frame) {
     }
     if (!async && r->affine_rays && !r->no_affine && !camera_is_affine(*r)) {
         // the camera went through something that is not an affine map: the kernel's w = 1 / w = 0 no longer holds for primary rays
-        r->no_affine = true;
+        r->no_affine = r->no_affine_just_set = true;
         int rc = build_kernel(r, nullptr, 0);
         if (rc != PTL_OK) return rc;
         ++r->rejit_count;
@@ -1392,7 +1405,7 @@ static int check_affine_now(ptl_renderer* r, int width, int height, unsigned lon
     r->affine_violations_seen = count;
     r->checked_source = r->kernel_source;
     if (count > 0 && r->affine_rays && !r->no_affine) {
-        r->no_affine = true;
+        r->no_affine = r->no_affine_just_set = true;
         drop_async_kernels(r);
         rc = build_kernel(r, nullptr, 0);
         if (rc != PTL_OK) return rc;
@@ -1705,7 +1718,7 @@ extern "C" ptl_kernel* ptl_renderer_kernel(ptl_renderer* r) {
     if (!r) return nullptr;
     // the kernel the next draw would use: a specialised build follows the mode switches (also on a handle without a device, which never draws)
     const bool camera_left_the_affine_maps = r->affine_rays && !r->no_affine && !camera_is_affine(*r);
-    if (camera_left_the_affine_maps && !((r->flags & kAsyncRejit) != 0 && r->device >= 0)) r->no_affine = true;
+    if (camera_left_the_affine_maps && !((r->flags & kAsyncRejit) != 0 && r->device >= 0)) r->no_affine = r->no_affine_just_set = true;
     if ((r->flags & kSpecialised) != 0 && !((r->flags & kAsyncRejit) != 0 && r->device >= 0) && (mode_switches(*r) != r->kernel_switches || camera_left_the_affine_maps)) {
         int rc = guarded([&] {
             int rc2 = build_kernel(r, nullptr, 0);
@@ -1745,6 +1758,13 @@ extern "C" int ptl_dmath(const char* op, const double* a, const double* b, const
     if (what == "teleport" && b) return store(load(b) * load(a).inverse());  // a_to_b = B * A^-1 (src/gui/scene.rs:624-632)
     if (what == "srt" && b && c)  // Simple / Parametrized: T * (Rx * Ry * Rz) * S (src/gui/matrix.rs:555-569); a = scale xyz, b = rotate xyz, c = offset xyz
         return store(DMat4::from_scale_rotation_translation(DVec3(a[0], a[1], a[2]), DQuat::rotation_x(b[0]) * DQuat::rotation_y(b[1]) * DQuat::rotation_z(b[2]), DVec3(c[0], c[1], c[2])));
+    if (what == "lerp" && b && c) {  // Matrix::Lerp (src/gui/matrix.rs:614-627): a = first, b = second, c[0] = t -- the very statements scene.cpp evaluates
+        DVec3 fs, ft, ss, st;
+        DQuat fr, sr;
+        load(a).to_scale_rotation_translation(&fs, &fr, &ft);
+        load(b).to_scale_rotation_translation(&ss, &sr, &st);
+        return store(DMat4::from_scale_rotation_translation(fs.lerp(ss, c[0]), fr.lerp(sr, c[0]), ft.lerp(st, c[0])));
+    }
     if (what == "camera" && b) {  // RotateAroundCam::get_matrix (src/main.rs:278-304): a = look_at xyz, alpha, beta, r; b = the teleport matrix
         Camera cam;
         cam.look_at = DVec3(a[0], a[1], a[2]);

@@ -1261,9 +1261,29 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
     {
         StringStorage processing, defines;
         int counter = 0;
+        // Round 6 -- table-driven Simple materials (KernelOptions::material_table).  The reference prints one `else if (i.material == X_M) return
+        // material_simple2(hit, r, <nine literals>)` per material (scene.rs:736-760): 30 of the headline's 34, each an inlined copy of the same body
+        // behind its own compare-and-branch, and a wave that straddles two materials runs two copies.  Here the nine literals of every Simple material
+        // (and of the three DEBUG_* system materials) sit in a table indexed by the material id -- staged in LDS per workgroup by the kernel entries,
+        // read back per lane with two ds_read_b128 -- and ONE call of material_simple2 serves all of them.  Same function, same argument values, same
+        // operation order: no bit moves (a literal `1.0f - 0.5f` folded by the compiler is the value the instruction computes).
+        struct TableEntry { float color[3], normal_coef, grid_scale, grid_coef; unsigned flags; };  // flags: 1 grid, 2 grid2, 4 grid3, 8 present
+        std::map<int, TableEntry> table;
+        if (opts.material_table) {
+            const float hi = 0.9f, lo = 0.2f;  // src/library.glsl:387-398 via ptl_trace.tpl: color(0.9, 0.2, 0.2) = the squares, one binary32 multiplication each
+            const float hh = hi * hi, ll = lo * lo;
+            table[3] = TableEntry{{hh, ll, ll}, 0.5f, 1.0f, 0.0f, 8u};  // DEBUG_RED / GREEN / BLUE
+            table[4] = TableEntry{{ll, hh, ll}, 0.5f, 1.0f, 0.0f, 8u};
+            table[5] = TableEntry{{ll, ll, hh}, 0.5f, 1.0f, 0.0f, 8u};
+        }
         for (const Material& m : scene.materials) {
             std::string name_m = m.name + "_M";
             defines.add_string("#define " + name_m + " (USER_MATERIAL_OFFSET + " + std::to_string(counter++) + ")\n");
+            if (opts.material_table && m.kind == Material::Simple) {
+                table[10 + counter - 1] = TableEntry{{(float)m.color[0], (float)m.color[1], (float)m.color[2]}, (float)m.normal_coef, (float)m.grid_scale, (float)m.grid_coef,
+                                                     8u | (m.grid ? 1u : 0u) | (m.grid2 ? 2u : 0u) | (m.grid3 ? 4u : 0u)};
+                continue;
+            }
             processing.add_string("} else if (i.material == " + name_m + ") {\n");
             switch (m.kind) {
                 case Material::Simple:
@@ -1300,6 +1320,39 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             processing.add_string("return material_teleport_transformed(transform(" + teleport_name(a, b) + ", r), hit.n);");
             processing.add_string("} else if (i.material == " + m2 + ") {\n");
             processing.add_string("return material_teleport_transformed(transform(" + teleport_name(b, a) + ", r), hit.n);");
+        }
+        if (opts.material_table) {
+            const int entries = table.rbegin()->first + 1;
+            auto bits = [](float v) {
+                unsigned u;
+                std::memcpy(&u, &v, 4);
+                char buf[16];
+                std::snprintf(buf, sizeof buf, "0x%08xu", u);
+                return std::string(buf);
+            };
+            std::string init, masks;
+            for (int id = 0; id < entries; ++id) {
+                auto it = table.find(id);
+                const TableEntry e = it == table.end() ? TableEntry{{0, 0, 0}, 0, 0, 0, 0u} : it->second;
+                init += "    " + bits(e.color[0]) + ", " + bits(e.color[1]) + ", " + bits(e.color[2]) + ", " + bits(e.normal_coef) + ", " + bits(e.grid_scale) + ", " +
+                        bits(e.grid_coef) + ", " + std::to_string(e.flags) + "u, 0u,\n";
+            }
+            for (int w = 0; w * 64 < entries; ++w) {
+                unsigned long long mask = 0;
+                for (int b = 0; b < 64; ++b)
+                    if (table.count(w * 64 + b)) mask |= 1ull << b;
+                char buf[48];
+                std::snprintf(buf, sizeof buf, "0x%016llxull", mask);
+                masks += std::string(w ? ", " : "") + buf;
+            }
+            defines.add_string("#define PTL_MATERIAL_TABLE 1\n#define PTL_MATERIAL_TABLE_WORDS " + std::to_string(entries * 8) + "\n"
+                               "// per material id: colour x y z, normal_coef | grid_scale, grid_coef, flags (1 grid, 2 grid2, 4 grid3, 8 = a Simple material), 0 -- binary32 bit patterns\n"
+                               "#if PTL_DEVICE_BUILD\n__constant__ const unsigned int ptl_material_table_init[PTL_MATERIAL_TABLE_WORDS] = {\n" + init + "};\n"
+                               "__shared__ __attribute__((aligned(16))) unsigned int ptl_material_table[PTL_MATERIAL_TABLE_WORDS];  // filled by the kernel entries (ptl_entry.h)\n"
+                               "#else\nstatic const unsigned int ptl_material_table[PTL_MATERIAL_TABLE_WORDS] __attribute__((aligned(16))) = {\n" + init + "};\n#endif\n"
+                               "PTL_FN bool ptl_material_in_table(int id) {\n"
+                               "    const unsigned long long masks[] = {" + masks + "};\n"
+                               "    return (unsigned)id < " + std::to_string(entries) + "u && ((masks[(unsigned)id >> 6] >> ((unsigned)id & 63u)) & 1ull) != 0;\n}\n");
         }
         storages["material_processing"] = std::move(processing);
         storages["materials_defines"] = std::move(defines);

@@ -163,6 +163,9 @@ struct KernelOptions {
     // the matrix-times-ray products, the bounce loop -- count the ray halves that arrive with another w than 1 / 0 into the `segments` counter
     // (device/ptl_glsl.h PTL_CHECK_AFFINE).  Its frame is right either way; a non-zero count says an affine-rays kernel's would not be.
     bool check_affine = false;
+    // Round 6: the Simple materials' literals in a per-workgroup LDS table, one material_simple2 call for all of them (codegen.cpp, materials).
+    // Identical frames; PTL_FLAG_NO_MATERIAL_TABLE (bit 26) keeps the reference's chain of one inlined call per material (A/B measurements, tests).
+    bool material_table = true;
     // A/B switch (PTL_FLAG_KEEP_TRANSFORM_DODGES): a kernel with affine rays still gets the deferred loop updates and the first-trip snippet copies
     // -- round 4's shape, for measurements; by default it gets neither (codegen.cpp: a transform is then a few additions, cheaper than its dodge)
     bool keep_transform_dodges = false;

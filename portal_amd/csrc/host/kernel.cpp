@@ -210,6 +210,7 @@ struct ptl_kernel {
     // block of slice blockIdx.z from a device buffer of blocks, so one launch can trace several frames with different uniforms.  The module's
     // own global block stays what the camera-teleport query uses.
     bool sliced = false;
+    bool affine_rays = false;  // compiled with PTL_AFFINE_RAYS: its products assume o.w = 1 / d.w = 0, which a matrix with another bottom row than 0 0 0 1 breaks
     hip::hipFunction_t derive_slices_fn = nullptr;
     void* dev_slices = nullptr;           // kMaxSlices blocks of dev_block_size bytes
     std::vector<unsigned char> staged;    // host side of it: slice j at j * dev_block_size (ptl_kernel_stage_slice)
@@ -302,6 +303,7 @@ extern "C" int ptl_kernel_compile(int device, const char* hip_source, const ptl_
 
     bool teleport_only = false;
     for (int i = 0; i < n_defines; ++i) {
+        if (std::string(defines[i]) == "PTL_AFFINE_RAYS") k->affine_rays = true;
         if (std::string(defines[i]) == "PTL_RENDER_MODULE") k->split = true;
         if (std::string(defines[i]) == "PTL_TELEPORT_MODULE") teleport_only = true;
     }
@@ -557,6 +559,9 @@ extern "C" int ptl_kernel_code_object(ptl_kernel* k, const void** data, size_t* 
 // `kernel_prefix` (NULL / "": all kernels); -1 when the key does not occur.  What the JIT's occupancy retry decides on; no device needed.
 extern "C" int ptl_code_object_note(const void* code, size_t size, const char* key, const char* kernel_prefix) {
     if (!code || !key) return -1;
+    // (a value is attributed to the kernel whose `.name` entry was seen last, which relies on the metadata map's alphabetical key order: right
+    // for keys that sort AFTER ".name" only -- the documented ones all do; with a kernel prefix any other key is refused rather than mis-attributed)
+    if (kernel_prefix && kernel_prefix[0] && std::strcmp(key, ".name") <= 0) return -1;
     std::vector<char> bytes(static_cast<const char*>(code), static_cast<const char*>(code) + size);
     return code_object_note_max(bytes, key, kernel_prefix);
 }
@@ -578,6 +583,23 @@ extern "C" int ptl_kernel_set_uniform(ptl_kernel* k, const char* name, ptl_type 
     if (it == k->slots.end()) return PTL_UNKNOWN_UNIFORM;
     if (it->second.type != type || type == PTL_SAMPLER) return PTL_ERR_TYPE;
     size_t n = type_size(type);
+    if (k->affine_rays && type == PTL_MAT4) {
+        // a layer-1 caller owns `_camera` and every run-time `X_mat`; a kernel with affine rays is only valid for matrices that map
+        // w = 1 to 1 and w = 0 to 0 (or are NaN throughout: a switched-off object).  The layer-2 renderer rebuilds BEFORE it uploads such a matrix
+        // (capi.cpp `camera_is_affine`, `zero_patterns_broken`); a direct caller gets the refusal instead of silently wrong frames.
+        const std::string nm = name;
+        auto tail = [&](const char* e) { const size_t m = std::strlen(e); return nm.size() >= m && nm.compare(nm.size() - m, m, e) == 0; };
+        if (nm == "_camera" || tail("_mat") || tail("_mat_inv") || tail("_mat_teleport")) {
+            const float* f = static_cast<const float*>(value);
+            bool all_nan = true;
+            for (int e = 0; e < 16; ++e) all_nan = all_nan && f[e] != f[e];
+            if (!all_nan && !(f[3] == 0.0f && f[7] == 0.0f && f[11] == 0.0f && f[15] == 1.0f)) {
+                set_last_error("ptl_kernel_set_uniform: `" + nm + "` is not an affine matrix (bottom row 0 0 0 1) but this kernel was generated with PTL_AFFINE_RAYS; "
+                               "regenerate with flag bit23 (NO AFFINE RAYS)");
+                return PTL_ERR_INVALID;
+            }
+        }
+    }
     if (std::memcmp(k->shadow.data() + it->second.offset, value, n) != 0) {
         std::memcpy(k->shadow.data() + it->second.offset, value, n);
         k->dirty = true;

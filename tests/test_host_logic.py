@@ -1923,3 +1923,50 @@ def test_affine_rays_draw_the_bits_of_the_general_products(pa, name, depth):
             frames.append(hb.host_kernel_for(r, sc, w, h, flags=flags | extra).render(w, h)["rgba32f"].copy())
         assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)), (name, label)
         assert len(np.unique(frames[0].reshape(-1, 4), axis=0)) > 50
+
+
+# ---- round 6: ADVICE r5 ---------------------------------------------------------------------------------------------------------------------
+def test_a_layer_1_kernel_with_affine_rays_refuses_a_matrix_that_is_not_affine(pa):
+    """ADVICE r5 (include/portal_amd.h layer 1): a caller that binds only ptl_kernel_* owns `_camera` and the run-time `X_mat` uniforms; a kernel
+    generated with PTL_AFFINE_RAYS is valid for affine matrices only, and `ptl_kernel_set_uniform` says so instead of drawing wrong frames."""
+    spec = pa.FLAG_SPECIALIZE_INTS
+    scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+    source = scene.generate_source(spec)
+    defines = scene.generated_defines()
+    assert "PTL_AFFINE_RAYS" in defines
+    layout, size = scene.uniform_layout()
+    k = pa.Kernel(source, layout, size, device=-1, defines=defines)
+    general = pa.Kernel(scene.generate_source(spec | pa.FLAG_NO_AFFINE_RAYS), layout, size, device=-1, defines=scene.generated_defines())
+    affine = np.eye(4, dtype=np.float32)
+    affine[:3, 3] = (1.0, 2.0, 3.0)
+    projective = affine.copy()
+    projective[3, 0] = 0.25
+    matrices = [n for n, t, _ in layout if t == pa.PTL_MAT4 and (n == "_camera" or n.endswith(("_mat", "_mat_inv", "_mat_teleport")))]
+    assert "_camera" in matrices and len(matrices) >= 3
+    for name in matrices:
+        assert k.set_uniform(name, pa.PTL_MAT4, affine) == 0
+        assert k.set_uniform(name, pa.PTL_MAT4, np.full((4, 4), np.nan, np.float32)) == 0   # a switched-off object
+        with pytest.raises(pa.PortalError, match="not an affine matrix"):
+            k.set_uniform(name, pa.PTL_MAT4, projective)
+        assert general.set_uniform(name, pa.PTL_MAT4, projective) == 0   # the general products take any matrix
+
+
+def test_one_return_to_affine_rays_per_stage(pa):
+    """a camera that leaves the affine maps switches affine rays off; once it is back, a rebuild that happens anyway (here: a mode switch)
+    returns to them -- once per stage, so a state that flickers cannot rebuild per frame."""
+    text = open(pa.scene_path("basics")).read()
+    cam_text = text.replace("matrix: (1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0),", "matrix: (1.0, 0.0, 0.0, 0.125, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0),", 1)
+    assert cam_text != text
+    r = pa.SceneRenderer(pa.Scene.from_text(cam_text), device=-1, flags=pa.FLAG_SPECIALIZE_PATTERNS | pa.FLAG_QUICK_JIT)
+    assert r.affine_rays()
+    r.use_camera("doorway")
+    assert not r.affine_rays() and r.rejit_count() == 1
+    r.use_camera("red")
+    assert not r.affine_rays() and r.rejit_count() == 1      # no rebuild of its own
+    r.set_option("use_360_camera", 1)                          # a rebuild for another reason ...
+    assert r.affine_rays() and r.rejit_count() == 2           # ... returns to affine rays
+    r.use_camera("doorway")
+    assert not r.affine_rays() and r.rejit_count() == 3
+    r.use_camera("red")
+    r.set_option("use_360_camera", 0)
+    assert not r.affine_rays() and r.rejit_count() == 4       # the second break of this stage keeps them off

@@ -203,3 +203,105 @@ if __name__ == "__main__":  # the totals over the corpus, for the record (profil
             totals[k] = totals.get(k, 0) + v
     print({"scenes": len(SCENES), "primitives_checked": totals, "binary32_elements_not_the_correctly_rounded_exact_value": ties, "of": 16 * sum(totals.values()),
            "worst_error_in_binary64_ulps": {k: round(v, 3) for k, v in WORST.items()}})
+
+
+# ---- round 6: Matrix::Lerp -----------------------------------------------------------------------------------------------------
+def exact_lerp(a16, b16, t):
+    """/root/reference/src/gui/matrix.rs:614-627 in exact arithmetic: both matrices to (scale, rotation, translation) -- glam 0.13.1's
+    `to_scale_rotation_translation`: scale = the axis lengths, x negated for a mirrored basis; rotation = the quaternion of the axes divided by the
+    scale -- then scale and translation blended linearly, the rotation by the shortest-arc normalised linear blend (`DQuat::lerp`), and recomposed
+    (`from_scale_rotation_translation`).  The quaternion of an exact rotation is unique up to sign and the blend is symmetric under it, so no
+    branch of glam's extraction is restated here: the largest-component formula serves."""
+    t = mp.mpf(float(t))
+
+    def decompose(m16):
+        m = M(m16)
+        sign = -1 if det4(m) < 0 else 1
+        cols = [[m[r, c] for r in range(3)] for c in range(3)]
+        scale = [mp.sqrt(sum(x * x for x in col)) for col in cols]
+        scale[0] *= sign
+        r = [[cols[c][i] / scale[c] for c in range(3)] for i in range(3)]   # r[row][col]
+        tr = r[0][0] + r[1][1] + r[2][2]
+        cand = [1 + tr, 1 + r[0][0] - r[1][1] - r[2][2], 1 - r[0][0] + r[1][1] - r[2][2], 1 - r[0][0] - r[1][1] + r[2][2]]
+        k = max(range(4), key=lambda i: cand[i])
+        s = 2 * mp.sqrt(cand[k])
+        if k == 0:
+            q = [(r[2][1] - r[1][2]) / s, (r[0][2] - r[2][0]) / s, (r[1][0] - r[0][1]) / s, s / 4]
+        elif k == 1:
+            q = [s / 4, (r[0][1] + r[1][0]) / s, (r[0][2] + r[2][0]) / s, (r[2][1] - r[1][2]) / s]
+        elif k == 2:
+            q = [(r[0][1] + r[1][0]) / s, s / 4, (r[1][2] + r[2][1]) / s, (r[0][2] - r[2][0]) / s]
+        else:
+            q = [(r[0][2] + r[2][0]) / s, (r[1][2] + r[2][1]) / s, s / 4, (r[1][0] - r[0][1]) / s]
+        return scale, q, [m[i, 3] for i in range(3)]
+
+    (fs, fq, ft), (ss, sq, st) = decompose(a16), decompose(b16)
+    scale = [fs[i] + (ss[i] - fs[i]) * t for i in range(3)]
+    trans = [ft[i] + (st[i] - ft[i]) * t for i in range(3)]
+    bias = 1 if sum(fq[i] * sq[i] for i in range(4)) >= 0 else -1
+    q = [fq[i] + (sq[i] * bias - fq[i]) * t for i in range(4)]
+    n = mp.sqrt(sum(x * x for x in q))
+    x, y, z, w = [c / n for c in q]
+    rot = mp.matrix([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    out = mp.eye(4)
+    for i in range(3):
+        for j in range(3):
+            out[i, j] = rot[i, j] * scale[j]
+        out[i, 3] = trans[i]
+    return out
+
+
+def test_matrix_lerp_against_exact_arithmetic(pa):
+    """Every Simple / Parametrized matrix of the 82 scene files, paired with the next one of its scene, blended at five t: the product's
+    `Matrix::Lerp` (scene.cpp -> dmath.h, here through ptl_dmath "lerp") against the same definition in 200-bit arithmetic."""
+    from oracle.scene_eval import OracleScene
+
+    rng = np.random.default_rng(6)
+    checked, worst_seen, near_ties = 0, 0.0, 0
+    for path in SCENES:
+        osc = OracleScene(path)
+        mats = []
+        for name, named, node in osc.matrices:
+            if node is None or node[0] != "Simple":
+                continue
+            _, off, sc, rot, mir = node
+            scale = [sc * (-1.0 if mir[k] else 1.0) for k in range(3)]
+            if sc == 0 or not all(math.isfinite(x) for x in list(scale) + list(rot) + list(off)):
+                continue
+            mats.append(pa.dmath("srt", scale, rot, off))
+        for a16, b16 in zip(mats, mats[1:]):
+            ea, eb = decompose_quat_dot(a16, b16)
+            for t in (0.0, 0.25, 0.5, 1.0, float(rng.uniform(-0.5, 1.5))):
+                exact = exact_lerp(a16, b16, t)
+                got = pa.dmath("lerp", a16, b16, [t])
+                worst, differ, far = ulps(got, flat(exact))
+                # the shortest-arc choice flips where the two rotations are (numerically) orthogonal as quaternions, and an antipodal blend at t = 0.5
+                # has length ~0: both are singular points of the definition, not of the implementation
+                if abs(ea) < 1e-9 or (abs(abs(ea) - 1.0) > 1e-9 and abs(eb) < 1e-6):
+                    continue
+                worst_seen = max(worst_seen, worst)
+                assert worst <= 64.0 and far == 0, (os.path.basename(path), t, worst, differ)
+                near_ties += differ
+                checked += 1
+    print({"lerps_checked": checked, "worst_error_in_binary64_ulps": round(worst_seen, 2), "binary32_near_ties": near_ties})
+    assert checked >= 1500 and near_ties <= checked * 16 // 200
+
+
+def decompose_quat_dot(a16, b16):
+    """(dot of the two rotations' quaternions, length of their blend at t = 0.5) in double precision: where the definition itself is singular"""
+    def quat(m16):
+        m = np.asarray(m16, np.float64).reshape(4, 4).T[:3, :3].copy()
+        s = np.linalg.norm(m, axis=0)
+        if np.linalg.det(m) < 0:
+            s[0] = -s[0]
+        r = m / s
+        w = math.sqrt(max(0.0, 1.0 + r[0, 0] + r[1, 1] + r[2, 2])) / 2
+        x = math.sqrt(max(0.0, 1.0 + r[0, 0] - r[1, 1] - r[2, 2])) / 2
+        y = math.sqrt(max(0.0, 1.0 - r[0, 0] + r[1, 1] - r[2, 2])) / 2
+        z = math.sqrt(max(0.0, 1.0 - r[0, 0] - r[1, 1] + r[2, 2])) / 2
+        x, y, z = math.copysign(x, r[2, 1] - r[1, 2]), math.copysign(y, r[0, 2] - r[2, 0]), math.copysign(z, r[1, 0] - r[0, 1])
+        return np.array([x, y, z, w])
+    qa, qb = quat(a16), quat(b16)
+    d = float(qa @ qb)
+    return d, float(np.linalg.norm(qa + (qb * (1.0 if d >= 0 else -1.0) - qa) * 0.5))
