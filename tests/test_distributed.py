@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, W=W, H=H, scene_name="monoportal"):
     import sys
 
     sys.path.insert(0, ROOT)
@@ -32,7 +32,7 @@ def _worker(rank, world, port, out_path):
         from oracle import host_build as hb
         from portal_amd import parallel
 
-        scene = pa.Scene.from_file(pa.scene_path("monoportal"))
+        scene = pa.Scene.from_file(pa.scene_path(scene_name))
         r = pa.SceneRenderer(scene, device=-1)
         r.set_option("render_depth", DEPTH)
         hk = hb.host_kernel_for(r, scene, W, H)
@@ -73,6 +73,29 @@ def test_sharded_render_and_gather_equals_single_process(pa, tmp_path, world):
     r.set_option("render_depth", DEPTH)
     want = hb.host_kernel_for(r, scene, W, H).render(W, H, rgba32f=False)["rgba8"]
     assert np.array_equal(np.load(out_path), want)
+
+
+@pytest.mark.parametrize("height, blocks_per_rank", [(2160, [34] * 6 + [33] * 2), (4320, [68] * 4 + [67] * 4), (2156, [34] * 6 + [33] * 2)])
+def test_eight_ranks_on_the_geometry_of_the_baseline_frames(pa, tmp_path, height, blocks_per_rank):
+    """the 8-rank shape before hardware exists.  BASELINE's 4K frames have 270 row blocks -- 33.75 per rank at G = 8: six ranks
+    with 34 blocks, two with 33, every shard padded to 34 for the gather -- C5's 8K frame 540 (68 / 67); a 2156-row frame ends in a ragged block of
+    four rows on rank 5.  Eight gloo ranks render their interleaved blocks (host build, a 24-pixel-wide frame of the same height), the
+    double-buffered gather assembles them on rank 0, and the frame equals the single-process one byte for byte."""
+    from oracle import host_build as hb
+    from portal_amd import parallel
+
+    world, width = 8, 24
+    counts = [len(range(g, parallel.blocks_of(height), world)) for g in range(world)]
+    assert counts == blocks_per_rank and parallel.shard_blocks_max(height, world) == max(blocks_per_rank)
+    assert [pa.shard_rows(pa.Frame(width, height, g, world)) for g in range(world)] == [sum(min(8, height - 8 * b) for b in range(g, parallel.blocks_of(height), world)) for g in range(world)]
+    out_path = str(tmp_path / "full.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out_path, width, height, "portal_in_portal"), nprocs=world, join=True)
+    scene = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    r = pa.SceneRenderer(scene, device=-1)
+    r.set_option("render_depth", DEPTH)
+    want = hb.host_kernel_for(r, scene, width, height).render(width, height, rgba32f=False)["rgba8"]
+    got = np.load(out_path)
+    assert got.shape == (height, width, 4) and np.array_equal(got, want)
 
 
 def test_gatherer_single_rank_is_identity():

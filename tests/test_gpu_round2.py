@@ -158,6 +158,28 @@ def test_frame_group_assembles_the_single_gpu_frame(gpu, transport, ranks):
     assert np.array_equal(big, single.draw(1920, 1080)["rgba8"])
 
 
+@pytest.mark.parametrize("transport", ["stores", "copy"])
+def test_frame_group_with_eight_ranks_on_the_baseline_geometry(gpu, transport):
+    """layer 3 with the one GPU of this box listed EIGHT times, on the headline's geometry -- 3840 x 2160 = 270 row blocks, six
+    ranks with 34 and two with 33 -- and a frame that ends in a ragged block: every rank's renderer, streams, row-block phase, double buffers and
+    the transfer into rank 0's frame run as they will on a node; the frame is the single renderer's, byte for byte, also pipelined."""
+    pa = gpu
+    scene = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
+    single = pa.SceneRenderer(scene, device=0, flags=pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)
+    single.set_option("render_depth", 40)
+    g = pa.FrameGroup(pa.Scene.from_file(pa.scene_path("portal_in_portal")), [0] * 8, flags=pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL,
+                      transport=pa.GROUP_PEER_STORES if transport == "stores" else pa.GROUP_COPY_GATHER)
+    g.set_option("render_depth", 40)
+    for w, h in ((3840, 2160), (1000, 2156)):
+        out = g.draw(w, h)
+        assert np.array_equal(out["rgba8"], single.draw(w, h)["rgba8"]), (w, h)
+        assert len(out["kernel_ms"]) == 8 and all(ms > 0 for ms in out["kernel_ms"])
+    tickets = [g.submit(3840, 2160), g.submit(3840, 2160)]
+    want = single.draw(3840, 2160)["rgba8"]
+    for t in tickets:
+        assert np.array_equal(g.wait(t)["rgba8"], want)
+
+
 def test_frame_group_rccl_gather_on_the_devices_of_this_box(gpu):
     """PTL_GROUP_RCCL_GATHER (the north star's "single RCCL gather", layer 3): librccl bound with dlopen, communicators from
     ncclCommInitAll, one group of ncclSend / ncclRecv into rank 0, strided copies into the frame.  On this box the communicator has as
