@@ -61,10 +61,18 @@ def workload_key(args):
     return key
 
 
-PROFILE_ROUNDS = ("r05", "r04", "r03")  # newest first; a round's files are measurements of that round's kernels
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03")  # newest first; a round's files are measurements of that round's kernels
 
 
-def stored_pmc(args, build, code_sha=None):
+def source_sha256(renderer):
+    """sha256 of the generated kernel source the renderer's current build was compiled from: the candidate builds of one workload (w0 ... w5, minreg) share
+    it -- they differ in the register budget / scheduler handed to the compiler, not in a single operation of the program."""
+    import hashlib
+
+    return hashlib.sha256(renderer.kernel_source().encode("utf-8")).hexdigest()
+
+
+def stored_pmc(args, build, code_sha=None, source_sha=None):
     """The committed rocprofv3 PMC passes of exactly this workload (profiles/rNN/pmc_<workload>_<spec>_<build>.json, one counter group per
     pass, tools/collect_pmc.sh): HBM bytes per launch (FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE, KB units),
     SQ_INSTS_VALU and the instruction classes per launch.  Round 5: a PMC file names the sha256 of the code object whose launches it counted
@@ -82,10 +90,17 @@ def stored_pmc(args, build, code_sha=None):
             try:
                 doc = json.load(open(path))
                 c = doc["counters"]
+                match = "code object"
                 if code_sha is not None and doc.get("code_object_sha256") != code_sha:
-                    refused.append(f"{os.path.relpath(path, HERE)}: counted code object {str(doc.get('code_object_sha256'))[:16]}, timed {code_sha[:16]}")
-                    continue
-                out = {"traffic": int((2 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024),
+                    # round 6: ... or of another register budget of the SAME generated source (`kernel_source_sha256` in the file and in the line): the
+                    # same program, the same arithmetic; the pick among candidates a per cent apart then no longer decides whether counters exist
+                    if source_sha is not None and doc.get("kernel_source_sha256") == source_sha:
+                        match = "same kernel source, another register budget"
+                    else:
+                        refused.append(f"{os.path.relpath(path, HERE)}: counted code object {str(doc.get('code_object_sha256'))[:16]}, timed {code_sha[:16]}")
+                        continue
+                out = {"traffic": int((2 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024), "match": match,
+                       "kernel_source_sha256": doc.get("kernel_source_sha256"),
                        "insts_valu": float(c["SQ_INSTS_VALU"]["mean_per_launch"]), "source": os.path.relpath(path, HERE), "code_object_sha256": doc.get("code_object_sha256")}
                 classes = ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "GRBM_GUI_ACTIVE")
                 if all(k in c for k in classes):
@@ -438,6 +453,8 @@ def valu_roofline(fl, pmc, segments, world, kernel_ms, traffic, specialize):
             roof["frac_is"] = "min(the oracle's count of executed arithmetic, the hardware's FP32 arithmetic counters of the same code object)"
         roof["pmc_source"] = pmc["source"] + " (stored rocprofv3 PMC passes of the code object named in pmc_code_object_sha256 -- the one this run timed; not re-measured by this run)"
         roof["pmc_code_object_sha256"] = pmc.get("code_object_sha256")
+        roof["pmc_kernel_source_sha256"] = pmc.get("kernel_source_sha256")
+        roof["pmc_match"] = pmc.get("match")
     return roof
 
 
@@ -456,13 +473,13 @@ def compact_line(out):
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype") if k in out}
     line["data"] = "synthetic: the reference's shipped scene file, scene camera, no stage"
     version = str(cfg.get("toolchain", ""))
-    line["config"] = {**_pick(cfg, ("workload", "trips_per_primary_ray", "build", "code_object_sha256", "affine_rays", "candidate_frames_identical", "transport")),
+    line["config"] = {**_pick(cfg, ("workload", "trips_per_primary_ray", "build", "code_object_sha256", "kernel_source_sha256", "affine_rays", "candidate_frames_identical", "transport")),
                       "parallelism": str(cfg.get("parallelism", ""))[:60], "jit_specialisation": cfg.get("jit_specialisation"),
                       "hiprtc_version": version.split("hiprtc_version=")[-1] if "hiprtc_version=" in version else None}
     line.update(_pick(out, ("kernel_ms", "kernel_ms_per_rank", "transport_ms", "segments_per_frame", "segment_mray_s", "jit_seconds")))
     roof = out.get("roofline") or {}
     line["roofline"] = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "hw_arith_frac", "frac_counted_by_the_oracle", "lane_utilisation",
-                                    "valu_insts_per_launch", "pmc_code_object_sha256"))
+                                    "valu_insts_per_launch", "pmc_code_object_sha256", "pmc_kernel_source_sha256", "pmc_match"))
     if "traffic" not in line["roofline"]:
         line["roofline"]["traffic"] = None
     if roof.get("pmc_source"):
@@ -702,7 +719,7 @@ def main():
     if rank == 0 and not args.build and args.waves < 0:
         near = [k for k in pool if pool[k][0] <= pool[best][0] * 1.015]
         for k in sorted(near, key=lambda k: pool[k][0]):
-            if stored_pmc(args, k, pool[k][1].code_object_sha256())[0] is not None:
+            if stored_pmc(args, k, pool[k][1].code_object_sha256())[0] is not None:  # (an exact match first; below, the same source is accepted too)
                 best = k
                 break
     if world > 1:  # all ranks must run the same build: take rank 0's choice
@@ -941,7 +958,7 @@ def main():
                 if world > 1:
                     dist.all_reduce(seg2)
                 sha2 = r2.code_object_sha256()
-                fl2, (pmc2, why2) = flops_per_segment(a2, r2.affine_rays()), stored_pmc(a2, "w0", sha2)
+                fl2, (pmc2, why2) = flops_per_segment(a2, r2.affine_rays()), stored_pmc(a2, "w0", sha2, source_sha256(r2))
                 second["segments_per_frame"] = int(seg2.item())
                 second["trips_per_primary_ray"] = round(int(seg2.item()) / (w2["width"] * w2["height"] * w2["aa"]), 4)
                 second["code_object_sha256"] = sha2
@@ -1019,7 +1036,7 @@ def main():
                        "steps": steps, "ms_per_step": round(ms_step, 4), "kernel_ms": round(kms, 4), "value": round(Wk * Hk * a.aa / (ms_step * 1e-3) / 1e6, 3), "unit": "Mray/s",
                        "build": f"w{waves}", "code_object_sha256": sha, "segments_per_frame": trips, "trips_per_primary_ray": round(trips / (Wk * Hk * a.aa), 4),
                        "segment_mray_s": round(trips / (ms_step * 1e-3) / 1e6, 3)}
-                fl_k, (pmc_k, why_k) = flops_per_segment(a, rr.affine_rays()), stored_pmc(a, f"w{waves}", sha)
+                fl_k, (pmc_k, why_k) = flops_per_segment(a, rr.affine_rays()), stored_pmc(a, f"w{waves}", sha, source_sha256(rr))
                 if fl_k:
                     rec["roofline"] = valu_roofline(fl_k, pmc_k, trips, 1, kms, pmc_k["traffic"] if pmc_k else None, args.specialize)
                     if pmc_k is None:
@@ -1244,7 +1261,8 @@ def main():
         out["config"]["code_object_sha256"] = timed_sha  # of the binary the timed region launched: what ties this line to stored PMC passes
         out["config"]["affine_rays"] = renderer.affine_rays()
         out["config"]["toolchain"] = pa.version()
-        pmc, pmc_why = stored_pmc(args, best, timed_sha)
+        out["config"]["kernel_source_sha256"] = source_sha256(renderer)
+        pmc, pmc_why = stored_pmc(args, best, timed_sha, out["config"]["kernel_source_sha256"])
         hbm = {
             "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": pmc["traffic"] if pmc else None,

@@ -299,6 +299,13 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * column then costs a direction nothing and the w row folds to a constant (headline kernel -16 %); the same operations on the same values
  * for finite rays, identical frames.  A renderer rebuilds without it when a matrix -- the camera's included -- stops being affine.
  * This bit keeps the general products (A/B measurements, tests),
+ * bit26 = MATERIAL TABLE IN LDS, bit27 = MATERIAL TABLE BEHIND SCALAR LOADS (round 6, A/B; both measured and left off): the reference prints one
+ * `else if (i.material == X_M) return material_simple2(hit, r, <nine literals>);` per Simple material (src/gui/scene.rs:736-760).  With one of these bits
+ * the nine literals of every Simple material (and of DEBUG_RED / GREEN / BLUE) sit in a table indexed by the material id and ONE call of
+ * material_simple2 serves them all -- bit26: the table staged in LDS per workgroup, two ds_read_b128 per lane; bit27: the table in constant memory,
+ * one scalar load per DISTINCT material of the wave (a readfirstlane loop), the grid flags on the scalar unit.  Same function, same argument
+ * values: identical frames.  Headline 0.1869 ms without, 0.1905 (LDS) / 0.1872 (scalar); C2 0.0369 / 0.0383 / 0.0376; C3 0.2133 / 0.2118 / 0.2086
+ * (profiles/r06/ab_material_table2.jsonl): a wave usually holds ONE material and its own copy with the literals folded beats a generic body.
  * bit25 = CHECK AFFINE (round 6, diagnostics): never affine rays; the kernel is generated with PTL_CHECK_AFFINE and its `segments` counter (bit1 is
  * implied) counts, instead of bounce-loop trips, the ray halves that reach a matrix-times-ray product or the bounce loop with a w that is
  * not 1 (origin) / 0 (direction) -- what a kernel with affine rays would have assumed wrongly.  Same frames as bit23.  See ptl_renderer_check_affine.

@@ -60,6 +60,8 @@ FLAG_QUICK_JIT = 262144  # compile at -O1 instead of the shipped -O3: half the J
 FLAG_SPECIALIZE_PATTERNS = 1048576  # compile in only what survives moving values: zero patterns of the matrices + the renderer's mode switches
 FLAG_BOUNDED_SNIPPETS = 2097152  # opt-in: scene_intersect first, its hit distance bounds the intersection-material snippets (exact; measured: no gain on the headline)
 FLAG_KEEP_TRANSFORM_DODGES = 16777216  # A/B: deferred loop updates + first-trip snippet copies also in a kernel with affine rays (default there: neither; identical frames)
+FLAG_MATERIAL_TABLE_LDS = 1 << 26  # A/B (measured slower, off by default): the Simple materials' literals in a per-workgroup LDS table, ONE material_simple2 call
+FLAG_MATERIAL_TABLE_SCALAR = 1 << 27  # A/B (measured: no gain): the same table in constant memory, a scalar load per distinct material of the wave (waterfall)
 FLAG_CHECK_AFFINE = 1 << 25  # diagnostics: general products, and `segments` counts the ray halves that meet a product / the bounce loop with a w that is not 1 / 0
 FLAG_NO_AFFINE_RAYS = 8388608  # A/B: matrix-times-ray products never assume o.w = 1 / d.w = 0 (default in specialised builds of affine scenes: they do; identical frames)
 FLAG_SLICES = 4194304  # the render entry reads its uniform block from a buffer of blocks (one per blockIdx.z): stage_slice / draw_slices, one launch for several draws

@@ -64,7 +64,7 @@ ptl_render_kernel(unsigned int* __restrict__ out_rgba8,   // packed rows of this
 #ifdef PTL_COUNT_SEGMENTS
     ptl_segments_lds[t] = 0u;
 #endif
-#ifdef PTL_MATERIAL_TABLE
+#if defined(PTL_MATERIAL_TABLE) && PTL_MATERIAL_TABLE == 1
     {  // stage the Simple materials' constants in LDS once per workgroup (codegen.cpp, materials): two ds_read_b128 per lane fetch a material's nine values
         for (int k = (int)threadIdx.x; k < PTL_MATERIAL_TABLE_WORDS; k += (int)blockDim.x) glsl::ptl_material_table[k] = glsl::ptl_material_table_init[k];
         __syncthreads();
@@ -126,7 +126,7 @@ extern "C" __global__ void __launch_bounds__(64) ptl_teleport_kernel(float* __re
 #ifdef PTL_COUNT_SEGMENTS
     ptl_segments_lds[threadIdx.x] = 0u;
 #endif
-#ifdef PTL_MATERIAL_TABLE
+#if defined(PTL_MATERIAL_TABLE) && PTL_MATERIAL_TABLE == 1
     {  // stage the Simple materials' constants in LDS once per workgroup (codegen.cpp, materials): two ds_read_b128 per lane fetch a material's nine values
         for (int k = (int)threadIdx.x; k < PTL_MATERIAL_TABLE_WORDS; k += (int)blockDim.x) glsl::ptl_material_table[k] = glsl::ptl_material_table_init[k];
         __syncthreads();

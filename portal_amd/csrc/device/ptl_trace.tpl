@@ -151,10 +151,30 @@ PTL_FN MaterialProcessing material_process(Ray r, const SceneIntersection& i) {
     // every Simple material of the scene and the three DEBUG_* ones: their nine literals from the LDS table, ONE copy of the body (codegen.cpp, materials)
     } else if (ptl_material_in_table(i.material)) {
         struct alignas(16) ptl_words4 { unsigned int x, y, z, w; };
+#if PTL_DEVICE_BUILD && PTL_MATERIAL_TABLE == 2
+        // the table in constant memory, one scalar load per DISTINCT material of the wave (usually one): the nine values arrive in SGPRs, the grid flags
+        // branch on the scalar unit, and the body runs once per material present
+        MaterialProcessing shaded = material_empty();
+        for (bool done = false; !done;) {
+            const int current = __builtin_amdgcn_readfirstlane(i.material);
+            // (the index through an opaque SGPR: where the compiler knows `current == i.material` it indexes with the per-lane value -- vector loads)
+            int row = 8 * current;
+            asm volatile("" : "+s"(row));
+            const ptl_words4 a = *reinterpret_cast<const ptl_words4*>(&ptl_material_table[row]);
+            const ptl_words4 b = *reinterpret_cast<const ptl_words4*>(&ptl_material_table[row + 4]);
+            if (i.material == current) {
+                shaded = material_simple2(hit, r, vec3(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, a.y), __builtin_bit_cast(float, a.z)), __builtin_bit_cast(float, a.w),
+                                          (b.z & 1u) != 0, __builtin_bit_cast(float, b.x), __builtin_bit_cast(float, b.y), (b.z & 2u) != 0, (b.z & 4u) != 0);
+                done = true;
+            }
+        }
+        return shaded;
+#else
         const ptl_words4 a = *reinterpret_cast<const ptl_words4*>(&ptl_material_table[8 * i.material]);
         const ptl_words4 b = *reinterpret_cast<const ptl_words4*>(&ptl_material_table[8 * i.material + 4]);
         return material_simple2(hit, r, vec3(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, a.y), __builtin_bit_cast(float, a.z)), __builtin_bit_cast(float, a.w),
                                 (b.z & 1u) != 0, __builtin_bit_cast(float, b.x), __builtin_bit_cast(float, b.y), (b.z & 2u) != 0, (b.z & 4u) != 0);
+#endif
 #else
     } else if (i.material == DEBUG_RED) {
         return material_simple2(hit, r, color(0.9f, 0.2f, 0.2f), 0.5f, false, 1.0f, 0.0f, false, false);

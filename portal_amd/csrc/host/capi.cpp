@@ -492,7 +492,9 @@ static KernelOptions options_from_flags(unsigned flags) {
     // is half of its hiprtc time for the headline scene (3.4 -> 1.8 s on this container's cores) and buys 0.05 ms of kernel
     o.unroll_baked_loops = (flags & 32768u) == 0 && !o.quick_jit;
     o.keep_transform_dodges = (flags & (1u << 24)) != 0;  // PTL_FLAG_KEEP_TRANSFORM_DODGES: deferred updates + first-trip snippet copies also with affine rays (A/B)
-    o.material_table = (flags & (1u << 26)) == 0;  // PTL_FLAG_NO_MATERIAL_TABLE: one inlined material_simple2 per Simple material, as the reference prints them (A/B)
+    // the Simple materials' literals from a table instead of one inlined material_simple2 per material (A/B: measured slower, off by default -- codegen.h):
+    // PTL_FLAG_MATERIAL_TABLE_LDS (bit 26) staged in LDS, PTL_FLAG_MATERIAL_TABLE_SCALAR (bit 27) in constant memory behind scalar loads
+    o.material_table = (flags & (1u << 27)) != 0 ? 2 : ((flags & (1u << 26)) != 0 ? 1 : 0);
     o.check_affine = (flags & (1u << 25)) != 0;   // PTL_FLAG_CHECK_AFFINE: general products, and `segments` counts the ray halves whose w is not 1 / 0
     o.affine_rays = (flags & (1u << 23)) == 0;    // PTL_FLAG_NO_AFFINE_RAYS: matrix-times-ray products never assume o.w = 1 / d.w = 0 (A/B measurements, tests)
     o.first_trip = (flags & 8192u) == 0;          // PTL_FLAG_NO_FIRST_TRIP: no first-trip copies of the intersection-material snippets
@@ -502,6 +504,9 @@ static KernelOptions options_from_flags(unsigned flags) {
 
 // The renderer's mode switches that a specialised build compiles in (KernelOptions::baked_options): the camera models and output modes.
 static std::map<std::string, int> mode_switches(const ptl_renderer& r) {
+    // (Round 6 measured the four display toggles -- `_grid_disable`, `_black_border_disable`, `_angle_color_disable`, `_darken_by_distance` -- and the scene's
+    // `teleport_light_u` compiled in as well: 10 % fewer static instructions (every scalar load with its address arithmetic and wait inside the headline's ~20
+    // inlined portal tests gone), 0.1873 -> 0.1869 ms: nothing -- the kernel is bound by VALU issue, scalar work hides behind it.  profiles/r06/README.md)
     return {{"_use_panini_projection", r.cam.use_panini_projection ? 1 : 0}, {"_use_360_camera", r.cam.use_360_camera ? 1 : 0},
             {"_use_180_camera", r.cam.use_180_camera ? 1 : 0},               {"_draw_depth_map", r.draw_depth_map ? 1 : 0},
             {"_draw_anaglyph", r.draw_anaglyph ? 1 : 0},                     {"_draw_side_by_side", r.draw_side_by_side ? 1 : 0}};

@@ -1269,7 +1269,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         // operation order: no bit moves (a literal `1.0f - 0.5f` folded by the compiler is the value the instruction computes).
         struct TableEntry { float color[3], normal_coef, grid_scale, grid_coef; unsigned flags; };  // flags: 1 grid, 2 grid2, 4 grid3, 8 present
         std::map<int, TableEntry> table;
-        if (opts.material_table) {
+        if (opts.material_table != 0) {
             const float hi = 0.9f, lo = 0.2f;  // src/library.glsl:387-398 via ptl_trace.tpl: color(0.9, 0.2, 0.2) = the squares, one binary32 multiplication each
             const float hh = hi * hi, ll = lo * lo;
             table[3] = TableEntry{{hh, ll, ll}, 0.5f, 1.0f, 0.0f, 8u};  // DEBUG_RED / GREEN / BLUE
@@ -1279,7 +1279,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
         for (const Material& m : scene.materials) {
             std::string name_m = m.name + "_M";
             defines.add_string("#define " + name_m + " (USER_MATERIAL_OFFSET + " + std::to_string(counter++) + ")\n");
-            if (opts.material_table && m.kind == Material::Simple) {
+            if (opts.material_table != 0 && m.kind == Material::Simple) {
                 table[10 + counter - 1] = TableEntry{{(float)m.color[0], (float)m.color[1], (float)m.color[2]}, (float)m.normal_coef, (float)m.grid_scale, (float)m.grid_coef,
                                                      8u | (m.grid ? 1u : 0u) | (m.grid2 ? 2u : 0u) | (m.grid3 ? 4u : 0u)};
                 continue;
@@ -1321,7 +1321,7 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
             processing.add_string("} else if (i.material == " + m2 + ") {\n");
             processing.add_string("return material_teleport_transformed(transform(" + teleport_name(b, a) + ", r), hit.n);");
         }
-        if (opts.material_table) {
+        if (opts.material_table != 0) {
             const int entries = table.rbegin()->first + 1;
             auto bits = [](float v) {
                 unsigned u;
@@ -1345,10 +1345,11 @@ GeneratedKernel generate_kernel_source(const Scene& scene, const CodegenFlags& f
                 std::snprintf(buf, sizeof buf, "0x%016llxull", mask);
                 masks += std::string(w ? ", " : "") + buf;
             }
-            defines.add_string("#define PTL_MATERIAL_TABLE 1\n#define PTL_MATERIAL_TABLE_WORDS " + std::to_string(entries * 8) + "\n"
+            defines.add_string("#define PTL_MATERIAL_TABLE " + std::to_string(opts.material_table) + "\n#define PTL_MATERIAL_TABLE_WORDS " + std::to_string(entries * 8) + "\n"
                                "// per material id: colour x y z, normal_coef | grid_scale, grid_coef, flags (1 grid, 2 grid2, 4 grid3, 8 = a Simple material), 0 -- binary32 bit patterns\n"
-                               "#if PTL_DEVICE_BUILD\n__constant__ const unsigned int ptl_material_table_init[PTL_MATERIAL_TABLE_WORDS] = {\n" + init + "};\n"
+                               "#if PTL_DEVICE_BUILD && PTL_MATERIAL_TABLE == 1\n__constant__ const unsigned int ptl_material_table_init[PTL_MATERIAL_TABLE_WORDS] = {\n" + init + "};\n"
                                "__shared__ __attribute__((aligned(16))) unsigned int ptl_material_table[PTL_MATERIAL_TABLE_WORDS];  // filled by the kernel entries (ptl_entry.h)\n"
+                               "#elif PTL_DEVICE_BUILD\n__constant__ const unsigned int ptl_material_table[PTL_MATERIAL_TABLE_WORDS] __attribute__((aligned(32))) = {\n" + init + "};\n"
                                "#else\nstatic const unsigned int ptl_material_table[PTL_MATERIAL_TABLE_WORDS] __attribute__((aligned(16))) = {\n" + init + "};\n#endif\n"
                                "PTL_FN bool ptl_material_in_table(int id) {\n"
                                "    const unsigned long long masks[] = {" + masks + "};\n"

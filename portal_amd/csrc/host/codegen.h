@@ -165,7 +165,12 @@ struct KernelOptions {
     bool check_affine = false;
     // Round 6: the Simple materials' literals in a per-workgroup LDS table, one material_simple2 call for all of them (codegen.cpp, materials).
     // Identical frames; PTL_FLAG_NO_MATERIAL_TABLE (bit 26) keeps the reference's chain of one inlined call per material (A/B measurements, tests).
-    bool material_table = true;
+    // MEASURED (profiles/r06/ab_material_table.jsonl): the LDS table is SLOWER than the reference's chain -- headline 0.1925 against 0.1873 ms, C2 0.0378
+    // against 0.0361 -- a workgroup cannot trace before its table is staged (a global load and a barrier at the head of a 3 us workgroup), and one body
+    // with run-time grid flags costs a wave of ONE material (the usual case) more than its own copy with the literals folded.  So: off by default;
+    // 1 = the LDS table (PTL_FLAG_MATERIAL_TABLE_LDS, bit 26), 2 = the same table in constant memory, read with SCALAR loads per distinct material
+    // of the wave (a waterfall loop; PTL_FLAG_MATERIAL_TABLE_SCALAR, bit 27).
+    int material_table = 0;
     // A/B switch (PTL_FLAG_KEEP_TRANSFORM_DODGES): a kernel with affine rays still gets the deferred loop updates and the first-trip snippet copies
     // -- round 4's shape, for measurements; by default it gets neither (codegen.cpp: a transform is then a few additions, cheaper than its dodge)
     bool keep_transform_dodges = false;

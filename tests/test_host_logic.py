@@ -1970,3 +1970,29 @@ def test_one_return_to_affine_rays_per_stage(pa):
     r.use_camera("red")
     r.set_option("use_360_camera", 0)
     assert not r.affine_rays() and r.rejit_count() == 4       # the second break of this stage keeps them off
+
+
+@pytest.mark.parametrize("name, depth", [("basics", 6), ("portal_in_portal", 8), ("mobius_monoportal", 10)])
+def test_material_tables_draw_the_bits_of_the_reference_chain(pa, name, depth):
+    """Round 6 (A/B builds, off by default after measuring): the Simple materials' nine literals from a table -- in LDS, or behind scalar loads -- and one
+    material_simple2 call for all of them, against the reference's chain of one inlined call per material (src/gui/scene.rs:736-760): same function, same
+    argument values, so the host build of the generated source draws the same bits; the table holds every Simple material and the three DEBUG_* ones."""
+    from oracle import host_build as hb
+
+    w, h = 64, 36
+    spec = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
+    frames = []
+    for extra in (0, pa.FLAG_MATERIAL_TABLE_LDS, pa.FLAG_MATERIAL_TABLE_SCALAR):
+        sc = pa.Scene.from_file(pa.scene_path(name))
+        r = pa.SceneRenderer(sc, device=-1, flags=spec | extra | pa.FLAG_QUICK_JIT)
+        r.set_option("render_depth", depth)
+        src = sc.generate_source(spec | extra)
+        assert ("#define PTL_MATERIAL_TABLE " in src) == (extra != 0)
+        copies = src.count("return material_simple2(hit, r, vec3(")
+        if extra:   # no generated per-material copy is left (what remains is the scene author's own Complex materials)
+            assert "ptl_material_in_table" in src and copies == chain_copies - sum(1 for m in sc.materials() if m["kind"] == "Simple") if hasattr(sc, "materials") else copies < chain_copies
+        else:
+            chain_copies = copies
+        frames.append(hb.host_kernel_for(r, sc, w, h, flags=spec | extra).render(w, h)["rgba32f"].copy())
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)) and np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
+    assert len(np.unique(frames[0].reshape(-1, 4), axis=0)) > 50

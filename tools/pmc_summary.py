@@ -33,6 +33,7 @@ if __name__ == "__main__":
                 try:
                     bench = json.loads(line)
                     doc["code_object_sha256"] = bench["config"]["code_object_sha256"]
+                    doc["kernel_source_sha256"] = bench["config"].get("kernel_source_sha256")
                     doc["bench_kernel_ms_under_the_profiler"] = bench.get("kernel_ms")
                     doc["toolchain"] = bench["config"].get("toolchain") or ("hiprtc_version=" + str(bench["config"].get("hiprtc_version")))
                 except Exception:

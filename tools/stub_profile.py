@@ -149,6 +149,19 @@ def _select_form_is_inside_portal(src):
 
 PATCHES["pip_select_is_inside_portal"] = _select_form_is_inside_portal
 
+# ---- round 6: BASELINE's C5, scenes/mobius_monoportal.ron (where do its 12.6 ms go?).  The strip is found by a search: behind a bounding-sphere
+# test, 8 seeds (+ 2 when one hit) x <= 10 Newton iterations x 2 evaluations of `mobius_step` (two sines, two cosines, a nearest-points solve) each.
+PATCHES["mob_no_search"] = [("    if (intersect_mobius_sphere(r)) {", "    if (intersect_mobius_sphere(r) && r.d.x > 2.f) {")]          # the sphere test stays, nothing behind it
+PATCHES["mob_one_seed"] = [("    best = update_best_approx(best, mobius_best_approx(PI, r, max, best));\n", "    return best;\n")]
+PATCHES["mob_two_seeds"] = [("    int count1 = 2;\n", "    return best;\n    int count1 = 2;\n")]
+PATCHES["mob_four_seeds"] = [("    int count2 = 4;\n", "    return best;\n    int count2 = 4;\n")]
+PATCHES["mob_no_refinement_seeds"] = [("    if (best.t < 0.f) {\n        return best;\n    }\n", "    if (best.t > -2.f) {\n        return best;\n    }\n")]
+PATCHES["mob_no_newton"] = [("    int count = 10; \n", "    int count = 0; \n")]
+PATCHES["mob_newton_3"] = [("    int count = 10; \n", "    int count = 3; \n")]
+PATCHES["mob_free_trig"] = [("    return vec3(cos(u), 0, sin(u));", "    return vec3(u, 0, 1.f - u);"),
+                            ("    return ptl_div(vec3(cos(ptl_div(u,2.f))*cos(u), sin(ptl_div(u,2.f)), cos(ptl_div(u,2.f))*sin(u)),2.f); // mobius", "    return ptl_div(vec3(u * u, 0.5f * u, u - u * u),2.f); // mobius")]
+PATCHES["mob_no_derivative_probe"] = [("        float du = ptl_div(-step.x,(mobius_step(u + eps_der, r).x - step.x))*eps_der;", "        float du = -step.x * 0.5f;")]
+
 if __name__ == "__main__":
     only = [a[2:] for a in sys.argv[1:] if a.startswith("--")]
     sys.argv = [a for a in sys.argv if not a.startswith("--")]
@@ -168,7 +181,7 @@ if __name__ == "__main__":
 
     for variant, subs in PATCHES.items():
         src = source
-        if variant.startswith("pip_") and name != "portal_in_portal":
+        if (variant.startswith("pip_") and name != "portal_in_portal") or (variant.startswith("mob_") and name != "mobius_monoportal"):
             continue
         if callable(subs):
             src, subs = subs(src), []
