@@ -934,3 +934,22 @@ def test_patterns_build_compiles_the_scenes_switches_in_and_follows_them(gpu, fl
     for s_ in (sa, sb):
         assert s_.set_uniform("filter_teleported", 0)
     same("another switch")
+
+
+# ---- round 6 -------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name, depth", [("basics", 8), ("monoportal", 20), ("triple_portal", 24), ("portal_in_portal", 24), ("mobius_monoportal", 32)])
+def test_material_tables_change_no_bit_on_the_gpu(gpu, name, depth):
+    """The two table-driven forms of the Simple materials (flag bits 26 / 27: LDS table, scalar-load waterfall; measured, left off by default) draw the
+    frame of the reference's chain of inlined calls, bit for bit, on the five BASELINE scenes -- everything baked and un-specialised."""
+    pa = gpu
+    w, h = 320, 180
+    for base in (pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL, 0):
+        frames = []
+        for extra in (0, pa.FLAG_MATERIAL_TABLE_LDS, pa.FLAG_MATERIAL_TABLE_SCALAR):
+            r = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path(name)), device=0, flags=base | extra)
+            r.set_option("render_depth", depth)
+            out = r.draw(w, h, rgba32f=True)
+            frames.append((out["rgba32f"].copy(), out["rgba8"].copy()))
+        for f32, u8 in frames[1:]:
+            assert np.array_equal(_bits(f32), _bits(frames[0][0])) and np.array_equal(u8, frames[0][1]), (name, base)
+        assert len(np.unique(frames[0][1].reshape(-1, 4), axis=0)) > 50
