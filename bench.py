@@ -194,6 +194,8 @@ def parse_args():
                    "ptl_render_kernel are then exactly the timed ones)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     p.add_argument("--save-png", default="")
+    p.add_argument("--lanes", type=int, default=2, help="frames in flight in the timed region at ONE GPU: consecutive frames go to alternating internal streams of the "
+                   "renderer (options concurrent_draws K + lane_fence 0), a target per lane, joined at the end; 1 = one stream, one frame at a time (rounds 1-5)")
     args = p.parse_args()
     for k, v in WORKLOADS.get(args.workload, {}).items():
         setattr(args, k, v)
@@ -473,7 +475,8 @@ def compact_line(out):
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype") if k in out}
     line["data"] = "synthetic: the reference's shipped scene file, scene camera, no stage"
     version = str(cfg.get("toolchain", ""))
-    line["config"] = {**_pick(cfg, ("workload", "trips_per_primary_ray", "build", "code_object_sha256", "kernel_source_sha256", "affine_rays", "candidate_frames_identical", "transport")),
+    line["config"] = {**_pick(cfg, ("workload", "trips_per_primary_ray", "build", "code_object_sha256", "kernel_source_sha256", "affine_rays", "candidate_frames_identical", "transport", "frames_in_flight",
+                                   "frames_identical_to_one_in_flight", "ms_per_step_one_frame_in_flight")),
                       "parallelism": str(cfg.get("parallelism", ""))[:60], "jit_specialisation": cfg.get("jit_specialisation"),
                       "hiprtc_version": version.split("hiprtc_version=")[-1] if "hiprtc_version=" in version else None}
     line.update(_pick(out, ("kernel_ms", "kernel_ms_per_rank", "transport_ms", "segments_per_frame", "segment_mray_s", "jit_seconds")))
@@ -514,7 +517,8 @@ def compact_line(out):
             continue
         r = w.get("roofline") or {}
         row = {"id": w.get("name"), "ms_per_step": w.get("ms_per_step"), "kernel_ms": w.get("kernel_ms"), "mray_s": w.get("value"), "trips": w.get("trips_per_primary_ray"),
-               "frac": r.get("frac"), "cpu_mray_s": (w.get("cpu_baseline") or {}).get("value"), "bit_exact": (w.get("oracle_check") or {}).get("bit_exact")}
+               "frac": r.get("frac"), "cpu_mray_s": (w.get("cpu_baseline") or {}).get("value"), "bit_exact": (w.get("oracle_check") or {}).get("bit_exact"),
+               "in_flight": w.get("frames_in_flight")}
         if "kernel_ms_per_rank" in w:
             row["kernel_ms_per_rank"] = w["kernel_ms_per_rank"]
             if row["kernel_ms"] is None:
@@ -815,6 +819,33 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), last
 
+    def timed_in_flight(r, fr, targets, warm, n):
+        """n frames of an unchanged state with len(targets) frames in flight: the renderer's lanes (concurrent_draws K, lane_fence 0: one packet per
+        draw, no cross-stream wait), a target per lane, ONE join behind all of them; wall time between two synchronisations."""
+        def queue(m):
+            for k in range(m):
+                r.draw_device(fr, out_rgba8=targets[k % len(targets)].data_ptr(), stream=stream.cuda_stream)
+            r.join(stream.cuda_stream)
+
+        r.set_option("concurrent_draws", len(targets))
+        r.set_option("lane_fence", 0)
+        torch.cuda.synchronize(dev)  # (no fence: what the caller's stream holds -- the targets' initialisation -- has to be over before the first lane draws)
+        queue(len(targets))          # the first draw on a lane creates its stream's queue and loads its kernel instance (milliseconds of host work, idle GPU)
+        torch.cuda.synchronize(dev)
+        spin_until = time.perf_counter() + 0.15  # ... so, like before the one-stream region: settled clocks first (untimed), then the W warm-up steps
+        while time.perf_counter() < spin_until:
+            queue(16)
+            torch.cuda.synchronize(dev)
+        queue(warm)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        queue(n)
+        torch.cuda.synchronize(dev)
+        seconds = time.perf_counter() - t0
+        r.set_option("concurrent_draws", 1)  # (drops the lanes' kernel instances; what follows is one stream again)
+        r.set_option("lane_fence", 1)
+        return seconds
+
     # untimed: keep the GPU busy for ~0.25 s so that the W warm-up steps and the timed region run at settled clocks
     # (a 20-step timed region is ~15 ms of work; without this it rides the power-management ramp)
     spin_until = time.perf_counter() + 0.25
@@ -869,7 +900,34 @@ def main():
     every = 8 if args.steps >= 64 else max(1, args.steps)
     events = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), min(every, args.steps - k)) for k in range(0, args.steps, every)}
     events["group"] = every
-    if world == 1:
+    in_flight = None
+    if world == 1 and args.lanes > 1:
+        # Round 6: TWO FRAMES IN FLIGHT.  A launch of this kernel ramps up for ~10 us and drains for as long (the last workgroups of a
+        # frame leave CUs idle that the next frame's first workgroups could use); a renderer that queues frames and looks at them later need not
+        # pay that per frame.  The renderer's own option does it (include/portal_amd.h "lane_fence"): consecutive draws go round-robin to K
+        # internal streams, each draw is ONE packet, each lane writes a target of its own, the caller's stream joins behind all of them at the
+        # end.  Same kernel, same bytes (compared below); the timed region is K frames queued, one join, one synchronisation.
+        lanes = args.lanes
+        targets = [shard] + [torch.empty_like(shard) for _ in range(lanes - 1)]
+        for t in targets:
+            t.zero_()
+        elapsed = timed_in_flight(renderer, frame, targets, max(args.warmup, lanes), args.steps)
+        # ... and the SAME K steps one at a time on one stream, right behind it, between two synchronisations and between one pair of HIP events:
+        # `kernel_ms` (the launch duration rocprofv3's per-dispatch average agrees with: what `roofline` divides by) and what a step costs with
+        # one frame in flight (`ms_per_step_one_frame_in_flight`, rounds 1-5's figure)
+        n_k = max(args.steps, 64)
+        ev_k = {0: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), n_k), "group": n_k}
+        one_elapsed, last = timed_steps(transport, n_k, ev_k)
+        kernel_ms = float(ev_k[0][0].elapsed_time(ev_k[0][1]) / n_k)
+        kernel_ms_from = (f"HIP events around ONE group of {n_k} consecutive launches on one stream, right behind the timed region (same kernel, same frame): elapsed / launches; "
+                          f"the timed region itself has {lanes} frames in flight on {lanes} streams, where a launch's own duration is not the time a frame costs")
+        same_bytes = bool(all(torch.equal(t[: last.shape[0]], last) for t in targets))
+        in_flight = {"frames_in_flight": lanes, "frames_identical_to_one_in_flight": same_bytes,
+                     "ms_per_step_one_frame_in_flight": round(one_elapsed / n_k * 1e3, 4), "steps_one_frame_in_flight": n_k}
+        if not same_bytes:
+            raise SystemExit("bench: a frame drawn with two frames in flight differs from the frame drawn alone")
+        del targets
+    elif world == 1:
         elapsed, last = timed_steps(transport, args.steps, events)
         groups = [v for k, v in events.items() if k != "group"]
         kernel_ms = float(sum(a.elapsed_time(b) for a, b, _ in groups) / sum(c for _, _, c in groups))
@@ -1011,6 +1069,10 @@ def main():
                 steps = int(max(10, min(200, 40.0 / max(probe_ms, 0.02))))  # ~40 ms of timed region
                 ev_every = 8 if steps >= 64 else steps  # (like the headline's: one event pair around every eight consecutive launches; a short region is one group)
                 ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), min(ev_every, steps - k)) for k in range(0, steps, ev_every)}
+                flight_k = None
+                if args.lanes > 1:  # like the headline: the timed frames with `lanes` in flight, then the same frames one at a time between one event pair
+                    bufs = [buf] + [torch.empty_like(buf) for _ in range(args.lanes - 1)]
+                    ms_flight = timed_in_flight(rr, fr, bufs, 6, steps) / steps * 1e3
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
                 for k in range(steps):
@@ -1023,6 +1085,11 @@ def main():
                 torch.cuda.synchronize(dev)
                 ms_step = (time.perf_counter() - t0) / steps * 1e3
                 kms = float(sum(x.elapsed_time(y) for x, y, _ in ev.values()) / sum(c for _, _, c in ev.values()))
+                if args.lanes > 1:
+                    flight_k = {"frames_in_flight": args.lanes, "ms_per_step_one_frame_in_flight": round(ms_step, 4),
+                                "frames_identical_to_one_in_flight": bool(all(torch.equal(b, buf) for b in bufs))}
+                    ms_step = ms_flight
+                    del bufs
                 cnt = pa.SceneRenderer(sc, device=local_rank, flags=pa.FLAG_COUNT_SEGMENTS | spec_flags, **sc_kw)
                 configure(cnt, a)
                 seg = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -1035,7 +1102,7 @@ def main():
                                                   + (f" camera look_at,alpha,beta,r={a.camera}" if a.camera else ""),
                        "steps": steps, "ms_per_step": round(ms_step, 4), "kernel_ms": round(kms, 4), "value": round(Wk * Hk * a.aa / (ms_step * 1e-3) / 1e6, 3), "unit": "Mray/s",
                        "build": f"w{waves}", "code_object_sha256": sha, "segments_per_frame": trips, "trips_per_primary_ray": round(trips / (Wk * Hk * a.aa), 4),
-                       "segment_mray_s": round(trips / (ms_step * 1e-3) / 1e6, 3)}
+                       "segment_mray_s": round(trips / (ms_step * 1e-3) / 1e6, 3), **(flight_k or {"frames_in_flight": 1})}
                 fl_k, (pmc_k, why_k) = flops_per_segment(a, rr.affine_rays()), stored_pmc(a, f"w{waves}", sha, source_sha256(rr))
                 if fl_k:
                     rec["roofline"] = valu_roofline(fl_k, pmc_k, trips, 1, kms, pmc_k["traffic"] if pmc_k else None, args.specialize)
@@ -1219,6 +1286,7 @@ def main():
                     "p2p-stores": " + kernel stores straight into rank 0's frame over xGMI (HIP IPC mapping), fenced by a 1-element RCCL all-reduce",
                     "p2p-copy": " + packed shard per rank and ONE strided peer copy each into rank 0's frame (HIP IPC mapping), fenced by a 1-element RCCL all-reduce"}[transport.name]),
                 "jit_specialisation": ["none", "int/bool scene uniforms baked", "all scene uniforms baked (camera dynamic)"][args.specialize],
+                **(in_flight if in_flight is not None else {"frames_in_flight": 1}),
                 "build": best, "waves_per_simd_hint": best_waves,
                 "tuning_ms": tuning,
                 # every candidate build drew the same bytes as the first one (compared on the device before timing); a build that did not is named here and was not eligible

@@ -370,7 +370,13 @@ int ptl_renderer_set_option(ptl_renderer* r, const char* name, double value);
  * consumed (averaged, downloaded).  Timed draws, counting draws, draws to host memory and the teleport query join by themselves.
  * Identical frames (tests/test_gpu_round2.py); measured on one MI355X it buys nothing (profiles/r04/concurrent_draws.jsonl: 1080p
  * 0.0519 ms per sub-frame with one instance, 0.0522 with two, 0.0559 with four) -- the cross-stream waits cost what the overlap saves --
- * so nothing switches it on by default. */
+ * so nothing switches it on by default.
+ * "lane_fence" 0 (round 6; default 1): a draw on a lane is the kernel's packet and nothing else -- the launch does NOT wait for what the
+ * caller's stream holds, and no event is recorded behind it (a lane's completion event is recorded when ptl_renderer_join or a host-side
+ * wait asks for it).  The caller orders the reuse of a target itself: ptl_renderer_join before a target is read or drawn into again.
+ * With two lanes and a target per lane this is two frames in flight -- frame n + 1's ramp under frame n's tail -- for a caller that queues
+ * frames and looks at them later (`bench.py`'s timed region at one GPU; profiles/r06/two_streams.jsonl: headline 4K 0.187 -> 0.177 ms per
+ * frame, monoportal 1080p 0.035 -> 0.027, identical bytes). */
 int ptl_renderer_join(ptl_renderer* r, void* stream);
 /* One launch for several draws of a renderer created with flag bit 22 (PTL_FLAG_SLICES): ptl_renderer_stage_slice does everything a draw
  * does short of launching -- camera, rebuild checks, uniform evaluation for `frame` -- and keeps the resulting uniform block as slice `index`;

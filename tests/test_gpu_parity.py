@@ -870,6 +870,9 @@ def test_bench_multi_rank_rehearsal_assembles_the_same_frame(gpu, tmp_path, tran
     single = json.loads(one.stdout.strip().splitlines()[-1])
     assert len(one.stdout.strip().splitlines()[-1]) <= 4096
     assert len(single["kernel_ms_per_rank"]) == 1 and "frame_check" not in single and single["roofline"]["bound"] in ("valu", "hbm")
+    # round 6: at one GPU the timed region has two frames in flight (the renderer's lanes), compared with the frame drawn alone inside the run
+    assert single["config"]["frames_in_flight"] == 2 and single["config"]["frames_identical_to_one_in_flight"] is True
+    assert single["config"]["ms_per_step_one_frame_in_flight"] > 0
 
 
 def test_bench_multi_rank_rehearsal_of_the_headline_line(gpu, tmp_path):

@@ -604,7 +604,9 @@ def test_concurrent_draws_give_the_frames_of_draws_one_by_one(gpu, flags_name):
     `_aa_start` window -- go round-robin to K instances of the kernel on K streams (each instance has a uniform block of its own) and overlap
     on the GPU; the frames must be the ones a renderer draws one by one, byte for byte, also when a target buffer is reused right away
     (the next round's draw has to wait for the consumer of the previous one), after a rebuild in the middle, and when a timed draw, a
-    draw to host memory or a teleport query comes in between (they join by themselves)."""
+    draw to host memory or a teleport query comes in between (they join by themselves).
+    Round 6, `lane_fence` 0: a draw on a lane is the kernel's packet alone (nothing waits for the caller's stream, no event behind it); the
+    caller orders the reuse of its targets itself -- here a synchronisation behind the consumer -- and gets the same bytes."""
     import torch
 
     pa = gpu
@@ -615,12 +617,13 @@ def test_concurrent_draws_give_the_frames_of_draws_one_by_one(gpu, flags_name):
     def values(k):  # what moves between sub-frames
         return 0.05 * k, ((0.02 * k, 0.1, -0.3), 0.9 + 0.03 * k, 1.2, 3.1)
 
-    def run(concurrent):
+    def run(concurrent, fence=1):
         scene = pa.Scene.from_file(pa.scene_path("monoportal"))
         r = pa.SceneRenderer(scene, device=0, flags=flags)
         r.set_option("render_depth", 20)
         r.set_option("aa_count", 2)
         r.set_option("concurrent_draws", concurrent)
+        r.set_option("lane_fence", fence)
         targets = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
         total = torch.zeros((h, w, 4), dtype=torch.int32, device=dev)
         sums = []
@@ -637,6 +640,8 @@ def test_concurrent_draws_give_the_frames_of_draws_one_by_one(gpu, flags_name):
             # the consumer, on the default (legacy) stream like the CLI's averaging kernel: torch's current stream IS that stream here
             total = total + targets.to(torch.int32).sum(dim=0)
             sums.append(total.clone())
+            if not fence:
+                torch.cuda.synchronize(dev)  # (without the fence the next round's launches would not wait for this consumer)
             if rnd == 0:  # in between: a timed draw, a draw to host memory, a teleport query -- each joins by itself
                 ms = r.draw_device(pa.Frame(w, h, 0, 1), out_rgba8=targets[0].data_ptr(), timed=True)
                 assert ms > 0
@@ -650,9 +655,10 @@ def test_concurrent_draws_give_the_frames_of_draws_one_by_one(gpu, flags_name):
 
     one_by_one, last1, _ = run(1)
     together, last4, rejits = run(4)
-    for a, b in zip(one_by_one, together):
-        assert np.array_equal(a, b)
-    assert np.array_equal(last1, last4)
+    unfenced, last2, rejits2 = run(2, fence=0)
+    for a, b, c in zip(one_by_one, together, unfenced):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert np.array_equal(last1, last4) and np.array_equal(last1, last2) and rejits2 == rejits
     assert len(np.unique(last1.reshape(-1, 4), axis=0)) > 100 and not np.array_equal(last1[0], last1[1])
     if flags_name == "static":
         assert rejits >= 1

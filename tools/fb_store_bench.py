@@ -39,6 +39,28 @@ def measure(k, frame, buf, stream, torch, n_back_to_back=20):
     return float(np.median(single)), float(np.median(runs))
 
 
+def measure_in_flight(k, frame, bufs, streams, torch, n=400):
+    """ms per launch of n launches queued round-robin on len(streams) non-blocking streams (a target per stream), wall time between two
+    synchronisations -- round 6: what the store pattern sustains with two frames in flight (the renderer's `lane_fence` 0 lanes do this)."""
+    import time
+
+    def launch(j):
+        rc = pa.lib().ptl_kernel_render(k._h, C.byref(frame), C.c_void_p(bufs[j].data_ptr()), C.c_void_p(bufs[j].data_ptr()), None, C.c_void_p(streams[j]), None)
+        assert rc == 0, pa.lib().ptl_last_error()
+
+    best = 1e9
+    for _ in range(4):
+        for j in range(len(streams)):
+            launch(j)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            launch(i % len(streams))
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / n * 1e3)
+    return best
+
+
 if __name__ == "__main__":
     import torch
 
@@ -46,6 +68,13 @@ if __name__ == "__main__":
     dev = torch.device("cuda", 0)
     buf = torch.empty(W * H * 16, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
+    bufs = [buf, torch.empty_like(buf)]
+    lanes = []
+    pa.lib().ptl_stream_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    for _ in range(2):
+        h = C.c_void_p()
+        assert pa.lib().ptl_stream_create(0, C.byref(h)) == 0
+        lanes.append(int(h.value))
     for variant, grids in ((0, [None]), (1, [None]), (2, [None]), (3, [None]), (4, [None]), (5, [256, 512, 1024, 2048, 4096]), (6, [256, 512, 1024, 2048, 4096]), (7, [None])):
         k = pa.Kernel(SRC, UNIFORMS, 16, device=0, defines=[f"PTL_FB_VARIANT={variant}"])
         k.set_uniform("seed_u", pa.PTL_I32, 12345)
@@ -56,6 +85,10 @@ if __name__ == "__main__":
             frame = pa.Frame(W, H, 0, 1) if wgs is None else pa.Frame(32 * 32, 8 * (wgs // 32), 0, 1)
             ms, ms_b2b = measure(k, frame, buf, stream, torch)
             nbytes = 0 if variant == 7 else W * H * (16 if variant == 1 else 4)
+            ms_1 = measure_in_flight(k, frame, bufs[:1], lanes[:1], torch)
+            ms_2 = measure_in_flight(k, frame, bufs, lanes, torch)
             print(json.dumps({"variant": NAMES[variant], **({"workgroups": wgs} if wgs else {}), "frame": f"{W}x{H}", "bytes": nbytes, "ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1),
                               "frac_of_8TB/s": round(nbytes / ms / 1e6 / 8000, 4), "ms_back_to_back": round(ms_b2b, 4),
-                              "frac_of_8TB/s_back_to_back": round(nbytes / ms_b2b / 1e6 / 8000, 4)}), flush=True)
+                              "frac_of_8TB/s_back_to_back": round(nbytes / ms_b2b / 1e6 / 8000, 4),
+                              "ms_queued_one_stream": round(ms_1, 4), "frac_of_8TB/s_queued_one_stream": round(nbytes / ms_1 / 1e6 / 8000, 4),
+                              "ms_two_in_flight": round(ms_2, 4), "frac_of_8TB/s_two_in_flight": round(nbytes / ms_2 / 1e6 / 8000, 4)}), flush=True)
