@@ -1048,8 +1048,10 @@ for (int k = 0; k < n_u; k++) {
     # the shipped scenes: the headline's snippet has two such chains (scenes/portal_in_portal.ron:1146-1147), the others none
     counts = {name: pa.Scene.from_file(pa.scene_path(name)).generate_source(pa.FLAG_NO_FIRST_TRIP).count("int ptl_pend_") for name in SCENES}
     assert counts == {"basics": 0, "monoportal": 0, "triple_portal": 0, "portal_in_portal": 2, "mobius_monoportal": 0}
-    # (by default the headline's snippet is compiled twice -- the copy for the first trip defers the same two chains)
-    assert pa.Scene.from_file(pa.scene_path("portal_in_portal")).generate_source(0).count("int ptl_pend_") == 4
+    # (with the first-trip forms -- opt-in since round 6, FLAG_KEEP_TRANSFORM_DODGES -- the headline's snippet is compiled twice: the copy for the first
+    # trip defers the same two chains)
+    assert pa.Scene.from_file(pa.scene_path("portal_in_portal")).generate_source(0).count("int ptl_pend_") == 2
+    assert pa.Scene.from_file(pa.scene_path("portal_in_portal")).generate_source(pa.FLAG_KEEP_TRANSFORM_DODGES).count("int ptl_pend_") == 4
     assert "ptl_pend_" not in pa.Scene.from_file(pa.scene_path("portal_in_portal")).generate_source(pa.FLAG_NO_DEFERRED_UPDATES)
 
 
@@ -1236,9 +1238,11 @@ def test_first_trip_copy_declares_the_rays_a_plain_uniform_expression_reads(pa):
     assert "intersection_materials: ([])," in text
     text = text.replace("intersection_materials: ([]),", 'intersection_materials: ([\n        (\n            name: "ball",\n            data: ((("' + _SPHERE_SNIPPET + '"))),\n        ),\n    ]),')
     frames = {}
-    for label, flags in (("first", 0), ("general", pa.FLAG_NO_FIRST_TRIP), ("first_baked", pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)):
+    keep = pa.FLAG_KEEP_TRANSFORM_DODGES  # (round 6: the first-trip forms are opt-in; the default is the general copy alone)
+    for label, flags in (("first", keep), ("general", 0), ("general_by_flag", keep | pa.FLAG_NO_FIRST_TRIP), ("first_baked", keep | pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL)):
         scene = pa.Scene.from_text(text)
         src = scene.generate_source(flags)
+        assert ("intersect_material_0_first(Ray r, float ptl_far) {" in src) == label.startswith("first")
         if label == "first":
             assert "intersect_material_0_first(Ray r, float ptl_far) {" in src
             derive = src[src.index("PTL_FN void derive(ptl_uniform_block* out)"):src.index("// Material id -> what happens to the path.")]
@@ -1248,6 +1252,7 @@ def test_first_trip_copy_declares_the_rays_a_plain_uniform_expression_reads(pa):
         r.set_option("render_depth", 6)
         frames[label] = hb.host_kernel_for(r, scene, 48, 27, flags=flags).render(48, 27)["rgba32f"].copy()
     assert np.array_equal(frames["first"].view(np.uint32), frames["general"].view(np.uint32))
+    assert np.array_equal(frames["general_by_flag"].view(np.uint32), frames["general"].view(np.uint32))
     assert np.array_equal(frames["first_baked"].view(np.uint32), frames["general"].view(np.uint32))
     assert len(np.unique(frames["first"].reshape(-1, 4), axis=0)) > 30
 
@@ -1309,8 +1314,9 @@ def test_first_trip_plane_tests_are_selfconsistent_and_change_no_bit_on_the_host
     import re
     from oracle import host_build as hb
 
+    keep = pa.FLAG_KEEP_TRANSFORM_DODGES  # (round 6: the first-trip forms are opt-in; the default is the one general scene_intersect)
     scene = pa.Scene.from_file(pa.scene_path("triple_portal"))
-    src = scene.generate_source(0)
+    src = scene.generate_source(keep)
     block = src[src.index("struct ptl_uniform_block {"):src.index("};", src.index("struct ptl_uniform_block {"))]
     members = set(re.findall(r"vec4 (ptl_dvo_\d+_[01]);", block))
     assert len(members) == 27
@@ -1320,11 +1326,11 @@ def test_first_trip_plane_tests_are_selfconsistent_and_change_no_bit_on_the_host
     general = src[src.index("PTL_FN SceneIntersection scene_intersect(const Ray& r"):src.index("PTL_FN SceneIntersection scene_intersect_first(")]
     assert set(re.findall(r"PTL_U\.(ptl_dvo_\d+_[01])", first)) == members and "PTL_U.ptl_dvo_" not in general
     assert first.count("ptl_plane_cull_o(") == 27 and general.count("ptl_plane_cull(") == 27
-    for flags in (pa.FLAG_NO_DERIVED_UNIFORMS, pa.FLAG_NO_FIRST_TRIP_PLANES, pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL):
+    for flags in (0, keep | pa.FLAG_NO_DERIVED_UNIFORMS, keep | pa.FLAG_NO_FIRST_TRIP_PLANES, keep | pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL):
         off = scene.generate_source(flags)
         assert "PTL_U.ptl_dvo_" not in off and "#define PTL_FIRST_TRIP_PLANES" not in off
     frames = {}
-    for label, flags in (("first", 0), ("general", pa.FLAG_NO_FIRST_TRIP_PLANES), ("first_baked", pa.FLAG_SPECIALIZE_INTS)):
+    for label, flags in (("first", keep), ("general", 0), ("first_baked", keep | pa.FLAG_SPECIALIZE_INTS)):
         sc = pa.Scene.from_file(pa.scene_path("triple_portal"))
         r = pa.SceneRenderer(sc, device=-1, flags=flags)
         r.set_option("render_depth", 12)
@@ -1373,11 +1379,13 @@ def test_a_matrix_with_infinities_keeps_every_full_chain(pa):
 def test_generated_defines_go_with_the_generated_source(pa):
     scene = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
     spec = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
-    # (PTL_FIRST_TRIP: the kernel has first-trip copies of its snippets -- not with affine rays, where a transform is cheaper than its dodge)
-    for flags, want in ((0, {"PTL_FIRST_TRIP"}), (spec, {"PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}), (spec | pa.FLAG_NO_AFFINE_RAYS, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS"}),
-                        (spec | pa.FLAG_KEEP_TRANSFORM_DODGES, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}),
-                        (pa.FLAG_SPECIALIZE_PATTERNS, {"PTL_AFFINE_RAYS"}), (spec | pa.FLAG_EXACT_CR, {"PTL_FIRST_TRIP", "PTL_CONTRACT_V1"}),
-                        (spec | pa.FLAG_FAST_MATH, {"PTL_AFFINE_RAYS", "PTL_FAST_MATH"}), (pa.FLAG_COUNT_SEGMENTS | pa.FLAG_ANAGLYPH, {"PTL_FIRST_TRIP", "PTL_COUNT_SEGMENTS", "PTL_ANAGLYPH"})):
+    # (PTL_FIRST_TRIP: the kernel has first-trip copies of its snippets -- opt-in since round 6 (FLAG_KEEP_TRANSFORM_DODGES): measured a loss on today's kernels)
+    keep = pa.FLAG_KEEP_TRANSFORM_DODGES
+    for flags, want in ((0, set()), (keep, {"PTL_FIRST_TRIP"}), (spec, {"PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}), (spec | pa.FLAG_NO_AFFINE_RAYS, {"PTL_DROP_ZERO_TERMS"}),
+                        (spec | pa.FLAG_NO_AFFINE_RAYS | keep, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS"}),
+                        (spec | keep, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}),
+                        (pa.FLAG_SPECIALIZE_PATTERNS, {"PTL_AFFINE_RAYS"}), (spec | pa.FLAG_EXACT_CR, {"PTL_CONTRACT_V1"}), (spec | pa.FLAG_EXACT_CR | keep, {"PTL_FIRST_TRIP", "PTL_CONTRACT_V1"}),
+                        (spec | pa.FLAG_FAST_MATH, {"PTL_AFFINE_RAYS", "PTL_FAST_MATH"}), (pa.FLAG_COUNT_SEGMENTS | pa.FLAG_ANAGLYPH, {"PTL_COUNT_SEGMENTS", "PTL_ANAGLYPH"})):
         scene.generate_source(flags)
         # (PTL_JIT_MODULE_INLINER: this scene's intersection-material snippet loops, and with the Ints baked the loop is force-unrolled -- the
         # JIT picks LLVM's module inliner for those builds, kernel.cpp)
@@ -1509,8 +1517,10 @@ def test_distance_bound_is_added_only_to_snippets_whose_shape_allows_it(pa):
     # scene level: the headline scene's snippet qualifies (both copies: general and first-trip); a scene that names subspace portals does not
     # (opt-in, FLAG_BOUNDED_SNIPPETS: on the headline scene it measures no gain, profiles/r04/ab_bounded_snippets.jsonl)
     pip = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
-    src = pip.generate_source(pa.FLAG_BOUNDED_SNIPPETS)
+    src = pip.generate_source(pa.FLAG_BOUNDED_SNIPPETS | pa.FLAG_KEEP_TRANSFORM_DODGES)
     assert src.count("&& !(hit_a.t > ptl_far)") == 2 and src.count("&& !(hit_b.t > ptl_far)") == 2 and "PTL_BOUNDED_SNIPPETS" in pip.generated_defines()
+    src = pip.generate_source(pa.FLAG_BOUNDED_SNIPPETS)  # (round 6: one copy of the snippet by default)
+    assert src.count("&& !(hit_a.t > ptl_far)") == 1 and src.count("&& !(hit_b.t > ptl_far)") == 1 and "PTL_BOUNDED_SNIPPETS" in pip.generated_defines()
     src = pip.generate_source(0)
     assert "> ptl_far)" not in src and "PTL_BOUNDED_SNIPPETS" not in pip.generated_defines()
     ultra = pa.Scene.from_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "corpus", "scenes", "portal_in_portal_plus_ultra.ron"))
@@ -1764,12 +1774,14 @@ def test_a_module_inliner_build_that_cannot_be_capped_falls_back_to_the_bottom_u
     monkeypatch.setenv("PTL_JIT_OPT", "-O3")
     monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path / "a"))
     monkeypatch.setenv("PTL_NO_OCCUPANCY_RETRY", "1")
-    first = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_SPECIALIZE_INTS, asset_root=os.path.join(os.path.dirname(__file__), "corpus")).code_object()
+    # (FLAG_KEEP_TRANSFORM_DODGES: the build this rule was found on has the first-trip copy of the plane tests, opt-in since round 6)
+    flags = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_KEEP_TRANSFORM_DODGES | pa.FLAG_NO_FIRST_TRIP | pa.FLAG_NO_DEFERRED_UPDATES
+    first = pa.SceneRenderer(scene, device=-1, flags=flags, asset_root=os.path.join(os.path.dirname(__file__), "corpus")).code_object()
     if not 128 < _note_max(first, b".vgpr_count") <= 168:
         pytest.skip("this toolchain builds the case outside the band the retry looks at")
     monkeypatch.delenv("PTL_NO_OCCUPANCY_RETRY")
     monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path / "b"))
-    kept = pa.SceneRenderer(scene, device=-1, flags=pa.FLAG_SPECIALIZE_INTS, asset_root=os.path.join(os.path.dirname(__file__), "corpus")).code_object()
+    kept = pa.SceneRenderer(scene, device=-1, flags=flags, asset_root=os.path.join(os.path.dirname(__file__), "corpus")).code_object()
     assert _note_max(kept, b".vgpr_count") <= 128 and _note_max(kept, b".vgpr_spill_count") == 0 and _note_max(kept, b".private_segment_fixed_size") == 0
 
 
