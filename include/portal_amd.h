@@ -260,17 +260,18 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * (`b0_mat * (a_mat_inv * normal_b)`, `d_mat * c_mat_inv`, normalize() of such a normal ...), loop-carried chains of them
  * included, is computed by the prologue kernel of bit5 into members behind the derived uniforms, and the snippet reads it
  * from there -- the same expression text compiled in the same module, identical frames (host/glsl_hoist.h).  Off with bit5.
- * bit13 = NO first-trip variants (meaningful with bit24): with the first-trip forms every intersection-material snippet is compiled twice, and
+ * bit13 = NO first-trip variants: with the first-trip forms (below: every specialised build; the un-specialised kernel with bit24) every intersection-material snippet is compiled twice, and
  * the copy that runs while a ray still starts at the camera (the first trip of the bounce loop: nine trips in ten) takes the ORIGIN half of its
  * `transform(uniform matrix, ray)` chains from the prologue kernel -- the origin of every primary ray is the same uniform value --
  * while the direction half stays per ray; same operations on the same values, identical frames.  Off with bit5 / bit12.
- * bit16 = NO first-trip form of the generated plane tests (meaningful with bit24): with the first-trip forms, where the scene's matrices are
+ * bit16 = NO first-trip form of the generated plane tests: with the first-trip forms, where the scene's matrices are
  * run-time uniforms, a second copy of scene_intersect serves the trip on which every ray of a wave still starts at the camera and takes
  * `plane_inv * r.o` of every Flat object from the prologue kernel (ptl_dvo_<object>_<side>) -- the same product of the same values, identical frames.
- * Round 6: BOTH first-trip forms are opt-in (bit24).  Rounds 3-5 built them by default; on today's kernels they lose -- un-specialised headline
- * 0.697 -> 0.664 ms without them (-3 ... -9 % over five views), triple_portal 0.445 -> 0.434, mobius 1.108 -> 1.046, monoportal equal
- * (profiles/r06/ab_unspec_code_size*.jsonl) -- and the un-specialised headline kernel is 12 535 instead of 17 090 instructions and compiles in a
- * quarter of the time.
+ * Round 6: in the UN-SPECIALISED kernel (none of bit0 / bit2 / bit3 / bit20) both first-trip forms are opt-in (bit24).  Rounds 3-5 built them in
+ * every kernel; the un-specialised one loses with either -- headline 0.697 -> 0.664 ms without them (-3 ... -9 % over five views), triple_portal
+ * 0.445 -> 0.434, mobius 1.108 -> 1.046, monoportal equal (profiles/r06/ab_unspec_code_size*.jsonl) -- and is 12 535 instead of 17 090 instructions
+ * and compiles in a quarter of the time.  The specialised builds keep them as before (the plane form still gains 1 ... 4 % in the patterns and
+ * Int-baked builds, profiles/r06/ab_first_trip_planes.jsonl; the snippet copies go where rays are affine, bit24).
  * bit17 = ASYNC REJIT (read by ptl_renderer_create only; the "specialize_static" option may be switched on such a renderer: the pair
  * of kernels is rebuilt synchronously, like at creation): see ptl_renderer_rejit_pending.
  * bit18 = QUICK JIT: compile at -O1 instead of the shipped -O3 without SLP: half the hiprtc time for a 5-20 % slower kernel, identical
@@ -313,8 +314,8 @@ int ptl_scene_texture(ptl_scene* s, int index, char* name, size_t name_cap, char
  * bit25 = CHECK AFFINE (round 6, diagnostics): never affine rays; the kernel is generated with PTL_CHECK_AFFINE and its `segments` counter (bit1 is
  * implied) counts, instead of bounce-loop trips, the ray halves that reach a matrix-times-ray product or the bounce loop with a w that is
  * not 1 (origin) / 0 (direction) -- what a kernel with affine rays would have assumed wrongly.  Same frames as bit23.  See ptl_renderer_check_affine.
- * bit24 = KEEP TRANSFORM DODGES (A/B): round 4's shape of a kernel.  (a) Every build gets the first-trip forms of bit13 / bit16 (opt-in since round 6,
- * see there).  (b) A kernel with affine rays (bit23 clear and everything affine) is by default generated WITHOUT the deferred loop updates (bit7) --
+ * bit24 = KEEP TRANSFORM DODGES (A/B): round 4's shape of a kernel.  (a) The un-specialised kernel gets the first-trip forms of bit13 / bit16 (opt-in there
+ * since round 6, see there), a kernel with affine rays its first-trip snippet copies.  (b) A kernel with affine rays (bit23 clear and everything affine) is by default generated WITHOUT the deferred loop updates (bit7) --
  * they dodge `transform(uniform matrix, ray)`, which is a handful of additions there and cheaper than the bookkeeping around it (headline baked
  * 0.2305 -> 0.2046 ms, Int-baked 0.272 -> 0.239, patterns 0.274 -> 0.239; identical frames); this bit keeps them.  Kernels without affine rays (the
  * un-specialised one above all: 0.70 against 0.89 ms) keep the deferral anyway,

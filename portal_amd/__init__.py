@@ -53,13 +53,13 @@ FLAG_SPECIALIZE_ALL = 4
 FLAG_SPECIALIZE_STATIC = 8  # bake what stays constant while a clip plays (checked before every draw, rebuilt if it moved)
 FLAG_ANAGLYPH = 16  # compile the anaglyph stereo mode in (the reference's `disable_anaglyph = false`)
 FLAG_NO_DERIVED_UNIFORMS = 32  # keep the per-call plane tests (default: ray-independent halves evaluated by the prologue kernel)
-FLAG_NO_FIRST_TRIP = 8192  # (with FLAG_KEEP_TRANSFORM_DODGES) no first-trip copies of the intersection-material snippets; round 6: no build has them by default
+FLAG_NO_FIRST_TRIP = 8192  # no first-trip copies of the intersection-material snippets (round 6: the un-specialised kernel has none unless FLAG_KEEP_TRANSFORM_DODGES asks)
 FLAG_NO_UNIFORM_HOIST = 4096  # scene snippets evaluate their uniform-only expressions per ray (default: once per upload, in the prologue kernel)
 FLAG_NO_DEFERRED_UPDATES = 128  # translate scene snippets exactly as written (default: loop-carried ray transforms are applied lazily)
 FLAG_QUICK_JIT = 262144  # compile at -O1 instead of the shipped -O3: half the JIT time, a 5-20 % slower kernel (one-off frames)
 FLAG_SPECIALIZE_PATTERNS = 1048576  # compile in only what survives moving values: zero patterns of the matrices + the renderer's mode switches
 FLAG_BOUNDED_SNIPPETS = 2097152  # opt-in: scene_intersect first, its hit distance bounds the intersection-material snippets (exact; measured: no gain on the headline)
-FLAG_KEEP_TRANSFORM_DODGES = 16777216  # A/B, round 4's shape: the first-trip forms (snippet copies + plane tests; opt-in since round 6) in every build, deferred loop updates also with affine rays; identical frames
+FLAG_KEEP_TRANSFORM_DODGES = 16777216  # A/B, round 4's shape: the first-trip forms (snippet copies + plane tests) also in the un-specialised kernel (opt-in there since round 6), snippet copies + deferred loop updates also with affine rays; identical frames
 FLAG_MATERIAL_TABLE_LDS = 1 << 26  # A/B (measured slower, off by default): the Simple materials' literals in a per-workgroup LDS table, ONE material_simple2 call
 FLAG_MATERIAL_TABLE_SCALAR = 1 << 27  # A/B (measured: no gain): the same table in constant memory, a scalar load per distinct material of the wave (waterfall)
 FLAG_CHECK_AFFINE = 1 << 25  # diagnostics: general products, and `segments` counts the ray halves that meet a product / the bounce loop with a w that is not 1 / 0
@@ -67,7 +67,7 @@ FLAG_NO_AFFINE_RAYS = 8388608  # A/B: matrix-times-ray products never assume o.w
 FLAG_SLICES = 4194304  # the render entry reads its uniform block from a buffer of blocks (one per blockIdx.z): stage_slice / draw_slices, one launch for several draws
 FLAG_NO_ZERO_MASKS = 524288  # A/B: run-time matrices keep their full products although their zero pattern is known (KernelOptions::mask_zero_elements)
 FLAG_ASYNC_REJIT = 131072  # a specialised renderer never stalls on a rebuild: it draws with the un-specialised kernel until a worker thread has the new one
-FLAG_NO_FIRST_TRIP_PLANES = 65536  # (with FLAG_KEEP_TRANSFORM_DODGES) no first-trip copy of the generated plane tests; round 6: no build has it by default
+FLAG_NO_FIRST_TRIP_PLANES = 65536  # no first-trip copy of the generated plane tests (round 6: the un-specialised kernel has none unless FLAG_KEEP_TRANSFORM_DODGES asks)
 FLAG_NO_UNROLL = 32768  # keep snippet loops whose bound is a baked Int uniform as loops (default: unrolled up to 16 iterations; identical frames)
 FLAG_EXACT_CR = 16384  # numerics contract 1 of rounds 1-2: IEEE correctly rounded / and sqrt on EVERY input (default: contract 2, device/ptl_glsl.h)
 FLAG_FAST_MATH = 64  # tolerance mode: hardware rcp / sqrt estimates, FMA contraction (not bit-exact; exact stays the default)

@@ -491,14 +491,16 @@ static KernelOptions options_from_flags(unsigned flags) {
     o.mask_zero_elements = (flags & (13u | (1u << 20))) != 0 && (flags & 524288u) == 0;
     o.slices_entry = (flags & (1u << 22)) != 0;  // PTL_FLAG_SLICES: the render entry reads its uniform block from a buffer of blocks, one per blockIdx.z
     o.bound_snippets = (flags & (1u << 21)) != 0;  // PTL_FLAG_BOUNDED_SNIPPETS: scene_intersect first, its distance bounds the intersection-material snippets (opt-in: measured, no gain)
-    // Round 6: the first-trip forms (a second copy of scene_intersect and of every intersection-material snippet for the trip on which all rays of a
-    // wave still start at the camera) are OPT-IN (bit 24, PTL_FLAG_KEEP_TRANSFORM_DODGES).  Round 3 measured +4 % for them on kernels whose transforms
-    // were 32 FMAs; on today's kernels they lose: un-specialised headline 0.697 -> 0.664 ms without them (five views: -3 ... -9 %), triple_portal 0.445
-    // -> 0.434, mobius 1.108 -> 1.046, monoportal equal (profiles/r06/ab_unspec_code_size*.jsonl) -- and the un-specialised headline kernel is 12 535
-    // instead of 17 090 instructions, compiles in 3.5 s instead of 15.8 on this container's cores and needs no occupancy retry.  Identical frames.
-    const bool first_trip_forms = (flags & (1u << 24)) != 0;
-    o.first_trip_planes = first_trip_forms && (flags & 65536u) == 0;   // (with bit 24) PTL_FLAG_NO_FIRST_TRIP_PLANES: one scene_intersect for every trip
-    if (const char* ab = std::getenv("PTL_AB_FIRST_TRIP_PLANES"); ab && ab[0] == '1') o.first_trip_planes = (flags & 65536u) == 0;  // (A/B hook: the plane form alone, as rounds 3-5 had it by default)
+    // Round 6: the first-trip forms -- a second copy of scene_intersect and of every intersection-material snippet for the trip on which all rays of a
+    // wave still start at the camera -- are OPT-IN IN THE UN-SPECIALISED KERNEL (bit 24, PTL_FLAG_KEEP_TRANSFORM_DODGES) and stay the default of the
+    // specialised builds (where a kernel with affine rays drops the snippet copies by itself, codegen.cpp).  Round 3 measured +4 % for them on kernels
+    // whose transforms were 32 FMAs.  Today: the un-specialised headline 0.697 -> 0.664 ms without them (five views: -3 ... -9 %), triple_portal 0.445 ->
+    // 0.434, mobius 1.108 -> 1.046, monoportal equal (profiles/r06/ab_unspec_code_size*.jsonl) -- and that kernel is 12 535 instead of 17 090
+    // instructions, compiles in 3.5 s instead of 15.8 on this container's cores and needs no occupancy retry; the specialised builds that keep run-time
+    // matrices (patterns, Int-baked) still gain 1 ... 4 % from the plane form (profiles/r06/ab_first_trip_planes.jsonl).  Identical frames either way.
+    const bool first_trip_forms = (flags & (1u << 24)) != 0 || (flags & (13u | (1u << 20))) != 0;
+    o.first_trip_planes = first_trip_forms && (flags & 65536u) == 0;   // PTL_FLAG_NO_FIRST_TRIP_PLANES: one scene_intersect for every trip
+    if (const char* ab = std::getenv("PTL_AB_FIRST_TRIP_PLANES"); ab && (ab[0] == '0' || ab[0] == '1')) o.first_trip_planes = ab[0] == '1' && (flags & 65536u) == 0;  // (A/B hook)
     // PTL_FLAG_NO_UNROLL: keep snippet loops with baked bounds as loops (A/B measurements).  The quick build keeps them too: unrolling
     // is half of its hiprtc time for the headline scene (3.4 -> 1.8 s on this container's cores) and buys 0.05 ms of kernel
     o.unroll_baked_loops = (flags & 32768u) == 0 && !o.quick_jit;
@@ -508,7 +510,7 @@ static KernelOptions options_from_flags(unsigned flags) {
     o.material_table = (flags & (1u << 27)) != 0 ? 2 : ((flags & (1u << 26)) != 0 ? 1 : 0);
     o.check_affine = (flags & (1u << 25)) != 0;   // PTL_FLAG_CHECK_AFFINE: general products, and `segments` counts the ray halves whose w is not 1 / 0
     o.affine_rays = (flags & (1u << 23)) == 0;    // PTL_FLAG_NO_AFFINE_RAYS: matrix-times-ray products never assume o.w = 1 / d.w = 0 (A/B measurements, tests)
-    o.first_trip = first_trip_forms && (flags & 8192u) == 0;  // (with bit 24) PTL_FLAG_NO_FIRST_TRIP: no first-trip copies of the intersection-material snippets
+    o.first_trip = first_trip_forms && (flags & 8192u) == 0;  // PTL_FLAG_NO_FIRST_TRIP: no first-trip copies of the intersection-material snippets
     o.hoist_uniform_work = (flags & 4096u) == 0;  // PTL_FLAG_NO_UNIFORM_HOIST: snippets evaluate their uniform-only expressions per ray
     return o;
 }

@@ -109,11 +109,14 @@ def test_first_trip_snippet_variants_change_no_bit(gpu, scene_file, spec):
     w, h = 320, 180
     frames = {}
     # (round 5: a specialised build of a scene with affine rays has no first-trip copies by default; FLAG_KEEP_TRANSFORM_DODGES keeps them)
-    # (round 6: no build has them by default any more -- measured a loss on today's kernels; the same flag keeps them)
+    # (round 6: nor has the un-specialised kernel -- measured a loss there; the same flag keeps them)
     keep = pa.FLAG_KEEP_TRANSFORM_DODGES
     for label, flags in (("first", spec | keep), ("general", spec | keep | pa.FLAG_NO_FIRST_TRIP), ("default", spec)):
         scene = pa.Scene.from_file(path)
-        assert ("_first(Ray r, float ptl_far) {" in scene.generate_source(flags)) == (label == "first")
+        if label != "default":
+            assert ("_first(Ray r, float ptl_far) {" in scene.generate_source(flags)) == (label == "first")
+        elif spec == 0:
+            assert "_first(Ray r, float ptl_far) {" not in scene.generate_source(flags)
         r = pa.SceneRenderer(scene, device=0, flags=flags, **extra)
         r.set_option("render_depth", 20)
         got = [r.draw(w, h, rgba32f=True)["rgba32f"].copy()]
@@ -483,12 +486,12 @@ def test_first_trip_plane_tests_change_no_bit(gpu, scene_name, spec):
     pa = gpu
     w, h = 320, 180
     frames = {}
-    # (round 6: opt-in with FLAG_KEEP_TRANSFORM_DODGES; the default is the one general scene_intersect)
+    # (round 6: the default of the specialised builds, opt-in -- FLAG_KEEP_TRANSFORM_DODGES -- in the un-specialised kernel, which measured a loss with it)
     keep = pa.FLAG_KEEP_TRANSFORM_DODGES
     for label, flags in (("first", spec | keep), ("general", spec | keep | pa.FLAG_NO_FIRST_TRIP_PLANES), ("default", spec)):
         scene = pa.Scene.from_file(pa.scene_path(scene_name))
         src = scene.generate_source(flags)
-        assert ("scene_intersect_first(const Ray& r" in src and "#define PTL_FIRST_TRIP_PLANES 1" in src) == (label == "first")
+        assert ("scene_intersect_first(const Ray& r" in src and "#define PTL_FIRST_TRIP_PLANES 1" in src) == (label == "first" or (label == "default" and spec != 0))
         r = pa.SceneRenderer(scene, device=0, flags=flags)
         r.set_option("render_depth", 20)
         got = [r.draw(w, h, rgba32f=True)["rgba32f"].copy()]

@@ -1326,11 +1326,13 @@ def test_first_trip_plane_tests_are_selfconsistent_and_change_no_bit_on_the_host
     general = src[src.index("PTL_FN SceneIntersection scene_intersect(const Ray& r"):src.index("PTL_FN SceneIntersection scene_intersect_first(")]
     assert set(re.findall(r"PTL_U\.(ptl_dvo_\d+_[01])", first)) == members and "PTL_U.ptl_dvo_" not in general
     assert first.count("ptl_plane_cull_o(") == 27 and general.count("ptl_plane_cull(") == 27
-    for flags in (0, keep | pa.FLAG_NO_DERIVED_UNIFORMS, keep | pa.FLAG_NO_FIRST_TRIP_PLANES, keep | pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL):
+    for flags in (0, keep | pa.FLAG_NO_DERIVED_UNIFORMS, keep | pa.FLAG_NO_FIRST_TRIP_PLANES, pa.FLAG_SPECIALIZE_INTS | pa.FLAG_NO_FIRST_TRIP_PLANES, keep | pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL):
         off = scene.generate_source(flags)
         assert "PTL_U.ptl_dvo_" not in off and "#define PTL_FIRST_TRIP_PLANES" not in off
+    # (the specialised builds that keep run-time matrices still have the plane form by default: measured a gain there, a loss in the un-specialised kernel)
+    assert "#define PTL_FIRST_TRIP_PLANES" in scene.generate_source(pa.FLAG_SPECIALIZE_INTS) and "#define PTL_FIRST_TRIP_PLANES" in scene.generate_source(pa.FLAG_SPECIALIZE_PATTERNS)
     frames = {}
-    for label, flags in (("first", keep), ("general", 0), ("first_baked", keep | pa.FLAG_SPECIALIZE_INTS)):
+    for label, flags in (("first", keep), ("general", 0), ("first_baked", pa.FLAG_SPECIALIZE_INTS)):
         sc = pa.Scene.from_file(pa.scene_path("triple_portal"))
         r = pa.SceneRenderer(sc, device=-1, flags=flags)
         r.set_option("render_depth", 12)
@@ -1379,13 +1381,14 @@ def test_a_matrix_with_infinities_keeps_every_full_chain(pa):
 def test_generated_defines_go_with_the_generated_source(pa):
     scene = pa.Scene.from_file(pa.scene_path("portal_in_portal"))
     spec = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_SPECIALIZE_ALL
-    # (PTL_FIRST_TRIP: the kernel has first-trip copies of its snippets -- opt-in since round 6 (FLAG_KEEP_TRANSFORM_DODGES): measured a loss on today's kernels)
+    # (PTL_FIRST_TRIP: the kernel has first-trip copies of its snippets -- not with affine rays, where a transform is cheaper than its dodge, and since
+    # round 6 not in the un-specialised kernel unless asked for (FLAG_KEEP_TRANSFORM_DODGES): measured a loss there)
     keep = pa.FLAG_KEEP_TRANSFORM_DODGES
-    for flags, want in ((0, set()), (keep, {"PTL_FIRST_TRIP"}), (spec, {"PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}), (spec | pa.FLAG_NO_AFFINE_RAYS, {"PTL_DROP_ZERO_TERMS"}),
-                        (spec | pa.FLAG_NO_AFFINE_RAYS | keep, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS"}),
+    for flags, want in ((0, set()), (keep, {"PTL_FIRST_TRIP"}), (spec, {"PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}), (spec | pa.FLAG_NO_AFFINE_RAYS, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS"}),
                         (spec | keep, {"PTL_FIRST_TRIP", "PTL_DROP_ZERO_TERMS", "PTL_AFFINE_RAYS"}),
-                        (pa.FLAG_SPECIALIZE_PATTERNS, {"PTL_AFFINE_RAYS"}), (spec | pa.FLAG_EXACT_CR, {"PTL_CONTRACT_V1"}), (spec | pa.FLAG_EXACT_CR | keep, {"PTL_FIRST_TRIP", "PTL_CONTRACT_V1"}),
-                        (spec | pa.FLAG_FAST_MATH, {"PTL_AFFINE_RAYS", "PTL_FAST_MATH"}), (pa.FLAG_COUNT_SEGMENTS | pa.FLAG_ANAGLYPH, {"PTL_COUNT_SEGMENTS", "PTL_ANAGLYPH"})):
+                        (pa.FLAG_SPECIALIZE_PATTERNS, {"PTL_AFFINE_RAYS"}), (spec | pa.FLAG_EXACT_CR, {"PTL_FIRST_TRIP", "PTL_CONTRACT_V1"}),
+                        (spec | pa.FLAG_FAST_MATH, {"PTL_AFFINE_RAYS", "PTL_FAST_MATH"}), (pa.FLAG_COUNT_SEGMENTS | pa.FLAG_ANAGLYPH, {"PTL_COUNT_SEGMENTS", "PTL_ANAGLYPH"}),
+                        (pa.FLAG_COUNT_SEGMENTS | pa.FLAG_ANAGLYPH | keep, {"PTL_FIRST_TRIP", "PTL_COUNT_SEGMENTS", "PTL_ANAGLYPH"})):
         scene.generate_source(flags)
         # (PTL_JIT_MODULE_INLINER: this scene's intersection-material snippet loops, and with the Ints baked the loop is force-unrolled -- the
         # JIT picks LLVM's module inliner for those builds, kernel.cpp)
@@ -1774,8 +1777,7 @@ def test_a_module_inliner_build_that_cannot_be_capped_falls_back_to_the_bottom_u
     monkeypatch.setenv("PTL_JIT_OPT", "-O3")
     monkeypatch.setenv("PTL_CACHE_DIR", str(tmp_path / "a"))
     monkeypatch.setenv("PTL_NO_OCCUPANCY_RETRY", "1")
-    # (FLAG_KEEP_TRANSFORM_DODGES: the build this rule was found on has the first-trip copy of the plane tests, opt-in since round 6)
-    flags = pa.FLAG_SPECIALIZE_INTS | pa.FLAG_KEEP_TRANSFORM_DODGES | pa.FLAG_NO_FIRST_TRIP | pa.FLAG_NO_DEFERRED_UPDATES
+    flags = pa.FLAG_SPECIALIZE_INTS
     first = pa.SceneRenderer(scene, device=-1, flags=flags, asset_root=os.path.join(os.path.dirname(__file__), "corpus")).code_object()
     if not 128 < _note_max(first, b".vgpr_count") <= 168:
         pytest.skip("this toolchain builds the case outside the band the retry looks at")
