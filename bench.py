@@ -983,10 +983,18 @@ def main():
             tr2 = parallel.GatherTransport(w2["height"], w2["width"], rank, world, dev, depth=3, stage_through_host=staged)
             run_steps(tr2, 2, r=r2)
             n2 = 6
+            flight2 = None
             if world == 1:  # one pair around the region (nothing between its launches); N > 1: a pair per launch, so that a wait for the transport is not timed
                 ev2 = {0: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), n2), "group": n2}
                 el2, _last2 = timed_steps(tr2, n2, ev2, r=r2)
                 k2 = [float(ev2[0][0].elapsed_time(ev2[0][1]) / n2)]
+                if args.lanes > 1:  # like the headline: the same frames with `lanes` in flight are what is reported; the one-stream pass above gives the kernel time
+                    bufs2 = [torch.empty_like(_last2) for _ in range(args.lanes)]
+                    one2 = el2
+                    el2 = timed_in_flight(r2, tr2.frame, bufs2, 2, n2)
+                    flight2 = {"frames_in_flight": args.lanes, "ms_per_step_one_frame_in_flight": round(one2 / n2 * 1e3, 4),
+                               "frames_identical_to_one_in_flight": bool(all(torch.equal(b, _last2) for b in bufs2))}
+                    del bufs2
             else:
                 ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n2)]
                 el2, _last2 = timed_steps(tr2, n2, ev2, r=r2)
@@ -999,7 +1007,8 @@ def main():
             second = {"workload": f"scenes/{w2['scene']}.ron {w2['width']}x{w2['height']} aa={w2['aa']} depth={w2['depth']}", "steps": n2, "warmup": 2,
                       "ms_per_step": round(ms2, 4), "value": round(w2["width"] * w2["height"] * w2["aa"] / (ms2 * 1e-3) / 1e6, 3), "unit": "Mray/s",
                       "kernel_ms_per_rank": [round(x, 4) for x in k2], "transport_ms": round(max(0.0, ms2 - max(k2)), 4), "transport": tr2.name,
-                      "jit_specialisation": ["none", "int/bool scene uniforms baked", "all scene uniforms baked (camera dynamic)"][args.specialize]}
+                      "jit_specialisation": ["none", "int/bool scene uniforms baked", "all scene uniforms baked (camera dynamic)"][args.specialize],
+                      **(flight2 or {"frames_in_flight": 1})}
             # ... with its own roofline (same accounting as the headline's: trips counted on the GPU, the oracle's operations per trip, PMC cap)
             try:
                 import argparse as _ap
