@@ -988,13 +988,7 @@ def main():
                 ev2 = {0: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), n2), "group": n2}
                 el2, _last2 = timed_steps(tr2, n2, ev2, r=r2)
                 k2 = [float(ev2[0][0].elapsed_time(ev2[0][1]) / n2)]
-                if args.lanes > 1:  # like the headline: the same frames with `lanes` in flight are what is reported; the one-stream pass above gives the kernel time
-                    bufs2 = [torch.empty_like(_last2) for _ in range(args.lanes)]
-                    one2 = el2
-                    el2 = timed_in_flight(r2, tr2.frame, bufs2, 2, n2)
-                    flight2 = {"frames_in_flight": args.lanes, "ms_per_step_one_frame_in_flight": round(one2 / n2 * 1e3, 4),
-                               "frames_identical_to_one_in_flight": bool(all(torch.equal(b, _last2) for b in bufs2))}
-                    del bufs2
+                # (one frame at a time: a 12.5 ms launch has nothing to gain from a second one in flight -- measured 12.64 against 12.58 ms, profiles/r06/README.md)
             else:
                 ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n2)]
                 el2, _last2 = timed_steps(tr2, n2, ev2, r=r2)
