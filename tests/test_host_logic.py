@@ -2010,3 +2010,19 @@ def test_material_tables_draw_the_bits_of_the_reference_chain(pa, name, depth):
         frames.append(hb.host_kernel_for(r, sc, w, h, flags=spec | extra).render(w, h)["rgba32f"].copy())
     assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)) and np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
     assert len(np.unique(frames[0].reshape(-1, 4), axis=0)) > 50
+
+
+def test_lane_options_are_renderer_options_that_do_not_touch_the_kernel(pa):
+    """Round 6: `concurrent_draws` K and `lane_fence` 0 / 1 (two frames in flight, include/portal_amd.h) are scheduling options: accepted on a renderer
+    without a device too, out of range refused, and neither changes the source a renderer would compile (no rebuild, same code-object key)."""
+    r = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("basics")), device=-1, flags=0)
+    before = r.kernel_source()
+    for name, value in (("concurrent_draws", 2), ("lane_fence", 0), ("lane_fence", 1), ("concurrent_draws", 1)):
+        r.set_option(name, value)
+        assert r.kernel_source() == before and r.rejit_count() == 0
+    for bad in (0, 9):
+        with pytest.raises(pa.PortalError):
+            r.set_option("concurrent_draws", bad)
+    with pytest.raises(pa.PortalError):
+        r.set_option("lane_fences", 1)
+    r.join()  # nothing in flight: a no-op
