@@ -901,32 +901,45 @@ def main():
     events = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), min(every, args.steps - k)) for k in range(0, args.steps, every)}
     events["group"] = every
     in_flight = None
+    lanes_failed = None
     if world == 1 and args.lanes > 1:
-        # Round 6: TWO FRAMES IN FLIGHT.  A launch of this kernel ramps up for ~10 us and drains for as long (the last workgroups of a
-        # frame leave CUs idle that the next frame's first workgroups could use); a renderer that queues frames and looks at them later need not
-        # pay that per frame.  The renderer's own option does it (include/portal_amd.h "lane_fence"): consecutive draws go round-robin to K
-        # internal streams, each draw is ONE packet, each lane writes a target of its own, the caller's stream joins behind all of them at the
-        # end.  Same kernel, same bytes (compared below); the timed region is K frames queued, one join, one synchronisation.
-        lanes = args.lanes
-        targets = [shard] + [torch.empty_like(shard) for _ in range(lanes - 1)]
-        for t in targets:
-            t.zero_()
-        elapsed = timed_in_flight(renderer, frame, targets, max(args.warmup, lanes), args.steps)
-        # ... and the SAME K steps one at a time on one stream, right behind it, between two synchronisations and between one pair of HIP events:
-        # `kernel_ms` (the launch duration rocprofv3's per-dispatch average agrees with: what `roofline` divides by) and what a step costs with
-        # one frame in flight (`ms_per_step_one_frame_in_flight`, rounds 1-5's figure)
-        n_k = max(args.steps, 64)
-        ev_k = {0: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), n_k), "group": n_k}
-        one_elapsed, last = timed_steps(transport, n_k, ev_k)
-        kernel_ms = float(ev_k[0][0].elapsed_time(ev_k[0][1]) / n_k)
-        kernel_ms_from = (f"HIP events around ONE group of {n_k} consecutive launches on one stream, right behind the timed region (same kernel, same frame): elapsed / launches; "
-                          f"the timed region itself has {lanes} frames in flight on {lanes} streams, where a launch's own duration is not the time a frame costs")
-        same_bytes = bool(all(torch.equal(t[: last.shape[0]], last) for t in targets))
-        in_flight = {"frames_in_flight": lanes, "frames_identical_to_one_in_flight": same_bytes,
-                     "ms_per_step_one_frame_in_flight": round(one_elapsed / n_k * 1e3, 4), "steps_one_frame_in_flight": n_k}
-        if not same_bytes:
-            raise SystemExit("bench: a frame drawn with two frames in flight differs from the frame drawn alone")
-        del targets
+        try:
+            # Round 6: TWO FRAMES IN FLIGHT.  A launch of this kernel ramps up for ~10 us and drains for as long (the last workgroups of a
+            # frame leave CUs idle that the next frame's first workgroups could use); a renderer that queues frames and looks at them later need not
+            # pay that per frame.  The renderer's own option does it (include/portal_amd.h "lane_fence"): consecutive draws go round-robin to K
+            # internal streams, each draw is ONE packet, each lane writes a target of its own, the caller's stream joins behind all of them at the
+            # end.  Same kernel, same bytes (compared below); the timed region is K frames queued, one join, one synchronisation.
+            lanes = args.lanes
+            targets = [shard] + [torch.empty_like(shard) for _ in range(lanes - 1)]
+            for t in targets:
+                t.zero_()
+            elapsed = timed_in_flight(renderer, frame, targets, max(args.warmup, lanes), args.steps)
+            # ... and the SAME K steps one at a time on one stream, right behind it, between two synchronisations and between one pair of HIP events:
+            # `kernel_ms` (the launch duration rocprofv3's per-dispatch average agrees with: what `roofline` divides by) and what a step costs with
+            # one frame in flight (`ms_per_step_one_frame_in_flight`, rounds 1-5's figure)
+            n_k = max(args.steps, 64)
+            ev_k = {0: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), n_k), "group": n_k}
+            one_elapsed, last = timed_steps(transport, n_k, ev_k)
+            kernel_ms = float(ev_k[0][0].elapsed_time(ev_k[0][1]) / n_k)
+            kernel_ms_from = (f"HIP events around ONE group of {n_k} consecutive launches on one stream, right behind the timed region (same kernel, same frame): elapsed / launches; "
+                              f"the timed region itself has {lanes} frames in flight on {lanes} streams, where a launch's own duration is not the time a frame costs")
+            same_bytes = bool(all(torch.equal(t[: last.shape[0]], last) for t in targets))
+            in_flight = {"frames_in_flight": lanes, "frames_identical_to_one_in_flight": same_bytes,
+                         "ms_per_step_one_frame_in_flight": round(one_elapsed / n_k * 1e3, 4), "steps_one_frame_in_flight": n_k}
+            if not same_bytes:
+                raise SystemExit("bench: a frame drawn with two frames in flight differs from the frame drawn alone")
+            del targets
+        except Exception as e:  # (streams or kernel instances could not be had: the line must still come out -- one frame at a time, and it says so)
+            lanes_failed = str(e)[:200]
+            print(f"[bench] two frames in flight unavailable, timing one frame at a time: {lanes_failed}", file=sys.stderr)
+            in_flight = None
+            try:
+                renderer.set_option("concurrent_draws", 1)
+                renderer.set_option("lane_fence", 1)
+            except Exception:
+                pass
+    if in_flight is not None:
+        pass
     elif world == 1:
         elapsed, last = timed_steps(transport, args.steps, events)
         groups = [v for k, v in events.items() if k != "group"]
@@ -1073,7 +1086,7 @@ def main():
                 ev_every = 8 if steps >= 64 else steps  # (like the headline's: one event pair around every eight consecutive launches; a short region is one group)
                 ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), min(ev_every, steps - k)) for k in range(0, steps, ev_every)}
                 flight_k = None
-                if args.lanes > 1:  # like the headline: the timed frames with `lanes` in flight, then the same frames one at a time between one event pair
+                if args.lanes > 1 and lanes_failed is None:  # like the headline: the timed frames with `lanes` in flight, then the same frames one at a time between one event pair
                     bufs = [buf] + [torch.empty_like(buf) for _ in range(args.lanes - 1)]
                     ms_flight = timed_in_flight(rr, fr, bufs, 6, steps) / steps * 1e3
                 torch.cuda.synchronize(dev)
@@ -1088,7 +1101,7 @@ def main():
                 torch.cuda.synchronize(dev)
                 ms_step = (time.perf_counter() - t0) / steps * 1e3
                 kms = float(sum(x.elapsed_time(y) for x, y, _ in ev.values()) / sum(c for _, _, c in ev.values()))
-                if args.lanes > 1:
+                if args.lanes > 1 and lanes_failed is None:
                     flight_k = {"frames_in_flight": args.lanes, "ms_per_step_one_frame_in_flight": round(ms_step, 4),
                                 "frames_identical_to_one_in_flight": bool(all(torch.equal(b, buf) for b in bufs))}
                     ms_step = ms_flight
@@ -1289,7 +1302,7 @@ def main():
                     "p2p-stores": " + kernel stores straight into rank 0's frame over xGMI (HIP IPC mapping), fenced by a 1-element RCCL all-reduce",
                     "p2p-copy": " + packed shard per rank and ONE strided peer copy each into rank 0's frame (HIP IPC mapping), fenced by a 1-element RCCL all-reduce"}[transport.name]),
                 "jit_specialisation": ["none", "int/bool scene uniforms baked", "all scene uniforms baked (camera dynamic)"][args.specialize],
-                **(in_flight if in_flight is not None else {"frames_in_flight": 1}),
+                **(in_flight if in_flight is not None else {"frames_in_flight": 1, **({"frames_in_flight_unavailable": lanes_failed} if lanes_failed else {})}),
                 "build": best, "waves_per_simd_hint": best_waves,
                 "tuning_ms": tuning,
                 # every candidate build drew the same bytes as the first one (compared on the device before timing); a build that did not is named here and was not eligible
