@@ -824,17 +824,14 @@ def main():
         draw, no cross-stream wait), a target per lane, ONE join behind all of them; wall time between two synchronisations."""
         # Lanes that start together stay together: two launches queued at the same moment share the chip evenly, end at the same moment, and their
         # drains coincide -- one drain per PAIR is hidden instead of one per frame (half the gain), and a region of 20 frames ends before the phases
-        # have drifted apart.  So the second lane's first launch of a region is issued half a launch later (a host-side wait while the GPU is busy
-        # with the first): the phases start apart and stay apart.  PTL_BENCH_STAGGER=<fraction of a launch> (0: off).
-        stagger = float(os.environ.get("PTL_BENCH_STAGGER", "0.5")) * 1e-3 * float(np.median([r.draw_device(fr, out_rgba8=targets[0].data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(5)]))
+        # have drifted apart.  So the second lane's first launch of a region is issued half a launch later (the renderer's option `lane_stagger_us`: a
+        # host-side wait while the GPU is busy with the first): the phases start apart and stay apart.  PTL_BENCH_STAGGER=<fraction of a launch> (0: off).
+        launch_ms = float(np.median([r.draw_device(fr, out_rgba8=targets[0].data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(5)]))
+        r.set_option("lane_stagger_us", float(os.environ.get("PTL_BENCH_STAGGER", "0.5")) * launch_ms * 1e3)
 
         def queue(m):
             for k in range(m):
                 r.draw_device(fr, out_rgba8=targets[k % len(targets)].data_ptr(), stream=stream.cuda_stream)
-                if k + 1 < len(targets) and stagger > 0.0:  # (between the first launches of the lanes only; with the default fraction the phases end up evenly spread)
-                    until = time.perf_counter() + stagger * 2.0 / len(targets)
-                    while time.perf_counter() < until:
-                        pass
             r.join(stream.cuda_stream)
 
         r.set_option("concurrent_draws", len(targets))
@@ -854,6 +851,7 @@ def main():
         seconds = time.perf_counter() - t0
         r.set_option("concurrent_draws", 1)  # (drops the lanes' kernel instances; what follows is one stream again)
         r.set_option("lane_fence", 1)
+        r.set_option("lane_stagger_us", 0)
         return seconds
 
     # untimed: keep the GPU busy for ~0.25 s so that the W warm-up steps and the timed region run at settled clocks

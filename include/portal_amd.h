@@ -382,9 +382,11 @@ int ptl_renderer_set_option(ptl_renderer* r, const char* name, double value);
  * wait asks for it).  The caller orders the reuse of a target itself: ptl_renderer_join before a target is read or drawn into again.
  * With two lanes and a target per lane this is two frames in flight -- frame n + 1's ramp under frame n's tail -- for a caller that queues
  * frames and looks at them later (`bench.py`'s timed region at one GPU; profiles/r06/two_streams.jsonl: headline 4K 0.187 -> 0.177 ms per
- * frame, monoportal 1080p 0.035 -> 0.027, identical bytes).  Lanes that start together stay together (two launches queued at the same moment
- * share the chip evenly and drain at the same moment): a caller that starts from an idle GPU does well to issue the second lane's first draw
- * half a launch after the first (bench.py does; profiles/r06/stagger.jsonl: 20-frame batches 0.1823 -> 0.180 ms per 4K frame). */
+ * frame, monoportal 1080p 0.035 -> 0.027, identical bytes).
+ * "lane_stagger_us" T (default 0): lanes that start together stay together -- two launches queued at the same moment share the chip evenly and
+ * drain at the same moment, so only one drain per PAIR is hidden.  With T > 0 the first draw of every lane but the first, counted from the last
+ * ptl_renderer_join (or host-side wait), is issued T x 2 / K microseconds after the previous lane's: a host-side spin while the GPU is busy with
+ * the first launch.  Half a launch is the natural T (bench.py sets it; profiles/r06/stagger.jsonl: 20-frame batches 0.1823 -> 0.180 ms per 4K frame). */
 int ptl_renderer_join(ptl_renderer* r, void* stream);
 /* One launch for several draws of a renderer created with flag bit 22 (PTL_FLAG_SLICES): ptl_renderer_stage_slice does everything a draw
  * does short of launching -- camera, rebuild checks, uniform evaluation for `frame` -- and keeps the resulting uniform block as slice `index`;

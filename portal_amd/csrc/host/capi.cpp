@@ -5,6 +5,7 @@
 //   SceneRenderer::set_uniforms src/main.rs:1266-1359  -> builtin_uniforms()
 //   RotateAroundCam::get_matrix src/main.rs:278-304    -> Camera::matrix()
 //   SceneRenderer::draw_texture src/main.rs:1411-1428  -> ptl_renderer_draw
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -190,6 +191,12 @@ struct ptl_renderer {
     std::vector<ptl_kernel*> parked_kernels;
     int concurrent = 1;
     bool lane_fence = true;
+    // "lane_stagger_us" (round 6): lanes that start together stay together -- two launches queued at the same moment share the chip evenly, end at the
+    // same moment, and their drains coincide (one drain per PAIR hidden instead of one per frame).  With this option the first draw of every lane but the
+    // first, counted from the last join / host-side wait, is issued that many microseconds (x 2 / K) after the previous lane's: a host-side spin while the GPU
+    // is busy with the first launch.  Half a launch is the natural value (bench.py sets it; profiles/r06/stagger.jsonl: 20-frame batches 0.1823 -> 0.180 ms).
+    double lane_stagger_us = 0.0;
+    unsigned lane_draws_since_join = 0;
     std::vector<Lane> lanes;
     ptl_kernel* lanes_of = nullptr;  // the kernel the clones were made from
     unsigned next_lane = 0;
@@ -773,6 +780,7 @@ static void* pooled_lane_stream(int device, size_t index) {
 }
 // (a lane's `done` event is recorded when somebody asks -- here and in join_lanes -- not behind every launch: one packet less per draw)
 static void wait_for_lanes(ptl_renderer* r) {  // host-side: everything issued on the lanes has finished
+    r->lane_draws_since_join = 0;
     for (auto& l : r->lanes)
         if (l.busy && l.done) {
             if (ptl_event_record(l.done, l.stream) == PTL_OK) ptl_event_synchronize(l.done);
@@ -788,6 +796,7 @@ static void drop_lane_clones(ptl_renderer* r) {  // before the kernel they were 
     r->lanes_of = nullptr;
 }
 static int join_lanes(ptl_renderer* r, void* stream) {  // GPU-side: `stream` continues behind every draw issued so far
+    r->lane_draws_since_join = 0;
     for (auto& l : r->lanes)
         if (l.busy && l.done) {
             if (int rc = ptl_event_record(l.done, l.stream); rc != PTL_OK) return rc;
@@ -998,6 +1007,11 @@ static int set_plain_option(ptl_renderer* r, const std::string& n, double v) {
             drop_lane_clones(r);
             r->concurrent = k;
         }
+        return PTL_OK;
+    }
+    else if (n == "lane_stagger_us") {  // the first draw of lanes 2 .. K after a join comes this much (x 2 / K) later than the previous lane's (ptl_renderer::lane_stagger_us)
+        if (!(v >= 0.0) || v > 1e6) return PTL_ERR_INVALID;
+        r->lane_stagger_us = v;
         return PTL_OK;
     }
     else if (n == "lane_fence") {  // 1 (default): a lane's launch waits for what the caller's stream holds; 0: it does not (ptl_renderer::Lane)
@@ -1334,6 +1348,12 @@ static int draw_on_a_lane(ptl_renderer* r, const ptl_frame* frame, void* out_rgb
         if (int rc = ptl_event_record(r->fence, stream); rc != PTL_OK) return rc;
         if (int rc = ptl_stream_wait_event(lane.stream, r->fence); rc != PTL_OK) return rc;
     }
+    if (r->lane_stagger_us > 0.0 && r->lane_draws_since_join >= 1 && r->lane_draws_since_join < r->lanes.size()) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::nanoseconds((long long)(r->lane_stagger_us * 2000.0 / (double)r->lanes.size()));
+        while (std::chrono::steady_clock::now() < until) {
+        }
+    }
+    ++r->lane_draws_since_join;
     if (int rc = ptl_kernel_render(k, frame, out_rgba8, out_rgba32f, nullptr, lane.stream, nullptr); rc != PTL_OK) return rc;
     lane.busy = true;
     return PTL_OK;

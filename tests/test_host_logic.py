@@ -2017,7 +2017,7 @@ def test_lane_options_are_renderer_options_that_do_not_touch_the_kernel(pa):
     without a device too, out of range refused, and neither changes the source a renderer would compile (no rebuild, same code-object key)."""
     r = pa.SceneRenderer(pa.Scene.from_file(pa.scene_path("basics")), device=-1, flags=0)
     before = r.kernel_source()
-    for name, value in (("concurrent_draws", 2), ("lane_fence", 0), ("lane_fence", 1), ("concurrent_draws", 1)):
+    for name, value in (("concurrent_draws", 2), ("lane_fence", 0), ("lane_stagger_us", 90.0), ("lane_stagger_us", 0), ("lane_fence", 1), ("concurrent_draws", 1)):
         r.set_option(name, value)
         assert r.kernel_source() == before and r.rejit_count() == 0
     for bad in (0, 9):
@@ -2025,4 +2025,6 @@ def test_lane_options_are_renderer_options_that_do_not_touch_the_kernel(pa):
             r.set_option("concurrent_draws", bad)
     with pytest.raises(pa.PortalError):
         r.set_option("lane_fences", 1)
+    with pytest.raises(pa.PortalError):
+        r.set_option("lane_stagger_us", -1.0)
     r.join()  # nothing in flight: a no-op
