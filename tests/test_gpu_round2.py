@@ -630,6 +630,8 @@ def test_concurrent_draws_give_the_frames_of_draws_one_by_one(gpu, flags_name):
         r.set_option("aa_count", 2)
         r.set_option("concurrent_draws", concurrent)
         r.set_option("lane_fence", fence)
+        if not fence:
+            r.set_option("lane_stagger_us", 25.0)  # (the second lane's first draw after a join a little later: scheduling only)
         targets = torch.zeros((n, h, w, 4), dtype=torch.uint8, device=dev)
         total = torch.zeros((h, w, 4), dtype=torch.int32, device=dev)
         sums = []
