@@ -13,12 +13,14 @@ def pytest_cmdline_main(config):
     """`pytest -m gpu` (the driver's round-end command, single process, 1 200 s limit) spreads itself over four worker processes: the GPU
     suite is ~650 independent frames + kernel builds and most of its wall time is host work (hiprtc, the numpy oracle), 131 s with four
     workers against 498 s with one (profiles/r04).  `-n ...` on the command line or PTL_GPU_SUITE_WORKERS=0 keeps the caller's choice."""
-    marker = config.getoption("-m", default="") or ""
-    if marker.strip() != "gpu" or not config.pluginmanager.hasplugin("xdist"):
+    marker = (config.getoption("-m", default="") or "").strip()
+    if marker not in ("gpu", "not gpu") or not config.pluginmanager.hasplugin("xdist"):
         return None
     if getattr(config.option, "numprocesses", None) is not None or getattr(config.option, "tx", None) or os.environ.get("PYTEST_XDIST_WORKER"):
         return None
-    workers = int(os.environ.get("PTL_GPU_SUITE_WORKERS", "4"))
+    # Round 6: the CPU suite (`-m "not gpu"`, 974 tests: hiprtc builds for gfx950, host builds of the generated sources through g++, the numpy oracle) does the
+    # same with six workers: 7 min 52 s in one process, ~1 min 40 s spread (it has been run under `-n 8` since round 5; PTL_CPU_SUITE_WORKERS=0: one process)
+    workers = int(os.environ.get("PTL_GPU_SUITE_WORKERS", "4")) if marker == "gpu" else int(os.environ.get("PTL_CPU_SUITE_WORKERS", "6"))
     if workers > 1:
         config.option.numprocesses = workers
     return None
